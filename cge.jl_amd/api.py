@@ -1,0 +1,418 @@
+"""ctypes binding of libcge_hip.so + the host-side mirror of the reference's interface for the hot
+path: ``landmarks`` (src/landmarks.jl:365-367), ``wGCL`` / ``wGCL_directed`` (src/divergence.jl:27-31,
+:282-286) with the reference's positional arguments, and ``score`` = example/CGE_CLI.jl:10-24 on
+device-resident inputs.
+
+There is no CPU path here: if the library is missing or no GPU is visible every compute entry point
+raises ``CGEError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+from .args import _SplitRule
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "csrc", "build", "libcge_hip.so")
+_lib = None
+
+CGE_OK = 0
+_CODES = {-1: "AssertionError", -2: "ErrorException: Trying to split homogenous cluster",
+          -3: "ErrorException: Unexpected empty cluster generated", -4: "HIP error / no GPU",
+          -5: "collective hook failed", -6: "out of memory", -7: "bad argument"}
+
+
+class CGEError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"{_CODES.get(code, 'error')} (code {code}){': ' + msg if msg else ''}")
+        self.code = code
+
+
+class AssertionErrorCGE(CGEError, AssertionError):
+    """A reference ``@assert`` fired (src/divergence.jl:50,81,303,363; src/landmarks.jl:93,...)."""
+
+
+class WgclArgs(C.Structure):
+    _fields_ = [("edges_src", C.c_void_p), ("edges_dst", C.c_void_p), ("eweights", C.c_void_p), ("m", C.c_int64),
+                ("comm", C.c_void_p), ("n_comm", C.c_int64), ("embed", C.c_void_p), ("embed_rows", C.c_int64),
+                ("d", C.c_int64), ("distances", C.c_void_p), ("n_distances", C.c_int64), ("vweights", C.c_void_p),
+                ("init_vweights", C.c_void_p), ("n_init", C.c_int64), ("v_to_l", C.c_void_p),
+                ("n_v_to_l", C.c_int64), ("init_edges_src", C.c_void_p), ("init_edges_dst", C.c_void_p),
+                ("m_init", C.c_int64), ("init_eweights", C.c_void_p), ("init_embed", C.c_void_p), ("split", C.c_int),
+                ("seed", C.c_int64), ("auc_samples", C.c_int64), ("verbose", C.c_int), ("directed", C.c_int),
+                ("pos_idx", C.c_void_p), ("neg_i", C.c_void_p), ("neg_j", C.c_void_p), ("pos_idx2", C.c_void_p),
+                ("n_sample_sets", C.c_int64)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("n_alpha", C.c_int64), ("iters", C.c_int64 * 64), ("div", C.c_double * 64),
+                ("auc", C.c_double * 64)]
+
+    def as_dict(self):
+        k = self.n_alpha
+        return {"n_alpha": k, "iters": list(self.iters[:k]), "div": list(self.div[:k]), "auc": list(self.auc[:k])}
+
+
+class ScoreArgs(C.Structure):
+    _fields_ = [("clusters_flat", C.c_void_p), ("clusters_off", C.c_void_p), ("n_clusters", C.c_int64),
+                ("land", C.c_int64), ("forced", C.c_int64), ("method", C.c_int), ("directed", C.c_int),
+                ("split", C.c_int), ("seed", C.c_int64), ("auc_samples", C.c_int64)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+
+class Collectives(C.Structure):
+    _fields_ = [("allreduce_f64", ALLREDUCE_FN), ("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int)]
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libcge_hip.so; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise CGEError(-4, f"{_LIB_PATH} not found: build it with `make -C cge.jl_amd/csrc` "
+                               f"(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(_LIB_PATH)
+        L.cge_last_error.restype = C.c_char_p
+        L.cge_last_error.argtypes = [C.c_void_p]
+        L.cge_idx.restype = C.c_int64
+        L.cge_idx.argtypes = [C.c_int64] * 3
+        L.cge_destroy.argtypes = [C.c_void_p]
+        L.cge_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _method_code(method):
+    if isinstance(method, _SplitRule):
+        return method.code
+    if isinstance(method, str):
+        return {"rss": 0, "rss2": 1, "size": 2, "diameter": 3}[method]
+    return int(method)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _colmajor(a):  # (rows, cols) array -> flat buffer in Julia (column-major) order
+    a = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    return a, a.ravel(order="K")
+
+
+def _edge_cols(edges):
+    e = np.asarray(edges, dtype=np.int64)
+    if e.size == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    return np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1])
+
+
+def _flatten_clusters(clusters):
+    off = np.zeros(len(clusters) + 1, dtype=np.int64)
+    for k, c in enumerate(clusters):
+        off[k + 1] = off[k] + len(c)
+    flat = np.concatenate([np.asarray(c, dtype=np.int64) for c in clusters]) if len(clusters) else np.zeros(0, np.int64)
+    return np.ascontiguousarray(flat), off
+
+
+class Context:
+    """One GPU, one stream.  Not re-entrant (one host thread drives it)."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.cge_create(C.byref(h), C.c_int(device), C.c_void_p(stream) if stream else None)
+        if rc:
+            raise CGEError(rc, "cge_create failed (no MI355X visible?)")
+        self.h = h
+        self.device = device
+        self._keep = []  # objects the C side holds pointers to (collective hook)
+        self.n = self.m = self.d = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cge_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            msg = self.L.cge_last_error(self.h).decode(errors="replace")
+            raise (AssertionErrorCGE if rc == -1 else CGEError)(rc, msg)
+
+    # ---- resident inputs ------------------------------------------------------------------------
+    def set_host_threads(self, n):
+        self._check(self.L.cge_set_host_threads(self.h, C.c_int(n)))
+
+    def set_graph(self, edges, eweights, n):
+        s, t = _edge_cols(edges)
+        w = _f64(eweights)
+        self._check(self.L.cge_set_graph(self.h, _p(s), _p(t), _p(w), C.c_int64(len(s)), C.c_int64(n)))
+        self.m, self.n = len(s), n
+
+    def set_embedding(self, embedding):
+        e, ef = _colmajor(embedding)
+        self._check(self.L.cge_set_embedding(self.h, _p(ef), C.c_int64(e.shape[0]), C.c_int64(e.shape[1])))
+        self.d = e.shape[1]
+
+    def set_vertex_data(self, comm, vweights):
+        cm = None if comm is None else _i64(np.asarray(comm).ravel())
+        vw = None if vweights is None else _f64(vweights)
+        n = len(cm) if cm is not None else len(vw)
+        self._check(self.L.cge_set_vertex_data(self.h, _p(cm), _p(vw), C.c_int64(n)))
+
+    def set_inputs(self, edges, eweights, vweights, comm, embedding):
+        n = int(np.asarray(embedding).shape[0])
+        self.set_graph(edges, eweights, n)
+        self.set_embedding(embedding)
+        self.set_vertex_data(comm, vweights)
+
+    # ---- landmarks ----------------------------------------------------------------------------------
+    def landmarks_run(self, clusters, land, forced, method, directed=False):
+        flat, off = _flatten_clusters(clusters)
+        N, ne, tr = C.c_int64(), C.c_int64(), C.c_int()
+        self._check(self.L.cge_landmarks_run(self.h, _p(flat), _p(off), C.c_int64(len(clusters)), C.c_int64(land),
+                                             C.c_int64(forced), C.c_int(_method_code(method)),
+                                             C.c_int(1 if directed else 0), C.byref(N), C.byref(ne), C.byref(tr)))
+        self.N, self.n_ledges, self.truncated = N.value, ne.value, bool(tr.value)
+        return self.N, self.n_ledges, self.truncated
+
+    def landmarks_fetch(self):
+        N, ne, n, d = self.N, self.n_ledges, self.n, self.d
+        dii = np.zeros(N)
+        embed = np.zeros((N, d), order="F")
+        cluster = np.zeros(N, dtype=np.int64)
+        ledges = np.zeros((ne, 2), dtype=np.int64, order="F")
+        lw = np.zeros(ne)
+        lweight = np.zeros(N)
+        v_to_l = np.zeros(n, dtype=np.int64)
+        self._check(self.L.cge_landmarks_fetch(self.h, _p(dii), _p(embed.ravel(order="K")), _p(cluster),
+                                               _p(ledges.ravel(order="K")), _p(lw), _p(lweight), _p(v_to_l)))
+        return dii, embed, cluster.reshape(-1, 1), ledges, lw, lweight, v_to_l
+
+    def runsplit(self, clusters, nland, forced, method):
+        flat, off = _flatten_clusters(clusters)
+        out = np.zeros(self.n, dtype=np.int64)
+        self._check(self.L.cge_runsplit(self.h, _p(flat), _p(off), C.c_int64(len(clusters)), C.c_int64(nland),
+                                        C.c_int64(forced), C.c_int(_method_code(method)), _p(out)))
+        return out
+
+    # ---- samples ---------------------------------------------------------------------------------------
+    def draw_samples(self, seed, S, directed=False, stream_id=0):
+        pos = np.zeros(S, dtype=np.int64)
+        ni = np.zeros(S, dtype=np.int64)
+        nj = np.zeros(S, dtype=np.int64)
+        self._check(self.L.cge_draw_samples(self.h, C.c_int64(seed), C.c_int64(stream_id), C.c_int64(S),
+                                            C.c_int(1 if directed else 0), _p(pos), _p(ni), _p(nj)))
+        return pos, ni, nj
+
+    # ---- wGCL ------------------------------------------------------------------------------------------
+    def wgcl(self, edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges,
+             init_eweights, init_embed, split, seed=-1, auc_samples=10000, verbose=False, directed=False,
+             samples=None, use_resident_original=False):
+        keep = []
+        s, t = _edge_cols(edges)
+        ew = _f64(eweights)
+        cm = _i64(np.asarray(comm).ravel())
+        em, emf = _colmajor(embed)
+        dist = _f64(distances)
+        vw = _f64(vweights)
+        ivw = _f64(init_vweights)
+        v2l = _i64(v_to_l)
+        a = WgclArgs()
+        a.edges_src, a.edges_dst, a.eweights, a.m = _p(s).value, _p(t).value, _p(ew).value, len(s)
+        a.comm, a.n_comm = _p(cm).value, len(cm)
+        a.embed, a.embed_rows, a.d = _p(emf).value, em.shape[0], em.shape[1]
+        a.distances, a.n_distances = _p(dist).value, len(dist)
+        a.vweights = _p(vw).value
+        a.init_vweights, a.n_init = (_p(ivw).value if len(ivw) else None), len(ivw)
+        a.v_to_l, a.n_v_to_l = (_p(v2l).value if len(v2l) else None), len(v2l)
+        if len(v2l) and not use_resident_original:
+            is_, it_ = _edge_cols(init_edges)
+            iew = _f64(init_eweights)
+            iem, iemf = _colmajor(init_embed)
+            keep += [is_, it_, iew, iem, iemf]
+            a.init_edges_src, a.init_edges_dst, a.m_init = _p(is_).value, _p(it_).value, len(is_)
+            a.init_eweights, a.init_embed = _p(iew).value, _p(iemf).value
+        a.split, a.seed, a.auc_samples = int(bool(split)), int(seed), int(auc_samples)
+        a.verbose, a.directed = int(bool(verbose)), int(bool(directed))
+        if samples is not None:
+            arrs = [np.ascontiguousarray(np.atleast_2d(x), dtype=np.int64) for x in samples[:3]]
+            keep += arrs
+            a.pos_idx, a.neg_i, a.neg_j = (_p(x).value for x in arrs)
+            a.n_sample_sets, a.auc_samples = arrs[0].shape
+            if len(samples) > 3 and samples[3] is not None:
+                p2 = np.ascontiguousarray(np.atleast_2d(samples[3]), dtype=np.int64)
+                keep.append(p2)
+                a.pos_idx2 = _p(p2).value
+        out = np.zeros(7)
+        olen = C.c_int(7)
+        tr = Trace()
+        self._check(self.L.cge_wgcl(self.h, C.byref(a), _p(out), C.byref(olen), C.byref(tr)))
+        self.last_trace = tr.as_dict()
+        del keep
+        return out[: olen.value].copy()
+
+    def score(self, clusters, land, forced=4, method="rss", directed=False, split=False, seed=-1, auc_samples=10000):
+        """example/CGE_CLI.jl:10-24 on the resident inputs; land = -1 => exact mode."""
+        flat, off = _flatten_clusters(clusters if clusters else [])
+        a = ScoreArgs()
+        a.clusters_flat, a.clusters_off, a.n_clusters = _p(flat).value, _p(off).value, len(off) - 1
+        a.land, a.forced, a.method = int(land), int(forced), _method_code(method)
+        a.directed, a.split, a.seed, a.auc_samples = int(bool(directed)), int(bool(split)), int(seed), int(auc_samples)
+        out = np.zeros(7)
+        olen = C.c_int(7)
+        tr = Trace()
+        self._check(self.L.cge_score(self.h, C.byref(a), _p(out), C.byref(olen), C.byref(tr)))
+        self.last_trace = tr.as_dict()
+        return out[: olen.value].copy()
+
+    # ---- kernel-level ----------------------------------------------------------------------------------
+    def edge_scatter(self, v_to_l, N, Cn, directed=False, e0=0, e1=None, want_wedges=True, want_vect_c=True):
+        e1 = self.m if e1 is None else e1
+        v2l = None if v_to_l is None else _i64(v_to_l)
+        wed = np.zeros((N, N)) if want_wedges else None
+        vlen = Cn * Cn if directed else Cn * (Cn + 1) // 2
+        vc = np.zeros(vlen) if want_vect_c else None
+        self._check(self.L.cge_edge_scatter(self.h, _p(v2l), C.c_int64(N), C.c_int64(Cn), C.c_int(int(directed)),
+                                            C.c_int64(e0), C.c_int64(e1), _p(wed), _p(vc)))
+        return wed, vc
+
+    def max_pair_dist(self, part=0, nparts=1):
+        hi, ai, aj = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(self.L.cge_max_pair_dist(self.h, C.c_int(part), C.c_int(nparts), C.byref(hi), C.byref(ai),
+                                             C.byref(aj)))
+        return hi.value, ai.value, aj.value
+
+    def js(self, vC, vB, vI=None, internal=True):
+        vC, vB = _f64(vC), _f64(vB)
+        vi = None if vI is None or len(vI) == 0 else np.ascontiguousarray(vI, dtype=np.uint8)
+        out = C.c_double()
+        self._check(self.L.cge_js(self.h, _p(vC), _p(vB), C.c_int64(len(vC)), _p(vi), C.c_int(int(bool(internal))),
+                                  C.byref(out)))
+        return out.value
+
+    # ---- collectives / profiling -----------------------------------------------------------------------
+    def exchange_buffer(self, min_doubles):
+        ptr, cap = C.c_void_p(), C.c_int64()
+        self._check(self.L.cge_exchange_buffer(self.h, C.c_int64(min_doubles), C.byref(ptr), C.byref(cap)))
+        return ptr.value, cap.value
+
+    def set_collectives(self, fn, rank, world):
+        cb = ALLREDUCE_FN(fn)
+        coll = Collectives(cb, None, rank, world)
+        self._keep = [cb, coll]
+        self._check(self.L.cge_set_collectives(self.h, C.byref(coll)))
+
+    def profile_enable(self, on=True):
+        self._check(self.L.cge_profile_enable(self.h, C.c_int(int(on))))
+
+    def profile_reset(self):
+        self._check(self.L.cge_profile_reset(self.h))
+
+    def profile(self):
+        buf = C.create_string_buffer(4096)
+        self._check(self.L.cge_profile_names(self.h, buf, C.c_int64(4096)))
+        res = {}
+        for name in filter(None, buf.value.decode().split(",")):
+            n, ms = C.c_int64(), C.c_double()
+            self._check(self.L.cge_profile_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
+            res[name] = {"launches": n.value, "total_ms": ms.value}
+        return res
+
+    def phase_ms(self):
+        res = {}
+        for ph in ("landmarks", "aggregate", "scatter", "diameter", "samples", "sweep"):
+            ms = C.c_double()
+            self._check(self.L.cge_phase_ms(self.h, ph.encode(), C.byref(ms)))
+            res[ph] = ms.value
+        return res
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def idx(n, i, j):
+    return load_library().cge_idx(n, i, j)
+
+
+# ---- the reference's exported functions ------------------------------------------------------------------
+def landmarks(edges, weights, vweights, clusters, comm, embedding, verbose, land, forced, method, directed,
+              ctx: Context | None = None):
+    """landmarks(edges, weights, vweights, clusters, comm, embedding, verbose, land, forced, method, directed)
+    -> (dii, embed, cluster, landmark_edges, weights, lweight, v_to_l)        (src/landmarks.jl:365-367, :465)"""
+    ctx = ctx or default_context()
+    verbose and print("Starts landmark generation")
+    ctx.set_inputs(edges, weights, vweights, comm, embedding)
+    N, _, truncated = ctx.landmarks_run(clusters, land, forced, method, directed)
+    if truncated:
+        print("Warning: Requested number of clusters larger than unique no. embeddings. Truncating.", file=sys.stderr)
+    verbose and print("Landmarks generated")
+    verbose and print(f"Using {N} landmarks")
+    return ctx.landmarks_fetch()
+
+
+def _wgcl(directed, edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges,
+          init_eweights, init_embed, split, seed, auc_samples, verbose, samples, trace, ctx):
+    ctx = ctx or default_context()
+    verbose and print(f"auc_samples: {auc_samples}")
+    res = ctx.wgcl(edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges,
+                   init_eweights, init_embed, split, seed, auc_samples, verbose, directed, samples)
+    sys.stderr.write("." * ctx.last_trace["n_alpha"] + "\n")  # src/divergence.jl:140,255
+    return (res, ctx.last_trace) if trace else res
+
+
+def wGCL(edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges, init_eweights,
+         init_embed, split, seed=-1, auc_samples=10000, verbose=False, *, samples=None, trace=False, ctx=None):
+    """src/divergence.jl:27-31.  `samples` (optional) = pre-drawn (pos_idx, neg_i, neg_j), each (n_sets, S)."""
+    return _wgcl(False, edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges,
+                 init_eweights, init_embed, split, seed, auc_samples, verbose, samples, trace, ctx)
+
+
+def wGCL_directed(edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges,
+                  init_eweights, init_embed, split, seed=-1, auc_samples=10000, verbose=False, *, samples=None,
+                  trace=False, ctx=None):
+    """src/divergence.jl:282-286."""
+    return _wgcl(True, edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges,
+                 init_eweights, init_embed, split, seed, auc_samples, verbose, samples, trace, ctx)
+
+
+def score(edges, eweights, vweights, comm, clusters, embedding, land, forced=4, method="rss", directed=False,
+          split=False, seed=-1, auc_samples=10000, ctx=None):
+    ctx = ctx or default_context()
+    ctx.set_inputs(edges, eweights, vweights, comm, embedding)
+    return ctx.score(clusters, land, forced, method, directed, split, seed, auc_samples)
+
+
+def draw_samples(ctx, seed, S, directed=False, n_sets=1):
+    sets = [ctx.draw_samples(seed, S, directed, t) for t in range(n_sets)]
+    return tuple(np.stack([s[k] for s in sets]) for k in range(3))

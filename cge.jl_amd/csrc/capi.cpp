@@ -1,0 +1,762 @@
+// capi.cpp -- the extern "C" surface declared in include/cge_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <thread>
+#include <unordered_set>
+
+#include "common.hpp"
+#include "../../include/cge_hip_testing.h"
+
+void k_gather_i32(cge_ctx *c, const i32 *arr, const i32 *idx, i64 S, i32 *out);
+
+#define CGE_TRY(ctx) try {
+#define CGE_CATCH(ctx)                                             \
+    }                                                              \
+    catch (const CgeError &e) {                                    \
+        if (ctx) (ctx)->err = e.msg;                               \
+        return e.code;                                             \
+    }                                                              \
+    catch (const std::bad_alloc &) {                               \
+        if (ctx) (ctx)->err = "host allocation failed";            \
+        return CGE_E_OOM;                                          \
+    }                                                              \
+    catch (const std::exception &e) {                              \
+        if (ctx) (ctx)->err = e.what();                            \
+        return CGE_E_ARG;                                          \
+    }                                                              \
+    return CGE_OK;
+
+static void flush_timers(cge_ctx *c) {
+    for (auto &kv : c->timers) {
+        for (auto &pr : kv.second.pending) {
+            float ms = 0.f;
+            (void)hipEventSynchronize(pr.second);
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.total_ms += ms;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+extern "C" {
+
+int cge_abi_version(void) { return CGE_ABI_VERSION; }
+
+int cge_create(cge_ctx **out, int device, void *stream) {
+    if (!out) return CGE_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CGE_E_HIP; // no GPU: fail loudly, no fallback
+    if (device < 0 || device >= ndev) return CGE_E_ARG;
+    cge_ctx *c = new (std::nothrow) cge_ctx();
+    if (!c) return CGE_E_OOM;
+    try {
+        HIP_CHECK(hipSetDevice(device));
+        c->device = device;
+        if (stream) {
+            c->stream = (hipStream_t)stream;
+        } else {
+            HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->own_stream = true;
+        }
+        unsigned hc = std::thread::hardware_concurrency();
+        c->n_threads = (int)std::max(1u, std::min(hc ? hc : 8u, 16u));
+    } catch (const CgeError &e) {
+        delete c;
+        return e.code;
+    }
+    *out = c;
+    return CGE_OK;
+}
+
+void cge_destroy(cge_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    flush_timers(c);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *cge_last_error(const cge_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int cge_set_host_threads(cge_ctx *c, int n) {
+    if (!c || n < 1) return CGE_E_ARG;
+    c->n_threads = n;
+    return CGE_OK;
+}
+
+int cge_set_collectives(cge_ctx *c, const cge_collectives *coll) {
+    if (!c) return CGE_E_ARG;
+    if (!coll || !coll->allreduce_f64 || coll->world <= 1) {
+        c->has_coll = false;
+        return CGE_OK;
+    }
+    c->coll = *coll;
+    c->has_coll = true;
+    return CGE_OK;
+}
+
+int cge_exchange_buffer(cge_ctx *c, int64_t min_doubles, void **dev_ptr, int64_t *cap) {
+    if (!c) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    if ((size_t)min_doubles > c->xbuf.n || !c->xbuf.p) c->xbuf.alloc_exact((size_t)std::max<i64>(min_doubles, 1024));
+    if (dev_ptr) *dev_ptr = c->xbuf.p;
+    if (cap) *cap = (int64_t)c->xbuf.n;
+    CGE_CATCH(c)
+}
+
+// ---- resident inputs ------------------------------------------------------------------------------
+int cge_set_graph(cge_ctx *c, const int64_t *src, const int64_t *dst, const double *w, int64_t m, int64_t n) {
+    if (!c || !src || !dst || m <= 0 || n <= 0 || n >= (1LL << 31)) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    std::vector<i32> s(m), t(m);
+    for (i64 e = 0; e < m; e++) {
+        if (src[e] < 1 || src[e] > n || dst[e] < 1 || dst[e] > n) CGE_THROW(CGE_E_ARG, "edge %lld has a vertex id outside 1..%lld", (long long)e + 1, (long long)n);
+        s[e] = (i32)(src[e] - 1);
+        t[e] = (i32)(dst[e] - 1);
+    }
+    c->h_w.assign(m, 1.0);
+    bool unit = true;
+    if (w)
+        for (i64 e = 0; e < m; e++) {
+            c->h_w[e] = w[e];
+            unit = unit && (w[e] == 1.0);
+        }
+    c->unit_weights = unit;
+    c->src.alloc_exact(m);
+    c->dst.alloc_exact(m);
+    c->w.alloc_exact(m);
+    HIP_CHECK(hipMemcpyAsync(c->src.p, s.data(), sizeof(i32) * m, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->dst.p, t.data(), sizeof(i32) * m, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->w.p, c->h_w.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->m = m;
+    if (c->n && c->n != n) { c->h_Xr.clear(); c->h_vw.clear(); c->h_comm.clear(); c->d = 0; }
+    c->n = n;
+    c->lm_ready = false;
+    CGE_CATCH(c)
+}
+
+int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
+    if (!c || !X || n <= 0 || d <= 0) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    if (c->n && c->n != n) CGE_THROW(CGE_E_ASSERT, "No. rows in embedding and no. vertices in a graph differ.");
+    DevBuf<double> col;
+    col.alloc_exact((size_t)n * d);
+    HIP_CHECK(hipMemcpyAsync(col.p, X, sizeof(double) * n * d, hipMemcpyHostToDevice, c->stream));
+    c->Xr.alloc_exact((size_t)n * d);
+    k_transpose_to_rowmajor(c, col.p, c->Xr.p, n, d);
+    c->h_Xr.resize((size_t)n * d);
+    HIP_CHECK(hipMemcpyAsync(c->h_Xr.data(), c->Xr.p, sizeof(double) * n * d, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    col.release();
+    c->n = n;
+    c->d = d;
+    // centred feature-major copy + row norms for the diameter kernel (layout prep, part of the upload)
+    c->ldn = (n + 127) / 128 * 128;
+    c->dpad = (d + 15) / 16 * 16;
+    c->Xc.alloc_exact((size_t)c->ldn * c->dpad);
+    c->rnorm.alloc_exact((size_t)c->ldn);
+    k_centre_featuremajor(c, c->Xr.p, c->Xc.p, c->rnorm.p, n, d, c->ldn, c->dpad);
+    c->centred_ready = true;
+    c->lm_ready = false;
+    CGE_CATCH(c)
+}
+
+int cge_set_vertex_data(cge_ctx *c, const int64_t *comm, const double *vw, int64_t n) {
+    if (!c || n <= 0) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    if (c->n && c->n != n) CGE_THROW(CGE_E_ASSERT, "No. communities (%lld) differ from no. nodes (%lld)", (long long)n, (long long)c->n);
+    c->n = n;
+    if (comm) {
+        c->h_comm.resize(n);
+        i64 cmax = 0;
+        for (i64 i = 0; i < n; i++) {
+            if (comm[i] < 1) CGE_THROW(CGE_E_ARG, "community ids must be 1-based");
+            c->h_comm[i] = (i32)(comm[i] - 1);
+            cmax = std::max<i64>(cmax, comm[i]);
+        }
+        c->n_comm_max = cmax;
+        c->comm.alloc_exact(n);
+        HIP_CHECK(hipMemcpyAsync(c->comm.p, c->h_comm.data(), sizeof(i32) * n, hipMemcpyHostToDevice, c->stream));
+    }
+    if (vw) {
+        c->h_vw.assign(vw, vw + n);
+        c->vw.alloc_exact(n);
+        HIP_CHECK(hipMemcpyAsync(c->vw.p, c->h_vw.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->lm_ready = false;
+    CGE_CATCH(c)
+}
+
+// ---- landmarks ------------------------------------------------------------------------------------
+// `size(unique(embedding, dims=1), 1)` clamp (src/landmarks.jl:371-376).  Equal rows have equal
+// hashes, so #distinct hashes <= #unique rows: once `land` distinct hashes are seen no clamp can
+// apply; otherwise count exactly on the host mirror.
+static i64 clamp_to_unique_rows(cge_ctx *c, i64 land, int *truncated) {
+    const i64 n = c->n, d = c->d;
+    *truncated = 0;
+    if (land <= 1) return land;
+    DevBuf<uint64_t> dh;
+    dh.ensure(n);
+    k_row_hash(c, c->Xr.p, dh.p, n, d);
+    std::vector<uint64_t> h(n);
+    HIP_CHECK(hipMemcpyAsync(h.data(), dh.p, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::unordered_set<uint64_t> seen;
+    seen.reserve((size_t)std::min<i64>(n, 2 * land));
+    for (i64 i = 0; i < n; i++) {
+        seen.insert(h[i]);
+        if ((i64)seen.size() >= land) return land;
+    }
+    // fewer distinct hashes than `land`: count bitwise-distinct rows exactly
+    std::vector<i64> ix(n);
+    for (i64 i = 0; i < n; i++) ix[i] = i;
+    const double *X = c->h_Xr.data();
+    auto cmp = [&](i64 a, i64 b) { return memcmp(X + a * d, X + b * d, sizeof(double) * d) < 0; };
+    std::sort(ix.begin(), ix.end(), cmp);
+    i64 uniq = n > 0 ? 1 : 0;
+    for (i64 i = 1; i < n; i++)
+        if (memcmp(X + ix[i - 1] * d, X + ix[i] * d, sizeof(double) * d) != 0) uniq++;
+    if (land > uniq) {
+        *truncated = 1;
+        return uniq;
+    }
+    return land;
+}
+
+static void allreduce(cge_ctx *c, double *dev, i64 count, int op) {
+    if (!c->has_coll) return;
+    // the hook works on the ctx exchange buffer (the host side wrapped that pointer once)
+    if ((size_t)count > c->xbuf.n) CGE_THROW(CGE_E_COLLECTIVE, "exchange buffer too small: need %lld doubles", (long long)count);
+    if (dev != c->xbuf.p)
+        HIP_CHECK(hipMemcpyAsync(c->xbuf.p, dev, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->coll.allreduce_f64(c->coll.user, c->xbuf.p, count, op) != 0) CGE_THROW(CGE_E_COLLECTIVE, "allreduce hook failed");
+    if (dev != c->xbuf.p)
+        HIP_CHECK(hipMemcpyAsync(dev, c->xbuf.p, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
+}
+
+static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 land, i64 forced,
+                               int method, int directed) {
+    if (!c->Xr.p || !c->vw.p || !c->comm.p || !c->src.p) CGE_THROW(CGE_E_ARG, "landmarks: graph, embedding and vertex data must be resident");
+    if (method < 0 || method > 3) CGE_THROW(CGE_E_ARG, "unknown split method %d", method);
+    const i64 n = c->n, d = c->d;
+    hipStream_t st = c->stream;
+    double t0 = now_ms();
+    land = clamp_to_unique_rows(c, land, &c->lm_truncated);
+    std::vector<i64> gid;
+    host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, nullptr);
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->phases.ms["landmarks"] = now_ms() - t0;
+    t0 = now_ms();
+    c->h_v2l.resize(n);
+    i64 N = 0;
+    for (i64 i = 0; i < n; i++) {
+        c->h_v2l[i] = gid[i] + 1; // :379
+        N = std::max(N, c->h_v2l[i]);
+    }
+    c->N = N;
+    // CSR landmark -> members in ascending vertex order
+    std::vector<i32> v2l0(n), mem_off(N + 1, 0), mem(n);
+    for (i64 i = 0; i < n; i++) {
+        v2l0[i] = (i32)gid[i];
+        mem_off[gid[i] + 1]++;
+    }
+    for (i64 l = 0; l < N; l++) mem_off[l + 1] += mem_off[l];
+    {
+        std::vector<i32> cur(mem_off.begin(), mem_off.end() - 1);
+        for (i64 i = 0; i < n; i++) mem[cur[gid[i]]++] = (i32)i;
+    }
+    DevBuf<i32> d_off, d_mem;
+    d_off.ensure(N + 1);
+    d_mem.ensure(n);
+    c->v2l.ensure(n);
+    HIP_CHECK(hipMemcpyAsync(c->v2l.p, v2l0.data(), sizeof(i32) * n, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(d_off.p, mem_off.data(), sizeof(i32) * (N + 1), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(d_mem.p, mem.data(), sizeof(i32) * n, hipMemcpyHostToDevice, st));
+    c->lemb.ensure((size_t)N * d);
+    c->lweight.ensure(N);
+    c->dii.ensure(N);
+    c->lcomm.ensure(N);
+    {
+        ScopedKernelTimer tm(c, "landmark_aggregate");
+        k_landmark_aggregate(c, c->Xr.p, c->vw.p, c->comm.p, d_off.p, d_mem.p, N, d, c->lemb.p, c->lweight.p, c->dii.p,
+                             c->lcomm.p);
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->phases.ms["aggregate"] = now_ms() - t0;
+    t0 = now_ms();
+    // per-edge scatter: wedges (N x N) and vect_C (from the original edges; every landmark lies in one community)
+    const i64 C = c->n_comm_max;
+    const i64 vlen = directed ? C * C : packed_len(C);
+    c->wedges.ensure((size_t)N * N);
+    c->vectC.ensure(vlen);
+    HIP_CHECK(hipMemsetAsync(c->wedges.p, 0, sizeof(double) * N * N, st));
+    HIP_CHECK(hipMemsetAsync(c->vectC.p, 0, sizeof(double) * vlen, st));
+    i64 e0 = 0, e1 = c->m;
+    if (c->has_coll) { // edge shard of this rank
+        e0 = c->m * c->coll.rank / c->coll.world;
+        e1 = c->m * (c->coll.rank + 1) / c->coll.world;
+    }
+    k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, c->v2l.p, c->comm.p, N, C,
+                   directed, c->wedges.p, c->vectC.p);
+    if (c->has_coll) {
+        allreduce(c, c->wedges.p, N * N, 0);
+        allreduce(c, c->vectC.p, vlen, 0);
+    }
+    DevBuf<i64> cnt;
+    cnt.ensure(1);
+    k_compact_count(c, c->wedges.p, N, directed, cnt.p);
+    HIP_CHECK(hipMemcpyAsync(&c->n_ledges, cnt.p, sizeof(i64), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->phases.ms["scatter"] = now_ms() - t0;
+    c->lm_directed = directed;
+    c->lm_ready = true;
+}
+
+int cge_landmarks_run(cge_ctx *c, const int64_t *cl_flat, const int64_t *cl_off, int64_t ncl, int64_t land,
+                      int64_t forced, int method, int directed, int64_t *N_out, int64_t *n_ledges_out, int *truncated) {
+    if (!c || !cl_flat || !cl_off) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    landmarks_run_impl(c, cl_flat, cl_off, ncl, land, forced, method, directed);
+    if (N_out) *N_out = c->N;
+    if (n_ledges_out) *n_ledges_out = c->n_ledges;
+    if (truncated) *truncated = c->lm_truncated;
+    CGE_CATCH(c)
+}
+
+int cge_landmarks_fetch(cge_ctx *c, double *dii, double *embed, int64_t *cluster, int64_t *ledges, double *lw_e,
+                        double *lweight, int64_t *v_to_l) {
+    if (!c) return CGE_E_ARG;
+    CGE_TRY(c)
+    if (!c->lm_ready) CGE_THROW(CGE_E_ARG, "landmarks_fetch: run cge_landmarks_run first");
+    HIP_CHECK(hipSetDevice(c->device));
+    const i64 N = c->N, d = c->d, n = c->n;
+    hipStream_t st = c->stream;
+    if (dii) HIP_CHECK(hipMemcpyAsync(dii, c->dii.p, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    if (lweight) HIP_CHECK(hipMemcpyAsync(lweight, c->lweight.p, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    std::vector<double> rm;
+    std::vector<i32> lc;
+    if (embed) {
+        rm.resize((size_t)N * d);
+        HIP_CHECK(hipMemcpyAsync(rm.data(), c->lemb.p, sizeof(double) * N * d, hipMemcpyDeviceToHost, st));
+    }
+    if (cluster) {
+        lc.resize(N);
+        HIP_CHECK(hipMemcpyAsync(lc.data(), c->lcomm.p, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
+    }
+    std::vector<double> we;
+    if (ledges || lw_e) {
+        we.resize((size_t)N * N);
+        HIP_CHECK(hipMemcpyAsync(we.data(), c->wedges.p, sizeof(double) * N * N, hipMemcpyDeviceToHost, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (embed)
+        for (i64 l = 0; l < N; l++)
+            for (i64 k = 0; k < d; k++) embed[l + k * N] = rm[l * d + k]; // column-major out
+    if (cluster)
+        for (i64 l = 0; l < N; l++) cluster[l] = lc[l] + 1;
+    if (ledges || lw_e) { // rows in idx order / N*(i-1)+j order, w > 0 only (src/landmarks.jl:441-463)
+        const i64 ne = c->n_ledges;
+        i64 k = 0;
+        for (i64 a = 0; a < N; a++)
+            for (i64 b = c->lm_directed ? 0 : a; b < N; b++) {
+                const double wv = we[a * N + b];
+                if (wv > 0) {
+                    if (k >= ne) CGE_THROW(CGE_E_ASSERT, "landmark edge count changed between run and fetch");
+                    if (ledges) { ledges[k] = a + 1; ledges[k + ne] = b + 1; }
+                    if (lw_e) lw_e[k] = wv;
+                    k++;
+                }
+            }
+    }
+    if (v_to_l) memcpy(v_to_l, c->h_v2l.data(), sizeof(i64) * n);
+    CGE_CATCH(c)
+}
+
+int cge_runsplit(cge_ctx *c, const int64_t *cl_flat, const int64_t *cl_off, int64_t ncl, int64_t nland,
+                 int64_t forced, int method, int64_t *group_ids) {
+    if (!c || !group_ids) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->Xr.p || !c->vw.p) CGE_THROW(CGE_E_ARG, "runsplit: embedding and vertex weights must be resident");
+    std::vector<i64> gid;
+    host_runsplit(c, cl_flat, cl_off, ncl, nland, forced, method, gid, nullptr);
+    memcpy(group_ids, gid.data(), sizeof(i64) * c->n);
+    CGE_CATCH(c)
+}
+
+// ---- samples --------------------------------------------------------------------------------------
+int cge_draw_samples(cge_ctx *c, int64_t seed, int64_t stream_id, int64_t S, int directed, int64_t *pos_idx,
+                     int64_t *neg_i, int64_t *neg_j) {
+    if (!c || S <= 0 || !pos_idx || !neg_i || !neg_j) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->src.p) CGE_THROW(CGE_E_ARG, "draw_samples: no resident graph");
+    host_draw_samples(c, seed, stream_id, S, directed, pos_idx, neg_i, neg_j);
+    CGE_CATCH(c)
+}
+
+static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_directed, SampleSet &smp) {
+    // seeded: one set reused at every alpha (Random.seed! before each draw, src/divergence.jl:184,193);
+    // unseeded: a fresh set per alpha, keyed by an arbitrary fixed base seed and the alpha index
+    const i64 n_alpha = 40;
+    smp.S = S;
+    smp.n_sets = (seed != -1) ? 1 : n_alpha;
+    const i64 base = (seed != -1) ? seed : 0x5eedc0de;
+    smp.pos_idx.resize(smp.n_sets * S);
+    smp.neg_i.resize(smp.n_sets * S);
+    smp.neg_j.resize(smp.n_sets * S);
+    for (i64 t = 0; t < smp.n_sets; t++)
+        host_draw_samples(c, base, t, S, directed, &smp.pos_idx[t * S], &smp.neg_i[t * S], &smp.neg_j[t * S]);
+    if (exact_directed) { // the un-reseeded second positive draw of :510
+        smp.pos_idx2.resize(smp.n_sets * S);
+        std::vector<i64> di(S), dj(S);
+        for (i64 t = 0; t < smp.n_sets; t++)
+            host_draw_samples(c, base + 0x7777, 1000 + t, S, directed, &smp.pos_idx2[t * S], di.data(), dj.data());
+    }
+}
+
+// diameter of the resident embedding (this rank's share), exact arithmetic of dist() on the arg-max pair
+static double resident_diameter(cge_ctx *c, int part, int nparts, i64 *ai, i64 *aj) {
+    if (!c->centred_ready) CGE_THROW(CGE_E_ARG, "diameter: embedding not resident");
+    double bv;
+    i64 bi, bj;
+    k_max_pair(c, c->Xc.p, c->rnorm.p, c->n, c->ldn, c->dpad, part, nparts, &bv, &bi, &bj);
+    double hi = 0.0;
+    if (bv >= 0.0) {
+        DevBuf<i32> pij;
+        DevBuf<double> dd;
+        pij.ensure(2);
+        dd.ensure(1);
+        const i32 h[2] = {(i32)bi, (i32)bj};
+        HIP_CHECK(hipMemcpyAsync(pij.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        k_pair_dist(c, c->Xr.p, c->d, pij.p, pij.p + 1, 1, 1.0, dd.p);
+        HIP_CHECK(hipMemcpyAsync(&hi, dd.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    if (ai) *ai = bi + 1;
+    if (aj) *aj = bj + 1;
+    return hi;
+}
+
+int cge_max_pair_dist(cge_ctx *c, int part, int nparts, double *hi, int64_t *arg_i, int64_t *arg_j) {
+    if (!c || !hi || nparts < 1 || part < 0 || part >= nparts) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    *hi = resident_diameter(c, part, nparts, arg_i, arg_j);
+    CGE_CATCH(c)
+}
+
+// ---- wGCL -------------------------------------------------------------------------------------------
+static void upload_i64_as_i32(cge_ctx *c, const i64 *h, i64 cnt, i64 lo, i64 hi, DevBuf<i32> &out, const char *what) {
+    std::vector<i32> t(cnt);
+    for (i64 i = 0; i < cnt; i++) {
+        if (h[i] < lo || h[i] > hi) CGE_THROW(CGE_E_ARG, "%s: id %lld outside %lld..%lld", what, (long long)h[i], (long long)lo, (long long)hi);
+        t[i] = (i32)(h[i] - 1);
+    }
+    out.ensure(cnt);
+    HIP_CHECK(hipMemcpyAsync(out.p, t.data(), sizeof(i32) * cnt, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+// star-graph guard of wGCL_directed (src/divergence.jl:321-334)
+static bool is_star(const std::vector<i32> &star, i64 N) {
+    bool has_nm1 = false, has_2nm1 = false;
+    i64 sum = 0, cnt2 = 0;
+    for (i64 i = 0; i < N; i++) {
+        if (star[i] == N - 1) has_nm1 = true;
+        if (star[i] == 2 * (N - 1)) has_2nm1 = true;
+        sum += star[i];
+        if (star[i] == 2) cnt2++;
+    }
+    return (has_nm1 && sum == 2 * (N - 1)) || (has_2nm1 && cnt2 == N - 1);
+}
+
+int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cge_trace *trace) {
+    if (!c || !a || !out || !out_len) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int directed = a->directed;
+    if (!a->edges_src || !a->edges_dst || a->m <= 0) CGE_THROW(CGE_E_ARG, "wGCL: empty edge list");
+    i64 N = 0;
+    for (i64 e = 0; e < a->m; e++) N = std::max(N, std::max(a->edges_src[e], a->edges_dst[e])); // maximum(edges) :41
+    const bool landmarks = a->n_v_to_l > 0;                                                      // :44
+    if (a->n_comm != N) CGE_THROW(CGE_E_ASSERT, "AssertionError: No. communities not matching no. vertices"); // :50
+    if (a->n_distances != N) CGE_THROW(CGE_E_ASSERT, "AssertionError: Distances vector length is not equal to no. vertices"); // :81
+    if (a->embed_rows < N) CGE_THROW(CGE_E_ARG, "wGCL: embedding has fewer rows than vertices");
+    i64 C = 0;
+    for (i64 i = 0; i < N; i++) C = std::max(C, a->comm[i]);
+    const i64 d = a->d;
+
+    // score graph -> device scratch
+    DevBuf<i32> g_src, g_dst;
+    DevBuf<double> g_w, colbuf;
+    upload_i64_as_i32(c, a->edges_src, a->m, 1, N, g_src, "edges");
+    upload_i64_as_i32(c, a->edges_dst, a->m, 1, N, g_dst, "edges");
+    g_w.ensure(a->m);
+    HIP_CHECK(hipMemcpyAsync(g_w.p, a->eweights, sizeof(double) * a->m, hipMemcpyHostToDevice, st));
+    upload_i64_as_i32(c, a->comm, N, 1, C, c->s_comm, "comm");
+    colbuf.ensure((size_t)a->embed_rows * d);
+    HIP_CHECK(hipMemcpyAsync(colbuf.p, a->embed, sizeof(double) * a->embed_rows * d, hipMemcpyHostToDevice, st));
+    c->s_emb.ensure((size_t)a->embed_rows * d);
+    k_transpose_to_rowmajor(c, colbuf.p, c->s_emb.p, a->embed_rows, d);
+    c->s_dist.ensure(N);
+    c->s_vw.ensure(N);
+    HIP_CHECK(hipMemcpyAsync(c->s_dist.p, a->distances, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->s_vw.p, a->vweights, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    const i64 vlen = directed ? C * C : packed_len(C);
+    c->s_vectC.ensure(vlen);
+    HIP_CHECK(hipMemsetAsync(c->s_vectC.p, 0, sizeof(double) * vlen, st));
+    k_edge_scatter(c, g_src.p, g_dst.p, g_w.p, 0, a->m, nullptr, c->s_comm.p, N, C, directed, nullptr, c->s_vectC.p);
+    ScoreGraph G;
+    G.N = N; G.d = d; G.C = C;
+    G.emb = c->s_emb.p; G.dist = c->s_dist.p; G.vw = c->s_vw.p; G.comm = c->s_comm.p; G.vectC = c->s_vectC.p;
+    if (directed) {
+        c->s_degin.ensure(N);
+        c->s_degout.ensure(N);
+        DevBuf<i32> star;
+        star.ensure(N);
+        HIP_CHECK(hipMemsetAsync(c->s_degin.p, 0, sizeof(double) * N, st));
+        HIP_CHECK(hipMemsetAsync(c->s_degout.p, 0, sizeof(double) * N, st));
+        HIP_CHECK(hipMemsetAsync(star.p, 0, sizeof(i32) * N, st));
+        k_edge_degrees(c, g_src.p, g_dst.p, g_w.p, a->m, c->s_degout.p, c->s_degin.p, star.p);
+        std::vector<i32> hstar(N);
+        HIP_CHECK(hipMemcpyAsync(hstar.data(), star.p, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (is_star(hstar, N)) {
+            out[0] = -1.0;
+            for (int k = 1; k < 6; k++) out[k] = 0.0;
+            *out_len = 6;
+            return CGE_OK;
+        }
+        G.deg_in = c->s_degin.p;
+        G.deg_out = c->s_degout.p;
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+
+    // the graph the local score samples from: the original graph in landmark mode, else the score graph
+    OrigView ov;
+    if (landmarks) {
+        const bool have_init = a->init_embed && a->init_edges_src && a->init_edges_dst && a->init_vweights;
+        if (have_init) { // (re)load the original graph as the resident one
+            const i64 n0 = a->n_init;
+            if (a->n_v_to_l != n0) CGE_THROW(CGE_E_ARG, "wGCL: v_to_l and init_vweights differ in length");
+            int rc = cge_set_graph(c, a->init_edges_src, a->init_edges_dst, a->init_eweights, a->m_init, n0);
+            if (rc) throw CgeError{rc, c->err};
+            rc = cge_set_embedding(c, a->init_embed, n0, d);
+            if (rc) throw CgeError{rc, c->err};
+            rc = cge_set_vertex_data(c, nullptr, a->init_vweights, n0);
+            if (rc) throw CgeError{rc, c->err};
+        } else if (!c->Xr.p || !c->src.p || !c->vw.p || c->n != a->n_v_to_l)
+            CGE_THROW(CGE_E_ARG, "wGCL: landmark mode needs init_* arrays or matching resident inputs");
+        upload_i64_as_i32(c, a->v_to_l, a->n_v_to_l, 1, N, c->v2l, "v_to_l");
+        ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p;
+        ov.lweight = c->s_vw.p; ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
+        double hi = resident_diameter(c, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1, nullptr, nullptr);
+        if (c->has_coll) {
+            c->xbuf.ensure(1024);
+            HIP_CHECK(hipMemcpyAsync(c->xbuf.p, &hi, sizeof(double), hipMemcpyHostToDevice, st));
+            allreduce(c, c->xbuf.p, 1, 1);
+            HIP_CHECK(hipMemcpyAsync(&hi, c->xbuf.p, sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        ov.hi = hi;
+    } else {
+        // exact mode: make the score graph the resident graph so the sampler can reject its edges
+        int rc = cge_set_graph(c, a->edges_src, a->edges_dst, a->eweights, a->m, N);
+        if (rc) throw CgeError{rc, c->err};
+    }
+    SampleSet smp;
+    if (a->pos_idx && a->neg_i && a->neg_j && a->n_sample_sets > 0) {
+        smp.S = a->auc_samples;
+        smp.n_sets = a->n_sample_sets;
+        const i64 tot = smp.S * smp.n_sets;
+        smp.pos_idx.assign(a->pos_idx, a->pos_idx + tot);
+        smp.neg_i.assign(a->neg_i, a->neg_i + tot);
+        smp.neg_j.assign(a->neg_j, a->neg_j + tot);
+        if (a->pos_idx2) smp.pos_idx2.assign(a->pos_idx2, a->pos_idx2 + tot);
+    } else
+        make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
+    host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.data(), c->m, directed, a->split, smp,
+                    out, out_len, trace);
+    flush_timers(c);
+    CGE_CATCH(c)
+}
+
+int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, cge_trace *trace) {
+    if (!c || !a || !out || !out_len) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (!c->Xr.p || !c->vw.p || !c->comm.p || !c->src.p) CGE_THROW(CGE_E_ARG, "score: graph, embedding and vertex data must be resident");
+    c->phases.ms.clear();
+    const int directed = a->directed;
+    const i64 d = c->d;
+    ScoreGraph G;
+    OrigView ov;
+    const bool landmarks = a->land != -1;
+    DevBuf<double> zeros;
+    double t0;
+    if (landmarks) {
+        landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed);
+        const i64 N = c->N, C = c->n_comm_max;
+        // wGCL's own `maximum(edges)` / size asserts (src/divergence.jl:41,50): the highest-numbered
+        // landmark must carry an edge -- always true when every vertex has positive weight
+        G.N = N; G.d = d; G.C = C;
+        G.emb = c->lemb.p; G.dist = c->dii.p; G.vw = c->lweight.p; G.comm = c->lcomm.p; G.vectC = c->vectC.p;
+        if (directed) { // degrees of the landmark graph = row / column sums of wedges
+            CGE_THROW(CGE_E_ARG, "score: directed landmark mode goes through cge_landmarks_run + cge_wgcl");
+        }
+        t0 = now_ms();
+        ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
+        ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
+        double hi = resident_diameter(c, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1, nullptr, nullptr);
+        if (c->has_coll) {
+            c->xbuf.ensure(1024);
+            HIP_CHECK(hipMemcpyAsync(c->xbuf.p, &hi, sizeof(double), hipMemcpyHostToDevice, st));
+            allreduce(c, c->xbuf.p, 1, 1);
+            HIP_CHECK(hipMemcpyAsync(&hi, c->xbuf.p, sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        ov.hi = hi;
+        c->phases.ms["diameter"] = now_ms() - t0;
+    } else {
+        if (directed) CGE_THROW(CGE_E_ARG, "score: directed exact mode goes through cge_wgcl");
+        const i64 N = c->n, C = c->n_comm_max;
+        zeros.ensure(N);
+        HIP_CHECK(hipMemsetAsync(zeros.p, 0, sizeof(double) * N, st)); // distances = zeros (CGE_CLI.jl:4)
+        const i64 vlen = packed_len(C);
+        c->vectC.ensure(vlen);
+        HIP_CHECK(hipMemsetAsync(c->vectC.p, 0, sizeof(double) * vlen, st));
+        k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, 0, c->m, nullptr, c->comm.p, N, C, 0,
+                       nullptr, c->vectC.p);
+        G.N = N; G.d = d; G.C = C;
+        G.emb = c->Xr.p; G.dist = zeros.p; G.vw = c->vw.p; G.comm = c->comm.p; G.vectC = c->vectC.p;
+    }
+    t0 = now_ms();
+    SampleSet smp;
+    make_samples(c, a->seed, a->auc_samples, directed, false, smp);
+    c->phases.ms["samples"] = now_ms() - t0;
+    t0 = now_ms();
+    host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.data(), c->m, directed, a->split, smp,
+                    out, out_len, trace);
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->phases.ms["sweep"] = now_ms() - t0;
+    flush_timers(c);
+    CGE_CATCH(c)
+}
+
+// ---- helpers ----------------------------------------------------------------------------------------
+int64_t cge_idx(int64_t n, int64_t i, int64_t j) { return n * (i - 1) - (i - 1) * (i - 2) / 2 + j - i + 1; }
+
+int cge_js(cge_ctx *c, const double *vC, const double *vB, int64_t len, const uint8_t *vI, int internal, double *out) {
+    if (!c || !vC || !vB || !out || len <= 0) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    // vI (when given) selects bins; the device kernel derives the diagonal mask from the packed/square
+    // layout, so here the selected bins are compacted on the host first and scored with mode 0.
+    std::vector<double> p, q;
+    for (i64 k = 0; k < len; k++)
+        if (!vI || ((vI[k] != 0) == (internal != 0))) { p.push_back(vC[k]); q.push_back(vB[k]); }
+    const i64 L = (i64)p.size();
+    DevBuf<double> dp, dq, r;
+    dp.ensure(L); dq.ensure(L); r.ensure(1);
+    HIP_CHECK(hipMemcpyAsync(dp.p, p.data(), sizeof(double) * L, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(dq.p, q.data(), sizeof(double) * L, hipMemcpyHostToDevice, c->stream));
+    k_js(c, dp.p, dq.p, L, 1, 0, 0, r.p);
+    HIP_CHECK(hipMemcpyAsync(out, r.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    CGE_CATCH(c)
+}
+
+int cge_edge_scatter(cge_ctx *c, const int64_t *v_to_l, int64_t N, int64_t C, int directed, int64_t e0, int64_t e1,
+                     double *wedges_out, double *vect_C_out) {
+    if (!c || N <= 0 || C <= 0 || e0 < 0 || e1 < e0) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->src.p || !c->comm.p) CGE_THROW(CGE_E_ARG, "edge_scatter: graph and vertex data must be resident");
+    if (e1 > c->m) CGE_THROW(CGE_E_ARG, "edge_scatter: edge range beyond m");
+    hipStream_t st = c->stream;
+    DevBuf<i32> dv;
+    if (v_to_l) upload_i64_as_i32(c, v_to_l, c->n, 1, N, dv, "v_to_l");
+    const i64 vlen = directed ? C * C : packed_len(C);
+    DevBuf<double> dw, dc;
+    if (wedges_out) {
+        if (!v_to_l) CGE_THROW(CGE_E_ARG, "edge_scatter: wedges need v_to_l");
+        dw.ensure((size_t)N * N);
+        HIP_CHECK(hipMemsetAsync(dw.p, 0, sizeof(double) * N * N, st));
+    }
+    if (vect_C_out) {
+        dc.ensure(vlen);
+        HIP_CHECK(hipMemsetAsync(dc.p, 0, sizeof(double) * vlen, st));
+    }
+    k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, v_to_l ? dv.p : nullptr,
+                   c->comm.p, N, C, directed, wedges_out ? dw.p : nullptr, vect_C_out ? dc.p : nullptr);
+    if (wedges_out) HIP_CHECK(hipMemcpyAsync(wedges_out, dw.p, sizeof(double) * N * N, hipMemcpyDeviceToHost, st));
+    if (vect_C_out) HIP_CHECK(hipMemcpyAsync(vect_C_out, dc.p, sizeof(double) * vlen, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    flush_timers(c);
+    CGE_CATCH(c)
+}
+
+// ---- profiling --------------------------------------------------------------------------------------
+int cge_profile_enable(cge_ctx *c, int on) {
+    if (!c) return CGE_E_ARG;
+    c->profiling = on != 0;
+    return CGE_OK;
+}
+int cge_profile_reset(cge_ctx *c) {
+    if (!c) return CGE_E_ARG;
+    flush_timers(c);
+    c->timers.clear();
+    return CGE_OK;
+}
+int cge_profile_get(cge_ctx *c, const char *name, int64_t *launches, double *total_ms) {
+    if (!c || !name) return CGE_E_ARG;
+    flush_timers(c);
+    auto it = c->timers.find(name);
+    if (launches) *launches = it == c->timers.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == c->timers.end() ? 0.0 : it->second.total_ms;
+    return CGE_OK;
+}
+int cge_profile_names(cge_ctx *c, char *buf, int64_t buf_len) {
+    if (!c || !buf || buf_len <= 0) return CGE_E_ARG;
+    std::string s;
+    for (auto &kv : c->timers) {
+        if (!s.empty()) s += ",";
+        s += kv.first;
+    }
+    snprintf(buf, (size_t)buf_len, "%s", s.c_str());
+    return CGE_OK;
+}
+int cge_phase_ms(cge_ctx *c, const char *phase, double *ms) {
+    if (!c || !phase || !ms) return CGE_E_ARG;
+    auto it = c->phases.ms.find(phase);
+    *ms = it == c->phases.ms.end() ? 0.0 : it->second;
+    return CGE_OK;
+}
+
+// ---- host-only test hooks (include/cge_hip_testing.h) ------------------------------------------------
+int cge_host_eig_top(const double *A, int64_t d, double *v) {
+    if (!A || !v || d <= 0) return CGE_E_ARG;
+    host_eig_top(A, d, v);
+    return CGE_OK;
+}
+int cge_host_pos_draw(int64_t seed, int64_t stream_id, int64_t S, int64_t m, int64_t *pos_idx) {
+    if (!pos_idx || S <= 0 || m <= 0) return CGE_E_ARG;
+    host_pos_draw(seed, stream_id, S, m, pos_idx);
+    return CGE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,259 @@
+// common.hpp -- context, device buffers, error handling and launch helpers of libcge_hip.so.
+// gfx950 (MI355X) only; there is no CPU fallback anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cge_hip.h"
+
+typedef int64_t i64;
+typedef int32_t i32;
+
+struct CgeError {
+    int code;
+    std::string msg;
+};
+
+#define CGE_THROW(code, ...)                                  \
+    do {                                                      \
+        char _b[512];                                         \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                \
+        throw CgeError{(code), std::string(_b)};              \
+    } while (0)
+
+#define HIP_CHECK(expr)                                                                                 \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            CGE_THROW(_e == hipErrorOutOfMemory ? CGE_E_OOM : CGE_E_HIP, "%s failed: %s (%s:%d)", #expr, \
+                      hipGetErrorString(_e), __FILE__, __LINE__);                                       \
+    } while (0)
+
+// RAII device buffer
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    // grow-only allocation (contents are NOT preserved)
+    void ensure(size_t count) {
+        if (count <= n && p) return;
+        release();
+        if (count == 0) count = 1;
+        HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void alloc_exact(size_t count) {
+        release();
+        HIP_CHECK(hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)));
+        n = count ? count : 1;
+    }
+};
+
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    i64 launches = 0;
+    double total_ms = 0.0;
+};
+
+struct Phase {
+    std::map<std::string, double> ms;
+};
+
+// Device view of the graph that wGCL scores ("score graph": the landmark graph in landmark mode,
+// the original graph in exact mode).  All ids 0-based on the device.
+struct ScoreGraph {
+    i64 N = 0, d = 0, C = 0;
+    const double *emb = nullptr;   // N x d row-major
+    const double *dist = nullptr;  // N   (diagonal of D: dii or zeros)
+    const double *vw = nullptr;    // N   (Chung-Lu target weights; undirected)
+    const i32 *comm = nullptr;     // N   0-based community
+    const double *vectC = nullptr; // packed p(C) (undirected) or C*C (directed)
+    const double *deg_in = nullptr, *deg_out = nullptr; // directed only
+};
+
+struct cge_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int n_threads = 8;
+    cge_collectives coll{};
+    bool has_coll = false;
+    DevBuf<double> xbuf; // exchange buffer for collectives
+
+    // ---- resident original graph --------------------------------------------------------
+    i64 n = 0, m = 0, d = 0;
+    bool unit_weights = false;
+    DevBuf<i32> src, dst;     // 0-based
+    DevBuf<double> w;         // edge weights
+    DevBuf<double> Xr;        // n x d row-major (node-major)
+    DevBuf<double> Xc;        // dpad x ldn feature-major, zero padded, centred at the global mean (diameter kernel)
+    DevBuf<double> rnorm;     // ldn: squared norm of the centred rows (0 in the padding)
+    i64 ldn = 0, dpad = 0;
+    bool centred_ready = false;
+    DevBuf<i32> comm;         // n, 0-based
+    DevBuf<double> vw;        // n
+    std::vector<double> h_Xr; // host mirror, row-major (cut rules + RSS run on the host)
+    std::vector<i32> h_comm;
+    std::vector<double> h_vw;
+    std::vector<double> h_w;       // edge weights mirror (sample weights)
+    i64 n_comm_max = 0;            // C of the original graph
+
+    // ---- landmark state (output of cge_landmarks_run) ------------------------------------
+    bool lm_ready = false;
+    int lm_directed = 0;
+    i64 N = 0;
+    int lm_truncated = 0;
+    std::vector<i64> h_v2l;   // 1-based landmark of each vertex
+    DevBuf<i32> v2l;          // 0-based
+    DevBuf<double> lemb;      // N x d row-major
+    DevBuf<double> lweight, dii;
+    DevBuf<i32> lcomm;        // 0-based
+    DevBuf<double> wedges;    // N x N, [a*N + b]
+    DevBuf<double> vectC;     // from the original edges
+    i64 n_ledges = 0;
+
+    // ---- scratch for host-array wGCL ------------------------------------------------------
+    DevBuf<double> s_emb, s_dist, s_vw, s_vectC, s_degin, s_degout;
+    DevBuf<i32> s_comm;
+    DevBuf<double> auc_part;
+    // scratch of the batched split engine (landmarks_host.cpp)
+    DevBuf<i32> ls_rows, ls_row_task, ls_ct, ls_cb, ls_ce, ls_tco;
+    DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z;
+
+    // ---- profiling -------------------------------------------------------------------------
+    bool profiling = false;
+    std::map<std::string, KernelTimer> timers;
+    Phase phases;
+};
+
+// Bracket a launch with events when profiling is on.
+struct ScopedKernelTimer {
+    cge_ctx *c;
+    KernelTimer *t = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedKernelTimer(cge_ctx *ctx, const char *name) : c(ctx) {
+        if (!c->profiling) return;
+        t = &c->timers[name];
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~ScopedKernelTimer() {
+        if (!t) return;
+        (void)hipEventRecord(b, c->stream);
+        t->pending.push_back({a, b});
+        t->launches++;
+    }
+};
+
+static inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static inline i64 packed_len(i64 n) { return n * (n + 1) / 2; }
+// 0-based packed upper-triangular index, i <= j  (== idx(n,i+1,j+1) - 1, src/auxilary.jl:57-59)
+static inline i64 pidx0(i64 n, i64 i, i64 j) { return n * i - i * (i - 1) / 2 + (j - i); }
+
+static inline unsigned grid_for(i64 work, int block, i64 cap = 256 * 8) {
+    i64 g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// ---- kernels_*.hip entry points (host launchers) ---------------------------------------------
+// layout
+void k_transpose_to_rowmajor(cge_ctx *c, const double *Xcol, double *Xrow, i64 n, i64 d);
+void k_centre_featuremajor(cge_ctx *c, const double *Xrow, double *Xc, double *rnorm, i64 n, i64 d, i64 ldn, i64 dpad);
+void k_row_hash(cge_ctx *c, const double *Xrow, uint64_t *hash, i64 n, i64 d);
+// landmark split primitives (batched over tasks; rows = concatenated 0-based vertex ids)
+void k_group_mean(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
+                  const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
+                  i64 d, double *part, double *mean, double *sw);
+void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
+                 const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
+                 i64 d, const double *mean, double *part, double *cov);
+void k_group_project(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *row_task, i64 n_rows,
+                     i64 d, const double *mean, const double *vec, double *z);
+// landmark aggregation (src/landmarks.jl:387-430) with CSR landmark -> members (ascending vertex id)
+void k_landmark_aggregate(cge_ctx *c, const double *Xr, const double *vw, const i32 *comm, const i32 *mem_off,
+                          const i32 *mem, i64 N, i64 d, double *lemb, double *lweight, double *dii, i32 *lcomm);
+// per-edge scatter
+void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 e0, i64 e1, const i32 *v2l,
+                    const i32 *comm, i64 N, i64 C, int directed, double *wedges, double *vectC);
+void k_edge_degrees(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 m, double *deg_out,
+                    double *deg_in, i32 *star);
+void k_compact_count(cge_ctx *c, const double *wedges, i64 N, int directed, i64 *count);
+// distances
+void k_dist_matrix(cge_ctx *c, const double *emb, const double *diag, i64 N, i64 d, double *D);
+void k_minmax_upper(cge_ctx *c, const double *D, i64 N, double *lo_hi);
+void k_normalise(cge_ctx *c, double *D, i64 N, const double *lo_hi);
+void k_max_pair(cge_ctx *c, const double *Xc, const double *rnorm, i64 n, i64 ldn, i64 dpad, int part, int nparts,
+                double *best_val, i64 *best_i, i64 *best_j);
+void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *pj, i64 S, double inv_scale_den,
+                 double *out);
+// alpha sweep
+void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD);
+void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done);
+void k_fit_update(cge_ctx *c, double *T, const double *S, const double *w, i64 N, double eps, double delta, int *done,
+                  int *iters, double *fout);
+void k_fit_symv_dir(cge_ctx *c, const double *GD, const double *Tin, const double *Tout, i64 N, double *Sin,
+                    double *Sout, const int *done);
+void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, const double *Sout,
+                      const double *deg_in, const double *deg_out, i64 N, double delta, int *done, int *iters,
+                      double *state /* [0]=eps,[1]=diff */);
+void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *comm, const i32 *cm_off,
+            const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB);
+void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int directed, int mode /*0 all,1 int,2 ext*/,
+          double *out);
+void k_auc_landmark(cge_ctx *c, const double *Ta, const double *Tb, const i32 *v2l, const double *vw_orig,
+                    const double *lweight, const i32 *pi, const i32 *pj, const i32 *ni, const i32 *nj,
+                    const double *dpos, const double *dneg, const double *wts, i64 S, double alpha, double *out2);
+void k_auc_exact(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, i64 N, const i32 *pi,
+                 const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, double *out2);
+void k_mark_edge_hits(cge_ctx *c, const i32 *src, const i32 *dst, i64 m, int directed, const uint64_t *table,
+                      i64 table_size, i32 *hit);
+
+// ---- host modules -----------------------------------------------------------------------------
+// landmarks_host.cpp
+void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
+                   std::vector<i64> &group_ids /*0-based*/, std::vector<std::vector<i64>> *members_out);
+void host_eig_top(const double *A, i64 d, double *v); // largest-eigenvalue eigenvector, sign: max |.| component > 0
+// wgcl_host.cpp
+struct SampleSet {
+    i64 S = 0, n_sets = 0;
+    std::vector<i64> pos_idx, neg_i, neg_j, pos_idx2; // 1-based
+};
+void host_draw_samples(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i64 *pos_idx, i64 *neg_i, i64 *neg_j);
+void host_pos_draw(i64 seed, i64 stream_id, i64 S, i64 m, i64 *pos_idx);
+struct OrigView { // original graph pieces needed in landmark mode (device, 0-based)
+    i64 n = 0, m = 0;
+    const double *Xr = nullptr;
+    const double *vw = nullptr;
+    const i32 *v2l = nullptr;
+    const double *lweight = nullptr; // == score graph vweights
+    const i32 *src = nullptr, *dst = nullptr;
+    const double *h_w = nullptr; // host edge weights
+    double hi = 0.0;             // diameter
+};
+void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, const i32 *ex_src, const i32 *ex_dst,
+                     const double *ex_hw, i64 ex_m, int directed, int split, const SampleSet &smp, double out[7],
+                     int *out_len, cge_trace *trace);

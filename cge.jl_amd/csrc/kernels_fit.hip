@@ -1,0 +1,370 @@
+// kernels_fit.hip -- the alpha sweep on the device.
+//   k_pow_matrix     GD = (1 - D)^alpha                               src/divergence.jl:142-148 (:426-432)
+//   k_fit_symv/_update       Chung-Lu fixed point, undirected         src/divergence.jl:150-168
+//   k_fit_symv_dir/_update_dir  directed (Tin/Tout, adaptive eps)     src/divergence.jl:434-467
+//   k_bvec           vect_B = community-pair sums of P                src/divergence.jl:226-234 (:530-538)
+//   k_js             JS(vect_C, vect_B[, vI])                         src/auxilary.jl:34-52
+//   k_auc_*          1 - AUC tallies over sampled pairs               src/divergence.jl:178-213 (:478-517)
+//   k_mark_edge_hits non-edge rejection for the sampler               src/divergence.jl:137 (NE = all pairs \ E)
+// All reductions use a fixed order (no float atomics) so a run is bitwise reproducible.
+#include "common.hpp"
+
+#define WAVE 64
+
+__device__ __forceinline__ double block_sum_256(double v, double *sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void pow_matrix_kernel(const double *__restrict__ D, i64 total, double alpha, double *__restrict__ GD) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) GD[e] = pow(1.0 - D[e], alpha);
+}
+void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD) {
+    ScopedKernelTimer t(c, "pow_matrix");
+    hipLaunchKernelGGL(pow_matrix_kernel, dim3(grid_for(N * N, 256, 256 * 16)), dim3(256), 0, c->stream, D, N * N,
+                       alpha, GD);
+}
+
+// ------------------------------------------------------------------------------------------------
+// S_i = sum_j (T_i*T_j)*GD_ij  (full symmetric GD: the diagonal is counted once, as :153-159).
+// One workgroup per row; every kernel of a fit returns at once when *done is set, so the host can
+// enqueue iterations in batches and still stop exactly at the reference's iteration.
+__global__ __launch_bounds__(256) void fit_symv_kernel(const double *__restrict__ GD, const double *__restrict__ T,
+                                                       i64 N, double *__restrict__ S, const int *__restrict__ done) {
+    __shared__ double sh[256];
+    if (*done) return;
+    const i64 i = blockIdx.x;
+    const double ti = T[i];
+    const double *row = GD + i * N;
+    double s = 0.0;
+    for (i64 j = threadIdx.x; j < N; j += 256) s += (ti * T[j]) * row[j];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) S[i] = s;
+}
+void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done) {
+    ScopedKernelTimer t(c, "fit_symv");
+    hipLaunchKernelGGL(fit_symv_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, GD, T, N, S, done);
+}
+// T_i += eps*T_i*(w_i/S_i - 1); f = max|w_i - S_i| with the pre-update S (:160-166)
+__global__ __launch_bounds__(1024) void fit_update_kernel(double *__restrict__ T, const double *__restrict__ S,
+                                                          const double *__restrict__ w, i64 N, double eps,
+                                                          double delta, int *__restrict__ done,
+                                                          int *__restrict__ iters, double *__restrict__ fout) {
+    __shared__ double sh[1024];
+    if (*done) return;
+    double f = 0.0;
+    for (i64 i = threadIdx.x; i < N; i += 1024) {
+        const double ti = T[i], si = S[i], wi = w[i];
+        const double move = (eps * ti) * (wi / si - 1.0);
+        T[i] = ti + move;
+        f = fmax(f, fabs(wi - si));
+    }
+    sh[threadIdx.x] = f;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *iters += 1;
+        *fout = sh[0];
+        if (!(sh[0] > delta)) *done = 1; // `while diff > delta`
+    }
+}
+void k_fit_update(cge_ctx *c, double *T, const double *S, const double *w, i64 N, double eps, double delta, int *done,
+                  int *iters, double *fout) {
+    hipLaunchKernelGGL(fit_update_kernel, dim3(1), dim3(1024), 0, c->stream, T, S, w, N, eps, delta, done, iters, fout);
+}
+
+// directed: Sin_i = sum_j (Tin_i*Tout_j)*g_ij + diagonal once more; Sout_i = sum_j (Tin_j*Tout_i)*g_ij + diagonal
+// once more (the reference's i..N inner loop visits j == i and adds both tmp1 and tmp2, :439-449)
+__global__ __launch_bounds__(256) void fit_symv_dir_kernel(const double *__restrict__ GD,
+                                                           const double *__restrict__ Tin,
+                                                           const double *__restrict__ Tout, i64 N,
+                                                           double *__restrict__ Sin, double *__restrict__ Sout,
+                                                           const int *__restrict__ done) {
+    __shared__ double sh[256];
+    if (*done) return;
+    const i64 i = blockIdx.x;
+    const double tin_i = Tin[i], tout_i = Tout[i];
+    const double *row = GD + i * N;
+    double a = 0.0, b = 0.0;
+    for (i64 j = threadIdx.x; j < N; j += 256) {
+        const double g = row[j];
+        double t1 = (tin_i * Tout[j]) * g, t2 = (Tin[j] * tout_i) * g;
+        if (j == i) { t1 += t1; t2 += t2; } // both tmp1 and tmp2 land in Sin[i] and in Sout[i]
+        a += t1;
+        b += t2;
+    }
+    // at j == i the reference adds tmp1 + tmp2 to Sin[i] and tmp2 + tmp1 to Sout[i]; tmp1 == tmp2 there
+    a = block_sum_256(a, sh);
+    b = block_sum_256(b, sh);
+    if (threadIdx.x == 0) { Sin[i] = a; Sout[i] = b; }
+}
+void k_fit_symv_dir(cge_ctx *c, const double *GD, const double *Tin, const double *Tout, i64 N, double *Sin,
+                    double *Sout, const int *done) {
+    ScopedKernelTimer t(c, "fit_symv");
+    hipLaunchKernelGGL(fit_symv_dir_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, GD, Tin, Tout, N, Sin, Sout,
+                       done);
+}
+__global__ __launch_bounds__(1024) void fit_update_dir_kernel(double *__restrict__ Tin, double *__restrict__ Tout,
+                                                              const double *__restrict__ Sin,
+                                                              const double *__restrict__ Sout,
+                                                              const double *__restrict__ deg_in,
+                                                              const double *__restrict__ deg_out, i64 N, double delta,
+                                                              int *__restrict__ done, int *__restrict__ iters,
+                                                              double *__restrict__ state) {
+    __shared__ double sh[1024];
+    if (*done) return;
+    const double eps = state[0];
+    double f = 0.0;
+    for (i64 i = threadIdx.x; i < N; i += 1024) {
+        const double di = deg_in[i], dout = deg_out[i];
+        if (di > 0) {
+            const double t = Tin[i], s = Sin[i];
+            Tin[i] = t + (eps * t) * (di / s - 1.0);
+            f = fmax(f, fabs(di - s));
+        }
+        if (dout > 0) {
+            const double t = Tout[i], s = Sout[i];
+            Tout[i] = t + (eps * t) * (dout / s - 1.0);
+            f = fmax(f, fabs(dout - s));
+        }
+    }
+    sh[threadIdx.x] = f;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double fv = sh[0];
+        if (fv > state[1]) state[0] = eps * 0.99; // :462-464
+        state[1] = fv;
+        *iters += 1;
+        if (!(fv > delta)) *done = 1;
+    }
+}
+void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, const double *Sout,
+                      const double *deg_in, const double *deg_out, i64 N, double delta, int *done, int *iters,
+                      double *state) {
+    hipLaunchKernelGGL(fit_update_dir_kernel, dim3(1), dim3(1024), 0, c->stream, Tin, Tout, Sin, Sout, deg_in,
+                       deg_out, N, delta, done, iters, state);
+}
+
+// ------------------------------------------------------------------------------------------------
+// vect_B.  Stage 1: rowbins[i][c] = sum over the members j of community c (ascending; j >= i when
+// undirected) of (Ta_i*Tb_j)*GD_ij.  Stage 2: sum the rows of each community into the bins.
+__global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
+                                                        const double *__restrict__ Tb,
+                                                        const i32 *__restrict__ cm_off, const i32 *__restrict__ cm_mem,
+                                                        i64 N, i64 C, int directed, double *__restrict__ rowbins) {
+    const i64 i = blockIdx.x;
+    const double ti = Ta[i];
+    const double *row = GD + i * N;
+    for (i64 cc = threadIdx.x; cc < C; cc += 256) {
+        double s = 0.0;
+        const i32 b = cm_off[cc], e = cm_off[cc + 1];
+        for (i32 t = b; t < e; t++) {
+            const i64 j = cm_mem[t];
+            if (directed || j >= i) s += (ti * Tb[j]) * row[j];
+        }
+        rowbins[i * C + cc] = s;
+    }
+}
+__global__ void bvec_bins_kernel(const double *__restrict__ rowbins, const i32 *__restrict__ cm_off,
+                                 const i32 *__restrict__ cm_mem, i64 C, int directed, double *__restrict__ vectB) {
+    const i64 total = C * C, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const i64 c1 = e / C, c2 = e - c1 * C;
+        if (!directed && c2 < c1) continue;
+        double s = 0.0;
+        for (i32 t = cm_off[c1]; t < cm_off[c1 + 1]; t++) s += rowbins[(i64)cm_mem[t] * C + c2];
+        if (!directed && c1 != c2)
+            for (i32 t = cm_off[c2]; t < cm_off[c2 + 1]; t++) s += rowbins[(i64)cm_mem[t] * C + c1];
+        vectB[directed ? e : (C * c1 - c1 * (c1 - 1) / 2 + (c2 - c1))] = s;
+    }
+}
+void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *comm, const i32 *cm_off,
+            const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB) {
+    (void)comm;
+    ScopedKernelTimer t(c, "bvec");
+    hipLaunchKernelGGL(bvec_rows_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off, cm_mem, N, C,
+                       directed, rowbins);
+    hipLaunchKernelGGL(bvec_bins_kernel, dim3(grid_for(C * C, 256)), dim3(256), 0, c->stream, rowbins, cm_off, cm_mem,
+                       C, directed, vectB);
+}
+
+// ------------------------------------------------------------------------------------------------
+// JS divergence with the +1 prior; one workgroup, fixed-order tree reductions.
+// mode 0: all bins; 1: internal (diagonal) bins; 2: external bins.
+__device__ __forceinline__ bool js_selected(i64 k, i64 C, int directed, int mode) {
+    if (mode == 0) return true;
+    bool diag;
+    if (directed)
+        diag = (k % (C + 1)) == 0;
+    else {
+        // packed row c starts at off(c) = C*c - c(c-1)/2; k is diagonal iff k == off(c) for some c
+        const double b = 2.0 * (double)C + 1.0;
+        i64 cc = (i64)((b - sqrt(b * b - 8.0 * (double)k)) * 0.5);
+        if (cc < 0) cc = 0;
+        if (cc > C - 1) cc = C - 1;
+        while (cc > 0 && C * cc - cc * (cc - 1) / 2 > k) cc--;
+        while (cc + 1 < C && C * (cc + 1) - (cc + 1) * cc / 2 <= k) cc++;
+        diag = (C * cc - cc * (cc - 1) / 2) == k;
+    }
+    return mode == 1 ? diag : !diag;
+}
+__global__ __launch_bounds__(256) void js_kernel(const double *__restrict__ vC, const double *__restrict__ vB, i64 len,
+                                                 i64 C, int directed, int mode, double *__restrict__ out) {
+    __shared__ double sh[256];
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (i64 k = threadIdx.x; k < len; k += 256)
+        if (js_selected(k, C, directed, mode)) { s1 += vC[k]; s2 += vB[k]; cnt += 1.0; }
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh);
+    cnt = block_sum_256(cnt, sh);
+    const double sp1 = s1 + cnt, sp2 = s2 + cnt;
+    double f = 0.0;
+    for (i64 k = threadIdx.x; k < len; k += 256)
+        if (js_selected(k, C, directed, mode)) {
+            const double p = (vC[k] + 1.0) / sp1, q = (vB[k] + 1.0) / sp2;
+            const double m = (p + q) / 2.0;
+            f += p * log(p / m) + q * log(q / m);
+        }
+    f = block_sum_256(f, sh);
+    if (threadIdx.x == 0) *out = f / 2.0;
+}
+void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int directed, int mode, double *out) {
+    hipLaunchKernelGGL(js_kernel, dim3(1), dim3(256), 0, c->stream, vC, vB, len, C, directed, mode, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Local score tallies: out2 = { sum_k [pos_k > neg_k] * w_k , sum_k w_k }  (:213 / :517)
+#define AUC_BLOCKS 64
+__global__ __launch_bounds__(256) void auc_landmark_kernel(const double *__restrict__ Ta, const double *__restrict__ Tb,
+                                                           const i32 *__restrict__ v2l,
+                                                           const double *__restrict__ vw_orig,
+                                                           const double *__restrict__ lweight,
+                                                           const i32 *__restrict__ pi, const i32 *__restrict__ pj,
+                                                           const i32 *__restrict__ ni, const i32 *__restrict__ nj,
+                                                           const double *__restrict__ dpos,
+                                                           const double *__restrict__ dneg,
+                                                           const double *__restrict__ wts, i64 S, double alpha,
+                                                           double *__restrict__ part) {
+    __shared__ double sh[256];
+    double num = 0.0, den = 0.0;
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < S; k += (i64)gridDim.x * 256) {
+        const i64 i = pi[k], j = pj[k], u = ni[k], v = nj[k];
+        const i64 li = v2l[i], lj = v2l[j], lu = v2l[u], lv = v2l[v];
+        const double ai = (Ta[li] * vw_orig[i]) / lweight[li], aj = (Tb[lj] * vw_orig[j]) / lweight[lj];
+        const double au = (Ta[lu] * vw_orig[u]) / lweight[lu], av = (Tb[lv] * vw_orig[v]) / lweight[lv];
+        const double pos = (ai * aj) * pow(1.0 - dpos[k], alpha);
+        const double neg = (au * av) * pow(1.0 - dneg[k], alpha);
+        const double w = wts[k];
+        num += (pos > neg ? 1.0 : 0.0) * w;
+        den += w;
+    }
+    num = block_sum_256(num, sh);
+    den = block_sum_256(den, sh);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = num; part[2 * blockIdx.x + 1] = den; }
+}
+__global__ __launch_bounds__(256) void auc_exact_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
+                                                        const double *__restrict__ Tb, i64 N,
+                                                        const i32 *__restrict__ pi, const i32 *__restrict__ pj,
+                                                        const i32 *__restrict__ ni, const i32 *__restrict__ nj,
+                                                        const double *__restrict__ wts, i64 S,
+                                                        double *__restrict__ part) {
+    __shared__ double sh[256];
+    double num = 0.0, den = 0.0;
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < S; k += (i64)gridDim.x * 256) {
+        const i64 i = pi[k], j = pj[k], u = ni[k], v = nj[k];
+        const double pos = (Ta[i] * Tb[j]) * GD[i * N + j];
+        const double neg = (Ta[u] * Tb[v]) * GD[u * N + v];
+        const double w = wts[k];
+        num += (pos > neg ? 1.0 : 0.0) * w;
+        den += w;
+    }
+    num = block_sum_256(num, sh);
+    den = block_sum_256(den, sh);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = num; part[2 * blockIdx.x + 1] = den; }
+}
+__global__ void auc_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ out2) {
+    double num = 0.0, den = 0.0;
+    for (int b = 0; b < nb; b++) { num += part[2 * b]; den += part[2 * b + 1]; }
+    out2[0] = num;
+    out2[1] = den;
+}
+static double *auc_partials(cge_ctx *c) {
+    c->auc_part.ensure(2 * AUC_BLOCKS);
+    return c->auc_part.p;
+}
+void k_auc_landmark(cge_ctx *c, const double *Ta, const double *Tb, const i32 *v2l, const double *vw_orig,
+                    const double *lweight, const i32 *pi, const i32 *pj, const i32 *ni, const i32 *nj,
+                    const double *dpos, const double *dneg, const double *wts, i64 S, double alpha, double *out2) {
+    double *part = auc_partials(c);
+    hipLaunchKernelGGL(auc_landmark_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, Ta, Tb, v2l, vw_orig, lweight,
+                       pi, pj, ni, nj, dpos, dneg, wts, S, alpha, part);
+    hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, c->stream, part, AUC_BLOCKS, out2);
+}
+void k_auc_exact(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, i64 N, const i32 *pi,
+                 const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, double *out2) {
+    double *part = auc_partials(c);
+    hipLaunchKernelGGL(auc_exact_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, GD, Ta, Tb, N, pi, pj, ni, nj, wts,
+                       S, part);
+    hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, c->stream, part, AUC_BLOCKS, out2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sampler support: stream the resident edge list once and flag every candidate pair that IS an
+// edge.  `table` is an open-addressing set of candidate keys ((i << 32) | j, 0-based; i < j when
+// undirected), empty slots = ~0.
+__device__ __forceinline__ uint64_t mixk(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+__global__ void mark_edge_hits_kernel(const i32 *__restrict__ src, const i32 *__restrict__ dst, i64 m, int directed,
+                                      const uint64_t *__restrict__ table, i64 mask, i32 *__restrict__ hit) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += stride) {
+        uint64_t a = (uint64_t)(uint32_t)src[e], b = (uint64_t)(uint32_t)dst[e];
+        if (!directed && a > b) { uint64_t t = a; a = b; b = t; }
+        const uint64_t key = (a << 32) | b;
+        i64 slot = (i64)(mixk(key) & (uint64_t)mask);
+        for (;;) {
+            const uint64_t tk = table[slot];
+            if (tk == ~0ULL) break;
+            if (tk == key) { hit[slot] = 1; break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+void k_mark_edge_hits(cge_ctx *c, const i32 *src, const i32 *dst, i64 m, int directed, const uint64_t *table,
+                      i64 table_size, i32 *hit) {
+    ScopedKernelTimer t(c, "mark_edge_hits");
+    hipLaunchKernelGGL(mark_edge_hits_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, src, dst, m, directed,
+                       table, table_size - 1, hit);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_i32_kernel(const i32 *__restrict__ arr, const i32 *__restrict__ idx, i64 S,
+                                  i32 *__restrict__ out) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < S; k += stride) out[k] = arr[idx[k]];
+}
+void k_gather_i32(cge_ctx *c, const i32 *arr, const i32 *idx, i64 S, i32 *out) {
+    if (S <= 0) return;
+    hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(S, 256)), dim3(256), 0, c->stream, arr, idx, S, out);
+}

@@ -1,0 +1,453 @@
+// kernels_lm.hip -- layout conversion, landmark split primitives, landmark aggregation and the
+// per-edge scatter.  gfx950, wave = 64.
+//
+// Reference loops replaced here:
+//   group mean / covariance / projection : matrix_w_mean, y'y, y*v   src/landmarks.jl:71-81, :97-99 (=:160-162,...)
+//   landmark aggregation                : src/landmarks.jl:387-430
+//   per-edge scatter                    : src/landmarks.jl:433-451, src/divergence.jl:59-63, :337-345
+#include "common.hpp"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// column-major (n x d, Julia) -> row-major (node-major).  32x32 tiles through LDS.
+__global__ void transpose_kernel(const double *__restrict__ Xcol, double *__restrict__ Xrow, i64 n, i64 d) {
+    __shared__ double tile[32][33];
+    i64 i0 = (i64)blockIdx.x * 32, k0 = (i64)blockIdx.y * 32;
+    int tx = threadIdx.x, ty = threadIdx.y; // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        i64 i = i0 + tx, k = k0 + r;
+        if (i < n && k < d) tile[r][tx] = Xcol[i + k * n];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        i64 i = i0 + r, k = k0 + tx;
+        if (i < n && k < d) Xrow[i * d + k] = tile[tx][r];
+    }
+}
+void k_transpose_to_rowmajor(cge_ctx *c, const double *Xcol, double *Xrow, i64 n, i64 d) {
+    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((d + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, c->stream, Xcol, Xrow, n, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Global mean (any centre is valid: distances are translation invariant), then the centred
+// feature-major copy Xc[k*n + i] and squared row norms for the diameter kernel.
+__global__ void colsum_partial_kernel(const double *__restrict__ Xrow, i64 n, i64 d, double *__restrict__ part) {
+    // block b sums rows b, b+G, ...; thread t handles columns t, t+256, ...
+    for (i64 k = threadIdx.x; k < d; k += blockDim.x) {
+        double s = 0.0;
+        for (i64 i = blockIdx.x; i < n; i += gridDim.x) s += Xrow[i * d + k];
+        part[(i64)blockIdx.x * d + k] = s;
+    }
+}
+__global__ void colsum_final_kernel(const double *__restrict__ part, i64 nb, i64 n, i64 d, double *__restrict__ mean) {
+    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= d) return;
+    double s = 0.0;
+    for (i64 b = 0; b < nb; b++) s += part[b * d + k];
+    mean[k] = s / (double)n;
+}
+__global__ void centre_kernel(const double *__restrict__ Xrow, const double *__restrict__ mean, double *__restrict__ Xc,
+                              i64 n, i64 d, i64 ldn) {
+    __shared__ double tile[32][33];
+    i64 i0 = (i64)blockIdx.x * 32, k0 = (i64)blockIdx.y * 32;
+    int tx = threadIdx.x, ty = threadIdx.y;
+    for (int r = ty; r < 32; r += 8) {
+        i64 i = i0 + r, k = k0 + tx;
+        if (i < n && k < d) tile[r][tx] = Xrow[i * d + k] - mean[k];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        i64 i = i0 + tx, k = k0 + r;
+        if (i < n && k < d) Xc[k * ldn + i] = tile[tx][r];
+    }
+}
+__global__ void rownorm_kernel(const double *__restrict__ Xc, i64 n, i64 d, i64 ldn, double *__restrict__ rnorm) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (i64 k = 0; k < d; k++) {
+        double v = Xc[k * ldn + i];
+        s += v * v;
+    }
+    rnorm[i] = s;
+}
+void k_centre_featuremajor(cge_ctx *c, const double *Xrow, double *Xc, double *rnorm, i64 n, i64 d, i64 ldn, i64 dpad) {
+    const int NB = 512;
+    DevBuf<double> part, mean;
+    part.ensure((size_t)NB * d);
+    mean.ensure((size_t)d);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(NB), dim3(256), 0, c->stream, Xrow, n, d, part.p);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, c->stream, part.p,
+                       (i64)NB, n, d, mean.p);
+    HIP_CHECK(hipMemsetAsync(Xc, 0, sizeof(double) * (size_t)(ldn * dpad), c->stream));
+    HIP_CHECK(hipMemsetAsync(rnorm, 0, sizeof(double) * (size_t)ldn, c->stream));
+    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((d + 31) / 32));
+    hipLaunchKernelGGL(centre_kernel, grid, dim3(32, 8), 0, c->stream, Xrow, mean.p, Xc, n, d, ldn);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, Xc, n, d, ldn, rnorm);
+    HIP_CHECK(hipStreamSynchronize(c->stream)); // part/mean are freed on return
+}
+
+// ------------------------------------------------------------------------------------------------
+// 64-bit hash of each row's bit pattern (for the `unique(embedding, dims=1)` clamp, src/landmarks.jl:371).
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+__global__ void row_hash_kernel(const double *__restrict__ Xrow, uint64_t *__restrict__ hash, i64 n, i64 d) {
+    i64 row = ((i64)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    int lane = threadIdx.x & (WAVE - 1);
+    if (row >= n) return;
+    const uint64_t *p = reinterpret_cast<const uint64_t *>(Xrow + row * d);
+    uint64_t h = 0;
+    for (i64 k = lane; k < d; k += WAVE) h += mix64(p[k] ^ (0x9e3779b97f4a7c15ULL * (uint64_t)(k + 1)));
+    for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
+    if (lane == 0) hash[row] = mix64(h);
+}
+void k_row_hash(cge_ctx *c, const double *Xrow, uint64_t *hash, i64 n, i64 d) {
+    i64 threads = n * WAVE;
+    hipLaunchKernelGGL(row_hash_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, Xrow, hash,
+                       n, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched group statistics.  A batch is a list of tasks (groups); `rows` holds their 0-based
+// vertex ids back to back; a task is cut into chunks of rows so that big groups use many CUs;
+// chunk partials are combined in chunk order (fixed order => reproducible).
+#define MAXSLOT 16 // columns handled per lane: d <= 64*MAXSLOT = 1024
+
+__global__ __launch_bounds__(256) void group_mean_partial_kernel(const double *__restrict__ Xr,
+                                                                 const double *__restrict__ vw,
+                                                                 const i32 *__restrict__ rows,
+                                                                 const i32 *__restrict__ chunk_beg,
+                                                                 const i32 *__restrict__ chunk_end, i64 d,
+                                                                 double *__restrict__ part /* [chunk][d+1] */) {
+    __shared__ double red[4][WAVE * 4 + 1]; // reused per slot group
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const i64 ch = blockIdx.x;
+    const i32 beg = chunk_beg[ch], end = chunk_end[ch];
+    double acc[MAXSLOT];
+#pragma unroll
+    for (int s = 0; s < MAXSLOT; s++) acc[s] = 0.0;
+    double wsum = 0.0;
+    for (i32 j = beg + wave; j < end; j += 4) {
+        const i64 v = rows[j];
+        const double w = vw[v];
+        wsum += w;
+        const double *x = Xr + v * d;
+#pragma unroll
+        for (int s = 0; s < MAXSLOT; s++) {
+            i64 col = lane + 64 * s;
+            if (col < d) acc[s] += x[col] * w;
+        }
+    }
+    double *out = part + ch * (d + 1);
+    // combine the 4 waves in wave order
+    for (int s0 = 0; s0 < MAXSLOT; s0 += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; s++) red[wave][lane * 4 + s] = acc[s0 + s];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                i64 col = lane + 64 * (s0 + s);
+                if (col < d) out[col] = ((red[0][lane * 4 + s] + red[1][lane * 4 + s]) + red[2][lane * 4 + s]) +
+                                        red[3][lane * 4 + s];
+            }
+        }
+        if ((i64)64 * (s0 + 4) >= d) break;
+    }
+    __syncthreads();
+    if (lane == 0) red[wave][0] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) out[d] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+}
+__global__ void group_mean_final_kernel(const double *__restrict__ part, const i32 *__restrict__ task_chunk_off, i64 d,
+                                        double *__restrict__ mean, double *__restrict__ sw) {
+    const i64 t = blockIdx.x;
+    const i32 c0 = task_chunk_off[t], c1 = task_chunk_off[t + 1];
+    double wt = 0.0;
+    for (i32 ch = c0; ch < c1; ch++) wt += part[(i64)ch * (d + 1) + d];
+    for (i64 col = threadIdx.x; col < d; col += blockDim.x) {
+        double s = 0.0;
+        for (i32 ch = c0; ch < c1; ch++) s += part[(i64)ch * (d + 1) + col];
+        mean[t * d + col] = s / wt;
+    }
+    if (threadIdx.x == 0) sw[t] = wt;
+}
+void k_group_mean(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
+                  const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
+                  i64 d, double *part, double *mean, double *sw) {
+    (void)chunk_task;
+    if (d > 64 * MAXSLOT) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * MAXSLOT);
+    hipLaunchKernelGGL(group_mean_partial_kernel, dim3((unsigned)n_chunks), dim3(256), 0, c->stream, Xr, vw, rows,
+                       chunk_beg, chunk_end, d, part);
+    hipLaunchKernelGGL(group_mean_final_kernel, dim3((unsigned)n_tasks), dim3(256), 0, c->stream, part,
+                       task_chunk_off, d, mean, sw);
+}
+
+// covariance A = sum_j w_j (x_j - mu)(x_j - mu)^T, per chunk then per task.
+// Thread tiles of TS x TS accumulators over an LDS tile of centred, sqrt(w)-scaled rows.
+template <int TS>
+__global__ __launch_bounds__(256) void group_cov_partial_kernel(const double *__restrict__ Xr,
+                                                                const double *__restrict__ vw,
+                                                                const i32 *__restrict__ rows,
+                                                                const i32 *__restrict__ chunk_task,
+                                                                const i32 *__restrict__ chunk_beg,
+                                                                const i32 *__restrict__ chunk_end, i64 d, int dp,
+                                                                int RT, const double *__restrict__ mean,
+                                                                double *__restrict__ part /* [chunk][d*d] */) {
+    extern __shared__ __attribute__((aligned(16))) double ytile[]; // RT x (dp + 2)
+    const int ld = dp + 2;
+    const i64 ch = blockIdx.x;
+    const i32 beg = chunk_beg[ch], end = chunk_end[ch];
+    const double *mu = mean + (i64)chunk_task[ch] * d;
+    const int nt = dp / TS;          // tiles per dimension
+    const int ntiles = nt * nt;
+    double *out = part + ch * d * d;
+    for (int tbase = 0; tbase < ntiles; tbase += 256) {
+        const int tile = tbase + threadIdx.x;
+        const bool active = tile < ntiles;
+        const int ta = active ? (tile / nt) * TS : 0, tb = active ? (tile % nt) * TS : 0;
+        double acc[TS][TS];
+#pragma unroll
+        for (int a = 0; a < TS; a++)
+#pragma unroll
+            for (int b = 0; b < TS; b++) acc[a][b] = 0.0;
+        for (i32 j0 = beg; j0 < end; j0 += RT) {
+            const int nr = min(RT, end - j0);
+            __syncthreads();
+            for (int e = threadIdx.x; e < nr * dp; e += 256) {
+                const int r = e / dp, col = e - r * dp;
+                const i64 v = rows[j0 + r];
+                double val = 0.0;
+                if (col < d) val = (Xr[v * d + col] - mu[col]) * sqrt(vw[v]);
+                ytile[r * ld + col] = val;
+            }
+            __syncthreads();
+            if (active) {
+                for (int r = 0; r < nr; r++) {
+                    double ya[TS], yb[TS];
+#pragma unroll
+                    for (int a = 0; a < TS; a++) ya[a] = ytile[r * ld + ta + a];
+#pragma unroll
+                    for (int b = 0; b < TS; b++) yb[b] = ytile[r * ld + tb + b];
+#pragma unroll
+                    for (int a = 0; a < TS; a++)
+#pragma unroll
+                        for (int b = 0; b < TS; b++) acc[a][b] = fma(ya[a], yb[b], acc[a][b]);
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int a = 0; a < TS; a++)
+#pragma unroll
+                for (int b = 0; b < TS; b++)
+                    if (ta + a < d && tb + b < d) out[(i64)(ta + a) * d + (tb + b)] = acc[a][b];
+        }
+    }
+}
+__global__ void group_cov_final_kernel(const double *__restrict__ part, const i32 *__restrict__ task_chunk_off, i64 dd,
+                                       double *__restrict__ cov) {
+    const i64 t = blockIdx.y;
+    const i32 c0 = task_chunk_off[t], c1 = task_chunk_off[t + 1];
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < dd; e += (i64)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (i32 ch = c0; ch < c1; ch++) s += part[(i64)ch * dd + e];
+        cov[t * dd + e] = s;
+    }
+}
+void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
+                 const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
+                 i64 d, const double *mean, double *part, double *cov) {
+    const int dp = (int)((d + 7) / 8 * 8);
+    int RT = 64;
+    while ((size_t)RT * (dp + 2) * sizeof(double) > 64 * 1024 && RT > 4) RT /= 2;
+    const size_t lds = (size_t)RT * (dp + 2) * sizeof(double);
+    dim3 grid((unsigned)n_chunks), block(256);
+    if (dp >= 128)
+        hipLaunchKernelGGL(group_cov_partial_kernel<8>, grid, block, lds, c->stream, Xr, vw, rows, chunk_task,
+                           chunk_beg, chunk_end, d, dp, RT, mean, part);
+    else if (dp >= 64)
+        hipLaunchKernelGGL(group_cov_partial_kernel<4>, grid, block, lds, c->stream, Xr, vw, rows, chunk_task,
+                           chunk_beg, chunk_end, d, dp, RT, mean, part);
+    else
+        hipLaunchKernelGGL(group_cov_partial_kernel<2>, grid, block, lds, c->stream, Xr, vw, rows, chunk_task,
+                           chunk_beg, chunk_end, d, dp, RT, mean, part);
+    const i64 dd = d * d;
+    dim3 g2((unsigned)std::min<i64>((dd + 255) / 256, 64), (unsigned)n_tasks);
+    hipLaunchKernelGGL(group_cov_final_kernel, g2, dim3(256), 0, c->stream, part, task_chunk_off, dd, cov);
+}
+
+// projection z_j = sum_c ((x_jc - mu_c) * sqrt(w_j)) * v_c ; one wave per row
+__global__ void group_project_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                     const i32 *__restrict__ rows, const i32 *__restrict__ row_task, i64 n_rows, i64 d,
+                                     const double *__restrict__ mean, const double *__restrict__ vec,
+                                     double *__restrict__ z) {
+    const i64 j = ((i64)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & 63;
+    if (j >= n_rows) return;
+    const i64 v = rows[j];
+    const i64 t = row_task[j];
+    const double sq = sqrt(vw[v]);
+    const double *x = Xr + v * d, *mu = mean + t * d, *ev = vec + t * d;
+    double s = 0.0;
+    for (i64 col = lane; col < d; col += WAVE) s = fma((x[col] - mu[col]) * sq, ev[col], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) z[j] = s;
+}
+void k_group_project(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *row_task, i64 n_rows,
+                     i64 d, const double *mean, const double *vec, double *z) {
+    i64 threads = n_rows * WAVE;
+    hipLaunchKernelGGL(group_project_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, Xr, vw,
+                       rows, row_task, n_rows, d, mean, vec, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Landmark aggregation, one workgroup per landmark, members in ascending vertex order so every
+// sum runs in the reference's order (src/landmarks.jl:391-397, :408-415) with unfused mul/add.
+__global__ __launch_bounds__(256) void landmark_aggregate_kernel(const double *__restrict__ Xr,
+                                                                 const double *__restrict__ vw,
+                                                                 const i32 *__restrict__ comm,
+                                                                 const i32 *__restrict__ mem_off,
+                                                                 const i32 *__restrict__ mem, i64 d,
+                                                                 double *__restrict__ lemb,
+                                                                 double *__restrict__ lweight,
+                                                                 double *__restrict__ dii, i32 *__restrict__ lcomm) {
+    extern __shared__ __attribute__((aligned(16))) double sh[]; // centroid[d] + buf[256]
+    double *cen = sh, *buf = sh + d;
+    const i64 l = blockIdx.x;
+    const i32 b = mem_off[l], e = mem_off[l + 1];
+    double lw = 0.0;
+    for (i32 t = b; t < e; t++) lw = __dadd_rn(lw, vw[mem[t]]);
+    for (i64 col = threadIdx.x; col < d; col += blockDim.x) {
+        double acc = 0.0;
+        for (i32 t = b; t < e; t++) {
+            const i64 v = mem[t];
+            acc = __dadd_rn(acc, __dmul_rn(vw[v], Xr[v * d + col]));
+        }
+        const double cv = acc / lw; // :402
+        cen[col] = cv;
+        lemb[l * d + col] = cv;
+    }
+    __syncthreads();
+    double tot = 0.0; // meaningful in thread 0
+    for (i32 base = b; base < e; base += 256) {
+        const i32 t = base + (i32)threadIdx.x;
+        if (t < e) {
+            const double *x = Xr + (i64)mem[t] * d;
+            double dist = 0.0;
+            for (i64 col = 0; col < d; col++) {
+                const double df = __dsub_rn(cen[col], x[col]);
+                dist = __dadd_rn(dist, __dmul_rn(df, df));
+            }
+            buf[threadIdx.x] = dist;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = min(256, e - base);
+            for (int q = 0; q < cnt; q++) tot = __dadd_rn(tot, buf[q]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        lweight[l] = lw;
+        dii[l] = lw > 0 ? sqrt(tot / lw) : tot; // :418-423
+        lcomm[l] = (e > b) ? comm[mem[e - 1]] : 0; // last writer wins (:427-429)
+    }
+}
+void k_landmark_aggregate(cge_ctx *c, const double *Xr, const double *vw, const i32 *comm, const i32 *mem_off,
+                          const i32 *mem, i64 N, i64 d, double *lemb, double *lweight, double *dii, i32 *lcomm) {
+    size_t lds = (size_t)(d + 256) * sizeof(double);
+    hipLaunchKernelGGL(landmark_aggregate_kernel, dim3((unsigned)N), dim3(256), lds, c->stream, Xr, vw, comm, mem_off,
+                       mem, d, lemb, lweight, dii, lcomm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-edge scatter: wedges[min(lu,lv), max(lu,lv)] += w  and  vect_C[bin(c_u,c_v)] += w.
+// Coalesced SoA reads of (src,dst,w); v2l/comm gathers are served by L2.  Community-pair bins on
+// the diagonal (the bulk of the edges of a graph with community structure) are pre-aggregated in
+// LDS; everything else goes out as no-return f64 atomics (exact for unit weights).
+__global__ __launch_bounds__(256) void edge_scatter_kernel(const i32 *__restrict__ src, const i32 *__restrict__ dst,
+                                                           const double *__restrict__ w, i64 e0, i64 e1,
+                                                           const i32 *__restrict__ v2l, const i32 *__restrict__ comm,
+                                                           i64 N, i64 C, int directed, double *__restrict__ wedges,
+                                                           double *__restrict__ vectC) {
+    extern __shared__ __attribute__((aligned(16))) double cdiag[]; // C diagonal bins
+    for (i64 k = threadIdx.x; k < C; k += blockDim.x) cdiag[k] = 0.0;
+    __syncthreads();
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = e0 + (i64)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += stride) {
+        const i32 u = src[e], v = dst[e];
+        const double we = w ? w[e] : 1.0;
+        i64 a = v2l[u], b = v2l[v];
+        i64 cu = comm[u], cv = comm[v];
+        if (!directed) {
+            if (a > b) { i64 t = a; a = b; b = t; }
+            if (cu > cv) { i64 t = cu; cu = cv; cv = t; }
+        }
+        if (wedges) unsafeAtomicAdd(&wedges[a * N + b], we);
+        if (vectC) {
+            if (cu == cv)
+                unsafeAtomicAdd(&cdiag[cu], we); // LDS atomic
+            else
+                unsafeAtomicAdd(&vectC[directed ? cu * C + cv : (C * cu - cu * (cu - 1) / 2 + (cv - cu))], we);
+        }
+    }
+    __syncthreads();
+    if (vectC)
+        for (i64 k = threadIdx.x; k < C; k += blockDim.x) {
+            const double s = cdiag[k];
+            if (s != 0.0) unsafeAtomicAdd(&vectC[directed ? k * C + k : (C * k - k * (k - 1) / 2)], s);
+        }
+}
+void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 e0, i64 e1, const i32 *v2l,
+                    const i32 *comm, i64 N, i64 C, int directed, double *wedges, double *vectC) {
+    if (e1 <= e0) return;
+    ScopedKernelTimer t(c, "edge_scatter");
+    const unsigned grid = grid_for(e1 - e0, 256, 256 * 8);
+    hipLaunchKernelGGL(edge_scatter_kernel, dim3(grid), dim3(256), (size_t)C * sizeof(double), c->stream, src, dst, w,
+                       e0, e1, v2l, comm, N, C, directed, wedges, vectC);
+}
+
+__global__ void edge_degrees_kernel(const i32 *__restrict__ src, const i32 *__restrict__ dst,
+                                    const double *__restrict__ w, i64 m, double *__restrict__ deg_out,
+                                    double *__restrict__ deg_in, i32 *__restrict__ star) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += stride) {
+        const double we = w ? w[e] : 1.0;
+        unsafeAtomicAdd(&deg_out[src[e]], we);
+        unsafeAtomicAdd(&deg_in[dst[e]], we);
+        if (star) {
+            atomicAdd(&star[src[e]], 1);
+            atomicAdd(&star[dst[e]], 1);
+        }
+    }
+}
+void k_edge_degrees(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 m, double *deg_out,
+                    double *deg_in, i32 *star) {
+    hipLaunchKernelGGL(edge_degrees_kernel, dim3(grid_for(m, 256)), dim3(256), 0, c->stream, src, dst, w, m, deg_out,
+                       deg_in, star);
+}
+
+__global__ void compact_count_kernel(const double *__restrict__ wedges, i64 N, int directed,
+                                     unsigned long long *__restrict__ count) {
+    const i64 total = N * N, stride = (i64)gridDim.x * blockDim.x;
+    unsigned long long local = 0;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const i64 a = e / N, b = e - a * N;
+        if ((directed || b >= a) && wedges[e] > 0) local++;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+void k_compact_count(cge_ctx *c, const double *wedges, i64 N, int directed, i64 *count) {
+    HIP_CHECK(hipMemsetAsync(count, 0, sizeof(i64), c->stream));
+    hipLaunchKernelGGL(compact_count_kernel, dim3(grid_for(N * N, 256)), dim3(256), 0, c->stream, wedges, N, directed,
+                       reinterpret_cast<unsigned long long *>(count));
+}

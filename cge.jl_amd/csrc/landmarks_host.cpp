@@ -1,0 +1,709 @@
+// landmarks_host.cpp -- runsplit() for the MI355X build (reference: src/landmarks.jl:279-345).
+//
+// Split of work:
+//   device : per-group weighted mean, covariance y'y (O(|c| d^2)) and projection z = y v, batched over
+//            many groups per launch (kernels_lm.hip);
+//   host   : the heap (bit-for-bit the reference's sift rules, :12-46), the principal eigenvector of
+//            each d x d covariance (Householder tridiagonalisation + bisection + inverse iteration), the
+//            1-D cut rules (:92-267) and the children's RSS, on a worker pool.
+// The reference splits strictly one group at a time.  Here the groups that the heap is about to pop
+// are split speculatively in one batch and the heap is then REPLAYED in the reference's order from
+// the cached results, so ids (= positions in the heap array, :337-342) come out identical while the
+// device sees hundreds of groups per launch.
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <deque>
+#include <memory>
+#include <thread>
+
+#include "common.hpp"
+
+namespace {
+
+struct Group {
+    std::vector<i64> what; // 1-based vertex ids, in the reference's order
+    double value = 0.0;    // heap key: -total_rss, or eps() for singletons
+    bool has_split = false;
+    int rc = CGE_OK;
+    std::vector<i64> low, high; // children (vertex ids)
+    double vlow = 0.0, vhigh = 0.0;
+};
+
+// 1-based binary min-heap on value with the reference's exact sift rules (src/landmarks.jl:12-46)
+struct Heap {
+    std::vector<Group *> a{nullptr};
+    size_t len() const { return a.size() - 1; }
+    void put(Group *g) {
+        a.push_back(g);
+        size_t i = a.size() - 1, j;
+        const double value = g->value;
+        while ((j = i / 2) >= 1) {
+            if (value < a[j]->value) {
+                a[i] = a[j];
+                i = j;
+            } else
+                break;
+        }
+        a[i] = g;
+    }
+    Group *pop() {
+        Group *x = a[1];
+        Group *y = a.back();
+        a.pop_back();
+        const size_t n = a.size() - 1;
+        if (n > 0) {
+            size_t i = 1, l;
+            while ((l = 2 * i) <= n) {
+                const size_t r = l + 1;
+                const size_t j = (r > n || a[l]->value < a[r]->value) ? l : r;
+                if (a[j]->value < y->value) {
+                    a[i] = a[j];
+                    i = j;
+                } else
+                    break;
+            }
+            a[i] = y;
+        }
+        return x;
+    }
+    Group *top() const { return a[1]; }
+};
+
+template <typename F>
+void parallel_for(int n_threads, i64 n, F &&fn) {
+    if (n <= 0) return;
+    const int nt = (int)std::min<i64>(std::max(1, n_threads), n);
+    if (nt == 1) {
+        for (i64 i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::atomic<i64> next{0};
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&]() {
+            for (;;) {
+                const i64 i = next.fetch_add(1);
+                if (i >= n) break;
+                fn(i);
+            }
+        });
+    for (auto &t : th) t.join();
+}
+
+struct Wsse {
+    double ss = 0, s = 0, ws = 0;
+};
+inline double wsse_val(const Wsse &x) { return x.ss - x.s * x.s / x.ws; }
+inline double sum_wsse(const std::vector<Wsse> &r) {
+    double t = 0.0;
+    for (const auto &x : r) t += wsse_val(x);
+    return t;
+}
+
+// View of one group on the host mirror (row-major rows, weights)
+struct HView {
+    const double *X; // n x d row-major
+    const double *w;
+    i64 d;
+    const i64 *what; // 1-based
+    i64 k;
+    const double *row(i64 j) const { return X + (what[j] - 1) * d; }
+    double wt(i64 j) const { return w[what[j] - 1]; }
+};
+
+// total_rss(m, w): src/landmarks.jl:269 + :56-61; per column the terms are added in member order
+double total_rss(const HView &v, const std::vector<i64> &members_local, bool all) {
+    const i64 d = v.d, cnt = all ? v.k : (i64)members_local.size();
+    std::vector<double> ss(d, 0.0), s(d, 0.0);
+    double ws = 0.0;
+    for (i64 t = 0; t < cnt; t++) {
+        const i64 j = all ? t : members_local[t];
+        const double *x = v.row(j);
+        const double w = v.wt(j);
+        ws += w;
+        for (i64 c = 0; c < d; c++) {
+            ss[c] += w * (x[c] * x[c]);
+            s[c] += w * x[c];
+        }
+    }
+    double tot = 0.0;
+    for (i64 c = 0; c < d; c++) tot += ss[c] - s[c] * s[c] / ws;
+    return tot;
+}
+
+// out[c] = base[c] + WSSE(rows sel)
+void add_wsse_set(const HView &v, const std::vector<Wsse> &base, const std::vector<i64> &sel, std::vector<Wsse> &out) {
+    const i64 d = v.d;
+    std::vector<double> ss(d, 0.0), s(d, 0.0);
+    double ws = 0.0;
+    for (i64 j : sel) {
+        const double *x = v.row(j);
+        const double w = v.wt(j);
+        ws += w;
+        for (i64 c = 0; c < d; c++) {
+            ss[c] += w * (x[c] * x[c]);
+            s[c] += w * x[c];
+        }
+    }
+    for (i64 c = 0; c < d; c++) {
+        out[c].ss = base[c].ss + ss[c];
+        out[c].s = base[c].s + s[c];
+        out[c].ws = base[c].ws + ws;
+    }
+}
+
+// Statistics.median: middle of the sorted values, even length -> x/2 + y/2
+double median_sel(const double *z, const std::vector<i64> *sel, i64 k, std::vector<double> &scr) {
+    const i64 cnt = sel ? (i64)sel->size() : k;
+    scr.resize(cnt);
+    for (i64 i = 0; i < cnt; i++) scr[i] = sel ? z[(*sel)[i]] : z[i];
+    const i64 mid = cnt / 2;
+    std::nth_element(scr.begin(), scr.begin() + mid, scr.end());
+    const double hi = scr[mid];
+    if (cnt & 1) return hi;
+    const double lo = *std::max_element(scr.begin(), scr.begin() + mid);
+    return lo / 2.0 + hi / 2.0;
+}
+
+// split_cluster_rss: src/landmarks.jl:155-210 (z given)
+int rule_rss(const HView &v, const double *z, std::vector<i64> &low, std::vector<i64> &high) {
+    const i64 k = v.k, d = v.d;
+    i64 imin = 0, imax = 0;
+    for (i64 j = 1; j < k; j++) {
+        if (z[j] < z[imin]) imin = j;
+        if (z[j] > z[imax]) imax = j;
+    }
+    if (imin == imax) return CGE_E_HOMOGENEOUS;
+    low.assign(1, imin);
+    high.assign(1, imax);
+    std::vector<i64> gray, t1, t2;
+    gray.reserve(k);
+    for (i64 j = 0; j < k; j++)
+        if (j != imin && j != imax) gray.push_back(j);
+    std::vector<Wsse> rl(d), rh(d), rlt(d), rht(d);
+    {
+        const double *x1 = v.row(imin), *x2 = v.row(imax);
+        const double w1 = v.wt(imin), w2 = v.wt(imax);
+        for (i64 c = 0; c < d; c++) {
+            rl[c] = {x1[c] * x1[c] * w1, x1[c] * w1, w1};
+            rh[c] = {x2[c] * x2[c] * w2, x2[c] * w2, w2};
+        }
+    }
+    std::vector<double> scr;
+    double med = median_sel(z, nullptr, k, scr);
+    for (;;) {
+        t1.clear();
+        t2.clear();
+        for (i64 j : gray) (z[j] < med ? t1 : t2).push_back(j);
+        add_wsse_set(v, rl, t1, rlt);
+        add_wsse_set(v, rh, t2, rht);
+        if (sum_wsse(rlt) < sum_wsse(rht)) {
+            if (t1.empty()) break;
+            rl = rlt;
+            low.insert(low.end(), t1.begin(), t1.end());
+            gray = t2;
+        } else {
+            if (t2.empty()) break;
+            rh = rht;
+            high.insert(high.end(), t2.begin(), t2.end());
+            gray = t1;
+        }
+        if (gray.empty()) break;
+        med = median_sel(z, &gray, k, scr);
+    }
+    if (!gray.empty()) {
+        add_wsse_set(v, rl, gray, rlt);
+        add_wsse_set(v, rh, gray, rht);
+        const double a = std::max(sum_wsse(rlt), sum_wsse(rh)), b = std::max(sum_wsse(rl), sum_wsse(rht));
+        auto &dst = (a < b) ? low : high;
+        dst.insert(dst.end(), gray.begin(), gray.end());
+    }
+    return CGE_OK;
+}
+
+// split_cluster_rss2: src/landmarks.jl:92-147 (z given)
+int rule_rss2(const HView &v, const double *z, std::vector<i64> &low, std::vector<i64> &high) {
+    const i64 k = v.k, d = v.d;
+    std::vector<i64> p(k);
+    for (i64 i = 0; i < k; i++) p[i] = i;
+    std::stable_sort(p.begin(), p.end(), [&](i64 a, i64 b) { return z[a] < z[b]; });
+    auto one = [&](i64 j, i64 c) {
+        const double x = v.row(j)[c], w = v.wt(j);
+        return Wsse{w * (x * x), w * x, w};
+    };
+    std::vector<Wsse> rl(d), rh(d), rlt(d), rht(d);
+    for (i64 c = 0; c < d; c++) {
+        rl[c] = one(p[0], c);
+        rh[c] = one(p[k - 1], c);
+    }
+    i64 lo = 0, hi = k - 1;
+    while (lo + 1 < hi) {
+        if (sum_wsse(rl) < sum_wsse(rh)) {
+            lo++;
+            for (i64 c = 0; c < d; c++) {
+                const Wsse a = one(p[lo], c);
+                rl[c].ss += a.ss; rl[c].s += a.s; rl[c].ws += a.ws;
+            }
+        } else {
+            hi--;
+            for (i64 c = 0; c < d; c++) {
+                const Wsse a = one(p[hi], c);
+                rh[c].ss += a.ss; rh[c].s += a.s; rh[c].ws += a.ws;
+            }
+        }
+    }
+    bool moved_low = false;
+    while (lo > 0) {
+        for (i64 c = 0; c < d; c++) {
+            const Wsse a = one(p[lo], c);
+            rlt[c] = {rl[c].ss - a.ss, rl[c].s - a.s, rl[c].ws - a.ws};
+            rht[c] = {rh[c].ss + a.ss, rh[c].s + a.s, rh[c].ws + a.ws};
+        }
+        if (std::max(sum_wsse(rlt), sum_wsse(rht)) < std::max(sum_wsse(rl), sum_wsse(rh))) {
+            moved_low = true;
+            lo--; hi--;
+            rl = rlt; rh = rht;
+        } else
+            break;
+    }
+    if (!moved_low)
+        while (hi < k - 1) {
+            for (i64 c = 0; c < d; c++) {
+                const Wsse a = one(p[hi], c);
+                rlt[c] = {rl[c].ss + a.ss, rl[c].s + a.s, rl[c].ws + a.ws};
+                rht[c] = {rh[c].ss - a.ss, rh[c].s - a.s, rh[c].ws - a.ws};
+            }
+            if (std::max(sum_wsse(rlt), sum_wsse(rht)) < std::max(sum_wsse(rl), sum_wsse(rh))) {
+                lo++; hi++;
+                rl = rlt; rh = rht;
+            } else
+                break;
+        }
+    low.assign(p.begin(), p.begin() + lo + 1);
+    high.assign(p.begin() + hi, p.end());
+    return CGE_OK;
+}
+
+// split_cluster_size (:218-238) / split_cluster_diameter (:247-267) (z given)
+int rule_cut(const double *z, i64 k, bool use_median, std::vector<i64> &low, std::vector<i64> &high) {
+    double cut;
+    if (use_median) {
+        std::vector<double> scr;
+        cut = median_sel(z, nullptr, k, scr);
+    } else {
+        double lo = z[0], hi = z[0];
+        for (i64 j = 1; j < k; j++) {
+            lo = std::min(lo, z[j]);
+            hi = std::max(hi, z[j]);
+        }
+        cut = (lo + hi) / 2.0;
+    }
+    low.clear();
+    high.clear();
+    for (i64 j = 0; j < k; j++) {
+        if (z[j] == cut)
+            (low.size() < high.size() ? low : high).push_back(j);
+        else
+            (z[j] < cut ? low : high).push_back(j);
+    }
+    return CGE_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Principal eigenvector of a symmetric d x d matrix: Householder tridiagonalisation, bisection for
+// the largest eigenvalue, inverse iteration, back-transformation.  Replaces `eigvecs(A)[:, end]`
+// (src/landmarks.jl:99 etc.).  Sign convention: the component of largest magnitude is positive.
+void host_eig_top(const double *Ain, i64 d, double *vout) {
+    if (d == 1) { vout[0] = 1.0; return; }
+    std::vector<double> A(Ain, Ain + d * d);
+    std::vector<double> diag(d), off(d, 0.0), beta(d, 0.0), p(d), vv(d);
+    for (i64 k = 0; k + 2 < d; k++) {
+        const i64 r = d - k - 1; // trailing size
+        double *xcol = &vv[0];   // x = A[k+1.., k]
+        for (i64 i = 0; i < r; i++) xcol[i] = A[(k + 1 + i) * d + k];
+        const double alpha = xcol[0];
+        double sigma = 0.0;
+        for (i64 i = 1; i < r; i++) sigma += xcol[i] * xcol[i];
+        if (sigma == 0.0) {
+            beta[k] = 0.0;
+            off[k] = alpha;
+            continue;
+        }
+        const double mu = std::sqrt(alpha * alpha + sigma);
+        const double v0 = (alpha <= 0.0) ? alpha - mu : -sigma / (alpha + mu);
+        const double bk = 2.0 * v0 * v0 / (sigma + v0 * v0);
+        xcol[0] = 1.0;
+        for (i64 i = 1; i < r; i++) xcol[i] /= v0;
+        beta[k] = bk;
+        off[k] = mu;
+        // p = beta * B v, B = A[k+1.., k+1..]
+        for (i64 i = 0; i < r; i++) {
+            const double *Bi = &A[(k + 1 + i) * d + (k + 1)];
+            double s = 0.0;
+            for (i64 j = 0; j < r; j++) s += Bi[j] * xcol[j];
+            p[i] = bk * s;
+        }
+        double pv = 0.0;
+        for (i64 i = 0; i < r; i++) pv += p[i] * xcol[i];
+        const double K = 0.5 * bk * pv;
+        for (i64 i = 0; i < r; i++) p[i] -= K * xcol[i]; // w
+        for (i64 i = 0; i < r; i++) {
+            double *Bi = &A[(k + 1 + i) * d + (k + 1)];
+            const double vi = xcol[i], wi = p[i];
+            for (i64 j = 0; j < r; j++) Bi[j] -= vi * p[j] + wi * xcol[j];
+        }
+        for (i64 i = 1; i < r; i++) A[(k + 1 + i) * d + k] = xcol[i]; // keep the reflector (v[0] = 1 implicit)
+    }
+    for (i64 i = 0; i < d; i++) diag[i] = A[i * d + i];
+    off[d - 2] = A[(d - 1) * d + (d - 2)];
+    // largest eigenvalue by bisection on the Sturm count
+    double lo = diag[0], hi = diag[0], tnorm = 0.0;
+    for (i64 i = 0; i < d; i++) {
+        const double rad = (i > 0 ? std::fabs(off[i - 1]) : 0.0) + (i + 1 < d ? std::fabs(off[i]) : 0.0);
+        lo = std::min(lo, diag[i] - rad);
+        hi = std::max(hi, diag[i] + rad);
+        tnorm = std::max(tnorm, std::fabs(diag[i]) + rad);
+    }
+    const double tiny = std::max(tnorm, DBL_MIN) * DBL_EPSILON;
+    auto count_below = [&](double x) { // number of eigenvalues < x
+        i64 cnt = 0;
+        double q = diag[0] - x;
+        if (q < 0) cnt++;
+        for (i64 i = 1; i < d; i++) {
+            if (q == 0.0) q = tiny;
+            q = diag[i] - x - off[i - 1] * off[i - 1] / q;
+            if (q < 0) cnt++;
+        }
+        return cnt;
+    };
+    hi += tiny;
+    for (int it = 0; it < 200; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (!(mid > lo && mid < hi)) break;
+        if (count_below(mid) >= d) hi = mid; else lo = mid;
+    }
+    const double lam = 0.5 * (lo + hi);
+    // inverse iteration on (T - lam I), tridiagonal LU with partial pivoting
+    std::vector<double> dl(d), dd(d), du(d), du2(d, 0.0), y(d);
+    std::vector<char> swp(d, 0);
+    for (i64 i = 0; i < d; i++) {
+        dd[i] = diag[i] - lam;
+        dl[i] = (i + 1 < d) ? off[i] : 0.0; // sub-diagonal below row i
+        du[i] = (i + 1 < d) ? off[i] : 0.0; // super-diagonal right of row i
+    }
+    for (i64 i = 0; i + 1 < d; i++) {
+        if (std::fabs(dd[i]) >= std::fabs(dl[i])) {
+            if (dd[i] == 0.0) dd[i] = tiny;
+            const double f = dl[i] / dd[i];
+            dl[i] = f;
+            dd[i + 1] -= f * du[i];
+            du2[i] = 0.0;
+        } else {
+            const double f = dd[i] / dl[i];
+            dd[i] = dl[i];
+            dl[i] = f;
+            const double t = du[i];
+            du[i] = dd[i + 1];
+            dd[i + 1] = t - f * dd[i + 1];
+            if (i + 2 < d) {
+                du2[i] = du[i + 1];
+                du[i + 1] = -f * du[i + 1];
+            }
+            swp[i] = 1;
+        }
+    }
+    if (dd[d - 1] == 0.0) dd[d - 1] = tiny;
+    for (i64 i = 0; i < d; i++) y[i] = 1.0 + 0.01 * (double)((i * 2654435761u) % 97) / 97.0;
+    for (int it = 0; it < 4; it++) {
+        for (i64 i = 0; i + 1 < d; i++) {
+            if (!swp[i])
+                y[i + 1] -= dl[i] * y[i];
+            else {
+                const double t = y[i];
+                y[i] = y[i + 1];
+                y[i + 1] = t - dl[i] * y[i];
+            }
+        }
+        y[d - 1] /= dd[d - 1];
+        if (d > 1) y[d - 2] = (y[d - 2] - du[d - 2] * y[d - 1]) / dd[d - 2];
+        for (i64 i = d - 3; i >= 0; i--) y[i] = (y[i] - du[i] * y[i + 1] - du2[i] * y[i + 2]) / dd[i];
+        double nrm = 0.0, amax = 0.0;
+        for (i64 i = 0; i < d; i++) amax = std::max(amax, std::fabs(y[i]));
+        if (!(amax > 0.0) || !std::isfinite(amax)) { // degenerate: fall back to a unit vector
+            for (i64 i = 0; i < d; i++) y[i] = (i == 0) ? 1.0 : 0.0;
+            break;
+        }
+        for (i64 i = 0; i < d; i++) { y[i] /= amax; nrm += y[i] * y[i]; }
+        nrm = std::sqrt(nrm);
+        for (i64 i = 0; i < d; i++) y[i] /= nrm;
+    }
+    // back-transform: x = H_0 H_1 ... H_{d-3} y
+    for (i64 k = d - 3; k >= 0; k--) {
+        if (beta[k] == 0.0) continue;
+        const i64 r = d - k - 1;
+        double s = y[k + 1];
+        for (i64 i = 1; i < r; i++) s += A[(k + 1 + i) * d + k] * y[k + 1 + i];
+        s *= beta[k];
+        y[k + 1] -= s;
+        for (i64 i = 1; i < r; i++) y[k + 1 + i] -= s * A[(k + 1 + i) * d + k];
+    }
+    double nrm = 0.0;
+    for (i64 i = 0; i < d; i++) nrm += y[i] * y[i];
+    nrm = std::sqrt(nrm);
+    i64 big = 0;
+    for (i64 i = 0; i < d; i++) {
+        vout[i] = y[i] / nrm;
+        if (std::fabs(vout[i]) > std::fabs(vout[big])) big = i;
+    }
+    if (vout[big] < 0.0)
+        for (i64 i = 0; i < d; i++) vout[i] = -vout[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// Compute the split of every task (device: mean/cov/projection; host: eigenvector, cut, RSS).
+void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
+    const i64 d = c->d;
+    const double *hX = c->h_Xr.data();
+    const double *hw = c->h_vw.data();
+    std::vector<Group *> big;
+    for (Group *g : tasks) {
+        const i64 k = (i64)g->what.size();
+        g->has_split = true;
+        g->rc = CGE_OK;
+        // the rules' own asserts (:93,:156,:219 `size(m,1) > 1`; :248 `size(m,2) > 1`)
+        if ((method != CGE_METHOD_DIAMETER && k <= 1) || (method == CGE_METHOD_DIAMETER && d <= 1)) {
+            g->rc = CGE_E_ASSERT;
+            continue;
+        }
+        if (k <= 1) { g->rc = CGE_E_EMPTY_CLUSTER; continue; } // diameter rule on one row: `low` comes out empty
+        if (k == 2) { // `return [1], [2]`
+            g->low.assign(1, g->what[0]);
+            g->high.assign(1, g->what[1]);
+            g->vlow = g->vhigh = DBL_EPSILON;
+            continue;
+        }
+        if (k < 2) { g->rc = CGE_E_ASSERT; continue; }
+        big.push_back(g);
+    }
+    if (big.empty()) return;
+
+    // Sub-batches bound the covariance buffers (T * d*d doubles) to ~1 GiB.
+    const i64 max_tasks = std::max<i64>(1, (i64)(1ull << 27) / (d * d));
+    for (size_t b0 = 0; b0 < big.size(); b0 += (size_t)max_tasks) {
+        const size_t b1 = std::min(big.size(), b0 + (size_t)max_tasks);
+        const i64 T = (i64)(b1 - b0);
+        i64 R = 0;
+        for (size_t t = b0; t < b1; t++) R += (i64)big[t]->what.size();
+        const i64 CH = 1024;
+        std::vector<i32> rows(R), row_task(R), chunk_task, chunk_beg, chunk_end, task_chunk_off(T + 1), task_row_off(T + 1);
+        i64 pos = 0;
+        for (i64 t = 0; t < T; t++) {
+            const Group *g = big[b0 + t];
+            task_row_off[t] = (i32)pos;
+            task_chunk_off[t] = (i32)chunk_task.size();
+            const i64 k = (i64)g->what.size();
+            for (i64 j = 0; j < k; j++) {
+                rows[pos + j] = (i32)(g->what[j] - 1);
+                row_task[pos + j] = (i32)t;
+            }
+            for (i64 s = 0; s < k; s += CH) {
+                chunk_task.push_back((i32)t);
+                chunk_beg.push_back((i32)(pos + s));
+                chunk_end.push_back((i32)(pos + std::min(k, s + CH)));
+            }
+            pos += k;
+        }
+        task_row_off[T] = (i32)pos;
+        task_chunk_off[T] = (i32)chunk_task.size();
+        const i64 NC = (i64)chunk_task.size();
+
+        // grow-only scratch owned by the ctx (no hipMalloc/hipFree per batch)
+        DevBuf<i32> &d_rows = c->ls_rows, &d_row_task = c->ls_row_task, &d_ct = c->ls_ct, &d_cb = c->ls_cb,
+                    &d_ce = c->ls_ce, &d_tco = c->ls_tco;
+        DevBuf<double> &d_part = c->ls_part, &d_mean = c->ls_mean, &d_sw = c->ls_sw, &d_cov = c->ls_cov,
+                       &d_vec = c->ls_vec, &d_z = c->ls_z;
+        d_rows.ensure(R); d_row_task.ensure(R); d_ct.ensure(NC); d_cb.ensure(NC); d_ce.ensure(NC); d_tco.ensure(T + 1);
+        d_part.ensure((size_t)NC * std::max(d * d, d + 1));
+        d_mean.ensure((size_t)T * d); d_sw.ensure(T); d_cov.ensure((size_t)T * d * d); d_vec.ensure((size_t)T * d);
+        d_z.ensure(R);
+        hipStream_t st = c->stream;
+        HIP_CHECK(hipMemcpyAsync(d_rows.p, rows.data(), sizeof(i32) * R, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_row_task.p, row_task.data(), sizeof(i32) * R, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_ct.p, chunk_task.data(), sizeof(i32) * NC, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_cb.p, chunk_beg.data(), sizeof(i32) * NC, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_ce.p, chunk_end.data(), sizeof(i32) * NC, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_tco.p, task_chunk_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
+        {
+            ScopedKernelTimer tm(c, "group_stats");
+            k_group_mean(c, c->Xr.p, c->vw.p, d_rows.p, d_ct.p, d_cb.p, d_ce.p, NC, d_tco.p, T, d, d_part.p, d_mean.p,
+                         d_sw.p);
+            k_group_cov(c, c->Xr.p, c->vw.p, d_rows.p, d_ct.p, d_cb.p, d_ce.p, NC, d_tco.p, T, d, d_mean.p, d_part.p,
+                        d_cov.p);
+        }
+        std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d), z(R);
+        HIP_CHECK(hipMemcpyAsync(cov.data(), d_cov.p, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        parallel_for(c->n_threads, T, [&](i64 t) { host_eig_top(&cov[(size_t)t * d * d], d, &vec[(size_t)t * d]); });
+        HIP_CHECK(hipMemcpyAsync(d_vec.p, vec.data(), sizeof(double) * vec.size(), hipMemcpyHostToDevice, st));
+        {
+            ScopedKernelTimer tm(c, "group_project");
+            k_group_project(c, c->Xr.p, c->vw.p, d_rows.p, d_row_task.p, R, d, d_mean.p, d_vec.p, d_z.p);
+        }
+        HIP_CHECK(hipMemcpyAsync(z.data(), d_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        parallel_for(c->n_threads, T, [&](i64 t) {
+            Group *g = big[b0 + t];
+            const i64 k = (i64)g->what.size();
+            HView v{hX, hw, d, g->what.data(), k};
+            const double *zt = &z[task_row_off[t]];
+            std::vector<i64> lo, hi;
+            int rc;
+            switch (method) {
+            case CGE_METHOD_RSS: rc = rule_rss(v, zt, lo, hi); break;
+            case CGE_METHOD_RSS2: rc = rule_rss2(v, zt, lo, hi); break;
+            case CGE_METHOD_SIZE: rc = rule_cut(zt, k, true, lo, hi); break;
+            default: rc = rule_cut(zt, k, false, lo, hi); break;
+            }
+            g->rc = rc;
+            if (rc != CGE_OK) return;
+            if (lo.empty() || hi.empty()) { g->rc = CGE_E_EMPTY_CLUSTER; return; }
+            g->vlow = lo.size() > 1 ? -total_rss(v, lo, false) : DBL_EPSILON;
+            g->vhigh = hi.size() > 1 ? -total_rss(v, hi, false) : DBL_EPSILON;
+            g->low.resize(lo.size());
+            g->high.resize(hi.size());
+            for (size_t q = 0; q < lo.size(); q++) g->low[q] = g->what[lo[q]];
+            for (size_t q = 0; q < hi.size(); q++) g->high[q] = g->what[hi[q]];
+        });
+    }
+}
+
+void throw_rc(int rc) {
+    switch (rc) {
+    case CGE_E_HOMOGENEOUS: CGE_THROW(rc, "Trying to split homogenous cluster");
+    case CGE_E_EMPTY_CLUSTER: CGE_THROW(rc, "Unexpected empty cluster generated");
+    default: CGE_THROW(rc, "AssertionError: size(m, 1) > 1");
+    }
+}
+
+// pop the top group of `h`, push its two children (the body of src/landmarks.jl:290-307 / :317-334)
+void replay_one(Heap &h, std::deque<Group> &pool) {
+    Group *g = h.pop();
+    if (g->rc != CGE_OK) throw_rc(g->rc);
+    pool.emplace_back();
+    Group *lo = &pool.back();
+    lo->what = std::move(g->low);
+    lo->value = g->vlow;
+    h.put(lo);
+    pool.emplace_back();
+    Group *hi = &pool.back();
+    hi->what = std::move(g->high);
+    hi->value = g->vhigh;
+    h.put(hi);
+    g->what.clear();
+    g->what.shrink_to_fit();
+}
+
+} // namespace
+
+void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
+                   std::vector<i64> &group_ids, std::vector<std::vector<i64>> *members_out) {
+    const i64 n = c->n, d = c->d;
+    if ((i64)c->h_Xr.size() != n * d || (i64)c->h_vw.size() != n)
+        CGE_THROW(CGE_E_ARG, "runsplit: embedding / vertex weights are not resident");
+    std::deque<Group> pool;
+    Heap H;
+    // sort(initial_clusters): lexicographic (:281)
+    std::vector<i64> order(ncl);
+    for (i64 i = 0; i < ncl; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](i64 a, i64 b) {
+        return std::lexicographical_compare(cl_flat + cl_off[a], cl_flat + cl_off[a + 1], cl_flat + cl_off[b],
+                                            cl_flat + cl_off[b + 1]);
+    });
+    for (i64 q = 0; q < ncl; q++)
+        for (i64 t = cl_off[q]; t < cl_off[q + 1]; t++)
+            if (cl_flat[t] < 1 || cl_flat[t] > n) CGE_THROW(CGE_E_ARG, "cluster member %lld out of range", (long long)cl_flat[t]);
+
+    // ---- forced per-community phase (:282-313): every big community owns a local heap -----------
+    struct Local { Heap h; i64 pos; };
+    std::vector<Local> locals;
+    // global-heap insertion order must follow the sorted community order, so first split all the
+    // local heaps (independent of each other), then insert community by community.
+    for (i64 q = 0; q < ncl; q++) {
+        const i64 cidx = order[q], len = cl_off[cidx + 1] - cl_off[cidx];
+        if (len > forced) {
+            locals.push_back(Local{Heap(), q});
+            pool.emplace_back();
+            Group *g = &pool.back();
+            g->what.assign(cl_flat + cl_off[cidx], cl_flat + cl_off[cidx + 1]);
+            locals.back().h.put(g);
+        }
+    }
+    if (!locals.empty()) {
+        // root values: -total_rss of each community (host, parallel)
+        parallel_for(c->n_threads, (i64)locals.size(), [&](i64 t) {
+            Group *g = locals[t].h.top();
+            HView v{c->h_Xr.data(), c->h_vw.data(), d, g->what.data(), (i64)g->what.size()};
+            g->value = -total_rss(v, g->what, true);
+        });
+        for (;;) {
+            std::vector<Group *> tasks;
+            for (auto &L : locals) {
+                while ((i64)L.h.len() < forced && L.h.top()->has_split) replay_one(L.h, pool);
+                if ((i64)L.h.len() < forced) tasks.push_back(L.h.top());
+            }
+            if (tasks.empty()) break;
+            compute_splits(c, tasks, method);
+        }
+    }
+    size_t li = 0;
+    for (i64 q = 0; q < ncl; q++) {
+        const i64 cidx = order[q], len = cl_off[cidx + 1] - cl_off[cidx];
+        if (len <= forced) {
+            for (i64 t = cl_off[cidx]; t < cl_off[cidx + 1]; t++) {
+                pool.emplace_back();
+                Group *g = &pool.back();
+                g->what.assign(1, cl_flat[t]);
+                g->value = DBL_EPSILON; // eps() (:284)
+                H.put(g);
+            }
+        } else {
+            Heap &L = locals[li++].h;
+            while (L.len() > 0) H.put(L.pop()); // :309-312
+        }
+    }
+    // ---- global phase (:316-335) with speculative batches ----------------------------------------
+    while ((i64)H.len() < nland) {
+        while ((i64)H.len() < nland && H.top()->has_split) replay_one(H, pool);
+        if ((i64)H.len() >= nland) break;
+        const i64 remaining = nland - (i64)H.len();
+        i64 K = std::max<i64>(1, std::min<i64>(remaining, std::max<i64>(32, (remaining + 1) / 2)));
+        K = std::min<i64>(K, 4096);
+        std::vector<Group *> cand;
+        for (size_t i = 1; i <= H.len(); i++)
+            if (!H.a[i]->has_split && (H.a[i]->what.size() > 1 || H.a[i] == H.top())) cand.push_back(H.a[i]);
+        if ((i64)cand.size() > K) {
+            std::nth_element(cand.begin(), cand.begin() + K, cand.end(),
+                             [](const Group *a, const Group *b) { return a->value < b->value; });
+            cand.resize(K);
+        }
+        if (std::find(cand.begin(), cand.end(), H.top()) == cand.end()) cand.back() = H.top(); // ties at the cut
+        // the top of the heap must be in the batch (it is the smallest value, so it is, unless it
+        // was filtered out above as an already split group -- impossible here)
+        compute_splits(c, cand, method);
+    }
+    group_ids.assign(n, -1);
+    if (members_out) members_out->clear();
+    for (size_t g = 1; g <= H.len(); g++) {
+        for (i64 v : H.a[g]->what) group_ids[v - 1] = (i64)g - 1;
+        if (members_out) members_out->push_back(H.a[g]->what);
+    }
+    for (i64 i = 0; i < n; i++)
+        if (group_ids[i] < 0) CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids)"); // :343
+}

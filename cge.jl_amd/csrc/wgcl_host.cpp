@@ -1,0 +1,379 @@
+// wgcl_host.cpp -- host side of the alpha sweep (wGCL / wGCL_directed, src/divergence.jl:27-257,
+// :282-561) and the local-score sampler.  The host owns only the alpha bookkeeping (best/patience
+// counters, :215-223, :242-253) and the batch-wise launch of fit iterations; every O(N^2) loop of the
+// reference runs in kernels_fit.hip / kernels_dist.hip.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+// ---- counter-based RNG (splitmix64 finaliser over a 4-word counter) ---------------------------------
+static inline uint64_t sm64(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+static inline uint64_t ctr_rand(uint64_t seed, uint64_t stream, uint64_t k, uint64_t attempt, uint64_t which) {
+    uint64_t h = sm64(seed ^ 0x6a09e667f3bcc909ULL);
+    h = sm64(h ^ (stream * 0xd1342543de82ef95ULL + 1));
+    h = sm64(h ^ (k * 0x2545f4914f6cdd1dULL + 2));
+    h = sm64(h ^ (attempt * 0x9e6c63d0676a9a99ULL + 3));
+    return sm64(h ^ (which + 4));
+}
+// uniform integer in [0, range): multiply-high (bias < range / 2^64)
+static inline uint64_t bounded(uint64_t r, uint64_t range) { return (uint64_t)(((__uint128_t)r * range) >> 64); }
+
+static inline uint64_t mixk_host(uint64_t x) { // must match mixk() in kernels_fit.hip
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+void host_pos_draw(i64 seed, i64 stream_id, i64 S, i64 m, i64 *pos_idx) {
+    for (i64 k = 0; k < S; k++)
+        pos_idx[k] = (i64)bounded(ctr_rand((uint64_t)seed, (uint64_t)stream_id, (uint64_t)k, 0, 0), (uint64_t)m) + 1;
+}
+
+// `sample(E, S, replace=true)` and `sample(NE, S, replace=true)` (src/divergence.jl:185,194,203,210;
+// directed :485,495,505,513) on the RESIDENT graph.  Uniform with replacement over the edge rows and
+// over the non-edge pairs (rejection against the resident edge list, checked on the device).
+void host_draw_samples(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i64 *pos_idx, i64 *neg_i, i64 *neg_j) {
+    const i64 n = c->n, m = c->m;
+    if (m <= 0 || n < 2) CGE_THROW(CGE_E_ARG, "draw_samples: no resident graph");
+    const uint64_t sd = (uint64_t)seed, st = (uint64_t)stream_id;
+    host_pos_draw(seed, stream_id, S, m, pos_idx);
+    // Small graphs (n(n-1) <= 2^25): enumerate NE itself (lexicographic order) and index into it --
+    // exact and immune to dense graphs; larger graphs: rejection against the edge list.
+    if ((double)n * (double)(n - 1) <= 33554432.0) {
+        std::vector<i32> hs(m), hd(m);
+        HIP_CHECK(hipMemcpyAsync(hs.data(), c->src.p, sizeof(i32) * m, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpyAsync(hd.data(), c->dst.p, sizeof(i32) * m, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        std::vector<uint8_t> adj((size_t)n * n, 0);
+        for (i64 e = 0; e < m; e++) {
+            i64 a = hs[e], b = hd[e];
+            if (!directed && a > b) std::swap(a, b);
+            adj[(size_t)a * n + b] = 1;
+        }
+        std::vector<uint32_t> ne;
+        ne.reserve((size_t)n * (n - 1) / (directed ? 1 : 2));
+        for (i64 i = 0; i < n; i++)
+            for (i64 j = directed ? 0 : i + 1; j < n; j++)
+                if (i != j && !adj[(size_t)i * n + j]) ne.push_back((uint32_t)(i * n + j));
+        if (ne.empty()) CGE_THROW(CGE_E_ARG, "draw_samples: the graph has no non-edges");
+        for (i64 k = 0; k < S; k++) {
+            const uint32_t code = ne[bounded(ctr_rand(sd, st, (uint64_t)k, 0, 1), (uint64_t)ne.size())];
+            neg_i[k] = (i64)(code / n) + 1;
+            neg_j[k] = (i64)(code % n) + 1;
+        }
+        return;
+    }
+    std::vector<uint32_t> attempt(S, 0);
+    std::vector<i64> todo(S);
+    for (i64 k = 0; k < S; k++) todo[k] = k;
+    auto draw = [&](i64 k) {
+        const uint64_t a = attempt[k];
+        uint64_t i = bounded(ctr_rand(sd, st, (uint64_t)k, a, 1), (uint64_t)n);
+        uint64_t j = bounded(ctr_rand(sd, st, (uint64_t)k, a, 2), (uint64_t)(n - 1));
+        if (j >= i) j++; // uniform over ordered pairs i != j
+        if (!directed && i > j) std::swap(i, j);
+        neg_i[k] = (i64)i + 1;
+        neg_j[k] = (i64)j + 1;
+    };
+    for (i64 k = 0; k < S; k++) draw(k);
+    DevBuf<uint64_t> d_table;
+    DevBuf<i32> d_hit;
+    for (int round = 0; round < 64 && !todo.empty(); round++) {
+        i64 tsize = 1024;
+        while (tsize < 4 * (i64)todo.size()) tsize <<= 1;
+        std::vector<uint64_t> table(tsize, ~0ULL);
+        auto slot_of = [&](uint64_t key, bool insert) -> i64 {
+            i64 s = (i64)(mixk_host(key) & (uint64_t)(tsize - 1));
+            for (;;) {
+                if (table[s] == key) return s;
+                if (table[s] == ~0ULL) {
+                    if (!insert) return -1;
+                    table[s] = key;
+                    return s;
+                }
+                s = (s + 1) & (tsize - 1);
+            }
+        };
+        for (i64 k : todo) slot_of(((uint64_t)(neg_i[k] - 1) << 32) | (uint64_t)(neg_j[k] - 1), true);
+        d_table.ensure(tsize);
+        d_hit.ensure(tsize);
+        HIP_CHECK(hipMemcpyAsync(d_table.p, table.data(), sizeof(uint64_t) * tsize, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemsetAsync(d_hit.p, 0, sizeof(i32) * tsize, c->stream));
+        k_mark_edge_hits(c, c->src.p, c->dst.p, m, directed, d_table.p, tsize, d_hit.p);
+        std::vector<i32> hit(tsize);
+        HIP_CHECK(hipMemcpyAsync(hit.data(), d_hit.p, sizeof(i32) * tsize, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        std::vector<i64> again;
+        for (i64 k : todo) {
+            const i64 s = slot_of(((uint64_t)(neg_i[k] - 1) << 32) | (uint64_t)(neg_j[k] - 1), false);
+            if (s >= 0 && hit[s]) {
+                attempt[k]++;
+                draw(k);
+                again.push_back(k);
+            }
+        }
+        todo.swap(again);
+    }
+    if (!todo.empty()) CGE_THROW(CGE_E_ARG, "draw_samples: could not find enough non-edges (graph too dense?)");
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevSamples { // one sample set on the device (0-based)
+    DevBuf<i32> pi, pj, ni, nj;
+    DevBuf<double> wts, dpos, dneg;
+};
+} // namespace
+
+// Endpoints / weights of sampled edge rows are gathered on the host from small D2H reads of the
+// resident edge arrays (S entries), so no host mirror of the edge list is needed.
+static void gather_rows(cge_ctx *c, const i32 *d_arr, const std::vector<i64> &rows0, std::vector<i32> &out,
+                        DevBuf<i32> &d_idx, DevBuf<i32> &d_out);
+
+void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, const i32 *ex_src, const i32 *ex_dst,
+                     const double *ex_hw, i64 ex_m, int directed, int split, const SampleSet &smp, double out[7],
+                     int *out_len, cge_trace *trace) {
+    const double delta = 0.001, AlphaMax = 10.0, AlphaStep = 0.25; // :35-37 / :288-290
+    const i64 N = G.N, C = G.C, d = G.d;
+    hipStream_t st = c->stream;
+    const i64 vlen = directed ? C * C : packed_len(C);
+    if ((double)N * (double)N * 8.0 * 2.2 > 200e9) CGE_THROW(CGE_E_OOM, "score graph with %lld vertices does not fit", (long long)N);
+
+    DevBuf<double> D, GD, T1, T2, S1, S2, rowbins, vectB, scal, lohi, fitstate;
+    DevBuf<int> flags; // [0]=done, [1]=iters
+    D.ensure((size_t)N * N);
+    GD.ensure((size_t)N * N);
+    T1.ensure(N); T2.ensure(N); S1.ensure(N); S2.ensure(N);
+    rowbins.ensure((size_t)N * C);
+    vectB.ensure(vlen);
+    scal.ensure(16);
+    lohi.ensure(2);
+    fitstate.ensure(4);
+    flags.ensure(4);
+
+    // D and its normalisation (:79-93 / :359-375)
+    k_dist_matrix(c, G.emb, G.dist, N, d, D.p);
+    k_minmax_upper(c, D.p, N, lohi.p);
+    k_normalise(c, D.p, N, lohi.p);
+
+    // community -> members CSR of the score graph
+    std::vector<i32> hcomm(N);
+    HIP_CHECK(hipMemcpyAsync(hcomm.data(), G.comm, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<i32> cm_off(C + 1, 0), cm_mem(N);
+    for (i64 i = 0; i < N; i++) {
+        if (hcomm[i] < 0 || hcomm[i] >= C) CGE_THROW(CGE_E_ARG, "community id out of range");
+        cm_off[hcomm[i] + 1]++;
+    }
+    for (i64 q = 0; q < C; q++) cm_off[q + 1] += cm_off[q];
+    {
+        std::vector<i32> cur(cm_off.begin(), cm_off.end() - 1);
+        for (i64 i = 0; i < N; i++) cm_mem[cur[hcomm[i]]++] = (i32)i;
+    }
+    DevBuf<i32> d_cm_off, d_cm_mem;
+    d_cm_off.ensure(C + 1);
+    d_cm_mem.ensure(N);
+    HIP_CHECK(hipMemcpyAsync(d_cm_off.p, cm_off.data(), sizeof(i32) * (C + 1), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(d_cm_mem.p, cm_mem.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+
+    // T (:118) / Tin,Tout (:399-402)
+    std::vector<double> hT1(N, 1.0), hT2(N, 1.0);
+    if (directed) {
+        std::vector<double> din(N), dout(N);
+        HIP_CHECK(hipMemcpyAsync(din.data(), G.deg_in, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(dout.data(), G.deg_out, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (i64 i = 0; i < N; i++) {
+            if (din[i] == 0) hT1[i] = 0.0;  // Tin
+            if (dout[i] == 0) hT2[i] = 0.0; // Tout
+        }
+    }
+    HIP_CHECK(hipMemcpyAsync(T1.p, hT1.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(T2.p, hT2.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const double *Tin = T1.p, *Tout = T2.p; // undirected uses T1 only
+
+    // ---- samples -> device ---------------------------------------------------------------------
+    const bool landmarks = orig != nullptr;
+    const i64 S = smp.S;
+    const i32 *e_src = landmarks ? orig->src : ex_src, *e_dst = landmarks ? orig->dst : ex_dst;
+    const double *e_hw = landmarks ? orig->h_w : ex_hw;
+    const i64 e_m = landmarks ? orig->m : ex_m;
+    std::vector<DevSamples> dsets(smp.n_sets);
+    {
+        DevBuf<i32> d_idx, d_tmp;
+        std::vector<i64> rows0(S);
+        std::vector<i32> hs, hd, hs2, hd2;
+        for (i64 t = 0; t < smp.n_sets; t++) {
+            DevSamples &ds = dsets[t];
+            for (i64 k = 0; k < S; k++) {
+                rows0[k] = smp.pos_idx[t * S + k] - 1;
+                if (rows0[k] < 0 || rows0[k] >= e_m) CGE_THROW(CGE_E_ARG, "positive sample row out of range");
+            }
+            gather_rows(c, e_src, rows0, hs, d_idx, d_tmp);
+            gather_rows(c, e_dst, rows0, hd, d_idx, d_tmp);
+            std::vector<double> wts(S);
+            for (i64 k = 0; k < S; k++) wts[k] = e_hw ? e_hw[rows0[k]] : 1.0;
+            if (directed && !landmarks && !smp.pos_idx2.empty()) { // the overwriting second draw (:510)
+                for (i64 k = 0; k < S; k++) rows0[k] = smp.pos_idx2[t * S + k] - 1;
+                gather_rows(c, e_src, rows0, hs, d_idx, d_tmp);
+                gather_rows(c, e_dst, rows0, hd, d_idx, d_tmp);
+            }
+            std::vector<i32> pi(S), pj(S), ni(S), nj(S);
+            for (i64 k = 0; k < S; k++) {
+                i32 a = hs[k], b = hd[k];
+                if (!directed && a > b) std::swap(a, b); // E tuple (min,max) :133
+                pi[k] = a; pj[k] = b;
+                i64 u = smp.neg_i[t * S + k] - 1, v = smp.neg_j[t * S + k] - 1;
+                if (!directed && u > v) std::swap(u, v);
+                const i64 lim = landmarks ? orig->n : N;
+                if (u < 0 || v < 0 || u >= lim || v >= lim) CGE_THROW(CGE_E_ARG, "negative sample out of range");
+                ni[k] = (i32)u; nj[k] = (i32)v;
+            }
+            ds.pi.ensure(S); ds.pj.ensure(S); ds.ni.ensure(S); ds.nj.ensure(S); ds.wts.ensure(S);
+            HIP_CHECK(hipMemcpyAsync(ds.pi.p, pi.data(), sizeof(i32) * S, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(ds.pj.p, pj.data(), sizeof(i32) * S, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(ds.ni.p, ni.data(), sizeof(i32) * S, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(ds.nj.p, nj.data(), sizeof(i32) * S, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(ds.wts.p, wts.data(), sizeof(double) * S, hipMemcpyHostToDevice, st));
+            if (landmarks) { // full_graph_D of the sampled pairs, normalised by hi (lo == 0) :104-114
+                ds.dpos.ensure(S); ds.dneg.ensure(S);
+                k_pair_dist(c, orig->Xr, d, ds.pi.p, ds.pj.p, S, orig->hi, ds.dpos.p);
+                k_pair_dist(c, orig->Xr, d, ds.ni.p, ds.nj.p, S, orig->hi, ds.dneg.p);
+            }
+            HIP_CHECK(hipStreamSynchronize(st)); // host vectors go out of scope
+        }
+    }
+
+    // ---- alpha sweep ---------------------------------------------------------------------------
+    int alpha_div_counter = 5, alpha_auc_counter = 5; // :38
+    bool skip_div = false, skip_auc = false;
+    double best_div = INFINITY, best_div_ext = INFINITY, best_div_int = INFINITY, best_auc_err = INFINITY,
+           best_auc = INFINITY; // typemax(Float64)
+    double best_alpha = -1.0, best_alpha_auc = -1.0;
+    if (trace) trace->n_alpha = 0;
+    const i64 n_alpha_total = (i64)std::floor((AlphaMax + delta) / AlphaStep + 1e-9);
+    i64 prev_iters = 16;
+    for (i64 ia = 1; ia <= n_alpha_total; ia++) {
+        const double alpha = AlphaStep * (double)ia;
+        k_pow_matrix(c, D.p, N, alpha, GD.p);
+        HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
+        if (directed) {
+            const double init[2] = {0.9, 1.0}; // epsilon, diff (:434-435)
+            HIP_CHECK(hipMemcpyAsync(fitstate.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+        }
+        i64 iters = 0;
+        i64 batch = std::max<i64>(4, std::min<i64>(prev_iters, 128));
+        for (;;) {
+            for (i64 b = 0; b < batch; b++) {
+                if (!directed) {
+                    k_fit_symv(c, GD.p, T1.p, N, S1.p, flags.p);
+                    k_fit_update(c, T1.p, S1.p, G.vw, N, 0.25, delta, flags.p, flags.p + 1, scal.p + 8);
+                } else {
+                    k_fit_symv_dir(c, GD.p, T1.p, T2.p, N, S1.p, S2.p, flags.p);
+                    k_fit_update_dir(c, T1.p, T2.p, S1.p, S2.p, G.deg_in, G.deg_out, N, delta, flags.p, flags.p + 1,
+                                     fitstate.p);
+                }
+            }
+            int hf[2];
+            HIP_CHECK(hipMemcpyAsync(hf, flags.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            iters = hf[1];
+            if (hf[0]) break;
+            if (iters > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g", alpha);
+            batch = std::max<i64>(4, std::min<i64>(batch, 32));
+        }
+        prev_iters = iters;
+
+        double auc_val = NAN, div_val = NAN, div_int = 0.0, div_ext = 0.0;
+        const double *Ta = directed ? Tout : T1.p, *Tb = directed ? Tin : T1.p;
+        if (!skip_auc) {
+            const DevSamples &ds = dsets[smp.n_sets == 1 ? 0 : ia - 1];
+            if (landmarks)
+                k_auc_landmark(c, Ta, Tb, orig->v2l, orig->vw, orig->lweight, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p,
+                               ds.dpos.p, ds.dneg.p, ds.wts.p, S, alpha, scal.p);
+            else
+                k_auc_exact(c, GD.p, Ta, Tb, N, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p, ds.wts.p, S, scal.p);
+        }
+        if (!skip_div) {
+            k_bvec(c, GD.p, Ta, Tb, G.comm, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
+            if (!split)
+                k_js(c, G.vectC, vectB.p, vlen, C, directed, 0, scal.p + 2);
+            else {
+                k_js(c, G.vectC, vectB.p, vlen, C, directed, 1, scal.p + 3);
+                k_js(c, G.vectC, vectB.p, vlen, C, directed, 2, scal.p + 4);
+            }
+        }
+        double hs[5];
+        HIP_CHECK(hipMemcpyAsync(hs, scal.p, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (!skip_auc) {
+            const double auc = 1.0 - hs[0] / hs[1]; // :213
+            auc_val = auc;
+            if (auc < best_auc) {
+                best_auc = auc;
+                best_auc_err = 1.96 * std::sqrt(auc * (1.0 - auc) / (double)S); // :217
+                best_alpha_auc = alpha;
+                alpha_auc_counter = 5;
+            } else {
+                alpha_auc_counter -= 1;
+                skip_auc = alpha_auc_counter == 0;
+            }
+        }
+        if (!skip_div) {
+            double f;
+            if (!split)
+                f = hs[2];
+            else {
+                div_int = hs[3];
+                div_ext = hs[4];
+                f = (div_int + div_ext) / 2.0;
+            }
+            div_val = f;
+            if (f < best_div) {
+                best_div = f;
+                best_alpha = alpha;
+                best_div_ext = !split ? 0.0 : div_ext;
+                best_div_int = !split ? 0.0 : div_int;
+                alpha_div_counter = 5;
+            } else {
+                alpha_div_counter -= 1;
+                skip_div = alpha_div_counter == 0;
+            }
+        }
+        if (trace && trace->n_alpha < 64) {
+            trace->iters[trace->n_alpha] = iters;
+            trace->div[trace->n_alpha] = div_val;
+            trace->auc[trace->n_alpha] = auc_val;
+            trace->n_alpha++;
+        }
+        if (skip_div && skip_auc) break; // :253
+    }
+    out[0] = best_alpha; out[1] = best_div; out[2] = best_div_ext; out[3] = best_div_int;
+    out[4] = best_alpha_auc; out[5] = best_auc; out[6] = best_auc_err; // :256
+    *out_len = 7;
+}
+
+// ---- small helpers ---------------------------------------------------------------------------------
+void k_gather_i32(cge_ctx *c, const i32 *arr, const i32 *idx, i64 S, i32 *out); // kernels_fit.hip
+
+static void gather_rows(cge_ctx *c, const i32 *d_arr, const std::vector<i64> &rows0, std::vector<i32> &out,
+                        DevBuf<i32> &d_idx, DevBuf<i32> &d_out) {
+    const i64 S = (i64)rows0.size();
+    std::vector<i32> idx(S);
+    for (i64 k = 0; k < S; k++) idx[k] = (i32)rows0[k];
+    d_idx.ensure(S);
+    d_out.ensure(S);
+    out.resize(S);
+    HIP_CHECK(hipMemcpyAsync(d_idx.p, idx.data(), sizeof(i32) * S, hipMemcpyHostToDevice, c->stream));
+    k_gather_i32(c, d_arr, d_idx.p, S, d_out.p);
+    HIP_CHECK(hipMemcpyAsync(out.data(), d_out.p, sizeof(i32) * S, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}

@@ -1,0 +1,198 @@
+/*
+ * cge_hip.h -- C-ABI of libcge_hip.so: the MI355X (gfx950) implementation of CGE.jl's
+ * divergence-scoring hot path.  This is the boundary a Julia `ccall`, a Python `ctypes`
+ * or a C/C++ caller binds to.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * What each entry point replaces in the reference (KrainskiL/CGE.jl v2.0.2):
+ *   cge_landmarks_*      landmarks()        src/landmarks.jl:365-466  (+ runsplit :279-345, split rules :92-267)
+ *   cge_wgcl             wGCL()             src/divergence.jl:27-257
+ *   cge_wgcl (directed)  wGCL_directed()    src/divergence.jl:282-561
+ *   cge_score            example/CGE_CLI.jl:4-24 (landmarks() followed by wGCL*() on device-resident data)
+ *   cge_draw_samples     the `sample(E,..)` / `sample(NE,..)` draws, src/divergence.jl:184-210
+ *   cge_js / cge_idx     JS() / idx()       src/auxilary.jl:34-52, :57-59
+ *
+ * Conventions (exactly the reference's, so a Julia Array can be passed as is):
+ *   - vertex / community / landmark ids are 1-based int64;
+ *   - matrices are column-major: edges (m x 2) = two contiguous int64 columns `src`,`dst`;
+ *     an embedding (n x d) = d contiguous columns of n doubles;
+ *   - host pointers are BORROWED for the duration of the call, never retained, never written
+ *     (outputs excepted); outputs are caller-allocated;
+ *   - every function returns an int status (0 = ok, <0 = error; cge_last_error() has the text);
+ *     nothing throws or exits across the boundary;
+ *   - a cge_ctx is bound to ONE GPU and is not re-entrant: one host thread drives it.  Multi-GPU
+ *     runs are one process (one ctx) per GPU; the cross-GPU exchange steps go through the
+ *     cge_collectives hooks (RCCL via torch.distributed in the Python host).
+ *   - there is NO CPU fallback: without a gfx950 device cge_create fails with CGE_E_HIP.
+ */
+#ifndef CGE_HIP_H
+#define CGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGE_ABI_VERSION 1
+
+/* status codes; the Julia wrapper maps them back to the reference's exceptions */
+#define CGE_OK 0
+#define CGE_E_ASSERT (-1)        /* an @assert of the reference (src/divergence.jl:50,81,303,363; src/landmarks.jl:93,...) */
+#define CGE_E_HOMOGENEOUS (-2)   /* ErrorException("Trying to split homogenous cluster")  src/landmarks.jl:166 */
+#define CGE_E_EMPTY_CLUSTER (-3) /* ErrorException("Unexpected empty cluster generated")  src/landmarks.jl:298,306,325,333 */
+#define CGE_E_HIP (-4)           /* HIP runtime error / no device */
+#define CGE_E_COLLECTIVE (-5)    /* a collective hook failed */
+#define CGE_E_OOM (-6)
+#define CGE_E_ARG (-7)           /* bad argument at the boundary */
+
+/* split rule enum: the reference passes the function itself (src/auxilary.jl:64-67) */
+#define CGE_METHOD_RSS 0
+#define CGE_METHOD_RSS2 1
+#define CGE_METHOD_SIZE 2
+#define CGE_METHOD_DIAMETER 3
+
+typedef struct cge_ctx cge_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* `stream`: a hipStream_t to launch on (NULL = the library creates its own).  Passing the host
+ * framework's stream keeps its events/collectives ordered with the library's kernels.          */
+int cge_create(cge_ctx **out, int device, void *stream);
+void cge_destroy(cge_ctx *ctx);
+const char *cge_last_error(const cge_ctx *ctx);
+int cge_abi_version(void);
+int cge_set_host_threads(cge_ctx *ctx, int n_threads); /* host worker pool for eigenvectors / cut rules */
+
+/* Cross-GPU hooks (optional).  `buf` is a DEVICE pointer into the ctx's exchange buffer (obtain it
+ * with cge_exchange_buffer and wrap it once on the host side); count is in doubles.  The hook must
+ * order itself after work already enqueued on the ctx stream and leave the reduced data in place
+ * (stream-ordered or synchronous).  op: 0 = sum, 1 = max.                                        */
+typedef struct {
+    int (*allreduce_f64)(void *user, void *buf, int64_t count, int op);
+    void *user;
+    int rank, world;
+} cge_collectives;
+int cge_set_collectives(cge_ctx *ctx, const cge_collectives *coll);
+int cge_exchange_buffer(cge_ctx *ctx, int64_t min_doubles, void **dev_ptr, int64_t *capacity_doubles);
+
+/* ---- resident inputs (the ORIGINAL graph; uploaded once, H2D + layout change) --------------- */
+/* src/dst: the two columns of the reference's `edges::Matrix{Int}` (src/auxilary.jl:106); w: eweights */
+int cge_set_graph(cge_ctx *ctx, const int64_t *src, const int64_t *dst, const double *w, int64_t m, int64_t n);
+/* embedding::Matrix{Float64} n x d column-major (src/auxilary.jl:164) */
+int cge_set_embedding(cge_ctx *ctx, const double *X_colmajor, int64_t n, int64_t d);
+/* comm::Matrix{Int} n x 1 (src/auxilary.jl:122-139) and vweight (src/auxilary.jl:104-110) */
+int cge_set_vertex_data(cge_ctx *ctx, const int64_t *comm, const double *vweights, int64_t n);
+
+/* ---- landmarks(): src/landmarks.jl:365-466 --------------------------------------------------- */
+/* clusters::Vector{Vector{Int}} as CSR: members clusters_flat[off[c] .. off[c+1]) (1-based ids).
+ * Runs on the resident inputs; results stay on the device (for cge_wgcl / cge_score) and can be
+ * fetched.  `*N_out` = number of landmarks, `*n_ledges_out` = rows of landmark_edges (w > 0),
+ * `*truncated` = 1 when the reference's @warn at :374 would have fired.                          */
+int cge_landmarks_run(cge_ctx *ctx, const int64_t *clusters_flat, const int64_t *clusters_off, int64_t n_clusters,
+                      int64_t land, int64_t forced, int method, int directed, int64_t *N_out,
+                      int64_t *n_ledges_out, int *truncated);
+/* the reference's 7-tuple (src/landmarks.jl:465): dii[N], embed[N x d col-major], cluster[N],
+ * landmark_edges[n_ledges x 2 col-major], weights[n_ledges], lweight[N], v_to_l[n]              */
+int cge_landmarks_fetch(cge_ctx *ctx, double *dii, double *embed, int64_t *cluster, int64_t *ledges,
+                        double *lweights_e, double *lweight, int64_t *v_to_l);
+/* runsplit() alone (src/landmarks.jl:279-345): 0-based group ids, for parity tests              */
+int cge_runsplit(cge_ctx *ctx, const int64_t *clusters_flat, const int64_t *clusters_off, int64_t n_clusters,
+                 int64_t nland, int64_t forced, int method, int64_t *group_ids);
+
+/* ---- local-score samples --------------------------------------------------------------------- */
+/* Counter-based draws (documented in DESIGN.md; the Julia stream cannot be reproduced):
+ * pos_idx[k] uniform in 1..m (rows of the original edge list, `sample(E,S,replace=true)`),
+ * (neg_i,neg_j)[k] uniform over NON-edges of the resident graph (`sample(NE,S,replace=true)`),
+ * by rejection against the resident edge list, i<j for undirected, ordered i!=j for directed.
+ * `stream_id` selects an independent stream (the alpha index when the run is unseeded).          */
+int cge_draw_samples(cge_ctx *ctx, int64_t seed, int64_t stream_id, int64_t S, int directed, int64_t *pos_idx,
+                     int64_t *neg_i, int64_t *neg_j);
+
+/* ---- wGCL() / wGCL_directed(): src/divergence.jl:27-31, :282-286 -------------------------------- */
+typedef struct {
+    /* the 15 reference arguments, pointer + length */
+    const int64_t *edges_src, *edges_dst; /* edges (m x 2)                     */
+    const double *eweights;              /* m                                  */
+    int64_t m;
+    const int64_t *comm;                 /* comm (N x 1)                       */
+    int64_t n_comm;
+    const double *embed;                 /* N x d column-major                 */
+    int64_t embed_rows, d;
+    const double *distances;             /* N                                  */
+    int64_t n_distances;
+    const double *vweights;              /* N                                  */
+    const double *init_vweights;         /* n or empty                         */
+    int64_t n_init;
+    const int64_t *v_to_l;               /* n or empty (empty <=> exact mode, src/divergence.jl:44) */
+    int64_t n_v_to_l;
+    const int64_t *init_edges_src, *init_edges_dst; /* m_init x 2 or empty    */
+    int64_t m_init;
+    const double *init_eweights;
+    const double *init_embed;            /* n x d column-major or empty        */
+    int split;                           /* --split-global                     */
+    int64_t seed;                        /* -1 = unseeded                      */
+    int64_t auc_samples;
+    int verbose;
+    int directed;                        /* 0: wGCL, 1: wGCL_directed          */
+    /* optional pre-drawn samples so the caller can own the RNG (n_sets = 1, or one set per alpha);
+     * NULL => the library draws them with cge_draw_samples(seed, ...)                              */
+    const int64_t *pos_idx, *neg_i, *neg_j, *pos_idx2;
+    int64_t n_sample_sets;
+} cge_wgcl_args;
+
+/* per-alpha trace (optional, for parity tests and the bench's evaluation count)                 */
+typedef struct {
+    int64_t n_alpha;
+    int64_t iters[64];
+    double div[64];
+    double auc[64];
+} cge_trace;
+
+/* Host-array form: uploads what it is given, runs on the GPU, returns the reference's vector:
+ * [best_alpha, best_div, best_div_ext, best_div_int, best_alpha_auc, best_auc, best_auc_err]
+ * (*out_len = 7; 6 for the directed star-graph early return, src/divergence.jl:332-334).          */
+int cge_wgcl(cge_ctx *ctx, const cge_wgcl_args *args, double out[7], int *out_len, cge_trace *trace);
+
+/* Device-resident form of example/CGE_CLI.jl:10-24: landmarks() on the resident inputs, then
+ * wGCL*() in landmark mode, with no host round trip of the landmark graph.  land = -1 runs
+ * the exact mode on the resident graph (distances = zeros, CGE_CLI.jl:4).                         */
+typedef struct {
+    const int64_t *clusters_flat, *clusters_off;
+    int64_t n_clusters;
+    int64_t land, forced;
+    int method, directed, split;
+    int64_t seed, auc_samples;
+} cge_score_args;
+int cge_score(cge_ctx *ctx, const cge_score_args *args, double out[7], int *out_len, cge_trace *trace);
+
+/* ---- small helpers (same arithmetic as the reference helpers, host side) -------------------- */
+int64_t cge_idx(int64_t n, int64_t i, int64_t j);                                   /* src/auxilary.jl:57-59 */
+int cge_js(cge_ctx *ctx, const double *vC, const double *vB, int64_t len, const uint8_t *vI, int internal,
+           double *out);                                                            /* src/auxilary.jl:34-52 (device) */
+
+/* ---- kernel-level entry points (device work units; used by the parity tests and the bench) -- */
+/* per-edge scatter (src/landmarks.jl:433-451 + src/divergence.jl:59-63) on the resident edge list,
+ * rows [e0,e1): wedges_out (N x N doubles, [a-1 + (b-1)*N], a<=b when !directed) and vect_C
+ * (packed p(C) when !directed, C*C when directed) are HOST outputs (may be NULL).                */
+int cge_edge_scatter(cge_ctx *ctx, const int64_t *v_to_l, int64_t N, int64_t C, int directed, int64_t e0,
+                     int64_t e1, double *wedges_out, double *vect_C_out);
+/* point-set diameter `hi` = maximum(full_graph_D) (src/divergence.jl:104-113) of the resident
+ * embedding.  Shard `part` of `nparts` visits its share of the pair tiles (nparts = 1: all);
+ * returns the distance of the shard's arg-max pair computed with dist()'s own arithmetic
+ * (src/auxilary.jl:14-20), so the max over shards is the reference's `hi`.                      */
+int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *arg_i, int64_t *arg_j);
+
+/* ---- profiling ------------------------------------------------------------------------------ */
+/* When enabled, every launch of the named kernels is bracketed by hipEvents on the ctx stream.   */
+int cge_profile_enable(cge_ctx *ctx, int on);
+int cge_profile_reset(cge_ctx *ctx);
+/* name: "edge_scatter", "max_pair_dist", "fit_symv", ...; returns launches and total milliseconds */
+int cge_profile_get(cge_ctx *ctx, const char *name, int64_t *launches, double *total_ms);
+int cge_profile_names(cge_ctx *ctx, char *buf, int64_t buf_len); /* comma-separated */
+/* wall-clock phase timers of the last cge_score call: "landmarks","aggregate","scatter","dist",
+ * "diameter","sweep","samples" (milliseconds, host clock around stream-synchronised phases)      */
+int cge_phase_ms(cge_ctx *ctx, const char *phase, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGE_HIP_H */

@@ -1,0 +1,17 @@
+/* cge_hip_testing.h -- host-only hooks of libcge_hip.so used by the CPU test-suite (no GPU needed).
+ * They expose the product's own host routines (NOT the oracle's) so that `-m "not gpu"` tests can
+ * check them against the oracle. */
+#ifndef CGE_HIP_TESTING_H
+#define CGE_HIP_TESTING_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* principal eigenvector of a symmetric d x d matrix (replaces eigvecs(A)[:, end], src/landmarks.jl:99) */
+int cge_host_eig_top(const double *A, int64_t d, double *v);
+/* the sampler's counter-based draw of positive rows: pos_idx[k] in 1..m (no device work) */
+int cge_host_pos_draw(int64_t seed, int64_t stream_id, int64_t S, int64_t m, int64_t *pos_idx);
+#ifdef __cplusplus
+}
+#endif
+#endif

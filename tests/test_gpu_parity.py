@@ -1,0 +1,396 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C-ABI of
+libcge_hip.so and is compared with the CPU oracle on the same inputs, with the committed golden
+fixtures, or -- at sizes the oracle cannot reach -- through size-independent invariants.
+
+Tolerances: landmark / cluster ids, landmark edge lists and unit-weight sums are bit-exact;
+score-vector elements are compared at rtol 1e-9 (the north star allows 1e-6); best alphas exact.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, canonical_partition
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+README_KAT = [6.25, 0.002961243353776198, 0.0, 0.0, 9.75, 0.0017000000000000348, 0.000807441501038938]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from cge.jl_amd import api
+
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def synth20k():
+    from cge.jl_amd import synth
+
+    return synth.abcd_like(20000, 200000, 20, 32, seed=1)
+
+
+def _check_landmarks(got, ref, unit_weights=True):
+    names = ["dii", "embed", "cluster", "landmark_edges", "weights", "lweight", "v_to_l"]
+    assert np.array_equal(got[6], ref[6]), "v_to_l (raw landmark ids) differ"
+    assert np.array_equal(got[2], ref[2]), "landmark communities differ"
+    assert np.array_equal(got[3], ref[3]), "landmark edge list differs"
+    if unit_weights:
+        assert np.array_equal(got[4], ref[4]) and np.array_equal(got[5], ref[5])
+    else:
+        assert np.allclose(got[4], ref[4], rtol=1e-13, atol=0) and np.allclose(got[5], ref[5], rtol=1e-13, atol=0)
+    # same summation order, unfused arithmetic => bit-exact centroids and d_ii
+    assert np.array_equal(got[1], ref[1]), f"embed max diff {np.abs(got[1] - ref[1]).max()}"
+    assert np.array_equal(got[0], ref[0]), f"dii max diff {np.abs(got[0] - ref[0]).max()}"
+    for g, r, nm in zip(got, ref, names):
+        assert g.shape == r.shape and g.dtype == r.dtype, nm
+
+
+@pytest.mark.parametrize("method", ["rss", "rss2", "size", "diameter"])
+def test_landmarks_parity_reference_fixture(ctx, orc, test115, method):
+    """test/runtests.jl:43-93 (all four rules, -l 20 -f 1) -- values, not only types."""
+    import cge.jl_amd as cg
+
+    a = test115
+    args = (a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], a["embedding"], False, 20, 1, method,
+            False)
+    _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
+
+
+@pytest.mark.parametrize("method,land,forced", [("rss", 200, 4), ("rss2", 300, 2), ("size", 400, 4),
+                                                 ("diameter", 330, 3)])
+def test_landmarks_parity_example10k(ctx, orc, example10k, method, land, forced):
+    import cge.jl_amd as cg
+
+    a = example10k
+    args = (a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], a["embedding"], False, land, forced,
+            method, False)
+    got, ref = cg.landmarks(*args, ctx=ctx), orc.landmarks(*args)
+    _check_landmarks(got, ref)
+    assert np.array_equal(canonical_partition(got[6]), canonical_partition(ref[6]))
+
+
+@pytest.mark.parametrize("method", ["rss", "rss2", "size", "diameter"])
+def test_landmarks_parity_synthetic(ctx, orc, synth20k, method):
+    import cge.jl_amd as cg
+
+    g = synth20k
+    args = (g["edges"], g["eweights"], g["vweights"], g["clusters"], g["comm"], g["embedding"], False, 300, 4, method,
+            False)
+    _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
+
+
+def test_landmarks_weighted_directed_and_truncation(ctx, orc, test115):
+    import cge.jl_amd as cg
+
+    a = test115
+    w = a["eweights"] * 1.42  # test_weights.edgelist (test/runtests.jl:16)
+    vw = a["vweights"] * 1.42
+    args = (a["edges"], w, vw, a["clusters"], a["comm"], a["embedding"], False, 25, 2, "rss", True)
+    got, ref = cg.landmarks(*args, ctx=ctx), orc.landmarks(*args)
+    assert np.array_equal(got[6], ref[6]) and np.array_equal(got[3], ref[3])
+    assert np.allclose(got[4], ref[4], rtol=1e-13, atol=0)
+    assert got[4].sum() == pytest.approx(w.sum(), rel=1e-13)
+    # more landmarks than unique rows: clamp + warning path (src/landmarks.jl:373-376)
+    emb = a["embedding"].copy()
+    emb[50:] = emb[:65]  # 65 unique rows
+    got = cg.landmarks(a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], emb, False, 90, 1, "size",
+                       False, ctx=ctx)
+    ref = orc.landmarks(a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], emb, False, 90, 1, "size",
+                        False)
+    assert ctx.truncated and np.array_equal(got[6], ref[6]) and len(got[0]) == len(ref[0])
+
+
+def _cmp_result(res, exp, tr=None, etr=None):
+    assert len(res) == len(exp)
+    assert res[0] == exp[0] and res[4] == exp[4], (res, exp)  # best alphas
+    assert np.allclose(res, exp, rtol=RTOL, atol=1e-12), (res, exp)
+    if tr is not None:
+        assert tr["iters"] == etr["iters"], "Chung-Lu iteration counts differ"
+        assert np.allclose(tr["div"], etr["div"], rtol=RTOL, equal_nan=True)
+        assert np.allclose(tr["auc"], etr["auc"], rtol=RTOL, atol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_wgcl_reference_test_shape(ctx, orc, test115, split):
+    """test/runtests.jl:95-103: landmarks (diameter rule) then wGCL with empty v_to_l, seed 42, 10000 samples."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api
+
+    a = test115
+    lm = cg.landmarks(a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], a["embedding"], False, 20, 1,
+                      cg.split_cluster_diameter, False, ctx=ctx)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    # the library draws the samples itself (seeded); fetch the same draw for the oracle
+    res, tr = cg.wGCL(ledges, lw, lcomm, lemb, dii, lweight, *empty, split, 42, 10000, trace=True, ctx=ctx)
+    assert res.dtype == np.float64 and res[0] <= 10.0  # the reference's own assertions
+    smp = api.draw_samples(ctx, 42, 10000)  # resident graph == landmark graph after the exact-mode call
+    exp, etr = orc.wGCL(ledges, lw, lcomm, lemb, dii, lweight, *empty, split, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+    res2 = cg.wGCL(ledges, lw, lcomm, lemb, dii, lweight, *empty, split, samples=smp, ctx=ctx)
+    assert np.array_equal(res, res2)  # pre-drawn samples == library-drawn samples; run-to-run reproducible
+
+
+def test_wgcl_exact_mode_original_graph(ctx, orc, test115):
+    """CGE_CLI.jl without landmarks: distances = zeros, exact mode on the 115-vertex graph, unseeded sets."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api
+
+    a = test115
+    n = len(a["vweights"])
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    ctx.set_graph(a["edges"], a["eweights"], n)
+    smp = api.draw_samples(ctx, 7, 3000, n_sets=40)  # a fresh draw per alpha (seed == -1 semantics)
+    res, tr = cg.wGCL(a["edges"], a["eweights"], a["comm"], a["embedding"], np.zeros(n), a["vweights"], *empty, False,
+                      samples=smp, trace=True, ctx=ctx)
+    exp, etr = orc.wGCL(a["edges"], a["eweights"], a["comm"], a["embedding"], np.zeros(n), a["vweights"], *empty,
+                        False, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+
+
+def test_wgcl_landmark_mode_readme_known_answer(ctx, orc, example10k):
+    """README.md:88-100 end to end through landmarks() + wGCL() in landmark mode."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api
+
+    a = example10k
+    lm = cg.landmarks(a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], a["embedding"], False,
+                      a["land"], a["forced"], a["method"], False, ctx=ctx)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+    smp = api.draw_samples(ctx, 42, 10000)  # resident graph = the original 10k graph
+    res, tr = cg.wGCL(ledges, lw, lcomm, lemb, dii, lweight, a["vweights"], v2l, a["edges"], a["eweights"],
+                      a["embedding"], False, 42, 10000, samples=smp, trace=True, ctx=ctx)
+    assert res[0] == README_KAT[0] and res[1] == pytest.approx(README_KAT[1], rel=1e-9)
+    assert res[2] == 0.0 and res[3] == 0.0
+    assert abs(res[5] - README_KAT[5]) < 3 * (README_KAT[6] + res[6])  # Monte-Carlo element, other stream
+    exp, etr = orc.wGCL(ledges, lw, lcomm, lemb, dii, lweight, a["vweights"], v2l, a["edges"], a["eweights"],
+                        a["embedding"], False, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+    with open(os.path.join(GOLDEN, "oracle_generated.json")) as f:
+        gold = json.load(f)["example10k_l200_rss"]
+    assert tr["iters"] == gold["iters"] and np.allclose(tr["div"][: len(gold["div"])], gold["div"], rtol=RTOL, equal_nan=True)
+    # library-drawn samples (seed 42) give the same numbers as the pre-drawn ones
+    res2 = cg.wGCL(ledges, lw, lcomm, lemb, dii, lweight, a["vweights"], v2l, a["edges"], a["eweights"],
+                   a["embedding"], False, 42, 10000, ctx=ctx)
+    assert np.array_equal(res, res2)
+
+
+def test_score_fused_pipeline(ctx, orc, example10k):
+    """cge_score (device-resident CGE_CLI.jl flow) == landmarks() + wGCL() through host arrays."""
+    from cge.jl_amd import api
+
+    a = example10k
+    ctx.set_inputs(a["edges"], a["eweights"], a["vweights"], a["comm"], a["embedding"])
+    res = ctx.score(a["clusters"], a["land"], a["forced"], a["method"], seed=42, auc_samples=10000)
+    tr = ctx.last_trace
+    assert res[0] == README_KAT[0] and res[1] == pytest.approx(README_KAT[1], rel=1e-9)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = ctx.landmarks_fetch()
+    smp = api.draw_samples(ctx, 42, 10000)
+    exp, etr = orc.wGCL(ledges, lw, lcomm, lemb, dii, lweight, a["vweights"], v2l, a["edges"], a["eweights"],
+                        a["embedding"], False, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+    ph = ctx.phase_ms()
+    assert ph["sweep"] > 0 and ph["landmarks"] > 0 and ph["diameter"] > 0
+
+
+def test_wgcl_directed(ctx, orc, test115):
+    """wGCL_directed (never exercised by the reference's tests): exact mode, landmark mode, star guard."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api
+
+    a = test115
+    n = len(a["vweights"])
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    ctx.set_graph(a["edges"], a["eweights"], n)
+    p1, ni, nj = api.draw_samples(ctx, 5, 4000, directed=True)
+    p2, _, _ = api.draw_samples(ctx, 6, 4000, directed=True)
+    smp = (p1, ni, nj, p2)  # p2 = the overwriting second draw of src/divergence.jl:510
+    res, tr = cg.wGCL_directed(a["edges"], a["eweights"], a["comm"], a["embedding"], np.zeros(n), a["vweights"],
+                               *empty, True, samples=smp, trace=True, ctx=ctx)
+    exp, etr = orc.wGCL_directed(a["edges"], a["eweights"], a["comm"], a["embedding"], np.zeros(n), a["vweights"],
+                                 *empty, True, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+    # landmark mode, directed landmark graph
+    lm = cg.landmarks(a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], a["embedding"], False, 30, 2,
+                      "rss", True, ctx=ctx)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+    smp = api.draw_samples(ctx, 9, 5000, directed=True)
+    res, tr = cg.wGCL_directed(ledges, lw, lcomm, lemb, dii, lweight, a["vweights"], v2l, a["edges"], a["eweights"],
+                               a["embedding"], False, samples=smp, trace=True, ctx=ctx)
+    exp, etr = orc.wGCL_directed(ledges, lw, lcomm, lemb, dii, lweight, a["vweights"], v2l, a["edges"],
+                                 a["eweights"], a["embedding"], False, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+    # star graph: 6-element early return (src/divergence.jl:332-334)
+    k = 12
+    star = np.asfortranarray(np.stack([np.ones(k - 1, np.int64), np.arange(2, k + 1)], axis=1))
+    out = cg.wGCL_directed(star, np.ones(k - 1), np.ones((k, 1), np.int64), np.random.default_rng(0).random((k, 4)),
+                           np.zeros(k), np.ones(k), *empty, False, 1, 10, ctx=ctx)
+    assert list(out) == [-1.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+
+
+def test_wgcl_asserts_mirror_reference(ctx, test115):
+    import cge.jl_amd as cg
+    from cge.jl_amd import api
+
+    a = test115
+    n = len(a["vweights"])
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    with pytest.raises(AssertionError):  # src/divergence.jl:50
+        cg.wGCL(a["edges"], a["eweights"], a["comm"][:-1], a["embedding"], np.zeros(n), a["vweights"], *empty, False,
+                1, 100, ctx=ctx)
+    with pytest.raises(AssertionError):  # src/divergence.jl:81
+        cg.wGCL(a["edges"], a["eweights"], a["comm"], a["embedding"], np.zeros(n - 1), a["vweights"], *empty, False,
+                1, 100, ctx=ctx)
+    emb = np.tile(a["embedding"][:1], (n, 1))  # homogeneous cluster: src/landmarks.jl:165-167
+    with pytest.raises(api.CGEError, match="homogenous"):
+        cg.landmarks(a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], emb, False, 1, 3, "rss",
+                     False, ctx=ctx)
+
+
+@pytest.mark.parametrize("directed", [False, True])
+def test_edge_scatter_kernel(ctx, synth20k, directed):
+    g = synth20k
+    n, C = g["n"], g["C"]
+    rng = np.random.default_rng(3)
+    N = 77
+    comm = g["comm"][:, 0]
+    v2l = np.zeros(n, dtype=np.int64)  # landmarks nested in communities
+    for c in range(1, C + 1):
+        idx = np.flatnonzero(comm == c)
+        v2l[idx] = rng.integers(0, 3, size=len(idx)) + 3 * (c - 1) + 1
+    w = rng.integers(1, 5, size=g["m"]).astype(np.float64) * 0.5  # exactly representable => order independent
+    ctx.set_graph(g["edges"], w, n)
+    ctx.set_vertex_data(g["comm"], g["vweights"])
+    wed, vc = ctx.edge_scatter(v2l, N, C, directed)
+    a, b = v2l[g["edges"][:, 0] - 1], v2l[g["edges"][:, 1] - 1]
+    ca, cb = comm[g["edges"][:, 0] - 1], comm[g["edges"][:, 1] - 1]
+    if not directed:
+        a, b = np.minimum(a, b), np.maximum(a, b)
+        ca, cb = np.minimum(ca, cb), np.maximum(ca, cb)
+    exp = np.zeros((N, N))
+    np.add.at(exp, (a - 1, b - 1), w)
+    assert np.array_equal(wed, exp) and wed.sum() == w.sum()
+    if directed:
+        expc = np.zeros(C * C)
+        np.add.at(expc, (ca - 1) * C + cb - 1, w)
+    else:
+        from oracle import oracle as o
+
+        expc = np.zeros(C * (C + 1) // 2)
+        np.add.at(expc, np.array([o.idx(C, int(x), int(y)) - 1 for x, y in zip(ca, cb)]), w)
+    assert np.array_equal(vc, expc)
+    # a shard of the edge list (multi-GPU path): partial sums add up
+    w1, c1 = ctx.edge_scatter(v2l, N, C, directed, 0, g["m"] // 3)
+    w2, c2 = ctx.edge_scatter(v2l, N, C, directed, g["m"] // 3, g["m"])
+    assert np.array_equal(w1 + w2, exp) and np.array_equal(c1 + c2, expc)
+
+
+@pytest.mark.parametrize("n,d", [(10000, 32), (2999, 37), (777, 128), (130, 5)])
+def test_max_pair_dist_kernel(ctx, orc, example10k, n, d):
+    """fp64-MFMA diameter kernel vs the O(n^2 d) brute force (src/divergence.jl:104-113)."""
+    if (n, d) == (10000, 32):
+        emb = example10k["embedding"]
+    else:
+        rng = np.random.default_rng(n + d)
+        emb = np.asfortranarray(rng.standard_normal((n, d)) * rng.random(d) + rng.standard_normal(d) * 3)
+    ctx.set_graph(np.array([[1, 2]]), [1.0], n)
+    ctx.set_embedding(emb)
+    hi, ai, aj = ctx.max_pair_dist()
+    exp = orc.max_pair_dist(emb)
+    assert hi == exp, (hi, exp)
+    assert 1 <= ai < aj <= n and np.sqrt(((emb[ai - 1] - emb[aj - 1]) ** 2).sum()) == pytest.approx(hi, rel=1e-14)
+    parts = [ctx.max_pair_dist(p, 3)[0] for p in range(3)]  # sharded over 3 ranks: max of the shards
+    assert max(parts) == exp
+
+
+def test_draw_samples_are_non_edges(ctx, synth20k):
+    from cge.jl_amd import api
+
+    g = synth20k
+    n = g["n"]
+    dense = np.asfortranarray(np.array([[i, j] for i in range(1, 41) for j in range(i + 1, 41) if (i + j) % 3], np.int64))
+    for edges, nn, directed in ((g["edges"], n, False), (g["edges"], n, True), (dense, 40, False)):
+        ctx.set_graph(edges, np.ones(len(edges)), nn)
+        pos, ni, nj = ctx.draw_samples(11, 20000, directed)
+        pos2, ni2, nj2 = ctx.draw_samples(11, 20000, directed)
+        assert np.array_equal(pos, pos2) and np.array_equal(ni, ni2) and np.array_equal(nj, nj2)
+        assert pos.min() >= 1 and pos.max() <= len(edges)
+        assert ni.min() >= 1 and nj.max() <= nn and np.all(ni != nj)
+        if directed:
+            eset = set(map(tuple, edges.tolist()))
+        else:
+            assert np.all(ni < nj)
+            eset = set(map(tuple, np.sort(edges, axis=1).tolist()))
+        assert not any((int(i), int(j)) in eset for i, j in zip(ni, nj))
+    # dense graph: the non-edge draw is uniform over the complement
+    ctx.set_graph(dense, np.ones(len(dense)), 40)
+    _, ni, nj = ctx.draw_samples(1, 60000)
+    comp = [(i, j) for i in range(1, 41) for j in range(i + 1, 41) if (i + j) % 3 == 0]
+    counts = np.array([np.sum((ni == i) & (nj == j)) for i, j in comp])
+    assert counts.sum() == 60000
+    chi2 = ((counts - 60000 / len(comp)) ** 2 / (60000 / len(comp))).sum()
+    assert chi2 < len(comp) + 6 * math.sqrt(2 * len(comp))
+
+
+def test_js_kernel(ctx, orc):
+    rng = np.random.default_rng(0)
+    for C, directed in ((7, False), (12, True), (64, False)):
+        ln = C * C if directed else C * (C + 1) // 2
+        p, q = rng.random(ln) * 50, rng.random(ln) * 50
+        assert ctx.js(p, q) == pytest.approx(orc.JS(p, q), rel=1e-12)
+        vI = np.zeros(ln, dtype=np.uint8)
+        if directed:
+            vI[:: C + 1] = 1
+        else:
+            vI[[orc.idx(C, i, i) - 1 for i in range(1, C + 1)]] = 1
+        assert ctx.js(p, q, vI, True) == pytest.approx(orc.JS(p, q, vI, True), rel=1e-12)
+        assert ctx.js(p, q, vI, False) == pytest.approx(orc.JS(p, q, vI, False), rel=1e-12)
+
+
+def test_larger_graph_invariants(ctx):
+    """n = 200k, m ~ 2M, d = 64, -l 600: beyond the oracle's reach in test time; size-independent
+    properties of the reference instead."""
+    from cge.jl_amd import synth
+
+    g = synth.abcd_like(200000, 2000000, 60, 64, seed=5)
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    res = ctx.score(g["clusters"], 600, 4, "rss", seed=42, auc_samples=20000)
+    tr = ctx.last_trace
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = ctx.landmarks_fetch()
+    N = len(dii)
+    assert N == 600 and v2l.min() == 1 and v2l.max() == N
+    comm = g["comm"][:, 0]
+    first = np.zeros(N + 1, dtype=np.int64)
+    first[v2l] = comm
+    assert np.array_equal(first[v2l], comm)  # every landmark inside one community
+    assert np.array_equal(lcomm[:, 0], first[1:])
+    assert lw.sum() == g["m"] and lweight.sum() == 2 * g["m"]  # unit weights: exact
+    assert np.bincount(v2l, weights=g["vweights"])[1:].tolist() == lweight.tolist()
+    cen = np.zeros((N, 64))
+    np.add.at(cen, v2l - 1, g["embedding"] * g["vweights"][:, None])
+    assert np.allclose(lemb, cen / lweight[:, None], rtol=1e-11, atol=1e-13)
+    assert np.all(np.isfinite(res)) and 0.25 <= res[0] <= 10 and 0 <= res[1] <= math.log(2)
+    assert 0 <= res[5] <= 1 and res[6] == pytest.approx(1.96 * math.sqrt(res[5] * (1 - res[5]) / 20000), rel=1e-12)
+    assert all(it >= 1 for it in tr["iters"]) and tr["n_alpha"] <= 40
+    best = np.nanargmin(tr["div"])
+    assert res[1] == tr["div"][best] and res[0] == 0.25 * (best + 1)
+    res2 = ctx.score(g["clusters"], 600, 4, "rss", seed=42, auc_samples=20000)
+    assert np.array_equal(res, res2)  # bitwise reproducible (no float atomics on the score path; unit weights)
+    hi, ai, aj = ctx.max_pair_dist()
+    rng = np.random.default_rng(0)
+    ii, jj = rng.integers(0, g["n"], 200000), rng.integers(0, g["n"], 200000)
+    assert hi >= np.sqrt(((g["embedding"][ii] - g["embedding"][jj]) ** 2).sum(1)).max()
