@@ -199,7 +199,14 @@ class Context:
         self.N, self.n_ledges, self.truncated = N.value, ne.value, bool(tr.value)
         return self.N, self.n_ledges, self.truncated
 
+    def landmarks_info(self):
+        N, ne, tr = C.c_int64(), C.c_int64(), C.c_int()
+        self._check(self.L.cge_landmarks_info(self.h, C.byref(N), C.byref(ne), C.byref(tr)))
+        self.N, self.n_ledges, self.truncated = N.value, ne.value, bool(tr.value)
+        return self.N, self.n_ledges, self.truncated
+
     def landmarks_fetch(self):
+        self.landmarks_info()  # sizes come from the library, never from Python-side state
         N, ne, n, d = self.N, self.n_ledges, self.n, self.d
         dii = np.zeros(N)
         embed = np.zeros((N, d), order="F")

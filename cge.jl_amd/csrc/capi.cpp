@@ -102,10 +102,19 @@ int cge_exchange_buffer(cge_ctx *c, int64_t min_doubles, void **dev_ptr, int64_t
     if (!c) return CGE_E_ARG;
     CGE_TRY(c)
     HIP_CHECK(hipSetDevice(c->device));
-    if ((size_t)min_doubles > c->xbuf.n || !c->xbuf.p) c->xbuf.alloc_exact((size_t)std::max<i64>(min_doubles, 1024));
-    if (dev_ptr) *dev_ptr = c->xbuf.p;
-    if (cap) *cap = (int64_t)c->xbuf.n;
+    if ((size_t)min_doubles > c->xown.n || !c->xown.p) c->xown.alloc_exact((size_t)std::max<i64>(min_doubles, 1024));
+    c->xptr = c->xown.p;
+    c->xcap = c->xown.n;
+    if (dev_ptr) *dev_ptr = c->xptr;
+    if (cap) *cap = (int64_t)c->xcap;
     CGE_CATCH(c)
+}
+
+int cge_set_exchange_buffer(cge_ctx *c, void *dev_ptr, int64_t cap) {
+    if (!c || !dev_ptr || cap < 1) return CGE_E_ARG;
+    c->xptr = (double *)dev_ptr;
+    c->xcap = (size_t)cap;
+    return CGE_OK;
 }
 
 // ---- resident inputs ------------------------------------------------------------------------------
@@ -235,13 +244,24 @@ static i64 clamp_to_unique_rows(cge_ctx *c, i64 land, int *truncated) {
 static void allreduce(cge_ctx *c, double *dev, i64 count, int op) {
     if (!c->has_coll) return;
     // the hook works on the ctx exchange buffer (the host side wrapped that pointer once)
-    if ((size_t)count > c->xbuf.n) CGE_THROW(CGE_E_COLLECTIVE, "exchange buffer too small: need %lld doubles", (long long)count);
-    if (dev != c->xbuf.p)
-        HIP_CHECK(hipMemcpyAsync(c->xbuf.p, dev, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
+    if (!c->xptr || (size_t)count > c->xcap)
+        CGE_THROW(CGE_E_COLLECTIVE, "exchange buffer too small: need %lld doubles, have %lld", (long long)count, (long long)c->xcap);
+    if (dev != c->xptr)
+        HIP_CHECK(hipMemcpyAsync(c->xptr, dev, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (c->coll.allreduce_f64(c->coll.user, c->xbuf.p, count, op) != 0) CGE_THROW(CGE_E_COLLECTIVE, "allreduce hook failed");
-    if (dev != c->xbuf.p)
-        HIP_CHECK(hipMemcpyAsync(dev, c->xbuf.p, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
+    if (c->coll.allreduce_f64(c->coll.user, c->xptr, count, op) != 0) CGE_THROW(CGE_E_COLLECTIVE, "allreduce hook failed");
+    if (dev != c->xptr)
+        HIP_CHECK(hipMemcpyAsync(dev, c->xptr, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
+}
+
+static double allreduce_scalar_max(cge_ctx *c, double v) {
+    if (!c->has_coll) return v;
+    if (!c->xptr || c->xcap < 1) CGE_THROW(CGE_E_COLLECTIVE, "no exchange buffer set");
+    HIP_CHECK(hipMemcpyAsync(c->xptr, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    allreduce(c, c->xptr, 1, 1);
+    HIP_CHECK(hipMemcpyAsync(&v, c->xptr, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return v;
 }
 
 static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 land, i64 forced,
@@ -332,6 +352,18 @@ int cge_landmarks_run(cge_ctx *c, const int64_t *cl_flat, const int64_t *cl_off,
     if (n_ledges_out) *n_ledges_out = c->n_ledges;
     if (truncated) *truncated = c->lm_truncated;
     CGE_CATCH(c)
+}
+
+int cge_landmarks_info(cge_ctx *c, int64_t *N_out, int64_t *n_ledges_out, int *truncated) {
+    if (!c) return CGE_E_ARG;
+    if (!c->lm_ready) {
+        c->err = "landmarks_info: run cge_landmarks_run first";
+        return CGE_E_ARG;
+    }
+    if (N_out) *N_out = c->N;
+    if (n_ledges_out) *n_ledges_out = c->n_ledges;
+    if (truncated) *truncated = c->lm_truncated;
+    return CGE_OK;
 }
 
 int cge_landmarks_fetch(cge_ctx *c, double *dii, double *embed, int64_t *cluster, int64_t *ledges, double *lw_e,
@@ -564,13 +596,7 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p;
         ov.lweight = c->s_vw.p; ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
         double hi = resident_diameter(c, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1, nullptr, nullptr);
-        if (c->has_coll) {
-            c->xbuf.ensure(1024);
-            HIP_CHECK(hipMemcpyAsync(c->xbuf.p, &hi, sizeof(double), hipMemcpyHostToDevice, st));
-            allreduce(c, c->xbuf.p, 1, 1);
-            HIP_CHECK(hipMemcpyAsync(&hi, c->xbuf.p, sizeof(double), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-        }
+        hi = allreduce_scalar_max(c, hi);
         ov.hi = hi;
     } else {
         // exact mode: make the score graph the resident graph so the sampler can reject its edges
@@ -622,13 +648,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
         ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
         double hi = resident_diameter(c, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1, nullptr, nullptr);
-        if (c->has_coll) {
-            c->xbuf.ensure(1024);
-            HIP_CHECK(hipMemcpyAsync(c->xbuf.p, &hi, sizeof(double), hipMemcpyHostToDevice, st));
-            allreduce(c, c->xbuf.p, 1, 1);
-            HIP_CHECK(hipMemcpyAsync(&hi, c->xbuf.p, sizeof(double), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-        }
+        hi = allreduce_scalar_max(c, hi);
         ov.hi = hi;
         c->phases.ms["diameter"] = now_ms() - t0;
     } else {

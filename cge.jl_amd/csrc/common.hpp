@@ -96,7 +96,9 @@ struct cge_ctx {
     int n_threads = 8;
     cge_collectives coll{};
     bool has_coll = false;
-    DevBuf<double> xbuf; // exchange buffer for collectives
+    DevBuf<double> xown;  // library-owned exchange buffer (cge_exchange_buffer)
+    double *xptr = nullptr; // exchange buffer in use (library- or caller-owned)
+    size_t xcap = 0;
 
     // ---- resident original graph --------------------------------------------------------
     i64 n = 0, m = 0, d = 0;

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(const i32 *__restrict
     for (i64 e = e0 + (i64)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += stride) {
         const i32 u = src[e], v = dst[e];
         const double we = w ? w[e] : 1.0;
-        i64 a = v2l[u], b = v2l[v];
+        i64 a = v2l ? v2l[u] : 0, b = v2l ? v2l[v] : 0; // v2l == nullptr: vect_C only (wedges must be null)
         i64 cu = comm[u], cv = comm[v];
         if (!directed) {
             if (a > b) { i64 t = a; a = b; b = t; }

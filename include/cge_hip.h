@@ -73,6 +73,8 @@ typedef struct {
 } cge_collectives;
 int cge_set_collectives(cge_ctx *ctx, const cge_collectives *coll);
 int cge_exchange_buffer(cge_ctx *ctx, int64_t min_doubles, void **dev_ptr, int64_t *capacity_doubles);
+/* or hand the library a caller-owned device buffer (e.g. a torch tensor) to use as exchange buffer */
+int cge_set_exchange_buffer(cge_ctx *ctx, void *dev_ptr, int64_t capacity_doubles);
 
 /* ---- resident inputs (the ORIGINAL graph; uploaded once, H2D + layout change) --------------- */
 /* src/dst: the two columns of the reference's `edges::Matrix{Int}` (src/auxilary.jl:106); w: eweights */
@@ -90,6 +92,8 @@ int cge_set_vertex_data(cge_ctx *ctx, const int64_t *comm, const double *vweight
 int cge_landmarks_run(cge_ctx *ctx, const int64_t *clusters_flat, const int64_t *clusters_off, int64_t n_clusters,
                       int64_t land, int64_t forced, int method, int directed, int64_t *N_out,
                       int64_t *n_ledges_out, int *truncated);
+/* sizes of the landmark state produced by the last cge_landmarks_run / cge_score on this ctx */
+int cge_landmarks_info(cge_ctx *ctx, int64_t *N_out, int64_t *n_ledges_out, int *truncated);
 /* the reference's 7-tuple (src/landmarks.jl:465): dii[N], embed[N x d col-major], cluster[N],
  * landmark_edges[n_ledges x 2 col-major], weights[n_ledges], lweight[N], v_to_l[n]              */
 int cge_landmarks_fetch(cge_ctx *ctx, double *dii, double *embed, int64_t *cluster, int64_t *ledges,
