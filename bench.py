@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- edge-alpha evaluations/s of the divergence-scoring hot path on MI355X.
+
+One step = example/CGE_CLI.jl:10-24 on device-resident inputs (cge_score): landmarks()
+(runsplit + aggregation + per-edge scatter) followed by wGCL() in landmark mode (diameter of the
+original embedding, landmark distance matrix, 40-step alpha sweep with Chung-Lu fit, JS and local
+score).  metric = m * A / T  (m original edges, A alphas evaluated, T wall time per step).
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json "metric": 10M-edge d=128 ABCD graph ("headline metric" row)
+    "headline": dict(n=1_000_000, m=10_000_000, C=500, d=128, land=4000, forced=4, method="rss", samples=10000),
+    # configs[1]: ABCD 100k nodes / 1M edges, d=64, -l 400 -m rss2
+    "cfg2": dict(n=100_000, m=1_000_000, C=50, d=64, land=400, forced=4, method="rss2", samples=10000),
+    "small": dict(n=50_000, m=500_000, C=25, d=128, land=200, forced=4, method="rss", samples=10000),
+}
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; MI355X_MICROARCH.md lists no f64 row)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(g, wl, budget_vertices=25000):
+    """The oracle (single-thread C restatement of the reference) on a bounded sample of the SAME graph:
+    the sub-graph induced by the first communities (~budget_vertices vertices), landmarks scaled by the
+    same ratio; call shape = landmarks() then wGCL(..., v_to_l = Int[]) on the landmark graph
+    (test/runtests.jl:95-96; BASELINE.md item 5: the reference cannot build its O(n^2) objects here)."""
+    from oracle import oracle as orc
+
+    comm = g["comm"][:, 0]
+    sizes = np.bincount(comm)[1:]
+    k = int(np.searchsorted(np.cumsum(sizes), budget_vertices)) + 1
+    k = max(2, min(k, len(sizes)))
+    keep = comm <= k
+    newid = np.cumsum(keep)  # 1-based ids of the kept vertices
+    e = g["edges"]
+    em = keep[e[:, 0] - 1] & keep[e[:, 1] - 1]
+    edges = np.asfortranarray(np.stack([newid[e[em, 0] - 1], newid[e[em, 1] - 1]], axis=1))
+    ew = g["eweights"][em]
+    n_s = int(keep.sum())
+    vw = np.zeros(n_s)
+    np.add.at(vw, edges[:, 0] - 1, ew)
+    np.add.at(vw, edges[:, 1] - 1, ew)
+    ok = vw > 0  # the induced sub-graph may isolate a few vertices: give them a unit weight instead of dropping
+    vw[~ok] = 1.0
+    emb = np.asfortranarray(g["embedding"][keep])
+    cm = np.asfortranarray(comm[keep].reshape(-1, 1))
+    clusters = [np.flatnonzero(cm[:, 0] == c) + 1 for c in range(1, k + 1)]
+    land = max(4 * k, int(round(wl["land"] * n_s / g["n"])))
+    rng = np.random.default_rng(42)
+    t0 = time.perf_counter()
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = orc.landmarks(edges, ew, vw, clusters, cm, emb, False, land,
+                                                               wl["forced"], wl["method"], False)
+    N = len(dii)
+    S = wl["samples"]
+    pos = rng.integers(1, len(lw) + 1, size=(1, S))
+    ni = rng.integers(1, N + 1, size=(1, S))
+    nj = rng.integers(1, N + 1, size=(1, S))
+    nj[ni == nj] = nj[ni == nj] % N + 1
+    res, tr = orc.wGCL(ledges, lw, lcomm, lemb, dii, lweight, [], [], np.zeros((0, 2), np.int64), [],
+                       np.zeros((0, 0)), False, (pos, ni, nj), trace=True)
+    t = time.perf_counter() - t0
+    A = len(tr["iters"])
+    return {"value": len(ew) * A / t, "unit": "edge-alpha evals/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (oracle/cge_oracle.c, 1 thread) on the sub-graph induced by the first {k} communities "
+                      f"of the bench graph: n={n_s}, m={len(ew)}, d={emb.shape[1]}, {N} landmarks; landmarks() + "
+                      f"wGCL(v_to_l=Int[]) on the landmark graph, {A} alphas, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=42)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        log("bench.py: no GPU visible; the hot path has no CPU fallback")
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    from cge.jl_amd import api, synth
+
+    if not os.path.exists(api.library_path()):
+        if local_rank == 0:
+            ge.build()
+        if world > 1:
+            dist.barrier()
+    wl = WORKLOADS[args.workload]
+    t0 = time.perf_counter()
+    g = synth.abcd_like(wl["n"], int(wl["m"] * 1.05), wl["C"], wl["d"], seed=args.seed)
+    if rank == 0:
+        log(f"[bench] synthetic ABCD-like graph: n={g['n']} m={g['m']} d={g['d']} C={g['C']} ({time.perf_counter()-t0:.1f} s)")
+    ctx = api.Context(local_rank)
+    t0 = time.perf_counter()
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    t_upload = time.perf_counter() - t0
+    coll = None
+    if world > 1:
+        from cge.jl_amd.dist import TorchCollectives
+
+        coll = TorchCollectives(ctx, wl["land"] * wl["land"] * 2 + 1024, dev)
+
+    def step():
+        return ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], seed=args.seed,
+                         auc_samples=wl["samples"])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = ctx.profile()
+    phases = ctx.phase_ms()
+    trace = ctx.last_trace
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    A = trace["n_alpha"]
+    sec_per_step = elapsed / max(1, args.steps)
+    value = g["m"] * A / sec_per_step
+
+    def kern(name):
+        p = prof.get(name, {"launches": 0, "total_ms": 0.0})
+        return p["launches"], (p["total_ms"] / p["launches"] if p["launches"] else float("nan"))
+
+    # dominant kernel: the fp64-MFMA diameter kernel.  Algorithmic work = 2*d flops per unordered vertex
+    # pair x the pairs ONE launch visits (this rank's share of the n(n-1)/2 pairs).
+    n, d = g["n"], g["d"]
+    launches, mp_ms = kern("max_pair_dist")
+    pair_share = n * (n - 1) / 2 / world
+    mp_tflops = (2.0 * d * pair_share) / (mp_ms * 1e-3) / 1e12 if launches else float("nan")
+    roofline = {"kernel": "max_pair_kernel (fp64 MFMA 16x16x4)", "bound": "mfma", "achieved": mp_tflops,
+                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mp_tflops / F64_MFMA_PEAK_TFLOPS,
+                "traffic": None, "avg_launch_ms": mp_ms, "launches": launches,
+                "algorithmic_flops_per_launch": 2.0 * d * pair_share}
+    es_l, es_ms = kern("edge_scatter")
+    m_share = g["m"] / world
+    es_gbs = 24.0 * m_share / (es_ms * 1e-3) / 1e9 if es_l else float("nan")
+    kernels = {
+        "edge_scatter": {"bound": "hbm", "achieved": es_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": es_gbs / HBM_PEAK_GBS, "avg_launch_ms": es_ms, "launches": es_l,
+                         "algorithmic_bytes_per_launch": 24.0 * m_share},
+    }
+    for name in prof:
+        if name not in ("max_pair_dist", "edge_scatter"):
+            l_, ms_ = kern(name)
+            kernels[name] = {"avg_launch_ms": ms_, "launches": l_}
+    out = {
+        "metric": "edge_alpha_evals_per_sec", "value": value, "unit": "edge-alpha evals/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: ABCD-like n={n} m={g['m']} d={d} C={g['C']}, -l {wl['land']} "
+                               f"-f {wl['forced']} -m {wl['method']} --seed {args.seed} --samples-local {wl['samples']}; "
+                               f"landmarks() + wGCL() in landmark mode, inputs resident in HBM",
+                   "n": n, "m": g["m"], "d": d, "communities": g["C"], "landmarks": int(ctx.landmarks_info()[0]),
+                   "alphas_evaluated": A, "parallelism": f"edges+pair-tiles sharded over {world} GPU(s)"},
+        "roofline": roofline, "kernels": kernels, "phases_ms": phases,
+        "result": [float(x) for x in res], "upload_s": t_upload,
+    }
+    if coll is not None:
+        out["collectives"] = {"allreduce_calls_per_step": coll.n_calls / (args.steps + args.warmup),
+                              "bytes_per_step": coll.bytes / (args.steps + args.warmup)}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(g, wl)
+        except Exception as e:  # the baseline is reported, never required for the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "edge-alpha evals/s", "cores": 1, "kind": "port",
+                                   "sample": f"failed: {e!r}"}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

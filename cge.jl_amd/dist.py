@@ -1,0 +1,77 @@
+"""One process per GPU: sharding + the collective hooks of the C-ABI, over torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
+
+What is sharded:
+  * the per-edge scatter: rank r takes the edge rows [m*r/W, m*(r+1)/W); one all-reduce(sum) of the
+    N x N landmark-pair matrix and one of vect_C;
+  * the point-set diameter: rank r takes the super-block rows SI = r (mod W); one all-reduce(max) of a scalar;
+and what is replicated: runsplit (bit-identical on every rank) and the alpha sweep (sequentially
+dependent, cache-resident).  No other collective is issued.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def edge_shard(m: int, rank: int, world: int):
+    """Rows of the edge list owned by `rank` -- the same formula as capi.cpp:landmarks_run_impl."""
+    return m * rank // world, m * (rank + 1) // world
+
+
+def diameter_shard(n_super_rows: int, rank: int, world: int):
+    """Super-block rows owned by `rank` (kernels_dist.hip: SI % nparts == part)."""
+    return [si for si in range(n_super_rows) if si % world == rank]
+
+
+class TorchCollectives:
+    """Implements cge_collectives.allreduce_f64 on a torch tensor that doubles as the library's
+    exchange buffer (cge_set_exchange_buffer)."""
+
+    def __init__(self, ctx, capacity_doubles: int, device):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.buf = torch.zeros(int(capacity_doubles), dtype=torch.float64, device=device)
+        self.base = self.buf.data_ptr()
+        self.n_calls = 0
+        self.bytes = 0
+        ctx._check(ctx.L.cge_set_exchange_buffer(ctx.h, _vp(self.base), _i64(self.buf.numel())))
+        ctx.set_collectives(self._hook, self.rank, self.world)
+
+    def _hook(self, user, ptr, count, op):
+        try:
+            off = (int(ptr) - self.base) // 8
+            t = self.buf[off: off + int(count)]
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM)
+            if t.is_cuda:
+                self.torch.cuda.synchronize(t.device)
+            self.n_calls += 1
+            self.bytes += int(count) * 8
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print(f"[cge.dist] allreduce hook failed: {e!r}", flush=True)
+            return 1
+
+
+def _vp(x):
+    import ctypes as C
+
+    return C.c_void_p(x)
+
+
+def _i64(x):
+    import ctypes as C
+
+    return C.c_int64(x)
+
+
+def allreduce_numpy(arr: np.ndarray, op: str = "sum"):
+    """Host-side reduction used by the gloo tests of the sharding logic."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return t.numpy()

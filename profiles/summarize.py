@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarises the rocprofv3 CSVs of profiles/run_profiles.sh into a small markdown table:
+per-kernel calls / total / average duration (kernel-trace --stats) and FETCH_SIZE / WRITE_SIZE per
+launch (PMC passes; FETCH_SIZE x2 on gfx950 for wide coalesced reads, MI355X_MICROARCH.md §HBM)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def find(sub, pat):
+    hits = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.replace("void ", "").strip()
+
+
+print(f"# rocprofv3 summary {tag}\n")
+ks = find("stats", "*kernel_stats.csv")
+if ks:
+    print("## kernel-trace --stats (bench.py --steps 1 --warmup 1)\n")
+    print("| kernel | calls | total ms | avg ms | % |")
+    print("|---|---|---|---|---|")
+    rows = list(csv.DictReader(open(ks)))
+    for r in rows[:25]:
+        print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
+              f"{float(r['AverageNs'])/1e6:.4f} | {float(r['Percentage']):.2f} |")
+for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    cc = find(sub, "*counter_collection.csv")
+    if not cc:
+        continue
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(cc)):
+        if r.get("Counter_Name") != ctr:
+            continue
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    print(f"\n## --pmc {ctr} (own pass)\n")
+    print(f"| kernel | launches | {ctr} sum (KiB) | per launch (MB) | gfx950-corrected per launch (MB) |")
+    print("|---|---|---|---|---|")
+    for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
+        per = v * 1024 / n / 1e6
+        corr = per * 2 if ctr == "FETCH_SIZE" else per
+        print(f"| {k} | {n} | {v:.0f} | {per:.2f} | {corr:.2f} |")
