@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--diameter", type=int, default=0, help="0 auto (pruned, brute-force fallback), 1 brute force, 2 pruned")
     args = ap.parse_args()
 
     import torch
@@ -129,6 +130,7 @@ def main():
     t0 = time.perf_counter()
     ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
     t_upload = time.perf_counter() - t0
+    ctx.set_option("diameter", args.diameter)
     coll = None
     if world > 1:
         from cge.jl_amd.dist import TorchCollectives
@@ -175,28 +177,43 @@ def main():
         p = prof.get(name, {"launches": 0, "total_ms": 0.0})
         return p["launches"], (p["total_ms"] / p["launches"] if p["launches"] else float("nan"))
 
-    # dominant kernel: the fp64-MFMA diameter kernel.  Algorithmic work = 2*d flops per unordered vertex
-    # pair x the pairs ONE launch visits (this rank's share of the n(n-1)/2 pairs).
-    n, d = g["n"], g["d"]
-    launches, mp_ms = kern("max_pair_dist")
-    pair_share = n * (n - 1) / 2 / world
-    mp_tflops = (2.0 * d * pair_share) / (mp_ms * 1e-3) / 1e12 if launches else float("nan")
-    roofline = {"kernel": "max_pair_kernel (fp64 MFMA 16x16x4)", "bound": "mfma", "achieved": mp_tflops,
-                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mp_tflops / F64_MFMA_PEAK_TFLOPS,
-                "traffic": None, "avg_launch_ms": mp_ms, "launches": launches,
-                "algorithmic_flops_per_launch": 2.0 * d * pair_share}
-    es_l, es_ms = kern("edge_scatter")
-    m_share = g["m"] / world
-    es_gbs = 24.0 * m_share / (es_ms * 1e-3) / 1e9 if es_l else float("nan")
-    kernels = {
-        "edge_scatter": {"bound": "hbm", "achieved": es_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": es_gbs / HBM_PEAK_GBS, "avg_launch_ms": es_ms, "launches": es_l,
-                         "algorithmic_bytes_per_launch": 24.0 * m_share},
+    # Roofline per kernel: ALGORITHMIC work of one launch / average launch time measured
+    # with HIP events on the library's stream.  The `roofline` object is the kernel with the largest total time.
+    n, d, N = g["n"], g["d"], int(ctx.landmarks_info()[0])
+    hi, dpath, cand_pairs, cand_tiles = ctx.last_diameter()
+    steps_prof = max(1, args.steps)
+    work = {  # name -> (bound, peak, unit, algorithmic work per launch, note)
+        "max_pair_dist": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", 2.0 * d * (n * (n - 1) / 2) / world,
+                          "fp64 MFMA, 2d flop per unordered vertex pair, all pairs"),
+        "pcent": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", 2.0 * d * n * N,
+                  "fp64 MFMA, 2d flop per (vertex, landmark centroid) pair"),
+        "pair_list": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", None,
+                      "fp64 MFMA, 2d flop per vertex pair of the candidate 128x128 tiles"),
+        "fit_symv": ("hbm", HBM_PEAK_GBS, "GB/s", 8.0 * N * (N + 1) / 2,
+                     "8 B per unordered landmark pair per Chung-Lu iteration"),
+        "edge_scatter": ("hbm", HBM_PEAK_GBS, "GB/s", 24.0 * g["m"] / world, "24 B per edge (2 x Int64 + Float64)"),
     }
+    kernels = {}
     for name in prof:
-        if name not in ("max_pair_dist", "edge_scatter"):
-            l_, ms_ = kern(name)
-            kernels[name] = {"avg_launch_ms": ms_, "launches": l_}
+        l_, ms_ = kern(name)
+        ent = {"avg_launch_ms": ms_, "launches": l_, "total_ms_per_step": prof[name]["total_ms"] / steps_prof}
+        if name in work and l_:
+            bound, peak, unit, w, note = work[name]
+            if name == "pair_list":
+                w = 2.0 * d * 128 * 128 * cand_tiles / max(1, l_ / steps_prof)
+            ach = w / (ms_ * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+            ent.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                        "algorithmic_work_per_launch": w, "work_unit": "flop" if unit == "TFLOP/s" else "B",
+                        "note": note})
+        kernels[name] = ent
+    ranked = sorted((k for k in kernels if "frac" in kernels[k]), key=lambda k: -kernels[k]["total_ms_per_step"])
+    dom = ranked[0] if ranked else None
+    roofline = None
+    if dom:
+        e = kernels[dom]
+        roofline = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
+                    "frac": e["frac"], "traffic": None, "avg_launch_ms": e["avg_launch_ms"], "launches": e["launches"],
+                    "algorithmic_work_per_launch": e["algorithmic_work_per_launch"], "note": e["note"]}
     out = {
         "metric": "edge_alpha_evals_per_sec", "value": value, "unit": "edge-alpha evals/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
@@ -204,9 +221,11 @@ def main():
         "config": {"workload": f"{args.workload}: ABCD-like n={n} m={g['m']} d={d} C={g['C']}, -l {wl['land']} "
                                f"-f {wl['forced']} -m {wl['method']} --seed {args.seed} --samples-local {wl['samples']}; "
                                f"landmarks() + wGCL() in landmark mode, inputs resident in HBM",
-                   "n": n, "m": g["m"], "d": d, "communities": g["C"], "landmarks": int(ctx.landmarks_info()[0]),
+                   "n": n, "m": g["m"], "d": d, "communities": g["C"], "landmarks": N,
                    "alphas_evaluated": A, "parallelism": f"edges+pair-tiles sharded over {world} GPU(s)"},
         "roofline": roofline, "kernels": kernels, "phases_ms": phases,
+        "diameter": {"hi": hi, "path": dpath, "candidate_landmark_pairs": cand_pairs, "candidate_tiles": cand_tiles,
+                     "all_landmark_pairs": N * (N + 1) // 2, "all_tiles": ((n + 127) // 128) * ((n + 127) // 128 + 1) // 2},
         "result": [float(x) for x in res], "upload_s": t_upload,
     }
     if coll is not None:

@@ -333,6 +333,22 @@ class Context:
         self._keep = [cb, coll]
         self._check(self.L.cge_set_collectives(self.h, C.byref(coll)))
 
+    def set_option(self, key, value):
+        self._check(self.L.cge_set_option(self.h, key.encode(), C.c_int64(int(value))))
+
+    def get_stat(self, key):
+        v = C.c_int64()
+        self._check(self.L.cge_get_stat(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def last_diameter(self):
+        """(hi, path, candidate landmark pairs, candidate tiles) of the last landmark-mode run."""
+        import struct
+
+        hi = struct.unpack("d", struct.pack("q", self.get_stat("diameter_bits")))[0]
+        return hi, {1: "brute", 2: "pruned"}.get(self.get_stat("diameter_path"), "none"), \
+            self.get_stat("diameter_candidate_pairs"), self.get_stat("diameter_candidate_tiles")
+
     def profile_enable(self, on=True):
         self._check(self.L.cge_profile_enable(self.h, C.c_int(int(on))))
 

@@ -171,7 +171,10 @@ int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
     c->dpad = (d + 15) / 16 * 16;
     c->Xc.alloc_exact((size_t)c->ldn * c->dpad);
     c->rnorm.alloc_exact((size_t)c->ldn);
-    k_centre_featuremajor(c, c->Xr.p, c->Xc.p, c->rnorm.p, n, d, c->ldn, c->dpad);
+    c->gmean.alloc_exact((size_t)d);
+    k_col_mean(c, c->Xr.p, n, d, c->gmean.p);
+    k_gather_centre_fm(c, c->Xr.p, nullptr, c->gmean.p, c->Xc.p, c->rnorm.p, n, d, c->ldn, c->dpad);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
     c->centred_ready = true;
     c->lm_ready = false;
     CGE_CATCH(c)
@@ -264,6 +267,7 @@ static double allreduce_scalar_max(cge_ctx *c, double v) {
     return v;
 }
 
+static void build_landmark_index(cge_ctx *c, const std::vector<i32> &v2l0, i64 N);
 static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 land, i64 forced,
                                int method, int directed) {
     if (!c->Xr.p || !c->vw.p || !c->comm.p || !c->src.p) CGE_THROW(CGE_E_ARG, "landmarks: graph, embedding and vertex data must be resident");
@@ -285,16 +289,10 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
     }
     c->N = N;
     // CSR landmark -> members in ascending vertex order
-    std::vector<i32> v2l0(n), mem_off(N + 1, 0), mem(n);
-    for (i64 i = 0; i < n; i++) {
-        v2l0[i] = (i32)gid[i];
-        mem_off[gid[i] + 1]++;
-    }
-    for (i64 l = 0; l < N; l++) mem_off[l + 1] += mem_off[l];
-    {
-        std::vector<i32> cur(mem_off.begin(), mem_off.end() - 1);
-        for (i64 i = 0; i < n; i++) mem[cur[gid[i]]++] = (i32)i;
-    }
+    std::vector<i32> v2l0(n);
+    for (i64 i = 0; i < n; i++) v2l0[i] = (i32)gid[i];
+    build_landmark_index(c, v2l0, N);
+    const std::vector<i32> &mem_off = c->h_mem_off, &mem = c->h_mem;
     DevBuf<i32> d_off, d_mem;
     d_off.ensure(N + 1);
     d_mem.ensure(n);
@@ -458,27 +456,56 @@ static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_d
     }
 }
 
-// diameter of the resident embedding (this rank's share), exact arithmetic of dist() on the arg-max pair
+// exact distance of one vertex pair with dist()'s own arithmetic (src/auxilary.jl:14-20)
+static double exact_pair_distance(cge_ctx *c, i64 bi, i64 bj) {
+    DevBuf<i32> pij;
+    DevBuf<double> dd;
+    pij.ensure(2);
+    dd.ensure(1);
+    const i32 h[2] = {(i32)bi, (i32)bj};
+    double hi = 0.0;
+    HIP_CHECK(hipMemcpyAsync(pij.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    k_pair_dist(c, c->Xr.p, c->d, pij.p, pij.p + 1, 1, 1.0, dd.p);
+    HIP_CHECK(hipMemcpyAsync(&hi, dd.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return hi;
+}
+
+// diameter of the resident embedding (this rank's share), brute force over all pair tiles
 static double resident_diameter(cge_ctx *c, int part, int nparts, i64 *ai, i64 *aj) {
     if (!c->centred_ready) CGE_THROW(CGE_E_ARG, "diameter: embedding not resident");
     double bv;
     i64 bi, bj;
     k_max_pair(c, c->Xc.p, c->rnorm.p, c->n, c->ldn, c->dpad, part, nparts, &bv, &bi, &bj);
-    double hi = 0.0;
-    if (bv >= 0.0) {
-        DevBuf<i32> pij;
-        DevBuf<double> dd;
-        pij.ensure(2);
-        dd.ensure(1);
-        const i32 h[2] = {(i32)bi, (i32)bj};
-        HIP_CHECK(hipMemcpyAsync(pij.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-        k_pair_dist(c, c->Xr.p, c->d, pij.p, pij.p + 1, 1, 1.0, dd.p);
-        HIP_CHECK(hipMemcpyAsync(&hi, dd.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-    }
+    c->stat_diameter_path = 1;
+    const double hi = bv >= 0.0 ? exact_pair_distance(c, bi, bj) : 0.0;
     if (ai) *ai = bi + 1;
     if (aj) *aj = bj + 1;
     return hi;
+}
+
+// the same with landmark-pair pruning in front (diameter_host.cpp); `mu` = N reference points (device, row-major)
+static double resident_diameter_lm(cge_ctx *c, const double *mu, i64 N, int part, int nparts) {
+    if (c->opt_diameter != 1 && (i64)c->h_mem_off.size() == N + 1) {
+        double d2;
+        i64 bi, bj;
+        if (host_diameter_pruned(c, mu, N, c->h_mem_off, c->h_mem, part, nparts, &d2, &bi, &bj)) {
+            c->stat_diameter_path = 2;
+            return exact_pair_distance(c, bi, bj);
+        }
+    }
+    return resident_diameter(c, part, nparts, nullptr, nullptr);
+}
+
+// landmark -> members CSR (ascending vertex id) from a 0-based assignment
+static void build_landmark_index(cge_ctx *c, const std::vector<i32> &v2l0, i64 N) {
+    const i64 n = (i64)v2l0.size();
+    c->h_mem_off.assign(N + 1, 0);
+    c->h_mem.resize(n);
+    for (i64 i = 0; i < n; i++) c->h_mem_off[v2l0[i] + 1]++;
+    for (i64 l = 0; l < N; l++) c->h_mem_off[l + 1] += c->h_mem_off[l];
+    std::vector<i32> cur(c->h_mem_off.begin(), c->h_mem_off.end() - 1);
+    for (i64 i = 0; i < n; i++) c->h_mem[cur[v2l0[i]]++] = (i32)i;
 }
 
 int cge_max_pair_dist(cge_ctx *c, int part, int nparts, double *hi, int64_t *arg_i, int64_t *arg_j) {
@@ -593,11 +620,17 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
         } else if (!c->Xr.p || !c->src.p || !c->vw.p || c->n != a->n_v_to_l)
             CGE_THROW(CGE_E_ARG, "wGCL: landmark mode needs init_* arrays or matching resident inputs");
         upload_i64_as_i32(c, a->v_to_l, a->n_v_to_l, 1, N, c->v2l, "v_to_l");
+        {
+            std::vector<i32> v2l0(a->n_v_to_l);
+            for (i64 i = 0; i < a->n_v_to_l; i++) v2l0[i] = (i32)(a->v_to_l[i] - 1);
+            build_landmark_index(c, v2l0, N);
+        }
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p;
         ov.lweight = c->s_vw.p; ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
-        double hi = resident_diameter(c, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1, nullptr, nullptr);
+        double hi = resident_diameter_lm(c, c->s_emb.p, N, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1);
         hi = allreduce_scalar_max(c, hi);
         ov.hi = hi;
+        c->stat_last_hi = hi;
     } else {
         // exact mode: make the score graph the resident graph so the sampler can reject its edges
         int rc = cge_set_graph(c, a->edges_src, a->edges_dst, a->eweights, a->m, N);
@@ -647,9 +680,10 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         t0 = now_ms();
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
         ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
-        double hi = resident_diameter(c, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1, nullptr, nullptr);
+        double hi = resident_diameter_lm(c, c->lemb.p, N, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1);
         hi = allreduce_scalar_max(c, hi);
         ov.hi = hi;
+        c->stat_last_hi = hi;
         c->phases.ms["diameter"] = now_ms() - t0;
     } else {
         if (directed) CGE_THROW(CGE_E_ARG, "score: directed exact mode goes through cge_wgcl");
@@ -728,6 +762,26 @@ int cge_edge_scatter(cge_ctx *c, const int64_t *v_to_l, int64_t N, int64_t C, in
     HIP_CHECK(hipStreamSynchronize(st));
     flush_timers(c);
     CGE_CATCH(c)
+}
+
+// ---- options / statistics ---------------------------------------------------------------------------
+int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) return CGE_E_ARG;
+    if (!strcmp(key, "diameter")) { // 0 auto, 1 brute force, 2 pruned only
+        if (value < 0 || value > 2) return CGE_E_ARG;
+        c->opt_diameter = (int)value;
+        return CGE_OK;
+    }
+    return CGE_E_ARG;
+}
+int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
+    if (!c || !key || !value) return CGE_E_ARG;
+    if (!strcmp(key, "diameter_path")) *value = c->stat_diameter_path;
+    else if (!strcmp(key, "diameter_candidate_pairs")) *value = c->stat_cand_pairs;
+    else if (!strcmp(key, "diameter_candidate_tiles")) *value = c->stat_cand_tiles;
+    else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`
+    else return CGE_E_ARG;
+    return CGE_OK;
 }
 
 // ---- profiling --------------------------------------------------------------------------------------

@@ -136,6 +136,19 @@ struct cge_ctx {
     DevBuf<double> s_emb, s_dist, s_vw, s_vectC, s_degin, s_degout;
     DevBuf<i32> s_comm;
     DevBuf<double> auc_part;
+    // diameter scratch
+    DevBuf<double> mp_recs;  // MaxRec records (3 doubles each)
+    DevBuf<i64> mp_count;
+    DevBuf<double> gmean;    // global feature mean (the centre used by Xc)
+    DevBuf<double> Xs, rns, Ms, mnorm, Pm; // landmark-sorted centred copy, centroids, P matrix
+    DevBuf<i32> pos2node, sub_land;
+    DevBuf<double> bound_list;             // BoundRec records (2 doubles each)
+    DevBuf<i32> tile_list;
+    std::vector<i32> h_mem_off, h_mem;     // landmark -> members (ascending vertex id), host copy
+    int opt_diameter = 0;                  // 0 auto (pruned with brute-force fallback), 1 brute force, 2 pruned only
+    i64 stat_cand_pairs = 0, stat_cand_tiles = 0; // last pruned run
+    int stat_diameter_path = 0;            // 1 brute, 2 pruned
+    double stat_last_hi = 0.0;
     // scratch of the batched split engine (landmarks_host.cpp)
     DevBuf<i32> ls_rows, ls_row_task, ls_ct, ls_cb, ls_ce, ls_tco;
     DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z;
@@ -184,7 +197,6 @@ static inline unsigned grid_for(i64 work, int block, i64 cap = 256 * 8) {
 // ---- kernels_*.hip entry points (host launchers) ---------------------------------------------
 // layout
 void k_transpose_to_rowmajor(cge_ctx *c, const double *Xcol, double *Xrow, i64 n, i64 d);
-void k_centre_featuremajor(cge_ctx *c, const double *Xrow, double *Xc, double *rnorm, i64 n, i64 d, i64 ldn, i64 dpad);
 void k_row_hash(cge_ctx *c, const double *Xrow, uint64_t *hash, i64 n, i64 d);
 // landmark split primitives (batched over tasks; rows = concatenated 0-based vertex ids)
 void k_group_mean(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
@@ -212,6 +224,15 @@ void k_max_pair(cge_ctx *c, const double *Xc, const double *rnorm, i64 n, i64 ld
                 double *best_val, i64 *best_i, i64 *best_j);
 void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *pj, i64 S, double inv_scale_den,
                  double *out);
+void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, const double *Ms, const double *mnorm,
+             i64 ldm, i64 N, i64 dpad, const i32 *sub_land, double *P);
+void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,
+                 i64 ntiles, double *best_val, i64 *best_i, i64 *best_j);
+i64 k_bound_select(cge_ctx *c, const double *P, const double *mu, i64 N, i64 d, double L, void *list, i64 cap);
+void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i);
+void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean);
+void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
+                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad);
 // alpha sweep
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD);
 void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done);
@@ -239,6 +260,9 @@ void k_mark_edge_hits(cge_ctx *c, const i32 *src, const i32 *dst, i64 m, int dir
 void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
                    std::vector<i64> &group_ids /*0-based*/, std::vector<std::vector<i64>> *members_out);
 void host_eig_top(const double *A, i64 d, double *v); // largest-eigenvalue eigenvector, sign: max |.| component > 0
+// diameter_host.cpp
+bool host_diameter_pruned(cge_ctx *c, const double *mu, i64 N, const std::vector<i32> &mem_off,
+                          const std::vector<i32> &mem, int part, int nparts, double *best_d2, i64 *bi, i64 *bj);
 // wgcl_host.cpp
 struct SampleSet {
     i64 S = 0, n_sets = 0;

@@ -1,0 +1,128 @@
+// diameter_host.cpp -- exact point-set diameter `hi = maximum(full_graph_D)` (src/divergence.jl:104-113)
+// by branch-and-bound over landmark pairs, with the brute-force MFMA kernel as fallback.
+//
+// For x_i in landmark a and x_j in landmark b, with ANY reference points mu_a, mu_b:
+//   ||x_i - x_j||^2 <= P_ab + P_ba - ||mu_a - mu_b||^2 + 2 sqrt(P_aa P_bb),   P_ab = max_{i in a} ||x_i - mu_b||^2
+// (expand both sides; the only inequality is Cauchy-Schwarz on <x_i - mu_a, x_j - mu_b>).
+// 1. P (N x N) by one fp64-MFMA pass of all n vertices against the N centroids (n*N*d FMA, ~1 % of the
+//    brute-force work for N = 4000 landmarks on 10^6 vertices);
+// 2. a lower bound L of the diameter^2 from three farthest-point sweeps;
+// 3. every landmark pair whose bound reaches L is evaluated exactly, in decreasing bound order, L rising
+//    as better pairs are found; pairs whose bound falls below L are dropped.
+// The result is the exact arg-max pair whatever the data; only the amount of pruning is data dependent.
+// When fewer than half of the brute-force tiles can be pruned the brute-force kernel runs instead.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+struct BoundRec {
+    double B;
+    i32 a, b;
+};
+} // namespace
+
+// returns false when the caller should fall back to brute force
+bool host_diameter_pruned(cge_ctx *c, const double *mu, i64 N, const std::vector<i32> &mem_off,
+                          const std::vector<i32> &mem, int part, int nparts, double *best_d2, i64 *bi, i64 *bj) {
+    const i64 n = c->n, d = c->d, dpad = c->dpad;
+    hipStream_t st = c->stream;
+    c->stat_cand_pairs = c->stat_cand_tiles = 0;
+    // ---- landmark-sorted layout: landmark a owns positions [soff[a], soff[a] + cnt16[a]) ------------
+    std::vector<i64> soff(N + 1, 0);
+    for (i64 a = 0; a < N; a++) soff[a + 1] = soff[a] + ((mem_off[a + 1] - mem_off[a] + 15) / 16) * 16;
+    const i64 npos = soff[N];
+    const i64 lds_rows = (npos + 127) / 128 * 128 + 128;
+    const i64 ldm = (N + 127) / 128 * 128;
+    std::vector<i32> pos2node(npos), sub_land(lds_rows / 16, -1);
+    for (i64 a = 0; a < N; a++) {
+        const i64 cnt = mem_off[a + 1] - mem_off[a];
+        for (i64 p = soff[a]; p < soff[a + 1]; p++) {
+            const i64 q = p - soff[a];
+            pos2node[p] = mem[mem_off[a] + (q < cnt ? q : cnt - 1)]; // padding repeats the last member
+            if ((q & 15) == 0) sub_land[p >> 4] = (i32)a;
+        }
+    }
+    c->pos2node.ensure(npos);
+    c->sub_land.ensure(lds_rows / 16);
+    HIP_CHECK(hipMemcpyAsync(c->pos2node.p, pos2node.data(), sizeof(i32) * npos, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->sub_land.p, sub_land.data(), sizeof(i32) * (lds_rows / 16), hipMemcpyHostToDevice, st));
+    c->Xs.ensure((size_t)lds_rows * dpad);
+    c->rns.ensure(lds_rows);
+    c->Ms.ensure((size_t)ldm * dpad);
+    c->mnorm.ensure(ldm);
+    c->Pm.ensure((size_t)N * N);
+    k_gather_centre_fm(c, c->Xr.p, c->pos2node.p, c->gmean.p, c->Xs.p, c->rns.p, npos, d, lds_rows, dpad);
+    k_gather_centre_fm(c, mu, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, N, d, ldm, dpad);
+    k_pcent(c, c->Xs.p, c->rns.p, lds_rows, c->Ms.p, c->mnorm.p, ldm, N, dpad, c->sub_land.p, c->Pm.p);
+    // ---- lower bound from farthest-point sweeps ----------------------------------------------------------
+    double L = 0.0;
+    i64 p0 = 0, far_i = 0, far_j = 0;
+    for (int it = 0; it < 3; it++) {
+        double v;
+        i64 q;
+        k_farthest(c, c->Xr.p, n, d, p0, &v, &q);
+        if (v > L) { L = v; far_i = p0; far_j = q; }
+        p0 = q;
+    }
+    // ---- candidate landmark pairs ---------------------------------------------------------------------------
+    const i64 cap = std::min<i64>(N * (N + 1) / 2, (i64)4 << 20);
+    c->bound_list.ensure((size_t)2 * cap);
+    const i64 cnt = k_bound_select(c, c->Pm.p, mu, N, d, L * (1.0 - 1e-9), c->bound_list.p, cap);
+    c->stat_cand_pairs = cnt;
+    if (cnt > cap) return false;
+    std::vector<BoundRec> cand(cnt);
+    if (cnt > 0) {
+        HIP_CHECK(hipMemcpyAsync(cand.data(), c->bound_list.p, sizeof(BoundRec) * cnt, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    std::sort(cand.begin(), cand.end(), [](const BoundRec &x, const BoundRec &y) {
+        return x.B > y.B || (x.B == y.B && (x.a < y.a || (x.a == y.a && x.b < y.b)));
+    });
+    auto ntiles_of = [&](i64 a) { return (soff[a + 1] - soff[a] + 127) / 128; };
+    double tiles_total = 0.0;
+    for (const auto &r : cand) {
+        const double ta = (double)ntiles_of(r.a), tb = (double)ntiles_of(r.b);
+        tiles_total += (r.a == r.b) ? ta * (ta + 1) / 2 : ta * tb;
+    }
+    const double nT = (double)((n + 127) / 128);
+    if (c->opt_diameter != 2 && tiles_total > 0.5 * nT * (nT + 1) / 2) return false; // pruning too weak: brute force
+    // ---- exact evaluation in decreasing-bound order ----------------------------------------------------------
+    double best = L; // the farthest-point pair is a valid answer so far
+    i64 best_pi = -1, best_pj = -1;
+    size_t next = 0;
+    i64 chunk_cap = 4096, global_tile = 0;
+    std::vector<int2> tiles;
+    while (next < cand.size()) {
+        tiles.clear();
+        while (next < cand.size() && (i64)tiles.size() < chunk_cap) {
+            const BoundRec &r = cand[next++];
+            if (r.B * (1.0 + 1e-9) + 1e-9 < best) { next = cand.size(); break; } // sorted: nothing further can win
+            const i64 ta = ntiles_of(r.a), tb = ntiles_of(r.b);
+            for (i64 x = 0; x < ta; x++)
+                for (i64 y = (r.a == r.b ? x : 0); y < tb; y++) {
+                    if ((global_tile++ % nparts) != part) continue;
+                    tiles.push_back(make_int2((int)(soff[r.a] + 128 * x), (int)(soff[r.b] + 128 * y)));
+                }
+        }
+        if (tiles.empty()) continue;
+        c->stat_cand_tiles += (i64)tiles.size();
+        c->tile_list.ensure(2 * tiles.size());
+        HIP_CHECK(hipMemcpyAsync(c->tile_list.p, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, st));
+        double v;
+        i64 pi, pj;
+        k_pair_list(c, c->Xs.p, c->rns.p, lds_rows, npos, dpad, c->tile_list.p, (i64)tiles.size(), &v, &pi, &pj);
+        if (v > best) { best = v; best_pi = pi; best_pj = pj; }
+        chunk_cap = 131072;
+    }
+    if (best_pi >= 0) {
+        far_i = pos2node[best_pi];
+        far_j = pos2node[best_pj];
+    }
+    if (far_i > far_j) std::swap(far_i, far_j);
+    *best_d2 = best;
+    *bi = far_i;
+    *bj = far_j;
+    return true;
+}

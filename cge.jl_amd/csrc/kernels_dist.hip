@@ -166,106 +166,75 @@ __device__ __forceinline__ void tile_from_linear(i64 t, i64 nS, i64 &SI, i64 &I,
     J = SJ * MP_SB + loc % MP_SB;
 }
 
-__global__ __launch_bounds__(256, 2) void max_pair_kernel(const double *__restrict__ Xc,
-                                                          const double *__restrict__ rnorm, i64 n, i64 ldn, i64 dpad,
-                                                          int part, int nparts, MaxRec *__restrict__ recs) {
-    extern __shared__ __attribute__((aligned(16))) double lds[]; // 2 stages x (A + B) x MP_BK x MP_LD
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wr = wave >> 1, wc = wave & 1; // wave sub-tile: rows wr*64.., cols wc*64..
-    const int lr = lane & 15, lk = lane >> 4;
-    const i64 nT = ldn / MP_BM;
-    const i64 nS = (nT + MP_SB - 1) / MP_SB;
-    const i64 total = nS * (nS + 1) / 2 * MP_SB * MP_SB;
-    const i64 nchunk = dpad / MP_BK;
-    double best = -1.0;
-    i64 best_i = 0, best_j = 0;
+// One 128x128 Gram tile G = A_tile * B_tile^T over the whole feature dimension.
+// pa/pb: this thread's first load address (operand base + wave*ld + tile offset + 2*lane); a k-row of
+// a tile is 128 contiguous doubles; chunk kc covers k-rows [kc*MP_BK, (kc+1)*MP_BK).
+// LDS: 2 stages x (A,B) x MP_BK x MP_LD doubles.  All 256 threads must call it (barriers inside).
+__device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, const double *__restrict__ pb, i64 lda,
+                                              i64 ldb, i64 nchunk, double *lds, d4 (&acc)[4][4], int wave, int c2,
+                                              int wr, int wc, int lr, int lk) {
     const size_t stage_doubles = (size_t)2 * MP_BK * MP_LD;
-    // loader geometry: slot q of this thread is k-row (wave + 4q), doubles [2*lane, 2*lane+1]
-    const int c2 = lane * 2;
-
-    for (i64 t = blockIdx.x; t < total; t += gridDim.x) {
-        i64 SI, I, J;
-        tile_from_linear(t, nS, SI, I, J);
-        if (I >= nT || J >= nT || J < I || (SI % nparts) != part) continue; // uniform per workgroup
-        const i64 i0 = I * MP_BM, j0 = J * MP_BN;
-        d4 acc[4][4];
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-        d2 ra[4], rb[4];
-        const double *pa = Xc + (i64)wave * ldn + i0 + c2;
-        const double *pb = Xc + (i64)wave * ldn + j0 + c2;
+        for (int b = 0; b < 4; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    d2 ra[4], rb[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        ra[q] = *reinterpret_cast<const d2 *>(pa + (i64)(4 * q) * lda);
+        rb[q] = *reinterpret_cast<const d2 *>(pb + (i64)(4 * q) * ldb);
+    }
+    __syncthreads(); // the previous tile's readers are done with both stages
+    {
+        double *As = lds, *Bs = lds + (size_t)MP_BK * MP_LD;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            ra[q] = *reinterpret_cast<const d2 *>(pa + (i64)(4 * q) * ldn);
-            rb[q] = *reinterpret_cast<const d2 *>(pb + (i64)(4 * q) * ldn);
+            *reinterpret_cast<d2 *>(As + (wave + 4 * q) * MP_LD + c2) = ra[q];
+            *reinterpret_cast<d2 *>(Bs + (wave + 4 * q) * MP_LD + c2) = rb[q];
         }
-        __syncthreads(); // the previous tile's readers are done with both stages
-        {
-            double *As = lds, *Bs = lds + (size_t)MP_BK * MP_LD;
+    }
+    __syncthreads();
+    for (i64 kc = 0; kc < nchunk; kc++) {
+        const int s = (int)(kc & 1);
+        const bool more = kc + 1 < nchunk;
+        if (more) { // issue the next chunk's global loads; they land while the MFMAs run
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                *reinterpret_cast<d2 *>(As + (wave + 4 * q) * MP_LD + c2) = ra[q];
-                *reinterpret_cast<d2 *>(Bs + (wave + 4 * q) * MP_LD + c2) = rb[q];
+                ra[q] = *reinterpret_cast<const d2 *>(pa + ((kc + 1) * MP_BK + 4 * q) * lda);
+                rb[q] = *reinterpret_cast<const d2 *>(pb + ((kc + 1) * MP_BK + 4 * q) * ldb);
             }
         }
-        __syncthreads();
-        for (i64 kc = 0; kc < nchunk; kc++) {
-            const int s = (int)(kc & 1);
-            const bool more = kc + 1 < nchunk;
-            if (more) { // issue the next chunk's global loads; they land while the MFMAs run
-                const i64 koff = (kc + 1) * MP_BK * ldn;
+        const double *As = lds + (size_t)s * stage_doubles;
+        const double *Bs = As + (size_t)MP_BK * MP_LD;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    ra[q] = *reinterpret_cast<const d2 *>(pa + koff + (i64)(4 * q) * ldn);
-                    rb[q] = *reinterpret_cast<const d2 *>(pb + koff + (i64)(4 * q) * ldn);
-                }
-            }
-            const double *As = lds + (size_t)s * stage_doubles;
-            const double *Bs = As + (size_t)MP_BK * MP_LD;
+        for (int ks = 0; ks < MP_BK / 4; ks++) {
+            double af[4], bf[4];
 #pragma unroll
-            for (int ks = 0; ks < MP_BK / 4; ks++) {
-                double af[4], bf[4];
+            for (int a = 0; a < 4; a++) af[a] = As[(ks * 4 + lk) * MP_LD + wr * 64 + a * 16 + lr];
 #pragma unroll
-                for (int a = 0; a < 4; a++) af[a] = As[(ks * 4 + lk) * MP_LD + wr * 64 + a * 16 + lr];
-#pragma unroll
-                for (int b = 0; b < 4; b++) bf[b] = Bs[(ks * 4 + lk) * MP_LD + wc * 64 + b * 16 + lr];
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
-            }
-            if (more) {
-                double *An = lds + (size_t)(s ^ 1) * stage_doubles;
-                double *Bn = An + (size_t)MP_BK * MP_LD;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    *reinterpret_cast<d2 *>(An + (wave + 4 * q) * MP_LD + c2) = ra[q];
-                    *reinterpret_cast<d2 *>(Bn + (wave + 4 * q) * MP_LD + c2) = rb[q];
-                }
-            }
-            __syncthreads();
-        }
-        // epilogue: dist^2 and running max.  acc[a][b][r]: row = i0 + wr*64 + a*16 + lk + 4r, col = j0 + wc*64 + b*16 + lr
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const i64 j = j0 + wc * 64 + b * 16 + lr;
-            const double rj = rnorm[j]; // rnorm is padded to ldn
+            for (int b = 0; b < 4; b++) bf[b] = Bs[(ks * 4 + lk) * MP_LD + wc * 64 + b * 16 + lr];
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const i64 i = i0 + wr * 64 + a * 16 + lk + 4 * r;
-                    if (j < n && i < j) {
-                        const double v = rnorm[i] + rj - 2.0 * acc[a][b][r];
-                        if (v > best) { best = v; best_i = i; best_j = j; }
-                    }
-                }
+                for (int b = 0; b < 4; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
+        if (more) {
+            double *An = lds + (size_t)(s ^ 1) * stage_doubles;
+            double *Bn = An + (size_t)MP_BK * MP_LD;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                *reinterpret_cast<d2 *>(An + (wave + 4 * q) * MP_LD + c2) = ra[q];
+                *reinterpret_cast<d2 *>(Bn + (wave + 4 * q) * MP_LD + c2) = rb[q];
+            }
+        }
+        __syncthreads();
     }
-    // workgroup reduction of (best, i, j): value max, ties -> smallest (i,j)
+}
+
+// workgroup reduction of (best, i, j) -> recs[blockIdx.x]: value max, ties -> smallest (i,j)
+__device__ __forceinline__ void reduce_best(double best, i64 best_i, i64 best_j, double *lds, MaxRec *recs) {
+    const int tid = threadIdx.x;
     __syncthreads();
     double *sv = lds;
     i64 *si = reinterpret_cast<i64 *>(lds + 256), *sj = reinterpret_cast<i64 *>(lds + 512);
@@ -288,29 +257,254 @@ __global__ __launch_bounds__(256, 2) void max_pair_kernel(const double *__restri
     }
 }
 
+// (1) brute force over all tile pairs J >= I of ONE operand
+__global__ __launch_bounds__(256, 2) void max_pair_kernel(const double *__restrict__ Xc,
+                                                          const double *__restrict__ rnorm, i64 n, i64 ldn, i64 dpad,
+                                                          int part, int nparts, MaxRec *__restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4, c2 = lane * 2;
+    const i64 nT = ldn / MP_BM;
+    const i64 nS = (nT + MP_SB - 1) / MP_SB;
+    const i64 total = nS * (nS + 1) / 2 * MP_SB * MP_SB;
+    const i64 nchunk = dpad / MP_BK;
+    double best = -1.0;
+    i64 best_i = 0, best_j = 0;
+    for (i64 t = blockIdx.x; t < total; t += gridDim.x) {
+        i64 SI, I, J;
+        tile_from_linear(t, nS, SI, I, J);
+        if (I >= nT || J >= nT || J < I || (SI % nparts) != part) continue; // uniform per workgroup
+        const i64 i0 = I * MP_BM, j0 = J * MP_BN;
+        d4 acc[4][4];
+        gram_tile_128(Xc + (i64)wave * ldn + i0 + c2, Xc + (i64)wave * ldn + j0 + c2, ldn, ldn, nchunk, lds, acc, wave,
+                      c2, wr, wc, lr, lk);
+        // acc[a][b][r]: row = i0 + wr*64 + a*16 + lk + 4r, col = j0 + wc*64 + b*16 + lr
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const i64 j = j0 + wc * 64 + b * 16 + lr;
+            const double rj = rnorm[j]; // rnorm is padded to ldn
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const i64 i = i0 + wr * 64 + a * 16 + lk + 4 * r;
+                    if (j < n && i < j) {
+                        const double v = rnorm[i] + rj - 2.0 * acc[a][b][r];
+                        if (v > best) { best = v; best_i = i; best_j = j; }
+                    }
+                }
+        }
+    }
+    reduce_best(best, best_i, best_j, lds, recs);
+}
+
+// (2) point-to-centroid maxima: P[a][b] = max over the rows of landmark a of ||x - mu_b||^2.
+// Rows are the landmark-sorted copy Xs (every landmark padded to a multiple of 16 rows, so a 16-row
+// MFMA sub-tile belongs to one landmark: sub_land[pos/16], -1 in the tail padding).  Results are
+// combined with integer atomic max on the bit pattern (values are clamped to >= 0).
+__global__ __launch_bounds__(256, 2) void pcent_kernel(const double *__restrict__ Xs, const double *__restrict__ rns,
+                                                       i64 lds_rows, const double *__restrict__ Ms,
+                                                       const double *__restrict__ mnorm, i64 ldm, i64 N, i64 dpad,
+                                                       const i32 *__restrict__ sub_land,
+                                                       unsigned long long *__restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4, c2 = lane * 2;
+    const i64 nTI = lds_rows / MP_BM, nTJ = ldm / MP_BN;
+    const i64 nchunk = dpad / MP_BK;
+    for (i64 t = blockIdx.x; t < nTI * nTJ; t += gridDim.x) {
+        const i64 I = t / nTJ, J = t - I * nTJ; // consecutive workgroups share the row tile
+        const i64 i0 = I * MP_BM, j0 = J * MP_BN;
+        d4 acc[4][4];
+        gram_tile_128(Xs + (i64)wave * lds_rows + i0 + c2, Ms + (i64)wave * ldm + j0 + c2, lds_rows, ldm, nchunk, lds,
+                      acc, wave, c2, wr, wc, lr, lk);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const i64 col = j0 + wc * 64 + b * 16 + lr;
+            const double mn = mnorm[col];
+            double cur = 0.0;
+            int curland = -1;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const i64 r0 = i0 + wr * 64 + a * 16;
+                const int land = sub_land[r0 >> 4]; // wave-uniform
+                double v = -1e300;
+#pragma unroll
+                for (int r = 0; r < 4; r++) v = fmax(v, rns[r0 + lk + 4 * r] - 2.0 * acc[a][b][r]);
+                v = fmax(v, __shfl_xor(v, 16));
+                v = fmax(v, __shfl_xor(v, 32));
+                if (land != curland) {
+                    if (curland >= 0 && lk == 0 && col < N)
+                        atomicMax(&P[(i64)curland * N + col], (unsigned long long)__double_as_longlong(fmax(cur + mn, 0.0)));
+                    curland = land;
+                    cur = v;
+                } else
+                    cur = fmax(cur, v);
+            }
+            if (curland >= 0 && lk == 0 && col < N)
+                atomicMax(&P[(i64)curland * N + col], (unsigned long long)__double_as_longlong(fmax(cur + mn, 0.0)));
+        }
+    }
+}
+
+// (3) exact evaluation of a list of 128x128 tiles of the landmark-sorted copy (row offsets posA, posB)
+__global__ __launch_bounds__(256, 2) void pair_list_kernel(const double *__restrict__ Xs,
+                                                           const double *__restrict__ rns, i64 lds_rows, i64 npos,
+                                                           i64 dpad, const int2 *__restrict__ tiles, i64 ntiles,
+                                                           MaxRec *__restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4, c2 = lane * 2;
+    const i64 nchunk = dpad / MP_BK;
+    double best = -1.0;
+    i64 best_i = 0, best_j = 0;
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const i64 i0 = tiles[t].x, j0 = tiles[t].y;
+        d4 acc[4][4];
+        gram_tile_128(Xs + (i64)wave * lds_rows + i0 + c2, Xs + (i64)wave * lds_rows + j0 + c2, lds_rows, lds_rows,
+                      nchunk, lds, acc, wave, c2, wr, wc, lr, lk);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const i64 j = j0 + wc * 64 + b * 16 + lr;
+            const double rj = rns[j];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const i64 i = i0 + wr * 64 + a * 16 + lk + 4 * r;
+                    if (i < npos && j < npos) { // rows past npos are zero padding (not vertices)
+                        const double v = rns[i] + rj - 2.0 * acc[a][b][r];
+                        if (v > best) { best = v; best_i = i; best_j = j; }
+                    }
+                }
+        }
+    }
+    reduce_best(best, best_i, best_j, lds, recs);
+}
+
+static void best_of_recs(cge_ctx *c, const MaxRec *d_recs, int nwg, double *bv, i64 *bi, i64 *bj) {
+    std::vector<MaxRec> h(nwg);
+    HIP_CHECK(hipMemcpyAsync(h.data(), d_recs, sizeof(MaxRec) * nwg, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    *bv = -1.0; *bi = 0; *bj = 0;
+    for (int k = 0; k < nwg; k++)
+        if (h[k].val > *bv || (h[k].val == *bv && (h[k].i < *bi || (h[k].i == *bi && h[k].j < *bj)))) {
+            *bv = h[k].val; *bi = h[k].i; *bj = h[k].j;
+        }
+}
+#define MP_NWG 512
+#define MP_LDS_BYTES ((size_t)2 * 2 * MP_BK * MP_LD * sizeof(double))
+
 // Shard `part` of `nparts` owns the super-block rows SI with SI % nparts == part (balanced to
 // one super-row; no tile is visited twice across shards).
 void k_max_pair(cge_ctx *c, const double *Xc, const double *rnorm, i64 n, i64 ldn, i64 dpad, int part, int nparts,
                 double *best_val, i64 *best_i, i64 *best_j) {
-    const int nwg = 512;
-    DevBuf<MaxRec> recs;
-    recs.ensure(nwg);
-    const size_t lds = (size_t)2 * 2 * MP_BK * MP_LD * sizeof(double);
+    c->mp_recs.ensure(MP_NWG * 3);
+    MaxRec *recs = reinterpret_cast<MaxRec *>(c->mp_recs.p);
     {
         ScopedKernelTimer t(c, "max_pair_dist");
-        hipLaunchKernelGGL(max_pair_kernel, dim3(nwg), dim3(256), lds, c->stream, Xc, rnorm, n, ldn, dpad, part,
-                           nparts, recs.p);
+        hipLaunchKernelGGL(max_pair_kernel, dim3(MP_NWG), dim3(256), MP_LDS_BYTES, c->stream, Xc, rnorm, n, ldn, dpad,
+                           part, nparts, recs);
     }
-    std::vector<MaxRec> h(nwg);
-    HIP_CHECK(hipMemcpyAsync(h.data(), recs.p, sizeof(MaxRec) * nwg, hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
-    double bv = -1.0;
-    i64 bi = 0, bj = 0;
-    for (int k = 0; k < nwg; k++)
-        if (h[k].val > bv || (h[k].val == bv && (h[k].i < bi || (h[k].i == bi && h[k].j < bj)))) {
-            bv = h[k].val; bi = h[k].i; bj = h[k].j;
+    best_of_recs(c, recs, MP_NWG, best_val, best_i, best_j);
+}
+
+void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, const double *Ms, const double *mnorm,
+             i64 ldm, i64 N, i64 dpad, const i32 *sub_land, double *P) {
+    HIP_CHECK(hipMemsetAsync(P, 0, sizeof(double) * N * N, c->stream));
+    ScopedKernelTimer t(c, "pcent");
+    const i64 ntiles = (lds_rows / MP_BM) * (ldm / MP_BN);
+    hipLaunchKernelGGL(pcent_kernel, dim3((unsigned)std::min<i64>(ntiles, 2048)), dim3(256), MP_LDS_BYTES, c->stream, Xs,
+                       rns, lds_rows, Ms, mnorm, ldm, N, dpad, sub_land, reinterpret_cast<unsigned long long *>(P));
+}
+
+void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,
+                 i64 ntiles, double *best_val, i64 *best_i, i64 *best_j) {
+    c->mp_recs.ensure(MP_NWG * 3);
+    MaxRec *recs = reinterpret_cast<MaxRec *>(c->mp_recs.p);
+    const int nwg = (int)std::max<i64>(1, std::min<i64>(ntiles, MP_NWG));
+    {
+        ScopedKernelTimer t(c, "pair_list");
+        hipLaunchKernelGGL(pair_list_kernel, dim3(nwg), dim3(256), MP_LDS_BYTES, c->stream, Xs, rns, lds_rows, npos,
+                           dpad, reinterpret_cast<const int2 *>(tiles), ntiles, recs);
+    }
+    best_of_recs(c, recs, nwg, best_val, best_i, best_j);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Landmark-pair upper bounds.  For x_i in landmark a, x_j in landmark b (any reference points mu):
+//   ||x_i - x_j||^2 = ||x_i - mu_b||^2 + ||x_j - mu_a||^2 - ||mu_a - mu_b||^2 - 2 <x_i - mu_a, x_j - mu_b>
+//                  <= P_ab + P_ba - D2_ab + 2 sqrt(P_aa P_bb)  =: B_ab .
+// Pairs with B_ab (slightly inflated for rounding) >= L, a known lower bound of the diameter^2,
+// are appended to `list` as (B, a, b); *count may exceed cap (then the caller falls back).
+struct BoundRec {
+    double B;
+    i32 a, b;
+};
+__global__ void bound_select_kernel(const double *__restrict__ P, const double *__restrict__ mu /* N x d row-major */,
+                                    i64 N, i64 d, double L, BoundRec *__restrict__ list, i64 cap,
+                                    unsigned long long *__restrict__ count) {
+    const i64 total = N * N, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const i64 a = e / N, b = e - a * N;
+        if (b < a) continue;
+        const double paa = P[a * N + a], pbb = P[b * N + b];
+        // cheap pre-test without D2 (D2 >= 0): skip most pairs before touching the centroids
+        const double pre = P[a * N + b] + P[b * N + a] + 2.0 * sqrt(paa * pbb);
+        if (pre * (1.0 + 1e-9) + 1e-9 < L) continue;
+        double d2 = 0.0;
+        const double *ma = mu + a * d, *mb = mu + b * d;
+        for (i64 k = 0; k < d; k++) {
+            const double t = ma[k] - mb[k];
+            d2 += t * t;
         }
-    *best_val = bv; *best_i = bi; *best_j = bj;
+        const double B = pre - d2 * (1.0 - 1e-9);
+        if (B * (1.0 + 1e-9) + 1e-9 >= L) {
+            const unsigned long long idx = atomicAdd(count, 1ULL);
+            if ((i64)idx < cap) list[idx] = BoundRec{B, (i32)a, (i32)b};
+        }
+    }
+}
+i64 k_bound_select(cge_ctx *c, const double *P, const double *mu, i64 N, i64 d, double L, void *list, i64 cap) {
+    c->mp_count.ensure(1);
+    HIP_CHECK(hipMemsetAsync(c->mp_count.p, 0, sizeof(i64), c->stream));
+    hipLaunchKernelGGL(bound_select_kernel, dim3(grid_for(N * N, 256)), dim3(256), 0, c->stream, P, mu, N, d, L,
+                       reinterpret_cast<BoundRec *>(list), cap, reinterpret_cast<unsigned long long *>(c->mp_count.p));
+    i64 cnt = 0;
+    HIP_CHECK(hipMemcpyAsync(&cnt, c->mp_count.p, sizeof(i64), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return cnt;
+}
+
+// farthest vertex from row `src` of Xr (exact dist() arithmetic is not needed: this only seeds a lower bound)
+__global__ __launch_bounds__(256) void farthest_kernel(const double *__restrict__ Xr, i64 n, i64 d, i64 src,
+                                                       MaxRec *__restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const i64 wave_global = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+    const double *s = Xr + src * d;
+    double best = -1.0;
+    i64 bi = 0;
+    for (i64 i = wave_global; i < n; i += nwaves) {
+        const double *x = Xr + i * d;
+        double acc = 0.0;
+        for (i64 k = lane; k < d; k += 64) {
+            const double t = x[k] - s[k];
+            acc += t * t;
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (acc > best) { best = acc; bi = i; }
+    }
+    reduce_best(best, bi, src, lds, recs);
+}
+void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i) {
+    c->mp_recs.ensure(MP_NWG * 3);
+    MaxRec *recs = reinterpret_cast<MaxRec *>(c->mp_recs.p);
+    const int nwg = 1024 > MP_NWG ? MP_NWG : 1024;
+    hipLaunchKernelGGL(farthest_kernel, dim3(nwg), dim3(256), 768 * sizeof(double), c->stream, Xr, n, d, src, recs);
+    i64 bj;
+    best_of_recs(c, recs, nwg, best_val, best_i, &bj);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -48,19 +48,21 @@ __global__ void colsum_final_kernel(const double *__restrict__ part, i64 nb, i64
     for (i64 b = 0; b < nb; b++) s += part[b * d + k];
     mean[k] = s / (double)n;
 }
-__global__ void centre_kernel(const double *__restrict__ Xrow, const double *__restrict__ mean, double *__restrict__ Xc,
-                              i64 n, i64 d, i64 ldn) {
+// dst[k*ld + p] = src[idx ? idx[p] : p][k] - mean[k]  (row-major rows -> centred feature-major, 32x32 LDS tiles)
+__global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i32 *__restrict__ idx,
+                                        const double *__restrict__ mean, double *__restrict__ dst, i64 npos, i64 d,
+                                        i64 ld) {
     __shared__ double tile[32][33];
-    i64 i0 = (i64)blockIdx.x * 32, k0 = (i64)blockIdx.y * 32;
+    i64 p0 = (i64)blockIdx.x * 32, k0 = (i64)blockIdx.y * 32;
     int tx = threadIdx.x, ty = threadIdx.y;
     for (int r = ty; r < 32; r += 8) {
-        i64 i = i0 + r, k = k0 + tx;
-        if (i < n && k < d) tile[r][tx] = Xrow[i * d + k] - mean[k];
+        i64 p = p0 + r, k = k0 + tx;
+        if (p < npos && k < d) tile[r][tx] = src[(idx ? (i64)idx[p] : p) * d + k] - mean[k];
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
-        i64 i = i0 + tx, k = k0 + r;
-        if (i < n && k < d) Xc[k * ldn + i] = tile[tx][r];
+        i64 p = p0 + tx, k = k0 + r;
+        if (p < npos && k < d) dst[k * ld + p] = tile[tx][r];
     }
 }
 __global__ void rownorm_kernel(const double *__restrict__ Xc, i64 n, i64 d, i64 ldn, double *__restrict__ rnorm) {
@@ -73,20 +75,25 @@ __global__ void rownorm_kernel(const double *__restrict__ Xc, i64 n, i64 d, i64 
     }
     rnorm[i] = s;
 }
-void k_centre_featuremajor(cge_ctx *c, const double *Xrow, double *Xc, double *rnorm, i64 n, i64 d, i64 ldn, i64 dpad) {
+void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean) {
     const int NB = 512;
-    DevBuf<double> part, mean;
+    DevBuf<double> part;
     part.ensure((size_t)NB * d);
-    mean.ensure((size_t)d);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(NB), dim3(256), 0, c->stream, Xrow, n, d, part.p);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, c->stream, part.p,
-                       (i64)NB, n, d, mean.p);
-    HIP_CHECK(hipMemsetAsync(Xc, 0, sizeof(double) * (size_t)(ldn * dpad), c->stream));
-    HIP_CHECK(hipMemsetAsync(rnorm, 0, sizeof(double) * (size_t)ldn, c->stream));
-    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((d + 31) / 32));
-    hipLaunchKernelGGL(centre_kernel, grid, dim3(32, 8), 0, c->stream, Xrow, mean.p, Xc, n, d, ldn);
-    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, Xc, n, d, ldn, rnorm);
-    HIP_CHECK(hipStreamSynchronize(c->stream)); // part/mean are freed on return
+                       (i64)NB, n, d, mean);
+    HIP_CHECK(hipStreamSynchronize(c->stream)); // part is freed on return
+}
+// Centred, zero-padded feature-major copy (dpad x ld) of npos gathered rows + squared row norms (ld entries).
+void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
+                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad) {
+    HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(ld * dpad), c->stream));
+    HIP_CHECK(hipMemsetAsync(rnorm, 0, sizeof(double) * (size_t)ld, c->stream));
+    dim3 grid((unsigned)((npos + 31) / 32), (unsigned)((d + 31) / 32));
+    hipLaunchKernelGGL(gather_centre_fm_kernel, grid, dim3(32, 8), 0, c->stream, src_rowmajor, idx, mean, dst, npos, d,
+                       ld);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, c->stream, dst, npos, d, ld,
+                       rnorm);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -185,6 +185,14 @@ int cge_edge_scatter(cge_ctx *ctx, const int64_t *v_to_l, int64_t N, int64_t C, 
  * (src/auxilary.jl:14-20), so the max over shards is the reference's `hi`.                      */
 int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *arg_i, int64_t *arg_j);
 
+/* ---- options / statistics --------------------------------------------------------------------- */
+/* "diameter": 0 = auto (exact landmark-pair pruning, brute-force MFMA kernel when pruning is weak),
+ *             1 = always brute force, 2 = always pruned.  All three return the same exact value.   */
+int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
+/* "diameter_path" (1 brute / 2 pruned), "diameter_candidate_pairs", "diameter_candidate_tiles" of the last run;
+ * "diameter_bits" = the bit pattern of the last `hi` (reinterpret the int64 as a double)           */
+int cge_get_stat(cge_ctx *ctx, const char *key, int64_t *value);
+
 /* ---- profiling ------------------------------------------------------------------------------ */
 /* When enabled, every launch of the named kernels is bracketed by hipEvents on the ctx stream.   */
 int cge_profile_enable(cge_ctx *ctx, int on);

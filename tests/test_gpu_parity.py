@@ -317,6 +317,35 @@ def test_max_pair_dist_kernel(ctx, orc, example10k, n, d):
     assert max(parts) == exp
 
 
+@pytest.mark.parametrize("which", ["example10k", "synth20k", "structureless"])
+def test_diameter_pruned_equals_brute(ctx, orc, example10k, synth20k, which):
+    """The branch-and-bound diameter (landmark-pair bounds) returns bit for bit the brute-force `hi`,
+    on clustered data (heavy pruning) and on an isotropic cloud (hardly any pruning)."""
+    if which == "example10k":
+        g, land, method = example10k, 200, "rss"
+        vw = g["vweights"]
+    elif which == "synth20k":
+        g, land, method = synth20k, 300, "size"
+        vw = g["vweights"]
+    else:
+        rng = np.random.default_rng(5)
+        g = dict(synth20k)
+        g["embedding"] = np.asfortranarray(rng.standard_normal((g["n"], 32)))
+        land, method, vw = 150, "diameter", g["vweights"]
+    exp = orc.max_pair_dist(g["embedding"])
+    ctx.set_inputs(g["edges"], g["eweights"], vw, g["comm"], g["embedding"])
+    got = {}
+    for opt in (1, 2, 0):
+        ctx.set_option("diameter", opt)
+        res = ctx.score(g["clusters"], land, 4, method, seed=3, auc_samples=2000)
+        hi, path, pairs, tiles = ctx.last_diameter()
+        got[opt] = (hi, path, res.tolist())
+        assert hi == exp, (which, opt, hi, exp, path, pairs, tiles)
+    ctx.set_option("diameter", 0)
+    assert got[1][1] == "brute" and got[2][1] == "pruned"
+    assert got[1][2] == got[2][2] == got[0][2]  # identical score vectors
+
+
 def test_draw_samples_are_non_edges(ctx, synth20k):
     from cge.jl_amd import api
 
