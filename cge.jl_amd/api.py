@@ -367,7 +367,9 @@ class Context:
 
     def phase_ms(self):
         res = {}
-        for ph in ("landmarks", "aggregate", "scatter", "diameter", "samples", "sweep"):
+        buf = C.create_string_buffer(4096)
+        self._check(self.L.cge_phase_names(self.h, buf, C.c_int64(4096)))
+        for ph in filter(None, buf.value.decode().split(",")):
             ms = C.c_double()
             self._check(self.L.cge_phase_ms(self.h, ph.encode(), C.byref(ms)))
             res[ph] = ms.value

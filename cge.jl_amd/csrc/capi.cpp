@@ -276,6 +276,7 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
     hipStream_t st = c->stream;
     double t0 = now_ms();
     land = clamp_to_unique_rows(c, land, &c->lm_truncated);
+    c->phases.ms["lm_unique"] = now_ms() - t0;
     std::vector<i64> gid;
     host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, nullptr);
     HIP_CHECK(hipStreamSynchronize(st));
@@ -808,6 +809,16 @@ int cge_profile_names(cge_ctx *c, char *buf, int64_t buf_len) {
     if (!c || !buf || buf_len <= 0) return CGE_E_ARG;
     std::string s;
     for (auto &kv : c->timers) {
+        if (!s.empty()) s += ",";
+        s += kv.first;
+    }
+    snprintf(buf, (size_t)buf_len, "%s", s.c_str());
+    return CGE_OK;
+}
+int cge_phase_names(cge_ctx *c, char *buf, int64_t buf_len) {
+    if (!c || !buf || buf_len <= 0) return CGE_E_ARG;
+    std::string s;
+    for (auto &kv : c->phases.ms) {
         if (!s.empty()) s += ",";
         s += kv.first;
     }

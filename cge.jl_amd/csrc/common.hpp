@@ -205,6 +205,7 @@ void k_group_mean(cge_ctx *c, const double *Xr, const double *vw, const i32 *row
 void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
                  const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
                  i64 d, const double *mean, double *part, double *cov);
+bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec);
 void k_group_project(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *row_task, i64 n_rows,
                      i64 d, const double *mean, const double *vec, double *z);
 // landmark aggregation (src/landmarks.jl:387-430) with CSR landmark -> members (ascending vertex id)

@@ -291,6 +291,232 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
     hipLaunchKernelGGL(group_cov_final_kernel, g2, dim3(256), 0, c->stream, part, task_chunk_off, dd, cov);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched principal eigenvector, one workgroup per d x d covariance (d <= 128: the matrix lives in
+// LDS).  Same algorithm as host_eig_top (landmarks_host.cpp): Householder tridiagonalisation,
+// largest eigenvalue by (64-way) multisection on the Sturm count, inverse iteration with a pivoted
+// tridiagonal LU, back-transformation, sign = largest-|component| positive.
+// Replaces `eigvecs(A)[:, end]` (src/landmarks.jl:99,162,225,254).
+__device__ __forceinline__ double eig_block_sum(double v, double *red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict__ cov, int d,
+                                                        double *__restrict__ vec) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *A = sh;            // d*d, symmetric, row-major
+    double *V = A + d * d;     // d  Householder vector, later the eigenvector y
+    double *W = V + d;         // d
+    double *Pp = W + d;        // 2*d partial mat-vec halves
+    double *beta = Pp + 2 * d; // d
+    double *diag = beta + d;   // d
+    double *off = diag + d;    // d
+    double *red = off + d;     // 32: [0..3] block sums, [4] lambda, [5] sign, [8..19] Gershgorin staging
+    double *tri = red + 32;    // 4*d: dl, dd, du, du2
+    const int tid = threadIdx.x;
+    const double *src = cov + (size_t)blockIdx.x * d * d;
+    double *out = vec + (size_t)blockIdx.x * d;
+    for (int e = tid; e < d * d; e += 256) A[e] = src[e];
+    if (tid < d) { beta[tid] = 0.0; off[tid] = 0.0; }
+    __syncthreads();
+    if (d == 1) {
+        if (tid == 0) out[0] = 1.0;
+        return;
+    }
+    // ---- tridiagonalisation ------------------------------------------------------------------------
+    for (int k = 0; k + 2 < d; k++) {
+        const int r = d - k - 1, o = k + 1;
+        const double xi = (tid < r) ? A[k * d + o + tid] : 0.0;
+        const double sigma = eig_block_sum((tid >= 1 && tid < r) ? xi * xi : 0.0, red);
+        const double alpha = A[k * d + o];
+        if (sigma == 0.0) { // uniform: no reflection needed
+            if (tid == 0) { beta[k] = 0.0; off[k] = alpha; }
+            __syncthreads();
+            continue;
+        }
+        const double mu = sqrt(alpha * alpha + sigma);
+        const double v0 = (alpha <= 0.0) ? alpha - mu : -sigma / (alpha + mu);
+        const double bk = 2.0 * v0 * v0 / (sigma + v0 * v0);
+        if (tid < r) V[tid] = (tid == 0) ? 1.0 : xi / v0;
+        if (tid == 0) { beta[k] = bk; off[k] = mu; }
+        __syncthreads();
+        { // p = bk * B v, B = A[o.., o..]; column access (B symmetric) keeps LDS reads conflict free
+            const int i = tid & 127, half = tid >> 7;
+            double s = 0.0;
+            if (i < r) {
+                const int jm = (r + 1) >> 1, j0 = half ? jm : 0, j1 = half ? r : jm;
+                for (int j = j0; j < j1; j++) s += A[(o + j) * d + o + i] * V[j];
+                Pp[half * d + i] = s; // i < r <= d: stays inside the 2*d staging area
+            }
+        }
+        __syncthreads();
+        const double pi = (tid < r) ? bk * (Pp[tid] + Pp[d + tid]) : 0.0;
+        const double pv = eig_block_sum((tid < r) ? pi * V[tid] : 0.0, red);
+        const double K = 0.5 * bk * pv;
+        if (tid < r) W[tid] = pi - K * V[tid];
+        __syncthreads();
+        {
+            const int i = tid & 127;
+            if (i < r) {
+                const double vi = V[i], wi = W[i];
+                for (int j = tid >> 7; j < r; j += 2) A[(o + j) * d + o + i] -= vi * W[j] + wi * V[j];
+            }
+        }
+        if (tid >= 1 && tid < r) A[k * d + o + tid] = V[tid]; // keep the reflector in row k (v[0] = 1 implicit)
+        __syncthreads();
+    }
+    if (tid < d) diag[tid] = A[tid * d + tid];
+    if (tid == 0) off[d - 2] = A[(d - 2) * d + (d - 1)];
+    __syncthreads();
+    // ---- Gershgorin bounds ---------------------------------------------------------------------------
+    double glo = 1e300, ghi = -1e300, gn = 0.0;
+    if (tid < d) {
+        const double rad = (tid > 0 ? fabs(off[tid - 1]) : 0.0) + (tid + 1 < d ? fabs(off[tid]) : 0.0);
+        glo = diag[tid] - rad;
+        ghi = diag[tid] + rad;
+        gn = fabs(diag[tid]) + rad;
+    }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        glo = fmin(glo, __shfl_xor(glo, o2));
+        ghi = fmax(ghi, __shfl_xor(ghi, o2));
+        gn = fmax(gn, __shfl_xor(gn, o2));
+    }
+    __syncthreads();
+    double *gs = red + 8;
+    if ((tid & 63) == 0) { gs[(tid >> 6) * 3] = glo; gs[(tid >> 6) * 3 + 1] = ghi; gs[(tid >> 6) * 3 + 2] = gn; }
+    __syncthreads();
+    glo = fmin(fmin(gs[0], gs[3]), fmin(gs[6], gs[9]));
+    ghi = fmax(fmax(gs[1], gs[4]), fmax(gs[7], gs[10]));
+    gn = fmax(fmax(gs[2], gs[5]), fmax(gs[8], gs[11]));
+    const double tiny = fmax(gn, 2.2250738585072014e-308) * 2.220446049250313e-16;
+    __syncthreads();
+    // ---- largest eigenvalue: 64-way multisection on the Sturm count (wave 0) ------------------------------
+    if (tid < 64) {
+        double lo = glo, hi = ghi + tiny;
+        for (int it = 0; it < 64; it++) {
+            const double x = lo + (hi - lo) * ((double)(tid + 1) / 65.0);
+            int cnt = 0;
+            double q = diag[0] - x;
+            if (q < 0) cnt++;
+            for (int i = 1; i < d; i++) {
+                if (q == 0.0) q = tiny;
+                q = diag[i] - x - off[i - 1] * off[i - 1] / q;
+                if (q < 0) cnt++;
+            }
+            const unsigned long long mask = __ballot(cnt >= d);
+            double nlo, nhi;
+            if (mask == 0ULL) {
+                nlo = __shfl(x, 63);
+                nhi = hi;
+            } else {
+                const int f = __ffsll((long long)mask) - 1;
+                nhi = __shfl(x, f);
+                nlo = (f > 0) ? __shfl(x, f - 1) : lo;
+            }
+            if (!(nhi > nlo) || (nlo == lo && nhi == hi)) break;
+            lo = fmax(lo, nlo);
+            hi = fmin(hi, nhi);
+        }
+        if (tid == 0) red[4] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    // ---- inverse iteration (one lane; O(d) per solve) ---------------------------------------------------------
+    if (tid == 0) {
+        const double lam = red[4];
+        double *dl = tri, *dd = tri + d, *du = tri + 2 * d, *du2 = tri + 3 * d;
+        unsigned long long swp0 = 0ULL, swp1 = 0ULL; // pivot flags, d <= 128
+        for (int i = 0; i < d; i++) {
+            dd[i] = diag[i] - lam;
+            dl[i] = (i + 1 < d) ? off[i] : 0.0;
+            du[i] = (i + 1 < d) ? off[i] : 0.0;
+            du2[i] = 0.0;
+        }
+        for (int i = 0; i + 1 < d; i++) {
+            if (fabs(dd[i]) >= fabs(dl[i])) {
+                if (dd[i] == 0.0) dd[i] = tiny;
+                const double f = dl[i] / dd[i];
+                dl[i] = f;
+                dd[i + 1] -= f * du[i];
+            } else {
+                const double f = dd[i] / dl[i];
+                dd[i] = dl[i];
+                dl[i] = f;
+                const double t = du[i];
+                du[i] = dd[i + 1];
+                dd[i + 1] = t - f * dd[i + 1];
+                if (i + 2 < d) {
+                    du2[i] = du[i + 1];
+                    du[i + 1] = -f * du[i + 1];
+                }
+                if (i < 64) swp0 |= 1ULL << i; else swp1 |= 1ULL << (i - 64);
+            }
+        }
+        if (dd[d - 1] == 0.0) dd[d - 1] = tiny;
+        double *y = V;
+        for (int i = 0; i < d; i++) y[i] = 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0;
+        for (int it = 0; it < 4; it++) {
+            for (int i = 0; i + 1 < d; i++) {
+                const bool sw = (i < 64) ? ((swp0 >> i) & 1ULL) : ((swp1 >> (i - 64)) & 1ULL);
+                if (!sw)
+                    y[i + 1] -= dl[i] * y[i];
+                else {
+                    const double t = y[i];
+                    y[i] = y[i + 1];
+                    y[i + 1] = t - dl[i] * y[i];
+                }
+            }
+            y[d - 1] /= dd[d - 1];
+            y[d - 2] = (y[d - 2] - du[d - 2] * y[d - 1]) / dd[d - 2];
+            for (int i = d - 3; i >= 0; i--) y[i] = (y[i] - du[i] * y[i + 1] - du2[i] * y[i + 2]) / dd[i];
+            double amax = 0.0;
+            for (int i = 0; i < d; i++) amax = fmax(amax, fabs(y[i]));
+            if (!(amax > 0.0) || !(amax < 1e300)) {
+                for (int i = 0; i < d; i++) y[i] = (i == 0) ? 1.0 : 0.0;
+                break;
+            }
+            double nrm = 0.0;
+            for (int i = 0; i < d; i++) { y[i] /= amax; nrm += y[i] * y[i]; }
+            nrm = sqrt(nrm);
+            for (int i = 0; i < d; i++) y[i] /= nrm;
+        }
+    }
+    __syncthreads();
+    // ---- back-transformation x = H_0 H_1 ... H_{d-3} y ------------------------------------------------------------
+    for (int k = d - 3; k >= 0; k--) {
+        const double bk = beta[k];
+        if (bk == 0.0) continue; // uniform
+        const int r = d - k - 1, o = k + 1;
+        const double vk = (tid < r) ? (tid == 0 ? 1.0 : A[k * d + o + tid]) : 0.0;
+        const double s = bk * eig_block_sum((tid < r) ? vk * V[o + tid] : 0.0, red);
+        if (tid < r) V[o + tid] -= s * vk;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double nrm = 0.0;
+        for (int i = 0; i < d; i++) nrm += V[i] * V[i];
+        nrm = sqrt(nrm);
+        int big = 0;
+        for (int i = 0; i < d; i++) {
+            V[i] /= nrm;
+            if (fabs(V[i]) > fabs(V[big])) big = i;
+        }
+        red[5] = (V[big] < 0.0) ? -1.0 : 1.0;
+    }
+    __syncthreads();
+    if (tid < d) out[tid] = V[tid] * red[5];
+}
+bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec) {
+    if (d > 128) return false; // the matrix no longer fits LDS: the caller uses the host solver
+    const size_t lds = (size_t)(d * d + 12 * d + 40) * sizeof(double);
+    ScopedKernelTimer t(c, "group_eig");
+    hipLaunchKernelGGL(group_eig_kernel, dim3((unsigned)n_tasks), dim3(256), lds, c->stream, cov, (int)d, vec);
+    return true;
+}
+
 // projection z_j = sum_c ((x_jc - mu_c) * sqrt(w_j)) * v_c ; one wave per row
 __global__ void group_project_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                      const i32 *__restrict__ rows, const i32 *__restrict__ row_task, i64 n_rows, i64 d,

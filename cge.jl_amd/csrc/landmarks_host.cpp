@@ -22,6 +22,15 @@
 
 namespace {
 
+// accumulates wall time of a scope into ctx->phases (reported by cge_phase_ms)
+struct PhaseAcc {
+    cge_ctx *c;
+    const char *name;
+    double t0;
+    PhaseAcc(cge_ctx *ctx, const char *n) : c(ctx), name(n), t0(now_ms()) {}
+    ~PhaseAcc() { c->phases.ms[name] += now_ms() - t0; }
+};
+
 struct Group {
     std::vector<i64> what; // 1-based vertex ids, in the reference's order
     double value = 0.0;    // heap key: -total_rss, or eps() for singletons
@@ -501,6 +510,7 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
         const i64 T = (i64)(b1 - b0);
         i64 R = 0;
         for (size_t t = b0; t < b1; t++) R += (i64)big[t]->what.size();
+        PhaseAcc *pa = new PhaseAcc(c, "lm_pack");
         const i64 CH = 1024;
         std::vector<i32> rows(R), row_task(R), chunk_task, chunk_beg, chunk_end, task_chunk_off(T + 1), task_row_off(T + 1);
         i64 pos = 0;
@@ -540,6 +550,8 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
         HIP_CHECK(hipMemcpyAsync(d_cb.p, chunk_beg.data(), sizeof(i32) * NC, hipMemcpyHostToDevice, st));
         HIP_CHECK(hipMemcpyAsync(d_ce.p, chunk_end.data(), sizeof(i32) * NC, hipMemcpyHostToDevice, st));
         HIP_CHECK(hipMemcpyAsync(d_tco.p, task_chunk_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
+        delete pa;
+        pa = new PhaseAcc(c, "lm_stats_dev");
         {
             ScopedKernelTimer tm(c, "group_stats");
             k_group_mean(c, c->Xr.p, c->vw.p, d_rows.p, d_ct.p, d_cb.p, d_ce.p, NC, d_tco.p, T, d, d_part.p, d_mean.p,
@@ -547,17 +559,27 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             k_group_cov(c, c->Xr.p, c->vw.p, d_rows.p, d_ct.p, d_cb.p, d_ce.p, NC, d_tco.p, T, d, d_mean.p, d_part.p,
                         d_cov.p);
         }
-        std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d), z(R);
-        HIP_CHECK(hipMemcpyAsync(cov.data(), d_cov.p, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        parallel_for(c->n_threads, T, [&](i64 t) { host_eig_top(&cov[(size_t)t * d * d], d, &vec[(size_t)t * d]); });
-        HIP_CHECK(hipMemcpyAsync(d_vec.p, vec.data(), sizeof(double) * vec.size(), hipMemcpyHostToDevice, st));
+        std::vector<double> z(R);
+        delete pa;
+        pa = new PhaseAcc(c, "lm_eig");
+        if (!k_group_eig(c, d_cov.p, T, d, d_vec.p)) { // d > 128: host solver on a worker pool
+            std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d);
+            HIP_CHECK(hipMemcpyAsync(cov.data(), d_cov.p, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            parallel_for(c->n_threads, T, [&](i64 t) { host_eig_top(&cov[(size_t)t * d * d], d, &vec[(size_t)t * d]); });
+            HIP_CHECK(hipMemcpyAsync(d_vec.p, vec.data(), sizeof(double) * vec.size(), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st)); // vec goes out of scope
+        }
+        delete pa;
+        pa = new PhaseAcc(c, "lm_project_dev");
         {
             ScopedKernelTimer tm(c, "group_project");
             k_group_project(c, c->Xr.p, c->vw.p, d_rows.p, d_row_task.p, R, d, d_mean.p, d_vec.p, d_z.p);
         }
         HIP_CHECK(hipMemcpyAsync(z.data(), d_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        delete pa;
+        PhaseAcc pcut(c, "lm_cut_host");
         parallel_for(c->n_threads, T, [&](i64 t) {
             Group *g = big[b0 + t];
             const i64 k = (i64)g->what.size();

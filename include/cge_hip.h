@@ -203,6 +203,7 @@ int cge_profile_names(cge_ctx *ctx, char *buf, int64_t buf_len); /* comma-separa
 /* wall-clock phase timers of the last cge_score call: "landmarks","aggregate","scatter","dist",
  * "diameter","sweep","samples" (milliseconds, host clock around stream-synchronised phases)      */
 int cge_phase_ms(cge_ctx *ctx, const char *phase, double *ms);
+int cge_phase_names(cge_ctx *ctx, char *buf, int64_t buf_len); /* comma-separated, incl. the lm_* sub-phases */
 
 #ifdef __cplusplus
 }
