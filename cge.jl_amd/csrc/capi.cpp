@@ -62,6 +62,7 @@ int cge_create(cge_ctx **out, int device, void *stream) {
         }
         unsigned hc = std::thread::hardware_concurrency();
         c->n_threads = (int)std::max(1u, std::min(hc ? hc : 8u, 16u));
+        c->pool = new ThreadPool(c->n_threads - 1);
     } catch (const CgeError &e) {
         delete c;
         return e.code;
@@ -76,6 +77,8 @@ void cge_destroy(cge_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     flush_timers(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c->pool;
+    c->pool = nullptr;
     delete c;
 }
 
@@ -84,6 +87,8 @@ const char *cge_last_error(const cge_ctx *c) { return c ? c->err.c_str() : "null
 int cge_set_host_threads(cge_ctx *c, int n) {
     if (!c || n < 1) return CGE_E_ARG;
     c->n_threads = n;
+    delete c->pool;
+    c->pool = new ThreadPool(n - 1);
     return CGE_OK;
 }
 

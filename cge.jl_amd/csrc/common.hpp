@@ -3,7 +3,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +71,97 @@ struct DevBuf {
     }
 };
 
+// pinned (page-locked) host buffer, grow-only
+template <typename T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PinBuf() {}
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t count) {
+        if (count <= n && p) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        if (count == 0) count = 1;
+        HIP_CHECK(hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+};
+
+// Persistent worker pool: run(n, fn) executes fn(0..n-1) on the workers + the calling thread.
+class ThreadPool {
+  public:
+    explicit ThreadPool(int n_workers) {
+        for (int t = 0; t < n_workers; t++) workers_.emplace_back([this]() { loop(); });
+    }
+    ~ThreadPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    int size() const { return (int)workers_.size() + 1; }
+    void run(i64 n, const std::function<void(i64)> &fn) {
+        if (n <= 0) return;
+        if (n == 1 || workers_.empty()) {
+            for (i64 i = 0; i < n; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            pending_ = (int)workers_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void work() {
+        for (;;) {
+            const i64 i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i);
+        }
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_cv_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(i64)> *fn_ = nullptr;
+    i64 n_ = 0;
+    std::atomic<i64> next_{0};
+    int pending_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+
 struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     i64 launches = 0;
@@ -94,6 +190,7 @@ struct cge_ctx {
     bool own_stream = false;
     std::string err;
     int n_threads = 8;
+    ThreadPool *pool = nullptr; // persistent host workers (n_threads - 1 + caller)
     cge_collectives coll{};
     bool has_coll = false;
     DevBuf<double> xown;  // library-owned exchange buffer (cge_exchange_buffer)
@@ -151,7 +248,10 @@ struct cge_ctx {
     double stat_last_hi = 0.0;
     // scratch of the batched split engine (landmarks_host.cpp)
     DevBuf<i32> ls_rows, ls_row_task, ls_ct, ls_cb, ls_ce, ls_tco;
-    DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z;
+    DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z, ls_sums;
+    DevBuf<unsigned char> ls_side, ls_state;
+    DevBuf<double> ls_params; // per-task round parameters of the rss rule
+    PinBuf<double> pin_sums, pin_z, pin_params;
 
     // ---- profiling -------------------------------------------------------------------------
     bool profiling = false;
@@ -205,6 +305,11 @@ void k_group_mean(cge_ctx *c, const double *Xr, const double *vw, const i32 *row
 void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
                  const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
                  i64 d, const double *mean, double *part, double *cov);
+void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const unsigned char *side,
+                       const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
+                       i64 d, double *part, double *out);
+void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, const double *params,
+                unsigned char *state, unsigned char *side);
 bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec);
 void k_group_project(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *row_task, i64 n_rows,
                      i64 d, const double *mean, const double *vec, double *z);

@@ -292,6 +292,120 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
 }
 
 // ------------------------------------------------------------------------------------------------
+// Per-task, per-side WSSE column sums (src/landmarks.jl:50-67): for the rows of a task whose side[j] is
+// 1 or 2, out[task][side-1] = { sum w x^2 [d], sum w x [d], sum w }.  Used by the rss rule's median-cut
+// rounds (:184-185, :201-202) and for the children's total_rss (:269).  Rows with side 0 are skipped.
+// Fixed order: rows of a chunk are dealt to the 4 waves round-robin, waves and chunks combined in order.
+#define SS_SLOTS 8 // columns per lane: d <= 512
+__global__ __launch_bounds__(256) void group_side_sums_partial_kernel(const double *__restrict__ Xr,
+                                                                      const double *__restrict__ vw,
+                                                                      const i32 *__restrict__ rows,
+                                                                      const unsigned char *__restrict__ side,
+                                                                      const i32 *__restrict__ chunk_beg,
+                                                                      const i32 *__restrict__ chunk_end, i64 d,
+                                                                      double *__restrict__ part /* [chunk][2][2d+1] */) {
+    __shared__ double red[4][64 + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const i64 ch = blockIdx.x;
+    const i32 beg = chunk_beg[ch], end = chunk_end[ch];
+    double ss[2][SS_SLOTS], s1[2][SS_SLOTS], ws[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int t = 0; t < SS_SLOTS; t++) { ss[q][t] = 0.0; s1[q][t] = 0.0; }
+    for (i32 j = beg + wave; j < end; j += 4) {
+        const int sd = side[j]; // wave-uniform
+        if (sd == 0) continue;
+        const i64 v = rows[j];
+        const double w = vw[v];
+        const double *x = Xr + v * d;
+        if (sd == 1) {
+            ws[0] += w;
+#pragma unroll
+            for (int t = 0; t < SS_SLOTS; t++) {
+                const i64 col = lane + 64 * t;
+                if (col < d) { const double xv = x[col]; ss[0][t] += w * (xv * xv); s1[0][t] += w * xv; }
+            }
+        } else {
+            ws[1] += w;
+#pragma unroll
+            for (int t = 0; t < SS_SLOTS; t++) {
+                const i64 col = lane + 64 * t;
+                if (col < d) { const double xv = x[col]; ss[1][t] += w * (xv * xv); s1[1][t] += w * xv; }
+            }
+        }
+    }
+    double *out = part + ch * 2 * (2 * d + 1);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+#pragma unroll
+        for (int t = 0; t < SS_SLOTS; t++) {
+            if ((i64)64 * t >= d) break;
+            const i64 col = lane + 64 * t;
+            __syncthreads();
+            red[wave][lane] = ss[q][t];
+            __syncthreads();
+            if (wave == 0 && col < d) out[q * (2 * d + 1) + col] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+            __syncthreads();
+            red[wave][lane] = s1[q][t];
+            __syncthreads();
+            if (wave == 0 && col < d) out[q * (2 * d + 1) + d + col] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        }
+        __syncthreads();
+        if (lane == 0) red[wave][0] = ws[q];
+        __syncthreads();
+        if (threadIdx.x == 0) out[q * (2 * d + 1) + 2 * d] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+    }
+}
+__global__ void group_side_sums_final_kernel(const double *__restrict__ part, const i32 *__restrict__ task_chunk_off,
+                                             i64 width, double *__restrict__ out) {
+    const i64 t = blockIdx.x;
+    const i32 c0 = task_chunk_off[t], c1 = task_chunk_off[t + 1];
+    for (i64 e = threadIdx.x; e < width; e += blockDim.x) {
+        double s = 0.0;
+        for (i32 ch = c0; ch < c1; ch++) s += part[(i64)ch * width + e];
+        out[t * width + e] = s;
+    }
+}
+void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const unsigned char *side,
+                       const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
+                       i64 d, double *part, double *out) {
+    if (d > 64 * SS_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * SS_SLOTS);
+    ScopedKernelTimer t(c, "group_side_sums");
+    hipLaunchKernelGGL(group_side_sums_partial_kernel, dim3((unsigned)n_chunks), dim3(256), 0, c->stream, Xr, vw, rows,
+                       side, chunk_beg, chunk_end, d, part);
+    hipLaunchKernelGGL(group_side_sums_final_kernel, dim3((unsigned)n_tasks), dim3(256), 0, c->stream, part,
+                       task_chunk_off, 2 * (2 * d + 1), out);
+}
+
+// Side flags of one rss round, derived on the device (no per-round row-sized upload).  Per task t,
+// params[4t..4t+3] = { prev_med, absorb (0/1/2: the side that was absorbed after the previous round),
+// cur_med, mode (0 idle, 1 median round, 2 leftover round) }.  state[j]: 0 = gray, 1 = low, 2 = high.
+__global__ void rss_side_kernel(const double *__restrict__ z, const i32 *__restrict__ row_task, i64 n_rows,
+                                const double *__restrict__ params, unsigned char *__restrict__ state,
+                                unsigned char *__restrict__ side) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rows) return;
+    const double *p = params + 4 * (i64)row_task[j];
+    unsigned char st = state[j], sd = 0;
+    if (st == 0) {
+        const int absorb = (int)p[1], mode = (int)p[3];
+        const double zj = z[j];
+        if (absorb != 0 && ((zj < p[0]) ? 1 : 2) == absorb) {
+            st = (unsigned char)absorb;
+            state[j] = st;
+        }
+        if (st == 0 && mode != 0) sd = (mode == 2) ? 1 : ((zj < p[2]) ? 1 : 2);
+    }
+    side[j] = sd;
+}
+void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, const double *params,
+                unsigned char *state, unsigned char *side) {
+    hipLaunchKernelGGL(rss_side_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, c->stream, z, row_task,
+                       n_rows, params, state, side);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Batched principal eigenvector, one workgroup per d x d covariance (d <= 128: the matrix lives in
 // LDS).  Same algorithm as host_eig_top (landmarks_host.cpp): Householder tridiagonalisation,
 // largest eigenvalue by (64-way) multisection on the Sturm count, inverse iteration with a pivoted
@@ -499,6 +613,10 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
         double nrm = 0.0;
         for (int i = 0; i < d; i++) nrm += V[i] * V[i];
         nrm = sqrt(nrm);
+        if (!(nrm > 0.0) || !(nrm < 1e300)) { // zero / degenerate matrix: any unit vector is an eigenvector
+            for (int i = 0; i < d; i++) V[i] = (i == 0) ? 1.0 : 0.0;
+            nrm = 1.0;
+        }
         int big = 0;
         for (int i = 0; i < d; i++) {
             V[i] /= nrm;

@@ -80,26 +80,16 @@ struct Heap {
     Group *top() const { return a[1]; }
 };
 
+// all host-parallel loops go through the ctx's persistent pool
 template <typename F>
-void parallel_for(int n_threads, i64 n, F &&fn) {
+void parallel_for(cge_ctx *c, i64 n, F &&fn) {
     if (n <= 0) return;
-    const int nt = (int)std::min<i64>(std::max(1, n_threads), n);
-    if (nt == 1) {
+    if (!c->pool || n == 1) {
         for (i64 i = 0; i < n; i++) fn(i);
         return;
     }
-    std::atomic<i64> next{0};
-    std::vector<std::thread> th;
-    th.reserve(nt);
-    for (int t = 0; t < nt; t++)
-        th.emplace_back([&]() {
-            for (;;) {
-                const i64 i = next.fetch_add(1);
-                if (i >= n) break;
-                fn(i);
-            }
-        });
-    for (auto &t : th) t.join();
+    const std::function<void(i64)> f = std::forward<F>(fn);
+    c->pool->run(n, f);
 }
 
 struct Wsse {
@@ -464,6 +454,10 @@ void host_eig_top(const double *Ain, i64 d, double *vout) {
     double nrm = 0.0;
     for (i64 i = 0; i < d; i++) nrm += y[i] * y[i];
     nrm = std::sqrt(nrm);
+    if (!(nrm > 0.0) || !std::isfinite(nrm)) { // zero / degenerate matrix: any unit vector is an eigenvector
+        for (i64 i = 0; i < d; i++) y[i] = (i == 0) ? 1.0 : 0.0;
+        nrm = 1.0;
+    }
     i64 big = 0;
     for (i64 i = 0; i < d; i++) {
         vout[i] = y[i] / nrm;
@@ -476,9 +470,228 @@ void host_eig_top(const double *Ain, i64 d, double *vout) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-// Compute the split of every task (device: mean/cov/projection; host: eigenvector, cut, RSS).
-void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
+// ---- batched device work --------------------------------------------------------------------------------
+// A batch = a list of groups; `rows` holds their 0-based vertex ids back to back in the groups' own
+// member order; every group is cut into chunks of CH rows (one workgroup each).
+struct Batch {
+    i64 T = 0, R = 0, NC = 0;
+    std::vector<i32> rows, row_task, chunk_task, chunk_beg, chunk_end, task_chunk_off, task_row_off;
+};
+void build_batch(Group *const *groups, i64 T, Batch &B) {
+    const i64 CH = 1024;
+    B.T = T;
+    B.R = 0;
+    for (i64 t = 0; t < T; t++) B.R += (i64)groups[t]->what.size();
+    B.rows.resize(B.R);
+    B.row_task.resize(B.R);
+    B.chunk_task.clear(); B.chunk_beg.clear(); B.chunk_end.clear();
+    B.task_chunk_off.assign(T + 1, 0);
+    B.task_row_off.assign(T + 1, 0);
+    i64 pos = 0;
+    for (i64 t = 0; t < T; t++) {
+        const Group *g = groups[t];
+        B.task_row_off[t] = (i32)pos;
+        B.task_chunk_off[t] = (i32)B.chunk_task.size();
+        const i64 k = (i64)g->what.size();
+        for (i64 j = 0; j < k; j++) {
+            B.rows[pos + j] = (i32)(g->what[j] - 1);
+            B.row_task[pos + j] = (i32)t;
+        }
+        for (i64 s = 0; s < k; s += CH) {
+            B.chunk_task.push_back((i32)t);
+            B.chunk_beg.push_back((i32)(pos + s));
+            B.chunk_end.push_back((i32)(pos + std::min(k, s + CH)));
+        }
+        pos += k;
+    }
+    B.task_row_off[T] = (i32)pos;
+    B.task_chunk_off[T] = (i32)B.chunk_task.size();
+    B.NC = (i64)B.chunk_task.size();
+}
+void upload_batch(cge_ctx *c, const Batch &B) { // grow-only scratch owned by the ctx
+    hipStream_t st = c->stream;
     const i64 d = c->d;
+    c->ls_rows.ensure(B.R); c->ls_row_task.ensure(B.R); c->ls_ct.ensure(B.NC); c->ls_cb.ensure(B.NC);
+    c->ls_ce.ensure(B.NC); c->ls_tco.ensure(B.T + 1);
+    c->ls_part.ensure((size_t)B.NC * std::max(d * d, 2 * (2 * d + 1)));
+    c->ls_side.ensure(B.R);
+    c->ls_sums.ensure((size_t)B.T * 2 * (2 * d + 1));
+    HIP_CHECK(hipMemcpyAsync(c->ls_rows.p, B.rows.data(), sizeof(i32) * B.R, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_row_task.p, B.row_task.data(), sizeof(i32) * B.R, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_ct.p, B.chunk_task.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_cb.p, B.chunk_beg.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_ce.p, B.chunk_end.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_tco.p, B.task_chunk_off.data(), sizeof(i32) * (B.T + 1), hipMemcpyHostToDevice, st));
+}
+// sums[t][q] = { sum w x^2 [d], sum w x [d], sum w } over the rows of task t with side == q+1 (device)
+// (the side flags are already in c->ls_side; the result lands in the pinned buffer c->pin_sums)
+const double *side_sums_resident(cge_ctx *c, const Batch &B) {
+    const i64 d = c->d, width = 2 * (2 * d + 1);
+    hipStream_t st = c->stream;
+    k_group_side_sums(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
+                      c->ls_part.p, c->ls_sums.p);
+    c->pin_sums.ensure((size_t)B.T * width);
+    HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->ls_sums.p, sizeof(double) * B.T * width, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return c->pin_sums.p;
+}
+const double *side_sums(cge_ctx *c, const Batch &B, const std::vector<unsigned char> &side) {
+    HIP_CHECK(hipMemcpyAsync(c->ls_side.p, side.data(), (size_t)B.R, hipMemcpyHostToDevice, c->stream));
+    return side_sums_resident(c, B);
+}
+// sum over the columns of wsse(ss, s, ws)  (total_rss, src/landmarks.jl:269, given the column sums)
+inline double rss_from_sums(const double *q, i64 d) {
+    const double ws = q[2 * d];
+    double tot = 0.0;
+    for (i64 c2 = 0; c2 < d; c2++) tot += q[c2] - q[d + c2] * q[d + c2] / ws;
+    return tot;
+}
+inline double sum_wsse_plus(const std::vector<Wsse> &base, const double *q, i64 d) { // sum(wsse, base .+ WSSE(set))
+    const double ws = q[2 * d];
+    double tot = 0.0;
+    for (i64 c2 = 0; c2 < d; c2++) {
+        const double ss = base[c2].ss + q[c2], s1 = base[c2].s + q[d + c2], w = base[c2].ws + ws;
+        tot += ss - s1 * s1 / w;
+    }
+    return tot;
+}
+inline void add_sums(std::vector<Wsse> &base, const double *q, i64 d) {
+    const double ws = q[2 * d];
+    for (i64 c2 = 0; c2 < d; c2++) {
+        base[c2].ss += q[c2];
+        base[c2].s += q[d + c2];
+        base[c2].ws += ws;
+    }
+}
+
+// -total_rss of every group of a batch (roots of the local heaps), on the device
+void device_group_values(cge_ctx *c, std::vector<Group *> &groups) {
+    if (groups.empty()) return;
+    const i64 d = c->d, width = 2 * (2 * d + 1);
+    Batch B;
+    build_batch(groups.data(), (i64)groups.size(), B);
+    upload_batch(c, B);
+    std::vector<unsigned char> side(B.R, 1);
+    const double *sums = side_sums(c, B, side);
+    for (i64 t = 0; t < B.T; t++) groups[t]->value = -rss_from_sums(&sums[(size_t)t * width], d);
+}
+
+// split_cluster_rss (src/landmarks.jl:155-210) for a whole batch: the 1-D logic (arg-min/max, medians,
+// which half joins which side) runs on the host from z; the WSSE column sums of the candidate halves
+// (:184-185, :201-202) come from one device pass per round over the rows that are still undecided.
+struct RssState {
+    std::vector<i64> low, high, gray, t1, t2;
+    std::vector<Wsse> rl, rh;
+    double med = 0.0;
+    int phase = 0; // 0 = median rounds, 1 = leftover decision (:200-208), 2 = done
+    int rc = CGE_OK;
+};
+void rule_rss_batched(cge_ctx *c, const Batch &B, Group *const *groups, const std::vector<double> &z,
+                      std::vector<RssState> &st) {
+    const i64 T = B.T, d = c->d, width = 2 * (2 * d + 1);
+    const double *hX = c->h_Xr.data(), *hw = c->h_vw.data();
+    st.assign(T, RssState());
+    parallel_for(c, T, [&](i64 t) {
+        RssState &S = st[t];
+        const Group *g = groups[t];
+        const i64 k = (i64)g->what.size();
+        const double *zt = &z[B.task_row_off[t]];
+        i64 imin = 0, imax = 0;
+        for (i64 j = 1; j < k; j++) {
+            if (zt[j] < zt[imin]) imin = j;
+            if (zt[j] > zt[imax]) imax = j;
+        }
+        if (imin == imax) { S.rc = CGE_E_HOMOGENEOUS; S.phase = 2; return; }
+        S.low.assign(1, imin);
+        S.high.assign(1, imax);
+        S.gray.reserve(k);
+        for (i64 j = 0; j < k; j++)
+            if (j != imin && j != imax) S.gray.push_back(j);
+        S.rl.resize(d);
+        S.rh.resize(d);
+        const double *x1 = hX + (g->what[imin] - 1) * d, *x2 = hX + (g->what[imax] - 1) * d;
+        const double w1 = hw[g->what[imin] - 1], w2 = hw[g->what[imax] - 1];
+        for (i64 q = 0; q < d; q++) { // :169-170
+            S.rl[q] = {x1[q] * x1[q] * w1, x1[q] * w1, w1};
+            S.rh[q] = {x2[q] * x2[q] * w2, x2[q] * w2, w2};
+        }
+        std::vector<double> scr;
+        S.med = median_sel(zt, nullptr, k, scr);
+    });
+    // device state: 0 = gray for every row; the two seed rows are decided from the start
+    std::vector<unsigned char> state0(B.R, 0);
+    for (i64 t = 0; t < T; t++) {
+        if (st[t].phase == 2) continue;
+        state0[B.task_row_off[t] + st[t].low[0]] = 1;
+        state0[B.task_row_off[t] + st[t].high[0]] = 2;
+    }
+    hipStream_t stream = c->stream;
+    c->ls_state.ensure(B.R);
+    c->ls_params.ensure((size_t)4 * T);
+    c->pin_params.ensure((size_t)4 * T);
+    HIP_CHECK(hipMemcpyAsync(c->ls_state.p, state0.data(), (size_t)B.R, hipMemcpyHostToDevice, stream));
+    double *prm = c->pin_params.p; // {prev_med, absorb, cur_med, mode} per task
+    for (i64 t = 0; t < T; t++) { prm[4 * t] = 0.0; prm[4 * t + 1] = 0.0; prm[4 * t + 2] = st[t].med; prm[4 * t + 3] = st[t].phase == 2 ? 0.0 : 1.0; }
+    for (;;) {
+        i64 n_active = 0;
+        for (i64 t = 0; t < T; t++) n_active += (st[t].phase != 2);
+        if (n_active == 0) break;
+        // host copy of this round's halves (needed to update the member lists afterwards)
+        parallel_for(c, T, [&](i64 t) {
+            RssState &S = st[t];
+            if (S.phase != 0) return;
+            const double *zt = &z[B.task_row_off[t]];
+            S.t1.clear();
+            S.t2.clear();
+            for (i64 j : S.gray) (zt[j] < S.med ? S.t1 : S.t2).push_back(j);
+        });
+        HIP_CHECK(hipMemcpyAsync(c->ls_params.p, prm, sizeof(double) * 4 * T, hipMemcpyHostToDevice, stream));
+        k_rss_side(c, c->ls_z.p, c->ls_row_task.p, B.R, c->ls_params.p, c->ls_state.p, c->ls_side.p);
+        const double *sums = side_sums_resident(c, B);
+        parallel_for(c, T, [&](i64 t) {
+            RssState &S = st[t];
+            double *pt = prm + 4 * t;
+            if (S.phase == 2) { pt[1] = 0.0; pt[3] = 0.0; return; }
+            const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
+            const double *zt = &z[B.task_row_off[t]];
+            pt[0] = S.med; // becomes prev_med of the next round
+            pt[1] = 0.0;
+            if (S.phase == 0) {
+                if (sum_wsse_plus(S.rl, q1, d) < sum_wsse_plus(S.rh, q2, d)) {
+                    if (S.t1.empty()) { S.phase = 1; pt[3] = 2.0; return; }
+                    add_sums(S.rl, q1, d);
+                    S.low.insert(S.low.end(), S.t1.begin(), S.t1.end());
+                    S.gray.swap(S.t2);
+                    pt[1] = 1.0;
+                } else {
+                    if (S.t2.empty()) { S.phase = 1; pt[3] = 2.0; return; }
+                    add_sums(S.rh, q2, d);
+                    S.high.insert(S.high.end(), S.t2.begin(), S.t2.end());
+                    S.gray.swap(S.t1);
+                    pt[1] = 2.0;
+                }
+                if (S.gray.empty()) { S.phase = 2; pt[3] = 0.0; return; }
+                std::vector<double> scr;
+                S.med = median_sel(zt, &S.gray, 0, scr);
+                pt[2] = S.med;
+                pt[3] = 1.0;
+            } else { // :200-208, sums of the whole leftover are in q1
+                const double a = std::max(sum_wsse_plus(S.rl, q1, d), sum_wsse(S.rh));
+                const double b = std::max(sum_wsse(S.rl), sum_wsse_plus(S.rh, q1, d));
+                auto &dst = (a < b) ? S.low : S.high;
+                dst.insert(dst.end(), S.gray.begin(), S.gray.end());
+                S.gray.clear();
+                S.phase = 2;
+                pt[3] = 0.0;
+            }
+        });
+    }
+}
+
+// Compute the split of every task.  Device: mean, covariance, principal eigenvector, projection,
+// WSSE column sums of the rss rounds and of the children.  Host: the 1-D cut logic on z.
+void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
+    const i64 d = c->d, width = 2 * (2 * d + 1);
     const double *hX = c->h_Xr.data();
     const double *hw = c->h_vw.data();
     std::vector<Group *> big;
@@ -498,7 +711,6 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             g->vlow = g->vhigh = DBL_EPSILON;
             continue;
         }
-        if (k < 2) { g->rc = CGE_E_ASSERT; continue; }
         big.push_back(g);
     }
     if (big.empty()) return;
@@ -508,101 +720,95 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
     for (size_t b0 = 0; b0 < big.size(); b0 += (size_t)max_tasks) {
         const size_t b1 = std::min(big.size(), b0 + (size_t)max_tasks);
         const i64 T = (i64)(b1 - b0);
-        i64 R = 0;
-        for (size_t t = b0; t < b1; t++) R += (i64)big[t]->what.size();
-        PhaseAcc *pa = new PhaseAcc(c, "lm_pack");
-        const i64 CH = 1024;
-        std::vector<i32> rows(R), row_task(R), chunk_task, chunk_beg, chunk_end, task_chunk_off(T + 1), task_row_off(T + 1);
-        i64 pos = 0;
-        for (i64 t = 0; t < T; t++) {
-            const Group *g = big[b0 + t];
-            task_row_off[t] = (i32)pos;
-            task_chunk_off[t] = (i32)chunk_task.size();
-            const i64 k = (i64)g->what.size();
-            for (i64 j = 0; j < k; j++) {
-                rows[pos + j] = (i32)(g->what[j] - 1);
-                row_task[pos + j] = (i32)t;
-            }
-            for (i64 s = 0; s < k; s += CH) {
-                chunk_task.push_back((i32)t);
-                chunk_beg.push_back((i32)(pos + s));
-                chunk_end.push_back((i32)(pos + std::min(k, s + CH)));
-            }
-            pos += k;
-        }
-        task_row_off[T] = (i32)pos;
-        task_chunk_off[T] = (i32)chunk_task.size();
-        const i64 NC = (i64)chunk_task.size();
-
-        // grow-only scratch owned by the ctx (no hipMalloc/hipFree per batch)
-        DevBuf<i32> &d_rows = c->ls_rows, &d_row_task = c->ls_row_task, &d_ct = c->ls_ct, &d_cb = c->ls_cb,
-                    &d_ce = c->ls_ce, &d_tco = c->ls_tco;
-        DevBuf<double> &d_part = c->ls_part, &d_mean = c->ls_mean, &d_sw = c->ls_sw, &d_cov = c->ls_cov,
-                       &d_vec = c->ls_vec, &d_z = c->ls_z;
-        d_rows.ensure(R); d_row_task.ensure(R); d_ct.ensure(NC); d_cb.ensure(NC); d_ce.ensure(NC); d_tco.ensure(T + 1);
-        d_part.ensure((size_t)NC * std::max(d * d, d + 1));
-        d_mean.ensure((size_t)T * d); d_sw.ensure(T); d_cov.ensure((size_t)T * d * d); d_vec.ensure((size_t)T * d);
-        d_z.ensure(R);
+        Group *const *groups = &big[b0];
         hipStream_t st = c->stream;
-        HIP_CHECK(hipMemcpyAsync(d_rows.p, rows.data(), sizeof(i32) * R, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d_row_task.p, row_task.data(), sizeof(i32) * R, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d_ct.p, chunk_task.data(), sizeof(i32) * NC, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d_cb.p, chunk_beg.data(), sizeof(i32) * NC, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d_ce.p, chunk_end.data(), sizeof(i32) * NC, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d_tco.p, task_chunk_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
-        delete pa;
-        pa = new PhaseAcc(c, "lm_stats_dev");
+        Batch B;
         {
-            ScopedKernelTimer tm(c, "group_stats");
-            k_group_mean(c, c->Xr.p, c->vw.p, d_rows.p, d_ct.p, d_cb.p, d_ce.p, NC, d_tco.p, T, d, d_part.p, d_mean.p,
-                         d_sw.p);
-            k_group_cov(c, c->Xr.p, c->vw.p, d_rows.p, d_ct.p, d_cb.p, d_ce.p, NC, d_tco.p, T, d, d_mean.p, d_part.p,
-                        d_cov.p);
+            PhaseAcc pa(c, "lm_pack");
+            build_batch(groups, T, B);
+            upload_batch(c, B);
         }
-        std::vector<double> z(R);
-        delete pa;
-        pa = new PhaseAcc(c, "lm_eig");
-        if (!k_group_eig(c, d_cov.p, T, d, d_vec.p)) { // d > 128: host solver on a worker pool
-            std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d);
-            HIP_CHECK(hipMemcpyAsync(cov.data(), d_cov.p, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            parallel_for(c->n_threads, T, [&](i64 t) { host_eig_top(&cov[(size_t)t * d * d], d, &vec[(size_t)t * d]); });
-            HIP_CHECK(hipMemcpyAsync(d_vec.p, vec.data(), sizeof(double) * vec.size(), hipMemcpyHostToDevice, st));
-            HIP_CHECK(hipStreamSynchronize(st)); // vec goes out of scope
-        }
-        delete pa;
-        pa = new PhaseAcc(c, "lm_project_dev");
+        const i64 R = B.R, NC = B.NC;
+        c->ls_mean.ensure((size_t)T * d); c->ls_sw.ensure(T); c->ls_cov.ensure((size_t)T * d * d);
+        c->ls_vec.ensure((size_t)T * d); c->ls_z.ensure(R);
+        c->pin_z.ensure(R);
+        std::vector<double> z; // filled from the pinned staging buffer
         {
-            ScopedKernelTimer tm(c, "group_project");
-            k_group_project(c, c->Xr.p, c->vw.p, d_rows.p, d_row_task.p, R, d, d_mean.p, d_vec.p, d_z.p);
-        }
-        HIP_CHECK(hipMemcpyAsync(z.data(), d_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        delete pa;
-        PhaseAcc pcut(c, "lm_cut_host");
-        parallel_for(c->n_threads, T, [&](i64 t) {
-            Group *g = big[b0 + t];
-            const i64 k = (i64)g->what.size();
-            HView v{hX, hw, d, g->what.data(), k};
-            const double *zt = &z[task_row_off[t]];
-            std::vector<i64> lo, hi;
-            int rc;
-            switch (method) {
-            case CGE_METHOD_RSS: rc = rule_rss(v, zt, lo, hi); break;
-            case CGE_METHOD_RSS2: rc = rule_rss2(v, zt, lo, hi); break;
-            case CGE_METHOD_SIZE: rc = rule_cut(zt, k, true, lo, hi); break;
-            default: rc = rule_cut(zt, k, false, lo, hi); break;
+            PhaseAcc pa(c, "lm_pca_dev");
+            {
+                ScopedKernelTimer tm(c, "group_stats");
+                k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
+                             c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
+                k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
+                            c->ls_mean.p, c->ls_part.p, c->ls_cov.p);
             }
-            g->rc = rc;
-            if (rc != CGE_OK) return;
-            if (lo.empty() || hi.empty()) { g->rc = CGE_E_EMPTY_CLUSTER; return; }
-            g->vlow = lo.size() > 1 ? -total_rss(v, lo, false) : DBL_EPSILON;
-            g->vhigh = hi.size() > 1 ? -total_rss(v, hi, false) : DBL_EPSILON;
-            g->low.resize(lo.size());
-            g->high.resize(hi.size());
-            for (size_t q = 0; q < lo.size(); q++) g->low[q] = g->what[lo[q]];
-            for (size_t q = 0; q < hi.size(); q++) g->high[q] = g->what[hi[q]];
-        });
+            if (!k_group_eig(c, c->ls_cov.p, T, d, c->ls_vec.p)) { // d > 128: host solver on a worker pool
+                std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d);
+                HIP_CHECK(hipMemcpyAsync(cov.data(), c->ls_cov.p, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                parallel_for(c, T, [&](i64 t) { host_eig_top(&cov[(size_t)t * d * d], d, &vec[(size_t)t * d]); });
+                HIP_CHECK(hipMemcpyAsync(c->ls_vec.p, vec.data(), sizeof(double) * vec.size(), hipMemcpyHostToDevice, st));
+                HIP_CHECK(hipStreamSynchronize(st)); // vec goes out of scope
+            }
+            {
+                ScopedKernelTimer tm(c, "group_project");
+                k_group_project(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_row_task.p, R, d, c->ls_mean.p, c->ls_vec.p,
+                                c->ls_z.p);
+            }
+            HIP_CHECK(hipMemcpyAsync(c->pin_z.p, c->ls_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            z.assign(c->pin_z.p, c->pin_z.p + R);
+        }
+        // ---- the cut: local positions of the two children -----------------------------------------------------
+        std::vector<std::vector<i64>> lows(T), highs(T);
+        {
+            PhaseAcc pa(c, "lm_cut");
+            if (method == CGE_METHOD_RSS) {
+                std::vector<RssState> rs;
+                rule_rss_batched(c, B, groups, z, rs);
+                for (i64 t = 0; t < T; t++) {
+                    groups[t]->rc = rs[t].rc;
+                    lows[t].swap(rs[t].low);
+                    highs[t].swap(rs[t].high);
+                }
+            } else {
+                parallel_for(c, T, [&](i64 t) {
+                    Group *g = groups[t];
+                    const i64 k = (i64)g->what.size();
+                    const double *zt = &z[B.task_row_off[t]];
+                    if (method == CGE_METHOD_RSS2) {
+                        HView v{hX, hw, d, g->what.data(), k};
+                        g->rc = rule_rss2(v, zt, lows[t], highs[t]);
+                    } else
+                        g->rc = rule_cut(zt, k, method == CGE_METHOD_SIZE, lows[t], highs[t]);
+                });
+            }
+        }
+        // ---- children: vertex lists and heap values (-total_rss, or eps() for singletons) ---------------------------
+        {
+            PhaseAcc pa(c, "lm_children");
+            std::vector<unsigned char> side(R, 0);
+            parallel_for(c, T, [&](i64 t) {
+                Group *g = groups[t];
+                if (g->rc != CGE_OK) return;
+                if (lows[t].empty() || highs[t].empty()) { g->rc = CGE_E_EMPTY_CLUSTER; return; }
+                unsigned char *sd = &side[B.task_row_off[t]];
+                for (i64 j : lows[t]) sd[j] = 1;
+                for (i64 j : highs[t]) sd[j] = 2;
+                g->low.resize(lows[t].size());
+                g->high.resize(highs[t].size());
+                for (size_t q = 0; q < lows[t].size(); q++) g->low[q] = g->what[lows[t][q]];
+                for (size_t q = 0; q < highs[t].size(); q++) g->high[q] = g->what[highs[t][q]];
+            });
+            const double *sums = side_sums(c, B, side);
+            for (i64 t = 0; t < T; t++) {
+                Group *g = groups[t];
+                if (g->rc != CGE_OK) continue;
+                const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
+                g->vlow = g->low.size() > 1 ? -rss_from_sums(q1, d) : DBL_EPSILON;
+                g->vhigh = g->high.size() > 1 ? -rss_from_sums(q2, d) : DBL_EPSILON;
+            }
+        }
     }
 }
 
@@ -668,12 +874,13 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         }
     }
     if (!locals.empty()) {
-        // root values: -total_rss of each community (host, parallel)
-        parallel_for(c->n_threads, (i64)locals.size(), [&](i64 t) {
-            Group *g = locals[t].h.top();
-            HView v{c->h_Xr.data(), c->h_vw.data(), d, g->what.data(), (i64)g->what.size()};
-            g->value = -total_rss(v, g->what, true);
-        });
+        // root values: -total_rss of each community (one device pass over all of them)
+        {
+            PhaseAcc pa(c, "lm_roots");
+            std::vector<Group *> roots;
+            for (auto &L : locals) roots.push_back(L.h.top());
+            device_group_values(c, roots);
+        }
         for (;;) {
             std::vector<Group *> tasks;
             for (auto &L : locals) {

@@ -255,9 +255,12 @@ def test_wgcl_asserts_mirror_reference(ctx, test115):
     with pytest.raises(AssertionError):  # src/divergence.jl:81
         cg.wGCL(a["edges"], a["eweights"], a["comm"], a["embedding"], np.zeros(n - 1), a["vweights"], *empty, False,
                 1, 100, ctx=ctx)
-    emb = np.tile(a["embedding"][:1], (n, 1))  # homogeneous cluster: src/landmarks.jl:165-167
+    # homogeneous cluster (src/landmarks.jl:165-167).  Integer coordinates and power-of-two weights keep the
+    # weighted mean exact, so z == 0 for every row whatever the summation order (with arbitrary data the
+    # reference itself ends in this error or in an @assert depending on rounding).
+    emb = np.tile(np.arange(1.0, 33.0), (n, 1))
     with pytest.raises(api.CGEError, match="homogenous"):
-        cg.landmarks(a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], emb, False, 1, 3, "rss",
+        cg.landmarks(a["edges"], a["eweights"], np.full(n, 2.0), a["clusters"], a["comm"], emb, False, 1, 3, "rss",
                      False, ctx=ctx)
 
 
