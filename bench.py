@@ -105,19 +105,27 @@ def main():
     if not torch.cuda.is_available():
         log("bench.py: no GPU visible; the hot path has no CPU fallback")
         sys.exit(3)
+    # CGE_REHEARSAL_ONE_GPU=1: every rank on cuda:0 with the gloo backend (functional rehearsal of the N > 1
+    # path on a one-GPU box; never used for reported numbers)
+    rehearsal = os.environ.get("CGE_REHEARSAL_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as ge
     from cge.jl_amd import api, synth
 
     if not os.path.exists(api.library_path()):
-        if local_rank == 0:
+        if rank == 0:
             ge.build()
         if world > 1:
             dist.barrier()
@@ -145,6 +153,9 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if rehearsal:
+        log(f"[bench] rank {rank}: REHEARSAL mode (gloo, all ranks on cuda:0) -- numbers are not reportable")
 
     res = None
     for _ in range(args.warmup):

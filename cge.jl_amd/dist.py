@@ -19,8 +19,13 @@ def edge_shard(m: int, rank: int, world: int):
 
 
 def diameter_shard(n_super_rows: int, rank: int, world: int):
-    """Super-block rows owned by `rank` (kernels_dist.hip: SI % nparts == part)."""
+    """Super-block rows owned by `rank` in the brute-force kernel (kernels_dist.hip: SI % nparts == part)."""
     return [si for si in range(n_super_rows) if si % world == rank]
+
+
+def candidate_tile_shard(n_tiles: int, rank: int, world: int):
+    """Candidate tiles owned by `rank` in the pruned diameter (diameter_host.cpp: global_tile % nparts == part)."""
+    return list(range(rank, n_tiles, world))
 
 
 class TorchCollectives:
@@ -37,14 +42,21 @@ class TorchCollectives:
         self.base = self.buf.data_ptr()
         self.n_calls = 0
         self.bytes = 0
-        ctx._check(ctx.L.cge_set_exchange_buffer(ctx.h, _vp(self.base), _i64(self.buf.numel())))
-        ctx.set_collectives(self._hook, self.rank, self.world)
+        if ctx is not None:  # (None: the hook alone, as the CPU tests drive it)
+            ctx._check(ctx.L.cge_set_exchange_buffer(ctx.h, _vp(self.base), _i64(self.buf.numel())))
+            ctx.set_collectives(self._hook, self.rank, self.world)
 
     def _hook(self, user, ptr, count, op):
         try:
             off = (int(ptr) - self.base) // 8
             t = self.buf[off: off + int(count)]
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM)
+            rop = self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM
+            if t.is_cuda and self.dist.get_backend() == "gloo":  # rehearsal on one GPU: stage through the host
+                h = t.cpu()
+                self.dist.all_reduce(h, op=rop)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=rop)
             if t.is_cuda:
                 self.torch.cuda.synchronize(t.device)
             self.n_calls += 1

@@ -1,0 +1,107 @@
+"""world_size = 2 over gloo on the CPU: the sharding rules and the collective hook of the N > 1 path.
+The GPU kernels are not involved (no GPU here); each rank computes its shard with numpy (the oracle's
+arithmetic for unit weights is exact integer counting) and the reductions must reproduce the whole."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from cge.jl_amd import dist as cd
+        from cge.jl_amd import synth
+
+        g = synth.abcd_like(3000, 24000, 6, 8, seed=3)
+        m, n, C = g["m"], g["n"], g["C"]
+        comm = g["comm"][:, 0]
+        rng = np.random.default_rng(0)
+        v2l = np.zeros(n, dtype=np.int64)
+        for c in range(1, C + 1):
+            idx = np.flatnonzero(comm == c)
+            v2l[idx] = rng.integers(0, 4, size=len(idx)) + 4 * (c - 1)
+        N = 4 * C
+
+        def scatter(e0, e1):  # src/landmarks.jl:448-451 + src/divergence.jl:59-63 on rows [e0, e1)
+            a, b = v2l[g["edges"][e0:e1, 0] - 1], v2l[g["edges"][e0:e1, 1] - 1]
+            lo, hi = np.minimum(a, b), np.maximum(a, b)
+            wed = np.zeros((N, N))
+            np.add.at(wed, (lo, hi), g["eweights"][e0:e1])
+            ca, cb = comm[g["edges"][e0:e1, 0] - 1] - 1, comm[g["edges"][e0:e1, 1] - 1] - 1
+            vc = np.zeros((C, C))
+            np.add.at(vc, (np.minimum(ca, cb), np.maximum(ca, cb)), g["eweights"][e0:e1])
+            return wed, vc
+
+        # 1. edge shards: contiguous, disjoint, covering; partial scatters all-reduce to the whole
+        e0, e1 = cd.edge_shard(m, rank, world)
+        bounds = [cd.edge_shard(m, r, world) for r in range(world)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == m and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+        wed, vc = scatter(e0, e1)
+        wed_all = cd.allreduce_numpy(wed.copy(), "sum")
+        vc_all = cd.allreduce_numpy(vc.copy(), "sum")
+        full_w, full_c = scatter(0, m)
+        assert np.array_equal(wed_all, full_w) and np.array_equal(vc_all, full_c)
+        assert wed_all.sum() == g["eweights"].sum()
+        # 2. diameter shards: every pair tile / candidate tile is owned by exactly one rank; max of shard maxima
+        nS = 7
+        owned = [set(cd.diameter_shard(nS, r, world)) for r in range(world)]
+        assert set().union(*owned) == set(range(nS)) and sum(map(len, owned)) == nS
+        tiles = [set(cd.candidate_tile_shard(1001, r, world)) for r in range(world)]
+        assert set().union(*tiles) == set(range(1001)) and sum(map(len, tiles)) == 1001
+        X = g["embedding"]
+        rows = np.arange(n)
+        mine = rows[rows % world == rank]
+        local = 0.0
+        for i in mine[:: max(1, len(mine) // 200)]:  # a sample of this rank's rows against all rows
+            local = max(local, np.sqrt(((X[i] - X) ** 2).sum(1)).max())
+        glob = cd.allreduce_numpy(np.array([local]), "max")[0]
+        assert glob >= local and glob == max(dist_gather(local, world))
+        # 3. the hook itself (what the C library calls): offset arithmetic + op mapping on the exchange buffer
+        coll = cd.TorchCollectives(None, 64, "cpu")
+        coll.buf[:] = 0
+        coll.buf[8:12] = torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64) * (rank + 1)
+        assert coll._hook(None, coll.base + 8 * 8, 4, 0) == 0
+        assert coll.buf[8:12].tolist() == [3.0, 6.0, 9.0, 12.0] and coll.buf[12].item() == 0.0
+        coll.buf[20] = float(10 + rank)
+        assert coll._hook(None, coll.base + 20 * 8, 1, 1) == 0
+        assert coll.buf[20].item() == 11.0 and coll.n_calls == 2 and coll.bytes == 40
+        q.put((rank, "ok"))
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def dist_gather(value, world):
+    t = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(t, torch.tensor([value], dtype=torch.float64))
+    return [float(x.item()) for x in t]
+
+
+def test_sharding_and_collective_hook_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results
