@@ -232,7 +232,7 @@ struct cge_ctx {
     // ---- scratch for host-array wGCL ------------------------------------------------------
     DevBuf<double> s_emb, s_dist, s_vw, s_vectC, s_degin, s_degout;
     DevBuf<i32> s_comm;
-    DevBuf<double> auc_part;
+    DevBuf<double> auc_part, js_part;
     // diameter scratch
     DevBuf<double> mp_recs;  // MaxRec records (3 doubles each)
     DevBuf<i64> mp_count;
@@ -252,6 +252,9 @@ struct cge_ctx {
     DevBuf<unsigned char> ls_side, ls_state;
     DevBuf<double> ls_params; // per-task round parameters of the rss rule
     PinBuf<double> pin_sums, pin_z, pin_params;
+    // sorted-prefix rss path
+    DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro;
+    DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;
 
     // ---- profiling -------------------------------------------------------------------------
     bool profiling = false;
@@ -308,6 +311,12 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
 void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const unsigned char *side,
                        const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
                        i64 d, double *part, double *out);
+void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *chunk_beg,
+                     const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks, i64 d, double *ctot,
+                     double *coff, double *prefix);
+void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const double *zs,
+                  const i32 *task_row_off, const double *prefix, i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals);
+#define CGE_RR_MAXROUNDS 63
 void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, const double *params,
                 unsigned char *state, unsigned char *side);
 bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec);

@@ -225,28 +225,52 @@ __device__ __forceinline__ bool js_selected(i64 k, i64 C, int directed, int mode
     }
     return mode == 1 ? diag : !diag;
 }
-__global__ __launch_bounds__(256) void js_kernel(const double *__restrict__ vC, const double *__restrict__ vB, i64 len,
-                                                 i64 C, int directed, int mode, double *__restrict__ out) {
+// three small launches, every sum in a fixed order: (1) per-block partial (sum C, sum B, count),
+// (2) per-block partial of the divergence terms (each block first re-adds the stage-1 partials in block
+// order, so all blocks use identical normalisers), (3) the final sum.
+#define JS_BLOCKS 64
+__global__ __launch_bounds__(256) void js_sums_kernel(const double *__restrict__ vC, const double *__restrict__ vB,
+                                                      i64 len, i64 C, int directed, int mode,
+                                                      double *__restrict__ part /* [JS_BLOCKS][3] */) {
     __shared__ double sh[256];
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
-    for (i64 k = threadIdx.x; k < len; k += 256)
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < len; k += (i64)gridDim.x * 256)
         if (js_selected(k, C, directed, mode)) { s1 += vC[k]; s2 += vB[k]; cnt += 1.0; }
     s1 = block_sum_256(s1, sh);
     s2 = block_sum_256(s2, sh);
     cnt = block_sum_256(cnt, sh);
+    if (threadIdx.x == 0) { part[3 * blockIdx.x] = s1; part[3 * blockIdx.x + 1] = s2; part[3 * blockIdx.x + 2] = cnt; }
+}
+__global__ __launch_bounds__(256) void js_terms_kernel(const double *__restrict__ vC, const double *__restrict__ vB,
+                                                       i64 len, i64 C, int directed, int mode,
+                                                       const double *__restrict__ part, double *__restrict__ fpart) {
+    __shared__ double sh[256];
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (int b = 0; b < JS_BLOCKS; b++) { s1 += part[3 * b]; s2 += part[3 * b + 1]; cnt += part[3 * b + 2]; }
     const double sp1 = s1 + cnt, sp2 = s2 + cnt;
     double f = 0.0;
-    for (i64 k = threadIdx.x; k < len; k += 256)
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < len; k += (i64)gridDim.x * 256)
         if (js_selected(k, C, directed, mode)) {
             const double p = (vC[k] + 1.0) / sp1, q = (vB[k] + 1.0) / sp2;
             const double m = (p + q) / 2.0;
             f += p * log(p / m) + q * log(q / m);
         }
     f = block_sum_256(f, sh);
-    if (threadIdx.x == 0) *out = f / 2.0;
+    if (threadIdx.x == 0) fpart[blockIdx.x] = f;
+}
+__global__ void js_final_kernel(const double *__restrict__ fpart, double *__restrict__ out) {
+    double f = 0.0;
+    for (int b = 0; b < JS_BLOCKS; b++) f += fpart[b];
+    *out = f / 2.0;
 }
 void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int directed, int mode, double *out) {
-    hipLaunchKernelGGL(js_kernel, dim3(1), dim3(256), 0, c->stream, vC, vB, len, C, directed, mode, out);
+    c->js_part.ensure(4 * JS_BLOCKS);
+    ScopedKernelTimer t(c, "js");
+    hipLaunchKernelGGL(js_sums_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, vC, vB, len, C, directed, mode,
+                       c->js_part.p);
+    hipLaunchKernelGGL(js_terms_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, vC, vB, len, C, directed, mode,
+                       c->js_part.p, c->js_part.p + 3 * JS_BLOCKS);
+    hipLaunchKernelGGL(js_final_kernel, dim3(1), dim3(1), 0, c->stream, c->js_part.p + 3 * JS_BLOCKS, out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -378,6 +378,207 @@ void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32
                        task_chunk_off, 2 * (2 * d + 1), out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// rss rule on sorted order.  Along ascending z every "gray" set of split_cluster_rss
+// (src/landmarks.jl:168-199) is a contiguous rank range, and `t1 = {z < med}` is its lower part.  With
+// inclusive prefix sums P[r] = sum_{q<=r} (w x^2 [d], w x [d], w) over the rows in sorted order, the WSSE
+// triple of any range is P[b-1] - P[a-1], so the whole median-cut loop runs in one small kernel.
+// srows = vertex ids in (task, ascending z) order; W = 2d+1.
+__device__ __forceinline__ double scan_term(const double *__restrict__ x, double w, i64 c, i64 d) {
+    if (c < d) { const double xv = x[c]; return w * (xv * xv); }
+    if (c < 2 * d) return w * x[c - d];
+    return w;
+}
+__global__ void scan_chunk_totals_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                         const i32 *__restrict__ srows, const i32 *__restrict__ chunk_beg,
+                                         const i32 *__restrict__ chunk_end, i64 d, i64 W, double *__restrict__ ctot) {
+    const i64 ch = blockIdx.x;
+    const i32 beg = chunk_beg[ch], end = chunk_end[ch];
+    for (i64 c = threadIdx.x; c < W; c += blockDim.x) {
+        double run = 0.0;
+        for (i32 j = beg; j < end; j++) {
+            const i64 v = srows[j];
+            run += scan_term(Xr + v * d, vw[v], c, d);
+        }
+        ctot[ch * W + c] = run;
+    }
+}
+__global__ void scan_chunk_offsets_kernel(const double *__restrict__ ctot, const i32 *__restrict__ task_chunk_off, i64 W,
+                                          double *__restrict__ coff) {
+    const i64 t = blockIdx.x;
+    const i32 c0 = task_chunk_off[t], c1 = task_chunk_off[t + 1];
+    for (i64 c = threadIdx.x; c < W; c += blockDim.x) {
+        double run = 0.0;
+        for (i32 ch = c0; ch < c1; ch++) {
+            coff[(i64)ch * W + c] = run;
+            run += ctot[(i64)ch * W + c];
+        }
+    }
+}
+__global__ void scan_write_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                  const i32 *__restrict__ srows, const i32 *__restrict__ chunk_beg,
+                                  const i32 *__restrict__ chunk_end, i64 d, i64 W, const double *__restrict__ coff,
+                                  double *__restrict__ prefix) {
+    const i64 ch = blockIdx.x;
+    const i32 beg = chunk_beg[ch], end = chunk_end[ch];
+    for (i64 c = threadIdx.x; c < W; c += blockDim.x) {
+        double run = coff[ch * W + c];
+        for (i32 j = beg; j < end; j++) {
+            const i64 v = srows[j];
+            run += scan_term(Xr + v * d, vw[v], c, d);
+            prefix[(i64)j * W + c] = run;
+        }
+    }
+}
+void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *chunk_beg,
+                     const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks, i64 d, double *ctot,
+                     double *coff, double *prefix) {
+    const i64 W = 2 * d + 1;
+    const int bs = (int)std::min<i64>(1024, (W + 63) / 64 * 64);
+    ScopedKernelTimer t(c, "sorted_prefix");
+    hipLaunchKernelGGL(scan_chunk_totals_kernel, dim3((unsigned)n_chunks), dim3(bs), 0, c->stream, Xr, vw, srows,
+                       chunk_beg, chunk_end, d, W, ctot);
+    hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3((unsigned)n_tasks), dim3(bs), 0, c->stream, ctot, task_chunk_off,
+                       W, coff);
+    hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)n_chunks), dim3(bs), 0, c->stream, Xr, vw, srows, chunk_beg,
+                       chunk_end, d, W, coff, prefix);
+}
+
+#define RR_SLOTS 8      // columns per lane: d <= 512
+#define RR_MAXROUNDS 63 // rounds logged per task (log2 of the group size + a few)
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+// one wave per task.  meta[t] = {n_rounds, rc}; rounds[t][r] = {first rank, end rank, side (1 low / 2 high)};
+// vals[t] = {vlow, vhigh} = -total_rss of the children (eps() for singletons is applied by the host).
+__global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                                        const i32 *__restrict__ srows, const double *__restrict__ zs,
+                                                        const i32 *__restrict__ task_row_off,
+                                                        const double *__restrict__ prefix, i64 d,
+                                                        i32 *__restrict__ meta, i32 *__restrict__ rounds,
+                                                        double *__restrict__ vals) {
+    const i64 t = blockIdx.x, W = 2 * d + 1;
+    const int lane = threadIdx.x;
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    const double *z = zs + o;
+    const double *P = prefix + o * W;
+    i32 *rlog = rounds + t * 3 * RR_MAXROUNDS;
+    // seeds: rank 0 (arg-min) and rank k-1 (arg-max), exact terms as :169-170
+    double rl_ss[RR_SLOTS], rl_s[RR_SLOTS], rh_ss[RR_SLOTS], rh_s[RR_SLOTS];
+    const i64 v1 = srows[o], v2 = srows[o + k - 1];
+    const double w1 = vw[v1], w2 = vw[v2];
+    double rl_w = w1, rh_w = w2;
+#pragma unroll
+    for (int s = 0; s < RR_SLOTS; s++) {
+        const i64 c = lane + 64 * s;
+        rl_ss[s] = rl_s[s] = rh_ss[s] = rh_s[s] = 0.0;
+        if (c < d) {
+            const double x1 = Xr[v1 * d + c], x2 = Xr[v2 * d + c];
+            rl_ss[s] = x1 * x1 * w1; rl_s[s] = x1 * w1;
+            rh_ss[s] = x2 * x2 * w2; rh_s[s] = x2 * w2;
+        }
+    }
+    // range sums S(a,b) = P[b-1] - P[a-1] for this lane's columns
+    auto range = [&](i64 a, i64 b, double (&ss)[RR_SLOTS], double (&s1)[RR_SLOTS], double &w) {
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; s++) {
+            const i64 c = lane + 64 * s;
+            ss[s] = s1[s] = 0.0;
+            if (c < d && b > a) {
+                ss[s] = P[(b - 1) * W + c] - (a > 0 ? P[(a - 1) * W + c] : 0.0);
+                s1[s] = P[(b - 1) * W + d + c] - (a > 0 ? P[(a - 1) * W + d + c] : 0.0);
+            }
+        }
+        w = (b > a) ? P[(b - 1) * W + 2 * d] - (a > 0 ? P[(a - 1) * W + 2 * d] : 0.0) : 0.0;
+    };
+    // sum over the columns of wsse(base + add)
+    auto fsum = [&](const double (&bss)[RR_SLOTS], const double (&bs1)[RR_SLOTS], double bw, const double (&ass)[RR_SLOTS],
+                    const double (&as1)[RR_SLOTS], double aw) {
+        double acc = 0.0;
+        const double w = bw + aw;
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; s++) {
+            const i64 c = lane + 64 * s;
+            if (c < d) {
+                const double ss = bss[s] + ass[s], s1 = bs1[s] + as1[s];
+                acc += ss - s1 * s1 / w;
+            }
+        }
+        return wave_sum(acc);
+    };
+    auto median = [&](i64 a, i64 b) { // Statistics.median of z[a..b) (sorted)
+        const i64 cnt = b - a;
+        return (cnt & 1) ? z[a + cnt / 2] : z[a + cnt / 2 - 1] / 2.0 + z[a + cnt / 2] / 2.0;
+    };
+    double zero_ss[RR_SLOTS], zero_s[RR_SLOTS];
+#pragma unroll
+    for (int s = 0; s < RR_SLOTS; s++) zero_ss[s] = zero_s[s] = 0.0;
+    i64 ga = 1, gb = k - 1; // gray = ranks [ga, gb)
+    int nr = 0, rc = 0;
+    double med = median(0, k);
+    double a_ss[RR_SLOTS], a_s[RR_SLOTS], b_ss[RR_SLOTS], b_s[RR_SLOTS], aw, bw;
+    bool leftover = false;
+    while (ga < gb) {
+        // number of gray ranks with z < med (binary search; z ascending)
+        i64 lo = ga, hi = gb;
+        while (lo < hi) {
+            const i64 mid = (lo + hi) >> 1;
+            if (z[mid] < med) lo = mid + 1; else hi = mid;
+        }
+        const i64 cut = lo; // t1 = [ga, cut), t2 = [cut, gb)
+        range(ga, cut, a_ss, a_s, aw);
+        range(cut, gb, b_ss, b_s, bw);
+        const double f1 = fsum(rl_ss, rl_s, rl_w, a_ss, a_s, aw);
+        const double f2 = fsum(rh_ss, rh_s, rh_w, b_ss, b_s, bw);
+        if (nr >= RR_MAXROUNDS - 1) { rc = 1; break; }
+        if (f1 < f2) {
+            if (cut == ga) { leftover = true; break; }
+#pragma unroll
+            for (int s = 0; s < RR_SLOTS; s++) { rl_ss[s] += a_ss[s]; rl_s[s] += a_s[s]; }
+            rl_w += aw;
+            if (lane == 0) { rlog[3 * nr] = (i32)ga; rlog[3 * nr + 1] = (i32)cut; rlog[3 * nr + 2] = 1; }
+            nr++;
+            ga = cut;
+        } else {
+            if (cut == gb) { leftover = true; break; }
+#pragma unroll
+            for (int s = 0; s < RR_SLOTS; s++) { rh_ss[s] += b_ss[s]; rh_s[s] += b_s[s]; }
+            rh_w += bw;
+            if (lane == 0) { rlog[3 * nr] = (i32)cut; rlog[3 * nr + 1] = (i32)gb; rlog[3 * nr + 2] = 2; }
+            nr++;
+            gb = cut;
+        }
+        if (ga < gb) med = median(ga, gb);
+    }
+    if (leftover && rc == 0) { // :200-208
+        range(ga, gb, a_ss, a_s, aw);
+        const double fa1 = fsum(rl_ss, rl_s, rl_w, a_ss, a_s, aw), fa2 = fsum(rh_ss, rh_s, rh_w, zero_ss, zero_s, 0.0);
+        const double fb1 = fsum(rl_ss, rl_s, rl_w, zero_ss, zero_s, 0.0), fb2 = fsum(rh_ss, rh_s, rh_w, a_ss, a_s, aw);
+        const int side = (fmax(fa1, fa2) < fmax(fb1, fb2)) ? 1 : 2;
+        if (lane == 0) { rlog[3 * nr] = (i32)ga; rlog[3 * nr + 1] = (i32)gb; rlog[3 * nr + 2] = side; }
+        nr++;
+        if (side == 1) ga = gb; else gb = ga;
+    }
+    // children: low = ranks [0, ga), high = ranks [ga, k); total_rss from the prefix sums
+    range(0, ga, a_ss, a_s, aw);
+    range(ga, k, b_ss, b_s, bw);
+    const double vlow = -fsum(zero_ss, zero_s, 0.0, a_ss, a_s, aw), vhigh = -fsum(zero_ss, zero_s, 0.0, b_ss, b_s, bw);
+    if (lane == 0) {
+        meta[2 * t] = nr;
+        meta[2 * t + 1] = rc;
+        vals[2 * t] = vlow;
+        vals[2 * t + 1] = vhigh;
+    }
+}
+void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const double *zs,
+                  const i32 *task_row_off, const double *prefix, i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals) {
+    if (d > 64 * RR_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * RR_SLOTS);
+    ScopedKernelTimer t(c, "rss_rounds");
+    hipLaunchKernelGGL(rss_rounds_kernel, dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, zs,
+                       task_row_off, prefix, d, meta, rounds, vals);
+}
+
 // Side flags of one rss round, derived on the device (no per-round row-sized upload).  Per task t,
 // params[4t..4t+3] = { prev_med, absorb (0/1/2: the side that was absorbed after the previous round),
 // cur_med, mode (0 idle, 1 median round, 2 leftover round) }.  state[j]: 0 = gray, 1 = low, 2 = high.

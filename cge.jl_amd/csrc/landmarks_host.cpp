@@ -688,6 +688,89 @@ void rule_rss_batched(cge_ctx *c, const Batch &B, Group *const *groups, const st
     }
 }
 
+// split_cluster_rss on sorted order (kernels_lm.hip: k_sorted_prefix + k_rss_rounds): the host sorts z
+// per task, the device scans the WSSE terms along that order and runs all median-cut rounds of every
+// task in one launch; the host then rebuilds the children's member lists in the reference's order
+// (seed first, then every absorbed batch in ascending original index, :163-164, :189, :194, :204-206).
+// Tasks the rank-range argument does not cover (a tie at the maximum of z, NaNs) go to `fallback`.
+void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const std::vector<double> &z,
+                     std::vector<std::vector<i64>> &lows, std::vector<std::vector<i64>> &highs,
+                     std::vector<double> &vlow, std::vector<double> &vhigh, std::vector<char> &have_vals,
+                     std::vector<i64> &fallback) {
+    const i64 T = B.T, R = B.R, d = c->d, W = 2 * d + 1;
+    hipStream_t st = c->stream;
+    std::vector<i32> perm(R), srows(R);
+    std::vector<double> zs(R);
+    std::vector<char> status(T, 0); // 0 sorted path, 1 fallback, 2 homogeneous
+    parallel_for(c, T, [&](i64 t) {
+        const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
+        const double *zt = &z[o];
+        i32 *p = &perm[o];
+        for (i64 j = 0; j < k; j++) p[j] = (i32)j;
+        std::stable_sort(p, p + k, [&](i32 a, i32 b) { return zt[a] < zt[b]; });
+        bool nan = false;
+        for (i64 j = 0; j < k; j++) nan = nan || (zt[j] != zt[j]);
+        if (nan) status[t] = 1;
+        else if (zt[p[0]] == zt[p[k - 1]]) status[t] = 2;      // argmin == argmax (:165-167)
+        else if (zt[p[k - 1]] == zt[p[k - 2]]) status[t] = 1;  // arg-max is not the last rank
+        for (i64 r = 0; r < k; r++) {
+            srows[o + r] = B.rows[o + p[r]];
+            zs[o + r] = zt[p[r]];
+        }
+    });
+    c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_tro.ensure(T + 1);
+    c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W); c->sp_prefix.ensure((size_t)R * W);
+    c->sp_meta.ensure(2 * T); c->sp_rounds.ensure((size_t)T * 3 * CGE_RR_MAXROUNDS); c->sp_vals.ensure(2 * T);
+    HIP_CHECK(hipMemcpyAsync(c->sp_srows.p, srows.data(), sizeof(i32) * R, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->sp_zs.p, zs.data(), sizeof(double) * R, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
+    k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
+                    c->sp_coff.p, c->sp_prefix.p);
+    k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->sp_prefix.p, T, d, c->sp_meta.p,
+                 c->sp_rounds.p, c->sp_vals.p);
+    std::vector<i32> meta(2 * T), rounds((size_t)T * 3 * CGE_RR_MAXROUNDS);
+    std::vector<double> vals(2 * T);
+    HIP_CHECK(hipMemcpyAsync(meta.data(), c->sp_meta.p, sizeof(i32) * 2 * T, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(rounds.data(), c->sp_rounds.p, sizeof(i32) * rounds.size(), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    parallel_for(c, T, [&](i64 t) {
+        Group *g = groups[t];
+        if (status[t] == 2) { g->rc = CGE_E_HOMOGENEOUS; return; }
+        if (status[t] == 1 || meta[2 * t + 1] != 0) { status[t] = 1; return; }
+        const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
+        const i32 *p = &perm[o];
+        const int nr = meta[2 * t];
+        const i32 *rl = &rounds[(size_t)t * 3 * CGE_RR_MAXROUNDS];
+        // round id of every original index (-1 = seed)
+        std::vector<int> rid(k, -1);
+        for (int r = 0; r < nr; r++)
+            for (i32 q = rl[3 * r]; q < rl[3 * r + 1]; q++) rid[p[q]] = r;
+        std::vector<i64> cnt(nr, 0), start(nr + 1, 0);
+        for (int r = 0; r < nr; r++) cnt[r] = rl[3 * r + 1] - rl[3 * r];
+        i64 nlow = 1, nhigh = 1;
+        std::vector<i64> pos(nr);
+        for (int r = 0; r < nr; r++) {
+            if (rl[3 * r + 2] == 1) { pos[r] = nlow; nlow += cnt[r]; } else { pos[r] = nhigh; nhigh += cnt[r]; }
+        }
+        lows[t].assign(nlow, 0);
+        highs[t].assign(nhigh, 0);
+        lows[t][0] = p[0];
+        highs[t][0] = p[k - 1];
+        for (i64 j = 0; j < k; j++) {
+            const int r = rid[j];
+            if (r < 0) continue;
+            if (rl[3 * r + 2] == 1) lows[t][pos[r]++] = j; else highs[t][pos[r]++] = j;
+        }
+        vlow[t] = vals[2 * t];
+        vhigh[t] = vals[2 * t + 1];
+        have_vals[t] = 1;
+        g->rc = CGE_OK;
+    });
+    for (i64 t = 0; t < T; t++)
+        if (status[t] == 1) fallback.push_back(t);
+}
+
 // Compute the split of every task.  Device: mean, covariance, principal eigenvector, projection,
 // WSSE column sums of the rss rounds and of the children.  Host: the 1-D cut logic on z.
 void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
@@ -761,15 +844,33 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
         }
         // ---- the cut: local positions of the two children -----------------------------------------------------
         std::vector<std::vector<i64>> lows(T), highs(T);
+        std::vector<double> vlow(T, 0.0), vhigh(T, 0.0);
+        std::vector<char> have_vals(T, 0);
         {
             PhaseAcc pa(c, "lm_cut");
             if (method == CGE_METHOD_RSS) {
-                std::vector<RssState> rs;
-                rule_rss_batched(c, B, groups, z, rs);
-                for (i64 t = 0; t < T; t++) {
-                    groups[t]->rc = rs[t].rc;
-                    lows[t].swap(rs[t].low);
-                    highs[t].swap(rs[t].high);
+                std::vector<i64> fallback;
+                rule_rss_sorted(c, B, groups, z, lows, highs, vlow, vhigh, have_vals, fallback);
+                if (!fallback.empty()) { // generic round-based path on a sub-batch (ties at max z, NaNs)
+                    std::vector<Group *> fg;
+                    for (i64 t : fallback) fg.push_back(groups[t]);
+                    Batch FB;
+                    build_batch(fg.data(), (i64)fg.size(), FB);
+                    upload_batch(c, FB);
+                    std::vector<double> fz(FB.R);
+                    for (size_t q = 0; q < fallback.size(); q++)
+                        std::copy(z.begin() + B.task_row_off[fallback[q]], z.begin() + B.task_row_off[fallback[q] + 1],
+                                  fz.begin() + FB.task_row_off[q]);
+                    c->ls_z.ensure(FB.R);
+                    HIP_CHECK(hipMemcpyAsync(c->ls_z.p, fz.data(), sizeof(double) * FB.R, hipMemcpyHostToDevice, st));
+                    std::vector<RssState> rs;
+                    rule_rss_batched(c, FB, fg.data(), fz, rs);
+                    for (size_t q = 0; q < fallback.size(); q++) {
+                        groups[fallback[q]]->rc = rs[q].rc;
+                        lows[fallback[q]].swap(rs[q].low);
+                        highs[fallback[q]].swap(rs[q].high);
+                    }
+                    upload_batch(c, B); // the children pass below works on the full batch again
                 }
             } else {
                 parallel_for(c, T, [&](i64 t) {
@@ -788,25 +889,33 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
         {
             PhaseAcc pa(c, "lm_children");
             std::vector<unsigned char> side(R, 0);
+            std::atomic<i64> need_pass{0};
             parallel_for(c, T, [&](i64 t) {
                 Group *g = groups[t];
                 if (g->rc != CGE_OK) return;
                 if (lows[t].empty() || highs[t].empty()) { g->rc = CGE_E_EMPTY_CLUSTER; return; }
-                unsigned char *sd = &side[B.task_row_off[t]];
-                for (i64 j : lows[t]) sd[j] = 1;
-                for (i64 j : highs[t]) sd[j] = 2;
+                if (!have_vals[t]) {
+                    need_pass.fetch_add(1);
+                    unsigned char *sd = &side[B.task_row_off[t]];
+                    for (i64 j : lows[t]) sd[j] = 1;
+                    for (i64 j : highs[t]) sd[j] = 2;
+                }
                 g->low.resize(lows[t].size());
                 g->high.resize(highs[t].size());
                 for (size_t q = 0; q < lows[t].size(); q++) g->low[q] = g->what[lows[t][q]];
                 for (size_t q = 0; q < highs[t].size(); q++) g->high[q] = g->what[highs[t][q]];
             });
-            const double *sums = side_sums(c, B, side);
+            const double *sums = need_pass.load() ? side_sums(c, B, side) : nullptr;
             for (i64 t = 0; t < T; t++) {
                 Group *g = groups[t];
                 if (g->rc != CGE_OK) continue;
-                const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
-                g->vlow = g->low.size() > 1 ? -rss_from_sums(q1, d) : DBL_EPSILON;
-                g->vhigh = g->high.size() > 1 ? -rss_from_sums(q2, d) : DBL_EPSILON;
+                if (!have_vals[t]) {
+                    const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
+                    vlow[t] = -rss_from_sums(q1, d);
+                    vhigh[t] = -rss_from_sums(q2, d);
+                }
+                g->vlow = g->low.size() > 1 ? vlow[t] : DBL_EPSILON;
+                g->vhigh = g->high.size() > 1 ? vhigh[t] : DBL_EPSILON;
             }
         }
     }

@@ -114,6 +114,29 @@ def test_landmarks_weighted_directed_and_truncation(ctx, orc, test115):
     assert ctx.truncated and np.array_equal(got[6], ref[6]) and len(got[0]) == len(ref[0])
 
 
+@pytest.mark.parametrize("method", ["rss", "rss2", "size", "diameter"])
+def test_landmarks_duplicate_rows_ties(ctx, orc, method):
+    """Every row appears twice: ties everywhere in z, including at its maximum (the sorted-order rss path
+    must hand those groups to the generic round-based path), medians landing on tied values, `==` branches
+    of the size / diameter rules."""
+    import cge.jl_amd as cg
+
+    rng = np.random.default_rng(11)
+    n, d, C = 600, 16, 5
+    base = rng.standard_normal((n // 2, d)) + np.repeat(rng.standard_normal((C, d)) * 3, n // 2 // C, axis=0)
+    emb = np.asfortranarray(np.repeat(base, 2, axis=0))
+    comm = np.asfortranarray(np.repeat(np.arange(1, C + 1), n // C).reshape(-1, 1))
+    src = rng.integers(1, n + 1, 4000)
+    dst = rng.integers(1, n + 1, 4000)
+    keep = src != dst
+    edges = np.asfortranarray(np.stack([np.minimum(src, dst)[keep], np.maximum(src, dst)[keep]], axis=1))
+    ew = np.ones(len(edges))
+    vw = np.bincount(np.concatenate([edges[:, 0], edges[:, 1]]), minlength=n + 1)[1:].astype(float) + 1.0
+    clusters = [np.flatnonzero(comm[:, 0] == c) + 1 for c in range(1, C + 1)]
+    args = (edges, ew, vw, clusters, comm, emb, False, 60, 4, method, False)
+    _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
+
+
 def _cmp_result(res, exp, tr=None, etr=None):
     assert len(res) == len(exp)
     assert res[0] == exp[0] and res[4] == exp[4], (res, exp)  # best alphas
