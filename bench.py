@@ -190,7 +190,7 @@ def main():
 
     # Roofline per kernel: ALGORITHMIC work of one launch / average launch time measured
     # with HIP events on the library's stream.  The `roofline` object is the kernel with the largest total time.
-    n, d, N = g["n"], g["d"], int(ctx.landmarks_info()[0])
+    n, d, N = g["n"], g["d"], int(ctx.get_stat("landmarks"))
     hi, dpath, cand_pairs, cand_tiles = ctx.last_diameter()
     steps_prof = max(1, args.steps)
     work = {  # name -> (bound, peak, unit, algorithmic work per launch, note)
@@ -202,7 +202,8 @@ def main():
                       "fp64 MFMA, 2d flop per vertex pair of the candidate 128x128 tiles"),
         "fit_symv": ("hbm", HBM_PEAK_GBS, "GB/s", 8.0 * N * (N + 1) / 2,
                      "8 B per unordered landmark pair per Chung-Lu iteration"),
-        "edge_scatter": ("hbm", HBM_PEAK_GBS, "GB/s", 24.0 * g["m"] / world, "24 B per edge (2 x Int64 + Float64)"),
+        "edge_scatter": ("hbm", HBM_PEAK_GBS, "GB/s", 24.0 * g["m"] / world,
+                         "C x C cluster-pair scatter-add, 24 B per edge (2 x Int64 + Float64 as the reference stores them)"),
     }
     kernels = {}
     for name in prof:

@@ -273,8 +273,30 @@ static double allreduce_scalar_max(cge_ctx *c, double v) {
 }
 
 static void build_landmark_index(cge_ctx *c, const std::vector<i32> &v2l0, i64 N);
+// per-edge scatter of the resident graph into the landmark-pair matrix (and its positive-entry count)
+static void scatter_wedges(cge_ctx *c, int directed) {
+    const i64 N = c->N;
+    hipStream_t st = c->stream;
+    c->wedges.ensure((size_t)N * N);
+    HIP_CHECK(hipMemsetAsync(c->wedges.p, 0, sizeof(double) * N * N, st));
+    i64 e0 = 0, e1 = c->m;
+    if (c->has_coll) { // edge shard of this rank
+        e0 = c->m * c->coll.rank / c->coll.world;
+        e1 = c->m * (c->coll.rank + 1) / c->coll.world;
+    }
+    k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, c->v2l.p, c->comm.p, N,
+                   c->n_comm_max, directed, c->wedges.p, nullptr);
+    if (c->has_coll) allreduce(c, c->wedges.p, N * N, 0);
+    DevBuf<i64> cnt;
+    cnt.ensure(1);
+    k_compact_count(c, c->wedges.p, N, directed, cnt.p);
+    HIP_CHECK(hipMemcpyAsync(&c->n_ledges, cnt.p, sizeof(i64), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->wedges_ready = true;
+}
+
 static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 land, i64 forced,
-                               int method, int directed) {
+                               int method, int directed, bool need_wedges) {
     if (!c->Xr.p || !c->vw.p || !c->comm.p || !c->src.p) CGE_THROW(CGE_E_ARG, "landmarks: graph, embedding and vertex data must be resident");
     if (method < 0 || method > 3) CGE_THROW(CGE_E_ARG, "unknown split method %d", method);
     const i64 n = c->n, d = c->d;
@@ -318,31 +340,27 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
     HIP_CHECK(hipStreamSynchronize(st));
     c->phases.ms["aggregate"] = now_ms() - t0;
     t0 = now_ms();
-    // per-edge scatter: wedges (N x N) and vect_C (from the original edges; every landmark lies in one community)
+    // per-edge scatter.  vect_C (C x C cluster pairs, from the original edges: every landmark lies in one
+    // community, so this equals the reference's sum over landmark edges, src/divergence.jl:59-63) is what the
+    // score needs; the N x N landmark-pair matrix (src/landmarks.jl:433-451) only feeds landmarks_fetch.
     const i64 C = c->n_comm_max;
     const i64 vlen = directed ? C * C : packed_len(C);
-    c->wedges.ensure((size_t)N * N);
     c->vectC.ensure(vlen);
-    HIP_CHECK(hipMemsetAsync(c->wedges.p, 0, sizeof(double) * N * N, st));
     HIP_CHECK(hipMemsetAsync(c->vectC.p, 0, sizeof(double) * vlen, st));
     i64 e0 = 0, e1 = c->m;
     if (c->has_coll) { // edge shard of this rank
         e0 = c->m * c->coll.rank / c->coll.world;
         e1 = c->m * (c->coll.rank + 1) / c->coll.world;
     }
-    k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, c->v2l.p, c->comm.p, N, C,
-                   directed, c->wedges.p, c->vectC.p);
-    if (c->has_coll) {
-        allreduce(c, c->wedges.p, N * N, 0);
-        allreduce(c, c->vectC.p, vlen, 0);
-    }
-    DevBuf<i64> cnt;
-    cnt.ensure(1);
-    k_compact_count(c, c->wedges.p, N, directed, cnt.p);
-    HIP_CHECK(hipMemcpyAsync(&c->n_ledges, cnt.p, sizeof(i64), hipMemcpyDeviceToHost, st));
+    k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, nullptr, c->comm.p, N, C,
+                   directed, nullptr, c->vectC.p);
+    if (c->has_coll) allreduce(c, c->vectC.p, vlen, 0);
+    c->lm_directed = directed;
+    c->wedges_ready = false;
+    c->n_ledges = -1;
+    if (need_wedges) scatter_wedges(c, directed);
     HIP_CHECK(hipStreamSynchronize(st));
     c->phases.ms["scatter"] = now_ms() - t0;
-    c->lm_directed = directed;
     c->lm_ready = true;
 }
 
@@ -351,7 +369,7 @@ int cge_landmarks_run(cge_ctx *c, const int64_t *cl_flat, const int64_t *cl_off,
     if (!c || !cl_flat || !cl_off) return CGE_E_ARG;
     CGE_TRY(c)
     HIP_CHECK(hipSetDevice(c->device));
-    landmarks_run_impl(c, cl_flat, cl_off, ncl, land, forced, method, directed);
+    landmarks_run_impl(c, cl_flat, cl_off, ncl, land, forced, method, directed, true);
     if (N_out) *N_out = c->N;
     if (n_ledges_out) *n_ledges_out = c->n_ledges;
     if (truncated) *truncated = c->lm_truncated;
@@ -363,6 +381,15 @@ int cge_landmarks_info(cge_ctx *c, int64_t *N_out, int64_t *n_ledges_out, int *t
     if (!c->lm_ready) {
         c->err = "landmarks_info: run cge_landmarks_run first";
         return CGE_E_ARG;
+    }
+    if (!c->wedges_ready) { // the score path skips the landmark-pair matrix; build it on first demand
+        try {
+            HIP_CHECK(hipSetDevice(c->device));
+            scatter_wedges(c, c->lm_directed);
+        } catch (const CgeError &e) {
+            c->err = e.msg;
+            return e.code;
+        }
     }
     if (N_out) *N_out = c->N;
     if (n_ledges_out) *n_ledges_out = c->n_ledges;
@@ -376,6 +403,7 @@ int cge_landmarks_fetch(cge_ctx *c, double *dii, double *embed, int64_t *cluster
     CGE_TRY(c)
     if (!c->lm_ready) CGE_THROW(CGE_E_ARG, "landmarks_fetch: run cge_landmarks_run first");
     HIP_CHECK(hipSetDevice(c->device));
+    if (!c->wedges_ready) scatter_wedges(c, c->lm_directed);
     const i64 N = c->N, d = c->d, n = c->n;
     hipStream_t st = c->stream;
     if (dii) HIP_CHECK(hipMemcpyAsync(dii, c->dii.p, sizeof(double) * N, hipMemcpyDeviceToHost, st));
@@ -674,7 +702,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     DevBuf<double> zeros;
     double t0;
     if (landmarks) {
-        landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed);
+        landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed, false);
         const i64 N = c->N, C = c->n_comm_max;
         // wGCL's own `maximum(edges)` / size asserts (src/divergence.jl:41,50): the highest-numbered
         // landmark must carry an edge -- always true when every vertex has positive weight
@@ -782,7 +810,8 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
 }
 int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     if (!c || !key || !value) return CGE_E_ARG;
-    if (!strcmp(key, "diameter_path")) *value = c->stat_diameter_path;
+    if (!strcmp(key, "landmarks")) *value = c->lm_ready ? c->N : 0; // no side effects (cge_landmarks_info may build the N x N matrix)
+    else if (!strcmp(key, "diameter_path")) *value = c->stat_diameter_path;
     else if (!strcmp(key, "diameter_candidate_pairs")) *value = c->stat_cand_pairs;
     else if (!strcmp(key, "diameter_candidate_tiles")) *value = c->stat_cand_tiles;
     else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`

@@ -228,6 +228,7 @@ struct cge_ctx {
     DevBuf<double> wedges;    // N x N, [a*N + b]
     DevBuf<double> vectC;     // from the original edges
     i64 n_ledges = 0;
+    bool wedges_ready = false; // the N x N landmark-pair matrix is built lazily (cge_score does not need it)
 
     // ---- scratch for host-array wGCL ------------------------------------------------------
     DevBuf<double> s_emb, s_dist, s_vw, s_vectC, s_degin, s_degout;

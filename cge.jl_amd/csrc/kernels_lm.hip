@@ -937,16 +937,16 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(const i32 *__restrict
     for (i64 e = e0 + (i64)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += stride) {
         const i32 u = src[e], v = dst[e];
         const double we = w ? w[e] : 1.0;
-        i64 a = v2l ? v2l[u] : 0, b = v2l ? v2l[v] : 0; // v2l == nullptr: vect_C only (wedges must be null)
-        i64 cu = comm[u], cv = comm[v];
-        if (!directed) {
-            if (a > b) { i64 t = a; a = b; b = t; }
-            if (cu > cv) { i64 t = cu; cu = cv; cv = t; }
+        if (wedges) { // landmark-pair matrix (v2l != nullptr)
+            i64 a = v2l[u], b = v2l[v];
+            if (!directed && a > b) { i64 t = a; a = b; b = t; }
+            unsafeAtomicAdd(&wedges[a * N + b], we);
         }
-        if (wedges) unsafeAtomicAdd(&wedges[a * N + b], we);
         if (vectC) {
+            i64 cu = comm[u], cv = comm[v];
+            if (!directed && cu > cv) { i64 t = cu; cu = cv; cv = t; }
             if (cu == cv)
-                unsafeAtomicAdd(&cdiag[cu], we); // LDS atomic
+                unsafeAtomicAdd(&cdiag[cu], we); // LDS atomic: the bulk of a graph with community structure
             else
                 unsafeAtomicAdd(&vectC[directed ? cu * C + cv : (C * cu - cu * (cu - 1) / 2 + (cv - cu))], we);
         }
@@ -961,8 +961,11 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(const i32 *__restrict
 void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 e0, i64 e1, const i32 *v2l,
                     const i32 *comm, i64 N, i64 C, int directed, double *wedges, double *vectC) {
     if (e1 <= e0) return;
-    ScopedKernelTimer t(c, "edge_scatter");
-    const unsigned grid = grid_for(e1 - e0, 256, 256 * 8);
+    if (wedges && !v2l) CGE_THROW(CGE_E_ARG, "edge_scatter: the landmark-pair matrix needs v_to_l");
+    // two timers: the C x C cluster-pair scatter (the score path) and the N x N landmark-pair scatter
+    ScopedKernelTimer t(c, wedges ? (vectC ? "edge_scatter_both" : "edge_scatter_wedges") : "edge_scatter");
+    // one workgroup per CU-slot, a few per CU: every workgroup flushes C diagonal bins at the end
+    const unsigned grid = grid_for(e1 - e0, 256, 256 * 4);
     hipLaunchKernelGGL(edge_scatter_kernel, dim3(grid), dim3(256), (size_t)C * sizeof(double), c->stream, src, dst, w,
                        e0, e1, v2l, comm, N, C, directed, wedges, vectC);
 }

@@ -1021,7 +1021,11 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         while ((i64)H.len() < nland && H.top()->has_split) replay_one(H, pool);
         if ((i64)H.len() >= nland) break;
         const i64 remaining = nland - (i64)H.len();
-        i64 K = std::max<i64>(1, std::min<i64>(remaining, std::max<i64>(32, (remaining + 1) / 2)));
+        // speculation width: every group that could still be popped before the loop ends (at most `remaining`
+        // pops are left); over-speculation only costs device work, the replay stays exact
+        const char *env_k = getenv("CGE_SPEC_DIV");
+        const i64 div = env_k ? std::max<i64>(1, atoll(env_k)) : 1;
+        i64 K = std::max<i64>(1, std::min<i64>(remaining, std::max<i64>(32, (remaining + div - 1) / div)));
         K = std::min<i64>(K, 4096);
         std::vector<Group *> cand;
         for (size_t i = 1; i <= H.len(); i++)
