@@ -249,7 +249,8 @@ struct cge_ctx {
     double stat_last_hi = 0.0;
     // scratch of the batched split engine (landmarks_host.cpp)
     DevBuf<i32> ls_rows, ls_row_task, ls_ct, ls_cb, ls_ce, ls_tco;
-    DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z, ls_sums;
+    DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z, ls_sums, ls_Y;
+    DevBuf<i32> ls_yoff;
     DevBuf<unsigned char> ls_side, ls_state;
     DevBuf<double> ls_params; // per-task round parameters of the rss rule
     PinBuf<double> pin_sums, pin_z, pin_params;
@@ -308,7 +309,7 @@ void k_group_mean(cge_ctx *c, const double *Xr, const double *vw, const i32 *row
                   i64 d, double *part, double *mean, double *sw);
 void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
                  const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
-                 i64 d, const double *mean, double *part, double *cov);
+                 i64 d, const double *mean, double *part, double *cov, double *Ybuf, const i32 *yoff);
 void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const unsigned char *side,
                        const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
                        i64 d, double *part, double *out);

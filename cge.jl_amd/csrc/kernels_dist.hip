@@ -5,6 +5,7 @@
 //                   extrema(full_graph_D), never materialised)             src/divergence.jl:104-113
 //   k_pair_dist   : distances of sampled pairs                              src/divergence.jl:189,198
 #include "common.hpp"
+#include "mfma_tile.hpp"
 
 #define WAVE 64
 
@@ -136,14 +137,6 @@ void k_normalise(cge_ctx *c, double *D, i64 N, const double *lo_hi) {
 //
 // MFMA operand maps (cdna_hip_programming.md §3, f64 note): A lane l -> A[row l&15][k l>>4],
 // B lane l -> B[k l>>4][col l&15]; C/D lane l, reg r -> row (l>>4) + 4r, col l&15.
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d2 __attribute__((ext_vector_type(2)));
-#define MP_BM 128          // tile rows  (I side)
-#define MP_BN 128          // tile cols  (J side)
-#define MP_BK 16           // k-chunk
-#define MP_LD (MP_BM + 16) // LDS row stride in doubles: (2*LD) % 64 == 32 => the 2 k-rows of a half-wave hit disjoint banks
-#define MP_SB 32           // super-block edge in tiles
-
 struct MaxRec {
     double val;
     i64 i, j;
@@ -164,72 +157,6 @@ __device__ __forceinline__ void tile_from_linear(i64 t, i64 nS, i64 &SI, i64 &I,
     SI = si;
     I = si * MP_SB + loc / MP_SB;
     J = SJ * MP_SB + loc % MP_SB;
-}
-
-// One 128x128 Gram tile G = A_tile * B_tile^T over the whole feature dimension.
-// pa/pb: this thread's first load address (operand base + wave*ld + tile offset + 2*lane); a k-row of
-// a tile is 128 contiguous doubles; chunk kc covers k-rows [kc*MP_BK, (kc+1)*MP_BK).
-// LDS: 2 stages x (A,B) x MP_BK x MP_LD doubles.  All 256 threads must call it (barriers inside).
-__device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, const double *__restrict__ pb, i64 lda,
-                                              i64 ldb, i64 nchunk, double *lds, d4 (&acc)[4][4], int wave, int c2,
-                                              int wr, int wc, int lr, int lk) {
-    const size_t stage_doubles = (size_t)2 * MP_BK * MP_LD;
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-    d2 ra[4], rb[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        ra[q] = *reinterpret_cast<const d2 *>(pa + (i64)(4 * q) * lda);
-        rb[q] = *reinterpret_cast<const d2 *>(pb + (i64)(4 * q) * ldb);
-    }
-    __syncthreads(); // the previous tile's readers are done with both stages
-    {
-        double *As = lds, *Bs = lds + (size_t)MP_BK * MP_LD;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            *reinterpret_cast<d2 *>(As + (wave + 4 * q) * MP_LD + c2) = ra[q];
-            *reinterpret_cast<d2 *>(Bs + (wave + 4 * q) * MP_LD + c2) = rb[q];
-        }
-    }
-    __syncthreads();
-    for (i64 kc = 0; kc < nchunk; kc++) {
-        const int s = (int)(kc & 1);
-        const bool more = kc + 1 < nchunk;
-        if (more) { // issue the next chunk's global loads; they land while the MFMAs run
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                ra[q] = *reinterpret_cast<const d2 *>(pa + ((kc + 1) * MP_BK + 4 * q) * lda);
-                rb[q] = *reinterpret_cast<const d2 *>(pb + ((kc + 1) * MP_BK + 4 * q) * ldb);
-            }
-        }
-        const double *As = lds + (size_t)s * stage_doubles;
-        const double *Bs = As + (size_t)MP_BK * MP_LD;
-#pragma unroll
-        for (int ks = 0; ks < MP_BK / 4; ks++) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int a = 0; a < 4; a++) af[a] = As[(ks * 4 + lk) * MP_LD + wr * 64 + a * 16 + lr];
-#pragma unroll
-            for (int b = 0; b < 4; b++) bf[b] = Bs[(ks * 4 + lk) * MP_LD + wc * 64 + b * 16 + lr];
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
-        if (more) {
-            double *An = lds + (size_t)(s ^ 1) * stage_doubles;
-            double *Bn = An + (size_t)MP_BK * MP_LD;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                *reinterpret_cast<d2 *>(An + (wave + 4 * q) * MP_LD + c2) = ra[q];
-                *reinterpret_cast<d2 *>(Bn + (wave + 4 * q) * MP_LD + c2) = rb[q];
-            }
-        }
-        __syncthreads();
-    }
 }
 
 // workgroup reduction of (best, i, j) -> recs[blockIdx.x]: value max, ties -> smallest (i,j)

@@ -6,6 +6,7 @@
 //   landmark aggregation                : src/landmarks.jl:387-430
 //   per-edge scatter                    : src/landmarks.jl:433-451, src/divergence.jl:59-63, :337-345
 #include "common.hpp"
+#include "mfma_tile.hpp"
 
 #define WAVE 64
 
@@ -259,6 +260,64 @@ __global__ __launch_bounds__(256) void group_cov_partial_kernel(const double *__
         }
     }
 }
+// ---- covariance on the fp64 matrix cores (d >= 96) ----------------------------------------------------
+// (a) the centred, sqrt(w)-scaled rows y_j = (x_j - mu) * sqrt(w_j) of every chunk are written once,
+//     row-major with dp = d rounded up to 128 columns, each chunk padded with zero rows to a multiple of 16;
+// (b) A_chunk = Y^T Y is the same 128x128 MFMA Gram tile as the distance kernels, with the sample index as
+//     the contraction dimension (operand "k-row" = one sample, 128 contiguous features).
+__global__ __launch_bounds__(256) void group_center_rows_kernel(const double *__restrict__ Xr,
+                                                                const double *__restrict__ vw,
+                                                                const i32 *__restrict__ rows,
+                                                                const i32 *__restrict__ chunk_task,
+                                                                const i32 *__restrict__ chunk_beg,
+                                                                const i32 *__restrict__ chunk_end,
+                                                                const i32 *__restrict__ yoff, i64 d, i64 dp,
+                                                                const double *__restrict__ mean,
+                                                                double *__restrict__ Y) {
+    const i64 ch = blockIdx.x;
+    const i32 beg = chunk_beg[ch], end = chunk_end[ch];
+    const i64 len = end - beg, len16 = (len + 15) / 16 * 16;
+    const double *mu = mean + (i64)chunk_task[ch] * d;
+    double *out = Y + (i64)yoff[ch] * dp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (i64 r = wave; r < len16; r += 4) {
+        double *yr = out + r * dp;
+        if (r < len) {
+            const i64 v = rows[beg + r];
+            const double sq = sqrt(vw[v]);
+            const double *x = Xr + v * d;
+            for (i64 col = lane; col < dp; col += 64) yr[col] = (col < d) ? (x[col] - mu[col]) * sq : 0.0;
+        } else
+            for (i64 col = lane; col < dp; col += 64) yr[col] = 0.0;
+    }
+}
+__global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__restrict__ Y,
+                                                                const i32 *__restrict__ chunk_beg,
+                                                                const i32 *__restrict__ chunk_end,
+                                                                const i32 *__restrict__ yoff, i64 d, i64 dp,
+                                                                double *__restrict__ part /* [chunk][d*d] */) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4, c2 = lane * 2;
+    const i64 ch = blockIdx.x;
+    const i64 nT = dp / 128;
+    const i64 a0 = (blockIdx.y / nT) * 128, b0 = (blockIdx.y % nT) * 128;
+    const i64 len16 = ((i64)(chunk_end[ch] - chunk_beg[ch]) + 15) / 16 * 16;
+    const double *base = Y + (i64)yoff[ch] * dp;
+    d4 acc[4][4];
+    gram_tile_128(base + (i64)wave * dp + a0 + c2, base + (i64)wave * dp + b0 + c2, dp, dp, len16 / MP_BK, lds, acc, wave,
+                  c2, wr, wc, lr, lk);
+    double *out = part + ch * d * d;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const i64 ia = a0 + wr * 64 + a * 16 + lk + 4 * r, ib = b0 + wc * 64 + b * 16 + lr;
+                if (ia < d && ib < d) out[ia * d + ib] = acc[a][b][r];
+            }
+}
 __global__ void group_cov_final_kernel(const double *__restrict__ part, const i32 *__restrict__ task_chunk_off, i64 dd,
                                        double *__restrict__ cov) {
     const i64 t = blockIdx.y;
@@ -271,21 +330,30 @@ __global__ void group_cov_final_kernel(const double *__restrict__ part, const i3
 }
 void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
                  const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
-                 i64 d, const double *mean, double *part, double *cov) {
-    const int dp = (int)((d + 7) / 8 * 8);
-    int RT = 64;
-    while ((size_t)RT * (dp + 2) * sizeof(double) > 64 * 1024 && RT > 4) RT /= 2;
-    const size_t lds = (size_t)RT * (dp + 2) * sizeof(double);
+                 i64 d, const double *mean, double *part, double *cov, double *Ybuf, const i32 *yoff) {
     dim3 grid((unsigned)n_chunks), block(256);
-    if (dp >= 128)
-        hipLaunchKernelGGL(group_cov_partial_kernel<8>, grid, block, lds, c->stream, Xr, vw, rows, chunk_task,
-                           chunk_beg, chunk_end, d, dp, RT, mean, part);
-    else if (dp >= 64)
-        hipLaunchKernelGGL(group_cov_partial_kernel<4>, grid, block, lds, c->stream, Xr, vw, rows, chunk_task,
-                           chunk_beg, chunk_end, d, dp, RT, mean, part);
-    else
-        hipLaunchKernelGGL(group_cov_partial_kernel<2>, grid, block, lds, c->stream, Xr, vw, rows, chunk_task,
-                           chunk_beg, chunk_end, d, dp, RT, mean, part);
+    if (Ybuf && yoff && d >= 96) { // fp64 MFMA SYRK
+        const i64 dp = (d + 127) / 128 * 128, nT = dp / 128;
+        hipLaunchKernelGGL(group_center_rows_kernel, grid, block, 0, c->stream, Xr, vw, rows, chunk_task, chunk_beg,
+                           chunk_end, yoff, d, dp, mean, Ybuf);
+        hipLaunchKernelGGL(group_cov_mfma_kernel, dim3((unsigned)n_chunks, (unsigned)(nT * nT)), block,
+                           (size_t)2 * 2 * MP_BK * MP_LD * sizeof(double), c->stream, Ybuf, chunk_beg, chunk_end, yoff, d,
+                           dp, part);
+    } else {
+        const int dpv = (int)((d + 7) / 8 * 8);
+        int RT = 64;
+        while ((size_t)RT * (dpv + 2) * sizeof(double) > 64 * 1024 && RT > 4) RT /= 2;
+        const size_t lds = (size_t)RT * (dpv + 2) * sizeof(double);
+        if (dpv >= 128)
+            hipLaunchKernelGGL(group_cov_partial_kernel<8>, grid, block, lds, c->stream, Xr, vw, rows, chunk_task,
+                               chunk_beg, chunk_end, d, dpv, RT, mean, part);
+        else if (dpv >= 64)
+            hipLaunchKernelGGL(group_cov_partial_kernel<4>, grid, block, lds, c->stream, Xr, vw, rows, chunk_task,
+                               chunk_beg, chunk_end, d, dpv, RT, mean, part);
+        else
+            hipLaunchKernelGGL(group_cov_partial_kernel<2>, grid, block, lds, c->stream, Xr, vw, rows, chunk_task,
+                               chunk_beg, chunk_end, d, dpv, RT, mean, part);
+    }
     const i64 dd = d * d;
     dim3 g2((unsigned)std::min<i64>((dd + 255) / 256, 64), (unsigned)n_tasks);
     hipLaunchKernelGGL(group_cov_final_kernel, g2, dim3(256), 0, c->stream, part, task_chunk_off, dd, cov);
