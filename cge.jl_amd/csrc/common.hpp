@@ -253,7 +253,8 @@ struct cge_ctx {
     DevBuf<i32> ls_yoff;
     DevBuf<unsigned char> ls_side, ls_state;
     DevBuf<double> ls_params; // per-task round parameters of the rss rule
-    PinBuf<double> pin_sums, pin_z, pin_params;
+    PinBuf<double> pin_sums, pin_z, pin_params, pin_zs;
+    PinBuf<i32> pin_rows[2], pin_row_task[2], pin_srows; // [slot]: 0 = main batch, 1 = fallback sub-batch
     // sorted-prefix rss path
     DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro;
     DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;

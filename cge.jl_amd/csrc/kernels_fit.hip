@@ -39,21 +39,44 @@ void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD) 
 // S_i = sum_j (T_i*T_j)*GD_ij  (full symmetric GD: the diagonal is counted once, as :153-159).
 // One workgroup per row; every kernel of a fit returns at once when *done is set, so the host can
 // enqueue iterations in batches and still stop exactly at the reference's iteration.
+// One wave per row, 16-byte loads, shuffle reduction (fixed lane pattern => reproducible); 4 rows per workgroup.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void fit_symv_kernel(const double *__restrict__ GD, const double *__restrict__ T,
                                                        i64 N, double *__restrict__ S, const int *__restrict__ done) {
-    __shared__ double sh[256];
     if (*done) return;
-    const i64 i = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const i64 i = (i64)blockIdx.x * 4 + wave;
+    if (i >= N) return;
     const double ti = T[i];
     const double *row = GD + i * N;
-    double s = 0.0;
-    for (i64 j = threadIdx.x; j < N; j += 256) s += (ti * T[j]) * row[j];
-    s = block_sum_256(s, sh);
-    if (threadIdx.x == 0) S[i] = s;
+    double s0 = 0.0, s1 = 0.0;
+    if ((N & 1) == 0) { // rows are 16-B aligned
+        const i64 n2 = N >> 1;
+        const dbl2 *row2 = reinterpret_cast<const dbl2 *>(row);
+        const dbl2 *T2 = reinterpret_cast<const dbl2 *>(T);
+        i64 k = lane;
+        for (; k + 192 < n2; k += 256) { // 4 independent 16-B loads in flight per operand
+            const dbl2 g0 = row2[k], g1 = row2[k + 64], g2 = row2[k + 128], g3 = row2[k + 192];
+            const dbl2 t0 = T2[k], t1 = T2[k + 64], t2 = T2[k + 128], t3 = T2[k + 192];
+            s0 += (ti * t0.x) * g0.x; s1 += (ti * t0.y) * g0.y;
+            s0 += (ti * t1.x) * g1.x; s1 += (ti * t1.y) * g1.y;
+            s0 += (ti * t2.x) * g2.x; s1 += (ti * t2.y) * g2.y;
+            s0 += (ti * t3.x) * g3.x; s1 += (ti * t3.y) * g3.y;
+        }
+        for (; k < n2; k += 64) {
+            const dbl2 g0 = row2[k], t0 = T2[k];
+            s0 += (ti * t0.x) * g0.x; s1 += (ti * t0.y) * g0.y;
+        }
+    } else {
+        for (i64 j = lane; j < N; j += 64) s0 += (ti * T[j]) * row[j];
+    }
+    double s = s0 + s1;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) S[i] = s;
 }
 void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done) {
     ScopedKernelTimer t(c, "fit_symv");
-    hipLaunchKernelGGL(fit_symv_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, GD, T, N, S, done);
+    hipLaunchKernelGGL(fit_symv_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, GD, T, N, S, done);
 }
 // T_i += eps*T_i*(w_i/S_i - 1); f = max|w_i - S_i| with the pre-update S (:160-166)
 __global__ __launch_bounds__(1024) void fit_update_kernel(double *__restrict__ T, const double *__restrict__ S,

@@ -680,6 +680,14 @@ void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, co
 // largest eigenvalue by (64-way) multisection on the Sturm count, inverse iteration with a pivoted
 // tridiagonal LU, back-transformation, sign = largest-|component| positive.
 // Replaces `eigvecs(A)[:, end]` (src/landmarks.jl:99,162,225,254).
+// 1/q to ~1 ulp without the IEEE division sequence: hardware reciprocal + one Newton step.  Used only in
+// chains whose results are themselves iterated (Sturm counts, inverse iteration), never in sums that
+// are compared with the reference.
+__device__ __forceinline__ double fast_rcp(double q) {
+    double r = __builtin_amdgcn_rcp(q);
+    r = fma(fma(-q, r, 1.0), r, r);
+    return r;
+}
 __device__ __forceinline__ double eig_block_sum(double v, double *red) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     const int wave = threadIdx.x >> 6;
@@ -787,7 +795,7 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
             if (q < 0) cnt++;
             for (int i = 1; i < d; i++) {
                 if (q == 0.0) q = tiny;
-                q = diag[i] - x - off[i - 1] * off[i - 1] / q;
+                q = diag[i] - x - (off[i - 1] * off[i - 1]) * fast_rcp(q);
                 if (q < 0) cnt++;
             }
             const unsigned long long mask = __ballot(cnt >= d);
@@ -839,9 +847,10 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
             }
         }
         if (dd[d - 1] == 0.0) dd[d - 1] = tiny;
+        for (int i = 0; i < d; i++) dd[i] = fast_rcp(dd[i]); // the solves multiply by the reciprocal pivots
         double *y = V;
         for (int i = 0; i < d; i++) y[i] = 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0;
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < 3; it++) {
             for (int i = 0; i + 1 < d; i++) {
                 const bool sw = (i < 64) ? ((swp0 >> i) & 1ULL) : ((swp1 >> (i - 64)) & 1ULL);
                 if (!sw)
@@ -852,9 +861,9 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
                     y[i + 1] = t - dl[i] * y[i];
                 }
             }
-            y[d - 1] /= dd[d - 1];
-            y[d - 2] = (y[d - 2] - du[d - 2] * y[d - 1]) / dd[d - 2];
-            for (int i = d - 3; i >= 0; i--) y[i] = (y[i] - du[i] * y[i + 1] - du2[i] * y[i + 2]) / dd[i];
+            y[d - 1] *= dd[d - 1];
+            y[d - 2] = (y[d - 2] - du[d - 2] * y[d - 1]) * dd[d - 2];
+            for (int i = d - 3; i >= 0; i--) y[i] = (y[i] - du[i] * y[i + 1] - du2[i] * y[i + 2]) * dd[i];
             double amax = 0.0;
             for (int i = 0; i < d; i++) amax = fmax(amax, fabs(y[i]));
             if (!(amax > 0.0) || !(amax < 1e300)) {

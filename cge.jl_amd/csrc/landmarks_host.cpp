@@ -475,15 +475,18 @@ namespace {
 // member order; every group is cut into chunks of CH rows (one workgroup each).
 struct Batch {
     i64 T = 0, R = 0, NC = 0;
-    std::vector<i32> rows, row_task, chunk_task, chunk_beg, chunk_end, task_chunk_off, task_row_off;
+    i32 *rows = nullptr, *row_task = nullptr; // pinned staging owned by the ctx (slot 0 main / 1 fallback)
+    std::vector<i32> chunk_task, chunk_beg, chunk_end, task_chunk_off, task_row_off;
 };
-void build_batch(Group *const *groups, i64 T, Batch &B) {
+void build_batch(cge_ctx *c, Group *const *groups, i64 T, Batch &B, int slot = 0) {
     const i64 CH = 1024;
     B.T = T;
     B.R = 0;
     for (i64 t = 0; t < T; t++) B.R += (i64)groups[t]->what.size();
-    B.rows.resize(B.R);
-    B.row_task.resize(B.R);
+    c->pin_rows[slot].ensure(B.R);
+    c->pin_row_task[slot].ensure(B.R);
+    B.rows = c->pin_rows[slot].p;
+    B.row_task = c->pin_row_task[slot].p;
     B.chunk_task.clear(); B.chunk_beg.clear(); B.chunk_end.clear();
     B.task_chunk_off.assign(T + 1, 0);
     B.task_row_off.assign(T + 1, 0);
@@ -493,10 +496,6 @@ void build_batch(Group *const *groups, i64 T, Batch &B) {
         B.task_row_off[t] = (i32)pos;
         B.task_chunk_off[t] = (i32)B.chunk_task.size();
         const i64 k = (i64)g->what.size();
-        for (i64 j = 0; j < k; j++) {
-            B.rows[pos + j] = (i32)(g->what[j] - 1);
-            B.row_task[pos + j] = (i32)t;
-        }
         for (i64 s = 0; s < k; s += CH) {
             B.chunk_task.push_back((i32)t);
             B.chunk_beg.push_back((i32)(pos + s));
@@ -507,6 +506,14 @@ void build_batch(Group *const *groups, i64 T, Batch &B) {
     B.task_row_off[T] = (i32)pos;
     B.task_chunk_off[T] = (i32)B.chunk_task.size();
     B.NC = (i64)B.chunk_task.size();
+    parallel_for(c, T, [&](i64 t) { // the row arrays (the bulk) are filled in parallel
+        const Group *g = groups[t];
+        const i64 o = B.task_row_off[t], k = (i64)g->what.size();
+        for (i64 j = 0; j < k; j++) {
+            B.rows[o + j] = (i32)(g->what[j] - 1);
+            B.row_task[o + j] = (i32)t;
+        }
+    });
 }
 void upload_batch(cge_ctx *c, const Batch &B) { // grow-only scratch owned by the ctx
     hipStream_t st = c->stream;
@@ -516,8 +523,8 @@ void upload_batch(cge_ctx *c, const Batch &B) { // grow-only scratch owned by th
     c->ls_part.ensure((size_t)B.NC * std::max(d * d, 2 * (2 * d + 1)));
     c->ls_side.ensure(B.R);
     c->ls_sums.ensure((size_t)B.T * 2 * (2 * d + 1));
-    HIP_CHECK(hipMemcpyAsync(c->ls_rows.p, B.rows.data(), sizeof(i32) * B.R, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->ls_row_task.p, B.row_task.data(), sizeof(i32) * B.R, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_rows.p, B.rows, sizeof(i32) * B.R, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_row_task.p, B.row_task, sizeof(i32) * B.R, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->ls_ct.p, B.chunk_task.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->ls_cb.p, B.chunk_beg.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->ls_ce.p, B.chunk_end.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
@@ -569,7 +576,7 @@ void device_group_values(cge_ctx *c, std::vector<Group *> &groups) {
     if (groups.empty()) return;
     const i64 d = c->d, width = 2 * (2 * d + 1);
     Batch B;
-    build_batch(groups.data(), (i64)groups.size(), B);
+    build_batch(c, groups.data(), (i64)groups.size(), B);
     upload_batch(c, B);
     std::vector<unsigned char> side(B.R, 1);
     const double *sums = side_sums(c, B, side);
@@ -586,8 +593,7 @@ struct RssState {
     int phase = 0; // 0 = median rounds, 1 = leftover decision (:200-208), 2 = done
     int rc = CGE_OK;
 };
-void rule_rss_batched(cge_ctx *c, const Batch &B, Group *const *groups, const std::vector<double> &z,
-                      std::vector<RssState> &st) {
+void rule_rss_batched(cge_ctx *c, const Batch &B, Group *const *groups, const double *z, std::vector<RssState> &st) {
     const i64 T = B.T, d = c->d, width = 2 * (2 * d + 1);
     const double *hX = c->h_Xr.data(), *hw = c->h_vw.data();
     st.assign(T, RssState());
@@ -693,15 +699,19 @@ void rule_rss_batched(cge_ctx *c, const Batch &B, Group *const *groups, const st
 // task in one launch; the host then rebuilds the children's member lists in the reference's order
 // (seed first, then every absorbed batch in ascending original index, :163-164, :189, :194, :204-206).
 // Tasks the rank-range argument does not cover (a tie at the maximum of z, NaNs) go to `fallback`.
-void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const std::vector<double> &z,
+void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const double *z,
                      std::vector<std::vector<i64>> &lows, std::vector<std::vector<i64>> &highs,
                      std::vector<double> &vlow, std::vector<double> &vhigh, std::vector<char> &have_vals,
                      std::vector<i64> &fallback) {
     const i64 T = B.T, R = B.R, d = c->d, W = 2 * d + 1;
     hipStream_t st = c->stream;
-    std::vector<i32> perm(R), srows(R);
-    std::vector<double> zs(R);
+    std::vector<i32> perm(R);
+    c->pin_srows.ensure(R);
+    c->pin_zs.ensure(R);
+    i32 *srows = c->pin_srows.p;
+    double *zs = c->pin_zs.p;
     std::vector<char> status(T, 0); // 0 sorted path, 1 fallback, 2 homogeneous
+    PhaseAcc *pa = new PhaseAcc(c, "lm_cut_sort");
     parallel_for(c, T, [&](i64 t) {
         const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
         const double *zt = &z[o];
@@ -718,11 +728,13 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const std
             zs[o + r] = zt[p[r]];
         }
     });
+    delete pa;
+    pa = new PhaseAcc(c, "lm_cut_dev");
     c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_tro.ensure(T + 1);
     c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W); c->sp_prefix.ensure((size_t)R * W);
     c->sp_meta.ensure(2 * T); c->sp_rounds.ensure((size_t)T * 3 * CGE_RR_MAXROUNDS); c->sp_vals.ensure(2 * T);
-    HIP_CHECK(hipMemcpyAsync(c->sp_srows.p, srows.data(), sizeof(i32) * R, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->sp_zs.p, zs.data(), sizeof(double) * R, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->sp_srows.p, srows, sizeof(i32) * R, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->sp_zs.p, zs, sizeof(double) * R, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
     k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
@@ -734,6 +746,8 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const std
     HIP_CHECK(hipMemcpyAsync(rounds.data(), c->sp_rounds.p, sizeof(i32) * rounds.size(), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    delete pa;
+    PhaseAcc pa2(c, "lm_cut_rebuild");
     parallel_for(c, T, [&](i64 t) {
         Group *g = groups[t];
         if (status[t] == 2) { g->rc = CGE_E_HOMOGENEOUS; return; }
@@ -808,14 +822,14 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
         Batch B;
         {
             PhaseAcc pa(c, "lm_pack");
-            build_batch(groups, T, B);
+            build_batch(c, groups, T, B);
             upload_batch(c, B);
         }
         const i64 R = B.R, NC = B.NC;
         c->ls_mean.ensure((size_t)T * d); c->ls_sw.ensure(T); c->ls_cov.ensure((size_t)T * d * d);
         c->ls_vec.ensure((size_t)T * d); c->ls_z.ensure(R);
         c->pin_z.ensure(R);
-        std::vector<double> z; // filled from the pinned staging buffer
+        const double *z = c->pin_z.p; // the projections stay in the pinned staging buffer
         {
             PhaseAcc pa(c, "lm_pca_dev");
             {
@@ -854,7 +868,6 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             }
             HIP_CHECK(hipMemcpyAsync(c->pin_z.p, c->ls_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
-            z.assign(c->pin_z.p, c->pin_z.p + R);
         }
         // ---- the cut: local positions of the two children -----------------------------------------------------
         std::vector<std::vector<i64>> lows(T), highs(T);
@@ -869,16 +882,16 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                     std::vector<Group *> fg;
                     for (i64 t : fallback) fg.push_back(groups[t]);
                     Batch FB;
-                    build_batch(fg.data(), (i64)fg.size(), FB);
+                    build_batch(c, fg.data(), (i64)fg.size(), FB, 1);
                     upload_batch(c, FB);
                     std::vector<double> fz(FB.R);
                     for (size_t q = 0; q < fallback.size(); q++)
-                        std::copy(z.begin() + B.task_row_off[fallback[q]], z.begin() + B.task_row_off[fallback[q] + 1],
+                        std::copy(z + B.task_row_off[fallback[q]], z + B.task_row_off[fallback[q] + 1],
                                   fz.begin() + FB.task_row_off[q]);
                     c->ls_z.ensure(FB.R);
                     HIP_CHECK(hipMemcpyAsync(c->ls_z.p, fz.data(), sizeof(double) * FB.R, hipMemcpyHostToDevice, st));
                     std::vector<RssState> rs;
-                    rule_rss_batched(c, FB, fg.data(), fz, rs);
+                    rule_rss_batched(c, FB, fg.data(), fz.data(), rs);
                     for (size_t q = 0; q < fallback.size(); q++) {
                         groups[fallback[q]]->rc = rs[q].rc;
                         lows[fallback[q]].swap(rs[q].low);
