@@ -318,8 +318,10 @@ void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *
                      const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks, i64 d, double *ctot,
                      double *coff, double *prefix);
 void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const double *zs,
-                  const i32 *task_row_off, const double *prefix, i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals);
+                  const i32 *task_row_off, const i32 *task_chunk_off, const double *prefix, const double *coff,
+                  i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals);
 #define CGE_RR_MAXROUNDS 63
+#define CGE_CHUNK_ROWS 1024 // rows per chunk of a batch (build_batch); the rounds kernel uses r >> 10
 void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, const double *params,
                 unsigned char *state, unsigned char *side);
 bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec);

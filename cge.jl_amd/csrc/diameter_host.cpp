@@ -59,7 +59,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, i64 N, const std::vector
     // ---- lower bound from farthest-point sweeps ----------------------------------------------------------
     double L = 0.0;
     i64 p0 = 0, far_i = 0, far_j = 0;
-    for (int it = 0; it < 3; it++) {
+    for (int it = 0; it < 2; it++) { // two sweeps seed the bound; the exact search below does the rest
         double v;
         i64 q;
         k_farthest(c, c->Xr.p, n, d, p0, &v, &q);

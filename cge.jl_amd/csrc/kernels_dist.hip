@@ -368,34 +368,48 @@ struct BoundRec {
     double B;
     i32 a, b;
 };
-__global__ void bound_select_kernel(const double *__restrict__ P, const double *__restrict__ mu /* N x d row-major */,
-                                    i64 N, i64 d, double L, BoundRec *__restrict__ list, i64 cap,
-                                    unsigned long long *__restrict__ count) {
-    const i64 total = N * N, stride = (i64)gridDim.x * blockDim.x;
-    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const i64 a = e / N, b = e - a * N;
-        if (b < a) continue;
+// 32x32 tiles (A <= B) so that both P[a][b] and P[b][a] are read coalesced (the mirror tile goes through LDS).
+__global__ __launch_bounds__(256) void bound_select_kernel(const double *__restrict__ P,
+                                                           const double *__restrict__ mu /* N x d row-major */, i64 N,
+                                                           i64 d, double L, BoundRec *__restrict__ list, i64 cap,
+                                                           unsigned long long *__restrict__ count) {
+    __shared__ double mirror[32][33];
+    const i64 nb = (N + 31) / 32;
+    i64 t = blockIdx.x, A = 0, rowlen = nb;
+    while (t >= rowlen) { t -= rowlen; rowlen--; A++; }
+    const i64 Bt = A + t;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    for (int r = ty; r < 32; r += 8) { // mirror[r][tx] = P[b = Bt*32 + r][a = A*32 + tx]
+        const i64 b = Bt * 32 + r, a = A * 32 + tx;
+        mirror[r][tx] = (a < N && b < N) ? P[b * N + a] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const i64 a = A * 32 + r, b = Bt * 32 + tx;
+        if (a >= N || b >= N || b < a) continue;
         const double paa = P[a * N + a], pbb = P[b * N + b];
-        // cheap pre-test without D2 (D2 >= 0): skip most pairs before touching the centroids
-        const double pre = P[a * N + b] + P[b * N + a] + 2.0 * sqrt(paa * pbb);
+        // cheap pre-test without D2 (D2 >= 0): most pairs stop here, before touching the centroids
+        const double pre = P[a * N + b] + mirror[tx][r] + 2.0 * sqrt(paa * pbb);
         if (pre * (1.0 + 1e-9) + 1e-9 < L) continue;
         double d2 = 0.0;
         const double *ma = mu + a * d, *mb = mu + b * d;
         for (i64 k = 0; k < d; k++) {
-            const double t = ma[k] - mb[k];
-            d2 += t * t;
+            const double df = ma[k] - mb[k];
+            d2 += df * df;
         }
-        const double B = pre - d2 * (1.0 - 1e-9);
-        if (B * (1.0 + 1e-9) + 1e-9 >= L) {
+        const double Bv = pre - d2 * (1.0 - 1e-9);
+        if (Bv * (1.0 + 1e-9) + 1e-9 >= L) {
             const unsigned long long idx = atomicAdd(count, 1ULL);
-            if ((i64)idx < cap) list[idx] = BoundRec{B, (i32)a, (i32)b};
+            if ((i64)idx < cap) list[idx] = BoundRec{Bv, (i32)a, (i32)b};
         }
     }
 }
 i64 k_bound_select(cge_ctx *c, const double *P, const double *mu, i64 N, i64 d, double L, void *list, i64 cap) {
     c->mp_count.ensure(1);
     HIP_CHECK(hipMemsetAsync(c->mp_count.p, 0, sizeof(i64), c->stream));
-    hipLaunchKernelGGL(bound_select_kernel, dim3(grid_for(N * N, 256)), dim3(256), 0, c->stream, P, mu, N, d, L,
+    const i64 nb32 = (N + 31) / 32;
+    ScopedKernelTimer tm(c, "bound_select");
+    hipLaunchKernelGGL(bound_select_kernel, dim3((unsigned)(nb32 * (nb32 + 1) / 2)), dim3(256), 0, c->stream, P, mu, N, d, L,
                        reinterpret_cast<BoundRec *>(list), cap, reinterpret_cast<unsigned long long *>(c->mp_count.p));
     i64 cnt = 0;
     HIP_CHECK(hipMemcpyAsync(&cnt, c->mp_count.p, sizeof(i64), hipMemcpyDeviceToHost, c->stream));
@@ -416,10 +430,18 @@ __global__ __launch_bounds__(256) void farthest_kernel(const double *__restrict_
     for (i64 i = wave_global; i < n; i += nwaves) {
         const double *x = Xr + i * d;
         double acc = 0.0;
-        for (i64 k = lane; k < d; k += 64) {
-            const double t = x[k] - s[k];
-            acc += t * t;
-        }
+        if ((d & 1) == 0) { // 16-byte loads
+            const d2 *x2 = reinterpret_cast<const d2 *>(x), *s2 = reinterpret_cast<const d2 *>(s);
+            for (i64 k = lane; k < (d >> 1); k += 64) {
+                const d2 xv = x2[k], sv = s2[k];
+                const double t0 = xv.x - sv.x, t1 = xv.y - sv.y;
+                acc += t0 * t0 + t1 * t1;
+            }
+        } else
+            for (i64 k = lane; k < d; k += 64) {
+                const double t = x[k] - s[k];
+                acc += t * t;
+            }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         if (acc > best) { best = acc; bi = i; }
     }

@@ -457,16 +457,30 @@ __device__ __forceinline__ double scan_term(const double *__restrict__ x, double
     if (c < 2 * d) return w * x[c - d];
     return w;
 }
-__global__ void scan_chunk_totals_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
-                                         const i32 *__restrict__ srows, const i32 *__restrict__ chunk_beg,
-                                         const i32 *__restrict__ chunk_end, i64 d, i64 W, double *__restrict__ ctot) {
+// One pass: the inclusive prefix INSIDE each chunk (starting from 0) and the chunk total; a tiny second
+// kernel turns the totals of a task's chunks into exclusive offsets.  P[r] = prefix[r] + coff[chunk of r].
+__global__ void scan_write_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                  const i32 *__restrict__ srows, const i32 *__restrict__ chunk_beg,
+                                  const i32 *__restrict__ chunk_end, i64 d, i64 W, double *__restrict__ ctot,
+                                  double *__restrict__ prefix) {
     const i64 ch = blockIdx.x;
     const i32 beg = chunk_beg[ch], end = chunk_end[ch];
     for (i64 c = threadIdx.x; c < W; c += blockDim.x) {
         double run = 0.0;
-        for (i32 j = beg; j < end; j++) {
+        i32 j = beg;
+        for (; j + 3 < end; j += 4) { // 4 rows in flight
+            const i64 v0 = srows[j], v1 = srows[j + 1], v2 = srows[j + 2], v3 = srows[j + 3];
+            const double t0 = scan_term(Xr + v0 * d, vw[v0], c, d), t1 = scan_term(Xr + v1 * d, vw[v1], c, d);
+            const double t2 = scan_term(Xr + v2 * d, vw[v2], c, d), t3 = scan_term(Xr + v3 * d, vw[v3], c, d);
+            run += t0; prefix[(i64)j * W + c] = run;
+            run += t1; prefix[(i64)(j + 1) * W + c] = run;
+            run += t2; prefix[(i64)(j + 2) * W + c] = run;
+            run += t3; prefix[(i64)(j + 3) * W + c] = run;
+        }
+        for (; j < end; j++) {
             const i64 v = srows[j];
             run += scan_term(Xr + v * d, vw[v], c, d);
+            prefix[(i64)j * W + c] = run;
         }
         ctot[ch * W + c] = run;
     }
@@ -483,33 +497,16 @@ __global__ void scan_chunk_offsets_kernel(const double *__restrict__ ctot, const
         }
     }
 }
-__global__ void scan_write_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
-                                  const i32 *__restrict__ srows, const i32 *__restrict__ chunk_beg,
-                                  const i32 *__restrict__ chunk_end, i64 d, i64 W, const double *__restrict__ coff,
-                                  double *__restrict__ prefix) {
-    const i64 ch = blockIdx.x;
-    const i32 beg = chunk_beg[ch], end = chunk_end[ch];
-    for (i64 c = threadIdx.x; c < W; c += blockDim.x) {
-        double run = coff[ch * W + c];
-        for (i32 j = beg; j < end; j++) {
-            const i64 v = srows[j];
-            run += scan_term(Xr + v * d, vw[v], c, d);
-            prefix[(i64)j * W + c] = run;
-        }
-    }
-}
 void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *chunk_beg,
                      const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks, i64 d, double *ctot,
                      double *coff, double *prefix) {
     const i64 W = 2 * d + 1;
     const int bs = (int)std::min<i64>(1024, (W + 63) / 64 * 64);
     ScopedKernelTimer t(c, "sorted_prefix");
-    hipLaunchKernelGGL(scan_chunk_totals_kernel, dim3((unsigned)n_chunks), dim3(bs), 0, c->stream, Xr, vw, srows,
-                       chunk_beg, chunk_end, d, W, ctot);
+    hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)n_chunks), dim3(bs), 0, c->stream, Xr, vw, srows, chunk_beg,
+                       chunk_end, d, W, ctot, prefix);
     hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3((unsigned)n_tasks), dim3(bs), 0, c->stream, ctot, task_chunk_off,
                        W, coff);
-    hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)n_chunks), dim3(bs), 0, c->stream, Xr, vw, srows, chunk_beg,
-                       chunk_end, d, W, coff, prefix);
 }
 
 #define RR_SLOTS 8      // columns per lane: d <= 512
@@ -523,14 +520,18 @@ __device__ __forceinline__ double wave_sum(double v) {
 __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                                         const i32 *__restrict__ srows, const double *__restrict__ zs,
                                                         const i32 *__restrict__ task_row_off,
-                                                        const double *__restrict__ prefix, i64 d,
+                                                        const i32 *__restrict__ task_chunk_off,
+                                                        const double *__restrict__ prefix,
+                                                        const double *__restrict__ coff, i64 d,
                                                         i32 *__restrict__ meta, i32 *__restrict__ rounds,
                                                         double *__restrict__ vals) {
     const i64 t = blockIdx.x, W = 2 * d + 1;
     const int lane = threadIdx.x;
     const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
     const double *z = zs + o;
-    const double *P = prefix + o * W;
+    const double *Ploc = prefix + o * W;                      // prefix inside each 1024-row chunk of the task
+    const double *Coff = coff + (i64)task_chunk_off[t] * W;   // exclusive offsets of the task's chunks
+    auto Pv = [&](i64 r, i64 cidx) { return Ploc[r * W + cidx] + Coff[(r / CGE_CHUNK_ROWS) * W + cidx]; };
     i32 *rlog = rounds + t * 3 * RR_MAXROUNDS;
     // seeds: rank 0 (arg-min) and rank k-1 (arg-max), exact terms as :169-170
     double rl_ss[RR_SLOTS], rl_s[RR_SLOTS], rh_ss[RR_SLOTS], rh_s[RR_SLOTS];
@@ -554,11 +555,11 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
             const i64 c = lane + 64 * s;
             ss[s] = s1[s] = 0.0;
             if (c < d && b > a) {
-                ss[s] = P[(b - 1) * W + c] - (a > 0 ? P[(a - 1) * W + c] : 0.0);
-                s1[s] = P[(b - 1) * W + d + c] - (a > 0 ? P[(a - 1) * W + d + c] : 0.0);
+                ss[s] = Pv(b - 1, c) - (a > 0 ? Pv(a - 1, c) : 0.0);
+                s1[s] = Pv(b - 1, d + c) - (a > 0 ? Pv(a - 1, d + c) : 0.0);
             }
         }
-        w = (b > a) ? P[(b - 1) * W + 2 * d] - (a > 0 ? P[(a - 1) * W + 2 * d] : 0.0) : 0.0;
+        w = (b > a) ? Pv(b - 1, 2 * d) - (a > 0 ? Pv(a - 1, 2 * d) : 0.0) : 0.0;
     };
     // sum over the columns of wsse(base + add)
     auto fsum = [&](const double (&bss)[RR_SLOTS], const double (&bs1)[RR_SLOTS], double bw, const double (&ass)[RR_SLOTS],
@@ -640,11 +641,12 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
     }
 }
 void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const double *zs,
-                  const i32 *task_row_off, const double *prefix, i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals) {
+                  const i32 *task_row_off, const i32 *task_chunk_off, const double *prefix, const double *coff,
+                  i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals) {
     if (d > 64 * RR_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * RR_SLOTS);
     ScopedKernelTimer t(c, "rss_rounds");
     hipLaunchKernelGGL(rss_rounds_kernel, dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, zs,
-                       task_row_off, prefix, d, meta, rounds, vals);
+                       task_row_off, task_chunk_off, prefix, coff, d, meta, rounds, vals);
 }
 
 // Side flags of one rss round, derived on the device (no per-round row-sized upload).  Per task t,

@@ -479,7 +479,7 @@ struct Batch {
     std::vector<i32> chunk_task, chunk_beg, chunk_end, task_chunk_off, task_row_off;
 };
 void build_batch(cge_ctx *c, Group *const *groups, i64 T, Batch &B, int slot = 0) {
-    const i64 CH = 1024;
+    const i64 CH = CGE_CHUNK_ROWS;
     B.T = T;
     B.R = 0;
     for (i64 t = 0; t < T; t++) B.R += (i64)groups[t]->what.size();
@@ -738,8 +738,8 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const dou
     HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
     k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
-    k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->sp_prefix.p, T, d, c->sp_meta.p,
-                 c->sp_rounds.p, c->sp_vals.p);
+    k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->ls_tco.p, c->sp_prefix.p, c->sp_coff.p,
+                 T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p);
     std::vector<i32> meta(2 * T), rounds((size_t)T * 3 * CGE_RR_MAXROUNDS);
     std::vector<double> vals(2 * T);
     HIP_CHECK(hipMemcpyAsync(meta.data(), c->sp_meta.p, sizeof(i32) * 2 * T, hipMemcpyDeviceToHost, st));
