@@ -701,15 +701,33 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     const bool landmarks = a->land != -1;
     DevBuf<double> zeros;
     double t0;
+    DevBuf<i32> star;
+    auto star_exit = [&](i64 Nv) -> bool { // star-graph guard of wGCL_directed (src/divergence.jl:321-334)
+        std::vector<i32> hstar(Nv);
+        HIP_CHECK(hipMemcpyAsync(hstar.data(), star.p, sizeof(i32) * Nv, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (!is_star(hstar, Nv)) return false;
+        out[0] = -1.0;
+        for (int k = 1; k < 6; k++) out[k] = 0.0;
+        *out_len = 6;
+        return true;
+    };
     if (landmarks) {
-        landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed, false);
+        landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed,
+                           directed != 0);
         const i64 N = c->N, C = c->n_comm_max;
         // wGCL's own `maximum(edges)` / size asserts (src/divergence.jl:41,50): the highest-numbered
         // landmark must carry an edge -- always true when every vertex has positive weight
         G.N = N; G.d = d; G.C = C;
         G.emb = c->lemb.p; G.dist = c->dii.p; G.vw = c->lweight.p; G.comm = c->lcomm.p; G.vectC = c->vectC.p;
-        if (directed) { // degrees of the landmark graph = row / column sums of wedges
-            CGE_THROW(CGE_E_ARG, "score: directed landmark mode goes through cge_landmarks_run + cge_wgcl");
+        if (directed) { // degrees / star counts of the landmark graph from the landmark-pair matrix
+            c->s_degin.ensure(N);
+            c->s_degout.ensure(N);
+            star.ensure(N);
+            k_wedge_degrees(c, c->wedges.p, N, c->s_degout.p, c->s_degin.p, star.p);
+            if (star_exit(N)) return CGE_OK;
+            G.deg_in = c->s_degin.p;
+            G.deg_out = c->s_degout.p;
         }
         t0 = now_ms();
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
@@ -720,21 +738,33 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         c->stat_last_hi = hi;
         c->phases.ms["diameter"] = now_ms() - t0;
     } else {
-        if (directed) CGE_THROW(CGE_E_ARG, "score: directed exact mode goes through cge_wgcl");
         const i64 N = c->n, C = c->n_comm_max;
         zeros.ensure(N);
         HIP_CHECK(hipMemsetAsync(zeros.p, 0, sizeof(double) * N, st)); // distances = zeros (CGE_CLI.jl:4)
-        const i64 vlen = packed_len(C);
+        const i64 vlen = directed ? C * C : packed_len(C);
         c->vectC.ensure(vlen);
         HIP_CHECK(hipMemsetAsync(c->vectC.p, 0, sizeof(double) * vlen, st));
-        k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, 0, c->m, nullptr, c->comm.p, N, C, 0,
-                       nullptr, c->vectC.p);
+        k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, 0, c->m, nullptr, c->comm.p, N, C,
+                       directed, nullptr, c->vectC.p);
         G.N = N; G.d = d; G.C = C;
         G.emb = c->Xr.p; G.dist = zeros.p; G.vw = c->vw.p; G.comm = c->comm.p; G.vectC = c->vectC.p;
+        if (directed) {
+            c->s_degin.ensure(N);
+            c->s_degout.ensure(N);
+            star.ensure(N);
+            HIP_CHECK(hipMemsetAsync(c->s_degin.p, 0, sizeof(double) * N, st));
+            HIP_CHECK(hipMemsetAsync(c->s_degout.p, 0, sizeof(double) * N, st));
+            HIP_CHECK(hipMemsetAsync(star.p, 0, sizeof(i32) * N, st));
+            k_edge_degrees(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, c->m, c->s_degout.p, c->s_degin.p,
+                           star.p);
+            if (star_exit(N)) return CGE_OK;
+            G.deg_in = c->s_degin.p;
+            G.deg_out = c->s_degout.p;
+        }
     }
     t0 = now_ms();
     SampleSet smp;
-    make_samples(c, a->seed, a->auc_samples, directed, false, smp);
+    make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
     c->phases.ms["samples"] = now_ms() - t0;
     t0 = now_ms();
     host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.data(), c->m, directed, a->split, smp,

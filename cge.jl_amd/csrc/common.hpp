@@ -335,6 +335,7 @@ void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w,
                     const i32 *comm, i64 N, i64 C, int directed, double *wedges, double *vectC);
 void k_edge_degrees(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 m, double *deg_out,
                     double *deg_in, i32 *star);
+void k_wedge_degrees(cge_ctx *c, const double *wedges, i64 N, double *deg_out, double *deg_in, i32 *star);
 void k_compact_count(cge_ctx *c, const double *wedges, i64 N, int directed, i64 *count);
 // distances
 void k_dist_matrix(cge_ctx *c, const double *emb, const double *diag, i64 N, i64 d, double *D);

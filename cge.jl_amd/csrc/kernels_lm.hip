@@ -1069,6 +1069,44 @@ void k_edge_degrees(cge_ctx *c, const i32 *src, const i32 *dst, const double *w,
                        deg_in, star);
 }
 
+// degrees of the (directed) landmark graph from the landmark-pair matrix: out-degree = row sums, in-degree =
+// column sums, star[v] = number of landmark-edge rows (w > 0) in which v appears (src/divergence.jl:311-319).
+__global__ __launch_bounds__(256) void wedge_degrees_kernel(const double *__restrict__ wedges, i64 N,
+                                                            double *__restrict__ deg_out, double *__restrict__ deg_in,
+                                                            i32 *__restrict__ star) {
+    __shared__ double sh[256];
+    __shared__ int shc[256];
+    const i64 a = blockIdx.x;
+    double ro = 0.0, ci = 0.0;
+    int cnt = 0;
+    for (i64 b = threadIdx.x; b < N; b += 256) {
+        const double wr = wedges[a * N + b], wc = wedges[b * N + a];
+        ro += wr;
+        ci += wc;
+        cnt += (wr > 0) + (wc > 0);
+    }
+    sh[threadIdx.x] = ro;
+    shc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sh[threadIdx.x] += sh[threadIdx.x + s]; shc[threadIdx.x] += shc[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    const double row_sum = sh[0];
+    const int count = shc[0];
+    __syncthreads();
+    sh[threadIdx.x] = ci;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { deg_out[a] = row_sum; deg_in[a] = sh[0]; star[a] = count; }
+}
+void k_wedge_degrees(cge_ctx *c, const double *wedges, i64 N, double *deg_out, double *deg_in, i32 *star) {
+    hipLaunchKernelGGL(wedge_degrees_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, wedges, N, deg_out, deg_in, star);
+}
+
 __global__ void compact_count_kernel(const double *__restrict__ wedges, i64 N, int directed,
                                      unsigned long long *__restrict__ count) {
     const i64 total = N * N, stride = (i64)gridDim.x * blockDim.x;

@@ -265,6 +265,38 @@ def test_wgcl_directed(ctx, orc, test115):
     assert list(out) == [-1.0, 0.0, 0.0, 0.0, 0.0, 0.0]
 
 
+def test_score_directed_device_resident(ctx, orc, test115):
+    """cge_score with -d (config 4 flow): landmark mode and exact mode give exactly what landmarks() +
+    wGCL_directed() through host arrays give (and those are checked against the oracle above)."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api
+
+    a = test115
+    n = len(a["vweights"])
+    for land in (30, -1):
+        ctx.set_inputs(a["edges"], a["eweights"], a["vweights"], a["comm"], a["embedding"])
+        res = ctx.score(a["clusters"] if land != -1 else [], land, 2, "rss", directed=True, split=True, seed=5,
+                        auc_samples=3000)
+        tr = ctx.last_trace
+        if land != -1:
+            dii, lemb, lcomm, ledges, lw, lweight, v2l = ctx.landmarks_fetch()
+            smp = api.draw_samples(ctx, 5, 3000, directed=True)
+            exp, etr = orc.wGCL_directed(ledges, lw, lcomm, lemb, dii, lweight, a["vweights"], v2l, a["edges"],
+                                         a["eweights"], a["embedding"], True, smp, trace=True)
+        else:
+            empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+            p1, ni, nj = api.draw_samples(ctx, 5, 3000, directed=True)
+            p2 = ctx.draw_samples(5 + 0x7777, 3000, True, 1000)[0].reshape(1, -1)  # the second draw (:510)
+            exp, etr = orc.wGCL_directed(a["edges"], a["eweights"], a["comm"], a["embedding"], np.zeros(n),
+                                         a["vweights"], *empty, True, (p1, ni, nj, p2), trace=True)
+        _cmp_result(res, exp, tr, etr)
+    # directed star graph through the device-resident path: 6-element early return
+    k = 12
+    star = np.asfortranarray(np.stack([np.ones(k - 1, np.int64), np.arange(2, k + 1)], axis=1))
+    ctx.set_inputs(star, np.ones(k - 1), np.ones(k), np.ones((k, 1), np.int64), np.random.default_rng(0).random((k, 4)))
+    assert list(ctx.score([], -1, directed=True, seed=1, auc_samples=10)) == [-1.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+
+
 def test_wgcl_asserts_mirror_reference(ctx, test115):
     import cge.jl_amd as cg
     from cge.jl_amd import api
