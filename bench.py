@@ -26,6 +26,11 @@ WORKLOADS = {
     "headline": dict(n=1_000_000, m=10_000_000, C=500, d=128, land=4000, forced=4, method="rss", samples=10000),
     # configs[1]: ABCD 100k nodes / 1M edges, d=64, -l 400 -m rss2
     "cfg2": dict(n=100_000, m=1_000_000, C=50, d=64, land=400, forced=4, method="rss2", samples=10000),
+    # configs[2]: ABCD 1M nodes / 20M edges, d=128, -l 4000 -m diameter (its 8-GPU sharding is the driver's N=8 run)
+    "cfg3": dict(n=1_000_000, m=20_000_000, C=500, d=128, land=4000, forced=4, method="diameter", samples=10000),
+    # configs[3]: directed 1M-node graph, d=128, --samples-local 1000000, automatic landmarks max(4 sqrt(n), 4C)
+    "cfg4": dict(n=1_000_000, m=10_000_000, C=500, d=128, land=4000, forced=4, method="rss", samples=1_000_000,
+                 directed=True),
     "small": dict(n=50_000, m=500_000, C=25, d=128, land=200, forced=4, method="rss", samples=10000),
 }
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; MI355X_MICROARCH.md lists no f64 row)
@@ -131,7 +136,8 @@ def main():
             dist.barrier()
     wl = WORKLOADS[args.workload]
     t0 = time.perf_counter()
-    g = synth.abcd_like(wl["n"], int(wl["m"] * 1.05), wl["C"], wl["d"], seed=args.seed)
+    directed = bool(wl.get("directed", False))
+    g = synth.abcd_like(wl["n"], int(wl["m"] * 1.05), wl["C"], wl["d"], seed=args.seed, directed=directed)
     if rank == 0:
         log(f"[bench] synthetic ABCD-like graph: n={g['n']} m={g['m']} d={g['d']} C={g['C']} ({time.perf_counter()-t0:.1f} s)")
     ctx = api.Context(local_rank)
@@ -146,7 +152,7 @@ def main():
         coll = TorchCollectives(ctx, wl["land"] * wl["land"] * 2 + 1024, dev)
 
     def step():
-        return ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], seed=args.seed,
+        return ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=args.seed,
                          auc_samples=wl["samples"])
 
     def fence():
@@ -243,7 +249,7 @@ def main():
     if coll is not None:
         out["collectives"] = {"allreduce_calls_per_step": coll.n_calls / (args.steps + args.warmup),
                               "bytes_per_step": coll.bytes / (args.steps + args.warmup)}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not directed:
         try:
             out["cpu_baseline"] = cpu_baseline(g, wl)
         except Exception as e:  # the baseline is reported, never required for the GPU number

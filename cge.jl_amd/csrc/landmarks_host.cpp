@@ -716,10 +716,14 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const dou
         const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
         const double *zt = &z[o];
         i32 *p = &perm[o];
-        for (i64 j = 0; j < k; j++) p[j] = (i32)j;
-        std::stable_sort(p, p + k, [&](i32 a, i32 b) { return zt[a] < zt[b]; });
         bool nan = false;
         for (i64 j = 0; j < k; j++) nan = nan || (zt[j] != zt[j]);
+        { // ascending z, ties by original index (= a stable sort); contiguous (key, index) pairs sort ~3x faster
+            std::vector<std::pair<double, i32>> kv(k);
+            for (i64 j = 0; j < k; j++) kv[j] = {zt[j], (i32)j};
+            if (!nan) std::sort(kv.begin(), kv.end());
+            for (i64 j = 0; j < k; j++) p[j] = kv[j].second;
+        }
         if (nan) status[t] = 1;
         else if (zt[p[0]] == zt[p[k - 1]]) status[t] = 2;      // argmin == argmax (:165-167)
         else if (zt[p[k - 1]] == zt[p[k - 2]]) status[t] = 1;  // arg-max is not the last rank
