@@ -519,11 +519,12 @@ static double resident_diameter(cge_ctx *c, int part, int nparts, i64 *ai, i64 *
 }
 
 // the same with landmark-pair pruning in front (diameter_host.cpp); `mu` = N reference points (device, row-major)
-static double resident_diameter_lm(cge_ctx *c, const double *mu, i64 N, int part, int nparts) {
+static double resident_diameter_lm(cge_ctx *c, const double *mu, const double *lw, const std::vector<i32> &lcomm, i64 C,
+                                   i64 N, int part, int nparts) {
     if (c->opt_diameter != 1 && (i64)c->h_mem_off.size() == N + 1) {
         double d2;
         i64 bi, bj;
-        if (host_diameter_pruned(c, mu, N, c->h_mem_off, c->h_mem, part, nparts, &d2, &bi, &bj)) {
+        if (host_diameter_pruned(c, mu, lw, lcomm, C, N, c->h_mem_off, c->h_mem, part, nparts, &d2, &bi, &bj)) {
             c->stat_diameter_path = 2;
             return exact_pair_distance(c, bi, bj);
         }
@@ -661,7 +662,10 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
         }
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p;
         ov.lweight = c->s_vw.p; ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
-        double hi = resident_diameter_lm(c, c->s_emb.p, N, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1);
+        std::vector<i32> lcomm0(N);
+        for (i64 i = 0; i < N; i++) lcomm0[i] = (i32)(a->comm[i] - 1);
+        double hi = resident_diameter_lm(c, c->s_emb.p, c->s_vw.p, lcomm0, C, N, c->has_coll ? c->coll.rank : 0,
+                                         c->has_coll ? c->coll.world : 1);
         hi = allreduce_scalar_max(c, hi);
         ov.hi = hi;
         c->stat_last_hi = hi;
@@ -732,7 +736,10 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         t0 = now_ms();
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
         ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
-        double hi = resident_diameter_lm(c, c->lemb.p, N, c->has_coll ? c->coll.rank : 0, c->has_coll ? c->coll.world : 1);
+        std::vector<i32> lcomm0(N); // community of a landmark = community of any member (landmarks never span two)
+        for (i64 l = 0; l < N; l++) lcomm0[l] = c->h_comm[c->h_mem[c->h_mem_off[l]]];
+        double hi = resident_diameter_lm(c, c->lemb.p, c->lweight.p, lcomm0, C, N, c->has_coll ? c->coll.rank : 0,
+                                         c->has_coll ? c->coll.world : 1);
         hi = allreduce_scalar_max(c, hi);
         ov.hi = hi;
         c->stat_last_hi = hi;

@@ -237,6 +237,8 @@ struct cge_ctx {
     // diameter scratch
     DevBuf<double> mp_recs;  // MaxRec records (3 doubles each)
     DevBuf<i64> mp_count;
+    DevBuf<double> mp_rd2, mp_refmu; // reference-point distances / centroids of the pruned diameter
+    DevBuf<i32> mp_lref, mp_refoff, mp_refmem;
     DevBuf<double> gmean;    // global feature mean (the centre used by Xc)
     DevBuf<double> Xs, rns, Ms, mnorm, Pm; // landmark-sorted centred copy, centroids, P matrix
     DevBuf<i32> pos2node, sub_land;
@@ -346,10 +348,13 @@ void k_max_pair(cge_ctx *c, const double *Xc, const double *rnorm, i64 n, i64 ld
 void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *pj, i64 S, double inv_scale_den,
                  double *out);
 void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, const double *Ms, const double *mnorm,
-             i64 ldm, i64 N, i64 dpad, const i32 *sub_land, double *P);
+             i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P);
 void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,
                  i64 ntiles, double *best_val, i64 *best_i, i64 *best_j);
-i64 k_bound_select(cge_ctx *c, const double *P, const double *mu, i64 N, i64 d, double L, void *list, i64 cap);
+i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *mu_ref, i64 N, i64 nref, i64 d, double L,
+                   void *list, i64 cap);
+void k_ref_centroids(cge_ctx *c, const double *mu, const double *lw, const i32 *ref_off, const i32 *ref_mem, i64 nref,
+                     i64 d, double *out);
 void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i);
 void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean);
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
@@ -382,8 +387,9 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                    std::vector<i64> &group_ids /*0-based*/, std::vector<std::vector<i64>> *members_out);
 void host_eig_top(const double *A, i64 d, double *v); // largest-eigenvalue eigenvector, sign: max |.| component > 0
 // diameter_host.cpp
-bool host_diameter_pruned(cge_ctx *c, const double *mu, i64 N, const std::vector<i32> &mem_off,
-                          const std::vector<i32> &mem, int part, int nparts, double *best_d2, i64 *bi, i64 *bj);
+bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const std::vector<i32> &lcomm, i64 C, i64 N,
+                          const std::vector<i32> &mem_off, const std::vector<i32> &mem, int part, int nparts,
+                          double *best_d2, i64 *bi, i64 *bj);
 // wgcl_host.cpp
 struct SampleSet {
     i64 S = 0, n_sets = 0;

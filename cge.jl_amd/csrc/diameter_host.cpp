@@ -24,8 +24,12 @@ struct BoundRec {
 } // namespace
 
 // returns false when the caller should fall back to brute force
-bool host_diameter_pruned(cge_ctx *c, const double *mu, i64 N, const std::vector<i32> &mem_off,
-                          const std::vector<i32> &mem, int part, int nparts, double *best_d2, i64 *bi, i64 *bj) {
+// `mu` = N landmark centroids (device, row-major), `lw` their weights (device) and `lcomm` their communities
+// (host, 0-based, C communities).  Reference points: the community centroids when there are at least 32
+// communities (the MFMA pass is then n*C*d instead of n*N*d), else the landmark centroids themselves.
+bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const std::vector<i32> &lcomm, i64 C, i64 N,
+                          const std::vector<i32> &mem_off, const std::vector<i32> &mem, int part, int nparts,
+                          double *best_d2, i64 *bi, i64 *bj) {
     const i64 n = c->n, d = c->d, dpad = c->dpad;
     hipStream_t st = c->stream;
     c->stat_cand_pairs = c->stat_cand_tiles = 0;
@@ -34,7 +38,6 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, i64 N, const std::vector
     for (i64 a = 0; a < N; a++) soff[a + 1] = soff[a] + ((mem_off[a + 1] - mem_off[a] + 15) / 16) * 16;
     const i64 npos = soff[N];
     const i64 lds_rows = (npos + 127) / 128 * 128 + 128;
-    const i64 ldm = (N + 127) / 128 * 128;
     std::vector<i32> pos2node(npos), sub_land(lds_rows / 16, -1);
     for (i64 a = 0; a < N; a++) {
         const i64 cnt = mem_off[a + 1] - mem_off[a];
@@ -48,14 +51,42 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, i64 N, const std::vector
     c->sub_land.ensure(lds_rows / 16);
     HIP_CHECK(hipMemcpyAsync(c->pos2node.p, pos2node.data(), sizeof(i32) * npos, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->sub_land.p, sub_land.data(), sizeof(i32) * (lds_rows / 16), hipMemcpyHostToDevice, st));
+    // ---- reference points ---------------------------------------------------------------------------------
+    const bool by_comm = C >= 32 && (i64)lcomm.size() == N && lw != nullptr;
+    const i64 nref = by_comm ? C : N;
+    std::vector<i32> lref(N);
+    const double *mu_ref = mu;
+    if (by_comm) {
+        std::vector<i32> roff(C + 1, 0), rmem(N);
+        for (i64 a = 0; a < N; a++) {
+            if (lcomm[a] < 0 || lcomm[a] >= C) CGE_THROW(CGE_E_ARG, "diameter: landmark community out of range");
+            lref[a] = lcomm[a];
+            roff[lcomm[a] + 1]++;
+        }
+        for (i64 q = 0; q < C; q++) roff[q + 1] += roff[q];
+        std::vector<i32> cur(roff.begin(), roff.end() - 1);
+        for (i64 a = 0; a < N; a++) rmem[cur[lcomm[a]]++] = (i32)a;
+        c->mp_refoff.ensure(C + 1);
+        c->mp_refmem.ensure(N);
+        c->mp_refmu.ensure((size_t)C * d);
+        HIP_CHECK(hipMemcpyAsync(c->mp_refoff.p, roff.data(), sizeof(i32) * (C + 1), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(c->mp_refmem.p, rmem.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+        k_ref_centroids(c, mu, lw, c->mp_refoff.p, c->mp_refmem.p, C, d, c->mp_refmu.p);
+        HIP_CHECK(hipStreamSynchronize(st)); // roff / rmem go out of scope
+        mu_ref = c->mp_refmu.p;
+    } else
+        for (i64 a = 0; a < N; a++) lref[a] = (i32)a;
+    c->mp_lref.ensure(N);
+    HIP_CHECK(hipMemcpyAsync(c->mp_lref.p, lref.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+    const i64 ldm = (nref + 127) / 128 * 128;
     c->Xs.ensure((size_t)lds_rows * dpad);
     c->rns.ensure(lds_rows);
     c->Ms.ensure((size_t)ldm * dpad);
     c->mnorm.ensure(ldm);
-    c->Pm.ensure((size_t)N * N);
+    c->Pm.ensure((size_t)N * nref);
     k_gather_centre_fm(c, c->Xr.p, c->pos2node.p, c->gmean.p, c->Xs.p, c->rns.p, npos, d, lds_rows, dpad);
-    k_gather_centre_fm(c, mu, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, N, d, ldm, dpad);
-    k_pcent(c, c->Xs.p, c->rns.p, lds_rows, c->Ms.p, c->mnorm.p, ldm, N, dpad, c->sub_land.p, c->Pm.p);
+    k_gather_centre_fm(c, mu_ref, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, nref, d, ldm, dpad);
+    k_pcent(c, c->Xs.p, c->rns.p, lds_rows, c->Ms.p, c->mnorm.p, ldm, N, nref, dpad, c->sub_land.p, c->Pm.p);
     // ---- lower bound from farthest-point sweeps ----------------------------------------------------------
     double L = 0.0;
     i64 p0 = 0, far_i = 0, far_j = 0;
@@ -69,7 +100,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, i64 N, const std::vector
     // ---- candidate landmark pairs ---------------------------------------------------------------------------
     const i64 cap = std::min<i64>(N * (N + 1) / 2, (i64)4 << 20);
     c->bound_list.ensure((size_t)2 * cap);
-    const i64 cnt = k_bound_select(c, c->Pm.p, mu, N, d, L * (1.0 - 1e-9), c->bound_list.p, cap);
+    const i64 cnt = k_bound_select(c, c->Pm.p, c->mp_lref.p, mu_ref, N, nref, d, L * (1.0 - 1e-9), c->bound_list.p, cap);
     c->stat_cand_pairs = cnt;
     if (cnt > cap) return false;
     std::vector<BoundRec> cand(cnt);

@@ -336,9 +336,10 @@ void k_max_pair(cge_ctx *c, const double *Xc, const double *rnorm, i64 n, i64 ld
     best_of_recs(c, recs, MP_NWG, best_val, best_i, best_j);
 }
 
+// P is (number of landmarks) x nref, row stride nref: P[a][r] = max over the rows of landmark a of ||x - ref_r||^2
 void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, const double *Ms, const double *mnorm,
-             i64 ldm, i64 N, i64 dpad, const i32 *sub_land, double *P) {
-    HIP_CHECK(hipMemsetAsync(P, 0, sizeof(double) * N * N, c->stream));
+             i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P) {
+    HIP_CHECK(hipMemsetAsync(P, 0, sizeof(double) * n_land * N, c->stream));
     ScopedKernelTimer t(c, "pcent");
     const i64 ntiles = (lds_rows / MP_BM) * (ldm / MP_BN);
     hipLaunchKernelGGL(pcent_kernel, dim3((unsigned)std::min<i64>(ntiles, 2048)), dim3(256), MP_LDS_BYTES, c->stream, Xs,
@@ -368,49 +369,53 @@ struct BoundRec {
     double B;
     i32 a, b;
 };
-// 32x32 tiles (A <= B) so that both P[a][b] and P[b][a] are read coalesced (the mirror tile goes through LDS).
-__global__ __launch_bounds__(256) void bound_select_kernel(const double *__restrict__ P,
-                                                           const double *__restrict__ mu /* N x d row-major */, i64 N,
-                                                           i64 d, double L, BoundRec *__restrict__ list, i64 cap,
+// Bounds with reference points: landmark a uses reference lref[a] (its community centroid, or itself).
+//   B_ab = Q[a][ref(b)] + Q[b][ref(a)] - ||ref(a) - ref(b)||^2 + 2 sqrt(Q[a][ref(a)] Q[b][ref(b)])
+// rd2 = nref x nref squared distances of the reference points.
+__global__ __launch_bounds__(256) void bound_select_kernel(const double *__restrict__ Q, const i32 *__restrict__ lref,
+                                                           const double *__restrict__ rd2, i64 N, i64 nref, double L,
+                                                           BoundRec *__restrict__ list, i64 cap,
                                                            unsigned long long *__restrict__ count) {
-    __shared__ double mirror[32][33];
-    const i64 nb = (N + 31) / 32;
-    i64 t = blockIdx.x, A = 0, rowlen = nb;
-    while (t >= rowlen) { t -= rowlen; rowlen--; A++; }
-    const i64 Bt = A + t;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
-    for (int r = ty; r < 32; r += 8) { // mirror[r][tx] = P[b = Bt*32 + r][a = A*32 + tx]
-        const i64 b = Bt * 32 + r, a = A * 32 + tx;
-        mirror[r][tx] = (a < N && b < N) ? P[b * N + a] : 0.0;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const i64 a = A * 32 + r, b = Bt * 32 + tx;
-        if (a >= N || b >= N || b < a) continue;
-        const double paa = P[a * N + a], pbb = P[b * N + b];
-        // cheap pre-test without D2 (D2 >= 0): most pairs stop here, before touching the centroids
-        const double pre = P[a * N + b] + mirror[tx][r] + 2.0 * sqrt(paa * pbb);
+    const i64 total = N * N, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const i64 a = e / N, b = e - a * N;
+        if (b < a) continue;
+        const i64 ra = lref[a], rb = lref[b];
+        const double qaa = Q[a * nref + ra], qbb = Q[b * nref + rb];
+        const double pre = Q[a * nref + rb] + Q[b * nref + ra] + 2.0 * sqrt(qaa * qbb);
         if (pre * (1.0 + 1e-9) + 1e-9 < L) continue;
-        double d2 = 0.0;
-        const double *ma = mu + a * d, *mb = mu + b * d;
-        for (i64 k = 0; k < d; k++) {
-            const double df = ma[k] - mb[k];
-            d2 += df * df;
-        }
-        const double Bv = pre - d2 * (1.0 - 1e-9);
+        const double Bv = pre - rd2[ra * nref + rb] * (1.0 - 1e-9);
         if (Bv * (1.0 + 1e-9) + 1e-9 >= L) {
             const unsigned long long idx = atomicAdd(count, 1ULL);
             if ((i64)idx < cap) list[idx] = BoundRec{Bv, (i32)a, (i32)b};
         }
     }
 }
-i64 k_bound_select(cge_ctx *c, const double *P, const double *mu, i64 N, i64 d, double L, void *list, i64 cap) {
+// squared distances of the nref reference points (row-major nref x d)
+__global__ void ref_dist2_kernel(const double *__restrict__ mu, i64 nref, i64 d, double *__restrict__ rd2) {
+    const i64 total = nref * nref, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const i64 a = e / nref, b = e - a * nref;
+        const double *ma = mu + a * d, *mb = mu + b * d;
+        double s = 0.0;
+        for (i64 k = 0; k < d; k++) {
+            const double df = ma[k] - mb[k];
+            s += df * df;
+        }
+        rd2[e] = s;
+    }
+}
+i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *mu_ref, i64 N, i64 nref, i64 d, double L,
+                   void *list, i64 cap) {
     c->mp_count.ensure(1);
+    c->mp_rd2.ensure((size_t)nref * nref);
     HIP_CHECK(hipMemsetAsync(c->mp_count.p, 0, sizeof(i64), c->stream));
-    const i64 nb32 = (N + 31) / 32;
     ScopedKernelTimer tm(c, "bound_select");
-    hipLaunchKernelGGL(bound_select_kernel, dim3((unsigned)(nb32 * (nb32 + 1) / 2)), dim3(256), 0, c->stream, P, mu, N, d, L,
-                       reinterpret_cast<BoundRec *>(list), cap, reinterpret_cast<unsigned long long *>(c->mp_count.p));
+    hipLaunchKernelGGL(ref_dist2_kernel, dim3(grid_for(nref * nref, 256)), dim3(256), 0, c->stream, mu_ref, nref, d,
+                       c->mp_rd2.p);
+    hipLaunchKernelGGL(bound_select_kernel, dim3(grid_for(N * N, 256)), dim3(256), 0, c->stream, Q, lref, c->mp_rd2.p, N,
+                       nref, L, reinterpret_cast<BoundRec *>(list), cap,
+                       reinterpret_cast<unsigned long long *>(c->mp_count.p));
     i64 cnt = 0;
     HIP_CHECK(hipMemcpyAsync(&cnt, c->mp_count.p, sizeof(i64), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));

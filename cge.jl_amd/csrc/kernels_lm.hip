@@ -1107,6 +1107,25 @@ void k_wedge_degrees(cge_ctx *c, const double *wedges, i64 N, double *deg_out, d
     hipLaunchKernelGGL(wedge_degrees_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, wedges, N, deg_out, deg_in, star);
 }
 
+// reference point r = weighted mean (weights lw) of the landmark centroids listed in ref_mem[ref_off[r]..)
+__global__ void ref_centroids_kernel(const double *__restrict__ mu, const double *__restrict__ lw,
+                                     const i32 *__restrict__ ref_off, const i32 *__restrict__ ref_mem, i64 d,
+                                     double *__restrict__ out) {
+    const i64 r = blockIdx.x;
+    const i32 b = ref_off[r], e = ref_off[r + 1];
+    double wsum = 0.0;
+    for (i32 t = b; t < e; t++) wsum += lw[ref_mem[t]];
+    for (i64 k = threadIdx.x; k < d; k += blockDim.x) {
+        double s = 0.0;
+        for (i32 t = b; t < e; t++) s += lw[ref_mem[t]] * mu[(i64)ref_mem[t] * d + k];
+        out[r * d + k] = wsum > 0 ? s / wsum : 0.0;
+    }
+}
+void k_ref_centroids(cge_ctx *c, const double *mu, const double *lw, const i32 *ref_off, const i32 *ref_mem, i64 nref,
+                     i64 d, double *out) {
+    hipLaunchKernelGGL(ref_centroids_kernel, dim3((unsigned)nref), dim3(128), 0, c->stream, mu, lw, ref_off, ref_mem, d, out);
+}
+
 __global__ void compact_count_kernel(const double *__restrict__ wedges, i64 N, int directed,
                                      unsigned long long *__restrict__ count) {
     const i64 total = N * N, stride = (i64)gridDim.x * blockDim.x;
