@@ -41,7 +41,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(g, wl, budget_vertices=25000):
+def cpu_baseline(g, wl, budget_vertices=60000):
     """The oracle (single-thread C restatement of the reference) on a bounded sample of the SAME graph:
     the sub-graph induced by the first communities (~budget_vertices vertices), landmarks scaled by the
     same ratio; call shape = landmarks() then wGCL(..., v_to_l = Int[]) on the landmark graph
@@ -224,13 +224,26 @@ def main():
                         "algorithmic_work_per_launch": w, "work_unit": "flop" if unit == "TFLOP/s" else "B",
                         "note": note})
         kernels[name] = ent
+    # HBM traffic per launch from the committed PMC passes of this same command (profiles/run_profiles.sh)
+    pmc, pmc_file = {}, os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    kernel_of = {"fit_symv": "fit_symv_kernel", "pcent": "pcent_kernel", "pair_list": "pair_list_kernel",
+                 "edge_scatter": "edge_scatter_kernel", "max_pair_dist": "max_pair_kernel"}
+    if os.path.exists(pmc_file) and args.workload == "headline" and world == 1:
+        try:
+            pmc = json.load(open(pmc_file))["kernels"]
+        except Exception:
+            pmc = {}
+    for name, kname in kernel_of.items():
+        if name in kernels and kname in pmc:
+            kernels[name]["traffic"] = pmc[kname]["hbm_bytes_per_launch"]
     ranked = sorted((k for k in kernels if "frac" in kernels[k]), key=lambda k: -kernels[k]["total_ms_per_step"])
     dom = ranked[0] if ranked else None
     roofline = None
     if dom:
         e = kernels[dom]
         roofline = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
-                    "frac": e["frac"], "traffic": None, "avg_launch_ms": e["avg_launch_ms"], "launches": e["launches"],
+                    "frac": e["frac"], "traffic": e.get("traffic"), "avg_launch_ms": e["avg_launch_ms"],
+                    "launches": e["launches"],
                     "algorithmic_work_per_launch": e["algorithmic_work_per_launch"], "note": e["note"]}
     out = {
         "metric": "edge_alpha_evals_per_sec", "value": value, "unit": "edge-alpha evals/s", "n_gpus": world,

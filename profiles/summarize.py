@@ -31,6 +31,7 @@ if ks:
     for r in rows[:25]:
         print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
               f"{float(r['AverageNs'])/1e6:.4f} | {float(r['Percentage']):.2f} |")
+traffic = {}
 for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     cc = find(sub, "*counter_collection.csv")
     if not cc:
@@ -45,7 +46,18 @@ for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     print(f"\n## --pmc {ctr} (own pass)\n")
     print(f"| kernel | launches | {ctr} sum (KiB) | per launch (MB) | gfx950-corrected per launch (MB) |")
     print("|---|---|---|---|---|")
+    for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        per = v * 1024 / n / 1e6
+        corr = per * 2 if ctr == "FETCH_SIZE" else per
+        traffic.setdefault(k, {"launches": n})[ctr + "_bytes_per_launch"] = corr * 1e6
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
         per = v * 1024 / n / 1e6
         corr = per * 2 if ctr == "FETCH_SIZE" else per
         print(f"| {k} | {n} | {v:.0f} | {per:.2f} | {corr:.2f} |")
+import json
+for k, v in traffic.items():
+    v["hbm_bytes_per_launch"] = v.get("FETCH_SIZE_bytes_per_launch", 0.0) + v.get("WRITE_SIZE_bytes_per_launch", 0.0)
+with open(os.path.join(out, f"pmc_traffic_{tag}.json"), "w") as f:
+    json.dump({"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `bench.py --steps 1 "
+                              "--warmup 1`; FETCH_SIZE x2 (gfx950, wide coalesced reads), KiB -> bytes", "kernels": traffic},
+              f, indent=1)
