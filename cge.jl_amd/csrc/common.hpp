@@ -258,7 +258,9 @@ struct cge_ctx {
     PinBuf<double> pin_sums, pin_z, pin_params, pin_zs;
     PinBuf<i32> pin_rows[2], pin_row_task[2], pin_srows; // [slot]: 0 = main batch, 1 = fallback sub-batch
     // sorted-prefix rss path
-    DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro;
+    DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro, sp_perm, sp_status, sort_idx;
+    DevBuf<unsigned char> sort_tmp;
+    PinBuf<i32> pin_perm;
     DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;
 
     // ---- profiling -------------------------------------------------------------------------
@@ -324,6 +326,8 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
                   i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals);
 #define CGE_RR_MAXROUNDS 63
 #define CGE_CHUNK_ROWS 1024 // rows per chunk of a batch (build_batch); the rounds kernel uses r >> 10
+void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 *row_task, const i32 *task_row_off,
+                        i64 R, i64 T, double *zs, i32 *perm, i32 *srows, i32 *status);
 void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, const double *params,
                 unsigned char *state, unsigned char *side);
 bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec);

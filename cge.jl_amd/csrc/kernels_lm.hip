@@ -699,7 +699,7 @@ __device__ __forceinline__ double eig_block_sum(double v, double *red) {
     return ((red[0] + red[1]) + red[2]) + red[3];
 }
 __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict__ cov, int d,
-                                                        double *__restrict__ vec) {
+                                                        double *__restrict__ vec, int diag_stage) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *A = sh;            // d*d, symmetric, row-major
     double *V = A + d * d;     // d  Householder vector, later the eigenvector y
@@ -742,7 +742,17 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
             double s = 0.0;
             if (i < r) {
                 const int jm = (r + 1) >> 1, j0 = half ? jm : 0, j1 = half ? r : jm;
-                for (int j = j0; j < j1; j++) s += A[(o + j) * d + o + i] * V[j];
+                const double *col = A + (i64)o * d + o + i; // element (o+j, o+i) = col[j*d]
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int j = j0;
+                for (; j + 7 < j1; j += 8) { // 8 independent LDS reads in flight
+                    const double a0 = col[(j + 0) * d], a1 = col[(j + 1) * d], a2 = col[(j + 2) * d], a3 = col[(j + 3) * d];
+                    const double a4 = col[(j + 4) * d], a5 = col[(j + 5) * d], a6 = col[(j + 6) * d], a7 = col[(j + 7) * d];
+                    s0 += a0 * V[j + 0]; s1 += a1 * V[j + 1]; s2 += a2 * V[j + 2]; s3 += a3 * V[j + 3];
+                    s0 += a4 * V[j + 4]; s1 += a5 * V[j + 5]; s2 += a6 * V[j + 6]; s3 += a7 * V[j + 7];
+                }
+                for (; j < j1; j++) s0 += col[j * d] * V[j];
+                s = (s0 + s1) + (s2 + s3);
                 Pp[half * d + i] = s; // i < r <= d: stays inside the 2*d staging area
             }
         }
@@ -756,7 +766,18 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
             const int i = tid & 127;
             if (i < r) {
                 const double vi = V[i], wi = W[i];
-                for (int j = tid >> 7; j < r; j += 2) A[(o + j) * d + o + i] -= vi * W[j] + wi * V[j];
+                double *col = A + (i64)o * d + o + i; // element (o+j, o+i) = col[j*d]
+                int j = tid >> 7;
+                for (; j + 14 < r; j += 16) { // rows j, j+2, ..., j+14: batched loads, then stores
+                    double a[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) a[q] = col[(j + 2 * q) * d];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) a[q] -= vi * W[j + 2 * q] + wi * V[j + 2 * q];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) col[(j + 2 * q) * d] = a[q];
+                }
+                for (; j < r; j += 2) col[j * d] -= vi * W[j] + wi * V[j];
             }
         }
         if (tid >= 1 && tid < r) A[k * d + o + tid] = V[tid]; // keep the reflector in row k (v[0] = 1 implicit)
@@ -765,6 +786,7 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
     if (tid < d) diag[tid] = A[tid * d + tid];
     if (tid == 0) off[d - 2] = A[(d - 2) * d + (d - 1)];
     __syncthreads();
+    if (diag_stage == 1) { if (tid < d) out[tid] = diag[tid]; return; } // timing diagnostic only
     // ---- Gershgorin bounds ---------------------------------------------------------------------------
     double glo = 1e300, ghi = -1e300, gn = 0.0;
     if (tid < d) {
@@ -817,6 +839,7 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
         if (tid == 0) red[4] = 0.5 * (lo + hi);
     }
     __syncthreads();
+    if (diag_stage == 2) { if (tid < d) out[tid] = red[4]; return; } // timing diagnostic only
     // ---- inverse iteration (one lane; O(d) per solve) ---------------------------------------------------------
     if (tid == 0) {
         const double lam = red[4];
@@ -879,6 +902,7 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
         }
     }
     __syncthreads();
+    if (diag_stage == 3) { if (tid < d) out[tid] = V[tid]; return; } // timing diagnostic only
     // ---- back-transformation x = H_0 H_1 ... H_{d-3} y ------------------------------------------------------------
     for (int k = d - 3; k >= 0; k--) {
         const double bk = beta[k];
@@ -911,7 +935,8 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
     if (d > 128) return false; // the matrix no longer fits LDS: the caller uses the host solver
     const size_t lds = (size_t)(d * d + 12 * d + 40) * sizeof(double);
     ScopedKernelTimer t(c, "group_eig");
-    hipLaunchKernelGGL(group_eig_kernel, dim3((unsigned)n_tasks), dim3(256), lds, c->stream, cov, (int)d, vec);
+    static const int diag_stage = getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0; // 0 = normal
+    hipLaunchKernelGGL(group_eig_kernel, dim3((unsigned)n_tasks), dim3(256), lds, c->stream, cov, (int)d, vec, diag_stage);
     return true;
 }
 

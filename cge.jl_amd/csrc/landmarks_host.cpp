@@ -705,41 +705,19 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const dou
                      std::vector<i64> &fallback) {
     const i64 T = B.T, R = B.R, d = c->d, W = 2 * d + 1;
     hipStream_t st = c->stream;
-    std::vector<i32> perm(R);
-    c->pin_srows.ensure(R);
-    c->pin_zs.ensure(R);
-    i32 *srows = c->pin_srows.p;
-    double *zs = c->pin_zs.p;
-    std::vector<char> status(T, 0); // 0 sorted path, 1 fallback, 2 homogeneous
-    PhaseAcc *pa = new PhaseAcc(c, "lm_cut_sort");
-    parallel_for(c, T, [&](i64 t) {
-        const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
-        const double *zt = &z[o];
-        i32 *p = &perm[o];
-        bool nan = false;
-        for (i64 j = 0; j < k; j++) nan = nan || (zt[j] != zt[j]);
-        { // ascending z, ties by original index (= a stable sort); contiguous (key, index) pairs sort ~3x faster
-            std::vector<std::pair<double, i32>> kv(k);
-            for (i64 j = 0; j < k; j++) kv[j] = {zt[j], (i32)j};
-            if (!nan) std::sort(kv.begin(), kv.end());
-            for (i64 j = 0; j < k; j++) p[j] = kv[j].second;
-        }
-        if (nan) status[t] = 1;
-        else if (zt[p[0]] == zt[p[k - 1]]) status[t] = 2;      // argmin == argmax (:165-167)
-        else if (zt[p[k - 1]] == zt[p[k - 2]]) status[t] = 1;  // arg-max is not the last rank
-        for (i64 r = 0; r < k; r++) {
-            srows[o + r] = B.rows[o + p[r]];
-            zs[o + r] = zt[p[r]];
-        }
-    });
-    delete pa;
-    pa = new PhaseAcc(c, "lm_cut_dev");
-    c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_tro.ensure(T + 1);
+    (void)z; // the projections are sorted on the device (c->ls_z); the host only needs the permutation
+    PhaseAcc *pa = new PhaseAcc(c, "lm_cut_dev");
+    c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_tro.ensure(T + 1); c->sp_perm.ensure(R); c->sp_status.ensure(T);
     c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W); c->sp_prefix.ensure((size_t)R * W);
     c->sp_meta.ensure(2 * T); c->sp_rounds.ensure((size_t)T * 3 * CGE_RR_MAXROUNDS); c->sp_vals.ensure(2 * T);
-    HIP_CHECK(hipMemcpyAsync(c->sp_srows.p, srows, sizeof(i32) * R, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->sp_zs.p, zs, sizeof(double) * R, hipMemcpyHostToDevice, st));
+    c->pin_perm.ensure(R);
     HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
+    k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
+                       c->sp_srows.p, c->sp_status.p);
+    std::vector<i32> status(T);
+    HIP_CHECK(hipMemcpyAsync(c->pin_perm.p, c->sp_perm.p, sizeof(i32) * R, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(status.data(), c->sp_status.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
+    const i32 *perm = c->pin_perm.p;
     k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
     k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->ls_tco.p, c->sp_prefix.p, c->sp_coff.p,
