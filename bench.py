@@ -202,8 +202,8 @@ def main():
     work = {  # name -> (bound, peak, unit, algorithmic work per launch, note)
         "max_pair_dist": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", 2.0 * d * (n * (n - 1) / 2) / world,
                           "fp64 MFMA, 2d flop per unordered vertex pair, all pairs"),
-        "pcent": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", 2.0 * d * n * N,
-                  "fp64 MFMA, 2d flop per (vertex, landmark centroid) pair"),
+        "pcent": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", 2.0 * d * n * max(1, ctx.get_stat("diameter_refs")),
+                  "fp64 MFMA, 2d flop per (vertex, reference point) pair; reference points = community centroids"),
         "pair_list": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", None,
                       "fp64 MFMA, 2d flop per vertex pair of the candidate 128x128 tiles"),
         "fit_symv": ("hbm", HBM_PEAK_GBS, "GB/s", 8.0 * N * (N + 1) / 2,

@@ -851,6 +851,7 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "diameter_path")) *value = c->stat_diameter_path;
     else if (!strcmp(key, "diameter_candidate_pairs")) *value = c->stat_cand_pairs;
     else if (!strcmp(key, "diameter_candidate_tiles")) *value = c->stat_cand_tiles;
+    else if (!strcmp(key, "diameter_refs")) *value = c->stat_nref;
     else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`
     else return CGE_E_ARG;
     return CGE_OK;

@@ -249,6 +249,7 @@ struct cge_ctx {
     i64 stat_cand_pairs = 0, stat_cand_tiles = 0; // last pruned run
     int stat_diameter_path = 0;            // 1 brute, 2 pruned
     double stat_last_hi = 0.0;
+    i64 stat_nref = 0; // reference points of the last pruned diameter (communities or landmarks)
     // scratch of the batched split engine (landmarks_host.cpp)
     DevBuf<i32> ls_rows, ls_row_task, ls_ct, ls_cb, ls_ce, ls_tco;
     DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z, ls_sums, ls_Y;

@@ -54,6 +54,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     // ---- reference points ---------------------------------------------------------------------------------
     const bool by_comm = C >= 32 && (i64)lcomm.size() == N && lw != nullptr;
     const i64 nref = by_comm ? C : N;
+    c->stat_nref = nref;
     std::vector<i32> lref(N);
     const double *mu_ref = mu;
     if (by_comm) {

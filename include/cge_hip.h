@@ -189,7 +189,7 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
 /* "diameter": 0 = auto (exact landmark-pair pruning, brute-force MFMA kernel when pruning is weak),
  *             1 = always brute force, 2 = always pruned.  All three return the same exact value.   */
 int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
-/* "landmarks" (N of the last run, no side effects), "diameter_path" (1 brute / 2 pruned), "diameter_candidate_pairs", "diameter_candidate_tiles" of the last run;
+/* "landmarks" (N of the last run, no side effects), "diameter_path" (1 brute / 2 pruned), "diameter_candidate_pairs", "diameter_candidate_tiles", "diameter_refs" (reference points) of the last run;
  * "diameter_bits" = the bit pattern of the last `hi` (reinterpret the int64 as a double)           */
 int cge_get_stat(cge_ctx *ctx, const char *key, int64_t *value);
 
