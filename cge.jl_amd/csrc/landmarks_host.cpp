@@ -36,8 +36,9 @@ struct Group {
     double value = 0.0;    // heap key: -total_rss, or eps() for singletons
     bool has_split = false;
     int rc = CGE_OK;
-    std::vector<i64> low, high; // children (vertex ids)
+    std::vector<i64> low, high; // children (vertex ids) until the child groups are materialised
     double vlow = 0.0, vhigh = 0.0;
+    Group *clo = nullptr, *chi = nullptr; // child groups, created as soon as the split is known
 };
 
 // 1-based binary min-heap on value with the reference's exact sift rules (src/landmarks.jl:12-46)
@@ -938,22 +939,87 @@ void throw_rc(int rc) {
     }
 }
 
+// create the child groups of every freshly split task (single-threaded: the pool is not thread-safe)
+void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool) {
+    for (Group *g : tasks) {
+        if (g->rc != CGE_OK || g->clo) continue;
+        pool.emplace_back();
+        g->clo = &pool.back();
+        g->clo->what = std::move(g->low);
+        g->clo->value = g->vlow;
+        pool.emplace_back();
+        g->chi = &pool.back();
+        g->chi->what = std::move(g->high);
+        g->chi->value = g->vhigh;
+    }
+}
+
 // pop the top group of `h`, push its two children (the body of src/landmarks.jl:290-307 / :317-334)
-void replay_one(Heap &h, std::deque<Group> &pool) {
+void replay_one(Heap &h) {
     Group *g = h.pop();
     if (g->rc != CGE_OK) throw_rc(g->rc);
-    pool.emplace_back();
-    Group *lo = &pool.back();
-    lo->what = std::move(g->low);
-    lo->value = g->vlow;
-    h.put(lo);
-    pool.emplace_back();
-    Group *hi = &pool.back();
-    hi->what = std::move(g->high);
-    hi->value = g->vhigh;
-    h.put(hi);
+    h.put(g->clo);
+    h.put(g->chi);
     g->what.clear();
     g->what.shrink_to_fit();
+}
+
+// Bring every heap to its target length.  Each round: replay as far as the cached splits allow; then split,
+// in ONE device batch, the most valuable unsplit nodes KNOWN so far -- heap members and descendants of cached
+// splits alike (speculative tree expansion) -- as many per heap as pops are still missing.  The number of
+// rounds is the depth of the relevant split tree, not the length of the pop sequence; the replay order (and
+// with it every landmark id) is exactly the reference's.
+// `speculate` = false: only the current top of each heap is split per round (no wasted splits; used for the
+// many small per-community heaps of the forced phase, which need s-1 rounds anyway).
+void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64> &targets, int method,
+                   std::deque<Group> &pool, bool speculate) {
+    for (;;) {
+        std::vector<Group *> batch;
+        for (size_t q = 0; q < heaps.size(); q++) {
+            Heap &h = *heaps[q];
+            while ((i64)h.len() < targets[q] && h.top()->has_split) replay_one(h);
+            if ((i64)h.len() >= targets[q]) continue;
+            if (!speculate) {
+                batch.push_back(h.top());
+                continue;
+            }
+            // Exactly `remaining` more pops will happen.  A node can only be among them if its value ranks within
+            // `remaining` among ALL known unpopped nodes (cached splits and unsplit ones alike): nodes still to be
+            // discovered only add competitors.  So every unsplit node above that threshold is a candidate and
+            // every one below it is certainly never popped.
+            const i64 remaining = targets[q] - (i64)h.len();
+            std::vector<Group *> frontier, stack;
+            std::vector<double> vals;
+            for (size_t i = 1; i <= h.len(); i++) stack.push_back(h.a[i]);
+            while (!stack.empty()) {
+                Group *g = stack.back();
+                stack.pop_back();
+                if (g->what.size() > 1 || g == h.top() || g->has_split) vals.push_back(g->value);
+                if (!g->has_split) {
+                    if (g->what.size() > 1 || g == h.top()) frontier.push_back(g);
+                } else if (g->rc == CGE_OK) {
+                    stack.push_back(g->clo);
+                    stack.push_back(g->chi);
+                }
+            }
+            if (frontier.empty()) continue;
+            double thr = INFINITY;
+            if ((i64)vals.size() > remaining) {
+                std::nth_element(vals.begin(), vals.begin() + (remaining - 1), vals.end());
+                thr = vals[remaining - 1];
+            }
+            {
+                std::vector<Group *> keep;
+                for (Group *g : frontier)
+                    if (g->value <= thr || g == h.top()) keep.push_back(g);
+                frontier.swap(keep);
+            }
+            batch.insert(batch.end(), frontier.begin(), frontier.end());
+        }
+        if (batch.empty()) break;
+        compute_splits(c, batch, method);
+        materialise_children(batch, pool);
+    }
 }
 
 } // namespace
@@ -999,15 +1065,10 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             for (auto &L : locals) roots.push_back(L.h.top());
             device_group_values(c, roots);
         }
-        for (;;) {
-            std::vector<Group *> tasks;
-            for (auto &L : locals) {
-                while ((i64)L.h.len() < forced && L.h.top()->has_split) replay_one(L.h, pool);
-                if ((i64)L.h.len() < forced) tasks.push_back(L.h.top());
-            }
-            if (tasks.empty()) break;
-            compute_splits(c, tasks, method);
-        }
+        std::vector<Heap *> hs;
+        std::vector<i64> tg;
+        for (auto &L : locals) { hs.push_back(&L.h); tg.push_back(forced); }
+        advance_heaps(c, hs, tg, method, pool, false);
     }
     size_t li = 0;
     for (i64 q = 0; q < ncl; q++) {
@@ -1025,29 +1086,11 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             while (L.len() > 0) H.put(L.pop()); // :309-312
         }
     }
-    // ---- global phase (:316-335) with speculative batches ----------------------------------------
-    while ((i64)H.len() < nland) {
-        while ((i64)H.len() < nland && H.top()->has_split) replay_one(H, pool);
-        if ((i64)H.len() >= nland) break;
-        const i64 remaining = nland - (i64)H.len();
-        // speculation width: every group that could still be popped before the loop ends (at most `remaining`
-        // pops are left); over-speculation only costs device work, the replay stays exact
-        const char *env_k = getenv("CGE_SPEC_DIV");
-        const i64 div = env_k ? std::max<i64>(1, atoll(env_k)) : 1;
-        i64 K = std::max<i64>(1, std::min<i64>(remaining, std::max<i64>(32, (remaining + div - 1) / div)));
-        K = std::min<i64>(K, 4096);
-        std::vector<Group *> cand;
-        for (size_t i = 1; i <= H.len(); i++)
-            if (!H.a[i]->has_split && (H.a[i]->what.size() > 1 || H.a[i] == H.top())) cand.push_back(H.a[i]);
-        if ((i64)cand.size() > K) {
-            std::nth_element(cand.begin(), cand.begin() + K, cand.end(),
-                             [](const Group *a, const Group *b) { return a->value < b->value; });
-            cand.resize(K);
-        }
-        if (std::find(cand.begin(), cand.end(), H.top()) == cand.end()) cand.back() = H.top(); // ties at the cut
-        // the top of the heap must be in the batch (it is the smallest value, so it is, unless it
-        // was filtered out above as an already split group -- impossible here)
-        compute_splits(c, cand, method);
+    // ---- global phase (:316-335) ----------------------------------------------------------------------------
+    {
+        std::vector<Heap *> hs{&H};
+        std::vector<i64> tg{nland};
+        advance_heaps(c, hs, tg, method, pool, true);
     }
     group_ids.assign(n, -1);
     if (members_out) members_out->clear();
