@@ -202,6 +202,14 @@ int cge_set_vertex_data(cge_ctx *c, const int64_t *comm, const double *vw, int64
         c->n_comm_max = cmax;
         c->comm.alloc_exact(n);
         HIP_CHECK(hipMemcpyAsync(c->comm.p, c->h_comm.data(), sizeof(i32) * n, hipMemcpyHostToDevice, c->stream));
+        c->comm16.release();
+        if (cmax < 65536) {
+            std::vector<unsigned short> c16(n);
+            for (i64 i = 0; i < n; i++) c16[i] = (unsigned short)c->h_comm[i];
+            c->comm16.alloc_exact(n);
+            HIP_CHECK(hipMemcpyAsync(c->comm16.p, c16.data(), sizeof(unsigned short) * n, hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream)); // c16 goes out of scope
+        }
     }
     if (vw) {
         c->h_vw.assign(vw, vw + n);

@@ -208,6 +208,7 @@ struct cge_ctx {
     i64 ldn = 0, dpad = 0;
     bool centred_ready = false;
     DevBuf<i32> comm;         // n, 0-based
+    DevBuf<unsigned short> comm16; // the same as uint16 when C < 65536 (2 MB at n = 10^6: L2-resident gather table)
     DevBuf<double> vw;        // n
     std::vector<double> h_Xr; // host mirror, row-major (cut rules + RSS run on the host)
     std::vector<i32> h_comm;

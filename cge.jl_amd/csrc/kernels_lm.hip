@@ -1029,9 +1029,10 @@ void k_landmark_aggregate(cge_ctx *c, const double *Xr, const double *vw, const 
 // Coalesced SoA reads of (src,dst,w); v2l/comm gathers are served by L2.  Community-pair bins on
 // the diagonal (the bulk of the edges of a graph with community structure) are pre-aggregated in
 // LDS; everything else goes out as no-return f64 atomics (exact for unit weights).
+template <typename CT> // CT = community table element type (uint16 when C < 65536: the table stays L2-resident)
 __global__ __launch_bounds__(256) void edge_scatter_kernel(const i32 *__restrict__ src, const i32 *__restrict__ dst,
                                                            const double *__restrict__ w, i64 e0, i64 e1,
-                                                           const i32 *__restrict__ v2l, const i32 *__restrict__ comm,
+                                                           const i32 *__restrict__ v2l, const CT *__restrict__ comm,
                                                            i64 N, i64 C, int directed, double *__restrict__ wedges,
                                                            double *__restrict__ vectC) {
     extern __shared__ __attribute__((aligned(16))) double cdiag[]; // C diagonal bins
@@ -1068,10 +1069,15 @@ void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w,
     if (wedges && !v2l) CGE_THROW(CGE_E_ARG, "edge_scatter: the landmark-pair matrix needs v_to_l");
     // two timers: the C x C cluster-pair scatter (the score path) and the N x N landmark-pair scatter
     ScopedKernelTimer t(c, wedges ? (vectC ? "edge_scatter_both" : "edge_scatter_wedges") : "edge_scatter");
-    // one workgroup per CU-slot, a few per CU: every workgroup flushes C diagonal bins at the end
-    const unsigned grid = grid_for(e1 - e0, 256, 256 * 4);
-    hipLaunchKernelGGL(edge_scatter_kernel, dim3(grid), dim3(256), (size_t)C * sizeof(double), c->stream, src, dst, w,
-                       e0, e1, v2l, comm, N, C, directed, wedges, vectC);
+    static const int env_grid = getenv("CGE_SCATTER_GRID") ? atoi(getenv("CGE_SCATTER_GRID")) : 0;
+    const unsigned grid = grid_for(e1 - e0, 256, env_grid > 0 ? env_grid : 512); // measured: 512 > 256, 1024, 2048
+    const bool use16 = comm == c->comm.p && c->comm16.p && C < 65536 && !getenv("CGE_SCATTER_NO16");
+    if (use16)
+        hipLaunchKernelGGL(edge_scatter_kernel<unsigned short>, dim3(grid), dim3(256), (size_t)C * sizeof(double), c->stream,
+                           src, dst, w, e0, e1, v2l, c->comm16.p, N, C, directed, wedges, vectC);
+    else
+        hipLaunchKernelGGL(edge_scatter_kernel<i32>, dim3(grid), dim3(256), (size_t)C * sizeof(double), c->stream, src, dst,
+                           w, e0, e1, v2l, comm, N, C, directed, wedges, vectC);
 }
 
 __global__ void edge_degrees_kernel(const i32 *__restrict__ src, const i32 *__restrict__ dst,

@@ -1,15 +1,17 @@
 // landmarks_host.cpp -- runsplit() for the MI355X build (reference: src/landmarks.jl:279-345).
 //
 // Split of work:
-//   device : per-group weighted mean, covariance y'y (O(|c| d^2)) and projection z = y v, batched over
-//            many groups per launch (kernels_lm.hip);
-//   host   : the heap (bit-for-bit the reference's sift rules, :12-46), the principal eigenvector of
-//            each d x d covariance (Householder tridiagonalisation + bisection + inverse iteration), the
-//            1-D cut rules (:92-267) and the children's RSS, on a worker pool.
-// The reference splits strictly one group at a time.  Here the groups that the heap is about to pop
-// are split speculatively in one batch and the heap is then REPLAYED in the reference's order from
-// the cached results, so ids (= positions in the heap array, :337-342) come out identical while the
-// device sees hundreds of groups per launch.
+//   device : per-group weighted mean, covariance y'y (fp64 MFMA SYRK), principal eigenvector (LDS-resident
+//            batched solver), projection z = y v, stable segmented sort of z, WSSE prefix sums along sorted z,
+//            all median-cut rounds of the rss rule, children / root RSS -- batched over many groups per launch
+//            (kernels_lm.hip, kernels_sort.hip);
+//   host   : the heap (bit-for-bit the reference's sift rules, :12-46) and its replay, the member lists of the
+//            children in the reference's order, the trivial cuts of the size / diameter rules, the sequential
+//            rss2 rule (:92-147), and the generic round-based rss path for groups with a tie at max z.
+// The reference splits strictly one group at a time.  Here the nodes of the split tree that can still be
+// popped are split speculatively in batches and the heap is then REPLAYED in the reference's order from the
+// cached results, so ids (= positions in the heap array, :337-342) come out identical while the device sees
+// hundreds of groups per launch.  host_eig_top below is the d > 128 fallback of the device eigen-solver.
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
@@ -114,47 +116,6 @@ struct HView {
     double wt(i64 j) const { return w[what[j] - 1]; }
 };
 
-// total_rss(m, w): src/landmarks.jl:269 + :56-61; per column the terms are added in member order
-double total_rss(const HView &v, const std::vector<i64> &members_local, bool all) {
-    const i64 d = v.d, cnt = all ? v.k : (i64)members_local.size();
-    std::vector<double> ss(d, 0.0), s(d, 0.0);
-    double ws = 0.0;
-    for (i64 t = 0; t < cnt; t++) {
-        const i64 j = all ? t : members_local[t];
-        const double *x = v.row(j);
-        const double w = v.wt(j);
-        ws += w;
-        for (i64 c = 0; c < d; c++) {
-            ss[c] += w * (x[c] * x[c]);
-            s[c] += w * x[c];
-        }
-    }
-    double tot = 0.0;
-    for (i64 c = 0; c < d; c++) tot += ss[c] - s[c] * s[c] / ws;
-    return tot;
-}
-
-// out[c] = base[c] + WSSE(rows sel)
-void add_wsse_set(const HView &v, const std::vector<Wsse> &base, const std::vector<i64> &sel, std::vector<Wsse> &out) {
-    const i64 d = v.d;
-    std::vector<double> ss(d, 0.0), s(d, 0.0);
-    double ws = 0.0;
-    for (i64 j : sel) {
-        const double *x = v.row(j);
-        const double w = v.wt(j);
-        ws += w;
-        for (i64 c = 0; c < d; c++) {
-            ss[c] += w * (x[c] * x[c]);
-            s[c] += w * x[c];
-        }
-    }
-    for (i64 c = 0; c < d; c++) {
-        out[c].ss = base[c].ss + ss[c];
-        out[c].s = base[c].s + s[c];
-        out[c].ws = base[c].ws + ws;
-    }
-}
-
 // Statistics.median: middle of the sorted values, even length -> x/2 + y/2
 double median_sel(const double *z, const std::vector<i64> *sel, i64 k, std::vector<double> &scr) {
     const i64 cnt = sel ? (i64)sel->size() : k;
@@ -166,62 +127,6 @@ double median_sel(const double *z, const std::vector<i64> *sel, i64 k, std::vect
     if (cnt & 1) return hi;
     const double lo = *std::max_element(scr.begin(), scr.begin() + mid);
     return lo / 2.0 + hi / 2.0;
-}
-
-// split_cluster_rss: src/landmarks.jl:155-210 (z given)
-int rule_rss(const HView &v, const double *z, std::vector<i64> &low, std::vector<i64> &high) {
-    const i64 k = v.k, d = v.d;
-    i64 imin = 0, imax = 0;
-    for (i64 j = 1; j < k; j++) {
-        if (z[j] < z[imin]) imin = j;
-        if (z[j] > z[imax]) imax = j;
-    }
-    if (imin == imax) return CGE_E_HOMOGENEOUS;
-    low.assign(1, imin);
-    high.assign(1, imax);
-    std::vector<i64> gray, t1, t2;
-    gray.reserve(k);
-    for (i64 j = 0; j < k; j++)
-        if (j != imin && j != imax) gray.push_back(j);
-    std::vector<Wsse> rl(d), rh(d), rlt(d), rht(d);
-    {
-        const double *x1 = v.row(imin), *x2 = v.row(imax);
-        const double w1 = v.wt(imin), w2 = v.wt(imax);
-        for (i64 c = 0; c < d; c++) {
-            rl[c] = {x1[c] * x1[c] * w1, x1[c] * w1, w1};
-            rh[c] = {x2[c] * x2[c] * w2, x2[c] * w2, w2};
-        }
-    }
-    std::vector<double> scr;
-    double med = median_sel(z, nullptr, k, scr);
-    for (;;) {
-        t1.clear();
-        t2.clear();
-        for (i64 j : gray) (z[j] < med ? t1 : t2).push_back(j);
-        add_wsse_set(v, rl, t1, rlt);
-        add_wsse_set(v, rh, t2, rht);
-        if (sum_wsse(rlt) < sum_wsse(rht)) {
-            if (t1.empty()) break;
-            rl = rlt;
-            low.insert(low.end(), t1.begin(), t1.end());
-            gray = t2;
-        } else {
-            if (t2.empty()) break;
-            rh = rht;
-            high.insert(high.end(), t2.begin(), t2.end());
-            gray = t1;
-        }
-        if (gray.empty()) break;
-        med = median_sel(z, &gray, k, scr);
-    }
-    if (!gray.empty()) {
-        add_wsse_set(v, rl, gray, rlt);
-        add_wsse_set(v, rh, gray, rht);
-        const double a = std::max(sum_wsse(rlt), sum_wsse(rh)), b = std::max(sum_wsse(rl), sum_wsse(rht));
-        auto &dst = (a < b) ? low : high;
-        dst.insert(dst.end(), gray.begin(), gray.end());
-    }
-    return CGE_OK;
 }
 
 // split_cluster_rss2: src/landmarks.jl:92-147 (z given)

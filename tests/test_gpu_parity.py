@@ -481,3 +481,78 @@ def test_larger_graph_invariants(ctx):
     rng = np.random.default_rng(0)
     ii, jj = rng.integers(0, g["n"], 200000), rng.integers(0, g["n"], 200000)
     assert hi >= np.sqrt(((g["embedding"][ii] - g["embedding"][jj]) ** 2).sum(1)).max()
+
+
+def test_headline_size_properties(ctx):
+    """BASELINE.json's headline size (n = 10^6, m ~ 10^7, d = 128, -l 4000): no oracle can run here, so the
+    size-independent properties of SURVEY.md §8c: partition validity, exact weight sums, centroids of sampled
+    landmarks, cluster-pair scatter vs numpy, pruned diameter == brute-force diameter (all 5e11 pairs on the
+    fp64 MFMA kernel), bitwise run-to-run reproducibility."""
+    from cge.jl_amd import synth
+
+    g = synth.abcd_like(1_000_000, 10_500_000, 500, 128, seed=42)
+    n, m, C = g["n"], g["m"], g["C"]
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    ctx.set_option("diameter", 0)
+    res = ctx.score(g["clusters"], 4000, 4, "rss", seed=42, auc_samples=10000)
+    tr = ctx.last_trace
+    hi, path, pairs, tiles = ctx.last_diameter()
+    assert path == "pruned" and tiles < 0.01 * (n / 128) ** 2 / 2
+    assert np.all(np.isfinite(res)) and 0.25 <= res[0] <= 10 and 0 < res[1] <= math.log(2) and 0 <= res[5] <= 1
+    assert res[6] == pytest.approx(1.96 * math.sqrt(res[5] * (1 - res[5]) / 10000), rel=1e-12)
+    best = int(np.nanargmin(tr["div"]))
+    assert res[1] == tr["div"][best] and res[0] == 0.25 * (best + 1) and all(it >= 1 for it in tr["iters"])
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = ctx.landmarks_fetch()
+    N = len(dii)
+    assert N == 4000 and v2l.min() == 1 and v2l.max() == N
+    comm = g["comm"][:, 0]
+    first = np.zeros(N + 1, dtype=np.int64)
+    first[v2l] = comm
+    assert np.array_equal(first[v2l], comm) and np.array_equal(lcomm[:, 0], first[1:])  # landmarks nest in communities
+    assert lw.sum() == m and lweight.sum() == 2 * m  # unit weights: exact
+    assert np.array_equal(np.bincount(v2l, weights=g["vweights"])[1:], lweight)
+    assert np.all(ledges[:, 0] <= ledges[:, 1]) and np.all(lw > 0)
+    for l in np.random.default_rng(1).integers(1, N + 1, 40):  # weighted centroids / d_ii of sampled landmarks
+        mem = np.flatnonzero(v2l == l)
+        w = g["vweights"][mem]
+        cen = (g["embedding"][mem] * w[:, None]).sum(0) / w.sum()
+        assert np.allclose(lemb[l - 1], cen, rtol=1e-12, atol=1e-14)
+        assert dii[l - 1] == pytest.approx(np.sqrt(((g["embedding"][mem] - lemb[l - 1]) ** 2).sum() / w.sum()), rel=1e-12)
+    # C x C cluster-pair scatter (the score path's edge pass) vs numpy
+    _, vc = ctx.edge_scatter(None, 1, C, False, want_wedges=False)
+    ca, cb = comm[g["edges"][:, 0] - 1] - 1, comm[g["edges"][:, 1] - 1] - 1
+    lo, hi_c = np.minimum(ca, cb), np.maximum(ca, cb)
+    expc = np.bincount(C * lo - lo * (lo - 1) // 2 + (hi_c - lo), minlength=C * (C + 1) // 2).astype(float)
+    assert np.array_equal(vc, expc)
+    # exactness of the pruned diameter at full size, and reproducibility
+    ctx.set_option("diameter", 1)
+    res_b = ctx.score(g["clusters"], 4000, 4, "rss", seed=42, auc_samples=10000)
+    hi_b, path_b, _, _ = ctx.last_diameter()
+    ctx.set_option("diameter", 0)
+    assert path_b == "brute" and hi_b == hi and np.array_equal(res, res_b)
+    rng = np.random.default_rng(0)
+    ii, jj = rng.integers(0, n, 300000), rng.integers(0, n, 300000)
+    assert hi >= np.sqrt(((g["embedding"][ii] - g["embedding"][jj]) ** 2).sum(1)).max()
+
+
+def test_config1_force_exact_against_oracle_fixture(ctx, example10k):
+    """BASELINE config 1 (example/10k.* --force-exact, N = n = 10 000) on the GPU vs the oracle's full-size run
+    (tests/golden/oracle_exact10k.json, generated by tests/golden/make_oracle_fixture_exact10k.py)."""
+    import cge.jl_amd as cg
+
+    path = os.path.join(GOLDEN, "oracle_exact10k.json")
+    if not os.path.exists(path):
+        pytest.skip("oracle_exact10k.json not generated")
+    with open(path) as f:
+        gold = json.load(f)
+    a = example10k
+    n = len(a["vweights"])
+    smp = (np.array([gold["pos_idx"]]), np.array([gold["neg_i"]]), np.array([gold["neg_j"]]))
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    res, tr = cg.wGCL(a["edges"], a["eweights"], a["comm"], a["embedding"], np.zeros(n), a["vweights"], *empty, False,
+                      samples=smp, trace=True, ctx=ctx)
+    assert tr["iters"] == gold["iters"]
+    assert np.allclose(tr["div"], gold["div"], rtol=RTOL, equal_nan=True)
+    assert np.allclose(tr["auc"], gold["auc"], rtol=RTOL, atol=1e-12, equal_nan=True)
+    assert res[0] == gold["result"][0] and res[4] == gold["result"][4]
+    assert np.allclose(res, gold["result"], rtol=RTOL, atol=1e-12)
