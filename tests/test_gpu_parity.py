@@ -137,6 +137,54 @@ def test_landmarks_duplicate_rows_ties(ctx, orc, method):
     _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
 
 
+@pytest.mark.parametrize("d,method", [(200, "rss"), (256, "size"), (96, "diameter"), (65, "rss2")])
+def test_landmarks_parity_wide_embeddings(ctx, orc, d, method):
+    """Embedding dimensions beyond one MFMA tile / one LDS-resident covariance: host eigen-solver fallback
+    (d > 128), multi-tile MFMA SYRK, dimensions that are not multiples of 8/16/128.  (The oracle's Jacobi solver
+    costs O(d^3) per sweep, so the oracle-checked cases stop at d = 256; d = 512 is covered below.)"""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    g = synth.abcd_like(1500, 12000, 4, d, seed=d)
+    args = (g["edges"], g["eweights"], g["vweights"], g["clusters"], g["comm"], g["embedding"], False, 22, 4, method,
+            False)
+    got, ref = cg.landmarks(*args, ctx=ctx), orc.landmarks(*args)
+    _check_landmarks(got, ref)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = got
+    smp = api.draw_samples(ctx, 3, 2000)
+    res, tr = cg.wGCL(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, g["edges"], g["eweights"],
+                      g["embedding"], False, samples=smp, trace=True, ctx=ctx)
+    exp, etr = orc.wGCL(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, g["edges"], g["eweights"],
+                        g["embedding"], False, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+
+
+def test_d512_invariants(ctx):
+    """Config 5's embedding width (d = 512) end to end on the device: invariants instead of the oracle."""
+    from cge.jl_amd import synth
+
+    g = synth.abcd_like(20000, 200000, 10, 512, seed=9)
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    res = ctx.score(g["clusters"], 120, 4, "rss", seed=1, auc_samples=5000)
+    hi, path, _, _ = ctx.last_diameter()
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = ctx.landmarks_fetch()
+    N = len(dii)
+    assert N == 120 and np.all(np.isfinite(res)) and 0 < res[1] <= math.log(2)
+    comm = g["comm"][:, 0]
+    first = np.zeros(N + 1, dtype=np.int64)
+    first[v2l] = comm
+    assert np.array_equal(first[v2l], comm) and lw.sum() == g["m"] and lweight.sum() == 2 * g["m"]
+    cen = np.zeros((N, 512))
+    np.add.at(cen, v2l - 1, g["embedding"] * g["vweights"][:, None])
+    assert np.allclose(lemb, cen / lweight[:, None], rtol=1e-11, atol=1e-13)
+    ctx.set_option("diameter", 1)
+    res_b = ctx.score(g["clusters"], 120, 4, "rss", seed=1, auc_samples=5000)
+    ctx.set_option("diameter", 0)
+    assert ctx.last_diameter()[0] == hi and np.array_equal(res, res_b)
+    # every group's cut is a threshold on ITS principal axis: children RSS never exceed the parent's
+    assert np.array_equal(res, ctx.score(g["clusters"], 120, 4, "rss", seed=1, auc_samples=5000))
+
+
 def _cmp_result(res, exp, tr=None, etr=None):
     assert len(res) == len(exp)
     assert res[0] == exp[0] and res[4] == exp[4], (res, exp)  # best alphas
