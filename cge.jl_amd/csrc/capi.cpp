@@ -711,7 +711,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     ScoreGraph G;
     OrigView ov;
     const bool landmarks = a->land != -1;
-    DevBuf<double> zeros;
+    DevBuf<double> &zeros = c->sw_zeros;
     double t0;
     DevBuf<i32> star;
     auto star_exit = [&](i64 Nv) -> bool { // star-graph guard of wGCL_directed (src/divergence.jl:321-334)

@@ -235,6 +235,11 @@ struct cge_ctx {
     DevBuf<double> s_emb, s_dist, s_vw, s_vectC, s_degin, s_degout;
     DevBuf<i32> s_comm;
     DevBuf<double> auc_part, js_part;
+    // alpha-sweep scratch (grow-only: no hipMalloc/hipFree inside a scoring call after the first)
+    DevBuf<double> sw_D, sw_GD, sw_T1, sw_T2, sw_S1, sw_S2, sw_rowbins, sw_vectB, sw_scal, sw_lohi, sw_fitstate, sw_mm;
+    DevBuf<int> sw_flags;
+    DevBuf<i32> sw_cm_off, sw_cm_mem;
+    DevBuf<double> sw_zeros;
     // diameter scratch
     DevBuf<double> mp_recs;  // MaxRec records (3 doubles each)
     DevBuf<i64> mp_count;

@@ -110,7 +110,7 @@ __global__ void minmax_final_kernel(const double *__restrict__ part, int nb, dou
 }
 void k_minmax_upper(cge_ctx *c, const double *D, i64 N, double *lo_hi) {
     const int nb = (int)grid_for(N * N, 256, 1024);
-    DevBuf<double> part;
+    DevBuf<double> &part = c->sw_mm;
     part.ensure((size_t)2 * nb);
     hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(256), 0, c->stream, D, N, part.p);
     hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1), 0, c->stream, part.p, nb, lo_hi);

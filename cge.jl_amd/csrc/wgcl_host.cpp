@@ -146,8 +146,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     const i64 vlen = directed ? C * C : packed_len(C);
     if ((double)N * (double)N * 8.0 * 2.2 > 200e9) CGE_THROW(CGE_E_OOM, "score graph with %lld vertices does not fit", (long long)N);
 
-    DevBuf<double> D, GD, T1, T2, S1, S2, rowbins, vectB, scal, lohi, fitstate;
-    DevBuf<int> flags; // [0]=done, [1]=iters
+    DevBuf<double> &D = c->sw_D, &GD = c->sw_GD, &T1 = c->sw_T1, &T2 = c->sw_T2, &S1 = c->sw_S1, &S2 = c->sw_S2,
+                   &rowbins = c->sw_rowbins, &vectB = c->sw_vectB, &scal = c->sw_scal, &lohi = c->sw_lohi,
+                   &fitstate = c->sw_fitstate;
+    DevBuf<int> &flags = c->sw_flags; // [0]=done, [1]=iters
     D.ensure((size_t)N * N);
     GD.ensure((size_t)N * N);
     T1.ensure(N); T2.ensure(N); S1.ensure(N); S2.ensure(N);
@@ -177,7 +179,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         std::vector<i32> cur(cm_off.begin(), cm_off.end() - 1);
         for (i64 i = 0; i < N; i++) cm_mem[cur[hcomm[i]]++] = (i32)i;
     }
-    DevBuf<i32> d_cm_off, d_cm_mem;
+    DevBuf<i32> &d_cm_off = c->sw_cm_off, &d_cm_mem = c->sw_cm_mem;
     d_cm_off.ensure(C + 1);
     d_cm_mem.ensure(N);
     HIP_CHECK(hipMemcpyAsync(d_cm_off.p, cm_off.data(), sizeof(i32) * (C + 1), hipMemcpyHostToDevice, st));
