@@ -313,6 +313,15 @@ class Context:
                                              C.byref(aj)))
         return hi.value, ai.value, aj.value
 
+    def group_eig(self, A):
+        """Testing hook (include/cge_hip_testing.h): principal eigenvectors of a (T, d, d) stack of symmetric
+        matrices by the batched device solver of the landmark phase (replaces `eigvecs(A)[:, end]`)."""
+        A = _f64(A)
+        T, d = A.shape[0], A.shape[1]
+        v = np.empty((T, d), dtype=np.float64)
+        self._check(self.L.cge_group_eig(self.h, _p(A), C.c_int64(T), C.c_int64(d), _p(v)))
+        return v
+
     def js(self, vC, vB, vI=None, internal=True):
         vC, vB = _f64(vC), _f64(vB)
         vi = None if vI is None or len(vI) == 0 else np.ascontiguousarray(vI, dtype=np.uint8)

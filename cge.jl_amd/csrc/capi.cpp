@@ -923,5 +923,18 @@ int cge_host_pos_draw(int64_t seed, int64_t stream_id, int64_t S, int64_t m, int
     host_pos_draw(seed, stream_id, S, m, pos_idx);
     return CGE_OK;
 }
+int cge_group_eig(void *ctx, const double *A, int64_t T, int64_t d, double *v) {
+    cge_ctx *c = (cge_ctx *)ctx;
+    if (!c || !A || !v || T <= 0 || d <= 0 || d > 128) return CGE_E_ARG;
+    CGE_TRY(c)
+    DevBuf<double> dA, dv;
+    dA.ensure((size_t)T * d * d);
+    dv.ensure((size_t)T * d);
+    HIP_CHECK(hipMemcpyAsync(dA.p, A, sizeof(double) * T * d * d, hipMemcpyHostToDevice, c->stream));
+    k_group_eig(c, dA.p, T, d, dv.p);
+    HIP_CHECK(hipMemcpyAsync(v, dv.p, sizeof(double) * T * d, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    CGE_CATCH(c)
+}
 
 } // extern "C"

@@ -677,11 +677,19 @@ void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Batched principal eigenvector, one workgroup per d x d covariance (d <= 128: the matrix lives in
-// LDS).  Same algorithm as host_eig_top (landmarks_host.cpp): Householder tridiagonalisation,
-// largest eigenvalue by (64-way) multisection on the Sturm count, inverse iteration with a pivoted
-// tridiagonal LU, back-transformation, sign = largest-|component| positive.
-// Replaces `eigvecs(A)[:, end]` (src/landmarks.jl:99,162,225,254).
+// Batched principal eigenvector, one workgroup per d x d covariance, d <= 128.  Same algorithm as
+// host_eig_top (landmarks_host.cpp): Householder tridiagonalisation, largest eigenvalue by (64-way)
+// multisection on the Sturm count, inverse iteration with a pivoted tridiagonal LU, back-transformation,
+// sign = largest-|component| positive.  Replaces `eigvecs(A)[:, end]` (src/landmarks.jl:99,162,225,254).
+//
+// The matrix lives in REGISTERS: wave w owns the columns [NC*w, NC*w+NC), lane l the rows l + 64*r (r < NR),
+// so a thread holds an NR x NC block.  A Householder step then needs two workgroup barriers only: everything
+// that is O(d) (the reflector, its norm, p.u, w) is recomputed by every wave from LDS with in-wave DPP
+// reductions; the O(d^2) work (B u and the rank-2 update) runs on the register blocks with u, w broadcast
+// from LDS.  Finished columns are never touched again (u and w are zero there), so column k keeps the
+// reflector of step k below its sub-diagonal -- the back-transformation reads it from the same registers,
+// wave by wave, with in-wave reductions (4 barriers in all).
+//
 // 1/q to ~1 ulp without the IEEE division sequence: hardware reciprocal + one Newton step.  Used only in
 // chains whose results are themselves iterated (Sturm counts, inverse iteration), never in sums that
 // are compared with the reference.
@@ -690,101 +698,150 @@ __device__ __forceinline__ double fast_rcp(double q) {
     r = fma(fma(-q, r, 1.0), r, r);
     return r;
 }
-__device__ __forceinline__ double eig_block_sum(double v, double *red) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[wave] = v;
-    __syncthreads();
-    return ((red[0] + red[1]) + red[2]) + red[3];
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-__global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict__ cov, int d,
-                                                        double *__restrict__ vec, int diag_stage) {
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *A = sh;            // d*d, symmetric, row-major
-    double *V = A + d * d;     // d  Householder vector, later the eigenvector y
-    double *W = V + d;         // d
-    double *Pp = W + d;        // 2*d partial mat-vec halves
-    double *beta = Pp + 2 * d; // d
-    double *diag = beta + d;   // d
-    double *off = diag + d;    // d
-    double *red = off + d;     // 32: [0..3] block sums, [4] lambda, [5] sign, [8..19] Gershgorin staging
-    double *tri = red + 32;    // 4*d: dl, dd, du, du2
-    const int tid = threadIdx.x;
+__device__ __forceinline__ double lane_value(double v, int lane) { // uniform result (two v_readlane_b32)
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)b, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// sum over the 64 lanes of a wave, the same bits in every lane and in every wave that sums the same values:
+// butterfly inside each row of 16 (quad swaps, half mirror, mirror), then the four row totals in fixed order
+__device__ __forceinline__ double wave_allsum(double v) {
+    v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v); // row_half_mirror
+    v += dpp_move<0x140>(v); // row_mirror
+    return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
+}
+template <int NR, int NC>
+__global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restrict__ cov, int d,
+                                                           double *__restrict__ vec, int diag_stage) {
+    constexpr int DP = 64 * NR; // padded dimension (rows held); 4*NC >= d columns held
+    __shared__ __attribute__((aligned(16))) double X[DP], U[DP], W[DP], Pp[4][DP], V[DP];
+    __shared__ __attribute__((aligned(16))) double diag[DP], off[DP], beta[DP], V0[DP], tri[4 * DP], red[32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *src = cov + (size_t)blockIdx.x * d * d;
     double *out = vec + (size_t)blockIdx.x * d;
-    for (int e = tid; e < d * d; e += 256) A[e] = src[e];
-    if (tid < d) { beta[tid] = 0.0; off[tid] = 0.0; }
-    __syncthreads();
     if (d == 1) {
         if (tid == 0) out[0] = 1.0;
         return;
     }
+    double a[NR][NC];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int row = lane + 64 * r;
+#pragma unroll
+        for (int jj = 0; jj < NC; jj++) {
+            const int col = NC * wv + jj;
+            a[r][jj] = (row < d && col < d) ? src[(size_t)col * d + row] : 0.0; // symmetric: coalesced along rows
+        }
+    }
+    // publish row kn of the matrix: X[col] = A[kn][col].  Row kn is read instead of column kn (the matrix stays
+    // bitwise symmetric: both triangles get the same update) because a row is spread over the waves' static column
+    // slots -- no dynamic register indexing.  Readers mask the part left of the sub-diagonal themselves.
+    auto extract = [&](int kn) {
+        if (lane == (kn & 63)) {
+            if (NR > 1 && kn >= 64) {
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) X[NC * wv + jj] = a[NR - 1][jj];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) X[NC * wv + jj] = a[0][jj];
+            }
+        }
+    };
+    if (tid < DP) { beta[tid] = 0.0; off[tid] = 0.0; V0[tid] = 0.0; X[tid] = 0.0; }
+    __syncthreads();
+    extract(0);
     // ---- tridiagonalisation ------------------------------------------------------------------------
     for (int k = 0; k + 2 < d; k++) {
-        const int r = d - k - 1, o = k + 1;
-        const double xi = (tid < r) ? A[k * d + o + tid] : 0.0;
-        const double sigma = eig_block_sum((tid >= 1 && tid < r) ? xi * xi : 0.0, red);
-        const double alpha = A[k * d + o];
-        if (sigma == 0.0) { // uniform: no reflection needed
-            if (tid == 0) { beta[k] = 0.0; off[k] = alpha; }
-            __syncthreads();
-            continue;
+        __syncthreads(); // (a) X, diag of column k are visible; U, W, Pp of the previous step are dead
+        const int o = k + 1;
+        double x[NR], u[NR];
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int row = lane + 64 * r;
+            x[r] = (row > k) ? X[row] : 0.0;
+            part += (row > o) ? x[r] * x[r] : 0.0;
         }
+        const double alpha = X[o];
+        if (tid == 0) diag[k] = X[k];
+        const double sigma = wave_allsum(part);
+        // sigma == 0: no reflection at this step.  It runs through the same code with u = w = 0 (the update then
+        // leaves every register bit as it is) -- a branch around the update would make the compiler keep two copies
+        // of the matrix block.
+        const bool refl = sigma != 0.0;
         const double mu = sqrt(alpha * alpha + sigma);
-        const double v0 = (alpha <= 0.0) ? alpha - mu : -sigma / (alpha + mu);
-        const double bk = 2.0 * v0 * v0 / (sigma + v0 * v0);
-        if (tid < r) V[tid] = (tid == 0) ? 1.0 : xi / v0;
-        if (tid == 0) { beta[k] = bk; off[k] = mu; }
-        __syncthreads();
-        { // p = bk * B v, B = A[o.., o..]; column access (B symmetric) keeps LDS reads conflict free
-            const int i = tid & 127, half = tid >> 7;
-            double s = 0.0;
-            if (i < r) {
-                const int jm = (r + 1) >> 1, j0 = half ? jm : 0, j1 = half ? r : jm;
-                const double *col = A + (i64)o * d + o + i; // element (o+j, o+i) = col[j*d]
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                int j = j0;
-                for (; j + 7 < j1; j += 8) { // 8 independent LDS reads in flight
-                    const double a0 = col[(j + 0) * d], a1 = col[(j + 1) * d], a2 = col[(j + 2) * d], a3 = col[(j + 3) * d];
-                    const double a4 = col[(j + 4) * d], a5 = col[(j + 5) * d], a6 = col[(j + 6) * d], a7 = col[(j + 7) * d];
-                    s0 += a0 * V[j + 0]; s1 += a1 * V[j + 1]; s2 += a2 * V[j + 2]; s3 += a3 * V[j + 3];
-                    s0 += a4 * V[j + 4]; s1 += a5 * V[j + 5]; s2 += a6 * V[j + 6]; s3 += a7 * V[j + 7];
+        const double v0r = (alpha <= 0.0) ? alpha - mu : -sigma / (alpha + mu);
+        const double v0 = refl ? v0r : 0.0;
+        const double bp = refl ? 2.0 / (sigma + v0r * v0r) : 0.0; // H = I - bp u u^T, u = (v0, x[o+1..])
+        if (tid == 0) { beta[k] = bp; off[k] = refl ? mu : alpha; V0[k] = v0; }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int row = lane + 64 * r;
+            u[r] = (row == o) ? v0 : x[r];
+            U[row] = u[r]; // every wave writes the same values
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool live = NC * wv + NC > o; // this wave still owns unfinished columns
+        { // partial p = B u over the wave's columns
+            double s[NR];
+#pragma unroll
+            for (int r = 0; r < NR; r++) s[r] = 0.0;
+            if (live) {
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) {
+                    if (jj % 8 == 0) asm volatile("" ::: "memory"); // at most 8 broadcast reads in flight (registers)
+                    const double uj = U[NC * wv + jj];
+#pragma unroll
+                    for (int r = 0; r < NR; r++) s[r] = fma(a[r][jj], uj, s[r]);
                 }
-                for (; j < j1; j++) s0 += col[j * d] * V[j];
-                s = (s0 + s1) + (s2 + s3);
-                Pp[half * d + i] = s; // i < r <= d: stays inside the 2*d staging area
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++) Pp[wv][lane + 64 * r] = s[r];
+        }
+        __syncthreads(); // (b)
+        double w[NR];
+        part = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int row = lane + 64 * r;
+            w[r] = bp * (((Pp[0][row] + Pp[1][row]) + Pp[2][row]) + Pp[3][row]);
+            part += w[r] * u[r];
+        }
+        const double K = 0.5 * bp * wave_allsum(part);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int row = lane + 64 * r;
+            w[r] = (row >= o) ? w[r] - K * u[r] : 0.0; // finished rows / columns stay as they are
+            W[row] = w[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        { // rank-2 update; waves whose columns are all finished run it too (u = w = 0 there: nothing changes)
+#pragma unroll
+            for (int jj = 0; jj < NC; jj++) {
+                if (jj % 8 == 0) asm volatile("" ::: "memory");
+                const double uj = U[NC * wv + jj], wj = W[NC * wv + jj];
+#pragma unroll
+                for (int r = 0; r < NR; r++) a[r][jj] -= u[r] * wj + w[r] * uj;
             }
         }
-        __syncthreads();
-        const double pi = (tid < r) ? bk * (Pp[tid] + Pp[d + tid]) : 0.0;
-        const double pv = eig_block_sum((tid < r) ? pi * V[tid] : 0.0, red);
-        const double K = 0.5 * bk * pv;
-        if (tid < r) W[tid] = pi - K * V[tid];
-        __syncthreads();
-        {
-            const int i = tid & 127;
-            if (i < r) {
-                const double vi = V[i], wi = W[i];
-                double *col = A + (i64)o * d + o + i; // element (o+j, o+i) = col[j*d]
-                int j = tid >> 7;
-                for (; j + 14 < r; j += 16) { // rows j, j+2, ..., j+14: batched loads, then stores
-                    double a[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) a[q] = col[(j + 2 * q) * d];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) a[q] -= vi * W[j + 2 * q] + wi * V[j + 2 * q];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) col[(j + 2 * q) * d] = a[q];
-                }
-                for (; j < r; j += 2) col[j * d] -= vi * W[j] + wi * V[j];
-            }
-        }
-        if (tid >= 1 && tid < r) A[k * d + o + tid] = V[tid]; // keep the reflector in row k (v[0] = 1 implicit)
-        __syncthreads();
+        extract(k + 1);
     }
-    if (tid < d) diag[tid] = A[tid * d + tid];
-    if (tid == 0) off[d - 2] = A[(d - 2) * d + (d - 1)];
+    __syncthreads();
+    if (tid == 0) { diag[d - 2] = X[d - 2]; off[d - 2] = X[d - 1]; } // row d-2 was the last one published
+    __syncthreads();
+    extract(d - 1);
+    __syncthreads();
+    if (tid == 0) diag[d - 1] = X[d - 1];
     __syncthreads();
     if (diag_stage == 1) { if (tid < d) out[tid] = diag[tid]; return; } // timing diagnostic only
     // ---- Gershgorin bounds ---------------------------------------------------------------------------
@@ -800,15 +857,13 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
         ghi = fmax(ghi, __shfl_xor(ghi, o2));
         gn = fmax(gn, __shfl_xor(gn, o2));
     }
-    __syncthreads();
     double *gs = red + 8;
-    if ((tid & 63) == 0) { gs[(tid >> 6) * 3] = glo; gs[(tid >> 6) * 3 + 1] = ghi; gs[(tid >> 6) * 3 + 2] = gn; }
+    if (lane == 0) { gs[wv * 3] = glo; gs[wv * 3 + 1] = ghi; gs[wv * 3 + 2] = gn; }
     __syncthreads();
     glo = fmin(fmin(gs[0], gs[3]), fmin(gs[6], gs[9]));
     ghi = fmax(fmax(gs[1], gs[4]), fmax(gs[7], gs[10]));
     gn = fmax(fmax(gs[2], gs[5]), fmax(gs[8], gs[11]));
     const double tiny = fmax(gn, 2.2250738585072014e-308) * 2.220446049250313e-16;
-    __syncthreads();
     // ---- largest eigenvalue: 64-way multisection on the Sturm count (wave 0) ------------------------------
     if (tid < 64) {
         double lo = glo, hi = ghi + tiny;
@@ -843,7 +898,7 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
     // ---- inverse iteration (one lane; O(d) per solve) ---------------------------------------------------------
     if (tid == 0) {
         const double lam = red[4];
-        double *dl = tri, *dd = tri + d, *du = tri + 2 * d, *du2 = tri + 3 * d;
+        double *dl = tri, *dd = tri + DP, *du = tri + 2 * DP, *du2 = tri + 3 * DP;
         unsigned long long swp0 = 0ULL, swp1 = 0ULL; // pivot flags, d <= 128
         for (int i = 0; i < d; i++) {
             dd[i] = diag[i] - lam;
@@ -900,17 +955,38 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
             nrm = sqrt(nrm);
             for (int i = 0; i < d; i++) y[i] /= nrm;
         }
+        for (int i = d; i < DP; i++) y[i] = 0.0;
     }
     __syncthreads();
     if (diag_stage == 3) { if (tid < d) out[tid] = V[tid]; return; } // timing diagnostic only
-    // ---- back-transformation x = H_0 H_1 ... H_{d-3} y ------------------------------------------------------------
-    for (int k = d - 3; k >= 0; k--) {
-        const double bk = beta[k];
-        if (bk == 0.0) continue; // uniform
-        const int r = d - k - 1, o = k + 1;
-        const double vk = (tid < r) ? (tid == 0 ? 1.0 : A[k * d + o + tid]) : 0.0;
-        const double s = bk * eig_block_sum((tid < r) ? vk * V[o + tid] : 0.0, red);
-        if (tid < r) V[o + tid] -= s * vk;
+    // ---- back-transformation x = H_0 H_1 ... H_{d-3} y: the wave that owns column k holds reflector k ------------
+    for (int ww = 3; ww >= 0; ww--) {
+        if (wv == ww && NC * ww <= d - 3) {
+            double y[NR];
+#pragma unroll
+            for (int r = 0; r < NR; r++) y[r] = V[lane + 64 * r];
+#pragma unroll
+            for (int jj = NC - 1; jj >= 0; jj--) {
+                int k = NC * ww + jj;
+                asm volatile("" : "+v"(k)); // keeps the 2*NC*NR row masks below from being hoisted (and spilled) together
+                if (k > d - 3) continue;
+                const double bp = beta[k];
+                if (bp == 0.0) continue; // no reflection at this step
+                const double v0 = V0[k];
+                double uu[NR], part = 0.0;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const int row = lane + 64 * r;
+                    uu[r] = (row > k + 1) ? a[r][jj] : (row == k + 1 ? v0 : 0.0);
+                    part += uu[r] * y[r];
+                }
+                const double s = bp * wave_allsum(part);
+#pragma unroll
+                for (int r = 0; r < NR; r++) y[r] -= s * uu[r];
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++) V[lane + 64 * r] = y[r];
+        }
         __syncthreads();
     }
     if (tid == 0) {
@@ -932,11 +1008,16 @@ __global__ __launch_bounds__(256) void group_eig_kernel(const double *__restrict
     if (tid < d) out[tid] = V[tid] * red[5];
 }
 bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec) {
-    if (d > 128) return false; // the matrix no longer fits LDS: the caller uses the host solver
-    const size_t lds = (size_t)(d * d + 12 * d + 40) * sizeof(double);
+    if (d > 128) return false; // beyond the register block: the caller uses the host solver
     ScopedKernelTimer t(c, "group_eig");
     static const int diag_stage = getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0; // 0 = normal
-    hipLaunchKernelGGL(group_eig_kernel, dim3((unsigned)n_tasks), dim3(256), lds, c->stream, cov, (int)d, vec, diag_stage);
+    const dim3 grid((unsigned)n_tasks), block(256);
+    if (d <= 32)
+        hipLaunchKernelGGL((group_eig_kernel<1, 8>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
+    else if (d <= 64)
+        hipLaunchKernelGGL((group_eig_kernel<1, 16>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
+    else
+        hipLaunchKernelGGL((group_eig_kernel<2, 32>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
     return true;
 }
 

@@ -137,6 +137,39 @@ def test_landmarks_duplicate_rows_ties(ctx, orc, method):
     _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
 
 
+@pytest.mark.parametrize("d", [2, 3, 5, 17, 32, 33, 64, 65, 100, 127, 128])
+def test_group_eig_kernel(ctx, d):
+    """The batched device eigen-solver (register-resident Householder tridiagonalisation, Sturm multisection,
+    inverse iteration; replaces `eigvecs(A)[:, end]`, src/landmarks.jl:99) against LAPACK on covariance-like
+    matrices: residual of the eigen-equation, agreement with numpy's vector, sign convention."""
+    rng = np.random.default_rng(100 + d)
+    mats = []
+    for t in range(40):
+        k = int(rng.integers(max(2, d // 2), 4 * d + 8))
+        Y = rng.normal(size=(k, d)) * rng.uniform(0.2, 3.0, size=d)
+        if t % 5 == 0:
+            Y[:, : d // 2] = 0.0      # zero columns: rank deficiency, steps without a reflection
+        if t % 7 == 3:
+            Y = np.round(Y * 4) / 4   # dyadic entries: exact zeros and ties in the arithmetic
+        mats.append(Y.T @ Y)
+    mats.append(np.diag(np.arange(1.0, d + 1)))       # already diagonal: no reflection at any step
+    mats.append(np.zeros((d, d)))                      # zero matrix: any unit vector; the solver returns e_1
+    A = np.stack(mats)
+    v = ctx.group_eig(A)
+    for t in range(len(mats)):
+        lam, vec = np.linalg.eigh(A[t])
+        assert abs(np.linalg.norm(v[t]) - 1.0) < 1e-12
+        big = int(np.argmax(np.abs(v[t])))
+        assert v[t][big] > 0
+        scale = max(lam[-1], 1e-300)
+        resid = np.linalg.norm(A[t] @ v[t] - lam[-1] * v[t]) / scale
+        assert resid < 1e-11, (d, t, resid)
+        gap = (lam[-1] - lam[-2]) / scale if d > 1 else 1.0
+        if gap > 1e-6:
+            ref = vec[:, -1] * np.sign(vec[big, -1])
+            assert np.max(np.abs(ref - v[t])) < 1e-10 / gap, (d, t)
+
+
 @pytest.mark.parametrize("d,method", [(200, "rss"), (256, "size"), (96, "diameter"), (65, "rss2")])
 def test_landmarks_parity_wide_embeddings(ctx, orc, d, method):
     """Embedding dimensions beyond one MFMA tile / one LDS-resident covariance: host eigen-solver fallback
