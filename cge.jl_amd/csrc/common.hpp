@@ -333,6 +333,7 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
                   i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals);
 #define CGE_RR_MAXROUNDS 63
 #define CGE_CHUNK_ROWS 1024 // rows per chunk of a batch (build_batch); the rounds kernel uses r >> 10
+#define CGE_PREFIX_STRIDE 8 // the sorted-order WSSE prefix is stored every 8th row of a chunk (CGE_CHUNK_ROWS % 8 == 0)
 void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 *row_task, const i32 *task_row_off,
                         i64 R, i64 T, double *zs, i32 *perm, i32 *srows, i32 *status);
 void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, const double *params,

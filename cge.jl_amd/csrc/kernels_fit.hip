@@ -188,19 +188,29 @@ void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, 
 // ------------------------------------------------------------------------------------------------
 // vect_B.  Stage 1: rowbins[i][c] = sum over the members j of community c (ascending; j >= i when
 // undirected) of (Ta_i*Tb_j)*GD_ij.  Stage 2: sum the rows of each community into the bins.
+// The row is streamed once, coalesced, into LDS as the products (Ta_i*Tb_j)*GD_ij (only j >= i when undirected);
+// the per-community sums then gather from LDS in member order -- the same additions in the same order as a
+// direct gather from the row, without its scattered global reads.  STAGED = false: rows beyond the LDS budget.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
                                                         const double *__restrict__ Tb,
                                                         const i32 *__restrict__ cm_off, const i32 *__restrict__ cm_mem,
                                                         i64 N, i64 C, int directed, double *__restrict__ rowbins) {
+    extern __shared__ __attribute__((aligned(16))) double prod[];
     const i64 i = blockIdx.x;
     const double ti = Ta[i];
     const double *row = GD + i * N;
+    const i64 j0 = directed ? 0 : i;
+    if (STAGED) {
+        for (i64 j = j0 + threadIdx.x; j < N; j += 256) prod[j - j0] = (ti * Tb[j]) * row[j];
+        __syncthreads();
+    }
     for (i64 cc = threadIdx.x; cc < C; cc += 256) {
         double s = 0.0;
         const i32 b = cm_off[cc], e = cm_off[cc + 1];
         for (i32 t = b; t < e; t++) {
             const i64 j = cm_mem[t];
-            if (directed || j >= i) s += (ti * Tb[j]) * row[j];
+            if (j >= j0) s += STAGED ? prod[j - j0] : (ti * Tb[j]) * row[j];
         }
         rowbins[i * C + cc] = s;
     }
@@ -222,8 +232,12 @@ void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, co
             const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB) {
     (void)comm;
     ScopedKernelTimer t(c, "bvec");
-    hipLaunchKernelGGL(bvec_rows_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off, cm_mem, N, C,
-                       directed, rowbins);
+    if (N * sizeof(double) <= 64 * 1024)
+        hipLaunchKernelGGL((bvec_rows_kernel<true>), dim3((unsigned)N), dim3(256), N * sizeof(double), c->stream, GD, Ta,
+                           Tb, cm_off, cm_mem, N, C, directed, rowbins);
+    else
+        hipLaunchKernelGGL((bvec_rows_kernel<false>), dim3((unsigned)N), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off,
+                           cm_mem, N, C, directed, rowbins);
     hipLaunchKernelGGL(bvec_bins_kernel, dim3(grid_for(C * C, 256)), dim3(256), 0, c->stream, rowbins, cm_off, cm_mem,
                        C, directed, vectB);
 }

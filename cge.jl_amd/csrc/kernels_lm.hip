@@ -457,30 +457,37 @@ __device__ __forceinline__ double scan_term(const double *__restrict__ x, double
     if (c < 2 * d) return w * x[c - d];
     return w;
 }
-// One pass: the inclusive prefix INSIDE each chunk (starting from 0) and the chunk total; a tiny second
-// kernel turns the totals of a task's chunks into exclusive offsets.  P[r] = prefix[r] + coff[chunk of r].
+// One pass: the inclusive prefix INSIDE each chunk (starting from 0), kept only at the end of every block of
+// CGE_PREFIX_STRIDE rows (the rounds kernel re-adds the few rows of a partial block in the same order, so every
+// P[r] has the bits of the full running sum at 1/8 of the write traffic), and the chunk total; a tiny second
+// kernel turns the totals of a task's chunks into exclusive offsets.  P[r] = prefix-in-chunk[r] + coff[chunk of r].
+// Block slots of chunk ch start at chunk_beg[ch] / STRIDE + ch (chunks never share a slot).
 __global__ void scan_write_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                   const i32 *__restrict__ srows, const i32 *__restrict__ chunk_beg,
                                   const i32 *__restrict__ chunk_end, i64 d, i64 W, double *__restrict__ ctot,
                                   double *__restrict__ prefix) {
+    constexpr int SB = CGE_PREFIX_STRIDE;
     const i64 ch = blockIdx.x;
     const i32 beg = chunk_beg[ch], end = chunk_end[ch];
+    double *slots = prefix + ((i64)(beg / SB) + ch) * W;
     for (i64 c = threadIdx.x; c < W; c += blockDim.x) {
         double run = 0.0;
         i32 j = beg;
-        for (; j + 3 < end; j += 4) { // 4 rows in flight
-            const i64 v0 = srows[j], v1 = srows[j + 1], v2 = srows[j + 2], v3 = srows[j + 3];
-            const double t0 = scan_term(Xr + v0 * d, vw[v0], c, d), t1 = scan_term(Xr + v1 * d, vw[v1], c, d);
-            const double t2 = scan_term(Xr + v2 * d, vw[v2], c, d), t3 = scan_term(Xr + v3 * d, vw[v3], c, d);
-            run += t0; prefix[(i64)j * W + c] = run;
-            run += t1; prefix[(i64)(j + 1) * W + c] = run;
-            run += t2; prefix[(i64)(j + 2) * W + c] = run;
-            run += t3; prefix[(i64)(j + 3) * W + c] = run;
+        i64 bi = 0;
+        for (; j + SB - 1 < end; j += SB, bi++) { // SB rows in flight
+            double t[SB];
+#pragma unroll
+            for (int q = 0; q < SB; q++) {
+                const i64 v = srows[j + q];
+                t[q] = scan_term(Xr + v * d, vw[v], c, d);
+            }
+#pragma unroll
+            for (int q = 0; q < SB; q++) run += t[q];
+            slots[bi * W + c] = run;
         }
         for (; j < end; j++) {
             const i64 v = srows[j];
             run += scan_term(Xr + v * d, vw[v], c, d);
-            prefix[(i64)j * W + c] = run;
         }
         ctot[ch * W + c] = run;
     }
@@ -529,9 +536,8 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
     const int lane = threadIdx.x;
     const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
     const double *z = zs + o;
-    const double *Ploc = prefix + o * W;                      // prefix inside each 1024-row chunk of the task
-    const double *Coff = coff + (i64)task_chunk_off[t] * W;   // exclusive offsets of the task's chunks
-    auto Pv = [&](i64 r, i64 cidx) { return Ploc[r * W + cidx] + Coff[(r / CGE_CHUNK_ROWS) * W + cidx]; };
+    const i64 tco = task_chunk_off[t];
+    const double *Coff = coff + tco * W; // exclusive offsets of the task's chunks
     i32 *rlog = rounds + t * 3 * RR_MAXROUNDS;
     // seeds: rank 0 (arg-min) and rank k-1 (arg-max), exact terms as :169-170
     double rl_ss[RR_SLOTS], rl_s[RR_SLOTS], rh_ss[RR_SLOTS], rh_s[RR_SLOTS];
@@ -548,18 +554,56 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
             rh_ss[s] = x2 * x2 * w2; rh_s[s] = x2 * w2;
         }
     }
-    // range sums S(a,b) = P[b-1] - P[a-1] for this lane's columns
-    auto range = [&](i64 a, i64 b, double (&ss)[RR_SLOTS], double (&s1)[RR_SLOTS], double &w) {
+    // inclusive prefix P[r] for this lane's columns: the stored running sum at the end of the previous block of
+    // the chunk, plus the rows of the partial block in scan order, plus the chunk offset (the same additions in the
+    // same order as a full running sum)
+    auto prefix_at = [&](i64 r, double (&ss)[RR_SLOTS], double (&s1)[RR_SLOTS], double &w) {
+        constexpr int SB = CGE_PREFIX_STRIDE;
+        const i64 chl = r / CGE_CHUNK_ROWS, cbeg = o + chl * CGE_CHUNK_ROWS, rin = r - chl * CGE_CHUNK_ROWS, bi = rin / SB;
+        const double *Sp = prefix + (cbeg / SB + tco + chl + (bi > 0 ? bi - 1 : 0)) * W;
 #pragma unroll
         for (int s = 0; s < RR_SLOTS; s++) {
             const i64 c = lane + 64 * s;
-            ss[s] = s1[s] = 0.0;
-            if (c < d && b > a) {
-                ss[s] = Pv(b - 1, c) - (a > 0 ? Pv(a - 1, c) : 0.0);
-                s1[s] = Pv(b - 1, d + c) - (a > 0 ? Pv(a - 1, d + c) : 0.0);
-            }
+            ss[s] = (c < d && bi > 0) ? Sp[c] : 0.0;
+            s1[s] = (c < d && bi > 0) ? Sp[d + c] : 0.0;
         }
-        w = (b > a) ? Pv(b - 1, 2 * d) - (a > 0 ? Pv(a - 1, 2 * d) : 0.0) : 0.0;
+        w = (bi > 0) ? Sp[2 * d] : 0.0;
+        for (i64 j = bi * SB; j <= rin; j++) {
+            const i64 v = srows[cbeg + j];
+            const double wv = vw[v];
+#pragma unroll
+            for (int s = 0; s < RR_SLOTS; s++) {
+                const i64 c = lane + 64 * s;
+                if (c < d) {
+                    const double xv = Xr[v * d + c];
+                    ss[s] += wv * (xv * xv);
+                    s1[s] += wv * xv;
+                }
+            }
+            w += wv;
+        }
+        const double *Cp = Coff + chl * W;
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; s++) {
+            const i64 c = lane + 64 * s;
+            if (c < d) { ss[s] += Cp[c]; s1[s] += Cp[d + c]; }
+        }
+        w += Cp[2 * d];
+    };
+    // range sums S(a,b) = P[b-1] - P[a-1] for this lane's columns
+    auto range = [&](i64 a, i64 b, double (&ss)[RR_SLOTS], double (&s1)[RR_SLOTS], double &w) {
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; s++) ss[s] = s1[s] = 0.0;
+        w = 0.0;
+        if (b <= a) return;
+        prefix_at(b - 1, ss, s1, w);
+        if (a > 0) {
+            double qs[RR_SLOTS], q1[RR_SLOTS], qw;
+            prefix_at(a - 1, qs, q1, qw);
+#pragma unroll
+            for (int s = 0; s < RR_SLOTS; s++) { ss[s] -= qs[s]; s1[s] -= q1[s]; }
+            w -= qw;
+        }
     };
     // sum over the columns of wsse(base + add)
     auto fsum = [&](const double (&bss)[RR_SLOTS], const double (&bs1)[RR_SLOTS], double bw, const double (&ass)[RR_SLOTS],
@@ -743,9 +787,10 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             a[r][jj] = (row < d && col < d) ? src[(size_t)col * d + row] : 0.0; // symmetric: coalesced along rows
         }
     }
-    // publish row kn of the matrix: X[col] = A[kn][col].  Row kn is read instead of column kn (the matrix stays
-    // bitwise symmetric: both triangles get the same update) because a row is spread over the waves' static column
-    // slots -- no dynamic register indexing.  Readers mask the part left of the sub-diagonal themselves.
+    // publish row kn of the matrix: X[col] = A[kn][col].  Row kn is read instead of column kn (the matrix is
+    // symmetric up to the rounding of the two fused updates, which is the rounding level of the method itself)
+    // because a row is spread over the waves' static column slots -- no dynamic register indexing.  Readers mask
+    // the part left of the sub-diagonal themselves.
     auto extract = [&](int kn) {
         if (lane == (kn & 63)) {
             if (NR > 1 && kn >= 64) {
@@ -831,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
                 if (jj % 8 == 0) asm volatile("" ::: "memory");
                 const double uj = U[NC * wv + jj], wj = W[NC * wv + jj];
 #pragma unroll
-                for (int r = 0; r < NR; r++) a[r][jj] -= u[r] * wj + w[r] * uj;
+                for (int r = 0; r < NR; r++) a[r][jj] = fma(-u[r], wj, fma(-w[r], uj, a[r][jj]));
             }
         }
         extract(k + 1);
@@ -895,67 +940,98 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
     }
     __syncthreads();
     if (diag_stage == 2) { if (tid < d) out[tid] = red[4]; return; } // timing diagnostic only
-    // ---- inverse iteration (one lane; O(d) per solve) ---------------------------------------------------------
-    if (tid == 0) {
+    // ---- inverse iteration (wave 0: lane 0 runs the O(d) recurrences with the carried values in registers, the
+    //      wave does the element-wise parts) ---------------------------------------------------------------------
+    if (wv == 0) {
         const double lam = red[4];
         double *dl = tri, *dd = tri + DP, *du = tri + 2 * DP, *du2 = tri + 3 * DP;
-        unsigned long long swp0 = 0ULL, swp1 = 0ULL; // pivot flags, d <= 128
-        for (int i = 0; i < d; i++) {
-            dd[i] = diag[i] - lam;
-            dl[i] = (i + 1 < d) ? off[i] : 0.0;
-            du[i] = (i + 1 < d) ? off[i] : 0.0;
-            du2[i] = 0.0;
-        }
-        for (int i = 0; i + 1 < d; i++) {
-            if (fabs(dd[i]) >= fabs(dl[i])) {
-                if (dd[i] == 0.0) dd[i] = tiny;
-                const double f = dl[i] / dd[i];
-                dl[i] = f;
-                dd[i + 1] -= f * du[i];
-            } else {
-                const double f = dd[i] / dl[i];
-                dd[i] = dl[i];
-                dl[i] = f;
-                const double t = du[i];
-                du[i] = dd[i + 1];
-                dd[i + 1] = t - f * dd[i + 1];
-                if (i + 2 < d) {
-                    du2[i] = du[i + 1];
-                    du[i + 1] = -f * du[i + 1];
-                }
-                if (i < 64) swp0 |= 1ULL << i; else swp1 |= 1ULL << (i - 64);
-            }
-        }
-        if (dd[d - 1] == 0.0) dd[d - 1] = tiny;
-        for (int i = 0; i < d; i++) dd[i] = fast_rcp(dd[i]); // the solves multiply by the reciprocal pivots
         double *y = V;
-        for (int i = 0; i < d; i++) y[i] = 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0;
-        for (int it = 0; it < 3; it++) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = lane + 64 * r;
+            dd[i] = (i < d) ? diag[i] - lam : 1.0;
+            dl[i] = du[i] = (i + 1 < d) ? off[i] : 0.0;
+            du2[i] = 0.0;
+            y[i] = (i < d) ? 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0 : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long swp0 = 0ULL, swp1 = 0ULL; // pivot flags, d <= 128 (lane 0)
+        if (lane == 0) { // LU with partial pivoting of the shifted tridiagonal matrix
+            double di = dd[0], ui = du[0];
             for (int i = 0; i + 1 < d; i++) {
-                const bool sw = (i < 64) ? ((swp0 >> i) & 1ULL) : ((swp1 >> (i - 64)) & 1ULL);
-                if (!sw)
-                    y[i + 1] -= dl[i] * y[i];
-                else {
-                    const double t = y[i];
-                    y[i] = y[i + 1];
-                    y[i + 1] = t - dl[i] * y[i];
+                const double li = dl[i], dn = dd[i + 1], un = du[i + 1];
+                if (fabs(di) >= fabs(li)) {
+                    if (di == 0.0) di = tiny;
+                    const double f = li * fast_rcp(di);
+                    dd[i] = di;
+                    dl[i] = f;
+                    du[i] = ui;
+                    di = dn - f * ui;
+                    ui = un;
+                } else {
+                    const double f = di * fast_rcp(li);
+                    dd[i] = li;
+                    dl[i] = f;
+                    du[i] = dn;
+                    di = ui - f * dn;
+                    if (i + 2 < d) du2[i] = un;
+                    ui = -f * un;
+                    if (i < 64) swp0 |= 1ULL << i; else swp1 |= 1ULL << (i - 64);
                 }
             }
-            y[d - 1] *= dd[d - 1];
-            y[d - 2] = (y[d - 2] - du[d - 2] * y[d - 1]) * dd[d - 2];
-            for (int i = d - 3; i >= 0; i--) y[i] = (y[i] - du[i] * y[i + 1] - du2[i] * y[i + 2]) * dd[i];
-            double amax = 0.0;
-            for (int i = 0; i < d; i++) amax = fmax(amax, fabs(y[i]));
-            if (!(amax > 0.0) || !(amax < 1e300)) {
-                for (int i = 0; i < d; i++) y[i] = (i == 0) ? 1.0 : 0.0;
+            if (di == 0.0) di = tiny;
+            dd[d - 1] = di;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < NR; r++) { // the solves multiply by the reciprocal pivots
+            const int i = lane + 64 * r;
+            if (i < d) dd[i] = fast_rcp(dd[i]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < 3; it++) {
+            if (lane == 0) {
+                double yi = y[0];
+                for (int i = 0; i + 1 < d; i++) { // forward: L with the recorded row swaps
+                    const bool sw = (i < 64) ? ((swp0 >> i) & 1ULL) : ((swp1 >> (i - 64)) & 1ULL);
+                    const double yn = y[i + 1], li = dl[i];
+                    y[i] = sw ? yn : yi;
+                    yi = sw ? yi - li * yn : yn - li * yi;
+                }
+                double y1 = yi * dd[d - 1]; // backward: U with two super-diagonals
+                y[d - 1] = y1;
+                double y0 = (y[d - 2] - du[d - 2] * y1) * dd[d - 2];
+                y[d - 2] = y0;
+                for (int i = d - 3; i >= 0; i--) {
+                    const double t = (y[i] - du[i] * y0 - du2[i] * y1) * dd[i];
+                    y[i] = t;
+                    y1 = y0;
+                    y0 = t;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            double yv[NR], amax = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                yv[r] = y[lane + 64 * r];
+                amax = fmax(amax, fabs(yv[r]));
+            }
+            for (int o2 = 32; o2 > 0; o2 >>= 1) amax = fmax(amax, __shfl_xor(amax, o2));
+            if (!(amax > 0.0) || !(amax < 1e300)) { // uniform over the wave
+#pragma unroll
+                for (int r = 0; r < NR; r++) y[lane + 64 * r] = (lane + 64 * r == 0) ? 1.0 : 0.0;
+                __builtin_amdgcn_wave_barrier();
                 break;
             }
-            double nrm = 0.0;
-            for (int i = 0; i < d; i++) { y[i] /= amax; nrm += y[i] * y[i]; }
-            nrm = sqrt(nrm);
-            for (int i = 0; i < d; i++) y[i] /= nrm;
+            const double ra = 1.0 / amax;
+            double part = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) { yv[r] *= ra; part += yv[r] * yv[r]; }
+            const double rn = 1.0 / sqrt(wave_allsum(part));
+#pragma unroll
+            for (int r = 0; r < NR; r++) y[lane + 64 * r] = yv[r] * rn;
+            __builtin_amdgcn_wave_barrier();
         }
-        for (int i = d; i < DP; i++) y[i] = 0.0;
     }
     __syncthreads();
     if (diag_stage == 3) { if (tid < d) out[tid] = V[tid]; return; } // timing diagnostic only
@@ -989,23 +1065,37 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        double nrm = 0.0;
-        for (int i = 0; i < d; i++) nrm += V[i] * V[i];
-        nrm = sqrt(nrm);
-        if (!(nrm > 0.0) || !(nrm < 1e300)) { // zero / degenerate matrix: any unit vector is an eigenvector
-            for (int i = 0; i < d; i++) V[i] = (i == 0) ? 1.0 : 0.0;
+    // normalise; sign: the component of largest magnitude (the first one on ties) is positive
+    if (wv == 0) {
+        double yv[NR], part = 0.0, best = -1.0;
+        int bi = 0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            yv[r] = V[lane + 64 * r]; // rows >= d are zero
+            part += yv[r] * yv[r];
+            if (fabs(yv[r]) > best) { best = fabs(yv[r]); bi = lane + 64 * r; }
+        }
+        double nrm = sqrt(wave_allsum(part));
+        const bool degenerate = !(nrm > 0.0) || !(nrm < 1e300); // zero matrix: any unit vector is an eigenvector
+        if (degenerate) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) { yv[r] = (lane + 64 * r == 0) ? 1.0 : 0.0; }
             nrm = 1.0;
+            best = (lane == 0) ? 1.0 : 0.0;
+            bi = lane;
         }
-        int big = 0;
-        for (int i = 0; i < d; i++) {
-            V[i] /= nrm;
-            if (fabs(V[i]) > fabs(V[big])) big = i;
+        double bv = best;
+        for (int o2 = 32; o2 > 0; o2 >>= 1) {
+            const double ob = __shfl_xor(bv, o2);
+            const int oi = __shfl_xor(bi, o2);
+            if (ob > bv || (ob == bv && oi < bi)) { bv = ob; bi = oi; }
         }
-        red[5] = (V[big] < 0.0) ? -1.0 : 1.0;
+        const double lead = (bi >= 64 && NR > 1) ? lane_value(yv[NR - 1], bi & 63) : lane_value(yv[0], bi & 63);
+        const double sg = ((lead < 0.0) ? -1.0 : 1.0) / nrm;
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+            if (lane + 64 * r < d) out[lane + 64 * r] = yv[r] * sg;
     }
-    __syncthreads();
-    if (tid < d) out[tid] = V[tid] * red[5];
 }
 bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec) {
     if (d > 128) return false; // beyond the register block: the caller uses the host solver

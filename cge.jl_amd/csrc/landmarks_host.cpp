@@ -614,7 +614,7 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const dou
     (void)z; // the projections are sorted on the device (c->ls_z); the host only needs the permutation
     PhaseAcc *pa = new PhaseAcc(c, "lm_cut_dev");
     c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_tro.ensure(T + 1); c->sp_perm.ensure(R); c->sp_status.ensure(T);
-    c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W); c->sp_prefix.ensure((size_t)R * W);
+    c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W); c->sp_prefix.ensure((size_t)(R / CGE_PREFIX_STRIDE + B.NC + 1) * W);
     c->sp_meta.ensure(2 * T); c->sp_rounds.ensure((size_t)T * 3 * CGE_RR_MAXROUNDS); c->sp_vals.ensure(2 * T);
     c->pin_perm.ensure(R);
     HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
