@@ -238,6 +238,7 @@ struct cge_ctx {
     // alpha-sweep scratch (grow-only: no hipMalloc/hipFree inside a scoring call after the first)
     DevBuf<double> sw_D, sw_GD, sw_T1, sw_T2, sw_S1, sw_S2, sw_rowbins, sw_vectB, sw_scal, sw_lohi, sw_fitstate, sw_mm;
     DevBuf<int> sw_flags;
+    DevBuf<unsigned long long> sw_fring; // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
     DevBuf<i32> sw_cm_off, sw_cm_mem;
     DevBuf<double> sw_zeros;
     // diameter scratch
@@ -258,8 +259,7 @@ struct cge_ctx {
     i64 stat_nref = 0; // reference points of the last pruned diameter (communities or landmarks)
     // scratch of the batched split engine (landmarks_host.cpp)
     DevBuf<i32> ls_rows, ls_row_task, ls_ct, ls_cb, ls_ce, ls_tco;
-    DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z, ls_sums, ls_Y;
-    DevBuf<i32> ls_yoff;
+    DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z, ls_sums;
     DevBuf<unsigned char> ls_side, ls_state;
     DevBuf<double> ls_params; // per-task round parameters of the rss rule
     PinBuf<double> pin_sums, pin_z, pin_params, pin_zs;
@@ -321,7 +321,7 @@ void k_group_mean(cge_ctx *c, const double *Xr, const double *vw, const i32 *row
                   i64 d, double *part, double *mean, double *sw);
 void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
                  const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
-                 i64 d, const double *mean, double *part, double *cov, double *Ybuf, const i32 *yoff);
+                 i64 d, const double *mean, double *part, double *cov);
 void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const unsigned char *side,
                        const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
                        i64 d, double *part, double *out);
@@ -373,6 +373,8 @@ void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, 
                         double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad);
 // alpha sweep
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD);
+void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
+                double delta, int k, unsigned long long *fring, int *done, int *iters);
 void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done);
 void k_fit_update(cge_ctx *c, double *T, const double *S, const double *w, i64 N, double eps, double delta, int *done,
                   int *iters, double *fout);

@@ -127,6 +127,7 @@ void k_row_hash(cge_ctx *c, const double *Xrow, uint64_t *hash, i64 n, i64 d) {
 // chunk partials are combined in chunk order (fixed order => reproducible).
 #define MAXSLOT 16 // columns handled per lane: d <= 64*MAXSLOT = 1024
 
+template <int NS> // NS = columns per lane (d <= 64*NS)
 __global__ __launch_bounds__(256) void group_mean_partial_kernel(const double *__restrict__ Xr,
                                                                  const double *__restrict__ vw,
                                                                  const i32 *__restrict__ rows,
@@ -141,14 +142,36 @@ __global__ __launch_bounds__(256) void group_mean_partial_kernel(const double *_
 #pragma unroll
     for (int s = 0; s < MAXSLOT; s++) acc[s] = 0.0;
     double wsum = 0.0;
-    for (i32 j = beg + wave; j < end; j += 4) {
+    constexpr int RF = NS <= 4 ? 4 : 1; // rows in flight per wave (the sums keep the row order)
+    i32 j = beg + wave;
+    for (; j + 4 * (RF - 1) < end; j += 4 * RF) {
+        double xv[RF][NS], w[RF];
+#pragma unroll
+        for (int q = 0; q < RF; q++) {
+            const i64 v = rows[j + 4 * q];
+            w[q] = vw[v];
+            const double *x = Xr + v * d;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const i64 col = lane + 64 * s;
+                xv[q][s] = (col < d) ? x[col] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RF; q++) {
+            wsum += w[q];
+#pragma unroll
+            for (int s = 0; s < NS; s++) acc[s] += xv[q][s] * w[q];
+        }
+    }
+    for (; j < end; j += 4) {
         const i64 v = rows[j];
         const double w = vw[v];
         wsum += w;
         const double *x = Xr + v * d;
 #pragma unroll
-        for (int s = 0; s < MAXSLOT; s++) {
-            i64 col = lane + 64 * s;
+        for (int s = 0; s < NS; s++) {
+            const i64 col = lane + 64 * s;
             if (col < d) acc[s] += x[col] * w;
         }
     }
@@ -192,8 +215,16 @@ void k_group_mean(cge_ctx *c, const double *Xr, const double *vw, const i32 *row
                   i64 d, double *part, double *mean, double *sw) {
     (void)chunk_task;
     if (d > 64 * MAXSLOT) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * MAXSLOT);
-    hipLaunchKernelGGL(group_mean_partial_kernel, dim3((unsigned)n_chunks), dim3(256), 0, c->stream, Xr, vw, rows,
-                       chunk_beg, chunk_end, d, part);
+    const dim3 grid((unsigned)n_chunks), block(256);
+#define CGE_MEAN_LAUNCH(NS)                                                                                            \
+    hipLaunchKernelGGL((group_mean_partial_kernel<NS>), grid, block, 0, c->stream, Xr, vw, rows, chunk_beg, chunk_end, d, \
+                       part)
+    if (d <= 64) CGE_MEAN_LAUNCH(1);
+    else if (d <= 128) CGE_MEAN_LAUNCH(2);
+    else if (d <= 256) CGE_MEAN_LAUNCH(4);
+    else if (d <= 512) CGE_MEAN_LAUNCH(8);
+    else CGE_MEAN_LAUNCH(16);
+#undef CGE_MEAN_LAUNCH
     hipLaunchKernelGGL(group_mean_final_kernel, dim3((unsigned)n_tasks), dim3(256), 0, c->stream, part,
                        task_chunk_off, d, mean, sw);
 }
@@ -261,52 +292,62 @@ __global__ __launch_bounds__(256) void group_cov_partial_kernel(const double *__
     }
 }
 // ---- covariance on the fp64 matrix cores (d >= 96) ----------------------------------------------------
-// (a) the centred, sqrt(w)-scaled rows y_j = (x_j - mu) * sqrt(w_j) of every chunk are written once,
-//     row-major with dp = d rounded up to 128 columns, each chunk padded with zero rows to a multiple of 16;
-// (b) A_chunk = Y^T Y is the same 128x128 MFMA Gram tile as the distance kernels, with the sample index as
-//     the contraction dimension (operand "k-row" = one sample, 128 contiguous features).
-__global__ __launch_bounds__(256) void group_center_rows_kernel(const double *__restrict__ Xr,
+// A_chunk = Y^T Y with y_j = (x_j - mu) * sqrt(w_j) (src/landmarks.jl:71-81,:97-98) is the same 128x128 MFMA Gram
+// tile as the distance kernels, with the sample index as the contraction dimension (operand "k-row" = one sample,
+// 128 contiguous features).  The rows are gathered from the embedding by vertex id, centred and scaled on the
+// way into LDS (no intermediate Y buffer); chunks are padded with zero rows to a multiple of 16.  A diagonal tile
+// (the only one when d <= 128) stages its operand once.
+template <bool SAME>
+__global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__restrict__ Xr,
                                                                 const double *__restrict__ vw,
                                                                 const i32 *__restrict__ rows,
                                                                 const i32 *__restrict__ chunk_task,
                                                                 const i32 *__restrict__ chunk_beg,
-                                                                const i32 *__restrict__ chunk_end,
-                                                                const i32 *__restrict__ yoff, i64 d, i64 dp,
+                                                                const i32 *__restrict__ chunk_end, i64 d, i64 nT,
                                                                 const double *__restrict__ mean,
-                                                                double *__restrict__ Y) {
-    const i64 ch = blockIdx.x;
-    const i32 beg = chunk_beg[ch], end = chunk_end[ch];
-    const i64 len = end - beg, len16 = (len + 15) / 16 * 16;
-    const double *mu = mean + (i64)chunk_task[ch] * d;
-    double *out = Y + (i64)yoff[ch] * dp;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (i64 r = wave; r < len16; r += 4) {
-        double *yr = out + r * dp;
-        if (r < len) {
-            const i64 v = rows[beg + r];
-            const double sq = sqrt(vw[v]);
-            const double *x = Xr + v * d;
-            for (i64 col = lane; col < dp; col += 64) yr[col] = (col < d) ? (x[col] - mu[col]) * sq : 0.0;
-        } else
-            for (i64 col = lane; col < dp; col += 64) yr[col] = 0.0;
-    }
-}
-__global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__restrict__ Y,
-                                                                const i32 *__restrict__ chunk_beg,
-                                                                const i32 *__restrict__ chunk_end,
-                                                                const i32 *__restrict__ yoff, i64 d, i64 dp,
                                                                 double *__restrict__ part /* [chunk][d*d] */) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ i32 s_row[CGE_CHUNK_ROWS];
+    __shared__ double s_sq[CGE_CHUNK_ROWS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4, c2 = lane * 2;
     const i64 ch = blockIdx.x;
-    const i64 nT = dp / 128;
-    const i64 a0 = (blockIdx.y / nT) * 128, b0 = (blockIdx.y % nT) * 128;
-    const i64 len16 = ((i64)(chunk_end[ch] - chunk_beg[ch]) + 15) / 16 * 16;
-    const double *base = Y + (i64)yoff[ch] * dp;
+    i64 ta, tb; // tile pair: all of them, or (SAME) the diagonal ones
+    if (SAME) { ta = tb = blockIdx.y; } else { ta = blockIdx.y / nT; tb = blockIdx.y % nT; if (ta == tb) return; }
+    const i64 a0 = ta * 128, b0 = tb * 128;
+    const i32 beg = chunk_beg[ch];
+    const i64 len = chunk_end[ch] - beg, len16 = (len + 15) / 16 * 16;
+    for (i64 r = tid; r < len; r += 256) {
+        const i32 v = rows[beg + r];
+        s_row[r] = v;
+        s_sq[r] = sqrt(vw[v]);
+    }
+    const double *mu = mean + (i64)chunk_task[ch] * d;
+    const i64 ca = a0 + c2, cb = b0 + c2;
+    const bool pair_ok = (d & 1) == 0; // 16-byte aligned pairs
+    const double ma0 = ca < d ? mu[ca] : 0.0, ma1 = ca + 1 < d ? mu[ca + 1] : 0.0;
+    const double mb0 = (!SAME && cb < d) ? mu[cb] : 0.0, mb1 = (!SAME && cb + 1 < d) ? mu[cb + 1] : 0.0;
+    __syncthreads();
+    auto load = [&](i64 kc, int q, i64 col, double m0, double m1) {
+        const i64 kr = kc * MP_BK + wave + 4 * q;
+        d2 y = (d2){0.0, 0.0};
+        if (kr < len) {
+            const double *x = Xr + (i64)s_row[kr] * d + col;
+            const double sq = s_sq[kr];
+            if (pair_ok && col + 1 < d) {
+                const d2 xv = *reinterpret_cast<const d2 *>(x);
+                y = (d2){(xv[0] - m0) * sq, (xv[1] - m1) * sq};
+            } else {
+                if (col < d) y[0] = (x[0] - m0) * sq;
+                if (col + 1 < d) y[1] = (x[1] - m1) * sq;
+            }
+        }
+        return y;
+    };
     d4 acc[4][4];
-    gram_tile_128(base + (i64)wave * dp + a0 + c2, base + (i64)wave * dp + b0 + c2, dp, dp, len16 / MP_BK, lds, acc, wave,
-                  c2, wr, wc, lr, lk);
+    gram_tile_128_ld<SAME>([&](i64 kc, int q) { return load(kc, q, ca, ma0, ma1); },
+                           [&](i64 kc, int q) { return load(kc, q, cb, mb0, mb1); }, len16 / MP_BK, lds, acc, wave, c2, wr,
+                           wc, lr, lk);
     double *out = part + ch * d * d;
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -330,15 +371,16 @@ __global__ void group_cov_final_kernel(const double *__restrict__ part, const i3
 }
 void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
                  const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
-                 i64 d, const double *mean, double *part, double *cov, double *Ybuf, const i32 *yoff) {
+                 i64 d, const double *mean, double *part, double *cov) {
     dim3 grid((unsigned)n_chunks), block(256);
-    if (Ybuf && yoff && d >= 96) { // fp64 MFMA SYRK
-        const i64 dp = (d + 127) / 128 * 128, nT = dp / 128;
-        hipLaunchKernelGGL(group_center_rows_kernel, grid, block, 0, c->stream, Xr, vw, rows, chunk_task, chunk_beg,
-                           chunk_end, yoff, d, dp, mean, Ybuf);
-        hipLaunchKernelGGL(group_cov_mfma_kernel, dim3((unsigned)n_chunks, (unsigned)(nT * nT)), block,
-                           (size_t)2 * 2 * MP_BK * MP_LD * sizeof(double), c->stream, Ybuf, chunk_beg, chunk_end, yoff, d,
-                           dp, part);
+    if (d >= 96) { // fp64 MFMA SYRK
+        const i64 nT = (d + 127) / 128;
+        const size_t stage = (size_t)2 * MP_BK * MP_LD * sizeof(double);
+        hipLaunchKernelGGL((group_cov_mfma_kernel<true>), dim3((unsigned)n_chunks, (unsigned)nT), block, stage, c->stream,
+                           Xr, vw, rows, chunk_task, chunk_beg, chunk_end, d, nT, mean, part);
+        if (nT > 1)
+            hipLaunchKernelGGL((group_cov_mfma_kernel<false>), dim3((unsigned)n_chunks, (unsigned)(nT * nT)), block,
+                               2 * stage, c->stream, Xr, vw, rows, chunk_task, chunk_beg, chunk_end, d, nT, mean, part);
     } else {
         const int dpv = (int)((d + 7) / 8 * 8);
         int RT = 64;
@@ -452,11 +494,6 @@ void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32
 // inclusive prefix sums P[r] = sum_{q<=r} (w x^2 [d], w x [d], w) over the rows in sorted order, the WSSE
 // triple of any range is P[b-1] - P[a-1], so the whole median-cut loop runs in one small kernel.
 // srows = vertex ids in (task, ascending z) order; W = 2d+1.
-__device__ __forceinline__ double scan_term(const double *__restrict__ x, double w, i64 c, i64 d) {
-    if (c < d) { const double xv = x[c]; return w * (xv * xv); }
-    if (c < 2 * d) return w * x[c - d];
-    return w;
-}
 // One pass: the inclusive prefix INSIDE each chunk (starting from 0), kept only at the end of every block of
 // CGE_PREFIX_STRIDE rows (the rounds kernel re-adds the few rows of a partial block in the same order, so every
 // P[r] has the bits of the full running sum at 1/8 of the write traffic), and the chunk total; a tiny second
@@ -470,26 +507,39 @@ __global__ void scan_write_kernel(const double *__restrict__ Xr, const double *_
     const i64 ch = blockIdx.x;
     const i32 beg = chunk_beg[ch], end = chunk_end[ch];
     double *slots = prefix + ((i64)(beg / SB) + ch) * W;
-    for (i64 c = threadIdx.x; c < W; c += blockDim.x) {
-        double run = 0.0;
+    // thread c < d owns columns c (w x^2) and d + c (w x): one load of x per row; thread 0 also owns column 2d (w)
+    for (i64 c = threadIdx.x; c < d; c += blockDim.x) {
+        double run_ss = 0.0, run_s = 0.0, run_w = 0.0;
         i32 j = beg;
         i64 bi = 0;
         for (; j + SB - 1 < end; j += SB, bi++) { // SB rows in flight
-            double t[SB];
+            double xv[SB], wv[SB];
 #pragma unroll
             for (int q = 0; q < SB; q++) {
                 const i64 v = srows[j + q];
-                t[q] = scan_term(Xr + v * d, vw[v], c, d);
+                wv[q] = vw[v];
+                xv[q] = Xr[v * d + c];
             }
 #pragma unroll
-            for (int q = 0; q < SB; q++) run += t[q];
-            slots[bi * W + c] = run;
+            for (int q = 0; q < SB; q++) {
+                run_ss += wv[q] * (xv[q] * xv[q]);
+                run_s += wv[q] * xv[q];
+                run_w += wv[q];
+            }
+            slots[bi * W + c] = run_ss;
+            slots[bi * W + d + c] = run_s;
+            if (c == 0) slots[bi * W + 2 * d] = run_w;
         }
         for (; j < end; j++) {
             const i64 v = srows[j];
-            run += scan_term(Xr + v * d, vw[v], c, d);
+            const double w = vw[v], xv = Xr[v * d + c];
+            run_ss += w * (xv * xv);
+            run_s += w * xv;
+            run_w += w;
         }
-        ctot[ch * W + c] = run;
+        ctot[ch * W + c] = run_ss;
+        ctot[ch * W + d + c] = run_s;
+        if (c == 0) ctot[ch * W + 2 * d] = run_w;
     }
 }
 __global__ void scan_chunk_offsets_kernel(const double *__restrict__ ctot, const i32 *__restrict__ task_chunk_off, i64 W,
@@ -508,9 +558,9 @@ void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *
                      const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks, i64 d, double *ctot,
                      double *coff, double *prefix) {
     const i64 W = 2 * d + 1;
-    const int bs = (int)std::min<i64>(1024, (W + 63) / 64 * 64);
+    const int bs = (int)std::min<i64>(1024, (W + 63) / 64 * 64), bs1 = (int)std::min<i64>(1024, (d + 63) / 64 * 64);
     ScopedKernelTimer t(c, "sorted_prefix");
-    hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)n_chunks), dim3(bs), 0, c->stream, Xr, vw, srows, chunk_beg,
+    hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)n_chunks), dim3(bs1), 0, c->stream, Xr, vw, srows, chunk_beg,
                        chunk_end, d, W, ctot, prefix);
     hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3((unsigned)n_tasks), dim3(bs), 0, c->stream, ctot, task_chunk_off,
                        W, coff);

@@ -724,22 +724,8 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                 ScopedKernelTimer tm(c, "group_stats");
                 k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                              c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
-                double *Ybuf = nullptr;
-                if (d >= 96) { // MFMA SYRK: compact row buffer, every chunk padded to a multiple of 16 rows
-                    std::vector<i32> yoff(NC);
-                    i64 ypos = 0;
-                    for (i64 q = 0; q < NC; q++) {
-                        yoff[q] = (i32)ypos;
-                        ypos += ((i64)(B.chunk_end[q] - B.chunk_beg[q]) + 15) / 16 * 16;
-                    }
-                    c->ls_yoff.ensure(NC);
-                    c->ls_Y.ensure((size_t)ypos * ((d + 127) / 128 * 128));
-                    HIP_CHECK(hipMemcpyAsync(c->ls_yoff.p, yoff.data(), sizeof(i32) * NC, hipMemcpyHostToDevice, st));
-                    HIP_CHECK(hipStreamSynchronize(st)); // yoff goes out of scope
-                    Ybuf = c->ls_Y.p;
-                }
                 k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
-                            c->ls_mean.p, c->ls_part.p, c->ls_cov.p, Ybuf, c->ls_yoff.p);
+                            c->ls_mean.p, c->ls_part.p, c->ls_cov.p);
             }
             if (!k_group_eig(c, c->ls_cov.p, T, d, c->ls_vec.p)) { // d > 128: host solver on a worker pool
                 std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d);

@@ -15,14 +15,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define MP_SB 32           // super-block edge in tiles
 
 
-// One 128x128 Gram tile G = A_tile * B_tile^T over the whole feature dimension.
-// pa/pb: this thread's first load address (operand base + wave*ld + tile offset + 2*lane); a k-row of
-// a tile is 128 contiguous doubles; chunk kc covers k-rows [kc*MP_BK, (kc+1)*MP_BK).
-// LDS: 2 stages x (A,B) x MP_BK x MP_LD doubles.  All 256 threads must call it (barriers inside).
-__device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, const double *__restrict__ pb, i64 lda,
-                                              i64 ldb, i64 nchunk, double *lds, d4 (&acc)[4][4], int wave, int c2,
-                                              int wr, int wc, int lr, int lk) {
-    const size_t stage_doubles = (size_t)2 * MP_BK * MP_LD;
+// One 128x128 Gram tile G = A_tile * B_tile^T over the whole contraction dimension, operands delivered by
+// loader functors: la(kc, q) / lb(kc, q) return this thread's two adjacent elements (columns c2, c2+1 of the
+// tile) of k-row kc*MP_BK + wave + 4q.  SAME = true: B is A (a diagonal tile of a SYRK) -- staged once.
+// LDS: 2 stages x (A[,B]) x MP_BK x MP_LD doubles.  All 256 threads must call it (barriers inside).
+template <bool SAME, class LA, class LB>
+__device__ __forceinline__ void gram_tile_128_ld(LA la, LB lb, i64 nchunk, double *lds, d4 (&acc)[4][4], int wave,
+                                                 int c2, int wr, int wc, int lr, int lk) {
+    const size_t stage_doubles = (size_t)(SAME ? 1 : 2) * MP_BK * MP_LD;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -30,8 +30,8 @@ __device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, con
     d2 ra[4], rb[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        ra[q] = *reinterpret_cast<const d2 *>(pa + (i64)(4 * q) * lda);
-        rb[q] = *reinterpret_cast<const d2 *>(pb + (i64)(4 * q) * ldb);
+        ra[q] = la((i64)0, q);
+        if (!SAME) rb[q] = lb((i64)0, q);
     }
     __syncthreads(); // the previous tile's readers are done with both stages
     {
@@ -39,7 +39,7 @@ __device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, con
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             *reinterpret_cast<d2 *>(As + (wave + 4 * q) * MP_LD + c2) = ra[q];
-            *reinterpret_cast<d2 *>(Bs + (wave + 4 * q) * MP_LD + c2) = rb[q];
+            if (!SAME) *reinterpret_cast<d2 *>(Bs + (wave + 4 * q) * MP_LD + c2) = rb[q];
         }
     }
     __syncthreads();
@@ -49,12 +49,12 @@ __device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, con
         if (more) { // issue the next chunk's global loads; they land while the MFMAs run
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                ra[q] = *reinterpret_cast<const d2 *>(pa + ((kc + 1) * MP_BK + 4 * q) * lda);
-                rb[q] = *reinterpret_cast<const d2 *>(pb + ((kc + 1) * MP_BK + 4 * q) * ldb);
+                ra[q] = la(kc + 1, q);
+                if (!SAME) rb[q] = lb(kc + 1, q);
             }
         }
         const double *As = lds + (size_t)s * stage_doubles;
-        const double *Bs = As + (size_t)MP_BK * MP_LD;
+        const double *Bs = SAME ? As : As + (size_t)MP_BK * MP_LD;
 #pragma unroll
         for (int ks = 0; ks < MP_BK / 4; ks++) {
             double af[4], bf[4];
@@ -74,10 +74,20 @@ __device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, con
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 *reinterpret_cast<d2 *>(An + (wave + 4 * q) * MP_LD + c2) = ra[q];
-                *reinterpret_cast<d2 *>(Bn + (wave + 4 * q) * MP_LD + c2) = rb[q];
+                if (!SAME) *reinterpret_cast<d2 *>(Bn + (wave + 4 * q) * MP_LD + c2) = rb[q];
             }
         }
         __syncthreads();
     }
 }
 
+// The dense-operand form: pa/pb = this thread's first load address (operand base + wave*ld + tile offset +
+// 2*lane); a k-row of a tile is 128 contiguous doubles; chunk kc covers k-rows [kc*MP_BK, (kc+1)*MP_BK).
+__device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, const double *__restrict__ pb, i64 lda,
+                                              i64 ldb, i64 nchunk, double *lds, d4 (&acc)[4][4], int wave, int c2,
+                                              int wr, int wc, int lr, int lk) {
+    gram_tile_128_ld<false>(
+        [&](i64 kc, int q) { return *reinterpret_cast<const d2 *>(pa + (kc * MP_BK + 4 * q) * lda); },
+        [&](i64 kc, int q) { return *reinterpret_cast<const d2 *>(pb + (kc * MP_BK + 4 * q) * ldb); }, nchunk, lds, acc,
+        wave, c2, wr, wc, lr, lk);
+}

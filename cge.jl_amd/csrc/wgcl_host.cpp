@@ -4,6 +4,7 @@
 // reference runs in kernels_fit.hip / kernels_dist.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "common.hpp"
 
@@ -159,6 +160,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     lohi.ensure(2);
     fitstate.ensure(4);
     flags.ensure(4);
+    c->sw_fring.ensure(4);
 
     // D and its normalisation (:79-93 / :359-375)
     k_dist_matrix(c, G.emb, G.dist, N, d, D.p);
@@ -200,7 +202,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     HIP_CHECK(hipMemcpyAsync(T1.p, hT1.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(T2.p, hT2.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    const double *Tin = T1.p, *Tout = T2.p; // undirected uses T1 only
+    const double *Tin = T1.p, *Tout = T2.p; // undirected: T alternates between T1 and T2, Tcur = the current iterate
+    double *Tcur = T1.p;
 
     // ---- samples -> device ---------------------------------------------------------------------
     const bool landmarks = orig != nullptr;
@@ -273,16 +276,35 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         }
         i64 iters = 0;
         i64 batch = std::max<i64>(4, std::min<i64>(prev_iters, 128));
+        if (!directed) {
+            // one launch per iteration (kernels_fit.hip: fit_step_kernel); T alternates between T1 and T2
+            HIP_CHECK(hipMemsetAsync(c->sw_fring.p, 0, sizeof(unsigned long long) * 4, st));
+            double *Tb2[2] = {Tcur, Tcur == T1.p ? T2.p : T1.p};
+            i64 k = 0;
+            for (;;) {
+                for (i64 b = 0; b < batch; b++, k++)
+                    k_fit_step(c, GD.p, Tb2[k & 1], Tb2[(k + 1) & 1], G.vw, N, 0.25, delta, (int)k, c->sw_fring.p, flags.p,
+                               flags.p + 1);
+                int hf[2];
+                unsigned long long hr[3];
+                HIP_CHECK(hipMemcpyAsync(hf, flags.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipMemcpyAsync(hr, c->sw_fring.p, sizeof(hr), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                iters = hf[1];
+                if (hf[0]) break;
+                double flast;
+                std::memcpy(&flast, &hr[(k - 1) % 3], sizeof(double));
+                if (!(flast > delta)) break; // the last launch of the batch was the converging iteration (iters == k)
+                if (iters > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g", alpha);
+                batch = std::max<i64>(4, std::min<i64>(batch, 32));
+            }
+            Tcur = Tb2[iters & 1];
+        } else
         for (;;) {
             for (i64 b = 0; b < batch; b++) {
-                if (!directed) {
-                    k_fit_symv(c, GD.p, T1.p, N, S1.p, flags.p);
-                    k_fit_update(c, T1.p, S1.p, G.vw, N, 0.25, delta, flags.p, flags.p + 1, scal.p + 8);
-                } else {
-                    k_fit_symv_dir(c, GD.p, T1.p, T2.p, N, S1.p, S2.p, flags.p);
-                    k_fit_update_dir(c, T1.p, T2.p, S1.p, S2.p, G.deg_in, G.deg_out, N, delta, flags.p, flags.p + 1,
-                                     fitstate.p);
-                }
+                k_fit_symv_dir(c, GD.p, T1.p, T2.p, N, S1.p, S2.p, flags.p);
+                k_fit_update_dir(c, T1.p, T2.p, S1.p, S2.p, G.deg_in, G.deg_out, N, delta, flags.p, flags.p + 1,
+                                 fitstate.p);
             }
             int hf[2];
             HIP_CHECK(hipMemcpyAsync(hf, flags.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
@@ -295,7 +317,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         prev_iters = iters;
 
         double auc_val = NAN, div_val = NAN, div_int = 0.0, div_ext = 0.0;
-        const double *Ta = directed ? Tout : T1.p, *Tb = directed ? Tin : T1.p;
+        const double *Ta = directed ? Tout : Tcur, *Tb = directed ? Tin : Tcur;
         if (!skip_auc) {
             const DevSamples &ds = dsets[smp.n_sets == 1 ? 0 : ia - 1];
             if (landmarks)
