@@ -851,6 +851,11 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_diameter = (int)value;
         return CGE_OK;
     }
+    if (!strcmp(key, "fit_persistent")) { // 0 auto, 1 never, 2 whenever the score graph fits the register file
+        if (value < 0 || value > 2) return CGE_E_ARG;
+        c->opt_fit_persistent = (int)value;
+        return CGE_OK;
+    }
     return CGE_E_ARG;
 }
 int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
@@ -860,6 +865,7 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "diameter_candidate_pairs")) *value = c->stat_cand_pairs;
     else if (!strcmp(key, "diameter_candidate_tiles")) *value = c->stat_cand_tiles;
     else if (!strcmp(key, "diameter_refs")) *value = c->stat_nref;
+    else if (!strcmp(key, "fit_persistent_alphas")) *value = c->stat_fit_persistent;
     else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`
     else return CGE_E_ARG;
     return CGE_OK;

@@ -238,7 +238,13 @@ struct cge_ctx {
     // alpha-sweep scratch (grow-only: no hipMalloc/hipFree inside a scoring call after the first)
     DevBuf<double> sw_D, sw_GD, sw_T1, sw_T2, sw_S1, sw_S2, sw_rowbins, sw_vectB, sw_scal, sw_lohi, sw_fitstate, sw_mm;
     DevBuf<int> sw_flags;
-    DevBuf<unsigned long long> sw_fring; // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
+    DevBuf<unsigned long long> sw_fring;
+    // persistent Chung-Lu fit (kernels_fitp.hip): T double buffer, partial vectors, per-workgroup maxima, barrier words
+    DevBuf<double> fp_T, fp_Tsave, fp_P, fp_fpart;
+    DevBuf<unsigned> fp_sync;
+    DevBuf<int> fp_flags;
+    int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it fits
+    i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
     DevBuf<i32> sw_cm_off, sw_cm_mem;
     DevBuf<double> sw_zeros;
     // diameter scratch
@@ -373,6 +379,8 @@ void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, 
                         double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad);
 // alpha sweep
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD);
+bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
+                      double delta, i64 *iters, int *final_parity);
 void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
                 double delta, int k, unsigned long long *fring, int *done, int *iters);
 void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done);

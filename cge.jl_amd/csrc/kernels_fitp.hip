@@ -1,0 +1,309 @@
+// kernels_fitp.hip -- the undirected Chung-Lu fixed point (src/divergence.jl:150-168) as ONE persistent launch
+// per alpha: the upper triangle of GD = (1 - D)^alpha lives in REGISTERS for the whole fit.
+//
+// Why: one iteration streams 8*N*(N+1)/2 algorithmic bytes (64 MB at N = 4000) for 2 flops per byte, a thousand
+// times per score.  As one launch per iteration that is ~20 us of Infinity-Cache traffic plus a launch boundary;
+// here the matrix is read once per alpha and an iteration costs two grid barriers plus a few KB of exchange.
+//
+// Layout.  The matrix is cut into 64 x 64 tiles; tile (I, J), I <= J, belongs to one wave (tile t -> wave t mod 4G,
+// slot t / 4G; G workgroups of 4 waves, at most TPW slots per wave).  Inside a tile lane l = 8*rq + cq holds the
+// 8 x 8 block rows 8*rq.., columns 8*cq.. (64 doubles).  One pass over the block gives both products of the
+// symmetric pair: p = (T_i*T_j)*g_ij is added to the row sum of i and to the column sum of j (the reference's own
+// product, src/divergence.jl:155-158).  The 8 partial rows / columns of a lane are combined across the 8 lanes that
+// share rq / cq by a transposing butterfly (4 + 2 + 1 exchanges), which leaves one finished row (column) per lane.
+//
+// An iteration:  A) every wave: tile products -> partial vectors P[block][other block][64] (write-through stores);
+//                   grid barrier;
+//                B) workgroup sb (one 16-row quarter of a block): S_i = sum of the block's Nt partial vectors in a
+//                   fixed order, T_i += eps*T_i*(w_i/S_i - 1), f = max|w_i - S_i| (:160-166); grid barrier;
+//                C) every workgroup reloads T (N doubles) and the G per-workgroup maxima; `while f > delta`.
+// Every value that crosses workgroups is stored and loaded with agent-scope relaxed atomics (sc1: write-through
+// stores, L1-bypassing loads), every storing wave drains its stores before its workgroup signals
+// (cdna_hip_programming.md, Guideline 16); the barrier is one monotonic counter.  Every spin is bounded: on a
+// timeout the launch sets `fail`, every workgroup leaves, and the host falls back to one launch per iteration.
+// All sums have a fixed order: a run is bitwise reproducible.
+#include <hip/hip_cooperative_groups.h>
+
+#include "common.hpp"
+
+namespace {
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, RLX_AGENT); }
+__device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, RLX_AGENT); }
+
+// combine v[0..8) across the 8 lanes that differ in lane bits SH, SH+1, SH+2: afterwards the lane whose three bits
+// spell q holds sum_lanes v[q].  Additions are pairwise in a fixed tree.
+template <int SH>
+__device__ __forceinline__ double transpose_reduce8(const double (&v)[8], int lane) {
+    double w4[4], w2[2];
+    const bool h2 = (lane >> (SH + 2)) & 1, h1 = (lane >> (SH + 1)) & 1, h0 = (lane >> SH) & 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const double keep = h2 ? v[q + 4] : v[q], send = h2 ? v[q] : v[q + 4];
+        w4[q] = keep + __shfl_xor(send, 4 << SH);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const double keep = h1 ? w4[q + 2] : w4[q], send = h1 ? w4[q] : w4[q + 2];
+        w2[q] = keep + __shfl_xor(send, 2 << SH);
+    }
+    const double keep = h0 ? w2[1] : w2[0], send = h0 ? w2[0] : w2[1];
+    return keep + __shfl_xor(send, 1 << SH);
+}
+
+// ---- grid barrier ------------------------------------------------------------------------------------------------
+// Two levels, so that the 256 arrivals do not serialise on one address: workgroups are grouped by the XCD they run
+// on (read from the hardware register; any grouping would be correct, this one keeps the arrivals and the release
+// of a group inside one L2).  The last arriver of a group adds to the top counter, waits for all groups, then bumps
+// its group's generation word, which the rest of the group polls.  Counters are monotonic (epoch e = 1, 2, ...),
+// each on its own 128-byte line, zeroed by the host before the launch.  Group sizes are counted in the kernel's
+// first barrier, which is a flat one.  Every spin is bounded by `deadline`; a timeout sets `fail` for everybody.
+#define SYNC_WORDS 1024 // unsigned words zeroed per launch
+struct GridSync {
+    unsigned *flat, *fail, *top, *garr, *ggen, *gcount; // garr/ggen/gcount: 8 entries, 32 words apart
+    unsigned gsize, ngroups, epoch;
+    int xcc;
+    long long deadline;
+    int *lds_ok;
+
+    __device__ __forceinline__ bool spin_until(unsigned *word, unsigned target) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(word, RLX_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0 && (wall_clock64() > deadline || __hip_atomic_load(fail, RLX_AGENT) != 0u)) {
+                __hip_atomic_store(fail, 1u, RLX_AGENT);
+                return false;
+            }
+        }
+        return true;
+    }
+    // the launch's first barrier: flat, and it counts the groups
+    __device__ __forceinline__ bool init(unsigned *sync, long long dl, int *ok_word) {
+        flat = sync; fail = sync + 1; top = sync + 32; garr = sync + 64; ggen = sync + 64 + 256; gcount = sync + 64 + 512;
+        deadline = dl; lds_ok = ok_word; epoch = 0;
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(id));
+        xcc = (int)(id & 7u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(gcount + 32 * xcc, 1u, RLX_AGENT);
+            __hip_atomic_fetch_add(flat, 1u, RLX_AGENT);
+            *lds_ok = spin_until(flat, gridDim.x) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!*lds_ok) return false;
+        gsize = __hip_atomic_load(gcount + 32 * xcc, RLX_AGENT);
+        ngroups = 0;
+        for (int x = 0; x < 8; x++) ngroups += __hip_atomic_load(gcount + 32 * x, RLX_AGENT) != 0u;
+        return true;
+    }
+    // all workgroups arrive; false = timed out (the launch is abandoned)
+    __device__ __forceinline__ bool sync() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its write-through stores have left
+        __syncthreads();
+        epoch++;
+        if (threadIdx.x == 0) {
+            int good = 1;
+            const unsigned before = __hip_atomic_fetch_add(garr + 32 * xcc, 1u, RLX_AGENT);
+            if (before + 1 == gsize * epoch) { // last of the group
+                __hip_atomic_fetch_add(top, 1u, RLX_AGENT);
+                good = spin_until(top, ngroups * epoch) ? 1 : 0;
+                __hip_atomic_store(ggen + 32 * xcc, epoch, RLX_AGENT);
+            } else
+                good = spin_until(ggen + 32 * xcc, epoch) ? 1 : 0;
+            *lds_ok = good;
+        }
+        __syncthreads();
+        return *lds_ok != 0;
+    }
+};
+
+template <int TPW>
+__global__ __launch_bounds__(256) void fit_persistent_kernel(const double *__restrict__ GD, i64 N, int Nt, double *Tbuf,
+                                                             i64 Tld, int parity, const double *__restrict__ w,
+                                                             double eps, double delta, int max_iters, double *P,
+                                                             double *fpart, unsigned *sync, int *flags,
+                                                             long long timeout_ticks) {
+    extern __shared__ __attribute__((aligned(16))) double Ts[]; // Nt*64 doubles: the current T, zero beyond N
+    __shared__ double red[16][17];
+    __shared__ double fred[4];
+    __shared__ int lds_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
+    const int rq = lane >> 3, cq = lane & 7;
+    const int NT = Nt * (Nt + 1) / 2;
+    GridSync gs;
+
+    // ---- the wave's tiles into registers ---------------------------------------------------------------------
+    double g[TPW][8][8];
+    int tI[TPW], tJ[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+        const int t = (wg * 4 + wave) + s * 4 * G;
+        tI[s] = -1;
+        tJ[s] = -1;
+        if (t < NT) { // row-major upper triangle: row I holds Nt - I tiles
+            int I = 0, rem = t;
+            while (rem >= Nt - I) { rem -= Nt - I; I++; }
+            tI[s] = I;
+            tJ[s] = I + rem;
+        }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const i64 row = (i64)64 * tI[s] + 8 * rq + a;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const i64 col = (i64)64 * tJ[s] + 8 * cq + b;
+                g[s][a][b] = (tI[s] >= 0 && row < N && col < N) ? GD[row * N + col] : 0.0;
+            }
+        }
+    }
+    const int Np = Nt * 64;
+    for (int i = tid; i < Np; i += 256) Ts[i] = Tbuf[(i64)parity * Tld + i]; // written before the launch
+    __syncthreads();
+
+    int par = parity, k = 0, converged = 0, failed = 0;
+    if (!gs.init(sync, wall_clock64() + timeout_ticks, &lds_ok)) { failed = 1; max_iters = 0; }
+    while (k < max_iters) {
+        // ---- A: tile products ----------------------------------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < TPW; s++) {
+            if (tI[s] < 0) continue; // uniform per wave
+            const int I = tI[s], J = tJ[s];
+            double ti[8], tj[8], pr[8], pc[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                ti[q] = Ts[64 * I + 8 * rq + q];
+                tj[q] = Ts[64 * J + 8 * cq + q];
+                pr[q] = 0.0;
+                pc[q] = 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const double p = (ti[a] * tj[b]) * g[s][a][b];
+                    pr[a] += p;
+                    pc[b] += p;
+                }
+            const double rsum = transpose_reduce8<0>(pr, lane); // row 8*rq + cq of the tile
+            st_sc1(P + ((i64)I * Nt + J) * 64 + lane, rsum);
+            if (I != J) {
+                const double csum = transpose_reduce8<3>(pc, lane); // column 8*cq + rq of the tile
+                st_sc1(P + ((i64)J * Nt + I) * 64 + 8 * cq + rq, csum);
+            }
+        }
+        if (!gs.sync()) { failed = 1; break; }
+        // ---- B: S, the update and f for this workgroup's quarter blocks -------------------------------------------
+        double fmine = 0.0;
+        for (int sb = wg; sb < 4 * Nt; sb += G) {
+            const int b = sb >> 2, r = tid & 15, qg = tid >> 4, rib = 16 * (sb & 3) + r;
+            double pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int q = qg + 16 * u;
+                pv[u] = (q < Nt) ? ld_sc1(P + ((i64)b * Nt + q) * 64 + rib) : 0.0;
+            }
+            __syncthreads(); // red is free again
+            red[qg][r] = ((pv[0] + pv[1]) + pv[2]) + pv[3];
+            __syncthreads();
+            if (qg == 0) {
+                double S = red[0][r];
+#pragma unroll
+                for (int u = 1; u < 16; u++) S += red[u][r];
+                const i64 row = (i64)64 * b + rib;
+                if (row < N) {
+                    const double tcur = Ts[row], wi = w[row];
+                    st_sc1(Tbuf + (i64)(par ^ 1) * Tld + row, tcur + (eps * tcur) * (wi / S - 1.0));
+                    fmine = fmax(fmine, fabs(wi - S));
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) fmine = fmax(fmine, __shfl_xor(fmine, off));
+        if (lane == 0) fred[wave] = fmine;
+        __syncthreads();
+        if (tid == 0) st_sc1(fpart + wg, fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3])));
+        if (!gs.sync()) { failed = 1; break; }
+        // ---- C: the new T and the convergence test, identical in every workgroup -----------------------------------
+        par ^= 1;
+        k++;
+        for (int i = tid; i < Np; i += 256) Ts[i] = (i < N) ? ld_sc1(Tbuf + (i64)par * Tld + i) : 0.0;
+        double f = (tid < G) ? ld_sc1(fpart + tid) : 0.0;
+        for (int q = tid + 256; q < G; q += 256) f = fmax(f, ld_sc1(fpart + q));
+        for (int off = 32; off > 0; off >>= 1) f = fmax(f, __shfl_xor(f, off));
+        if (lane == 0) fred[wave] = f;
+        __syncthreads();
+        f = fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3]));
+        __syncthreads(); // fred, Ts
+        if (!(f > delta)) { converged = 1; break; } // `while diff > delta`
+    }
+    if (wg == 0 && tid == 0) {
+        flags[0] = converged;
+        flags[1] = k;       // iterations done by this launch
+        flags[2] = failed;
+        flags[3] = par;     // the buffer that holds the current T
+    }
+}
+
+} // namespace
+
+// Runs the fit of one alpha from T = Tbuf[parity] (two buffers of `Tld` doubles, zero beyond N).  Returns false when the
+// persistent path does not apply or was abandoned (nothing usable was written: the caller restarts the fit with the
+// launch-per-iteration path from its own copy of T); otherwise *iters / *final_parity describe the converged state.
+bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
+                      double delta, i64 *iters, int *final_parity) {
+    const int Nt = (int)((N + 63) / 64);
+    const i64 NT = (i64)Nt * (Nt + 1) / 2;
+    int dev = 0, cus = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0 || Tld < (i64)Nt * 64) return false;
+    const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
+    const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
+    if (tpw > 3) return false; // beyond the register file: N > ~4900 on 256 CUs
+    const size_t lds = (size_t)Nt * 64 * sizeof(double);
+    if (lds > 48 * 1024) return false;
+    c->fp_P.ensure((size_t)Nt * Nt * 64);
+    c->fp_fpart.ensure(cus);
+    c->fp_sync.ensure(SYNC_WORDS);
+    c->fp_flags.ensure(4);
+    hipStream_t st = c->stream;
+    i64 total = 0;
+    int par = parity;
+    ScopedKernelTimer tm(c, "fit_persistent");
+    for (int round = 0; round < 64; round++) {
+        HIP_CHECK(hipMemsetAsync(c->fp_sync.p, 0, sizeof(unsigned) * SYNC_WORDS, st));
+        const double *aGD = GD;
+        i64 aN = N, aTld = Tld;
+        int aNt = Nt, aPar = par, aMax = 100000;
+        double *aT = Tbuf, *aP = c->fp_P.p, *aF = c->fp_fpart.p;
+        const double *aW = w;
+        double aEps = eps, aDelta = delta;
+        unsigned *aSync = c->fp_sync.p;
+        int *aFlags = c->fp_flags.p;
+        long long aTicks = 300000000LL; // 3 s of the 100 MHz wall clock
+        void *args[] = {&aGD, &aN, &aNt, &aT, &aTld, &aPar, &aW, &aEps, &aDelta, &aMax, &aP, &aF, &aSync, &aFlags, &aTicks};
+        const void *fn = tpw == 1 ? (const void *)fit_persistent_kernel<1>
+                         : tpw == 2 ? (const void *)fit_persistent_kernel<2>
+                                    : (const void *)fit_persistent_kernel<3>;
+        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)G), dim3(256), args, lds, st);
+        if (e != hipSuccess) { // e.g. the grid cannot be co-resident on this device
+            (void)hipGetLastError();
+            return false;
+        }
+        int hf[4];
+        HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (hf[2]) return false; // a barrier timed out
+        total += hf[1];
+        par = hf[3];
+        if (hf[0]) {
+            *iters = total;
+            *final_parity = par;
+            return true;
+        }
+        if (total > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge");
+    }
+    return false;
+}

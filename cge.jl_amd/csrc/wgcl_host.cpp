@@ -202,8 +202,18 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     HIP_CHECK(hipMemcpyAsync(T1.p, hT1.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(T2.p, hT2.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    const double *Tin = T1.p, *Tout = T2.p; // undirected: T alternates between T1 and T2, Tcur = the current iterate
-    double *Tcur = T1.p;
+    const double *Tin = T1.p, *Tout = T2.p; // directed
+    // undirected: T alternates between the two halves of TT (Tld doubles each, zero beyond N); Tcur = the current iterate
+    DevBuf<double> &TT = c->fp_T;
+    const i64 Tld = (N + 63) / 64 * 64;
+    int tpar = 0;
+    TT.ensure((size_t)2 * Tld);
+    c->fp_Tsave.ensure(N);
+    HIP_CHECK(hipMemsetAsync(TT.p, 0, sizeof(double) * 2 * Tld, st));
+    HIP_CHECK(hipMemcpyAsync(TT.p, T1.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+    double *Tcur = TT.p;
+    bool use_persistent = !directed && c->opt_fit_persistent != 1 && (c->opt_fit_persistent == 2 || N >= 512);
+    c->stat_fit_persistent = 0;
 
     // ---- samples -> device ---------------------------------------------------------------------
     const bool landmarks = orig != nullptr;
@@ -277,28 +287,45 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         i64 iters = 0;
         i64 batch = std::max<i64>(4, std::min<i64>(prev_iters, 128));
         if (!directed) {
-            // one launch per iteration (kernels_fit.hip: fit_step_kernel); T alternates between T1 and T2
-            HIP_CHECK(hipMemsetAsync(c->sw_fring.p, 0, sizeof(unsigned long long) * 4, st));
-            double *Tb2[2] = {Tcur, Tcur == T1.p ? T2.p : T1.p};
-            i64 k = 0;
-            for (;;) {
-                for (i64 b = 0; b < batch; b++, k++)
-                    k_fit_step(c, GD.p, Tb2[k & 1], Tb2[(k + 1) & 1], G.vw, N, 0.25, delta, (int)k, c->sw_fring.p, flags.p,
-                               flags.p + 1);
-                int hf[2];
-                unsigned long long hr[3];
-                HIP_CHECK(hipMemcpyAsync(hf, flags.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipMemcpyAsync(hr, c->sw_fring.p, sizeof(hr), hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipStreamSynchronize(st));
-                iters = hf[1];
-                if (hf[0]) break;
-                double flast;
-                std::memcpy(&flast, &hr[(k - 1) % 3], sizeof(double));
-                if (!(flast > delta)) break; // the last launch of the batch was the converging iteration (iters == k)
-                if (iters > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g", alpha);
-                batch = std::max<i64>(4, std::min<i64>(batch, 32));
+            bool fitted = false;
+            if (use_persistent) { // the whole fit in one launch, GD's upper triangle in registers (kernels_fitp.hip)
+                HIP_CHECK(hipMemcpyAsync(c->fp_Tsave.p, TT.p + (i64)tpar * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+                int fpar = tpar;
+                fitted = k_fit_persistent(c, GD.p, N, TT.p, Tld, tpar, G.vw, 0.25, delta, &iters, &fpar);
+                if (fitted) {
+                    tpar = fpar;
+                    c->stat_fit_persistent++;
+                } else { // not co-resident / timed out: restore T and use one launch per iteration from here on
+                    use_persistent = false;
+                    HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+                    HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
+                }
             }
-            Tcur = Tb2[iters & 1];
+            if (!fitted) {
+                // one launch per iteration (kernels_fit.hip: fit_step_kernel); T alternates between the two buffers
+                HIP_CHECK(hipMemsetAsync(c->sw_fring.p, 0, sizeof(unsigned long long) * 4, st));
+                double *Tb2[2] = {TT.p + (i64)tpar * Tld, TT.p + (i64)(tpar ^ 1) * Tld};
+                i64 k = 0;
+                for (;;) {
+                    for (i64 b = 0; b < batch; b++, k++)
+                        k_fit_step(c, GD.p, Tb2[k & 1], Tb2[(k + 1) & 1], G.vw, N, 0.25, delta, (int)k, c->sw_fring.p, flags.p,
+                                   flags.p + 1);
+                    int hf[2];
+                    unsigned long long hr[3];
+                    HIP_CHECK(hipMemcpyAsync(hf, flags.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+                    HIP_CHECK(hipMemcpyAsync(hr, c->sw_fring.p, sizeof(hr), hipMemcpyDeviceToHost, st));
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    iters = hf[1];
+                    if (hf[0]) break;
+                    double flast;
+                    std::memcpy(&flast, &hr[(k - 1) % 3], sizeof(double));
+                    if (!(flast > delta)) break; // the last launch of the batch was the converging iteration (iters == k)
+                    if (iters > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g", alpha);
+                    batch = std::max<i64>(4, std::min<i64>(batch, 32));
+                }
+                tpar = (int)((tpar + iters) & 1);
+            }
+            Tcur = TT.p + (i64)tpar * Tld;
         } else
         for (;;) {
             for (i64 b = 0; b < batch; b++) {

@@ -266,6 +266,55 @@ def test_wgcl_exact_mode_original_graph(ctx, orc, test115):
     _cmp_result(res, exp, tr, etr)
 
 
+@pytest.mark.parametrize("n", [40, 130, 700, 1500])
+def test_fit_persistent_kernel_matches_stepwise_and_oracle(ctx, orc, n):
+    """The Chung-Lu fixed point (src/divergence.jl:150-168) as one persistent launch per alpha (register-resident
+    upper triangle, grid barriers) against one launch per iteration and against the oracle: same iteration counts,
+    same scores.  Sizes cover one tile, ragged last tiles, and several tiles per wave row."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    g = synth.abcd_like(n, 6 * n, max(2, n // 60), 8, seed=n)
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    ctx.set_graph(g["edges"], g["eweights"], n)
+    smp = api.draw_samples(ctx, 11, 2000)
+    args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
+    out = {}
+    try:
+        for mode in (1, 2):
+            ctx.set_option("fit_persistent", mode)
+            out[mode] = cg.wGCL(*args, samples=smp, trace=True, ctx=ctx)
+            assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode == 2)
+    finally:
+        ctx.set_option("fit_persistent", 0)
+    (r1, t1), (r2, t2) = out[1], out[2]
+    assert t1["iters"] == t2["iters"]
+    assert np.allclose(r1, r2, rtol=1e-11, atol=1e-13)
+    assert np.allclose(t1["div"], t2["div"], rtol=1e-11, equal_nan=True)
+    if n <= 700:
+        exp, etr = orc.wGCL(*args, smp, trace=True)
+        _cmp_result(r2, exp, t2, etr)
+
+
+def test_fit_persistent_kernel_headline_landmark_count(ctx):
+    """4000 landmarks (two tiles per wave, every CU busy): the persistent fit and the launch-per-iteration path
+    give the same score vector."""
+    from cge.jl_amd import synth
+
+    g = synth.abcd_like(60000, 600000, 40, 16, seed=5)
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    res = {}
+    try:
+        for mode in (1, 2):
+            ctx.set_option("fit_persistent", mode)
+            res[mode] = ctx.score(g["clusters"], 4000, 4, "rss", seed=3, auc_samples=5000)
+            assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode == 2)
+    finally:
+        ctx.set_option("fit_persistent", 0)
+    assert res[1][0] == res[2][0] and res[1][4] == res[2][4]
+    assert np.allclose(res[1], res[2], rtol=1e-10, atol=1e-13)
+
+
 def test_wgcl_landmark_mode_readme_known_answer(ctx, orc, example10k):
     """README.md:88-100 end to end through landmarks() + wGCL() in landmark mode."""
     import cge.jl_amd as cg
