@@ -313,21 +313,19 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
     land = clamp_to_unique_rows(c, land, &c->lm_truncated);
     c->phases.ms["lm_unique"] = now_ms() - t0;
     std::vector<i64> gid;
-    host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, nullptr);
+    host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, nullptr, &c->h_mem_off, &c->h_mem);
     HIP_CHECK(hipStreamSynchronize(st));
     c->phases.ms["landmarks"] = now_ms() - t0;
     t0 = now_ms();
+    const i64 N = (i64)c->h_mem_off.size() - 1; // every group is non-empty
+    c->N = N;
     c->h_v2l.resize(n);
-    i64 N = 0;
+    std::vector<i32> &v2l0 = c->h_v2l0;
+    v2l0.resize(n);
     for (i64 i = 0; i < n; i++) {
         c->h_v2l[i] = gid[i] + 1; // :379
-        N = std::max(N, c->h_v2l[i]);
+        v2l0[i] = (i32)gid[i];
     }
-    c->N = N;
-    // CSR landmark -> members in ascending vertex order
-    std::vector<i32> v2l0(n);
-    for (i64 i = 0; i < n; i++) v2l0[i] = (i32)gid[i];
-    build_landmark_index(c, v2l0, N);
     const std::vector<i32> &mem_off = c->h_mem_off, &mem = c->h_mem;
     DevBuf<i32> d_off, d_mem;
     d_off.ensure(N + 1);
@@ -866,6 +864,7 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "diameter_candidate_tiles")) *value = c->stat_cand_tiles;
     else if (!strcmp(key, "diameter_refs")) *value = c->stat_nref;
     else if (!strcmp(key, "fit_persistent_alphas")) *value = c->stat_fit_persistent;
+    else if (!strcmp(key, "fit_iterations")) *value = c->stat_fit_iters;
     else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`
     else return CGE_E_ARG;
     return CGE_OK;

@@ -222,6 +222,7 @@ struct cge_ctx {
     i64 N = 0;
     int lm_truncated = 0;
     std::vector<i64> h_v2l;   // 1-based landmark of each vertex
+    std::vector<i32> h_v2l0;  // the same, 0-based (upload staging)
     DevBuf<i32> v2l;          // 0-based
     DevBuf<double> lemb;      // N x d row-major
     DevBuf<double> lweight, dii;
@@ -244,7 +245,9 @@ struct cge_ctx {
     DevBuf<unsigned> fp_sync;
     DevBuf<int> fp_flags;
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it fits
-    i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
+    i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
+    i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
+    bool fit_persistent_broken = false; // a grid barrier timed out once (e.g. another process holds CUs): not tried again // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
     DevBuf<i32> sw_cm_off, sw_cm_mem;
     DevBuf<double> sw_zeros;
     // diameter scratch
@@ -406,7 +409,8 @@ void k_mark_edge_hits(cge_ctx *c, const i32 *src, const i32 *dst, i64 m, int dir
 // ---- host modules -----------------------------------------------------------------------------
 // landmarks_host.cpp
 void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
-                   std::vector<i64> &group_ids /*0-based*/, std::vector<std::vector<i64>> *members_out);
+                   std::vector<i64> &group_ids /*0-based*/, std::vector<std::vector<i64>> *members_out,
+                   std::vector<i32> *csr_off = nullptr, std::vector<i32> *csr_mem = nullptr); // group -> ascending 0-based members
 void host_eig_top(const double *A, i64 d, double *v); // largest-eigenvalue eigenvector, sign: max |.| component > 0
 // diameter_host.cpp
 bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const std::vector<i32> &lcomm, i64 C, i64 N,

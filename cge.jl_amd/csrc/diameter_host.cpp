@@ -33,6 +33,12 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     const i64 n = c->n, d = c->d, dpad = c->dpad;
     hipStream_t st = c->stream;
     c->stat_cand_pairs = c->stat_cand_tiles = 0;
+    double tphase = now_ms();
+    auto lap = [&](const char *name) { // host wall time per stage (the stream is not synchronised here)
+        const double t = now_ms();
+        c->phases.ms[name] += t - tphase;
+        tphase = t;
+    };
     // ---- landmark-sorted layout: landmark a owns positions [soff[a], soff[a] + cnt16[a]) ------------
     std::vector<i64> soff(N + 1, 0);
     for (i64 a = 0; a < N; a++) soff[a + 1] = soff[a] + ((mem_off[a + 1] - mem_off[a] + 15) / 16) * 16;
@@ -51,6 +57,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     c->sub_land.ensure(lds_rows / 16);
     HIP_CHECK(hipMemcpyAsync(c->pos2node.p, pos2node.data(), sizeof(i32) * npos, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->sub_land.p, sub_land.data(), sizeof(i32) * (lds_rows / 16), hipMemcpyHostToDevice, st));
+    lap("dm_layout");
     // ---- reference points ---------------------------------------------------------------------------------
     const bool by_comm = C >= 32 && (i64)lcomm.size() == N && lw != nullptr;
     const i64 nref = by_comm ? C : N;
@@ -88,6 +95,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     k_gather_centre_fm(c, c->Xr.p, c->pos2node.p, c->gmean.p, c->Xs.p, c->rns.p, npos, d, lds_rows, dpad);
     k_gather_centre_fm(c, mu_ref, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, nref, d, ldm, dpad);
     k_pcent(c, c->Xs.p, c->rns.p, lds_rows, c->Ms.p, c->mnorm.p, ldm, N, nref, dpad, c->sub_land.p, c->Pm.p);
+    lap("dm_refs_pcent");
     // ---- lower bound from farthest-point sweeps ----------------------------------------------------------
     double L = 0.0;
     i64 p0 = 0, far_i = 0, far_j = 0;
@@ -98,6 +106,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
         if (v > L) { L = v; far_i = p0; far_j = q; }
         p0 = q;
     }
+    lap("dm_farthest");
     // ---- candidate landmark pairs ---------------------------------------------------------------------------
     const i64 cap = std::min<i64>(N * (N + 1) / 2, (i64)4 << 20);
     c->bound_list.ensure((size_t)2 * cap);
@@ -109,9 +118,13 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
         HIP_CHECK(hipMemcpyAsync(cand.data(), c->bound_list.p, sizeof(BoundRec) * cnt, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
     }
-    std::sort(cand.begin(), cand.end(), [](const BoundRec &x, const BoundRec &y) {
-        return x.B > y.B || (x.B == y.B && (x.a < y.a || (x.a == y.a && x.b < y.b)));
-    });
+    lap("dm_select");
+    // candidates are consumed in decreasing-bound order (ties: by landmark pair) until the bound drops below the best
+    // pair found: a heap delivers exactly that order without sorting the (mostly never visited) tail
+    auto later = [](const BoundRec &x, const BoundRec &y) { // x comes after y
+        return x.B < y.B || (x.B == y.B && (x.a > y.a || (x.a == y.a && x.b > y.b)));
+    };
+    std::make_heap(cand.begin(), cand.end(), later);
     auto ntiles_of = [&](i64 a) { return (soff[a + 1] - soff[a] + 127) / 128; };
     double tiles_total = 0.0;
     for (const auto &r : cand) {
@@ -123,14 +136,15 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     // ---- exact evaluation in decreasing-bound order ----------------------------------------------------------
     double best = L; // the farthest-point pair is a valid answer so far
     i64 best_pi = -1, best_pj = -1;
-    size_t next = 0;
+    size_t left = cand.size(); // the heap is cand[0, left)
     i64 chunk_cap = 4096, global_tile = 0;
     std::vector<int2> tiles;
-    while (next < cand.size()) {
+    while (left > 0) {
         tiles.clear();
-        while (next < cand.size() && (i64)tiles.size() < chunk_cap) {
-            const BoundRec &r = cand[next++];
-            if (r.B * (1.0 + 1e-9) + 1e-9 < best) { next = cand.size(); break; } // sorted: nothing further can win
+        while (left > 0 && (i64)tiles.size() < chunk_cap) {
+            std::pop_heap(cand.begin(), cand.begin() + left, later);
+            const BoundRec r = cand[--left];
+            if (r.B * (1.0 + 1e-9) + 1e-9 < best) { left = 0; break; } // decreasing order: nothing further can win
             const i64 ta = ntiles_of(r.a), tb = ntiles_of(r.b);
             for (i64 x = 0; x < ta; x++)
                 for (i64 y = (r.a == r.b ? x : 0); y < tb; y++) {
@@ -148,6 +162,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
         if (v > best) { best = v; best_pi = pi; best_pj = pj; }
         chunk_cap = 131072;
     }
+    lap("dm_exact");
     if (best_pi >= 0) {
         far_i = pos2node[best_pi];
         far_j = pos2node[best_pj];

@@ -295,7 +295,10 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
         int hf[4];
         HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        if (hf[2]) return false; // a barrier timed out
+        if (hf[2]) { // a barrier timed out
+            c->fit_persistent_broken = true;
+            return false;
+        }
         total += hf[1];
         par = hf[3];
         if (hf[0]) {

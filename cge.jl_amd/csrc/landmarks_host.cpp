@@ -865,6 +865,7 @@ void replay_one(Heap &h) {
 void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64> &targets, int method,
                    std::deque<Group> &pool, bool speculate) {
     for (;;) {
+        PhaseAcc *ph = new PhaseAcc(c, "lm_heap"); // replay + choice of the next batch (host)
         std::vector<Group *> batch;
         for (size_t q = 0; q < heaps.size(); q++) {
             Heap &h = *heaps[q];
@@ -907,8 +908,10 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
             }
             batch.insert(batch.end(), frontier.begin(), frontier.end());
         }
+        delete ph;
         if (batch.empty()) break;
         compute_splits(c, batch, method);
+        PhaseAcc pm(c, "lm_materialise");
         materialise_children(batch, pool);
     }
 }
@@ -916,12 +919,14 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
 } // namespace
 
 void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
-                   std::vector<i64> &group_ids, std::vector<std::vector<i64>> *members_out) {
+                   std::vector<i64> &group_ids, std::vector<std::vector<i64>> *members_out, std::vector<i32> *csr_off,
+                   std::vector<i32> *csr_mem) {
     const i64 n = c->n, d = c->d;
     if ((i64)c->h_Xr.size() != n * d || (i64)c->h_vw.size() != n)
         CGE_THROW(CGE_E_ARG, "runsplit: embedding / vertex weights are not resident");
     std::deque<Group> pool;
     Heap H;
+    PhaseAcc *pinit = new PhaseAcc(c, "lm_init");
     // sort(initial_clusters): lexicographic (:281)
     std::vector<i64> order(ncl);
     for (i64 i = 0; i < ncl; i++) order[i] = i;
@@ -948,6 +953,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             locals.back().h.put(g);
         }
     }
+    delete pinit;
     if (!locals.empty()) {
         // root values: -total_rss of each community (one device pass over all of them)
         {
@@ -961,6 +967,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         for (auto &L : locals) { hs.push_back(&L.h); tg.push_back(forced); }
         advance_heaps(c, hs, tg, method, pool, false);
     }
+    PhaseAcc *pmerge = new PhaseAcc(c, "lm_merge");
     size_t li = 0;
     for (i64 q = 0; q < ncl; q++) {
         const i64 cidx = order[q], len = cl_off[cidx + 1] - cl_off[cidx];
@@ -977,18 +984,48 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             while (L.len() > 0) H.put(L.pop()); // :309-312
         }
     }
+    delete pmerge;
     // ---- global phase (:316-335) ----------------------------------------------------------------------------
     {
         std::vector<Heap *> hs{&H};
         std::vector<i64> tg{nland};
         advance_heaps(c, hs, tg, method, pool, true);
     }
+    PhaseAcc pfin(c, "lm_final");
+    const i64 NG = (i64)H.len();
     group_ids.assign(n, -1);
-    if (members_out) members_out->clear();
-    for (size_t g = 1; g <= H.len(); g++) {
-        for (i64 v : H.a[g]->what) group_ids[v - 1] = (i64)g - 1;
-        if (members_out) members_out->push_back(H.a[g]->what);
+    parallel_for(c, NG, [&](i64 g) { // groups are disjoint: the writes do not collide
+        for (i64 v : H.a[g + 1]->what) group_ids[v - 1] = g;
+    });
+    if (members_out) {
+        members_out->clear();
+        for (i64 g = 0; g < NG; g++) members_out->push_back(H.a[g + 1]->what);
     }
-    for (i64 i = 0; i < n; i++)
-        if (group_ids[i] < 0) CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids)"); // :343
+    bool all_set = true;
+    for (i64 i = 0; i < n; i++) all_set &= group_ids[i] >= 0;
+    if (!all_set) CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids)"); // :343
+    if (csr_off && csr_mem) { // group -> members (0-based, ascending): a two-pass counting sort over vertex ranges
+        csr_off->assign(NG + 1, 0);
+        for (i64 g = 0; g < NG; g++) (*csr_off)[g + 1] = (*csr_off)[g] + (i32)H.a[g + 1]->what.size();
+        csr_mem->resize(n);
+        const i64 P = std::max<i64>(1, std::min<i64>(c->n_threads, 16));
+        std::vector<std::vector<i32>> start(P, std::vector<i32>(NG, 0));
+        parallel_for(c, P, [&](i64 t) {
+            std::vector<i32> &cnt = start[t];
+            for (i64 i = n * t / P; i < n * (t + 1) / P; i++) cnt[group_ids[i]]++;
+        });
+        for (i64 g = 0; g < NG; g++) { // exclusive prefix over the ranges, inside each group's slot
+            i32 run = (*csr_off)[g];
+            for (i64 t = 0; t < P; t++) {
+                const i32 k = start[t][g];
+                start[t][g] = run;
+                run += k;
+            }
+        }
+        parallel_for(c, P, [&](i64 t) {
+            std::vector<i32> &cur = start[t];
+            i32 *out = csr_mem->data();
+            for (i64 i = n * t / P; i < n * (t + 1) / P; i++) out[cur[group_ids[i]]++] = (i32)i;
+        });
+    }
 }

@@ -212,8 +212,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     HIP_CHECK(hipMemsetAsync(TT.p, 0, sizeof(double) * 2 * Tld, st));
     HIP_CHECK(hipMemcpyAsync(TT.p, T1.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
     double *Tcur = TT.p;
-    bool use_persistent = !directed && c->opt_fit_persistent != 1 && (c->opt_fit_persistent == 2 || N >= 512);
+    bool use_persistent = !directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
+                          (c->opt_fit_persistent == 2 || N >= 512);
     c->stat_fit_persistent = 0;
+    c->stat_fit_iters = 0;
 
     // ---- samples -> device ---------------------------------------------------------------------
     const bool landmarks = orig != nullptr;
@@ -342,6 +344,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             batch = std::max<i64>(4, std::min<i64>(batch, 32));
         }
         prev_iters = iters;
+        c->stat_fit_iters += iters;
 
         double auc_val = NAN, div_val = NAN, div_int = 0.0, div_ext = 0.0;
         const double *Ta = directed ? Tout : Tcur, *Tb = directed ? Tin : Tcur;
