@@ -184,6 +184,7 @@ def main():
     phases = ctx.phase_ms()
     trace = ctx.last_trace
     if rank != 0:
+        ctx.close()
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -278,6 +279,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "edge-alpha evals/s", "cores": 1, "kind": "port",
                                    "sample": f"failed: {e!r}"}
     print(json.dumps(out), flush=True)
+    ctx.close()  # tear the context down before interpreter exit (profilers finalise their HIP hooks at exit)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

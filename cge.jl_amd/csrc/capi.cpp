@@ -60,6 +60,9 @@ int cge_create(cge_ctx **out, int device, void *stream) {
             HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
             c->own_stream = true;
         }
+        HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
         unsigned hc = std::thread::hardware_concurrency();
         c->n_threads = (int)std::max(1u, std::min(hc ? hc : 8u, 16u));
         c->pool = new ThreadPool(c->n_threads - 1);
@@ -77,6 +80,9 @@ void cge_destroy(cge_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     flush_timers(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     delete c->pool;
     c->pool = nullptr;
     delete c;

@@ -188,6 +188,8 @@ struct cge_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t copy_stream = nullptr; // device->host result copies that overlap the kernels queued behind them
+    hipEvent_t copy_ev = nullptr, copy_done = nullptr;
     std::string err;
     int n_threads = 8;
     ThreadPool *pool = nullptr; // persistent host workers (n_threads - 1 + caller)

@@ -344,11 +344,35 @@ __global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__
         }
         return y;
     };
-    d4 acc[4][4];
-    gram_tile_128_ld<SAME>([&](i64 kc, int q) { return load(kc, q, ca, ma0, ma1); },
-                           [&](i64 kc, int q) { return load(kc, q, cb, mb0, mb1); }, len16 / MP_BK, lds, acc, wave, c2, wr,
-                           wc, lr, lk);
     double *out = part + ch * d * d;
+    if (SAME) { // upper-triangular blocks only, mirrored on the way out
+        d4 acc[9];
+        auto la = [&](i64 kc, int q) { return load(kc, q, ca, ma0, ma1); };
+        switch (wave) {
+        case 0: syrk_tile_128_wave<0>(la, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
+        case 1: syrk_tile_128_wave<1>(la, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
+        case 2: syrk_tile_128_wave<2>(la, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
+        default: syrk_tile_128_wave<3>(la, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            int bi, bj;
+            syrk_slot_block(wave, q, bi, bj);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const i64 ia = a0 + 16 * bi + lk + 4 * r, ib = a0 + 16 * bj + lr;
+                if (ia < d && ib < d) {
+                    out[ia * d + ib] = acc[q][r];
+                    if (bi != bj) out[ib * d + ia] = acc[q][r];
+                }
+            }
+        }
+        return;
+    }
+    d4 acc[4][4];
+    gram_tile_128_ld<false>([&](i64 kc, int q) { return load(kc, q, ca, ma0, ma1); },
+                            [&](i64 kc, int q) { return load(kc, q, cb, mb0, mb1); }, len16 / MP_BK, lds, acc, wave, c2, wr,
+                            wc, lr, lk);
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll

@@ -621,8 +621,11 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const dou
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                        c->sp_srows.p, c->sp_status.p);
     std::vector<i32> status(T);
-    HIP_CHECK(hipMemcpyAsync(c->pin_perm.p, c->sp_perm.p, sizeof(i32) * R, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(status.data(), c->sp_status.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
+    // the permutation (4 B per row) goes to the host on the copy stream while the scan and the rounds run
+    HIP_CHECK(hipEventRecord(c->copy_ev, st));
+    HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->copy_ev, 0));
+    HIP_CHECK(hipMemcpyAsync(c->pin_perm.p, c->sp_perm.p, sizeof(i32) * R, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_CHECK(hipMemcpyAsync(status.data(), c->sp_status.p, sizeof(i32) * T, hipMemcpyDeviceToHost, c->copy_stream));
     const i32 *perm = c->pin_perm.p;
     k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
@@ -634,6 +637,7 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const dou
     HIP_CHECK(hipMemcpyAsync(rounds.data(), c->sp_rounds.p, sizeof(i32) * rounds.size(), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipStreamSynchronize(c->copy_stream));
     delete pa;
     PhaseAcc pa2(c, "lm_cut_rebuild");
     parallel_for(c, T, [&](i64 t) {
@@ -740,8 +744,10 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                 k_group_project(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_row_task.p, R, d, c->ls_mean.p, c->ls_vec.p,
                                 c->ls_z.p);
             }
-            HIP_CHECK(hipMemcpyAsync(c->pin_z.p, c->ls_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
+            if (method != CGE_METHOD_RSS) { // the rss rule cuts on the device; the other rules' 1-D logic runs on the host
+                HIP_CHECK(hipMemcpyAsync(c->pin_z.p, c->ls_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
         }
         // ---- the cut: local positions of the two children -----------------------------------------------------
         std::vector<std::vector<i64>> lows(T), highs(T);
@@ -753,6 +759,8 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                 std::vector<i64> fallback;
                 rule_rss_sorted(c, B, groups, z, lows, highs, vlow, vhigh, have_vals, fallback);
                 if (!fallback.empty()) { // generic round-based path on a sub-batch (ties at max z, NaNs)
+                    HIP_CHECK(hipMemcpyAsync(c->pin_z.p, c->ls_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
+                    HIP_CHECK(hipStreamSynchronize(st));
                     std::vector<Group *> fg;
                     for (i64 t : fallback) fg.push_back(groups[t]);
                     Batch FB;

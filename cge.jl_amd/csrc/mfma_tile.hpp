@@ -91,3 +91,53 @@ __device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, con
         [&](i64 kc, int q) { return *reinterpret_cast<const d2 *>(pb + (kc * MP_BK + 4 * q) * ldb); }, nchunk, lds, acc,
         wave, c2, wr, wc, lr, lk);
 }
+
+// The diagonal tile of a SYRK, G = A_tile * A_tile^T: only the 36 upper-triangular 16x16 blocks of the 8x8 block
+// grid are computed.  Wave w owns block-rows w and 7-w (8-w + w+1 = 9 blocks each way: the four waves are balanced);
+// slot q < 8-w is block (w, w+q), slot q >= 8-w is block (7-w, 7-w + q-(8-w)).  Same staging as gram_tile_128_ld
+// with SAME = true.  acc[q] has the MFMA C/D layout of its block: lane l, register r -> row (l>>4)+4r, col l&15.
+template <int W, class LA>
+__device__ __forceinline__ void syrk_tile_128_wave(LA la, i64 nchunk, double *lds, d4 (&acc)[9], int wave, int c2, int lr,
+                                                   int lk) {
+    const size_t stage_doubles = (size_t)MP_BK * MP_LD;
+#pragma unroll
+    for (int q = 0; q < 9; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+    d2 ra[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) ra[q] = la((i64)0, q);
+    __syncthreads(); // the previous tile's readers are done with both stages
+#pragma unroll
+    for (int q = 0; q < 4; q++) *reinterpret_cast<d2 *>(lds + (wave + 4 * q) * MP_LD + c2) = ra[q];
+    __syncthreads();
+    for (i64 kc = 0; kc < nchunk; kc++) {
+        const int s = (int)(kc & 1);
+        const bool more = kc + 1 < nchunk;
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) ra[q] = la(kc + 1, q);
+        }
+        const double *As = lds + (size_t)s * stage_doubles;
+#pragma unroll
+        for (int ks = 0; ks < MP_BK / 4; ks++) {
+            const double *rowp = As + (ks * 4 + lk) * MP_LD + lr;
+            double f[8]; // operand fragments of block-columns W..7 (block-rows W and 7-W are among them)
+#pragma unroll
+            for (int b = W; b < 8; b++) f[b] = rowp[16 * b];
+#pragma unroll
+            for (int q = 0; q < 8 - W; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[W], f[W + q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q <= W; q++)
+                acc[8 - W + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[7 - W], f[7 - W + q], acc[8 - W + q], 0, 0, 0);
+        }
+        if (more) {
+            double *An = lds + (size_t)(s ^ 1) * stage_doubles;
+#pragma unroll
+            for (int q = 0; q < 4; q++) *reinterpret_cast<d2 *>(An + (wave + 4 * q) * MP_LD + c2) = ra[q];
+        }
+        __syncthreads();
+    }
+}
+// block coordinates of slot q of wave w (see above)
+__device__ __forceinline__ void syrk_slot_block(int w, int q, int &bi, int &bj) {
+    if (q < 8 - w) { bi = w; bj = w + q; } else { bi = 7 - w; bj = 7 - w + (q - (8 - w)); }
+}
