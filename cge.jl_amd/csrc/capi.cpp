@@ -169,6 +169,7 @@ int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
     DevBuf<double> col;
     col.alloc_exact((size_t)n * d);
     HIP_CHECK(hipMemcpyAsync(col.p, X, sizeof(double) * n * d, hipMemcpyHostToDevice, c->stream));
+    c->uniq_rows_ge = 0;
     c->Xr.alloc_exact((size_t)n * d);
     k_transpose_to_rowmajor(c, col.p, c->Xr.p, n, d);
     c->h_Xr.resize((size_t)n * d);
@@ -234,7 +235,7 @@ int cge_set_vertex_data(cge_ctx *c, const int64_t *comm, const double *vw, int64
 static i64 clamp_to_unique_rows(cge_ctx *c, i64 land, int *truncated) {
     const i64 n = c->n, d = c->d;
     *truncated = 0;
-    if (land <= 1) return land;
+    if (land <= 1 || land <= c->uniq_rows_ge) return land; // a property of the resident embedding: remembered
     DevBuf<uint64_t> dh;
     dh.ensure(n);
     k_row_hash(c, c->Xr.p, dh.p, n, d);
@@ -245,7 +246,10 @@ static i64 clamp_to_unique_rows(cge_ctx *c, i64 land, int *truncated) {
     seen.reserve((size_t)std::min<i64>(n, 2 * land));
     for (i64 i = 0; i < n; i++) {
         seen.insert(h[i]);
-        if ((i64)seen.size() >= land) return land;
+        if ((i64)seen.size() >= land) {
+            c->uniq_rows_ge = land;
+            return land;
+        }
     }
     // fewer distinct hashes than `land`: count bitwise-distinct rows exactly
     std::vector<i64> ix(n);

@@ -263,6 +263,7 @@ struct cge_ctx {
     DevBuf<double> bound_list;             // BoundRec records (2 doubles each)
     DevBuf<i32> tile_list;
     std::vector<i32> h_mem_off, h_mem;     // landmark -> members (ascending vertex id), host copy
+    i64 uniq_rows_ge = 0;                  // the resident embedding is known to hold at least this many distinct rows
     int opt_diameter = 0;                  // 0 auto (pruned with brute-force fallback), 1 brute force, 2 pruned only
     i64 stat_cand_pairs = 0, stat_cand_tiles = 0; // last pruned run
     int stat_diameter_path = 0;            // 1 brute, 2 pruned
@@ -273,13 +274,13 @@ struct cge_ctx {
     DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z, ls_sums;
     DevBuf<unsigned char> ls_side, ls_state;
     DevBuf<double> ls_params; // per-task round parameters of the rss rule
-    PinBuf<double> pin_sums, pin_z, pin_params, pin_zs;
+    PinBuf<double> pin_sums, pin_z, pin_params, pin_zs, pin_means, pin_cmeans;
     PinBuf<i32> pin_rows[2], pin_row_task[2], pin_srows; // [slot]: 0 = main batch, 1 = fallback sub-batch
     // sorted-prefix rss path
     DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro, sp_perm, sp_status, sort_idx;
     DevBuf<unsigned char> sort_tmp;
     PinBuf<i32> pin_perm;
-    DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;
+    DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals, sp_cmeans;
 
     // ---- profiling -------------------------------------------------------------------------
     bool profiling = false;
@@ -341,7 +342,7 @@ void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *
                      double *coff, double *prefix);
 void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const double *zs,
                   const i32 *task_row_off, const i32 *task_chunk_off, const double *prefix, const double *coff,
-                  i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals);
+                  i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals, double *cmeans /* [task][2][d] */);
 #define CGE_RR_MAXROUNDS 63
 #define CGE_CHUNK_ROWS 1024 // rows per chunk of a batch (build_batch); the rounds kernel uses r >> 10
 #define CGE_PREFIX_STRIDE 8 // the sorted-order WSSE prefix is stored every 8th row of a chunk (CGE_CHUNK_ROWS % 8 == 0)

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
                                                         const double *__restrict__ prefix,
                                                         const double *__restrict__ coff, i64 d,
                                                         i32 *__restrict__ meta, i32 *__restrict__ rounds,
-                                                        double *__restrict__ vals) {
+                                                        double *__restrict__ vals, double *__restrict__ cmeans) {
     const i64 t = blockIdx.x, W = 2 * d + 1;
     const int lane = threadIdx.x;
     const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
@@ -751,6 +751,15 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
     range(0, ga, a_ss, a_s, aw);
     range(ga, k, b_ss, b_s, bw);
     const double vlow = -fsum(zero_ss, zero_s, 0.0, a_ss, a_s, aw), vhigh = -fsum(zero_ss, zero_s, 0.0, b_ss, b_s, bw);
+    // the children's weighted means (matrix_w_mean, :71-81) are the same column sums: sum w x / sum w
+#pragma unroll
+    for (int s = 0; s < RR_SLOTS; s++) {
+        const i64 c = lane + 64 * s;
+        if (c < d) {
+            cmeans[(2 * t) * d + c] = a_s[s] / aw;
+            cmeans[(2 * t + 1) * d + c] = b_s[s] / bw;
+        }
+    }
     if (lane == 0) {
         meta[2 * t] = nr;
         meta[2 * t + 1] = rc;
@@ -760,11 +769,11 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
 }
 void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const double *zs,
                   const i32 *task_row_off, const i32 *task_chunk_off, const double *prefix, const double *coff,
-                  i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals) {
+                  i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals, double *cmeans) {
     if (d > 64 * RR_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * RR_SLOTS);
     ScopedKernelTimer t(c, "rss_rounds");
     hipLaunchKernelGGL(rss_rounds_kernel, dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, zs,
-                       task_row_off, task_chunk_off, prefix, coff, d, meta, rounds, vals);
+                       task_row_off, task_chunk_off, prefix, coff, d, meta, rounds, vals, cmeans);
 }
 
 // Side flags of one rss round, derived on the device (no per-round row-sized upload).  Per task t,

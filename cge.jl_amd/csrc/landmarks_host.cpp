@@ -41,6 +41,9 @@ struct Group {
     std::vector<i64> low, high; // children (vertex ids) until the child groups are materialised
     double vlow = 0.0, vhigh = 0.0;
     Group *clo = nullptr, *chi = nullptr; // child groups, created as soon as the split is known
+    // weighted mean of the rows (matrix_w_mean, src/landmarks.jl:71-81) when it is already known from the parent's
+    // split (the WSSE column sums of a child are sum w x and sum w); empty = compute it on the device
+    std::vector<double> mean, mlow, mhigh;
 };
 
 // 1-based binary min-heap on value with the reference's exact sift rules (src/landmarks.jl:12-46)
@@ -629,10 +632,13 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const dou
     const i32 *perm = c->pin_perm.p;
     k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
+    c->sp_cmeans.ensure((size_t)2 * T * d);
     k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->ls_tco.p, c->sp_prefix.p, c->sp_coff.p,
-                 T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p);
+                 T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p, c->sp_cmeans.p);
     std::vector<i32> meta(2 * T), rounds((size_t)T * 3 * CGE_RR_MAXROUNDS);
     std::vector<double> vals(2 * T);
+    c->pin_cmeans.ensure((size_t)2 * T * d);
+    HIP_CHECK(hipMemcpyAsync(c->pin_cmeans.p, c->sp_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(meta.data(), c->sp_meta.p, sizeof(i32) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(rounds.data(), c->sp_rounds.p, sizeof(i32) * rounds.size(), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
@@ -671,6 +677,9 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const dou
         vlow[t] = vals[2 * t];
         vhigh[t] = vals[2 * t + 1];
         have_vals[t] = 1;
+        const double *cm = c->pin_cmeans.p + (size_t)2 * t * d;
+        g->mlow.assign(cm, cm + d);
+        g->mhigh.assign(cm + d, cm + 2 * d);
         g->rc = CGE_OK;
     });
     for (i64 t = 0; t < T; t++)
@@ -726,8 +735,15 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             PhaseAcc pa(c, "lm_pca_dev");
             {
                 ScopedKernelTimer tm(c, "group_stats");
-                k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
-                             c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
+                bool have_means = true;
+                for (i64 t = 0; t < T && have_means; t++) have_means = (i64)groups[t]->mean.size() == d;
+                if (have_means) { // known from the parents' splits: one small upload instead of a pass over the rows
+                    c->pin_means.ensure((size_t)T * d);
+                    parallel_for(c, T, [&](i64 t) { std::copy(groups[t]->mean.begin(), groups[t]->mean.end(), c->pin_means.p + t * d); });
+                    HIP_CHECK(hipMemcpyAsync(c->ls_mean.p, c->pin_means.p, sizeof(double) * T * d, hipMemcpyHostToDevice, st));
+                } else
+                    k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
+                                 c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
                 k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                             c->ls_mean.p, c->ls_part.p, c->ls_cov.p);
             }
@@ -822,6 +838,12 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                     const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
                     vlow[t] = -rss_from_sums(q1, d);
                     vhigh[t] = -rss_from_sums(q2, d);
+                    g->mlow.resize(d);
+                    g->mhigh.resize(d);
+                    for (i64 c2 = 0; c2 < d; c2++) {
+                        g->mlow[c2] = q1[d + c2] / q1[2 * d];
+                        g->mhigh[c2] = q2[d + c2] / q2[2 * d];
+                    }
                 }
                 g->vlow = g->low.size() > 1 ? vlow[t] : DBL_EPSILON;
                 g->vhigh = g->high.size() > 1 ? vhigh[t] : DBL_EPSILON;
@@ -846,10 +868,12 @@ void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool) 
         g->clo = &pool.back();
         g->clo->what = std::move(g->low);
         g->clo->value = g->vlow;
+        g->clo->mean = std::move(g->mlow);
         pool.emplace_back();
         g->chi = &pool.back();
         g->chi->what = std::move(g->high);
         g->chi->value = g->vhigh;
+        g->chi->mean = std::move(g->mhigh);
     }
 }
 
@@ -964,7 +988,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     delete pinit;
     if (!locals.empty()) {
         // root values: -total_rss of each community (one device pass over all of them)
-        {
+        if (forced <= 1) { // with forced >= 2 every root is popped from its one-element heap: its value is never compared
             PhaseAcc pa(c, "lm_roots");
             std::vector<Group *> roots;
             for (auto &L : locals) roots.push_back(L.h.top());
