@@ -859,8 +859,8 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_diameter = (int)value;
         return CGE_OK;
     }
-    if (!strcmp(key, "fit_persistent")) { // 0 auto, 1 never, 2 whenever the score graph fits the register file
-        if (value < 0 || value > 2) return CGE_E_ARG;
+    if (!strcmp(key, "fit_persistent")) { // 0 auto, 1 never, 2 whenever the score graph fits the register file, 3 = 2 with grid barriers
+        if (value < 0 || value > 3) return CGE_E_ARG;
         c->opt_fit_persistent = (int)value;
         return CGE_OK;
     }

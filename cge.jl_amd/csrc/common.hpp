@@ -243,10 +243,11 @@ struct cge_ctx {
     DevBuf<int> sw_flags;
     DevBuf<unsigned long long> sw_fring;
     // persistent Chung-Lu fit (kernels_fitp.hip): T double buffer, partial vectors, per-workgroup maxima, barrier words
-    DevBuf<double> fp_T, fp_Tsave, fp_P, fp_fpart;
+    DevBuf<double> fp_T, fp_Tsave, fp_P, fp_fpart, fp_fq;
     DevBuf<unsigned> fp_sync;
     DevBuf<int> fp_flags;
-    int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it fits
+    int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it
+                                // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
     bool fit_persistent_broken = false; // a grid barrier timed out once (e.g. another process holds CUs): not tried again // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
@@ -386,7 +387,7 @@ void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, 
 // alpha sweep
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD);
 bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
-                      double delta, i64 *iters, int *final_parity);
+                      double delta, i64 *iters, int *final_parity, bool dataflow);
 void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
                 double delta, int k, unsigned long long *fring, int *done, int *iters);
 void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done);

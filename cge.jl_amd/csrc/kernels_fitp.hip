@@ -246,13 +246,201 @@ __global__ __launch_bounds__(256) void fit_persistent_kernel(const double *__res
     }
 }
 
+// ---- the same fit without grid barriers ---------------------------------------------------------------------------
+// Dependencies are tracked per 64-row block instead: cntP[b] counts the partial vectors published for block b (Nt per
+// iteration), cntT[b] the 16-row quarters of T published for it (4 per iteration).  A workgroup starts the tile
+// products of iteration k as soon as the T blocks of ITS tiles are there, and the reduction of its quarter block as
+// soon as that block's Nt partial vectors are there; nobody waits for the whole grid.  Buffer reuse is safe without
+// further flags: P[b][q] of iteration k+1 is written only after T_{k+1} of blocks b and q was published, i.e. after
+// their reducers have read P of iteration k; T_{k+1} overwrites T_{k-1} only after every tile that reads block b has
+// delivered its iteration-k partial, i.e. finished reading T_{k-1}; f of iteration k-1 (one maximum per quarter
+// block, two buffers) is complete when any block's iteration-k partials are.  Convergence (`while diff > delta`) is
+// decided by every reducing workgroup from the same values at the same iteration; workgroups without a quarter block
+// leave through the `done` word.  Signals follow cdna_hip_programming.md Guideline 16: write-through stores, every
+// wave drains, a workgroup barrier, then ONE lane adds to the counter; the consumer polls with one wave, a workgroup
+// barrier, then L1-bypassing loads.  Every spin is bounded (timeout -> `fail` -> host fallback).
+#define DF_WORDS 8192 // unsigned words zeroed per launch: [1] fail, [2] done, cntP at 64+32b, cntT at 4096+32b
+__device__ __forceinline__ int poll_ge(unsigned *word, unsigned target, unsigned *fail, unsigned *done, long long deadline) {
+    unsigned spins = 0; // 0 = reached, 1 = the fit is over, 2 = abandoned
+    while (__hip_atomic_load(word, RLX_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0) {
+            if (__hip_atomic_load(done, RLX_AGENT) != 0u) return 1;
+            if (wall_clock64() > deadline || __hip_atomic_load(fail, RLX_AGENT) != 0u) {
+                __hip_atomic_store(fail, 1u, RLX_AGENT);
+                return 2;
+            }
+        }
+    }
+    return 0;
+}
+template <int TPW>
+__global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restrict__ GD, i64 N, int Nt, double *Tbuf,
+                                                           i64 Tld, int parity, const double *__restrict__ w, double eps,
+                                                           double delta, int max_iters, double *P, double *fq,
+                                                           unsigned *sync, int *flags, long long timeout_ticks) {
+    __shared__ double red[16][17];
+    __shared__ double fred[4];
+    __shared__ int lds_flag;
+    __shared__ int blkI[4 * TPW], blkJ[4 * TPW]; // the workgroup's tiles, by wave and slot (-1 = none)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
+    const int rq = lane >> 3, cq = lane & 7;
+    const int NT = Nt * (Nt + 1) / 2;
+    unsigned *fail = sync + 1, *done = sync + 2, *cntP = sync + 64, *cntT = sync + 4096;
+    const long long deadline = wall_clock64() + timeout_ticks;
+
+    double g[TPW][8][8];
+    int tI[TPW], tJ[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+        const int t = (wg * 4 + wave) + s * 4 * G;
+        tI[s] = -1;
+        tJ[s] = -1;
+        if (t < NT) {
+            int I = 0, rem = t;
+            while (rem >= Nt - I) { rem -= Nt - I; I++; }
+            tI[s] = I;
+            tJ[s] = I + rem;
+        }
+        if (lane == 0) { blkI[wave * TPW + s] = tI[s]; blkJ[wave * TPW + s] = tJ[s]; }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const i64 row = (i64)64 * tI[s] + 8 * rq + a;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const i64 col = (i64)64 * tJ[s] + 8 * cq + b;
+                g[s][a][b] = (tI[s] >= 0 && row < N && col < N) ? GD[row * N + col] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    // this thread's share of the workgroup's signalling / waiting: entry tid -> block of tile tid/2, side tid%2
+    int my_blk = -1;
+    if (tid < 8 * TPW) {
+        const int e = tid >> 1;
+        my_blk = (tid & 1) ? ((blkJ[e] != blkI[e]) ? blkJ[e] : -1) : blkI[e];
+    }
+
+    int par = parity, k = 0, converged = 0, failed = 0;
+    for (;;) {
+        if (k >= max_iters) { failed = 1; break; }
+        // ---- 1. wait for T_k of the blocks this workgroup's tiles read (published by iteration k-1) --------------
+        if (k > 0) {
+            if (wave == 0) {
+                int r = 0;
+                if (my_blk >= 0) r = poll_ge(cntT + 32 * my_blk, 4u * (unsigned)k, fail, done, deadline);
+                r = __any(r == 2) ? 2 : (__any(r == 1) ? 1 : 0);
+                if (lane == 0) lds_flag = r;
+            }
+            __syncthreads();
+            const int r = lds_flag;
+            __syncthreads();
+            if (r == 2) { failed = 1; break; }
+            if (r == 1) { converged = 1; break; } // see below
+        }
+        // ---- 2. tile products with T_k ------------------------------------------------------------------------------
+        const double *Tk = Tbuf + (i64)par * Tld;
+#pragma unroll
+        for (int s = 0; s < TPW; s++) {
+            if (tI[s] < 0) continue; // uniform per wave
+            const int I = tI[s], J = tJ[s];
+            double ti[8], tj[8], pr[8], pc[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                ti[q] = ld_sc1(Tk + 64 * I + 8 * rq + q);
+                tj[q] = ld_sc1(Tk + 64 * J + 8 * cq + q);
+                pr[q] = 0.0;
+                pc[q] = 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const double p = (ti[a] * tj[b]) * g[s][a][b];
+                    pr[a] += p;
+                    pc[b] += p;
+                }
+            const double rsum = transpose_reduce8<0>(pr, lane);
+            st_sc1(P + ((i64)I * Nt + J) * 64 + lane, rsum);
+            if (I != J) {
+                const double csum = transpose_reduce8<3>(pc, lane);
+                st_sc1(P + ((i64)J * Nt + I) * 64 + 8 * cq + rq, csum);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its partial vectors have left
+        __syncthreads();
+        if (my_blk >= 0) __hip_atomic_fetch_add(cntP + 32 * my_blk, 1u, RLX_AGENT);
+        // ---- 3. the quarter blocks this workgroup reduces ---------------------------------------------------------
+        bool stop = false;
+        for (int sb = wg; sb < 4 * Nt; sb += G) {
+            const int b = sb >> 2, r = tid & 15, qg = tid >> 4, rib = 16 * (sb & 3) + r;
+            if (tid == 0) lds_flag = poll_ge(cntP + 32 * b, (unsigned)Nt * (unsigned)(k + 1), fail, done, deadline);
+            __syncthreads();
+            const int pr_ = lds_flag;
+            if (pr_ != 0) { failed = (pr_ == 2); converged = (pr_ == 1); stop = true; break; } // uniform
+            double pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int q = qg + 16 * u;
+                pv[u] = (q < Nt) ? ld_sc1(P + ((i64)b * Nt + q) * 64 + rib) : 0.0;
+            }
+            if (k > 0 && sb == wg) { // f of iteration k-1 is complete now: `while diff > delta`
+                double f = 0.0;
+                const double *fp = fq + (i64)((k - 1) & 1) * 4 * Nt;
+                for (int q = tid; q < 4 * Nt; q += 256) f = fmax(f, ld_sc1(fp + q));
+                for (int off = 32; off > 0; off >>= 1) f = fmax(f, __shfl_xor(f, off));
+                if (lane == 0) fred[wave] = f;
+                __syncthreads();
+                f = fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3]));
+                if (!(f > delta)) { converged = 1; stop = true; break; } // uniform
+            }
+            __syncthreads(); // red and lds_flag are free again
+            red[qg][r] = ((pv[0] + pv[1]) + pv[2]) + pv[3];
+            __syncthreads();
+            if (qg == 0) { // lanes 0..15 of wave 0
+                double S = red[0][r];
+#pragma unroll
+                for (int u = 1; u < 16; u++) S += red[u][r];
+                const i64 row = (i64)64 * b + rib;
+                double fr = 0.0;
+                if (row < N) {
+                    const double tcur = ld_sc1(Tk + row), wi = w[row];
+                    st_sc1(Tbuf + (i64)(par ^ 1) * Tld + row, tcur + (eps * tcur) * (wi / S - 1.0));
+                    fr = fabs(wi - S);
+                }
+                for (int off = 8; off > 0; off >>= 1) fr = fmax(fr, __shfl_xor(fr, off));
+                if (r == 0) st_sc1(fq + (i64)(k & 1) * 4 * Nt + sb, fr);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cntT + 32 * b, 1u, RLX_AGENT);
+        }
+        if (stop) {
+            // Whoever finds f_{k-1} <= delta says so.  `done` may be honoured at any poll: it is set only after some block's
+            // iteration-k partials were complete, i.e. after every workgroup finished its iteration-(k-1) reduction and
+            // its iteration-k products -- so every workgroup that sees it holds the same k and the same parity, T_k is
+            // complete, and nobody who has not decided yet will write T_{k+1} (the decision precedes the update).
+            if (converged && tid == 0) __hip_atomic_store(done, 1u, RLX_AGENT);
+            break;
+        }
+        par ^= 1;
+        k++;
+    }
+    if (wg == 0 && tid == 0) {
+        flags[0] = converged;
+        flags[1] = k;   // iterations done: T_k is final
+        flags[2] = failed || !converged;
+        flags[3] = par; // the buffer that holds T_k
+    }
+}
+
 } // namespace
 
 // Runs the fit of one alpha from T = Tbuf[parity] (two buffers of `Tld` doubles, zero beyond N).  Returns false when the
 // persistent path does not apply or was abandoned (nothing usable was written: the caller restarts the fit with the
 // launch-per-iteration path from its own copy of T); otherwise *iters / *final_parity describe the converged state.
 bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
-                      double delta, i64 *iters, int *final_parity) {
+                      double delta, i64 *iters, int *final_parity, bool dataflow) {
     const int Nt = (int)((N + 63) / 64);
     const i64 NT = (i64)Nt * (Nt + 1) / 2;
     int dev = 0, cus = 0;
@@ -266,28 +454,34 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
     if (lds > 48 * 1024) return false;
     c->fp_P.ensure((size_t)Nt * Nt * 64);
     c->fp_fpart.ensure(cus);
-    c->fp_sync.ensure(SYNC_WORDS);
+    c->fp_sync.ensure(DF_WORDS);
+    c->fp_fq.ensure((size_t)2 * 4 * Nt);
+    if (dataflow && 4096 + 32 * Nt > DF_WORDS) dataflow = false;
     c->fp_flags.ensure(4);
     hipStream_t st = c->stream;
     i64 total = 0;
     int par = parity;
     ScopedKernelTimer tm(c, "fit_persistent");
     for (int round = 0; round < 64; round++) {
-        HIP_CHECK(hipMemsetAsync(c->fp_sync.p, 0, sizeof(unsigned) * SYNC_WORDS, st));
+        HIP_CHECK(hipMemsetAsync(c->fp_sync.p, 0, sizeof(unsigned) * (dataflow ? DF_WORDS : SYNC_WORDS), st));
         const double *aGD = GD;
         i64 aN = N, aTld = Tld;
         int aNt = Nt, aPar = par, aMax = 100000;
-        double *aT = Tbuf, *aP = c->fp_P.p, *aF = c->fp_fpart.p;
+        double *aT = Tbuf, *aP = c->fp_P.p, *aF = dataflow ? c->fp_fq.p : c->fp_fpart.p;
+        if (dataflow) aMax = 2000000;
         const double *aW = w;
         double aEps = eps, aDelta = delta;
         unsigned *aSync = c->fp_sync.p;
         int *aFlags = c->fp_flags.p;
         long long aTicks = 300000000LL; // 3 s of the 100 MHz wall clock
         void *args[] = {&aGD, &aN, &aNt, &aT, &aTld, &aPar, &aW, &aEps, &aDelta, &aMax, &aP, &aF, &aSync, &aFlags, &aTicks};
-        const void *fn = tpw == 1 ? (const void *)fit_persistent_kernel<1>
-                         : tpw == 2 ? (const void *)fit_persistent_kernel<2>
-                                    : (const void *)fit_persistent_kernel<3>;
-        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)G), dim3(256), args, lds, st);
+        const void *fn = dataflow ? (tpw == 1   ? (const void *)fit_dataflow_kernel<1>
+                                     : tpw == 2 ? (const void *)fit_dataflow_kernel<2>
+                                                : (const void *)fit_dataflow_kernel<3>)
+                                  : (tpw == 1   ? (const void *)fit_persistent_kernel<1>
+                                     : tpw == 2 ? (const void *)fit_persistent_kernel<2>
+                                                : (const void *)fit_persistent_kernel<3>);
+        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)G), dim3(256), args, dataflow ? 0 : lds, st);
         if (e != hipSuccess) { // e.g. the grid cannot be co-resident on this device
             (void)hipGetLastError();
             return false;

@@ -213,7 +213,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     HIP_CHECK(hipMemcpyAsync(TT.p, T1.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
     double *Tcur = TT.p;
     bool use_persistent = !directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
-                          (c->opt_fit_persistent == 2 || N >= 512);
+                          (c->opt_fit_persistent >= 2 || N >= 512);
     c->stat_fit_persistent = 0;
     c->stat_fit_iters = 0;
 
@@ -293,7 +293,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             if (use_persistent) { // the whole fit in one launch, GD's upper triangle in registers (kernels_fitp.hip)
                 HIP_CHECK(hipMemcpyAsync(c->fp_Tsave.p, TT.p + (i64)tpar * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
                 int fpar = tpar;
-                fitted = k_fit_persistent(c, GD.p, N, TT.p, Tld, tpar, G.vw, 0.25, delta, &iters, &fpar);
+                fitted = k_fit_persistent(c, GD.p, N, TT.p, Tld, tpar, G.vw, 0.25, delta, &iters, &fpar, c->opt_fit_persistent != 3);
                 if (fitted) {
                     tpar = fpar;
                     c->stat_fit_persistent++;
