@@ -236,16 +236,17 @@ def main():
         kernels[name] = ent
     # HBM traffic per launch from the committed PMC passes of this same command (profiles/run_profiles.sh)
     pmc, pmc_file = {}, os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    kernel_of = {"fit_symv": "fit_step_kernel", "fit_persistent": "fit_persistent_kernel", "pcent": "pcent_kernel", "pair_list": "pair_list_kernel",
+    kernel_of = {"fit_symv": "fit_step_kernel", "fit_persistent": "fit_dataflow_kernel", "pcent": "pcent_kernel", "pair_list": "pair_list_kernel",
                  "edge_scatter": "edge_scatter_kernel", "max_pair_dist": "max_pair_kernel"}
     if os.path.exists(pmc_file) and args.workload == "headline" and world == 1:
         try:
             pmc = json.load(open(pmc_file))["kernels"]
         except Exception:
             pmc = {}
-    for name, kname in kernel_of.items():
-        if name in kernels and kname in pmc:
-            kernels[name]["traffic"] = pmc[kname]["hbm_bytes_per_launch"]
+    for name, kname in kernel_of.items():  # template instances carry a <...> suffix in the profile
+        hit = [k for k in pmc if k == kname or k.startswith(kname + "<")]
+        if name in kernels and hit:
+            kernels[name]["traffic"] = pmc[hit[0]]["hbm_bytes_per_launch"]
     ranked = sorted((k for k in kernels if "frac" in kernels[k]), key=lambda k: -kernels[k]["total_ms_per_step"])
     dom = ranked[0] if ranked else None
     roofline = None

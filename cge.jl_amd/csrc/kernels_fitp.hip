@@ -22,8 +22,6 @@
 // (cdna_hip_programming.md, Guideline 16); the barrier is one monotonic counter.  Every spin is bounded: on a
 // timeout the launch sets `fail`, every workgroup leaves, and the host falls back to one launch per iteration.
 // All sums have a fixed order: a run is bitwise reproducible.
-#include <hip/hip_cooperative_groups.h>
-
 #include "common.hpp"
 
 namespace {
@@ -436,6 +434,10 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
 
 } // namespace
 
+static hipError_t hipModuleLaunchKernelCompat(const void *fn, int G, void **args, size_t lds, hipStream_t st) {
+    return hipLaunchKernel(fn, dim3((unsigned)G), dim3(256), args, lds, st);
+}
+
 // Runs the fit of one alpha from T = Tbuf[parity] (two buffers of `Tld` doubles, zero beyond N).  Returns false when the
 // persistent path does not apply or was abandoned (nothing usable was written: the caller restarts the fit with the
 // launch-per-iteration path from its own copy of T); otherwise *iters / *final_parity describe the converged state.
@@ -481,8 +483,17 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
                                   : (tpw == 1   ? (const void *)fit_persistent_kernel<1>
                                      : tpw == 2 ? (const void *)fit_persistent_kernel<2>
                                                 : (const void *)fit_persistent_kernel<3>);
-        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3((unsigned)G), dim3(256), args, dataflow ? 0 : lds, st);
-        if (e != hipSuccess) { // e.g. the grid cannot be co-resident on this device
+        // A plain launch: the grid is at most one workgroup per CU and nothing else runs on this stream's device queue, so
+        // it is resident as a whole (checked once against the occupancy query below); the cooperative-launch entry point
+        // would add only its launch-time size check (and rocprofv3 crashes at exit after it).  Every spin in the kernels is
+        // bounded, so a grid that is not co-resident after all ends in `fail` and the fallback, not in a hang.
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, dataflow ? 0 : lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            return false;
+        }
+        const hipError_t e = hipModuleLaunchKernelCompat(fn, G, args, dataflow ? 0 : lds, st);
+        if (e != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }

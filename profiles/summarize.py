@@ -17,6 +17,7 @@ def find(sub, pat):
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = name.split("(")[0]
     return name.replace("void ", "").strip()
 
