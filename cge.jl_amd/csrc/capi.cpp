@@ -864,6 +864,10 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_fit_persistent = (int)value;
         return CGE_OK;
     }
+    if (!strcmp(key, "fit_persistent_test_timeout")) { // testing: 1 = the persistent fit abandons every launch at once
+        c->opt_fit_test_timeout = value != 0;
+        return CGE_OK;
+    }
     return CGE_E_ARG;
 }
 int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {

@@ -248,6 +248,7 @@ struct cge_ctx {
     DevBuf<int> fp_flags;
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it
                                 // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
+    int opt_fit_test_timeout = 0; // testing: the persistent fit gives up at once, so the fallback path runs
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
     bool fit_persistent_broken = false; // a grid barrier timed out once (e.g. another process holds CUs): not tried again // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
@@ -281,6 +282,7 @@ struct cge_ctx {
     DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro, sp_perm, sp_status, sort_idx;
     DevBuf<unsigned char> sort_tmp;
     PinBuf<i32> pin_perm;
+    PinBuf<unsigned char> pin_side;
     DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals, sp_cmeans;
 
     // ---- profiling -------------------------------------------------------------------------
@@ -341,6 +343,10 @@ void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32
 void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *chunk_beg,
                      const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks, i64 d, double *ctot,
                      double *coff, double *prefix);
+void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
+                 i32 *meta, double *vals, double *cmeans);
+void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
+                 unsigned char *side);
 void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const double *zs,
                   const i32 *task_row_off, const i32 *task_chunk_off, const double *prefix, const double *coff,
                   i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals, double *cmeans /* [task][2][d] */);

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void fit_persistent_kernel(const double *__res
     __syncthreads();
 
     int par = parity, k = 0, converged = 0, failed = 0;
-    if (!gs.init(sync, wall_clock64() + timeout_ticks, &lds_ok)) { failed = 1; max_iters = 0; }
+    if (timeout_ticks <= 0 || !gs.init(sync, wall_clock64() + timeout_ticks, &lds_ok)) { failed = 1; max_iters = 0; }
     while (k < max_iters) {
         // ---- A: tile products ----------------------------------------------------------------------------------
 #pragma unroll
@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
     }
 
     int par = parity, k = 0, converged = 0, failed = 0;
+    if (timeout_ticks <= 0) max_iters = 0; // test hook: abandon at once (exercises the host's restore-and-fall-back path)
     for (;;) {
         if (k >= max_iters) { failed = 1; break; }
         // ---- 1. wait for T_k of the blocks this workgroup's tiles read (published by iteration k-1) --------------
@@ -475,7 +476,7 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
         double aEps = eps, aDelta = delta;
         unsigned *aSync = c->fp_sync.p;
         int *aFlags = c->fp_flags.p;
-        long long aTicks = 300000000LL; // 3 s of the 100 MHz wall clock
+        long long aTicks = c->opt_fit_test_timeout ? 0LL : 300000000LL; // 3 s of the 100 MHz wall clock (0: the test hook)
         void *args[] = {&aGD, &aN, &aNt, &aT, &aTld, &aPar, &aW, &aEps, &aDelta, &aMax, &aP, &aF, &aSync, &aFlags, &aTicks};
         const void *fn = dataflow ? (tpw == 1   ? (const void *)fit_dataflow_kernel<1>
                                      : tpw == 2 ? (const void *)fit_dataflow_kernel<2>
@@ -500,8 +501,8 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
         int hf[4];
         HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        if (hf[2]) { // a barrier timed out
-            c->fit_persistent_broken = true;
+        if (hf[2]) { // a wait timed out
+            if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
             return false;
         }
         total += hf[1];

@@ -776,6 +776,189 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
                        task_row_off, task_chunk_off, prefix, coff, d, meta, rounds, vals, cmeans);
 }
 
+// ------------------------------------------------------------------------------------------------
+// split_cluster_rss2 (src/landmarks.jl:92-152) on the device, one wave per task, rows in ascending-z order (srows):
+// the two-pointer walk absorbs one row per step into the low or the high WSSE triple -- the reference's own
+// additions in the reference's order (:105-117) -- then the boundary adjustment loops (:118-150).  Lane l holds the
+// columns l + 64 s.  The next candidate row of either side is loaded ahead of the decision.
+// meta[t] = {lo, hi}: low = ranks [0, lo], high = ranks [hi, k); vals / cmeans as in the rss kernel.
+__global__ __launch_bounds__(64) void rss2_walk_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                                       const i32 *__restrict__ srows,
+                                                       const i32 *__restrict__ task_row_off, i64 d,
+                                                       i32 *__restrict__ meta, double *__restrict__ vals,
+                                                       double *__restrict__ cmeans) {
+    const i64 t = blockIdx.x;
+    const int lane = threadIdx.x;
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    const i32 *p = srows + o;
+    struct Row { double x[RR_SLOTS]; double w; };
+    auto load = [&](i64 rank) {
+        Row r;
+        const i64 v = p[rank];
+        r.w = vw[v];
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; s++) {
+            const i64 c = lane + 64 * s;
+            r.x[s] = (c < d) ? Xr[v * d + c] : 0.0;
+        }
+        return r;
+    };
+    double l_ss[RR_SLOTS], l_s[RR_SLOTS], h_ss[RR_SLOTS], h_s[RR_SLOTS], l_w, h_w;
+    auto fsum = [&](const double (&ss)[RR_SLOTS], const double (&s1)[RR_SLOTS], double w) { // sum(wsse, r)
+        double acc = 0.0;
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; s++)
+            if (lane + 64 * s < d) acc += ss[s] - s1[s] * s1[s] / w;
+        return wave_sum(acc);
+    };
+    {
+        const Row a = load(0), b = load(k - 1);
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; s++) {
+            l_ss[s] = a.w * (a.x[s] * a.x[s]); l_s[s] = a.w * a.x[s];
+            h_ss[s] = b.w * (b.x[s] * b.x[s]); h_s[s] = b.w * b.x[s];
+        }
+        l_w = a.w;
+        h_w = b.w;
+    }
+    double fl = fsum(l_ss, l_s, l_w), fh = fsum(h_ss, h_s, h_w);
+    i64 lo = 0, hi = k - 1;
+    Row nl = load(lo + 1 < k ? lo + 1 : lo), nh = load(hi >= 1 ? hi - 1 : hi);
+    while (lo + 1 < hi) {
+        if (fl < fh) {
+            lo++;
+#pragma unroll
+            for (int s = 0; s < RR_SLOTS; s++) { l_ss[s] += nl.w * (nl.x[s] * nl.x[s]); l_s[s] += nl.w * nl.x[s]; }
+            l_w += nl.w;
+            if (lo + 1 < hi) nl = load(lo + 1);
+            fl = fsum(l_ss, l_s, l_w);
+        } else {
+            hi--;
+#pragma unroll
+            for (int s = 0; s < RR_SLOTS; s++) { h_ss[s] += nh.w * (nh.x[s] * nh.x[s]); h_s[s] += nh.w * nh.x[s]; }
+            h_w += nh.w;
+            if (lo + 1 < hi) nh = load(hi - 1);
+            fh = fsum(h_ss, h_s, h_w);
+        }
+    }
+    // boundary adjustment: move the last low row up, or the first high row down, while the larger RSS shrinks
+    bool moved_low = false;
+    double t_ss[RR_SLOTS], t_s[RR_SLOTS], u_ss[RR_SLOTS], u_s[RR_SLOTS];
+    while (lo > 0) {
+        const Row a = load(lo);
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; s++) {
+            const double ass = a.w * (a.x[s] * a.x[s]), as1 = a.w * a.x[s];
+            t_ss[s] = l_ss[s] - ass; t_s[s] = l_s[s] - as1;
+            u_ss[s] = h_ss[s] + ass; u_s[s] = h_s[s] + as1;
+        }
+        const double tw = l_w - a.w, uw = h_w + a.w;
+        const double ft = fsum(t_ss, t_s, tw), fu = fsum(u_ss, u_s, uw);
+        if (fmax(ft, fu) < fmax(fl, fh)) {
+            moved_low = true;
+            lo--; hi--;
+#pragma unroll
+            for (int s = 0; s < RR_SLOTS; s++) { l_ss[s] = t_ss[s]; l_s[s] = t_s[s]; h_ss[s] = u_ss[s]; h_s[s] = u_s[s]; }
+            l_w = tw; h_w = uw; fl = ft; fh = fu;
+        } else
+            break;
+    }
+    if (!moved_low)
+        while (hi < k - 1) {
+            const Row a = load(hi);
+#pragma unroll
+            for (int s = 0; s < RR_SLOTS; s++) {
+                const double ass = a.w * (a.x[s] * a.x[s]), as1 = a.w * a.x[s];
+                t_ss[s] = l_ss[s] + ass; t_s[s] = l_s[s] + as1;
+                u_ss[s] = h_ss[s] - ass; u_s[s] = h_s[s] - as1;
+            }
+            const double tw = l_w + a.w, uw = h_w - a.w;
+            const double ft = fsum(t_ss, t_s, tw), fu = fsum(u_ss, u_s, uw);
+            if (fmax(ft, fu) < fmax(fl, fh)) {
+                lo++; hi++;
+#pragma unroll
+                for (int s = 0; s < RR_SLOTS; s++) { l_ss[s] = t_ss[s]; l_s[s] = t_s[s]; h_ss[s] = u_ss[s]; h_s[s] = u_s[s]; }
+                l_w = tw; h_w = uw; fl = ft; fh = fu;
+            } else
+                break;
+        }
+#pragma unroll
+    for (int s = 0; s < RR_SLOTS; s++) {
+        const i64 c = lane + 64 * s;
+        if (c < d) {
+            cmeans[(2 * t) * d + c] = l_s[s] / l_w;
+            cmeans[(2 * t + 1) * d + c] = h_s[s] / h_w;
+        }
+    }
+    if (lane == 0) {
+        meta[2 * t] = (i32)lo;
+        meta[2 * t + 1] = (i32)hi;
+        vals[2 * t] = -fl;
+        vals[2 * t + 1] = -fh;
+    }
+}
+void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
+                 i32 *meta, double *vals, double *cmeans) {
+    if (d > 64 * RR_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * RR_SLOTS);
+    ScopedKernelTimer t(c, "rss2_walk");
+    hipLaunchKernelGGL(rss2_walk_kernel, dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off, d,
+                       meta, vals, cmeans);
+}
+
+// split_cluster_size / split_cluster_diameter (src/landmarks.jl:212-262): the 1-D cut of z at its median
+// (`zs` = z sorted per task) or at (min + max)/2, one wave per task.  side[j] = 1 (low) / 2 (high) in the rows' own
+// order.  A row with z == cut joins the side that is smaller at that moment of the reference's sequential pass
+// (:229-236, :255-261); the running sizes are carried across 64-row chunks as ballot counts, the ties of a chunk are
+// settled in lane order.
+__global__ __launch_bounds__(64) void cut_sides_kernel(const double *__restrict__ z, const double *__restrict__ zs,
+                                                       const i32 *__restrict__ task_row_off, int use_median,
+                                                       unsigned char *__restrict__ side) {
+    const i64 t = blockIdx.x;
+    const int lane = threadIdx.x;
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    double cut;
+    if (use_median)
+        cut = (k & 1) ? zs[o + k / 2] : zs[o + k / 2 - 1] / 2.0 + zs[o + k / 2] / 2.0;
+    else {
+        double lo = z[o], hi = z[o];
+        for (i64 j = lane; j < k; j += 64) {
+            const double v = z[o + j];
+            lo = fmin(lo, v);
+            hi = fmax(hi, v);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fmin(lo, __shfl_xor(lo, off));
+            hi = fmax(hi, __shfl_xor(hi, off));
+        }
+        cut = (lo + hi) / 2.0;
+    }
+    i64 nlow = 0, nhigh = 0;
+    for (i64 base = 0; base < k; base += 64) {
+        const i64 j = base + lane;
+        const bool valid = j < k;
+        const double zj = valid ? z[o + j] : 0.0;
+        const bool isl = valid && zj < cut, ise = valid && zj == cut, ish = valid && !isl && !ise;
+        const unsigned long long ml = __ballot(isl), mh = __ballot(ish);
+        unsigned long long me = __ballot(ise), al = 0ULL; // al: ties that go low
+        i64 el = 0, eh = 0;
+        while (me) {
+            const int i = __ffsll((long long)me) - 1;
+            me &= me - 1;
+            const unsigned long long below = (i == 0) ? 0ULL : (~0ULL >> (64 - i));
+            const i64 cl = nlow + __popcll(ml & below) + el, ch = nhigh + __popcll(mh & below) + eh;
+            if (cl < ch) { al |= 1ULL << i; el++; } else eh++;
+        }
+        if (valid) side[o + j] = (isl || (ise && ((al >> lane) & 1ULL))) ? 1 : 2;
+        nlow += __popcll(ml) + el;
+        nhigh += __popcll(mh) + eh;
+    }
+}
+void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
+                 unsigned char *side) {
+    ScopedKernelTimer t(c, "cut_sides");
+    hipLaunchKernelGGL(cut_sides_kernel, dim3((unsigned)n_tasks), dim3(64), 0, c->stream, z, zs, task_row_off, use_median, side);
+}
+
 // Side flags of one rss round, derived on the device (no per-round row-sized upload).  Per task t,
 // params[4t..4t+3] = { prev_med, absorb (0/1/2: the side that was absorbed after the previous round),
 // cur_med, mode (0 idle, 1 median round, 2 leftover round) }.  state[j]: 0 = gray, 1 = low, 2 = high.

@@ -108,16 +108,6 @@ inline double sum_wsse(const std::vector<Wsse> &r) {
     return t;
 }
 
-// View of one group on the host mirror (row-major rows, weights)
-struct HView {
-    const double *X; // n x d row-major
-    const double *w;
-    i64 d;
-    const i64 *what; // 1-based
-    i64 k;
-    const double *row(i64 j) const { return X + (what[j] - 1) * d; }
-    double wt(i64 j) const { return w[what[j] - 1]; }
-};
 
 // Statistics.median: middle of the sorted values, even length -> x/2 + y/2
 double median_sel(const double *z, const std::vector<i64> *sel, i64 k, std::vector<double> &scr) {
@@ -132,93 +122,6 @@ double median_sel(const double *z, const std::vector<i64> *sel, i64 k, std::vect
     return lo / 2.0 + hi / 2.0;
 }
 
-// split_cluster_rss2: src/landmarks.jl:92-147 (z given)
-int rule_rss2(const HView &v, const double *z, std::vector<i64> &low, std::vector<i64> &high) {
-    const i64 k = v.k, d = v.d;
-    std::vector<i64> p(k);
-    for (i64 i = 0; i < k; i++) p[i] = i;
-    std::stable_sort(p.begin(), p.end(), [&](i64 a, i64 b) { return z[a] < z[b]; });
-    auto one = [&](i64 j, i64 c) {
-        const double x = v.row(j)[c], w = v.wt(j);
-        return Wsse{w * (x * x), w * x, w};
-    };
-    std::vector<Wsse> rl(d), rh(d), rlt(d), rht(d);
-    for (i64 c = 0; c < d; c++) {
-        rl[c] = one(p[0], c);
-        rh[c] = one(p[k - 1], c);
-    }
-    i64 lo = 0, hi = k - 1;
-    while (lo + 1 < hi) {
-        if (sum_wsse(rl) < sum_wsse(rh)) {
-            lo++;
-            for (i64 c = 0; c < d; c++) {
-                const Wsse a = one(p[lo], c);
-                rl[c].ss += a.ss; rl[c].s += a.s; rl[c].ws += a.ws;
-            }
-        } else {
-            hi--;
-            for (i64 c = 0; c < d; c++) {
-                const Wsse a = one(p[hi], c);
-                rh[c].ss += a.ss; rh[c].s += a.s; rh[c].ws += a.ws;
-            }
-        }
-    }
-    bool moved_low = false;
-    while (lo > 0) {
-        for (i64 c = 0; c < d; c++) {
-            const Wsse a = one(p[lo], c);
-            rlt[c] = {rl[c].ss - a.ss, rl[c].s - a.s, rl[c].ws - a.ws};
-            rht[c] = {rh[c].ss + a.ss, rh[c].s + a.s, rh[c].ws + a.ws};
-        }
-        if (std::max(sum_wsse(rlt), sum_wsse(rht)) < std::max(sum_wsse(rl), sum_wsse(rh))) {
-            moved_low = true;
-            lo--; hi--;
-            rl = rlt; rh = rht;
-        } else
-            break;
-    }
-    if (!moved_low)
-        while (hi < k - 1) {
-            for (i64 c = 0; c < d; c++) {
-                const Wsse a = one(p[hi], c);
-                rlt[c] = {rl[c].ss + a.ss, rl[c].s + a.s, rl[c].ws + a.ws};
-                rht[c] = {rh[c].ss - a.ss, rh[c].s - a.s, rh[c].ws - a.ws};
-            }
-            if (std::max(sum_wsse(rlt), sum_wsse(rht)) < std::max(sum_wsse(rl), sum_wsse(rh))) {
-                lo++; hi++;
-                rl = rlt; rh = rht;
-            } else
-                break;
-        }
-    low.assign(p.begin(), p.begin() + lo + 1);
-    high.assign(p.begin() + hi, p.end());
-    return CGE_OK;
-}
-
-// split_cluster_size (:218-238) / split_cluster_diameter (:247-267) (z given)
-int rule_cut(const double *z, i64 k, bool use_median, std::vector<i64> &low, std::vector<i64> &high) {
-    double cut;
-    if (use_median) {
-        std::vector<double> scr;
-        cut = median_sel(z, nullptr, k, scr);
-    } else {
-        double lo = z[0], hi = z[0];
-        for (i64 j = 1; j < k; j++) {
-            lo = std::min(lo, z[j]);
-            hi = std::max(hi, z[j]);
-        }
-        cut = (lo + hi) / 2.0;
-    }
-    low.clear();
-    high.clear();
-    for (i64 j = 0; j < k; j++) {
-        if (z[j] == cut)
-            (low.size() < high.size() ? low : high).push_back(j);
-        else
-            (z[j] < cut ? low : high).push_back(j);
-    }
-    return CGE_OK;
-}
 
 } // namespace
 
@@ -686,12 +589,96 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const dou
         if (status[t] == 1) fallback.push_back(t);
 }
 
+// split_cluster_rss2 on the device (kernels_lm.hip: rss2_walk_kernel).  The children are rank ranges of the sorted
+// order, in that order (`p[1:low]`, `p[high:end]`, src/landmarks.jl:151), so the host only slices the permutation.
+void rule_rss2_device(cge_ctx *c, const Batch &B, Group *const *groups, std::vector<std::vector<i64>> &lows,
+                      std::vector<std::vector<i64>> &highs, std::vector<double> &vlow, std::vector<double> &vhigh,
+                      std::vector<char> &have_vals) {
+    const i64 T = B.T, R = B.R, d = c->d;
+    hipStream_t st = c->stream;
+    c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_tro.ensure(T + 1); c->sp_perm.ensure(R); c->sp_status.ensure(T);
+    c->sp_meta.ensure(2 * T); c->sp_vals.ensure(2 * T); c->sp_cmeans.ensure((size_t)2 * T * d);
+    c->pin_perm.ensure(R);
+    c->pin_cmeans.ensure((size_t)2 * T * d);
+    HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
+    k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
+                       c->sp_srows.p, c->sp_status.p);
+    HIP_CHECK(hipEventRecord(c->copy_ev, st));
+    HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->copy_ev, 0));
+    HIP_CHECK(hipMemcpyAsync(c->pin_perm.p, c->sp_perm.p, sizeof(i32) * R, hipMemcpyDeviceToHost, c->copy_stream));
+    k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->sp_cmeans.p);
+    std::vector<i32> meta(2 * T);
+    std::vector<double> vals(2 * T);
+    HIP_CHECK(hipMemcpyAsync(meta.data(), c->sp_meta.p, sizeof(i32) * 2 * T, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(c->pin_cmeans.p, c->sp_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+    const i32 *perm = c->pin_perm.p;
+    parallel_for(c, T, [&](i64 t) {
+        Group *g = groups[t];
+        const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
+        const i32 *p = &perm[o];
+        const i64 lo = meta[2 * t], hi = meta[2 * t + 1];
+        lows[t].assign(p, p + lo + 1);
+        highs[t].assign(p + hi, p + k);
+        vlow[t] = vals[2 * t];
+        vhigh[t] = vals[2 * t + 1];
+        have_vals[t] = 1;
+        const double *cm = c->pin_cmeans.p + (size_t)2 * t * d;
+        g->mlow.assign(cm, cm + d);
+        g->mhigh.assign(cm + d, cm + 2 * d);
+        g->rc = CGE_OK;
+    });
+}
+
+// split_cluster_size / split_cluster_diameter on the device (kernels_lm.hip: cut_sides_kernel): the side of every row,
+// then the children's WSSE column sums (values and means) by the side-sums pass; the host only lists the members of
+// either side in the rows' order.
+void rule_cut_device(cge_ctx *c, const Batch &B, Group *const *groups, bool use_median, std::vector<std::vector<i64>> &lows,
+                     std::vector<std::vector<i64>> &highs, std::vector<double> &vlow, std::vector<double> &vhigh,
+                     std::vector<char> &have_vals) {
+    const i64 T = B.T, R = B.R, d = c->d, width = 2 * (2 * d + 1);
+    hipStream_t st = c->stream;
+    c->sp_tro.ensure(T + 1);
+    HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
+    if (use_median) { // the median needs the sorted projections
+        c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
+        k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
+                           c->sp_srows.p, c->sp_status.p);
+    }
+    k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p);
+    c->pin_side.ensure(R);
+    HIP_CHECK(hipEventRecord(c->copy_ev, st));
+    HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->copy_ev, 0));
+    HIP_CHECK(hipMemcpyAsync(c->pin_side.p, c->ls_side.p, (size_t)R, hipMemcpyDeviceToHost, c->copy_stream));
+    const double *sums = side_sums_resident(c, B); // synchronises the main stream
+    HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+    const unsigned char *side = c->pin_side.p;
+    parallel_for(c, T, [&](i64 t) {
+        Group *g = groups[t];
+        const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
+        lows[t].clear();
+        highs[t].clear();
+        for (i64 j = 0; j < k; j++) (side[o + j] == 1 ? lows[t] : highs[t]).push_back(j);
+        const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
+        vlow[t] = -rss_from_sums(q1, d);
+        vhigh[t] = -rss_from_sums(q2, d);
+        have_vals[t] = 1;
+        g->mlow.resize(d);
+        g->mhigh.resize(d);
+        for (i64 c2 = 0; c2 < d; c2++) {
+            g->mlow[c2] = q1[d + c2] / q1[2 * d];
+            g->mhigh[c2] = q2[d + c2] / q2[2 * d];
+        }
+        g->rc = CGE_OK;
+    });
+}
+
 // Compute the split of every task.  Device: mean, covariance, principal eigenvector, projection,
 // WSSE column sums of the rss rounds and of the children.  Host: the 1-D cut logic on z.
 void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
     const i64 d = c->d, width = 2 * (2 * d + 1);
-    const double *hX = c->h_Xr.data();
-    const double *hw = c->h_vw.data();
     std::vector<Group *> big;
     for (Group *g : tasks) {
         const i64 k = (i64)g->what.size();
@@ -760,10 +747,6 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                 k_group_project(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_row_task.p, R, d, c->ls_mean.p, c->ls_vec.p,
                                 c->ls_z.p);
             }
-            if (method != CGE_METHOD_RSS) { // the rss rule cuts on the device; the other rules' 1-D logic runs on the host
-                HIP_CHECK(hipMemcpyAsync(c->pin_z.p, c->ls_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipStreamSynchronize(st));
-            }
         }
         // ---- the cut: local positions of the two children -----------------------------------------------------
         std::vector<std::vector<i64>> lows(T), highs(T);
@@ -797,18 +780,10 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                     }
                     upload_batch(c, B); // the children pass below works on the full batch again
                 }
-            } else {
-                parallel_for(c, T, [&](i64 t) {
-                    Group *g = groups[t];
-                    const i64 k = (i64)g->what.size();
-                    const double *zt = &z[B.task_row_off[t]];
-                    if (method == CGE_METHOD_RSS2) {
-                        HView v{hX, hw, d, g->what.data(), k};
-                        g->rc = rule_rss2(v, zt, lows[t], highs[t]);
-                    } else
-                        g->rc = rule_cut(zt, k, method == CGE_METHOD_SIZE, lows[t], highs[t]);
-                });
-            }
+            } else if (method == CGE_METHOD_RSS2)
+                rule_rss2_device(c, B, groups, lows, highs, vlow, vhigh, have_vals);
+            else
+                rule_cut_device(c, B, groups, method == CGE_METHOD_SIZE, lows, highs, vlow, vhigh, have_vals);
         }
         // ---- children: vertex lists and heap values (-total_rss, or eps() for singletons) ---------------------------
         {

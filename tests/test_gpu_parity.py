@@ -297,6 +297,34 @@ def test_fit_persistent_kernel_matches_stepwise_and_oracle(ctx, orc, n):
         _cmp_result(r2, exp, t2, etr)
 
 
+def test_fit_persistent_abandoned_launch_falls_back(ctx):
+    """A persistent launch that gives up (here: forced through the testing option; in production a wait that timed
+    out) leaves T untouched for the host, which restores it and fits the alpha with one launch per iteration."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    n = 600
+    g = synth.abcd_like(n, 5 * n, 8, 8, seed=77)
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    ctx.set_graph(g["edges"], g["eweights"], n)
+    smp = api.draw_samples(ctx, 5, 1500)
+    args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
+    try:
+        ctx.set_option("fit_persistent", 1)
+        ref, tref = cg.wGCL(*args, samples=smp, trace=True, ctx=ctx)
+        ctx.set_option("fit_persistent", 2)
+        ctx.set_option("fit_persistent_test_timeout", 1)
+        got, tgot = cg.wGCL(*args, samples=smp, trace=True, ctx=ctx)
+        assert ctx.get_stat("fit_persistent_alphas") == 0
+        assert np.array_equal(ref, got) and tref["iters"] == tgot["iters"]
+        ctx.set_option("fit_persistent_test_timeout", 0)
+        again, _ = cg.wGCL(*args, samples=smp, trace=True, ctx=ctx)
+        assert ctx.get_stat("fit_persistent_alphas") > 0 and np.allclose(again, ref, rtol=1e-11, atol=1e-13)
+    finally:
+        ctx.set_option("fit_persistent_test_timeout", 0)
+        ctx.set_option("fit_persistent", 0)
+
+
 def test_fit_persistent_kernel_headline_landmark_count(ctx):
     """4000 landmarks (two tiles per wave, every CU busy): the persistent fit and the launch-per-iteration path
     give the same score vector."""
