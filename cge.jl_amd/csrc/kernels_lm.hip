@@ -10,6 +10,30 @@
 
 #define WAVE 64
 
+// ---- in-wave reductions by DPP (no LDS crossbar): used by the eigen-solver and the sequential rule kernels ----------
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane) { // uniform result (two v_readlane_b32)
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)b, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// sum over the 64 lanes of a wave, the same bits in every lane and in every wave that sums the same values:
+// butterfly inside each row of 16 (quad swaps, half mirror, mirror), then the four row totals in fixed order
+__device__ __forceinline__ double wave_allsum(double v) {
+    v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v); // row_half_mirror
+    v += dpp_move<0x140>(v); // row_mirror
+    return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
+}
+
 // ------------------------------------------------------------------------------------------------
 // column-major (n x d, Julia) -> row-major (node-major).  32x32 tiles through LDS.
 __global__ void transpose_kernel(const double *__restrict__ Xcol, double *__restrict__ Xrow, i64 n, i64 d) {
@@ -782,108 +806,168 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
 // additions in the reference's order (:105-117) -- then the boundary adjustment loops (:118-150).  Lane l holds the
 // columns l + 64 s.  The next candidate row of either side is loaded ahead of the decision.
 // meta[t] = {lo, hi}: low = ranks [0, lo], high = ranks [hi, k); vals / cmeans as in the rss kernel.
+template <int NS> // NS = columns per lane (d <= 64*NS)
 __global__ __launch_bounds__(64) void rss2_walk_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                                        const i32 *__restrict__ srows,
                                                        const i32 *__restrict__ task_row_off, i64 d,
                                                        i32 *__restrict__ meta, double *__restrict__ vals,
                                                        double *__restrict__ cmeans) {
+    // The walk consumes WR-row windows on either side.  A window is filled with all its row loads in flight together,
+    // and the RSS after absorbing each of its rows -- sum(wsse, rss_low) of :106 for the next WR low ranks, likewise on
+    // the high side -- is computed right away: the WR running triples are a short dependent chain, the WR
+    // divide-and-reduce evaluations behind them are independent and overlap.  The walk itself then only compares two
+    // precomputed numbers per step.
+    constexpr int WR = NS <= 2 ? 16 : NS <= 4 ? 8 : 4;
+    __shared__ __attribute__((aligned(16))) double win[2][WR][NS][64]; // rows of the two windows
+    __shared__ double wwin[2][WR], fwin[2][WR];                          // their weights, the RSS after each row
     const i64 t = blockIdx.x;
     const int lane = threadIdx.x;
     const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
     const i32 *p = srows + o;
-    struct Row { double x[RR_SLOTS]; double w; };
-    auto load = [&](i64 rank) {
-        Row r;
-        const i64 v = p[rank];
-        r.w = vw[v];
-#pragma unroll
-        for (int s = 0; s < RR_SLOTS; s++) {
-            const i64 c = lane + 64 * s;
-            r.x[s] = (c < d) ? Xr[v * d + c] : 0.0;
-        }
-        return r;
-    };
-    double l_ss[RR_SLOTS], l_s[RR_SLOTS], h_ss[RR_SLOTS], h_s[RR_SLOTS], l_w, h_w;
-    auto fsum = [&](const double (&ss)[RR_SLOTS], const double (&s1)[RR_SLOTS], double w) { // sum(wsse, r)
+    double b_ss[2][NS], b_s[2][NS], b_w[2]; // WSSE triples at the start of either window
+    auto wsse_part = [&](const double (&ss)[NS], const double (&s1)[NS], double w) { // this lane's share of sum(wsse, r)
         double acc = 0.0;
 #pragma unroll
-        for (int s = 0; s < RR_SLOTS; s++)
-            if (lane + 64 * s < d) acc += ss[s] - s1[s] * s1[s] / w;
-        return wave_sum(acc);
+        for (int s = 0; s < NS; s++) acc += ss[s] - s1[s] * s1[s] / w; // padded columns are 0
+        return acc;
     };
-    {
-        const Row a = load(0), b = load(k - 1);
+    // window of `side` <- ranks first, first+step, ... (step +1 low / -1 high); fwin[side][q] = RSS with slots 0..q absorbed
+    auto fill = [&](const int side, i64 first, i64 step) {
+        constexpr int U = NS <= 1 ? 16 : NS <= 2 ? 8 : NS <= 4 ? 4 : 2;
+        const i64 rankq = first + step * lane;
+        const bool okq = lane < WR && rankq >= 0 && rankq < k;
+        const int vq = okq ? p[rankq] : p[0]; // slots past the end: a valid row with weight 0
+        if (lane < WR) wwin[side][lane] = okq ? vw[vq] : 0.0;
+        for (int q0 = 0; q0 < WR; q0 += U) {
+            double x[U][NS];
 #pragma unroll
-        for (int s = 0; s < RR_SLOTS; s++) {
-            l_ss[s] = a.w * (a.x[s] * a.x[s]); l_s[s] = a.w * a.x[s];
-            h_ss[s] = b.w * (b.x[s] * b.x[s]); h_s[s] = b.w * b.x[s];
+            for (int u = 0; u < U; u++) {
+                const i64 v = __shfl(vq, (q0 + u) & 63);
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const i64 c = lane + 64 * s;
+                    x[u][s] = (c < d) ? Xr[v * d + c] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (q0 + u < WR) {
+#pragma unroll
+                    for (int s = 0; s < NS; s++) win[side][q0 + u][s][lane] = x[u][s];
+                }
         }
-        l_w = a.w;
-        h_w = b.w;
-    }
-    double fl = fsum(l_ss, l_s, l_w), fh = fsum(h_ss, h_s, h_w);
+        __builtin_amdgcn_wave_barrier();
+        double r_ss[NS], r_s[NS], r_w = b_w[side], part[WR];
+#pragma unroll
+        for (int s = 0; s < NS; s++) { r_ss[s] = b_ss[side][s]; r_s[s] = b_s[side][s]; }
+#pragma unroll
+        for (int q = 0; q < WR; q++) {
+            const double w = wwin[side][q];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const double xv = win[side][q][s][lane];
+                r_ss[s] += w * (xv * xv);
+                r_s[s] += w * xv;
+            }
+            r_w += w;
+            part[q] = wsse_part(r_ss, r_s, r_w);
+        }
+#pragma unroll
+        for (int q = 0; q < WR; q++) {
+            const double f = wave_allsum(part[q]);
+            if (lane == 0) fwin[side][q] = f;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // b[side] += the first `cnt` rows of the window
+    auto absorb = [&](const int side, int cnt) {
+        for (int q = 0; q < cnt; q++) {
+            const double w = wwin[side][q];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const double xv = win[side][q][s][lane];
+                b_ss[side][s] += w * (xv * xv);
+                b_s[side][s] += w * xv;
+            }
+            b_w[side] += w;
+        }
+    };
+    auto term = [&](i64 rank, double (&ss)[NS], double (&s1)[NS], double &w) { // WSSE(m[p[rank], :], w[p[rank]])
+        const i64 v = p[rank];
+        w = vw[v];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const i64 c = lane + 64 * s;
+            const double x = (c < d) ? Xr[v * d + c] : 0.0;
+            ss[s] = w * (x * x);
+            s1[s] = w * x;
+        }
+    };
+    auto fsum = [&](const double (&ss)[NS], const double (&s1)[NS], double w) { return wave_allsum(wsse_part(ss, s1, w)); };
+    term(0, b_ss[0], b_s[0], b_w[0]);
+    term(k - 1, b_ss[1], b_s[1], b_w[1]);
+    double fl = fsum(b_ss[0], b_s[0], b_w[0]), fh = fsum(b_ss[1], b_s[1], b_w[1]);
     i64 lo = 0, hi = k - 1;
-    Row nl = load(lo + 1 < k ? lo + 1 : lo), nh = load(hi >= 1 ? hi - 1 : hi);
+    int il = 0, ih = 0; // slots of the windows already absorbed
+    fill(0, lo + 1, 1);
+    fill(1, hi - 1, -1);
     while (lo + 1 < hi) {
         if (fl < fh) {
             lo++;
-#pragma unroll
-            for (int s = 0; s < RR_SLOTS; s++) { l_ss[s] += nl.w * (nl.x[s] * nl.x[s]); l_s[s] += nl.w * nl.x[s]; }
-            l_w += nl.w;
-            if (lo + 1 < hi) nl = load(lo + 1);
-            fl = fsum(l_ss, l_s, l_w);
+            fl = fwin[0][il++];
+            if (il == WR && lo + 1 < hi) { absorb(0, WR); il = 0; fill(0, lo + 1, 1); }
         } else {
             hi--;
-#pragma unroll
-            for (int s = 0; s < RR_SLOTS; s++) { h_ss[s] += nh.w * (nh.x[s] * nh.x[s]); h_s[s] += nh.w * nh.x[s]; }
-            h_w += nh.w;
-            if (lo + 1 < hi) nh = load(hi - 1);
-            fh = fsum(h_ss, h_s, h_w);
+            fh = fwin[1][ih++];
+            if (ih == WR && lo + 1 < hi) { absorb(1, WR); ih = 0; fill(1, hi - 1, -1); }
         }
     }
+    absorb(0, il);
+    absorb(1, ih);
+    double l_ss[NS], l_s[NS], h_ss[NS], h_s[NS], l_w = b_w[0], h_w = b_w[1];
+#pragma unroll
+    for (int s = 0; s < NS; s++) { l_ss[s] = b_ss[0][s]; l_s[s] = b_s[0][s]; h_ss[s] = b_ss[1][s]; h_s[s] = b_s[1][s]; }
     // boundary adjustment: move the last low row up, or the first high row down, while the larger RSS shrinks
     bool moved_low = false;
-    double t_ss[RR_SLOTS], t_s[RR_SLOTS], u_ss[RR_SLOTS], u_s[RR_SLOTS];
+    double a_ss[NS], a_s[NS], t_ss[NS], t_s[NS], u_ss[NS], u_s[NS], aw;
     while (lo > 0) {
-        const Row a = load(lo);
+        term(lo, a_ss, a_s, aw);
 #pragma unroll
-        for (int s = 0; s < RR_SLOTS; s++) {
-            const double ass = a.w * (a.x[s] * a.x[s]), as1 = a.w * a.x[s];
-            t_ss[s] = l_ss[s] - ass; t_s[s] = l_s[s] - as1;
-            u_ss[s] = h_ss[s] + ass; u_s[s] = h_s[s] + as1;
+        for (int s = 0; s < NS; s++) {
+            t_ss[s] = l_ss[s] - a_ss[s]; t_s[s] = l_s[s] - a_s[s];
+            u_ss[s] = h_ss[s] + a_ss[s]; u_s[s] = h_s[s] + a_s[s];
         }
-        const double tw = l_w - a.w, uw = h_w + a.w;
+        const double tw = l_w - aw, uw = h_w + aw;
         const double ft = fsum(t_ss, t_s, tw), fu = fsum(u_ss, u_s, uw);
         if (fmax(ft, fu) < fmax(fl, fh)) {
             moved_low = true;
             lo--; hi--;
 #pragma unroll
-            for (int s = 0; s < RR_SLOTS; s++) { l_ss[s] = t_ss[s]; l_s[s] = t_s[s]; h_ss[s] = u_ss[s]; h_s[s] = u_s[s]; }
+            for (int s = 0; s < NS; s++) { l_ss[s] = t_ss[s]; l_s[s] = t_s[s]; h_ss[s] = u_ss[s]; h_s[s] = u_s[s]; }
             l_w = tw; h_w = uw; fl = ft; fh = fu;
         } else
             break;
     }
     if (!moved_low)
         while (hi < k - 1) {
-            const Row a = load(hi);
+            term(hi, a_ss, a_s, aw);
 #pragma unroll
-            for (int s = 0; s < RR_SLOTS; s++) {
-                const double ass = a.w * (a.x[s] * a.x[s]), as1 = a.w * a.x[s];
-                t_ss[s] = l_ss[s] + ass; t_s[s] = l_s[s] + as1;
-                u_ss[s] = h_ss[s] - ass; u_s[s] = h_s[s] - as1;
+            for (int s = 0; s < NS; s++) {
+                t_ss[s] = l_ss[s] + a_ss[s]; t_s[s] = l_s[s] + a_s[s];
+                u_ss[s] = h_ss[s] - a_ss[s]; u_s[s] = h_s[s] - a_s[s];
             }
-            const double tw = l_w + a.w, uw = h_w - a.w;
+            const double tw = l_w + aw, uw = h_w - aw;
             const double ft = fsum(t_ss, t_s, tw), fu = fsum(u_ss, u_s, uw);
             if (fmax(ft, fu) < fmax(fl, fh)) {
                 lo++; hi++;
 #pragma unroll
-                for (int s = 0; s < RR_SLOTS; s++) { l_ss[s] = t_ss[s]; l_s[s] = t_s[s]; h_ss[s] = u_ss[s]; h_s[s] = u_s[s]; }
+                for (int s = 0; s < NS; s++) { l_ss[s] = t_ss[s]; l_s[s] = t_s[s]; h_ss[s] = u_ss[s]; h_s[s] = u_s[s]; }
                 l_w = tw; h_w = uw; fl = ft; fh = fu;
             } else
                 break;
         }
 #pragma unroll
-    for (int s = 0; s < RR_SLOTS; s++) {
+    for (int s = 0; s < NS; s++) {
         const i64 c = lane + 64 * s;
         if (c < d) {
             cmeans[(2 * t) * d + c] = l_s[s] / l_w;
@@ -901,8 +985,15 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
                  i32 *meta, double *vals, double *cmeans) {
     if (d > 64 * RR_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * RR_SLOTS);
     ScopedKernelTimer t(c, "rss2_walk");
-    hipLaunchKernelGGL(rss2_walk_kernel, dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off, d,
-                       meta, vals, cmeans);
+    const int ns = d <= 64 ? 1 : d <= 128 ? 2 : d <= 256 ? 4 : 8;
+    const dim3 grid((unsigned)n_tasks), block(64);
+#define CGE_RSS2_LAUNCH(NS) \
+    hipLaunchKernelGGL((rss2_walk_kernel<NS>), grid, block, 0, c->stream, Xr, vw, srows, task_row_off, d, meta, vals, cmeans)
+    if (ns == 1) CGE_RSS2_LAUNCH(1);
+    else if (ns == 2) CGE_RSS2_LAUNCH(2);
+    else if (ns == 4) CGE_RSS2_LAUNCH(4);
+    else CGE_RSS2_LAUNCH(8);
+#undef CGE_RSS2_LAUNCH
 }
 
 // split_cluster_size / split_cluster_diameter (src/landmarks.jl:212-262): the 1-D cut of z at its median
@@ -1007,28 +1098,6 @@ __device__ __forceinline__ double fast_rcp(double q) {
     double r = __builtin_amdgcn_rcp(q);
     r = fma(fma(-q, r, 1.0), r, r);
     return r;
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double lane_value(double v, int lane) { // uniform result (two v_readlane_b32)
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(unsigned)b, lane);
-    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-// sum over the 64 lanes of a wave, the same bits in every lane and in every wave that sums the same values:
-// butterfly inside each row of 16 (quad swaps, half mirror, mirror), then the four row totals in fixed order
-__device__ __forceinline__ double wave_allsum(double v) {
-    v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
-    v += dpp_move<0x141>(v); // row_half_mirror
-    v += dpp_move<0x140>(v); // row_mirror
-    return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
 }
 template <int NR, int NC>
 __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restrict__ cov, int d,
