@@ -243,7 +243,7 @@ struct cge_ctx {
     DevBuf<int> sw_flags;
     DevBuf<unsigned long long> sw_fring;
     // persistent Chung-Lu fit (kernels_fitp.hip): T double buffer, partial vectors, per-workgroup maxima, barrier words
-    DevBuf<double> fp_T, fp_Tsave, fp_P, fp_fpart, fp_fq;
+    DevBuf<double> fp_T, fp_Tsave, fp_P, fp_fpart, fp_fq, fp_Td;
     DevBuf<unsigned> fp_sync;
     DevBuf<int> fp_flags;
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it
@@ -394,6 +394,8 @@ void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, 
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD);
 bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
                       double delta, i64 *iters, int *final_parity, bool dataflow);
+bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
+                          const double *deg_out, double eps0, double f0, double delta, i64 *iters);
 void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
                 double delta, int k, unsigned long long *fring, int *done, int *iters);
 void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done);

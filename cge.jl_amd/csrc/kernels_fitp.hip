@@ -433,6 +433,182 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
     }
 }
 
+// ---- the directed fit (src/divergence.jl:434-467) in the same dataflow form ----------------------------------------
+// Sin_i = sum_j (Tin_i*Tout_j)*g_ij, Sout_i = sum_j (Tin_j*Tout_i)*g_ij, the diagonal term counted twice (:439-449).
+// A tile element feeds four sums: e1 = (Tin_i*Tout_j)*g goes to Sin_i and Sout_j, e2 = (Tin_j*Tout_i)*g to Sout_i and
+// Sin_j.  T holds four vectors per parity (Tbuf[(2*par + 0/1)*Tld] = Tin / Tout), P two partial vectors per
+// (block, other block) (P[0] for Sin, P[1] for Sout).  The step size decays (`epsilon *= 0.99` whenever f grew, :462-464):
+// every reducing workgroup replays that rule from the same f history, which it reads anyway for the convergence test.
+template <int TPW>
+__global__ __launch_bounds__(256) void fit_dataflow_dir_kernel(const double *__restrict__ GD, i64 N, int Nt, double *Tbuf,
+                                                               i64 Tld, int parity, const double *__restrict__ deg_in,
+                                                               const double *__restrict__ deg_out, double eps0,
+                                                               double f0, double delta, int max_iters, double *P,
+                                                               double *fq, unsigned *sync, int *flags,
+                                                               long long timeout_ticks) {
+    __shared__ double red[2][16][17];
+    __shared__ double fred[4];
+    __shared__ int lds_flag;
+    __shared__ int blkI[4 * TPW], blkJ[4 * TPW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
+    const int rq = lane >> 3, cq = lane & 7;
+    const int NT = Nt * (Nt + 1) / 2;
+    unsigned *fail = sync + 1, *done = sync + 2, *cntP = sync + 64, *cntT = sync + 4096;
+    const long long deadline = wall_clock64() + timeout_ticks;
+    const i64 Pstride = (i64)Nt * Nt * 64;
+
+    double g[TPW][8][8];
+    int tI[TPW], tJ[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+        const int t = (wg * 4 + wave) + s * 4 * G;
+        tI[s] = -1;
+        tJ[s] = -1;
+        if (t < NT) {
+            int I = 0, rem = t;
+            while (rem >= Nt - I) { rem -= Nt - I; I++; }
+            tI[s] = I;
+            tJ[s] = I + rem;
+        }
+        if (lane == 0) { blkI[wave * TPW + s] = tI[s]; blkJ[wave * TPW + s] = tJ[s]; }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const i64 row = (i64)64 * tI[s] + 8 * rq + a;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const i64 col = (i64)64 * tJ[s] + 8 * cq + b;
+                g[s][a][b] = (tI[s] >= 0 && row < N && col < N) ? GD[row * N + col] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    int my_blk = -1;
+    if (tid < 8 * TPW) {
+        const int e = tid >> 1;
+        my_blk = (tid & 1) ? ((blkJ[e] != blkI[e]) ? blkJ[e] : -1) : blkI[e];
+    }
+
+    int par = parity, k = 0, converged = 0, failed = 0;
+    double eps = eps0, fprev = f0;
+    if (timeout_ticks <= 0) max_iters = 0; // test hook
+    for (;;) {
+        if (k >= max_iters) { failed = 1; break; }
+        if (k > 0) { // 1. T_k of the blocks this workgroup's tiles read
+            if (wave == 0) {
+                int r = 0;
+                if (my_blk >= 0) r = poll_ge(cntT + 32 * my_blk, 4u * (unsigned)k, fail, done, deadline);
+                r = __any(r == 2) ? 2 : (__any(r == 1) ? 1 : 0);
+                if (lane == 0) lds_flag = r;
+            }
+            __syncthreads();
+            const int r = lds_flag;
+            __syncthreads();
+            if (r == 2) { failed = 1; break; }
+            if (r == 1) { converged = 1; break; }
+        }
+        const double *Tin = Tbuf + (i64)(2 * par) * Tld, *Tout = Tin + Tld;
+#pragma unroll
+        for (int s = 0; s < TPW; s++) { // 2. tile products
+            if (tI[s] < 0) continue;
+            const int I = tI[s], J = tJ[s];
+            double ini[8], oui[8], inj[8], ouj[8], ri[8], ro[8], ci[8], co[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                ini[q] = ld_sc1(Tin + 64 * I + 8 * rq + q);
+                oui[q] = ld_sc1(Tout + 64 * I + 8 * rq + q);
+                inj[q] = ld_sc1(Tin + 64 * J + 8 * cq + q);
+                ouj[q] = ld_sc1(Tout + 64 * J + 8 * cq + q);
+                ri[q] = ro[q] = ci[q] = co[q] = 0.0;
+            }
+            const bool diag_tile = I == J;
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    double e1 = (ini[a] * ouj[b]) * g[s][a][b], e2 = (inj[b] * oui[a]) * g[s][a][b];
+                    if (diag_tile && rq == cq && a == b) { e1 += e1; e2 += e2; } // the j == i term counts twice
+                    ri[a] += e1; co[b] += e1;
+                    ro[a] += e2; ci[b] += e2;
+                }
+            const double s_ri = transpose_reduce8<0>(ri, lane), s_ro = transpose_reduce8<0>(ro, lane);
+            st_sc1(P + ((i64)I * Nt + J) * 64 + lane, s_ri);
+            st_sc1(P + Pstride + ((i64)I * Nt + J) * 64 + lane, s_ro);
+            if (!diag_tile) {
+                const double s_ci = transpose_reduce8<3>(ci, lane), s_co = transpose_reduce8<3>(co, lane);
+                st_sc1(P + ((i64)J * Nt + I) * 64 + 8 * cq + rq, s_ci);
+                st_sc1(P + Pstride + ((i64)J * Nt + I) * 64 + 8 * cq + rq, s_co);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (my_blk >= 0) __hip_atomic_fetch_add(cntP + 32 * my_blk, 1u, RLX_AGENT);
+        bool stop = false;
+        for (int sb = wg; sb < 4 * Nt; sb += G) { // 3. the quarter blocks this workgroup reduces
+            const int b = sb >> 2, r = tid & 15, qg = tid >> 4, rib = 16 * (sb & 3) + r;
+            if (tid == 0) lds_flag = poll_ge(cntP + 32 * b, (unsigned)Nt * (unsigned)(k + 1), fail, done, deadline);
+            __syncthreads();
+            const int pr_ = lds_flag;
+            if (pr_ != 0) { failed = (pr_ == 2); converged = (pr_ == 1); stop = true; break; }
+            double pi[4], po[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int q = qg + 16 * u;
+                pi[u] = (q < Nt) ? ld_sc1(P + ((i64)b * Nt + q) * 64 + rib) : 0.0;
+                po[u] = (q < Nt) ? ld_sc1(P + Pstride + ((i64)b * Nt + q) * 64 + rib) : 0.0;
+            }
+            if (k > 0 && sb == wg) { // f of iteration k-1: the step-size rule, then `while diff > delta`
+                double f = 0.0;
+                const double *fp = fq + (i64)((k - 1) & 1) * 4 * Nt;
+                for (int q = tid; q < 4 * Nt; q += 256) f = fmax(f, ld_sc1(fp + q));
+                for (int off = 32; off > 0; off >>= 1) f = fmax(f, __shfl_xor(f, off));
+                if (lane == 0) fred[wave] = f;
+                __syncthreads();
+                f = fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3]));
+                if (f > fprev) eps *= 0.99;
+                fprev = f;
+                if (!(f > delta)) { converged = 1; stop = true; break; }
+            }
+            __syncthreads();
+            red[0][qg][r] = ((pi[0] + pi[1]) + pi[2]) + pi[3];
+            red[1][qg][r] = ((po[0] + po[1]) + po[2]) + po[3];
+            __syncthreads();
+            if (qg == 0) {
+                double Si = red[0][0][r], So = red[1][0][r];
+#pragma unroll
+                for (int u = 1; u < 16; u++) { Si += red[0][u][r]; So += red[1][u][r]; }
+                const i64 row = (i64)64 * b + rib;
+                double fr = 0.0;
+                if (row < N) {
+                    const double di = deg_in[row], dout = deg_out[row];
+                    const double tin = ld_sc1(Tin + row), tout = ld_sc1(Tout + row);
+                    double nin = tin, nout = tout;
+                    if (di > 0) { nin = tin + (eps * tin) * (di / Si - 1.0); fr = fmax(fr, fabs(di - Si)); }
+                    if (dout > 0) { nout = tout + (eps * tout) * (dout / So - 1.0); fr = fmax(fr, fabs(dout - So)); }
+                    st_sc1(Tbuf + (i64)(2 * (par ^ 1)) * Tld + row, nin);
+                    st_sc1(Tbuf + (i64)(2 * (par ^ 1) + 1) * Tld + row, nout);
+                }
+                for (int off = 8; off > 0; off >>= 1) fr = fmax(fr, __shfl_xor(fr, off));
+                if (r == 0) st_sc1(fq + (i64)(k & 1) * 4 * Nt + sb, fr);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cntT + 32 * b, 1u, RLX_AGENT);
+        }
+        if (stop) {
+            if (converged && tid == 0) __hip_atomic_store(done, 1u, RLX_AGENT);
+            break;
+        }
+        par ^= 1;
+        k++;
+    }
+    if (wg == 0 && tid == 0) {
+        flags[0] = converged;
+        flags[1] = k;
+        flags[2] = failed || !converged;
+        flags[3] = par;
+    }
+}
+
 } // namespace
 
 static hipError_t hipModuleLaunchKernelCompat(const void *fn, int G, void **args, size_t lds, hipStream_t st) {
@@ -515,4 +691,62 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
         if (total > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge");
     }
     return false;
+}
+
+// Directed fit of one alpha from Tin / Tout (N doubles each, updated in place on success).  Returns false when the
+// persistent path does not apply or was abandoned; Tin / Tout are then untouched.
+bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
+                          const double *deg_out, double eps0, double f0, double delta, i64 *iters) {
+    const int Nt = (int)((N + 63) / 64);
+    const i64 NT = (i64)Nt * (Nt + 1) / 2, Tld = (i64)Nt * 64;
+    int dev = 0, cus = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0) return false;
+    const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
+    const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
+    if (tpw > 2 || 4096 + 32 * Nt > DF_WORDS) return false; // the directed tile role needs more registers: N <= ~4000
+    c->fp_P.ensure((size_t)2 * Nt * Nt * 64);
+    c->fp_Td.ensure((size_t)4 * Tld);
+    c->fp_sync.ensure(DF_WORDS);
+    c->fp_fq.ensure((size_t)2 * 4 * Nt);
+    c->fp_flags.ensure(4);
+    hipStream_t st = c->stream;
+    ScopedKernelTimer tm(c, "fit_persistent");
+    HIP_CHECK(hipMemsetAsync(c->fp_Td.p, 0, sizeof(double) * 4 * Tld, st));
+    HIP_CHECK(hipMemcpyAsync(c->fp_Td.p, Tin, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->fp_Td.p + Tld, Tout, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemsetAsync(c->fp_sync.p, 0, sizeof(unsigned) * DF_WORDS, st));
+    const double *aGD = GD;
+    i64 aN = N, aTld = Tld;
+    int aNt = Nt, aPar = 0, aMax = 2000000;
+    double *aT = c->fp_Td.p, *aP = c->fp_P.p, *aF = c->fp_fq.p;
+    const double *aDi = deg_in, *aDo = deg_out;
+    double aEps = eps0, aF0 = f0, aDelta = delta;
+    unsigned *aSync = c->fp_sync.p;
+    int *aFlags = c->fp_flags.p;
+    long long aTicks = c->opt_fit_test_timeout ? 0LL : 300000000LL;
+    void *args[] = {&aGD, &aN, &aNt, &aT, &aTld, &aPar, &aDi, &aDo, &aEps, &aF0, &aDelta, &aMax, &aP, &aF, &aSync, &aFlags, &aTicks};
+    const void *fn = tpw == 1 ? (const void *)fit_dataflow_dir_kernel<1> : (const void *)fit_dataflow_dir_kernel<2>;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (hipModuleLaunchKernelCompat(fn, G, args, 0, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    int hf[4];
+    HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (hf[2] || !hf[0]) {
+        if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
+        return false;
+    }
+    const int par = hf[3];
+    HIP_CHECK(hipMemcpyAsync(Tin, c->fp_Td.p + (i64)(2 * par) * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(Tout, c->fp_Td.p + (i64)(2 * par + 1) * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+    *iters = hf[1];
+    return true;
 }

@@ -214,6 +214,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     double *Tcur = TT.p;
     bool use_persistent = !directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
                           (c->opt_fit_persistent >= 2 || N >= 512);
+    bool use_persistent_dir = directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
+                              (c->opt_fit_persistent >= 2 || N >= 512);
     c->stat_fit_persistent = 0;
     c->stat_fit_iters = 0;
 
@@ -328,8 +330,15 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
                 tpar = (int)((tpar + iters) & 1);
             }
             Tcur = TT.p + (i64)tpar * Tld;
+        } else if (use_persistent_dir &&
+                   k_fit_persistent_dir(c, GD.p, N, T1.p, T2.p, G.deg_in, G.deg_out, 0.9, 1.0, delta, &iters)) {
+            c->stat_fit_persistent++; // the whole directed fit in one launch (kernels_fitp.hip)
         } else
         for (;;) {
+            if (use_persistent_dir) { // abandoned: T1 / T2 are untouched; one launch pair per iteration from here on
+                use_persistent_dir = false;
+                HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
+            }
             for (i64 b = 0; b < batch; b++) {
                 k_fit_symv_dir(c, GD.p, T1.p, T2.p, N, S1.p, S2.p, flags.p);
                 k_fit_update_dir(c, T1.p, T2.p, S1.p, S2.p, G.deg_in, G.deg_out, N, delta, flags.p, flags.p + 1,

@@ -297,6 +297,40 @@ def test_fit_persistent_kernel_matches_stepwise_and_oracle(ctx, orc, n):
         _cmp_result(r2, exp, t2, etr)
 
 
+@pytest.mark.parametrize("n", [90, 700])
+def test_fit_persistent_directed_matches_stepwise_and_oracle(ctx, orc, n):
+    """wGCL_directed's fixed point (src/divergence.jl:434-467: two iterates, the diagonal counted twice, the decaying
+    step size) as one persistent launch per alpha against the launch-pair-per-iteration path and the oracle."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    g = synth.abcd_like(n, 6 * n, max(2, n // 60), 8, seed=n + 1, directed=True)
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    ctx.set_graph(g["edges"], g["eweights"], n)
+    p1, ni, nj = api.draw_samples(ctx, 5, 2000, directed=True)
+    p2, _, _ = api.draw_samples(ctx, 6, 2000, directed=True)
+    smp = (p1, ni, nj, p2)
+    args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
+    out = {}
+    try:
+        for mode in (1, 2):
+            ctx.set_option("fit_persistent", mode)
+            out[mode] = cg.wGCL_directed(*args, samples=smp, trace=True, ctx=ctx)
+            assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode == 2)
+        ctx.set_option("fit_persistent_test_timeout", 1)  # abandoned launches: the iterates must be untouched
+        out[3] = cg.wGCL_directed(*args, samples=smp, trace=True, ctx=ctx)
+        assert ctx.get_stat("fit_persistent_alphas") == 0
+    finally:
+        ctx.set_option("fit_persistent_test_timeout", 0)
+        ctx.set_option("fit_persistent", 0)
+    (r1, t1), (r2, t2), (r3, t3) = out[1], out[2], out[3]
+    assert t1["iters"] == t2["iters"] == t3["iters"]
+    assert np.array_equal(r1, r3)
+    assert np.allclose(r1, r2, rtol=1e-10, atol=1e-13)
+    exp, etr = orc.wGCL_directed(*args, smp, trace=True)
+    _cmp_result(r2, exp, t2, etr)
+
+
 def test_fit_persistent_abandoned_launch_falls_back(ctx):
     """A persistent launch that gives up (here: forced through the testing option; in production a wait that timed
     out) leaves T untouched for the host, which restores it and fits the alpha with one launch per iteration."""
