@@ -187,10 +187,22 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
 
 /* ---- options / statistics --------------------------------------------------------------------- */
 /* "diameter": 0 = auto (exact landmark-pair pruning, brute-force MFMA kernel when pruning is weak),
- *             1 = always brute force, 2 = always pruned.  All three return the same exact value.   */
+ *             1 = always brute force, 2 = always pruned.  All three return the same exact value.
+ * "fit_persistent": how the Chung-Lu fixed point (src/divergence.jl:150-168, :434-467) is launched.
+ *             0 = auto: one persistent launch per alpha (the matrix register-resident, per-block dependency
+ *                 counters) for score graphs of >= 512 vertices that fit the register file (N <= ~4900 undirected,
+ *                 ~4000 directed on 256 CUs), else one launch per iteration;
+ *             1 = always one launch per iteration; 2 = persistent whenever it fits; 3 = 2 with grid barriers
+ *             instead of the dependency counters (undirected only).  Same iterates and iteration counts in all
+ *             modes; sums are grouped differently between the launch-per-iteration and the persistent forms
+ *             (last-bit differences of the score vector).
+ * "fit_persistent_test_timeout": testing hook, 1 = every persistent launch gives up at once (the host then
+ *             restores the iterate and falls back to one launch per iteration).                              */
 int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
 /* "landmarks" (N of the last run, no side effects), "diameter_path" (1 brute / 2 pruned), "diameter_candidate_pairs", "diameter_candidate_tiles", "diameter_refs" (reference points) of the last run;
- * "diameter_bits" = the bit pattern of the last `hi` (reinterpret the int64 as a double)           */
+ * "diameter_bits" = the bit pattern of the last `hi` (reinterpret the int64 as a double);
+ * "fit_persistent_alphas" = alphas of the last sweep fitted by a persistent launch, "fit_iterations" = Chung-Lu
+ * iterations of the last sweep (all alphas)                                                          */
 int cge_get_stat(cge_ctx *ctx, const char *key, int64_t *value);
 
 /* ---- profiling ------------------------------------------------------------------------------ */
