@@ -252,7 +252,7 @@ struct cge_ctx {
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
     bool fit_persistent_broken = false; // a grid barrier timed out once (e.g. another process holds CUs): not tried again // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
-    DevBuf<i32> sw_cm_off, sw_cm_mem;
+    DevBuf<i32> sw_cm_off, sw_cm_mem, sw_cm_pos; // community -> members CSR of the score graph and its inverse
     DevBuf<double> sw_zeros;
     // diameter scratch
     DevBuf<double> mp_recs;  // MaxRec records (3 doubles each)
@@ -391,7 +391,7 @@ void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean);
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
                         double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad);
 // alpha sweep
-void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD);
+void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD, bool upper_only = false);
 bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
                       double delta, i64 *iters, int *final_parity, bool dataflow);
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
@@ -406,7 +406,7 @@ void k_fit_symv_dir(cge_ctx *c, const double *GD, const double *Tin, const doubl
 void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, const double *Sout,
                       const double *deg_in, const double *deg_out, i64 N, double delta, int *done, int *iters,
                       double *state /* [0]=eps,[1]=diff */);
-void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *comm, const i32 *cm_off,
+void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_pos, const i32 *cm_off,
             const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB);
 void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int directed, int mode /*0 all,1 int,2 ext*/,
           double *out);

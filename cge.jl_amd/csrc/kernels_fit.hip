@@ -29,8 +29,25 @@ __global__ void pow_matrix_kernel(const double *__restrict__ D, i64 total, doubl
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) GD[e] = pow(1.0 - D[e], alpha);
 }
-void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD) {
+// upper triangle only (64 x 64 tiles with tile-row <= tile-column): what the persistent fit and vect_B read
+__global__ __launch_bounds__(256) void pow_matrix_upper_kernel(const double *__restrict__ D, i64 N, double alpha,
+                                                               double *__restrict__ GD) {
+    const i64 I = blockIdx.y, J = blockIdx.x;
+    if (J < I) return;
+    const i64 c0 = J * 64 + (threadIdx.x & 63);
+    if (c0 >= N) return;
+    for (i64 r = I * 64 + (threadIdx.x >> 6); r < std::min<i64>(N, I * 64 + 64); r += 4) {
+        const i64 e = r * N + c0;
+        GD[e] = pow(1.0 - D[e], alpha);
+    }
+}
+void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD, bool upper_only) {
     ScopedKernelTimer t(c, "pow_matrix");
+    if (upper_only) {
+        const unsigned nt = (unsigned)((N + 63) / 64);
+        hipLaunchKernelGGL(pow_matrix_upper_kernel, dim3(nt, nt), dim3(256), 0, c->stream, D, N, alpha, GD);
+        return;
+    }
     hipLaunchKernelGGL(pow_matrix_kernel, dim3(grid_for(N * N, 256, 256 * 16)), dim3(256), 0, c->stream, D, N * N,
                        alpha, GD);
 }
@@ -260,29 +277,43 @@ void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, 
 // ------------------------------------------------------------------------------------------------
 // vect_B.  Stage 1: rowbins[i][c] = sum over the members j of community c (ascending; j >= i when
 // undirected) of (Ta_i*Tb_j)*GD_ij.  Stage 2: sum the rows of each community into the bins.
-// The row is streamed once, coalesced, into LDS as the products (Ta_i*Tb_j)*GD_ij (only j >= i when undirected);
-// the per-community sums then gather from LDS in member order -- the same additions in the same order as a
-// direct gather from the row, without its scattered global reads.  STAGED = false: rows beyond the LDS budget.
+// The row is streamed once, coalesced, into LDS as the products (Ta_i*Tb_j)*GD_ij (only j >= i when undirected),
+// each product stored at the position of j in the community-sorted member list (cm_pos = the inverse of cm_mem):
+// the sum of community c is then a contiguous LDS range in member (= ascending j) order -- the same additions in the
+// same order as a direct gather from the row (the skipped j < i hold 0.0, which leaves a sum's bits alone), without
+// scattered global reads or dependent index loads.  STAGED = false: rows beyond the LDS budget.
 template <bool STAGED>
 __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
                                                         const double *__restrict__ Tb,
                                                         const i32 *__restrict__ cm_off, const i32 *__restrict__ cm_mem,
-                                                        i64 N, i64 C, int directed, double *__restrict__ rowbins) {
+                                                        const i32 *__restrict__ cm_pos, i64 N, i64 C, int directed,
+                                                        double *__restrict__ rowbins) {
     extern __shared__ __attribute__((aligned(16))) double prod[];
     const i64 i = blockIdx.x;
     const double ti = Ta[i];
     const double *row = GD + i * N;
     const i64 j0 = directed ? 0 : i;
     if (STAGED) {
-        for (i64 j = j0 + threadIdx.x; j < N; j += 256) prod[j - j0] = (ti * Tb[j]) * row[j];
+        if (j0 > 0) {
+            for (i64 j = threadIdx.x; j < N; j += 256) prod[j] = 0.0;
+            __syncthreads();
+        }
+        for (i64 j = j0 + threadIdx.x; j < N; j += 256) prod[cm_pos[j]] = (ti * Tb[j]) * row[j];
         __syncthreads();
+        for (i64 cc = threadIdx.x; cc < C; cc += 256) {
+            double s = 0.0;
+            const i32 b = cm_off[cc], e = cm_off[cc + 1];
+            for (i32 t = b; t < e; t++) s += prod[t];
+            rowbins[i * C + cc] = s;
+        }
+        return;
     }
     for (i64 cc = threadIdx.x; cc < C; cc += 256) {
         double s = 0.0;
         const i32 b = cm_off[cc], e = cm_off[cc + 1];
         for (i32 t = b; t < e; t++) {
             const i64 j = cm_mem[t];
-            if (j >= j0) s += STAGED ? prod[j - j0] : (ti * Tb[j]) * row[j];
+            if (j >= j0) s += (ti * Tb[j]) * row[j];
         }
         rowbins[i * C + cc] = s;
     }
@@ -300,16 +331,15 @@ __global__ void bvec_bins_kernel(const double *__restrict__ rowbins, const i32 *
         vectB[directed ? e : (C * c1 - c1 * (c1 - 1) / 2 + (c2 - c1))] = s;
     }
 }
-void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *comm, const i32 *cm_off,
+void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_pos, const i32 *cm_off,
             const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB) {
-    (void)comm;
     ScopedKernelTimer t(c, "bvec");
     if (N * sizeof(double) <= 64 * 1024)
         hipLaunchKernelGGL((bvec_rows_kernel<true>), dim3((unsigned)N), dim3(256), N * sizeof(double), c->stream, GD, Ta,
-                           Tb, cm_off, cm_mem, N, C, directed, rowbins);
+                           Tb, cm_off, cm_mem, cm_pos, N, C, directed, rowbins);
     else
         hipLaunchKernelGGL((bvec_rows_kernel<false>), dim3((unsigned)N), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off,
-                           cm_mem, N, C, directed, rowbins);
+                           cm_mem, cm_pos, N, C, directed, rowbins);
     hipLaunchKernelGGL(bvec_bins_kernel, dim3(grid_for(C * C, 256)), dim3(256), 0, c->stream, rowbins, cm_off, cm_mem,
                        C, directed, vectB);
 }

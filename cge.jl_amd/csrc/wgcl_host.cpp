@@ -186,6 +186,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     d_cm_mem.ensure(N);
     HIP_CHECK(hipMemcpyAsync(d_cm_off.p, cm_off.data(), sizeof(i32) * (C + 1), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(d_cm_mem.p, cm_mem.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+    std::vector<i32> cm_pos(N); // position of every vertex in the community-sorted list
+    for (i64 q = 0; q < N; q++) cm_pos[cm_mem[q]] = (i32)q;
+    c->sw_cm_pos.ensure(N);
+    HIP_CHECK(hipMemcpyAsync(c->sw_cm_pos.p, cm_pos.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
 
     // T (:118) / Tin,Tout (:399-402)
     std::vector<double> hT1(N, 1.0), hT2(N, 1.0);
@@ -282,7 +286,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     i64 prev_iters = 16;
     for (i64 ia = 1; ia <= n_alpha_total; ia++) {
         const double alpha = AlphaStep * (double)ia;
-        k_pow_matrix(c, D.p, N, alpha, GD.p);
+        // the undirected persistent fit and vect_B read the upper triangle only; the exact-mode AUC, the directed vect_B
+        // and the launch-per-iteration fits read whole rows
+        const bool gd_upper = landmarks && !directed && use_persistent;
+        k_pow_matrix(c, D.p, N, alpha, GD.p, gd_upper);
         HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
         if (directed) {
             const double init[2] = {0.9, 1.0}; // epsilon, diff (:434-435)
@@ -301,6 +308,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
                     c->stat_fit_persistent++;
                 } else { // not co-resident / timed out: restore T and use one launch per iteration from here on
                     use_persistent = false;
+                    if (gd_upper) k_pow_matrix(c, D.p, N, alpha, GD.p, false);
                     HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
                     HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
                 }
@@ -366,7 +374,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
                 k_auc_exact(c, GD.p, Ta, Tb, N, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p, ds.wts.p, S, scal.p);
         }
         if (!skip_div) {
-            k_bvec(c, GD.p, Ta, Tb, G.comm, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
+            k_bvec(c, GD.p, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
             if (!split)
                 k_js(c, G.vectC, vectB.p, vlen, C, directed, 0, scal.p + 2);
             else {
