@@ -323,34 +323,21 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
     land = clamp_to_unique_rows(c, land, &c->lm_truncated);
     c->phases.ms["lm_unique"] = now_ms() - t0;
     std::vector<i64> gid;
-    host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, nullptr, &c->h_mem_off, &c->h_mem);
+    host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, true); // leaves v2l and the landmark index on the device
     HIP_CHECK(hipStreamSynchronize(st));
     c->phases.ms["landmarks"] = now_ms() - t0;
     t0 = now_ms();
     const i64 N = (i64)c->h_mem_off.size() - 1; // every group is non-empty
     c->N = N;
     c->h_v2l.resize(n);
-    std::vector<i32> &v2l0 = c->h_v2l0;
-    v2l0.resize(n);
-    for (i64 i = 0; i < n; i++) {
-        c->h_v2l[i] = gid[i] + 1; // :379
-        v2l0[i] = (i32)gid[i];
-    }
-    const std::vector<i32> &mem_off = c->h_mem_off, &mem = c->h_mem;
-    DevBuf<i32> d_off, d_mem;
-    d_off.ensure(N + 1);
-    d_mem.ensure(n);
-    c->v2l.ensure(n);
-    HIP_CHECK(hipMemcpyAsync(c->v2l.p, v2l0.data(), sizeof(i32) * n, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(d_off.p, mem_off.data(), sizeof(i32) * (N + 1), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(d_mem.p, mem.data(), sizeof(i32) * n, hipMemcpyHostToDevice, st));
+    for (i64 i = 0; i < n; i++) c->h_v2l[i] = gid[i] + 1; // :379
     c->lemb.ensure((size_t)N * d);
     c->lweight.ensure(N);
     c->dii.ensure(N);
     c->lcomm.ensure(N);
     {
         ScopedKernelTimer tm(c, "landmark_aggregate");
-        k_landmark_aggregate(c, c->Xr.p, c->vw.p, c->comm.p, d_off.p, d_mem.p, N, d, c->lemb.p, c->lweight.p, c->dii.p,
+        k_landmark_aggregate(c, c->Xr.p, c->vw.p, c->comm.p, c->lm_memoff.p, c->lm_mem.p, N, d, c->lemb.p, c->lweight.p, c->dii.p,
                              c->lcomm.p);
     }
     HIP_CHECK(hipStreamSynchronize(st));
@@ -470,7 +457,7 @@ int cge_runsplit(cge_ctx *c, const int64_t *cl_flat, const int64_t *cl_off, int6
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->Xr.p || !c->vw.p) CGE_THROW(CGE_E_ARG, "runsplit: embedding and vertex weights must be resident");
     std::vector<i64> gid;
-    host_runsplit(c, cl_flat, cl_off, ncl, nland, forced, method, gid, nullptr);
+    host_runsplit(c, cl_flat, cl_off, ncl, nland, forced, method, gid);
     memcpy(group_ids, gid.data(), sizeof(i64) * c->n);
     CGE_CATCH(c)
 }

@@ -279,7 +279,14 @@ struct cge_ctx {
     PinBuf<double> pin_sums, pin_z, pin_params, pin_zs, pin_means, pin_cmeans;
     PinBuf<i32> pin_rows[2], pin_row_task[2], pin_srows; // [slot]: 0 = main batch, 1 = fallback sub-batch
     // sorted-prefix rss path
-    DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro, sp_perm, sp_status, sort_idx;
+    DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro, sp_perm, sp_status, sort_idx, sort_keys32, sort_cnt;
+    DevBuf<unsigned char> sort_keys8;
+    // member lists of the landmark phase: a group is a range of this arena (vertex ids, reference order)
+    DevBuf<i32> lm_arena;
+    i64 lm_arena_used = 0;
+    DevBuf<i32> ls_toff, ls_nlow, lm_goff, lm_glen, lm_mem, lm_memoff; // task arena offsets, low-child counts, final groups, landmark index
+    DevBuf<unsigned char> ls_keys;
+    PinBuf<i32> pin_small;
     DevBuf<unsigned char> sort_tmp;
     PinBuf<i32> pin_perm;
     PinBuf<unsigned char> pin_side;
@@ -353,6 +360,14 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
 #define CGE_RR_MAXROUNDS 63
 #define CGE_CHUNK_ROWS 1024 // rows per chunk of a batch (build_batch); the rounds kernel uses r >> 10
 #define CGE_PREFIX_STRIDE 8 // the sorted-order WSSE prefix is stored every 8th row of a chunk (CGE_CHUNK_ROWS % 8 == 0)
+void k_gather_rows(cge_ctx *c, const i32 *arena, const i32 *task_off, const i32 *task_row_off, const i32 *chunk_task,
+                   const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, i32 *rows, i32 *row_task);
+void k_rss_child_keys(cge_ctx *c, const i32 *perm, const i32 *row_task, const i32 *task_row_off, const i32 *meta,
+                      const i32 *rounds, i64 R, i64 T, unsigned char *keys, i32 *nlow);
+void k_side_counts(cge_ctx *c, const unsigned char *side, const i32 *task_row_off, i64 T, i32 *nlow);
+void k_sort_children(cge_ctx *c, const unsigned char *keys, const i32 *rows, const i32 *task_row_off, i64 R, i64 T,
+                     int key_bits, i32 *out);
+i64 k_groups_to_index(cge_ctx *c, const i32 *arena, const i32 *goff, const i32 *glen, i64 N, i64 n, i32 *v2l, i32 *mem);
 void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 *row_task, const i32 *task_row_off,
                         i64 R, i64 T, double *zs, i32 *perm, i32 *srows, i32 *status);
 void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, const double *params,
@@ -421,8 +436,7 @@ void k_mark_edge_hits(cge_ctx *c, const i32 *src, const i32 *dst, i64 m, int dir
 // ---- host modules -----------------------------------------------------------------------------
 // landmarks_host.cpp
 void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
-                   std::vector<i64> &group_ids /*0-based*/, std::vector<std::vector<i64>> *members_out,
-                   std::vector<i32> *csr_off = nullptr, std::vector<i32> *csr_mem = nullptr); // group -> ascending 0-based members
+                   std::vector<i64> &group_ids /*0-based*/, bool want_index = false); // also fills c->v2l / lm_mem / lm_memoff (device)
 void host_eig_top(const double *A, i64 d, double *v); // largest-eigenvalue eigenvector, sign: max |.| component > 0
 // diameter_host.cpp
 bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const std::vector<i32> &lcomm, i64 C, i64 N,

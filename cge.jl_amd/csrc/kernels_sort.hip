@@ -50,3 +50,147 @@ void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 
     hipLaunchKernelGGL(sort_status_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, c->stream, zs, task_row_off, T,
                        status);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Member lists on the device.  A group is a range of the member arena (vertex ids, 0-based, in the reference's
+// order); a split writes its two children behind each other into a fresh range, low first.
+//
+// rows of a batch <- the arena ranges of its tasks (one workgroup per 1024-row chunk of a task)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const i32 *__restrict__ arena, const i32 *__restrict__ task_off,
+                                                          const i32 *__restrict__ task_row_off,
+                                                          const i32 *__restrict__ chunk_task,
+                                                          const i32 *__restrict__ chunk_beg,
+                                                          const i32 *__restrict__ chunk_end, i32 *__restrict__ rows,
+                                                          i32 *__restrict__ row_task) {
+    const i64 ch = blockIdx.x;
+    const i32 t = chunk_task[ch], beg = chunk_beg[ch], end = chunk_end[ch];
+    const i64 src = (i64)task_off[t] - task_row_off[t];
+    for (i32 p = beg + (i32)threadIdx.x; p < end; p += 256) {
+        rows[p] = arena[src + p];
+        row_task[p] = t;
+    }
+}
+void k_gather_rows(cge_ctx *c, const i32 *arena, const i32 *task_off, const i32 *task_row_off, const i32 *chunk_task,
+                   const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, i32 *rows, i32 *row_task) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_chunks), dim3(256), 0, c->stream, arena, task_off, task_row_off,
+                       chunk_task, chunk_beg, chunk_end, rows, row_task);
+}
+
+// rss rule: the position of every row in its parent's child lists, as a bucket key.  The reference's order is: the
+// low seed (arg-min), then every batch the low side absorbed, in round order, each in ascending original index
+// (src/landmarks.jl:163-164, :189, :204-206); then the same for the high side.  Bucket = that position's block;
+// a stable sort of the rows (which are in original index order) by bucket gives exactly those two lists.
+// One thread per sorted rank; rounds[t][r] = {first rank, end rank, side}, meta[t] = {rounds, rc}.
+#define CK_MAXROUNDS 63
+__global__ void rss_child_keys_kernel(const i32 *__restrict__ perm, const i32 *__restrict__ row_task,
+                                      const i32 *__restrict__ task_row_off, const i32 *__restrict__ meta,
+                                      const i32 *__restrict__ rounds, i64 R, unsigned char *__restrict__ keys) {
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= R) return;
+    const i64 t = row_task[p];
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o, q = p - o;
+    const int nr = meta[2 * t];
+    const i32 *rl = rounds + t * 3 * CK_MAXROUNDS;
+    int n_low_rounds = 0, mine = -1, before_same = 0;
+    for (int r = 0; r < nr; r++) {
+        const int side = rl[3 * r + 2];
+        n_low_rounds += (side == 1);
+        if (mine < 0 && q >= rl[3 * r] && q < rl[3 * r + 1]) {
+            mine = side;
+            before_same = 0;
+            for (int r2 = 0; r2 < r; r2++) before_same += (rl[3 * r2 + 2] == side);
+        }
+    }
+    int b;
+    if (q == 0) b = 0;                          // low seed
+    else if (q == k - 1) b = 1 + n_low_rounds;  // high seed
+    else if (mine == 1) b = 1 + before_same;
+    else b = 2 + n_low_rounds + before_same;    // mine == 2 (or a task that failed: overwritten by the host path)
+    keys[o + perm[p]] = (unsigned char)b;
+}
+__global__ void rss_child_counts_kernel(const i32 *__restrict__ meta, const i32 *__restrict__ rounds, i64 T,
+                                        i32 *__restrict__ nlow) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int nr = meta[2 * t];
+    const i32 *rl = rounds + t * 3 * CK_MAXROUNDS;
+    i32 cnt = 1;
+    for (int r = 0; r < nr; r++)
+        if (rl[3 * r + 2] == 1) cnt += rl[3 * r + 1] - rl[3 * r];
+    nlow[t] = cnt;
+}
+void k_rss_child_keys(cge_ctx *c, const i32 *perm, const i32 *row_task, const i32 *task_row_off, const i32 *meta,
+                      const i32 *rounds, i64 R, i64 T, unsigned char *keys, i32 *nlow) {
+    hipLaunchKernelGGL(rss_child_keys_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream, perm, row_task,
+                       task_row_off, meta, rounds, R, keys);
+    hipLaunchKernelGGL(rss_child_counts_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, c->stream, meta, rounds, T,
+                       nlow);
+}
+// cut rules: side flag 1 / 2 per row -> number of low rows per task (one wave per task)
+__global__ __launch_bounds__(64) void side_counts_kernel(const unsigned char *__restrict__ side,
+                                                         const i32 *__restrict__ task_row_off, i32 *__restrict__ nlow) {
+    const i64 t = blockIdx.x;
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    i32 cnt = 0;
+    for (i64 j = threadIdx.x; j < k; j += 64) cnt += (side[o + j] == 1);
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (threadIdx.x == 0) nlow[t] = cnt;
+}
+void k_side_counts(cge_ctx *c, const unsigned char *side, const i32 *task_row_off, i64 T, i32 *nlow) {
+    hipLaunchKernelGGL(side_counts_kernel, dim3((unsigned)T), dim3(64), 0, c->stream, side, task_row_off, nlow);
+}
+// children lists: stable sort of every task's rows (vertex ids, original order) by key, written to `out`
+// (the fresh arena range of the batch; task t lands at out + task_row_off[t], low children first)
+void k_sort_children(cge_ctx *c, const unsigned char *keys, const i32 *rows, const i32 *task_row_off, i64 R, i64 T,
+                     int key_bits, i32 *out) {
+    ScopedKernelTimer tm(c, "children_sort");
+    c->sort_keys8.ensure(R);
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, bytes, keys, c->sort_keys8.p, rows, out, (unsigned)R, (unsigned)T,
+                                                  task_row_off, task_row_off + 1, 0, key_bits, c->stream));
+    c->sort_tmp.ensure(bytes);
+    HIP_CHECK(rocprim::segmented_radix_sort_pairs(c->sort_tmp.p, bytes, keys, c->sort_keys8.p, rows, out, (unsigned)R,
+                                                  (unsigned)T, task_row_off, task_row_off + 1, 0, key_bits, c->stream));
+}
+
+// The final groups (the heap array, src/landmarks.jl:337-342) -> v2l and the landmark -> members index.
+__global__ __launch_bounds__(256) void assign_groups_kernel(const i32 *__restrict__ arena, const i32 *__restrict__ goff,
+                                                            const i32 *__restrict__ glen, i32 *__restrict__ v2l) {
+    const i64 g = blockIdx.x;
+    const i64 o = goff[g], k = glen[g];
+    for (i64 q = threadIdx.x; q < k; q += 256) v2l[arena[o + q]] = (i32)g;
+}
+__global__ void count_unassigned_kernel(const i32 *__restrict__ v2l, i64 n, i32 *__restrict__ cnt) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && v2l[i] < 0) atomicAdd(cnt, 1);
+}
+__global__ void iota_kernel(i32 *__restrict__ x, i64 n) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = (i32)i;
+}
+// v2l[i] = group of vertex i (0-based); mem = vertices grouped by landmark, ascending inside a landmark (stable sort
+// of 0..n-1 by landmark); returns the number of vertices no group claimed (the reference asserts 0, :343)
+i64 k_groups_to_index(cge_ctx *c, const i32 *arena, const i32 *goff, const i32 *glen, i64 N, i64 n, i32 *v2l, i32 *mem) {
+    hipStream_t st = c->stream;
+    HIP_CHECK(hipMemsetAsync(v2l, 0xFF, sizeof(i32) * n, st));
+    hipLaunchKernelGGL(assign_groups_kernel, dim3((unsigned)N), dim3(256), 0, st, arena, goff, glen, v2l);
+    c->sort_cnt.ensure(1);
+    HIP_CHECK(hipMemsetAsync(c->sort_cnt.p, 0, sizeof(i32), st));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(count_unassigned_kernel, dim3(nb), dim3(256), 0, st, v2l, n, c->sort_cnt.p);
+    c->sort_idx.ensure(n);
+    c->sort_keys32.ensure(n);
+    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, st, c->sort_idx.p, n);
+    int bits = 1;
+    while (((i64)1 << bits) < N) bits++;
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned *)v2l, (unsigned *)c->sort_keys32.p, c->sort_idx.p, mem,
+                                        (size_t)n, 0, bits, st));
+    c->sort_tmp.ensure(bytes);
+    HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, (const unsigned *)v2l, (unsigned *)c->sort_keys32.p,
+                                        c->sort_idx.p, mem, (size_t)n, 0, bits, st));
+    i32 bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, c->sort_cnt.p, sizeof(i32), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return bad;
+}

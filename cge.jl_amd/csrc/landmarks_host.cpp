@@ -33,18 +33,41 @@ struct PhaseAcc {
     ~PhaseAcc() { c->phases.ms[name] += now_ms() - t0; }
 };
 
+// A group of the split tree.  Its members live on the device: the range [off, off + len) of the member arena
+// (c->lm_arena: 0-based vertex ids in the reference's order).  A split writes the two children behind each other into
+// a fresh range [coff, coff + len): low first (nlow entries), then high.
 struct Group {
-    std::vector<i64> what; // 1-based vertex ids, in the reference's order
+    i64 off = -1, len = 0;
+    std::vector<i64> what; // host copy (1-based ids), fetched only for the generic round-based rss path
     double value = 0.0;    // heap key: -total_rss, or eps() for singletons
     bool has_split = false;
     int rc = CGE_OK;
-    std::vector<i64> low, high; // children (vertex ids) until the child groups are materialised
+    i64 coff = -1, nlow = 0; // children ranges until the child groups are materialised
     double vlow = 0.0, vhigh = 0.0;
     Group *clo = nullptr, *chi = nullptr; // child groups, created as soon as the split is known
     // weighted mean of the rows (matrix_w_mean, src/landmarks.jl:71-81) when it is already known from the parent's
     // split (the WSSE column sums of a child are sum w x and sum w); empty = compute it on the device
     std::vector<double> mean, mlow, mhigh;
 };
+
+// reserve `cnt` entries of the member arena (grows by copying: ranges handed out earlier stay valid as offsets)
+i64 arena_alloc(cge_ctx *c, i64 cnt) {
+    const i64 need = c->lm_arena_used + cnt;
+    if ((i64)c->lm_arena.n < need || !c->lm_arena.p) {
+        const i64 cap = std::max<i64>(need + need / 2, 1024);
+        i32 *fresh = nullptr;
+        HIP_CHECK(hipMalloc((void **)&fresh, (size_t)cap * sizeof(i32)));
+        if (c->lm_arena.p && c->lm_arena_used > 0)
+            HIP_CHECK(hipMemcpyAsync(fresh, c->lm_arena.p, sizeof(i32) * c->lm_arena_used, hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->lm_arena.p) (void)hipFree(c->lm_arena.p);
+        c->lm_arena.p = fresh;
+        c->lm_arena.n = (size_t)cap;
+    }
+    const i64 at = c->lm_arena_used;
+    c->lm_arena_used = need;
+    return at;
+}
 
 // 1-based binary min-heap on value with the reference's exact sift rules (src/landmarks.jl:12-46)
 struct Heap {
@@ -283,31 +306,25 @@ void host_eig_top(const double *Ain, i64 d, double *vout) {
 namespace {
 
 // ---- batched device work --------------------------------------------------------------------------------
-// A batch = a list of groups; `rows` holds their 0-based vertex ids back to back in the groups' own
-// member order; every group is cut into chunks of CH rows (one workgroup each).
+// A batch = a list of groups; `rows` (device: c->ls_rows) holds their 0-based vertex ids back to back in the groups'
+// own member order; every group is cut into chunks of CH rows (one workgroup each).
 struct Batch {
     i64 T = 0, R = 0, NC = 0;
-    i32 *rows = nullptr, *row_task = nullptr; // pinned staging owned by the ctx (slot 0 main / 1 fallback)
-    std::vector<i32> chunk_task, chunk_beg, chunk_end, task_chunk_off, task_row_off;
+    i32 *rows = nullptr, *row_task = nullptr; // host-built batches only: pinned staging owned by the ctx
+    std::vector<i32> chunk_task, chunk_beg, chunk_end, task_chunk_off, task_row_off, task_off;
 };
-void build_batch(cge_ctx *c, Group *const *groups, i64 T, Batch &B, int slot = 0) {
-    const i64 CH = CGE_CHUNK_ROWS;
+// chunk tables from the groups' lengths; `lens` = what.size() for a host-built batch
+void batch_tables(Batch &B, const std::vector<i64> &lens) {
+    const i64 CH = CGE_CHUNK_ROWS, T = (i64)lens.size();
     B.T = T;
-    B.R = 0;
-    for (i64 t = 0; t < T; t++) B.R += (i64)groups[t]->what.size();
-    c->pin_rows[slot].ensure(B.R);
-    c->pin_row_task[slot].ensure(B.R);
-    B.rows = c->pin_rows[slot].p;
-    B.row_task = c->pin_row_task[slot].p;
     B.chunk_task.clear(); B.chunk_beg.clear(); B.chunk_end.clear();
     B.task_chunk_off.assign(T + 1, 0);
     B.task_row_off.assign(T + 1, 0);
     i64 pos = 0;
     for (i64 t = 0; t < T; t++) {
-        const Group *g = groups[t];
         B.task_row_off[t] = (i32)pos;
         B.task_chunk_off[t] = (i32)B.chunk_task.size();
-        const i64 k = (i64)g->what.size();
+        const i64 k = lens[t];
         for (i64 s = 0; s < k; s += CH) {
             B.chunk_task.push_back((i32)t);
             B.chunk_beg.push_back((i32)(pos + s));
@@ -315,10 +332,52 @@ void build_batch(cge_ctx *c, Group *const *groups, i64 T, Batch &B, int slot = 0
         }
         pos += k;
     }
+    B.R = pos;
     B.task_row_off[T] = (i32)pos;
     B.task_chunk_off[T] = (i32)B.chunk_task.size();
     B.NC = (i64)B.chunk_task.size();
-    parallel_for(c, T, [&](i64 t) { // the row arrays (the bulk) are filled in parallel
+}
+void upload_tables(cge_ctx *c, const Batch &B) { // grow-only scratch owned by the ctx
+    hipStream_t st = c->stream;
+    const i64 d = c->d;
+    c->ls_rows.ensure(B.R); c->ls_row_task.ensure(B.R); c->ls_ct.ensure(B.NC); c->ls_cb.ensure(B.NC);
+    c->ls_ce.ensure(B.NC); c->ls_tco.ensure(B.T + 1); c->sp_tro.ensure(B.T + 1);
+    c->ls_part.ensure((size_t)B.NC * std::max(d * d, 2 * (2 * d + 1)));
+    c->ls_side.ensure(B.R);
+    c->ls_sums.ensure((size_t)B.T * 2 * (2 * d + 1));
+    HIP_CHECK(hipMemcpyAsync(c->ls_ct.p, B.chunk_task.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_cb.p, B.chunk_beg.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_ce.p, B.chunk_end.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->ls_tco.p, B.task_chunk_off.data(), sizeof(i32) * (B.T + 1), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (B.T + 1), hipMemcpyHostToDevice, st));
+}
+// the usual batch: rows gathered on the device from the groups' arena ranges
+void build_batch(cge_ctx *c, Group *const *groups, i64 T, Batch &B) {
+    std::vector<i64> lens(T);
+    B.task_off.resize(T);
+    for (i64 t = 0; t < T; t++) {
+        lens[t] = groups[t]->len;
+        B.task_off[t] = (i32)groups[t]->off;
+    }
+    batch_tables(B, lens);
+}
+void upload_batch(cge_ctx *c, const Batch &B) {
+    upload_tables(c, B);
+    c->ls_toff.ensure(B.T);
+    HIP_CHECK(hipMemcpyAsync(c->ls_toff.p, B.task_off.data(), sizeof(i32) * B.T, hipMemcpyHostToDevice, c->stream));
+    k_gather_rows(c, c->lm_arena.p, c->ls_toff.p, c->sp_tro.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_rows.p,
+                  c->ls_row_task.p);
+}
+// a batch from host member lists (the generic rss path): rows staged through pinned memory
+void build_batch_host(cge_ctx *c, Group *const *groups, i64 T, Batch &B) {
+    std::vector<i64> lens(T);
+    for (i64 t = 0; t < T; t++) lens[t] = (i64)groups[t]->what.size();
+    batch_tables(B, lens);
+    c->pin_rows[1].ensure(B.R);
+    c->pin_row_task[1].ensure(B.R);
+    B.rows = c->pin_rows[1].p;
+    B.row_task = c->pin_row_task[1].p;
+    parallel_for(c, T, [&](i64 t) {
         const Group *g = groups[t];
         const i64 o = B.task_row_off[t], k = (i64)g->what.size();
         for (i64 j = 0; j < k; j++) {
@@ -327,20 +386,10 @@ void build_batch(cge_ctx *c, Group *const *groups, i64 T, Batch &B, int slot = 0
         }
     });
 }
-void upload_batch(cge_ctx *c, const Batch &B) { // grow-only scratch owned by the ctx
-    hipStream_t st = c->stream;
-    const i64 d = c->d;
-    c->ls_rows.ensure(B.R); c->ls_row_task.ensure(B.R); c->ls_ct.ensure(B.NC); c->ls_cb.ensure(B.NC);
-    c->ls_ce.ensure(B.NC); c->ls_tco.ensure(B.T + 1);
-    c->ls_part.ensure((size_t)B.NC * std::max(d * d, 2 * (2 * d + 1)));
-    c->ls_side.ensure(B.R);
-    c->ls_sums.ensure((size_t)B.T * 2 * (2 * d + 1));
-    HIP_CHECK(hipMemcpyAsync(c->ls_rows.p, B.rows, sizeof(i32) * B.R, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->ls_row_task.p, B.row_task, sizeof(i32) * B.R, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->ls_ct.p, B.chunk_task.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->ls_cb.p, B.chunk_beg.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->ls_ce.p, B.chunk_end.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->ls_tco.p, B.task_chunk_off.data(), sizeof(i32) * (B.T + 1), hipMemcpyHostToDevice, st));
+void upload_batch_host(cge_ctx *c, const Batch &B) {
+    upload_tables(c, B);
+    HIP_CHECK(hipMemcpyAsync(c->ls_rows.p, B.rows, sizeof(i32) * B.R, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->ls_row_task.p, B.row_task, sizeof(i32) * B.R, hipMemcpyHostToDevice, c->stream));
 }
 // sums[t][q] = { sum w x^2 [d], sum w x [d], sum w } over the rows of task t with side == q+1 (device)
 // (the side flags are already in c->ls_side; the result lands in the pinned buffer c->pin_sums)
@@ -506,106 +555,71 @@ void rule_rss_batched(cge_ctx *c, const Batch &B, Group *const *groups, const do
     }
 }
 
-// split_cluster_rss on sorted order (kernels_lm.hip: k_sorted_prefix + k_rss_rounds): the host sorts z
-// per task, the device scans the WSSE terms along that order and runs all median-cut rounds of every
-// task in one launch; the host then rebuilds the children's member lists in the reference's order
-// (seed first, then every absorbed batch in ascending original index, :163-164, :189, :194, :204-206).
-// Tasks the rank-range argument does not cover (a tie at the maximum of z, NaNs) go to `fallback`.
-void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, const double *z,
-                     std::vector<std::vector<i64>> &lows, std::vector<std::vector<i64>> &highs,
-                     std::vector<double> &vlow, std::vector<double> &vhigh, std::vector<char> &have_vals,
-                     std::vector<i64> &fallback) {
+// What a rule leaves behind for every task of a batch: the children's member lists are already in the arena range of
+// the batch (task t at base + task_row_off[t], low first); the host gets the sizes, values and means.
+struct CutResult {
+    std::vector<i32> nlow;
+    std::vector<double> vlow, vhigh;
+    std::vector<char> done; // 0 = this task still needs the generic host path
+};
+
+// split_cluster_rss on sorted order (kernels_lm.hip: k_sorted_prefix + k_rss_rounds; kernels_sort.hip): the device
+// sorts z per task, scans the WSSE terms along that order, runs all median-cut rounds of every task in one launch, and
+// writes the children's member lists in the reference's order (seed first, then every absorbed batch in ascending
+// original index, :163-164, :189, :194, :204-206) by one stable radix pass over per-row bucket keys.
+// Tasks the rank-range argument does not cover (a tie at the maximum of z, NaNs) are left to the generic path.
+void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, i64 base, CutResult &out) {
     const i64 T = B.T, R = B.R, d = c->d, W = 2 * d + 1;
     hipStream_t st = c->stream;
-    (void)z; // the projections are sorted on the device (c->ls_z); the host only needs the permutation
-    PhaseAcc *pa = new PhaseAcc(c, "lm_cut_dev");
-    c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_tro.ensure(T + 1); c->sp_perm.ensure(R); c->sp_status.ensure(T);
-    c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W); c->sp_prefix.ensure((size_t)(R / CGE_PREFIX_STRIDE + B.NC + 1) * W);
+    c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
+    c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W);
+    c->sp_prefix.ensure((size_t)(R / CGE_PREFIX_STRIDE + B.NC + 1) * W);
     c->sp_meta.ensure(2 * T); c->sp_rounds.ensure((size_t)T * 3 * CGE_RR_MAXROUNDS); c->sp_vals.ensure(2 * T);
-    c->pin_perm.ensure(R);
-    HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
+    c->sp_cmeans.ensure((size_t)2 * T * d);
+    c->ls_keys.ensure(R); c->ls_nlow.ensure(T);
+    c->pin_cmeans.ensure((size_t)2 * T * d);
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                        c->sp_srows.p, c->sp_status.p);
-    std::vector<i32> status(T);
-    // the permutation (4 B per row) goes to the host on the copy stream while the scan and the rounds run
-    HIP_CHECK(hipEventRecord(c->copy_ev, st));
-    HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->copy_ev, 0));
-    HIP_CHECK(hipMemcpyAsync(c->pin_perm.p, c->sp_perm.p, sizeof(i32) * R, hipMemcpyDeviceToHost, c->copy_stream));
-    HIP_CHECK(hipMemcpyAsync(status.data(), c->sp_status.p, sizeof(i32) * T, hipMemcpyDeviceToHost, c->copy_stream));
-    const i32 *perm = c->pin_perm.p;
     k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
-    c->sp_cmeans.ensure((size_t)2 * T * d);
     k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->ls_tco.p, c->sp_prefix.p, c->sp_coff.p,
                  T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p, c->sp_cmeans.p);
-    std::vector<i32> meta(2 * T), rounds((size_t)T * 3 * CGE_RR_MAXROUNDS);
+    k_rss_child_keys(c, c->sp_perm.p, c->ls_row_task.p, c->sp_tro.p, c->sp_meta.p, c->sp_rounds.p, R, T, c->ls_keys.p,
+                     c->ls_nlow.p);
+    k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + base);
+    std::vector<i32> status(T), meta(2 * T);
     std::vector<double> vals(2 * T);
-    c->pin_cmeans.ensure((size_t)2 * T * d);
-    HIP_CHECK(hipMemcpyAsync(c->pin_cmeans.p, c->sp_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(status.data(), c->sp_status.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(meta.data(), c->sp_meta.p, sizeof(i32) * 2 * T, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(rounds.data(), c->sp_rounds.p, sizeof(i32) * rounds.size(), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(out.nlow.data(), c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(c->pin_cmeans.p, c->sp_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    HIP_CHECK(hipStreamSynchronize(c->copy_stream));
-    delete pa;
-    PhaseAcc pa2(c, "lm_cut_rebuild");
     parallel_for(c, T, [&](i64 t) {
         Group *g = groups[t];
-        if (status[t] == 2) { g->rc = CGE_E_HOMOGENEOUS; return; }
-        if (status[t] == 1 || meta[2 * t + 1] != 0) { status[t] = 1; return; }
-        const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
-        const i32 *p = &perm[o];
-        const int nr = meta[2 * t];
-        const i32 *rl = &rounds[(size_t)t * 3 * CGE_RR_MAXROUNDS];
-        // round id of every original index (-1 = seed)
-        std::vector<int> rid(k, -1);
-        for (int r = 0; r < nr; r++)
-            for (i32 q = rl[3 * r]; q < rl[3 * r + 1]; q++) rid[p[q]] = r;
-        std::vector<i64> cnt(nr, 0), start(nr + 1, 0);
-        for (int r = 0; r < nr; r++) cnt[r] = rl[3 * r + 1] - rl[3 * r];
-        i64 nlow = 1, nhigh = 1;
-        std::vector<i64> pos(nr);
-        for (int r = 0; r < nr; r++) {
-            if (rl[3 * r + 2] == 1) { pos[r] = nlow; nlow += cnt[r]; } else { pos[r] = nhigh; nhigh += cnt[r]; }
-        }
-        lows[t].assign(nlow, 0);
-        highs[t].assign(nhigh, 0);
-        lows[t][0] = p[0];
-        highs[t][0] = p[k - 1];
-        for (i64 j = 0; j < k; j++) {
-            const int r = rid[j];
-            if (r < 0) continue;
-            if (rl[3 * r + 2] == 1) lows[t][pos[r]++] = j; else highs[t][pos[r]++] = j;
-        }
-        vlow[t] = vals[2 * t];
-        vhigh[t] = vals[2 * t + 1];
-        have_vals[t] = 1;
+        if (status[t] == 2) { g->rc = CGE_E_HOMOGENEOUS; out.done[t] = 1; return; }
+        if (status[t] == 1 || meta[2 * t + 1] != 0) { out.done[t] = 0; return; }
+        out.vlow[t] = vals[2 * t];
+        out.vhigh[t] = vals[2 * t + 1];
         const double *cm = c->pin_cmeans.p + (size_t)2 * t * d;
         g->mlow.assign(cm, cm + d);
         g->mhigh.assign(cm + d, cm + 2 * d);
         g->rc = CGE_OK;
+        out.done[t] = 1;
     });
-    for (i64 t = 0; t < T; t++)
-        if (status[t] == 1) fallback.push_back(t);
 }
 
 // split_cluster_rss2 on the device (kernels_lm.hip: rss2_walk_kernel).  The children are rank ranges of the sorted
-// order, in that order (`p[1:low]`, `p[high:end]`, src/landmarks.jl:151), so the host only slices the permutation.
-void rule_rss2_device(cge_ctx *c, const Batch &B, Group *const *groups, std::vector<std::vector<i64>> &lows,
-                      std::vector<std::vector<i64>> &highs, std::vector<double> &vlow, std::vector<double> &vhigh,
-                      std::vector<char> &have_vals) {
+// order, in that order (`p[1:low]`, `p[high:end]`, src/landmarks.jl:151): the sorted rows ARE the two lists.
+void rule_rss2_device(cge_ctx *c, const Batch &B, Group *const *groups, i64 base, CutResult &out) {
     const i64 T = B.T, R = B.R, d = c->d;
     hipStream_t st = c->stream;
-    c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_tro.ensure(T + 1); c->sp_perm.ensure(R); c->sp_status.ensure(T);
+    c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
     c->sp_meta.ensure(2 * T); c->sp_vals.ensure(2 * T); c->sp_cmeans.ensure((size_t)2 * T * d);
-    c->pin_perm.ensure(R);
     c->pin_cmeans.ensure((size_t)2 * T * d);
-    HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                        c->sp_srows.p, c->sp_status.p);
-    HIP_CHECK(hipEventRecord(c->copy_ev, st));
-    HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->copy_ev, 0));
-    HIP_CHECK(hipMemcpyAsync(c->pin_perm.p, c->sp_perm.p, sizeof(i32) * R, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_CHECK(hipMemcpyAsync(c->lm_arena.p + base, c->sp_srows.p, sizeof(i32) * R, hipMemcpyDeviceToDevice, st));
     k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->sp_cmeans.p);
     std::vector<i32> meta(2 * T);
     std::vector<double> vals(2 * T);
@@ -613,58 +627,41 @@ void rule_rss2_device(cge_ctx *c, const Batch &B, Group *const *groups, std::vec
     HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(c->pin_cmeans.p, c->sp_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    HIP_CHECK(hipStreamSynchronize(c->copy_stream));
-    const i32 *perm = c->pin_perm.p;
     parallel_for(c, T, [&](i64 t) {
         Group *g = groups[t];
-        const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
-        const i32 *p = &perm[o];
-        const i64 lo = meta[2 * t], hi = meta[2 * t + 1];
-        lows[t].assign(p, p + lo + 1);
-        highs[t].assign(p + hi, p + k);
-        vlow[t] = vals[2 * t];
-        vhigh[t] = vals[2 * t + 1];
-        have_vals[t] = 1;
+        out.nlow[t] = meta[2 * t] + 1; // low = ranks [0, lo], high = ranks [hi, k) with hi == lo + 1
+        out.vlow[t] = vals[2 * t];
+        out.vhigh[t] = vals[2 * t + 1];
         const double *cm = c->pin_cmeans.p + (size_t)2 * t * d;
         g->mlow.assign(cm, cm + d);
         g->mhigh.assign(cm + d, cm + 2 * d);
         g->rc = CGE_OK;
+        out.done[t] = 1;
     });
 }
 
 // split_cluster_size / split_cluster_diameter on the device (kernels_lm.hip: cut_sides_kernel): the side of every row,
-// then the children's WSSE column sums (values and means) by the side-sums pass; the host only lists the members of
-// either side in the rows' order.
-void rule_cut_device(cge_ctx *c, const Batch &B, Group *const *groups, bool use_median, std::vector<std::vector<i64>> &lows,
-                     std::vector<std::vector<i64>> &highs, std::vector<double> &vlow, std::vector<double> &vhigh,
-                     std::vector<char> &have_vals) {
+// the children's WSSE column sums (values and means) by the side-sums pass, and the two member lists -- the rows of
+// either side in the rows' own order -- by a stable one-bit sort.
+void rule_cut_device(cge_ctx *c, const Batch &B, Group *const *groups, bool use_median, i64 base, CutResult &out) {
     const i64 T = B.T, R = B.R, d = c->d, width = 2 * (2 * d + 1);
     hipStream_t st = c->stream;
-    c->sp_tro.ensure(T + 1);
-    HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (T + 1), hipMemcpyHostToDevice, st));
     if (use_median) { // the median needs the sorted projections
         c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
         k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                            c->sp_srows.p, c->sp_status.p);
     }
+    c->ls_nlow.ensure(T);
     k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p);
-    c->pin_side.ensure(R);
-    HIP_CHECK(hipEventRecord(c->copy_ev, st));
-    HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->copy_ev, 0));
-    HIP_CHECK(hipMemcpyAsync(c->pin_side.p, c->ls_side.p, (size_t)R, hipMemcpyDeviceToHost, c->copy_stream));
-    const double *sums = side_sums_resident(c, B); // synchronises the main stream
-    HIP_CHECK(hipStreamSynchronize(c->copy_stream));
-    const unsigned char *side = c->pin_side.p;
+    k_side_counts(c, c->ls_side.p, c->sp_tro.p, T, c->ls_nlow.p);
+    k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + base);
+    HIP_CHECK(hipMemcpyAsync(out.nlow.data(), c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
+    const double *sums = side_sums_resident(c, B); // synchronises the stream
     parallel_for(c, T, [&](i64 t) {
         Group *g = groups[t];
-        const i64 o = B.task_row_off[t], k = B.task_row_off[t + 1] - o;
-        lows[t].clear();
-        highs[t].clear();
-        for (i64 j = 0; j < k; j++) (side[o + j] == 1 ? lows[t] : highs[t]).push_back(j);
         const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
-        vlow[t] = -rss_from_sums(q1, d);
-        vhigh[t] = -rss_from_sums(q2, d);
-        have_vals[t] = 1;
+        out.vlow[t] = -rss_from_sums(q1, d);
+        out.vhigh[t] = -rss_from_sums(q2, d);
         g->mlow.resize(d);
         g->mhigh.resize(d);
         for (i64 c2 = 0; c2 < d; c2++) {
@@ -672,16 +669,89 @@ void rule_cut_device(cge_ctx *c, const Batch &B, Group *const *groups, bool use_
             g->mhigh[c2] = q2[d + c2] / q2[2 * d];
         }
         g->rc = CGE_OK;
+        out.done[t] = 1;
     });
 }
 
-// Compute the split of every task.  Device: mean, covariance, principal eigenvector, projection,
-// WSSE column sums of the rss rounds and of the children.  Host: the 1-D cut logic on z.
-void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
+// The generic round-based rss path for the tasks the sorted-order kernels declined (ties at the maximum of z, NaNs):
+// their member lists and projections come to the host, rule_rss_batched runs on a sub-batch, and the children's
+// lists go back into the tasks' arena ranges.
+void rss_generic_tasks(cge_ctx *c, const Batch &B, Group *const *groups, i64 base, const std::vector<i64> &todo,
+                       CutResult &out) {
     const i64 d = c->d, width = 2 * (2 * d + 1);
+    hipStream_t st = c->stream;
+    std::vector<Group *> fg;
+    std::vector<std::vector<i32>> rows(todo.size());
+    std::vector<double> fz;
+    std::vector<i64> zoff(todo.size() + 1, 0);
+    for (size_t q = 0; q < todo.size(); q++) zoff[q + 1] = zoff[q] + groups[todo[q]]->len;
+    fz.resize(zoff.back());
+    for (size_t q = 0; q < todo.size(); q++) {
+        const i64 t = todo[q], o = B.task_row_off[t], k = groups[t]->len;
+        rows[q].resize(k);
+        HIP_CHECK(hipMemcpyAsync(rows[q].data(), c->ls_rows.p + o, sizeof(i32) * k, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(fz.data() + zoff[q], c->ls_z.p + o, sizeof(double) * k, hipMemcpyDeviceToHost, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (size_t q = 0; q < todo.size(); q++) {
+        Group *g = groups[todo[q]];
+        g->what.resize(rows[q].size());
+        for (size_t j = 0; j < rows[q].size(); j++) g->what[j] = (i64)rows[q][j] + 1;
+        fg.push_back(g);
+    }
+    Batch FB;
+    build_batch_host(c, fg.data(), (i64)fg.size(), FB);
+    upload_batch_host(c, FB);
+    c->ls_z.ensure(FB.R);
+    HIP_CHECK(hipMemcpyAsync(c->ls_z.p, fz.data(), sizeof(double) * FB.R, hipMemcpyHostToDevice, st));
+    std::vector<RssState> rs;
+    rule_rss_batched(c, FB, fg.data(), fz.data(), rs);
+    // children: values and means by one side-sums pass over the sub-batch, lists straight into the arena
+    std::vector<unsigned char> side(FB.R, 0);
+    for (size_t q = 0; q < fg.size(); q++) {
+        if (rs[q].rc != CGE_OK) continue;
+        unsigned char *sd = &side[FB.task_row_off[q]];
+        for (i64 j : rs[q].low) sd[j] = 1;
+        for (i64 j : rs[q].high) sd[j] = 2;
+    }
+    const double *sums = side_sums(c, FB, side);
+    for (size_t q = 0; q < fg.size(); q++) {
+        const i64 t = todo[q];
+        Group *g = fg[q];
+        g->rc = rs[q].rc;
+        out.done[t] = 1;
+        if (g->rc != CGE_OK) continue;
+        std::vector<i32> kids;
+        kids.reserve(g->what.size());
+        for (i64 j : rs[q].low) kids.push_back((i32)(g->what[j] - 1));
+        for (i64 j : rs[q].high) kids.push_back((i32)(g->what[j] - 1));
+        out.nlow[t] = (i32)rs[q].low.size();
+        if (kids.size() == g->what.size())
+            HIP_CHECK(hipMemcpy(c->lm_arena.p + base + B.task_row_off[t], kids.data(), sizeof(i32) * kids.size(),
+                                hipMemcpyHostToDevice));
+        else
+            g->rc = CGE_E_EMPTY_CLUSTER;
+        const double *q1 = &sums[(size_t)q * width], *q2 = q1 + (2 * d + 1);
+        out.vlow[t] = -rss_from_sums(q1, d);
+        out.vhigh[t] = -rss_from_sums(q2, d);
+        g->mlow.resize(d);
+        g->mhigh.resize(d);
+        for (i64 c2 = 0; c2 < d; c2++) {
+            g->mlow[c2] = q1[d + c2] / q1[2 * d];
+            g->mhigh[c2] = q2[d + c2] / q2[2 * d];
+        }
+        g->what.clear();
+        g->what.shrink_to_fit();
+    }
+}
+
+// Compute the split of every task, on the device: mean, covariance, principal eigenvector, projection, the rule's
+// 1-D cut, the children's member lists, values and means.  The host only books the results.
+void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
+    const i64 d = c->d;
     std::vector<Group *> big;
     for (Group *g : tasks) {
-        const i64 k = (i64)g->what.size();
+        const i64 k = g->len;
         g->has_split = true;
         g->rc = CGE_OK;
         // the rules' own asserts (:93,:156,:219 `size(m,1) > 1`; :248 `size(m,2) > 1`)
@@ -690,10 +760,12 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             continue;
         }
         if (k <= 1) { g->rc = CGE_E_EMPTY_CLUSTER; continue; } // diameter rule on one row: `low` comes out empty
-        if (k == 2) { // `return [1], [2]`
-            g->low.assign(1, g->what[0]);
-            g->high.assign(1, g->what[1]);
+        if (k == 2) { // `return [1], [2]`: the two members stay where they are
+            g->coff = g->off;
+            g->nlow = 1;
             g->vlow = g->vhigh = DBL_EPSILON;
+            g->mlow.clear();
+            g->mhigh.clear();
             continue;
         }
         big.push_back(g);
@@ -708,16 +780,16 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
         Group *const *groups = &big[b0];
         hipStream_t st = c->stream;
         Batch B;
+        i64 base;
         {
             PhaseAcc pa(c, "lm_pack");
             build_batch(c, groups, T, B);
+            base = arena_alloc(c, B.R); // the children of task t: [base + task_row_off[t], + len)
             upload_batch(c, B);
         }
         const i64 R = B.R, NC = B.NC;
         c->ls_mean.ensure((size_t)T * d); c->ls_sw.ensure(T); c->ls_cov.ensure((size_t)T * d * d);
         c->ls_vec.ensure((size_t)T * d); c->ls_z.ensure(R);
-        c->pin_z.ensure(R);
-        const double *z = c->pin_z.p; // the projections stay in the pinned staging buffer
         {
             PhaseAcc pa(c, "lm_pca_dev");
             {
@@ -748,81 +820,34 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                                 c->ls_z.p);
             }
         }
-        // ---- the cut: local positions of the two children -----------------------------------------------------
-        std::vector<std::vector<i64>> lows(T), highs(T);
-        std::vector<double> vlow(T, 0.0), vhigh(T, 0.0);
-        std::vector<char> have_vals(T, 0);
+        // ---- the cut: children lists into the arena, sizes / values / means to the host -----------------------------
+        CutResult cr;
+        cr.nlow.assign(T, 0);
+        cr.vlow.assign(T, 0.0);
+        cr.vhigh.assign(T, 0.0);
+        cr.done.assign(T, 0);
         {
             PhaseAcc pa(c, "lm_cut");
             if (method == CGE_METHOD_RSS) {
-                std::vector<i64> fallback;
-                rule_rss_sorted(c, B, groups, z, lows, highs, vlow, vhigh, have_vals, fallback);
-                if (!fallback.empty()) { // generic round-based path on a sub-batch (ties at max z, NaNs)
-                    HIP_CHECK(hipMemcpyAsync(c->pin_z.p, c->ls_z.p, sizeof(double) * R, hipMemcpyDeviceToHost, st));
-                    HIP_CHECK(hipStreamSynchronize(st));
-                    std::vector<Group *> fg;
-                    for (i64 t : fallback) fg.push_back(groups[t]);
-                    Batch FB;
-                    build_batch(c, fg.data(), (i64)fg.size(), FB, 1);
-                    upload_batch(c, FB);
-                    std::vector<double> fz(FB.R);
-                    for (size_t q = 0; q < fallback.size(); q++)
-                        std::copy(z + B.task_row_off[fallback[q]], z + B.task_row_off[fallback[q] + 1],
-                                  fz.begin() + FB.task_row_off[q]);
-                    c->ls_z.ensure(FB.R);
-                    HIP_CHECK(hipMemcpyAsync(c->ls_z.p, fz.data(), sizeof(double) * FB.R, hipMemcpyHostToDevice, st));
-                    std::vector<RssState> rs;
-                    rule_rss_batched(c, FB, fg.data(), fz.data(), rs);
-                    for (size_t q = 0; q < fallback.size(); q++) {
-                        groups[fallback[q]]->rc = rs[q].rc;
-                        lows[fallback[q]].swap(rs[q].low);
-                        highs[fallback[q]].swap(rs[q].high);
-                    }
-                    upload_batch(c, B); // the children pass below works on the full batch again
-                }
+                rule_rss_sorted(c, B, groups, base, cr);
+                std::vector<i64> todo;
+                for (i64 t = 0; t < T; t++)
+                    if (!cr.done[t]) todo.push_back(t);
+                if (!todo.empty()) rss_generic_tasks(c, B, groups, base, todo, cr);
             } else if (method == CGE_METHOD_RSS2)
-                rule_rss2_device(c, B, groups, lows, highs, vlow, vhigh, have_vals);
+                rule_rss2_device(c, B, groups, base, cr);
             else
-                rule_cut_device(c, B, groups, method == CGE_METHOD_SIZE, lows, highs, vlow, vhigh, have_vals);
+                rule_cut_device(c, B, groups, method == CGE_METHOD_SIZE, base, cr);
         }
-        // ---- children: vertex lists and heap values (-total_rss, or eps() for singletons) ---------------------------
-        {
-            PhaseAcc pa(c, "lm_children");
-            std::vector<unsigned char> side(R, 0);
-            std::atomic<i64> need_pass{0};
-            parallel_for(c, T, [&](i64 t) {
-                Group *g = groups[t];
-                if (g->rc != CGE_OK) return;
-                if (lows[t].empty() || highs[t].empty()) { g->rc = CGE_E_EMPTY_CLUSTER; return; }
-                if (!have_vals[t]) {
-                    need_pass.fetch_add(1);
-                    unsigned char *sd = &side[B.task_row_off[t]];
-                    for (i64 j : lows[t]) sd[j] = 1;
-                    for (i64 j : highs[t]) sd[j] = 2;
-                }
-                g->low.resize(lows[t].size());
-                g->high.resize(highs[t].size());
-                for (size_t q = 0; q < lows[t].size(); q++) g->low[q] = g->what[lows[t][q]];
-                for (size_t q = 0; q < highs[t].size(); q++) g->high[q] = g->what[highs[t][q]];
-            });
-            const double *sums = need_pass.load() ? side_sums(c, B, side) : nullptr;
-            for (i64 t = 0; t < T; t++) {
-                Group *g = groups[t];
-                if (g->rc != CGE_OK) continue;
-                if (!have_vals[t]) {
-                    const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
-                    vlow[t] = -rss_from_sums(q1, d);
-                    vhigh[t] = -rss_from_sums(q2, d);
-                    g->mlow.resize(d);
-                    g->mhigh.resize(d);
-                    for (i64 c2 = 0; c2 < d; c2++) {
-                        g->mlow[c2] = q1[d + c2] / q1[2 * d];
-                        g->mhigh[c2] = q2[d + c2] / q2[2 * d];
-                    }
-                }
-                g->vlow = g->low.size() > 1 ? vlow[t] : DBL_EPSILON;
-                g->vhigh = g->high.size() > 1 ? vhigh[t] : DBL_EPSILON;
-            }
+        for (i64 t = 0; t < T; t++) {
+            Group *g = groups[t];
+            if (g->rc != CGE_OK) continue;
+            const i64 nl = cr.nlow[t], nh = g->len - nl;
+            if (nl <= 0 || nh <= 0) { g->rc = CGE_E_EMPTY_CLUSTER; continue; }
+            g->coff = base + B.task_row_off[t];
+            g->nlow = nl;
+            g->vlow = nl > 1 ? cr.vlow[t] : DBL_EPSILON;
+            g->vhigh = nh > 1 ? cr.vhigh[t] : DBL_EPSILON;
         }
     }
 }
@@ -841,12 +866,14 @@ void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool) 
         if (g->rc != CGE_OK || g->clo) continue;
         pool.emplace_back();
         g->clo = &pool.back();
-        g->clo->what = std::move(g->low);
+        g->clo->off = g->coff;
+        g->clo->len = g->nlow;
         g->clo->value = g->vlow;
         g->clo->mean = std::move(g->mlow);
         pool.emplace_back();
         g->chi = &pool.back();
-        g->chi->what = std::move(g->high);
+        g->chi->off = g->coff + g->nlow;
+        g->chi->len = g->len - g->nlow;
         g->chi->value = g->vhigh;
         g->chi->mean = std::move(g->mhigh);
     }
@@ -858,8 +885,6 @@ void replay_one(Heap &h) {
     if (g->rc != CGE_OK) throw_rc(g->rc);
     h.put(g->clo);
     h.put(g->chi);
-    g->what.clear();
-    g->what.shrink_to_fit();
 }
 
 // Bring every heap to its target length.  Each round: replay as far as the cached splits allow; then split,
@@ -893,9 +918,9 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
             while (!stack.empty()) {
                 Group *g = stack.back();
                 stack.pop_back();
-                if (g->what.size() > 1 || g == h.top() || g->has_split) vals.push_back(g->value);
+                if (g->len > 1 || g == h.top() || g->has_split) vals.push_back(g->value);
                 if (!g->has_split) {
-                    if (g->what.size() > 1 || g == h.top()) frontier.push_back(g);
+                    if (g->len > 1 || g == h.top()) frontier.push_back(g);
                 } else if (g->rc == CGE_OK) {
                     stack.push_back(g->clo);
                     stack.push_back(g->chi);
@@ -925,10 +950,13 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
 
 } // namespace
 
+// group_ids[i] = 0-based group (= heap position - 1) of vertex i; also leaves on the device c->v2l (the same, int32)
+// and the landmark -> members index c->lm_memoff / c->lm_mem (ascending inside a landmark), mirrored in
+// c->h_mem_off / c->h_mem when `want_index`.
 void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
-                   std::vector<i64> &group_ids, std::vector<std::vector<i64>> *members_out, std::vector<i32> *csr_off,
-                   std::vector<i32> *csr_mem) {
+                   std::vector<i64> &group_ids, bool want_index) {
     const i64 n = c->n, d = c->d;
+    hipStream_t st = c->stream;
     if ((i64)c->h_Xr.size() != n * d || (i64)c->h_vw.size() != n)
         CGE_THROW(CGE_E_ARG, "runsplit: embedding / vertex weights are not resident");
     std::deque<Group> pool;
@@ -941,9 +969,23 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         return std::lexicographical_compare(cl_flat + cl_off[a], cl_flat + cl_off[a + 1], cl_flat + cl_off[b],
                                             cl_flat + cl_off[b + 1]);
     });
-    for (i64 q = 0; q < ncl; q++)
-        for (i64 t = cl_off[q]; t < cl_off[q + 1]; t++)
-            if (cl_flat[t] < 1 || cl_flat[t] > n) CGE_THROW(CGE_E_ARG, "cluster member %lld out of range", (long long)cl_flat[t]);
+    // the member arena starts as the clusters themselves (0-based), cluster q at cl_off[q]
+    const i64 total = cl_off[ncl];
+    c->lm_arena_used = 0;
+    {
+        c->pin_rows[0].ensure(total);
+        i32 *stage = c->pin_rows[0].p;
+        std::atomic<int> bad{0};
+        parallel_for(c, 64, [&](i64 part) {
+            for (i64 q = total * part / 64; q < total * (part + 1) / 64; q++) {
+                if (cl_flat[q] < 1 || cl_flat[q] > n) { bad.store(1); continue; }
+                stage[q] = (i32)(cl_flat[q] - 1);
+            }
+        });
+        if (bad.load()) CGE_THROW(CGE_E_ARG, "cluster member out of range 1..%lld", (long long)n);
+        arena_alloc(c, total);
+        HIP_CHECK(hipMemcpyAsync(c->lm_arena.p, stage, sizeof(i32) * total, hipMemcpyHostToDevice, st));
+    }
 
     // ---- forced per-community phase (:282-313): every big community owns a local heap -----------
     struct Local { Heap h; i64 pos; };
@@ -956,13 +998,13 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             locals.push_back(Local{Heap(), q});
             pool.emplace_back();
             Group *g = &pool.back();
-            g->what.assign(cl_flat + cl_off[cidx], cl_flat + cl_off[cidx + 1]);
+            g->off = cl_off[cidx];
+            g->len = len;
             locals.back().h.put(g);
         }
     }
     delete pinit;
     if (!locals.empty()) {
-        // root values: -total_rss of each community (one device pass over all of them)
         if (forced <= 1) { // with forced >= 2 every root is popped from its one-element heap: its value is never compared
             PhaseAcc pa(c, "lm_roots");
             std::vector<Group *> roots;
@@ -982,7 +1024,8 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             for (i64 t = cl_off[cidx]; t < cl_off[cidx + 1]; t++) {
                 pool.emplace_back();
                 Group *g = &pool.back();
-                g->what.assign(1, cl_flat[t]);
+                g->off = t;
+                g->len = 1;
                 g->value = DBL_EPSILON; // eps() (:284)
                 H.put(g);
             }
@@ -998,41 +1041,33 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         std::vector<i64> tg{nland};
         advance_heaps(c, hs, tg, method, pool, true);
     }
+    // ---- the heap array is the numbering (:337-342): v2l and the landmark index, on the device -----------------------
     PhaseAcc pfin(c, "lm_final");
     const i64 NG = (i64)H.len();
-    group_ids.assign(n, -1);
-    parallel_for(c, NG, [&](i64 g) { // groups are disjoint: the writes do not collide
-        for (i64 v : H.a[g + 1]->what) group_ids[v - 1] = g;
+    c->pin_small.ensure((size_t)2 * NG + 2);
+    i32 *goff = c->pin_small.p, *glen = goff + NG;
+    c->h_mem_off.assign(NG + 1, 0);
+    for (i64 g = 0; g < NG; g++) {
+        goff[g] = (i32)H.a[g + 1]->off;
+        glen[g] = (i32)H.a[g + 1]->len;
+        c->h_mem_off[g + 1] = c->h_mem_off[g] + glen[g];
+    }
+    c->lm_goff.ensure(NG); c->lm_glen.ensure(NG); c->v2l.ensure(n); c->lm_mem.ensure(n); c->lm_memoff.ensure(NG + 1);
+    HIP_CHECK(hipMemcpyAsync(c->lm_goff.p, goff, sizeof(i32) * NG, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->lm_glen.p, glen, sizeof(i32) * NG, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->lm_memoff.p, c->h_mem_off.data(), sizeof(i32) * (NG + 1), hipMemcpyHostToDevice, st));
+    const i64 unassigned = k_groups_to_index(c, c->lm_arena.p, c->lm_goff.p, c->lm_glen.p, NG, n, c->v2l.p, c->lm_mem.p);
+    if (unassigned != 0 || c->h_mem_off[NG] != n)
+        CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids)"); // :343
+    c->h_v2l0.resize(n);
+    HIP_CHECK(hipMemcpyAsync(c->h_v2l0.data(), c->v2l.p, sizeof(i32) * n, hipMemcpyDeviceToHost, st));
+    if (want_index) {
+        c->h_mem.resize(n);
+        HIP_CHECK(hipMemcpyAsync(c->h_mem.data(), c->lm_mem.p, sizeof(i32) * n, hipMemcpyDeviceToHost, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    group_ids.resize(n);
+    parallel_for(c, 64, [&](i64 part) {
+        for (i64 i = n * part / 64; i < n * (part + 1) / 64; i++) group_ids[i] = c->h_v2l0[i];
     });
-    if (members_out) {
-        members_out->clear();
-        for (i64 g = 0; g < NG; g++) members_out->push_back(H.a[g + 1]->what);
-    }
-    bool all_set = true;
-    for (i64 i = 0; i < n; i++) all_set &= group_ids[i] >= 0;
-    if (!all_set) CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids)"); // :343
-    if (csr_off && csr_mem) { // group -> members (0-based, ascending): a two-pass counting sort over vertex ranges
-        csr_off->assign(NG + 1, 0);
-        for (i64 g = 0; g < NG; g++) (*csr_off)[g + 1] = (*csr_off)[g] + (i32)H.a[g + 1]->what.size();
-        csr_mem->resize(n);
-        const i64 P = std::max<i64>(1, std::min<i64>(c->n_threads, 16));
-        std::vector<std::vector<i32>> start(P, std::vector<i32>(NG, 0));
-        parallel_for(c, P, [&](i64 t) {
-            std::vector<i32> &cnt = start[t];
-            for (i64 i = n * t / P; i < n * (t + 1) / P; i++) cnt[group_ids[i]]++;
-        });
-        for (i64 g = 0; g < NG; g++) { // exclusive prefix over the ranges, inside each group's slot
-            i32 run = (*csr_off)[g];
-            for (i64 t = 0; t < P; t++) {
-                const i32 k = start[t][g];
-                start[t][g] = run;
-                run += k;
-            }
-        }
-        parallel_for(c, P, [&](i64 t) {
-            std::vector<i32> &cur = start[t];
-            i32 *out = csr_mem->data();
-            for (i64 i = n * t / P; i < n * (t + 1) / P; i++) out[cur[group_ids[i]]++] = (i32)i;
-        });
-    }
 }
