@@ -169,7 +169,6 @@ int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
     DevBuf<double> col;
     col.alloc_exact((size_t)n * d);
     HIP_CHECK(hipMemcpyAsync(col.p, X, sizeof(double) * n * d, hipMemcpyHostToDevice, c->stream));
-    c->uniq_rows_ge = 0;
     c->Xr.alloc_exact((size_t)n * d);
     k_transpose_to_rowmajor(c, col.p, c->Xr.p, n, d);
     c->h_Xr.resize((size_t)n * d);
@@ -235,21 +234,26 @@ int cge_set_vertex_data(cge_ctx *c, const int64_t *comm, const double *vw, int64
 static i64 clamp_to_unique_rows(cge_ctx *c, i64 land, int *truncated) {
     const i64 n = c->n, d = c->d;
     *truncated = 0;
-    if (land <= 1 || land <= c->uniq_rows_ge) return land; // a property of the resident embedding: remembered
-    DevBuf<uint64_t> dh;
-    dh.ensure(n);
-    k_row_hash(c, c->Xr.p, dh.p, n, d);
-    std::vector<uint64_t> h(n);
-    HIP_CHECK(hipMemcpyAsync(h.data(), dh.p, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (land <= 1) return land;
+    // `land` distinct hashes among a prefix of the rows already prove `land` distinct rows: hash 8*land rows first,
+    // the whole matrix only when that prefix does not settle it
+    std::vector<uint64_t> h;
     std::unordered_set<uint64_t> seen;
     seen.reserve((size_t)std::min<i64>(n, 2 * land));
-    for (i64 i = 0; i < n; i++) {
-        seen.insert(h[i]);
-        if ((i64)seen.size() >= land) {
-            c->uniq_rows_ge = land;
-            return land;
+    i64 done = 0;
+    c->uniq_hash.ensure(n);
+    for (int pass = 0; pass < 2 && done < n; pass++) {
+        const i64 upto = pass == 0 ? std::min<i64>(n, 8 * land) : n;
+        k_row_hash(c, c->Xr.p + done * d, c->uniq_hash.p + done, upto - done, d);
+        h.resize(upto);
+        HIP_CHECK(hipMemcpyAsync(h.data() + done, c->uniq_hash.p + done, sizeof(uint64_t) * (upto - done), hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (i64 i = done; i < upto; i++) {
+            seen.insert(h[i]);
+            if ((i64)seen.size() >= land) return land;
         }
+        done = upto;
     }
     // fewer distinct hashes than `land`: count bitwise-distinct rows exactly
     std::vector<i64> ix(n);
@@ -538,6 +542,7 @@ static double resident_diameter_lm(cge_ctx *c, const double *mu, const double *l
 // landmark -> members CSR (ascending vertex id) from a 0-based assignment
 static void build_landmark_index(cge_ctx *c, const std::vector<i32> &v2l0, i64 N) {
     const i64 n = (i64)v2l0.size();
+    c->lm_index_on_device = false;
     c->h_mem_off.assign(N + 1, 0);
     c->h_mem.resize(n);
     for (i64 i = 0; i < n; i++) c->h_mem_off[v2l0[i] + 1]++;

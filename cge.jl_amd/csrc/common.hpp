@@ -261,11 +261,11 @@ struct cge_ctx {
     DevBuf<i32> mp_lref, mp_refoff, mp_refmem;
     DevBuf<double> gmean;    // global feature mean (the centre used by Xc)
     DevBuf<double> Xs, rns, Ms, mnorm, Pm; // landmark-sorted centred copy, centroids, P matrix
-    DevBuf<i32> pos2node, sub_land;
+    DevBuf<i32> pos2node, sub_land, dm_soff, dm_memoff, dm_mem;
     DevBuf<double> bound_list;             // BoundRec records (2 doubles each)
     DevBuf<i32> tile_list;
     std::vector<i32> h_mem_off, h_mem;     // landmark -> members (ascending vertex id), host copy
-    i64 uniq_rows_ge = 0;                  // the resident embedding is known to hold at least this many distinct rows
+    DevBuf<uint64_t> uniq_hash;            // row hashes of the unique-row check
     int opt_diameter = 0;                  // 0 auto (pruned with brute-force fallback), 1 brute force, 2 pruned only
     i64 stat_cand_pairs = 0, stat_cand_tiles = 0; // last pruned run
     int stat_diameter_path = 0;            // 1 brute, 2 pruned
@@ -284,6 +284,7 @@ struct cge_ctx {
     // member lists of the landmark phase: a group is a range of this arena (vertex ids, reference order)
     DevBuf<i32> lm_arena;
     i64 lm_arena_used = 0;
+    bool lm_index_on_device = false; // lm_memoff / lm_mem mirror h_mem_off / h_mem (set by runsplit, cleared when the host rebuilds the index)
     DevBuf<i32> ls_toff, ls_nlow, lm_goff, lm_glen, lm_mem, lm_memoff; // task arena offsets, low-child counts, final groups, landmark index
     DevBuf<unsigned char> ls_keys;
     PinBuf<i32> pin_small;
@@ -393,6 +394,8 @@ void k_max_pair(cge_ctx *c, const double *Xc, const double *rnorm, i64 n, i64 ld
                 double *best_val, i64 *best_i, i64 *best_j);
 void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *pj, i64 S, double inv_scale_den,
                  double *out);
+void k_diameter_layout(cge_ctx *c, const i32 *mem_off, const i32 *mem, const i32 *soff, i64 N, i32 *pos2node, i32 *sub_land,
+                       i64 n_sub);
 void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, const double *Ms, const double *mnorm,
              i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P);
 void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,

@@ -44,19 +44,25 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     for (i64 a = 0; a < N; a++) soff[a + 1] = soff[a] + ((mem_off[a + 1] - mem_off[a] + 15) / 16) * 16;
     const i64 npos = soff[N];
     const i64 lds_rows = (npos + 127) / 128 * 128 + 128;
-    std::vector<i32> pos2node(npos), sub_land(lds_rows / 16, -1);
-    for (i64 a = 0; a < N; a++) {
-        const i64 cnt = mem_off[a + 1] - mem_off[a];
-        for (i64 p = soff[a]; p < soff[a + 1]; p++) {
-            const i64 q = p - soff[a];
-            pos2node[p] = mem[mem_off[a] + (q < cnt ? q : cnt - 1)]; // padding repeats the last member
-            if ((q & 15) == 0) sub_land[p >> 4] = (i32)a;
-        }
-    }
     c->pos2node.ensure(npos);
     c->sub_land.ensure(lds_rows / 16);
-    HIP_CHECK(hipMemcpyAsync(c->pos2node.p, pos2node.data(), sizeof(i32) * npos, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->sub_land.p, sub_land.data(), sizeof(i32) * (lds_rows / 16), hipMemcpyHostToDevice, st));
+    {
+        std::vector<i32> soff32(soff.begin(), soff.end());
+        c->dm_soff.ensure(N + 1);
+        HIP_CHECK(hipMemcpyAsync(c->dm_soff.p, soff32.data(), sizeof(i32) * (N + 1), hipMemcpyHostToDevice, st));
+        const i32 *d_off = c->lm_memoff.p, *d_mem = c->lm_mem.p;
+        if (!(c->lm_index_on_device && mem_off.data() == c->h_mem_off.data())) {
+            // index not produced by the landmark phase of this context (exact-mode callers): upload it
+            c->dm_memoff.ensure(N + 1);
+            c->dm_mem.ensure(n);
+            HIP_CHECK(hipMemcpyAsync(c->dm_memoff.p, mem_off.data(), sizeof(i32) * (N + 1), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(c->dm_mem.p, mem.data(), sizeof(i32) * n, hipMemcpyHostToDevice, st));
+            d_off = c->dm_memoff.p;
+            d_mem = c->dm_mem.p;
+        }
+        k_diameter_layout(c, d_off, d_mem, c->dm_soff.p, N, c->pos2node.p, c->sub_land.p, lds_rows / 16);
+        HIP_CHECK(hipStreamSynchronize(st)); // soff32 goes out of scope
+    }
     lap("dm_layout");
     // ---- reference points ---------------------------------------------------------------------------------
     const bool by_comm = C >= 32 && (i64)lcomm.size() == N && lw != nullptr;
@@ -164,8 +170,12 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     }
     lap("dm_exact");
     if (best_pi >= 0) {
-        far_i = pos2node[best_pi];
-        far_j = pos2node[best_pj];
+        i32 a = 0, b = 0;
+        HIP_CHECK(hipMemcpyAsync(&a, c->pos2node.p + best_pi, sizeof(i32), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&b, c->pos2node.p + best_pj, sizeof(i32), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        far_i = a;
+        far_j = b;
     }
     if (far_i > far_j) std::swap(far_i, far_j);
     *best_d2 = best;

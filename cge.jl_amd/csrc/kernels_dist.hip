@@ -483,3 +483,23 @@ void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *
     if (S <= 0) return;
     hipLaunchKernelGGL(pair_dist_kernel, dim3(grid_for(S, 128)), dim3(128), 0, c->stream, Xr, d, pi, pj, S, den, out);
 }
+
+// landmark-sorted layout of the pruned diameter: landmark a owns the positions [soff[a], soff[a+1]) (its members in
+// ascending order, padded to a multiple of 16 by repeating the last one); sub_land[pos/16] = a.
+__global__ __launch_bounds__(256) void diameter_layout_kernel(const i32 *__restrict__ mem_off, const i32 *__restrict__ mem,
+                                                              const i32 *__restrict__ soff, i32 *__restrict__ pos2node,
+                                                              i32 *__restrict__ sub_land) {
+    const i64 a = blockIdx.x;
+    const i64 m0 = mem_off[a], cnt = mem_off[a + 1] - m0, p0 = soff[a], p1 = soff[a + 1];
+    for (i64 p = p0 + threadIdx.x; p < p1; p += 256) {
+        const i64 q = p - p0;
+        pos2node[p] = mem[m0 + (q < cnt ? q : cnt - 1)];
+        if ((q & 15) == 0) sub_land[p >> 4] = (i32)a;
+    }
+}
+void k_diameter_layout(cge_ctx *c, const i32 *mem_off, const i32 *mem, const i32 *soff, i64 N, i32 *pos2node, i32 *sub_land,
+                       i64 n_sub) {
+    HIP_CHECK(hipMemsetAsync(sub_land, 0xFF, sizeof(i32) * n_sub, c->stream));
+    hipLaunchKernelGGL(diameter_layout_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, mem_off, mem, soff, pos2node,
+                       sub_land);
+}

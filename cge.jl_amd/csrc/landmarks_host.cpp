@@ -1061,6 +1061,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids)"); // :343
     c->h_v2l0.resize(n);
     HIP_CHECK(hipMemcpyAsync(c->h_v2l0.data(), c->v2l.p, sizeof(i32) * n, hipMemcpyDeviceToHost, st));
+    c->lm_index_on_device = want_index;
     if (want_index) {
         c->h_mem.resize(n);
         HIP_CHECK(hipMemcpyAsync(c->h_mem.data(), c->lm_mem.p, sizeof(i32) * n, hipMemcpyDeviceToHost, st));
