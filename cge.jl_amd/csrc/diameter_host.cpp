@@ -105,13 +105,22 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     // ---- lower bound from farthest-point sweeps ----------------------------------------------------------
     double L = 0.0;
     i64 p0 = 0, far_i = 0, far_j = 0;
-    for (int it = 0; it < 2; it++) { // two sweeps seed the bound; the exact search below does the rest
-        double v;
-        i64 q;
-        k_farthest(c, c->Xr.p, n, d, p0, &v, &q);
-        if (v > L) { L = v; far_i = p0; far_j = q; }
-        p0 = q;
+    // The two sweeps (memory-bound reads of Xr, each with a host round trip) run on the side stream while the MFMA pass
+    // above occupies the main one.
+    std::swap(c->stream, c->copy_stream);
+    try {
+        for (int it = 0; it < 2; it++) { // two sweeps seed the bound; the exact search below does the rest
+            double v;
+            i64 q;
+            k_farthest(c, c->Xr.p, n, d, p0, &v, &q);
+            if (v > L) { L = v; far_i = p0; far_j = q; }
+            p0 = q;
+        }
+    } catch (...) {
+        std::swap(c->stream, c->copy_stream);
+        throw;
     }
+    std::swap(c->stream, c->copy_stream);
     lap("dm_farthest");
     // ---- candidate landmark pairs ---------------------------------------------------------------------------
     const i64 cap = std::min<i64>(N * (N + 1) / 2, (i64)4 << 20);
