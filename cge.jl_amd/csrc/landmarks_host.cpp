@@ -1,13 +1,14 @@
 // landmarks_host.cpp -- runsplit() for the MI355X build (reference: src/landmarks.jl:279-345).
 //
 // Split of work:
-//   device : per-group weighted mean, covariance y'y (fp64 MFMA SYRK), principal eigenvector (LDS-resident
-//            batched solver), projection z = y v, stable segmented sort of z, WSSE prefix sums along sorted z,
-//            all median-cut rounds of the rss rule, children / root RSS -- batched over many groups per launch
-//            (kernels_lm.hip, kernels_sort.hip);
-//   host   : the heap (bit-for-bit the reference's sift rules, :12-46) and its replay, the member lists of the
-//            children in the reference's order, the trivial cuts of the size / diameter rules, the sequential
-//            rss2 rule (:92-147), and the generic round-based rss path for groups with a tie at max z.
+//   device : the member lists (an int32 arena: a group is a range, a split appends its two children), per-group
+//            weighted mean, covariance y'y (fp64 MFMA SYRK), principal eigenvector (register-resident batched
+//            solver), projection z = y v, stable segmented sort of z, the cut of all four rules (rss: WSSE prefix
+//            sums along sorted z + all median-cut rounds in one launch; rss2: two-pointer walk; size / diameter:
+//            side flags with the sequential tie rule), children values / means / member lists, and finally v2l and
+//            the landmark -> members index -- batched over many groups per launch (kernels_lm.hip, kernels_sort.hip);
+//   host   : the heap (bit-for-bit the reference's sift rules, :12-46) and its replay from (offset, length, value)
+//            triples, and the generic round-based rss path for groups with a tie at max z or NaNs.
 // The reference splits strictly one group at a time.  Here the nodes of the split tree that can still be
 // popped are split speculatively in batches and the heap is then REPLAYED in the reference's order from the
 // cached results, so ids (= positions in the heap array, :337-342) come out identical while the device sees
