@@ -284,6 +284,9 @@ struct cge_ctx {
     // member lists of the landmark phase: a group is a range of this arena (vertex ids, reference order)
     DevBuf<i32> lm_arena;
     i64 lm_arena_used = 0;
+    DevBuf<double> lm_means; // weighted means of groups, known from their parents' splits (d doubles each)
+    i64 lm_means_used = 0;
+    DevBuf<i64> ls_moff;
     bool lm_index_on_device = false; // lm_memoff / lm_mem mirror h_mem_off / h_mem (set by runsplit, cleared when the host rebuilds the index)
     DevBuf<i32> ls_toff, ls_nlow, lm_goff, lm_glen, lm_mem, lm_memoff; // task arena offsets, low-child counts, final groups, landmark index
     DevBuf<unsigned char> ls_keys;
@@ -361,6 +364,7 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
 #define CGE_RR_MAXROUNDS 63
 #define CGE_CHUNK_ROWS 1024 // rows per chunk of a batch (build_batch); the rounds kernel uses r >> 10
 #define CGE_PREFIX_STRIDE 8 // the sorted-order WSSE prefix is stored every 8th row of a chunk (CGE_CHUNK_ROWS % 8 == 0)
+void k_gather_means(cge_ctx *c, const double *arena, const i64 *off, i64 T, i64 d, double *mean);
 void k_gather_rows(cge_ctx *c, const i32 *arena, const i32 *task_off, const i32 *task_row_off, const i32 *chunk_task,
                    const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, i32 *rows, i32 *row_task);
 void k_rss_child_keys(cge_ctx *c, const i32 *perm, const i32 *row_task, const i32 *task_row_off, const i32 *meta,

@@ -194,3 +194,14 @@ i64 k_groups_to_index(cge_ctx *c, const i32 *arena, const i32 *goff, const i32 *
     HIP_CHECK(hipStreamSynchronize(st));
     return bad;
 }
+
+// mean[t][:] <- the d doubles at off[t] of the means arena
+__global__ void gather_means_kernel(const double *__restrict__ arena, const i64 *__restrict__ off, i64 d,
+                                    double *__restrict__ mean) {
+    const i64 t = blockIdx.x;
+    const double *src = arena + off[t];
+    for (i64 q = threadIdx.x; q < d; q += blockDim.x) mean[t * d + q] = src[q];
+}
+void k_gather_means(cge_ctx *c, const double *arena, const i64 *off, i64 T, i64 d, double *mean) {
+    hipLaunchKernelGGL(gather_means_kernel, dim3((unsigned)T), dim3(128), 0, c->stream, arena, off, d, mean);
+}

@@ -47,8 +47,9 @@ struct Group {
     double vlow = 0.0, vhigh = 0.0;
     Group *clo = nullptr, *chi = nullptr; // child groups, created as soon as the split is known
     // weighted mean of the rows (matrix_w_mean, src/landmarks.jl:71-81) when it is already known from the parent's
-    // split (the WSSE column sums of a child are sum w x and sum w); empty = compute it on the device
-    std::vector<double> mean, mlow, mhigh;
+    // split (the WSSE column sums of a child are sum w x and sum w): d doubles at this offset of the means arena
+    // (c->lm_means), -1 = compute it on the device.  cmean_off: the two children's means, low then high.
+    i64 mean_off = -1, cmean_off = -1;
 };
 
 // reserve `cnt` entries of the member arena (grows by copying: ranges handed out earlier stay valid as offsets)
@@ -67,6 +68,25 @@ i64 arena_alloc(cge_ctx *c, i64 cnt) {
     }
     const i64 at = c->lm_arena_used;
     c->lm_arena_used = need;
+    return at;
+}
+
+// reserve `cnt` doubles of the means arena (same growth rule as the member arena)
+i64 means_alloc(cge_ctx *c, i64 cnt) {
+    const i64 need = c->lm_means_used + cnt;
+    if ((i64)c->lm_means.n < need || !c->lm_means.p) {
+        const i64 cap = std::max<i64>(need + need / 2, 1024);
+        double *fresh = nullptr;
+        HIP_CHECK(hipMalloc((void **)&fresh, (size_t)cap * sizeof(double)));
+        if (c->lm_means.p && c->lm_means_used > 0)
+            HIP_CHECK(hipMemcpyAsync(fresh, c->lm_means.p, sizeof(double) * c->lm_means_used, hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->lm_means.p) (void)hipFree(c->lm_means.p);
+        c->lm_means.p = fresh;
+        c->lm_means.n = (size_t)cap;
+    }
+    const i64 at = c->lm_means_used;
+    c->lm_means_used = need;
     return at;
 }
 
@@ -576,15 +596,14 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, i64 base,
     c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W);
     c->sp_prefix.ensure((size_t)(R / CGE_PREFIX_STRIDE + B.NC + 1) * W);
     c->sp_meta.ensure(2 * T); c->sp_rounds.ensure((size_t)T * 3 * CGE_RR_MAXROUNDS); c->sp_vals.ensure(2 * T);
-    c->sp_cmeans.ensure((size_t)2 * T * d);
     c->ls_keys.ensure(R); c->ls_nlow.ensure(T);
-    c->pin_cmeans.ensure((size_t)2 * T * d);
+    const i64 mbase = means_alloc(c, 2 * T * d); // the children's means stay on the device
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                        c->sp_srows.p, c->sp_status.p);
     k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
     k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->ls_tco.p, c->sp_prefix.p, c->sp_coff.p,
-                 T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p, c->sp_cmeans.p);
+                 T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p, c->lm_means.p + mbase);
     k_rss_child_keys(c, c->sp_perm.p, c->ls_row_task.p, c->sp_tro.p, c->sp_meta.p, c->sp_rounds.p, R, T, c->ls_keys.p,
                      c->ls_nlow.p);
     k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + base);
@@ -594,20 +613,17 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, i64 base,
     HIP_CHECK(hipMemcpyAsync(meta.data(), c->sp_meta.p, sizeof(i32) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(out.nlow.data(), c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(c->pin_cmeans.p, c->sp_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    parallel_for(c, T, [&](i64 t) {
+    for (i64 t = 0; t < T; t++) {
         Group *g = groups[t];
-        if (status[t] == 2) { g->rc = CGE_E_HOMOGENEOUS; out.done[t] = 1; return; }
-        if (status[t] == 1 || meta[2 * t + 1] != 0) { out.done[t] = 0; return; }
+        if (status[t] == 2) { g->rc = CGE_E_HOMOGENEOUS; out.done[t] = 1; continue; }
+        if (status[t] == 1 || meta[2 * t + 1] != 0) { out.done[t] = 0; continue; }
         out.vlow[t] = vals[2 * t];
         out.vhigh[t] = vals[2 * t + 1];
-        const double *cm = c->pin_cmeans.p + (size_t)2 * t * d;
-        g->mlow.assign(cm, cm + d);
-        g->mhigh.assign(cm + d, cm + 2 * d);
+        g->cmean_off = mbase + 2 * t * d;
         g->rc = CGE_OK;
         out.done[t] = 1;
-    });
+    }
 }
 
 // split_cluster_rss2 on the device (kernels_lm.hip: rss2_walk_kernel).  The children are rank ranges of the sorted
@@ -616,29 +632,26 @@ void rule_rss2_device(cge_ctx *c, const Batch &B, Group *const *groups, i64 base
     const i64 T = B.T, R = B.R, d = c->d;
     hipStream_t st = c->stream;
     c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
-    c->sp_meta.ensure(2 * T); c->sp_vals.ensure(2 * T); c->sp_cmeans.ensure((size_t)2 * T * d);
-    c->pin_cmeans.ensure((size_t)2 * T * d);
+    c->sp_meta.ensure(2 * T); c->sp_vals.ensure(2 * T);
+    const i64 mbase = means_alloc(c, 2 * T * d);
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                        c->sp_srows.p, c->sp_status.p);
     HIP_CHECK(hipMemcpyAsync(c->lm_arena.p + base, c->sp_srows.p, sizeof(i32) * R, hipMemcpyDeviceToDevice, st));
-    k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->sp_cmeans.p);
+    k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->lm_means.p + mbase);
     std::vector<i32> meta(2 * T);
     std::vector<double> vals(2 * T);
     HIP_CHECK(hipMemcpyAsync(meta.data(), c->sp_meta.p, sizeof(i32) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(c->pin_cmeans.p, c->sp_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    parallel_for(c, T, [&](i64 t) {
+    for (i64 t = 0; t < T; t++) {
         Group *g = groups[t];
         out.nlow[t] = meta[2 * t] + 1; // low = ranks [0, lo], high = ranks [hi, k) with hi == lo + 1
         out.vlow[t] = vals[2 * t];
         out.vhigh[t] = vals[2 * t + 1];
-        const double *cm = c->pin_cmeans.p + (size_t)2 * t * d;
-        g->mlow.assign(cm, cm + d);
-        g->mhigh.assign(cm + d, cm + 2 * d);
+        g->cmean_off = mbase + 2 * t * d;
         g->rc = CGE_OK;
         out.done[t] = 1;
-    });
+    }
 }
 
 // split_cluster_size / split_cluster_diameter on the device (kernels_lm.hip: cut_sides_kernel): the side of every row,
@@ -658,20 +671,23 @@ void rule_cut_device(cge_ctx *c, const Batch &B, Group *const *groups, bool use_
     k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + base);
     HIP_CHECK(hipMemcpyAsync(out.nlow.data(), c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
     const double *sums = side_sums_resident(c, B); // synchronises the stream
+    const i64 mbase = means_alloc(c, 2 * T * d);
+    c->pin_cmeans.ensure((size_t)2 * T * d);
     parallel_for(c, T, [&](i64 t) {
         Group *g = groups[t];
         const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
         out.vlow[t] = -rss_from_sums(q1, d);
         out.vhigh[t] = -rss_from_sums(q2, d);
-        g->mlow.resize(d);
-        g->mhigh.resize(d);
+        double *ml = c->pin_cmeans.p + (size_t)2 * t * d, *mh = ml + d;
         for (i64 c2 = 0; c2 < d; c2++) {
-            g->mlow[c2] = q1[d + c2] / q1[2 * d];
-            g->mhigh[c2] = q2[d + c2] / q2[2 * d];
+            ml[c2] = q1[d + c2] / q1[2 * d];
+            mh[c2] = q2[d + c2] / q2[2 * d];
         }
+        g->cmean_off = mbase + 2 * t * d;
         g->rc = CGE_OK;
         out.done[t] = 1;
     });
+    HIP_CHECK(hipMemcpyAsync(c->lm_means.p + mbase, c->pin_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyHostToDevice, st));
 }
 
 // The generic round-based rss path for the tasks the sorted-order kernels declined (ties at the maximum of z, NaNs):
@@ -735,12 +751,13 @@ void rss_generic_tasks(cge_ctx *c, const Batch &B, Group *const *groups, i64 bas
         const double *q1 = &sums[(size_t)q * width], *q2 = q1 + (2 * d + 1);
         out.vlow[t] = -rss_from_sums(q1, d);
         out.vhigh[t] = -rss_from_sums(q2, d);
-        g->mlow.resize(d);
-        g->mhigh.resize(d);
+        std::vector<double> m2(2 * d);
         for (i64 c2 = 0; c2 < d; c2++) {
-            g->mlow[c2] = q1[d + c2] / q1[2 * d];
-            g->mhigh[c2] = q2[d + c2] / q2[2 * d];
+            m2[c2] = q1[d + c2] / q1[2 * d];
+            m2[d + c2] = q2[d + c2] / q2[2 * d];
         }
+        g->cmean_off = means_alloc(c, 2 * d);
+        HIP_CHECK(hipMemcpy(c->lm_means.p + g->cmean_off, m2.data(), sizeof(double) * 2 * d, hipMemcpyHostToDevice));
         g->what.clear();
         g->what.shrink_to_fit();
     }
@@ -765,8 +782,7 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             g->coff = g->off;
             g->nlow = 1;
             g->vlow = g->vhigh = DBL_EPSILON;
-            g->mlow.clear();
-            g->mhigh.clear();
+            g->cmean_off = -1;
             continue;
         }
         big.push_back(g);
@@ -796,11 +812,14 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             {
                 ScopedKernelTimer tm(c, "group_stats");
                 bool have_means = true;
-                for (i64 t = 0; t < T && have_means; t++) have_means = (i64)groups[t]->mean.size() == d;
-                if (have_means) { // known from the parents' splits: one small upload instead of a pass over the rows
-                    c->pin_means.ensure((size_t)T * d);
-                    parallel_for(c, T, [&](i64 t) { std::copy(groups[t]->mean.begin(), groups[t]->mean.end(), c->pin_means.p + t * d); });
-                    HIP_CHECK(hipMemcpyAsync(c->ls_mean.p, c->pin_means.p, sizeof(double) * T * d, hipMemcpyHostToDevice, st));
+                for (i64 t = 0; t < T && have_means; t++) have_means = groups[t]->mean_off >= 0;
+                if (have_means) { // known from the parents' splits: gathered from the means arena, no pass over the rows
+                    std::vector<i64> moff(T);
+                    for (i64 t = 0; t < T; t++) moff[t] = groups[t]->mean_off;
+                    c->ls_moff.ensure(T);
+                    HIP_CHECK(hipMemcpyAsync(c->ls_moff.p, moff.data(), sizeof(i64) * T, hipMemcpyHostToDevice, st));
+                    k_gather_means(c, c->lm_means.p, c->ls_moff.p, T, d, c->ls_mean.p);
+                    HIP_CHECK(hipStreamSynchronize(st)); // moff goes out of scope
                 } else
                     k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                                  c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
@@ -862,7 +881,7 @@ void throw_rc(int rc) {
 }
 
 // create the child groups of every freshly split task (single-threaded: the pool is not thread-safe)
-void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool) {
+void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool, i64 c_d) {
     for (Group *g : tasks) {
         if (g->rc != CGE_OK || g->clo) continue;
         pool.emplace_back();
@@ -870,13 +889,13 @@ void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool) 
         g->clo->off = g->coff;
         g->clo->len = g->nlow;
         g->clo->value = g->vlow;
-        g->clo->mean = std::move(g->mlow);
+        g->clo->mean_off = g->cmean_off;
         pool.emplace_back();
         g->chi = &pool.back();
         g->chi->off = g->coff + g->nlow;
         g->chi->len = g->len - g->nlow;
         g->chi->value = g->vhigh;
-        g->chi->mean = std::move(g->mhigh);
+        g->chi->mean_off = g->cmean_off >= 0 ? g->cmean_off + c_d : -1;
     }
 }
 
@@ -945,7 +964,7 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
         if (batch.empty()) break;
         compute_splits(c, batch, method);
         PhaseAcc pm(c, "lm_materialise");
-        materialise_children(batch, pool);
+        materialise_children(batch, pool, c->d);
     }
 }
 
@@ -973,6 +992,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     // the member arena starts as the clusters themselves (0-based), cluster q at cl_off[q]
     const i64 total = cl_off[ncl];
     c->lm_arena_used = 0;
+    c->lm_means_used = 0;
     {
         c->pin_rows[0].ensure(total);
         i32 *stage = c->pin_rows[0].p;
