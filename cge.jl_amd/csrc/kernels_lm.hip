@@ -622,6 +622,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 // one wave per task.  meta[t] = {n_rounds, rc}; rounds[t][r] = {first rank, end rank, side (1 low / 2 high)};
 // vals[t] = {vlow, vhigh} = -total_rss of the children (eps() for singletons is applied by the host).
+template <int NS> // NS = columns per lane (d <= 64*NS): no work is issued for slots beyond the embedding width
 __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                                         const i32 *__restrict__ srows, const double *__restrict__ zs,
                                                         const i32 *__restrict__ task_row_off,
@@ -638,12 +639,12 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
     const double *Coff = coff + tco * W; // exclusive offsets of the task's chunks
     i32 *rlog = rounds + t * 3 * RR_MAXROUNDS;
     // seeds: rank 0 (arg-min) and rank k-1 (arg-max), exact terms as :169-170
-    double rl_ss[RR_SLOTS], rl_s[RR_SLOTS], rh_ss[RR_SLOTS], rh_s[RR_SLOTS];
+    double rl_ss[NS], rl_s[NS], rh_ss[NS], rh_s[NS];
     const i64 v1 = srows[o], v2 = srows[o + k - 1];
     const double w1 = vw[v1], w2 = vw[v2];
     double rl_w = w1, rh_w = w2;
 #pragma unroll
-    for (int s = 0; s < RR_SLOTS; s++) {
+    for (int s = 0; s < NS; s++) {
         const i64 c = lane + 64 * s;
         rl_ss[s] = rl_s[s] = rh_ss[s] = rh_s[s] = 0.0;
         if (c < d) {
@@ -655,80 +656,91 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
     // inclusive prefix P[r] for this lane's columns: the stored running sum at the end of the previous block of
     // the chunk, plus the rows of the partial block in scan order, plus the chunk offset (the same additions in the
     // same order as a full running sum)
-    auto prefix_at = [&](i64 r, double (&ss)[RR_SLOTS], double (&s1)[RR_SLOTS], double &w) {
+    auto prefix_at = [&](i64 r, double (&ss)[NS], double (&s1)[NS], double &w) {
         constexpr int SB = CGE_PREFIX_STRIDE;
         const i64 chl = r / CGE_CHUNK_ROWS, cbeg = o + chl * CGE_CHUNK_ROWS, rin = r - chl * CGE_CHUNK_ROWS, bi = rin / SB;
         const double *Sp = prefix + (cbeg / SB + tco + chl + (bi > 0 ? bi - 1 : 0)) * W;
 #pragma unroll
-        for (int s = 0; s < RR_SLOTS; s++) {
+        for (int s = 0; s < NS; s++) {
             const i64 c = lane + 64 * s;
             ss[s] = (c < d && bi > 0) ? Sp[c] : 0.0;
             s1[s] = (c < d && bi > 0) ? Sp[d + c] : 0.0;
         }
         w = (bi > 0) ? Sp[2 * d] : 0.0;
-        for (i64 j = bi * SB; j <= rin; j++) {
-            const i64 v = srows[cbeg + j];
-            const double wv = vw[v];
+        { // the <= SB-1 rows of the partial block: all loads first, then the additions in scan order
+            double xr[SB][NS], wr[SB];
 #pragma unroll
-            for (int s = 0; s < RR_SLOTS; s++) {
-                const i64 c = lane + 64 * s;
-                if (c < d) {
-                    const double xv = Xr[v * d + c];
-                    ss[s] += wv * (xv * xv);
-                    s1[s] += wv * xv;
+            for (int u = 0; u < SB; u++) {
+                const i64 j = bi * SB + u;
+                const bool on = j <= rin;
+                const i64 v = srows[cbeg + (on ? j : rin)];
+                wr[u] = on ? vw[v] : 0.0;
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const i64 c = lane + 64 * s;
+                    xr[u][s] = (on && c < d) ? Xr[v * d + c] : 0.0;
                 }
             }
-            w += wv;
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                if (bi * SB + u > rin) break; // uniform
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    ss[s] += wr[u] * (xr[u][s] * xr[u][s]);
+                    s1[s] += wr[u] * xr[u][s];
+                }
+                w += wr[u];
+            }
         }
         const double *Cp = Coff + chl * W;
 #pragma unroll
-        for (int s = 0; s < RR_SLOTS; s++) {
+        for (int s = 0; s < NS; s++) {
             const i64 c = lane + 64 * s;
             if (c < d) { ss[s] += Cp[c]; s1[s] += Cp[d + c]; }
         }
         w += Cp[2 * d];
     };
     // range sums S(a,b) = P[b-1] - P[a-1] for this lane's columns
-    auto range = [&](i64 a, i64 b, double (&ss)[RR_SLOTS], double (&s1)[RR_SLOTS], double &w) {
+    auto range = [&](i64 a, i64 b, double (&ss)[NS], double (&s1)[NS], double &w) {
 #pragma unroll
-        for (int s = 0; s < RR_SLOTS; s++) ss[s] = s1[s] = 0.0;
+        for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
         w = 0.0;
         if (b <= a) return;
         prefix_at(b - 1, ss, s1, w);
         if (a > 0) {
-            double qs[RR_SLOTS], q1[RR_SLOTS], qw;
+            double qs[NS], q1[NS], qw;
             prefix_at(a - 1, qs, q1, qw);
 #pragma unroll
-            for (int s = 0; s < RR_SLOTS; s++) { ss[s] -= qs[s]; s1[s] -= q1[s]; }
+            for (int s = 0; s < NS; s++) { ss[s] -= qs[s]; s1[s] -= q1[s]; }
             w -= qw;
         }
     };
     // sum over the columns of wsse(base + add)
-    auto fsum = [&](const double (&bss)[RR_SLOTS], const double (&bs1)[RR_SLOTS], double bw, const double (&ass)[RR_SLOTS],
-                    const double (&as1)[RR_SLOTS], double aw) {
+    auto fsum = [&](const double (&bss)[NS], const double (&bs1)[NS], double bw, const double (&ass)[NS],
+                    const double (&as1)[NS], double aw) {
         double acc = 0.0;
         const double w = bw + aw;
 #pragma unroll
-        for (int s = 0; s < RR_SLOTS; s++) {
+        for (int s = 0; s < NS; s++) {
             const i64 c = lane + 64 * s;
             if (c < d) {
                 const double ss = bss[s] + ass[s], s1 = bs1[s] + as1[s];
                 acc += ss - s1 * s1 / w;
             }
         }
-        return wave_sum(acc);
+        return wave_allsum(acc);
     };
     auto median = [&](i64 a, i64 b) { // Statistics.median of z[a..b) (sorted)
         const i64 cnt = b - a;
         return (cnt & 1) ? z[a + cnt / 2] : z[a + cnt / 2 - 1] / 2.0 + z[a + cnt / 2] / 2.0;
     };
-    double zero_ss[RR_SLOTS], zero_s[RR_SLOTS];
+    double zero_ss[NS], zero_s[NS];
 #pragma unroll
-    for (int s = 0; s < RR_SLOTS; s++) zero_ss[s] = zero_s[s] = 0.0;
+    for (int s = 0; s < NS; s++) zero_ss[s] = zero_s[s] = 0.0;
     i64 ga = 1, gb = k - 1; // gray = ranks [ga, gb)
     int nr = 0, rc = 0;
     double med = median(0, k);
-    double a_ss[RR_SLOTS], a_s[RR_SLOTS], b_ss[RR_SLOTS], b_s[RR_SLOTS], aw, bw;
+    double a_ss[NS], a_s[NS], b_ss[NS], b_s[NS], aw, bw;
     bool leftover = false;
     while (ga < gb) {
         // number of gray ranks with z < med (binary search; z ascending)
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
         if (f1 < f2) {
             if (cut == ga) { leftover = true; break; }
 #pragma unroll
-            for (int s = 0; s < RR_SLOTS; s++) { rl_ss[s] += a_ss[s]; rl_s[s] += a_s[s]; }
+            for (int s = 0; s < NS; s++) { rl_ss[s] += a_ss[s]; rl_s[s] += a_s[s]; }
             rl_w += aw;
             if (lane == 0) { rlog[3 * nr] = (i32)ga; rlog[3 * nr + 1] = (i32)cut; rlog[3 * nr + 2] = 1; }
             nr++;
@@ -754,7 +766,7 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
         } else {
             if (cut == gb) { leftover = true; break; }
 #pragma unroll
-            for (int s = 0; s < RR_SLOTS; s++) { rh_ss[s] += b_ss[s]; rh_s[s] += b_s[s]; }
+            for (int s = 0; s < NS; s++) { rh_ss[s] += b_ss[s]; rh_s[s] += b_s[s]; }
             rh_w += bw;
             if (lane == 0) { rlog[3 * nr] = (i32)cut; rlog[3 * nr + 1] = (i32)gb; rlog[3 * nr + 2] = 2; }
             nr++;
@@ -777,7 +789,7 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
     const double vlow = -fsum(zero_ss, zero_s, 0.0, a_ss, a_s, aw), vhigh = -fsum(zero_ss, zero_s, 0.0, b_ss, b_s, bw);
     // the children's weighted means (matrix_w_mean, :71-81) are the same column sums: sum w x / sum w
 #pragma unroll
-    for (int s = 0; s < RR_SLOTS; s++) {
+    for (int s = 0; s < NS; s++) {
         const i64 c = lane + 64 * s;
         if (c < d) {
             cmeans[(2 * t) * d + c] = a_s[s] / aw;
@@ -796,8 +808,15 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
                   i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals, double *cmeans) {
     if (d > 64 * RR_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * RR_SLOTS);
     ScopedKernelTimer t(c, "rss_rounds");
-    hipLaunchKernelGGL(rss_rounds_kernel, dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, zs,
-                       task_row_off, task_chunk_off, prefix, coff, d, meta, rounds, vals, cmeans);
+    const dim3 grid((unsigned)n_tasks), block(64);
+#define CGE_RR_LAUNCH(NS)                                                                                              \
+    hipLaunchKernelGGL((rss_rounds_kernel<NS>), grid, block, 0, c->stream, Xr, vw, srows, zs, task_row_off, task_chunk_off, \
+                       prefix, coff, d, meta, rounds, vals, cmeans)
+    if (d <= 64) CGE_RR_LAUNCH(1);
+    else if (d <= 128) CGE_RR_LAUNCH(2);
+    else if (d <= 256) CGE_RR_LAUNCH(4);
+    else CGE_RR_LAUNCH(8);
+#undef CGE_RR_LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------------
