@@ -455,6 +455,7 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
 // rounds (:184-185, :201-202) and for the children's total_rss (:269).  Rows with side 0 are skipped.
 // Fixed order: rows of a chunk are dealt to the 4 waves round-robin, waves and chunks combined in order.
 #define SS_SLOTS 8 // columns per lane: d <= 512
+template <int NS> // NS = columns per lane actually used (d <= 64*NS)
 __global__ __launch_bounds__(256) void group_side_sums_partial_kernel(const double *__restrict__ Xr,
                                                                       const double *__restrict__ vw,
                                                                       const i32 *__restrict__ rows,
@@ -471,26 +472,30 @@ __global__ __launch_bounds__(256) void group_side_sums_partial_kernel(const doub
     for (int q = 0; q < 2; q++)
 #pragma unroll
         for (int t = 0; t < SS_SLOTS; t++) { ss[q][t] = 0.0; s1[q][t] = 0.0; }
-    for (i32 j = beg + wave; j < end; j += 4) {
-        const int sd = side[j]; // wave-uniform
-        if (sd == 0) continue;
-        const i64 v = rows[j];
-        const double w = vw[v];
-        const double *x = Xr + v * d;
-        if (sd == 1) {
-            ws[0] += w;
+    constexpr int RF = NS <= 2 ? 4 : NS <= 4 ? 2 : 1; // rows in flight per wave; the additions keep the row order
+    for (i32 j0 = beg + wave; j0 < end; j0 += 4 * RF) {
+        int sd[RF];
+        double w[RF], xv[RF][NS];
 #pragma unroll
-            for (int t = 0; t < SS_SLOTS; t++) {
-                const i64 col = lane + 64 * t;
-                if (col < d) { const double xv = x[col]; ss[0][t] += w * (xv * xv); s1[0][t] += w * xv; }
-            }
-        } else {
-            ws[1] += w;
+        for (int u = 0; u < RF; u++) {
+            const i32 j = j0 + 4 * u;
+            sd[u] = j < end ? side[j] : 0; // wave-uniform
+            const i64 v = rows[j < end ? j : beg];
+            w[u] = vw[v];
+            const double *x = Xr + v * d;
 #pragma unroll
-            for (int t = 0; t < SS_SLOTS; t++) {
+            for (int t = 0; t < NS; t++) {
                 const i64 col = lane + 64 * t;
-                if (col < d) { const double xv = x[col]; ss[1][t] += w * (xv * xv); s1[1][t] += w * xv; }
+                xv[u][t] = (col < d) ? x[col] : 0.0;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < RF; u++) {
+            if (sd[u] == 0) continue;
+            const int q = sd[u] == 1 ? 0 : 1;
+            ws[q] += w[u];
+#pragma unroll
+            for (int t = 0; t < NS; t++) { ss[q][t] += w[u] * (xv[u][t] * xv[u][t]); s1[q][t] += w[u] * xv[u][t]; }
         }
     }
     double *out = part + ch * 2 * (2 * d + 1);
@@ -530,8 +535,14 @@ void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32
                        i64 d, double *part, double *out) {
     if (d > 64 * SS_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * SS_SLOTS);
     ScopedKernelTimer t(c, "group_side_sums");
-    hipLaunchKernelGGL(group_side_sums_partial_kernel, dim3((unsigned)n_chunks), dim3(256), 0, c->stream, Xr, vw, rows,
-                       side, chunk_beg, chunk_end, d, part);
+    const dim3 grid((unsigned)n_chunks), block(256);
+#define CGE_SS_LAUNCH(NS) \
+    hipLaunchKernelGGL((group_side_sums_partial_kernel<NS>), grid, block, 0, c->stream, Xr, vw, rows, side, chunk_beg, chunk_end, d, part)
+    if (d <= 64) CGE_SS_LAUNCH(1);
+    else if (d <= 128) CGE_SS_LAUNCH(2);
+    else if (d <= 256) CGE_SS_LAUNCH(4);
+    else CGE_SS_LAUNCH(8);
+#undef CGE_SS_LAUNCH
     hipLaunchKernelGGL(group_side_sums_final_kernel, dim3((unsigned)n_tasks), dim3(256), 0, c->stream, part,
                        task_chunk_off, 2 * (2 * d + 1), out);
 }
