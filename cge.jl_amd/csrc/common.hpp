@@ -253,7 +253,7 @@ struct cge_ctx {
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
     bool fit_persistent_broken = false; // a grid barrier timed out once (e.g. another process holds CUs): not tried again // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
     DevBuf<i32> sw_cm_off, sw_cm_mem, sw_cm_pos; // community -> members CSR of the score graph and its inverse
-    DevBuf<double> sw_zeros;
+    DevBuf<double> sw_zeros, sw_zsum;
     // diameter scratch
     DevBuf<double> mp_recs;  // MaxRec records (3 doubles each)
     DevBuf<i64> mp_count;

@@ -276,7 +276,7 @@ void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, 
 
 // ------------------------------------------------------------------------------------------------
 // vect_B.  Stage 1: rowbins[i][c] = sum over the members j of community c (ascending; j >= i when
-// undirected) of (Ta_i*Tb_j)*GD_ij.  Stage 2: sum the rows of each community into the bins.
+// undirected) of (Ta_i*Tb_j)*GD_ij.  Stage 2: sum the rows of each community, then fold the two orientations.
 // The row is streamed once, coalesced, into LDS as the products (Ta_i*Tb_j)*GD_ij (only j >= i when undirected),
 // each product stored at the position of j in the community-sorted member list (cm_pos = the inverse of cm_mem):
 // the sum of community c is then a contiguous LDS range in member (= ascending j) order -- the same additions in the
@@ -318,17 +318,26 @@ __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict
         rowbins[i * C + cc] = s;
     }
 }
-__global__ void bvec_bins_kernel(const double *__restrict__ rowbins, const i32 *__restrict__ cm_off,
-                                 const i32 *__restrict__ cm_mem, i64 C, int directed, double *__restrict__ vectB) {
+// Stage 2a: Z[c1][c2] = sum over the members i of community c1 (ascending) of rowbins[i][c2] -- whole rows of
+// rowbins, coalesced.  Stage 2b: vect_B[c1, c2] = Z[c1][c2] + Z[c2][c1] for c1 < c2 (both orientations of an
+// unordered community pair), Z[c1][c1] on the diagonal; the directed vector is Z itself.
+__global__ __launch_bounds__(256) void bvec_zsum_kernel(const double *__restrict__ rowbins, const i32 *__restrict__ cm_off,
+                                                        const i32 *__restrict__ cm_mem, i64 C, double *__restrict__ Z) {
+    const i64 c1 = blockIdx.x;
+    const i32 b = cm_off[c1], e = cm_off[c1 + 1];
+    for (i64 c2 = threadIdx.x; c2 < C; c2 += 256) {
+        double s = 0.0;
+        for (i32 t = b; t < e; t++) s += rowbins[(i64)cm_mem[t] * C + c2];
+        Z[c1 * C + c2] = s;
+    }
+}
+__global__ void bvec_fold_kernel(const double *__restrict__ Z, i64 C, int directed, double *__restrict__ vectB) {
     const i64 total = C * C, stride = (i64)gridDim.x * blockDim.x;
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const i64 c1 = e / C, c2 = e - c1 * C;
-        if (!directed && c2 < c1) continue;
-        double s = 0.0;
-        for (i32 t = cm_off[c1]; t < cm_off[c1 + 1]; t++) s += rowbins[(i64)cm_mem[t] * C + c2];
-        if (!directed && c1 != c2)
-            for (i32 t = cm_off[c2]; t < cm_off[c2 + 1]; t++) s += rowbins[(i64)cm_mem[t] * C + c1];
-        vectB[directed ? e : (C * c1 - c1 * (c1 - 1) / 2 + (c2 - c1))] = s;
+        if (directed) { vectB[e] = Z[e]; continue; }
+        if (c2 < c1) continue;
+        vectB[C * c1 - c1 * (c1 - 1) / 2 + (c2 - c1)] = (c1 == c2) ? Z[e] : Z[e] + Z[c2 * C + c1];
     }
 }
 void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_pos, const i32 *cm_off,
@@ -340,8 +349,10 @@ void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, co
     else
         hipLaunchKernelGGL((bvec_rows_kernel<false>), dim3((unsigned)N), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off,
                            cm_mem, cm_pos, N, C, directed, rowbins);
-    hipLaunchKernelGGL(bvec_bins_kernel, dim3(grid_for(C * C, 256)), dim3(256), 0, c->stream, rowbins, cm_off, cm_mem,
-                       C, directed, vectB);
+    c->sw_zsum.ensure((size_t)C * C);
+    hipLaunchKernelGGL(bvec_zsum_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, rowbins, cm_off, cm_mem, C, c->sw_zsum.p);
+    hipLaunchKernelGGL(bvec_fold_kernel, dim3(grid_for(C * C, 256)), dim3(256), 0, c->stream, c->sw_zsum.p, C, directed,
+                       vectB);
 }
 
 // ------------------------------------------------------------------------------------------------
