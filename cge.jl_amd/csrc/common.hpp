@@ -248,6 +248,7 @@ struct cge_ctx {
     DevBuf<int> fp_flags;
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it
                                 // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
+    int opt_speculation_pct = 40;  // global phase: share of the still missing pops that one round may split speculatively
     int opt_fit_test_timeout = 0; // testing: the persistent fit gives up at once, so the fallback path runs
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)

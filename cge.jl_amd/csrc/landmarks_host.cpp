@@ -958,6 +958,20 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
                     if (g->value <= thr || g == h.top()) keep.push_back(g);
                 frontier.swap(keep);
             }
+            // Every candidate COULD be popped, but a good half of a large frontier never is (its competitors' children
+            // outrank it).  Splitting only the most valuable part per round costs a round or two more and saves the
+            // eigen-problems of the rest; what is left over is reconsidered, with more known, in the next round.
+            // (never fewer than 256 at a time: the last pops would otherwise trickle through many tiny rounds)
+            const i64 take = std::max<i64>(std::min<i64>(remaining, 256), (i64)((double)remaining * c->opt_speculation_pct / 100.0));
+            if ((i64)frontier.size() > take) {
+                std::nth_element(frontier.begin(), frontier.begin() + (take - 1), frontier.end(),
+                                 [](const Group *a, const Group *b) { return a->value < b->value; });
+                const double cut = frontier[take - 1]->value;
+                std::vector<Group *> keep;
+                for (Group *g : frontier)
+                    if (g->value <= cut || g == h.top()) keep.push_back(g);
+                frontier.swap(keep);
+            }
             batch.insert(batch.end(), frontier.begin(), frontier.end());
         }
         delete ph;
