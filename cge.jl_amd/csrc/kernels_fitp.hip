@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void fit_dataflow_dir_kernel(const double *__r
 
 } // namespace
 
-static hipError_t hipModuleLaunchKernelCompat(const void *fn, int G, void **args, size_t lds, hipStream_t st) {
+static hipError_t launch_plain(const void *fn, int G, void **args, size_t lds, hipStream_t st) {
     return hipLaunchKernel(fn, dim3((unsigned)G), dim3(256), args, lds, st);
 }
 
@@ -669,7 +669,7 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
             (void)hipGetLastError();
             return false;
         }
-        const hipError_t e = hipModuleLaunchKernelCompat(fn, G, args, dataflow ? 0 : lds, st);
+        const hipError_t e = launch_plain(fn, G, args, dataflow ? 0 : lds, st);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             return false;
@@ -733,7 +733,7 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
         (void)hipGetLastError();
         return false;
     }
-    if (hipModuleLaunchKernelCompat(fn, G, args, 0, st) != hipSuccess) {
+    if (launch_plain(fn, G, args, 0, st) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
