@@ -331,6 +331,41 @@ def test_fit_persistent_directed_matches_stepwise_and_oracle(ctx, orc, n):
     _cmp_result(r2, exp, t2, etr)
 
 
+def test_fit_persistent_handoffs_under_varied_geometry(ctx):
+    """The cross-workgroup hand-offs of the persistent fits (partial vectors, iterates, maxima through write-through
+    stores and dependency counters) on many grid geometries -- from a handful of workgroups to every CU with two tile
+    slots per wave, ragged last tiles, undirected and directed: a stale read anywhere would change an iterate, hence
+    an iteration count or a score; both must equal the launch-per-iteration path, run after run."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    for n, directed in [(513, False), (640, True), (1000, False), (1337, True), (2049, False), (3100, False),
+                        (3977, False), (2500, True)]:
+        g = synth.abcd_like(n, 5 * n, max(2, n // 80), 6, seed=3 * n + 1, directed=directed)
+        ctx.set_graph(g["edges"], g["eweights"], n)
+        if directed:
+            p1, ni, nj = api.draw_samples(ctx, 5, 1000, directed=True)
+            smp = (p1, ni, nj, p1)
+            fn = cg.wGCL_directed
+        else:
+            smp = api.draw_samples(ctx, 5, 1000)
+            fn = cg.wGCL
+        args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
+        try:
+            ctx.set_option("fit_persistent", 1)
+            ref, tref = fn(*args, samples=smp, trace=True, ctx=ctx)
+            ctx.set_option("fit_persistent", 2)
+            runs = [fn(*args, samples=smp, trace=True, ctx=ctx) for _ in range(3)]
+            assert ctx.get_stat("fit_persistent_alphas") > 0
+        finally:
+            ctx.set_option("fit_persistent", 0)
+        for res, tr in runs:
+            assert tr["iters"] == tref["iters"], (n, directed)
+            assert np.array_equal(res, runs[0][0]), (n, directed)  # bitwise reproducible
+            assert np.allclose(res, ref, rtol=1e-10, atol=1e-13), (n, directed)
+
+
 def test_fit_persistent_abandoned_launch_falls_back(ctx):
     """A persistent launch that gives up (here: forced through the testing option; in production a wait that timed
     out) leaves T untouched for the host, which restores it and fits the alpha with one launch per iteration."""
