@@ -3,10 +3,10 @@
 
 What is sharded:
   * the per-edge scatter: rank r takes the edge rows [m*r/W, m*(r+1)/W); one all-reduce(sum) of the
-    N x N landmark-pair matrix and one of vect_C;
+    C x C cluster-pair vector vect_C (and of the N x N landmark-pair matrix when `landmarks_fetch` asks for it);
   * the point-set diameter: rank r takes the super-block rows SI = r (mod W); one all-reduce(max) of a scalar;
 and what is replicated: runsplit (bit-identical on every rank) and the alpha sweep (sequentially
-dependent, cache-resident).  No other collective is issued.
+dependent iterations of a register-resident persistent fit that already uses every CU).  No other collective is issued.
 """
 from __future__ import annotations
 
