@@ -280,7 +280,7 @@ struct cge_ctx {
     PinBuf<double> pin_sums, pin_z, pin_params, pin_zs, pin_means, pin_cmeans;
     PinBuf<i32> pin_rows[2], pin_row_task[2], pin_srows; // [slot]: 0 = main batch, 1 = fallback sub-batch
     // sorted-prefix rss path
-    DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro, sp_perm, sp_status, sort_idx, sort_keys32, sort_cnt;
+    DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro, sp_perm, sp_status, sort_idx, sort_idx2, sort_keys32, sort_k32b, sort_cnt;
     DevBuf<unsigned char> sort_keys8;
     // member lists of the landmark phase: a group is a range of this arena (vertex ids, reference order)
     DevBuf<i32> lm_arena;

@@ -34,18 +34,61 @@ __global__ void sort_status_kernel(const double *__restrict__ zs, const i32 *__r
     status[t] = st;
 }
 
+// helpers of the two-pass form
+__global__ void iota_kernel(i32 *__restrict__ x, i64 n);
+__global__ void gather_task_keys_kernel(const i32 *__restrict__ pos, const i32 *__restrict__ row_task, i64 R,
+                                        unsigned *__restrict__ keys) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < R) keys[j] = (unsigned)row_task[pos[j]];
+}
+__global__ void finish_two_pass_kernel(const i32 *__restrict__ pos, const double *__restrict__ z,
+                                       const i32 *__restrict__ row_task, const i32 *__restrict__ task_row_off, i64 R,
+                                       double *__restrict__ zs, i32 *__restrict__ perm) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    const i32 p = pos[j];
+    zs[j] = z[p];
+    perm[j] = p - task_row_off[row_task[p]];
+}
 void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 *row_task, const i32 *task_row_off,
                         i64 R, i64 T, double *zs, i32 *perm, i32 *srows, i32 *status) {
     ScopedKernelTimer tm(c, "segmented_sort");
     c->sort_idx.ensure(R);
     const unsigned nb = (unsigned)((R + 255) / 256);
-    hipLaunchKernelGGL(iota_local_kernel, dim3(nb), dim3(256), 0, c->stream, row_task, task_row_off, R, c->sort_idx.p);
-    size_t bytes = 0;
-    HIP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, bytes, z, zs, c->sort_idx.p, perm, (unsigned)R, (unsigned)T,
-                                                  task_row_off, task_row_off + 1, 0, 64, c->stream));
-    c->sort_tmp.ensure(bytes);
-    HIP_CHECK(rocprim::segmented_radix_sort_pairs(c->sort_tmp.p, bytes, z, zs, c->sort_idx.p, perm, (unsigned)R,
-                                                  (unsigned)T, task_row_off, task_row_off + 1, 0, 64, c->stream));
+    if (R / std::max<i64>(T, 1) >= 768) {
+        // Few long segments: the segmented sort walks each of them alone through all its radix passes.  Two device-wide
+        // stable sorts do the same job at full occupancy: all rows by z, then (stably) by task.
+        c->sort_keys32.ensure(R);
+        c->sort_idx2.ensure(R);
+        c->sort_k32b.ensure(R);
+        hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, c->stream, c->sort_idx.p, R);
+        size_t bytes = 0;
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, z, zs, c->sort_idx.p, c->sort_idx2.p, (size_t)R, 0, 64, c->stream));
+        c->sort_tmp.ensure(bytes);
+        HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, z, zs, c->sort_idx.p, c->sort_idx2.p, (size_t)R, 0, 64,
+                                            c->stream));
+        hipLaunchKernelGGL(gather_task_keys_kernel, dim3(nb), dim3(256), 0, c->stream, c->sort_idx2.p, row_task, R,
+                           (unsigned *)c->sort_keys32.p);
+        int bits = 1;
+        while (((i64)1 << bits) < T) bits++;
+        bytes = 0;
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned *)c->sort_keys32.p, (unsigned *)c->sort_k32b.p,
+                                            c->sort_idx2.p, c->sort_idx.p, (size_t)R, 0, bits, c->stream));
+        c->sort_tmp.ensure(bytes);
+        HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, (const unsigned *)c->sort_keys32.p,
+                                            (unsigned *)c->sort_k32b.p, c->sort_idx2.p, c->sort_idx.p, (size_t)R, 0, bits,
+                                            c->stream));
+        hipLaunchKernelGGL(finish_two_pass_kernel, dim3(nb), dim3(256), 0, c->stream, c->sort_idx.p, z, row_task,
+                           task_row_off, R, zs, perm);
+    } else {
+        hipLaunchKernelGGL(iota_local_kernel, dim3(nb), dim3(256), 0, c->stream, row_task, task_row_off, R, c->sort_idx.p);
+        size_t bytes = 0;
+        HIP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, bytes, z, zs, c->sort_idx.p, perm, (unsigned)R, (unsigned)T,
+                                                      task_row_off, task_row_off + 1, 0, 64, c->stream));
+        c->sort_tmp.ensure(bytes);
+        HIP_CHECK(rocprim::segmented_radix_sort_pairs(c->sort_tmp.p, bytes, z, zs, c->sort_idx.p, perm, (unsigned)R,
+                                                      (unsigned)T, task_row_off, task_row_off + 1, 0, 64, c->stream));
+    }
     hipLaunchKernelGGL(sorted_gather_kernel, dim3(nb), dim3(256), 0, c->stream, rows, row_task, task_row_off, perm, R, srows);
     hipLaunchKernelGGL(sort_status_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, c->stream, zs, task_row_off, T,
                        status);
