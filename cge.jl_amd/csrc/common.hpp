@@ -277,8 +277,8 @@ struct cge_ctx {
     DevBuf<double> ls_part, ls_mean, ls_sw, ls_cov, ls_vec, ls_z, ls_sums;
     DevBuf<unsigned char> ls_side, ls_state;
     DevBuf<double> ls_params; // per-task round parameters of the rss rule
-    PinBuf<double> pin_sums, pin_z, pin_params, pin_zs, pin_means, pin_cmeans;
-    PinBuf<i32> pin_rows[2], pin_row_task[2], pin_srows; // [slot]: 0 = main batch, 1 = fallback sub-batch
+    PinBuf<double> pin_sums, pin_params, pin_cmeans;
+    PinBuf<i32> pin_rows[2], pin_row_task[2]; // [0]: cluster upload staging, [1]: rows of a host-built (generic rss path) batch
     // sorted-prefix rss path
     DevBuf<i32> sp_srows, sp_meta, sp_rounds, sp_tro, sp_perm, sp_status, sort_idx, sort_idx2, sort_keys32, sort_k32b, sort_cnt;
     DevBuf<unsigned char> sort_keys8;
@@ -293,9 +293,8 @@ struct cge_ctx {
     DevBuf<unsigned char> ls_keys;
     PinBuf<i32> pin_small;
     DevBuf<unsigned char> sort_tmp;
-    PinBuf<i32> pin_perm;
-    PinBuf<unsigned char> pin_side;
-    DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals, sp_cmeans;
+
+    DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;
 
     // ---- profiling -------------------------------------------------------------------------
     bool profiling = false;
@@ -421,9 +420,6 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
                           const double *deg_out, double eps0, double f0, double delta, i64 *iters);
 void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
                 double delta, int k, unsigned long long *fring, int *done, int *iters);
-void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done);
-void k_fit_update(cge_ctx *c, double *T, const double *S, const double *w, i64 N, double eps, double delta, int *done,
-                  int *iters, double *fout);
 void k_fit_symv_dir(cge_ctx *c, const double *GD, const double *Tin, const double *Tout, i64 N, double *Sin,
                     double *Sout, const int *done);
 void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, const double *Sout,

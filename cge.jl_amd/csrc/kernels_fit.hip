@@ -1,6 +1,7 @@
 // kernels_fit.hip -- the alpha sweep on the device.
 //   k_pow_matrix     GD = (1 - D)^alpha                               src/divergence.jl:142-148 (:426-432)
-//   k_fit_symv/_update       Chung-Lu fixed point, undirected         src/divergence.jl:150-168
+//   k_fit_step               one Chung-Lu iteration, undirected       src/divergence.jl:150-168
+//                            (the launch-per-iteration fallback of the persistent fit, kernels_fitp.hip)
 //   k_fit_symv_dir/_update_dir  directed (Tin/Tout, adaptive eps)     src/divergence.jl:434-467
 //   k_bvec           vect_B = community-pair sums of P                src/divergence.jl:226-234 (:530-538)
 //   k_js             JS(vect_C, vect_B[, vI])                         src/auxilary.jl:34-52
@@ -53,44 +54,11 @@ void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// S_i = sum_j (T_i*T_j)*GD_ij  (full symmetric GD: the diagonal is counted once, as :153-159).
-// One workgroup per row; every kernel of a fit returns at once when *done is set, so the host can
-// enqueue iterations in batches and still stop exactly at the reference's iteration.
-// One wave per row, 16-byte loads, shuffle reduction (fixed lane pattern => reproducible); 4 rows per workgroup.
+// S_i = sum_j (T_i*T_j)*GD_ij  (full symmetric GD: the diagonal is counted once, as :153-159).  One wave per row,
+// 16-byte loads, shuffle reduction (fixed lane pattern => reproducible); 4 rows per workgroup.  Every launch of a fit
+// returns at once when *done is set, so the host can enqueue iterations in batches and still stop exactly at the
+// reference's iteration.
 typedef double dbl2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void fit_symv_kernel(const double *__restrict__ GD, const double *__restrict__ T,
-                                                       i64 N, double *__restrict__ S, const int *__restrict__ done) {
-    if (*done) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const i64 i = (i64)blockIdx.x * 4 + wave;
-    if (i >= N) return;
-    const double ti = T[i];
-    const double *row = GD + i * N;
-    double s0 = 0.0, s1 = 0.0;
-    if ((N & 1) == 0) { // rows are 16-B aligned
-        const i64 n2 = N >> 1;
-        const dbl2 *row2 = reinterpret_cast<const dbl2 *>(row);
-        const dbl2 *T2 = reinterpret_cast<const dbl2 *>(T);
-        i64 k = lane;
-        for (; k + 192 < n2; k += 256) { // 4 independent 16-B loads in flight per operand
-            const dbl2 g0 = row2[k], g1 = row2[k + 64], g2 = row2[k + 128], g3 = row2[k + 192];
-            const dbl2 t0 = T2[k], t1 = T2[k + 64], t2 = T2[k + 128], t3 = T2[k + 192];
-            s0 += (ti * t0.x) * g0.x; s1 += (ti * t0.y) * g0.y;
-            s0 += (ti * t1.x) * g1.x; s1 += (ti * t1.y) * g1.y;
-            s0 += (ti * t2.x) * g2.x; s1 += (ti * t2.y) * g2.y;
-            s0 += (ti * t3.x) * g3.x; s1 += (ti * t3.y) * g3.y;
-        }
-        for (; k < n2; k += 64) {
-            const dbl2 g0 = row2[k], t0 = T2[k];
-            s0 += (ti * t0.x) * g0.x; s1 += (ti * t0.y) * g0.y;
-        }
-    } else {
-        for (i64 j = lane; j < N; j += 64) s0 += (ti * T[j]) * row[j];
-    }
-    double s = s0 + s1;
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) S[i] = s;
-}
 // One whole Chung-Lu iteration per launch (undirected): S_i as above from T = Tin, then the update
 // Tout_i = T_i + eps*T_i*(w_i/S_i - 1) and f = max_i |w_i - S_i| (:160-166) in the epilogue -- no separate update
 // launch.  T is double-buffered by the caller (iteration k reads buf[k&1], writes buf[(k+1)&1]); f is an atomic
@@ -163,41 +131,6 @@ void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, c
     hipLaunchKernelGGL(fit_step_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, GD, Tin, Tout, w, N, eps,
                        delta, k, fring, done, iters);
 }
-void k_fit_symv(cge_ctx *c, const double *GD, const double *T, i64 N, double *S, const int *done) {
-    ScopedKernelTimer t(c, "fit_symv");
-    hipLaunchKernelGGL(fit_symv_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, GD, T, N, S, done);
-}
-// T_i += eps*T_i*(w_i/S_i - 1); f = max|w_i - S_i| with the pre-update S (:160-166)
-__global__ __launch_bounds__(1024) void fit_update_kernel(double *__restrict__ T, const double *__restrict__ S,
-                                                          const double *__restrict__ w, i64 N, double eps,
-                                                          double delta, int *__restrict__ done,
-                                                          int *__restrict__ iters, double *__restrict__ fout) {
-    __shared__ double sh[1024];
-    if (*done) return;
-    double f = 0.0;
-    for (i64 i = threadIdx.x; i < N; i += 1024) {
-        const double ti = T[i], si = S[i], wi = w[i];
-        const double move = (eps * ti) * (wi / si - 1.0);
-        T[i] = ti + move;
-        f = fmax(f, fabs(wi - si));
-    }
-    sh[threadIdx.x] = f;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *iters += 1;
-        *fout = sh[0];
-        if (!(sh[0] > delta)) *done = 1; // `while diff > delta`
-    }
-}
-void k_fit_update(cge_ctx *c, double *T, const double *S, const double *w, i64 N, double eps, double delta, int *done,
-                  int *iters, double *fout) {
-    hipLaunchKernelGGL(fit_update_kernel, dim3(1), dim3(1024), 0, c->stream, T, S, w, N, eps, delta, done, iters, fout);
-}
-
 // directed: Sin_i = sum_j (Tin_i*Tout_j)*g_ij + diagonal once more; Sout_i = sum_j (Tin_j*Tout_i)*g_ij + diagonal
 // once more (the reference's i..N inner loop visits j == i and adds both tmp1 and tmp2, :439-449)
 __global__ __launch_bounds__(256) void fit_symv_dir_kernel(const double *__restrict__ GD,
