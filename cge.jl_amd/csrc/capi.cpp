@@ -32,8 +32,8 @@ static void flush_timers(cge_ctx *c) {
             float ms = 0.f;
             (void)hipEventSynchronize(pr.second);
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.total_ms += ms;
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
         }
         kv.second.pending.clear();
     }
@@ -81,6 +81,8 @@ void cge_destroy(cge_ctx *c) {
     flush_timers(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    c->event_pool.clear();
     if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     delete c->pool;

@@ -188,6 +188,7 @@ struct cge_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    std::vector<hipEvent_t> event_pool; // recycled kernel-timer events
     hipStream_t copy_stream = nullptr; // device->host result copies that overlap the kernels queued behind them
     hipEvent_t copy_ev = nullptr, copy_done = nullptr;
     std::string err;
@@ -310,9 +311,19 @@ struct ScopedKernelTimer {
     ScopedKernelTimer(cge_ctx *ctx, const char *name) : c(ctx) {
         if (!c->profiling) return;
         t = &c->timers[name];
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
+        a = take_event();
+        b = take_event();
         (void)hipEventRecord(a, c->stream);
+    }
+    hipEvent_t take_event() { // events are recycled by flush_timers: no create/destroy in the timed region
+        if (!c->event_pool.empty()) {
+            hipEvent_t e = c->event_pool.back();
+            c->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
     }
     ~ScopedKernelTimer() {
         if (!t) return;
