@@ -343,6 +343,13 @@ def test_fit_persistent_handoffs_under_varied_geometry(ctx):
     for n, directed in [(513, False), (640, True), (1000, False), (1337, True), (2049, False), (3100, False),
                         (3977, False), (2500, True)]:
         g = synth.abcd_like(n, 5 * n, max(2, n // 80), 6, seed=3 * n + 1, directed=directed)
+        if n % 2 == 1 and not directed:  # weighted edges (dyadic: the per-edge scatter's float atomics stay exact, so
+            rng = np.random.default_rng(n)  # run-to-run bits can be compared), vertex weights = weighted degrees
+            g["eweights"] = rng.integers(1, 17, size=len(g["eweights"])) / 4.0
+            vw = np.zeros(n)
+            np.add.at(vw, g["edges"][:, 0] - 1, g["eweights"])
+            np.add.at(vw, g["edges"][:, 1] - 1, g["eweights"])
+            g["vweights"] = vw
         ctx.set_graph(g["edges"], g["eweights"], n)
         if directed:
             p1, ni, nj = api.draw_samples(ctx, 5, 1000, directed=True)
