@@ -289,6 +289,7 @@ struct cge_ctx {
     DevBuf<double> lm_means; // weighted means of groups, known from their parents' splits (d doubles each)
     i64 lm_means_used = 0;
     DevBuf<i64> ls_moff;
+    PinBuf<i64> pin_moff;
     bool lm_index_on_device = false; // lm_memoff / lm_mem mirror h_mem_off / h_mem (set by runsplit, cleared when the host rebuilds the index)
     DevBuf<i32> ls_toff, ls_nlow, lm_goff, lm_glen, lm_mem, lm_memoff; // task arena offsets, low-child counts, final groups, landmark index
     DevBuf<unsigned char> ls_keys;

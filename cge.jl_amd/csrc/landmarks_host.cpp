@@ -814,12 +814,12 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                 bool have_means = true;
                 for (i64 t = 0; t < T && have_means; t++) have_means = groups[t]->mean_off >= 0;
                 if (have_means) { // known from the parents' splits: gathered from the means arena, no pass over the rows
-                    std::vector<i64> moff(T);
+                    c->pin_moff.ensure(T); // pinned and owned by the ctx: no wait for the copy (the next batch's fill comes
+                    i64 *moff = c->pin_moff.p; // after at least one synchronisation of this batch)
                     for (i64 t = 0; t < T; t++) moff[t] = groups[t]->mean_off;
                     c->ls_moff.ensure(T);
-                    HIP_CHECK(hipMemcpyAsync(c->ls_moff.p, moff.data(), sizeof(i64) * T, hipMemcpyHostToDevice, st));
+                    HIP_CHECK(hipMemcpyAsync(c->ls_moff.p, moff, sizeof(i64) * T, hipMemcpyHostToDevice, st));
                     k_gather_means(c, c->lm_means.p, c->ls_moff.p, T, d, c->ls_mean.p);
-                    HIP_CHECK(hipStreamSynchronize(st)); // moff goes out of scope
                 } else
                     k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                                  c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
