@@ -943,7 +943,7 @@ int cge_host_pos_draw(int64_t seed, int64_t stream_id, int64_t S, int64_t m, int
 }
 int cge_group_eig(void *ctx, const double *A, int64_t T, int64_t d, double *v) {
     cge_ctx *c = (cge_ctx *)ctx;
-    if (!c || !A || !v || T <= 0 || d <= 0 || d > 128) return CGE_E_ARG;
+    if (!c || !A || !v || T <= 0 || d <= 0 || d > 512) return CGE_E_ARG;
     CGE_TRY(c)
     DevBuf<double> dA, dv;
     dA.ensure((size_t)T * d * d);

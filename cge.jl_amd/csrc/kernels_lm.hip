@@ -1462,8 +1462,276 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             if (lane + 64 * r < d) out[lane + 64 * r] = yv[r] * sg;
     }
 }
+// ---- the same solver for wider matrices (128 < d <= 512): the matrix stays in global memory (it is read and
+// written by one workgroup only, so it lives in that CU's L1/L2 path), the O(d) vectors in LDS.  Same algorithm and
+// conventions as above; thread j owns column j (and j + 256): for a fixed row the threads read consecutive addresses.
+// The covariance buffer is overwritten (row k keeps the reflector of step k right of the sub-diagonal).
+__device__ __forceinline__ double block_sum_256w(double v, double *red4) {
+    v = wave_allsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red4[0] + red4[1]) + red4[2]) + red4[3];
+}
+__global__ __launch_bounds__(256) void group_eig_wide_kernel(double *__restrict__ cov, int d, double *__restrict__ vec) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *V = sh, *W = V + d, *P = W + d, *beta = P + d, *diag = beta + d, *off = diag + d, *tri = off + d; // tri: 4*d
+    double *red = tri + 4 * d;                                                                                 // 32
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *A = cov + (size_t)blockIdx.x * d * d;
+    double *out = vec + (size_t)blockIdx.x * d;
+    for (int i = tid; i < d; i += 256) { beta[i] = 0.0; off[i] = 0.0; }
+    __syncthreads();
+    // ---- tridiagonalisation ------------------------------------------------------------------------
+    for (int k = 0; k + 2 < d; k++) {
+        const int r = d - k - 1, o = k + 1;
+        const double *xrow = A + (size_t)k * d + o; // x = A[k][o..]
+        double part = 0.0;
+        for (int i = tid; i < r; i += 256) {
+            const double xi = xrow[i];
+            if (i >= 1) part += xi * xi;
+        }
+        const double sigma = block_sum_256w(part, red);
+        const double alpha = xrow[0];
+        if (sigma == 0.0) { // uniform: no reflection needed
+            if (tid == 0) { beta[k] = 0.0; off[k] = alpha; }
+            __syncthreads();
+            continue;
+        }
+        const double mu = sqrt(alpha * alpha + sigma);
+        const double v0 = (alpha <= 0.0) ? alpha - mu : -sigma / (alpha + mu);
+        const double bk = 2.0 * v0 * v0 / (sigma + v0 * v0);
+        for (int i = tid; i < r; i += 256) V[i] = (i == 0) ? 1.0 : xrow[i] / v0;
+        if (tid == 0) { beta[k] = bk; off[k] = mu; }
+        __syncthreads();
+        const double *B = A + (size_t)o * d + o; // B[i][j] = B[i*d + j], i, j < r
+        for (int j = tid; j < r; j += 256) { // p = bk * B v (B symmetric: column sums, coalesced along rows)
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int i = 0;
+            for (; i + 7 < r; i += 8) {
+                const double a0 = B[(size_t)(i + 0) * d + j], a1 = B[(size_t)(i + 1) * d + j], a2 = B[(size_t)(i + 2) * d + j],
+                             a3 = B[(size_t)(i + 3) * d + j], a4 = B[(size_t)(i + 4) * d + j], a5 = B[(size_t)(i + 5) * d + j],
+                             a6 = B[(size_t)(i + 6) * d + j], a7 = B[(size_t)(i + 7) * d + j];
+                s0 += a0 * V[i + 0]; s1 += a1 * V[i + 1]; s2 += a2 * V[i + 2]; s3 += a3 * V[i + 3];
+                s0 += a4 * V[i + 4]; s1 += a5 * V[i + 5]; s2 += a6 * V[i + 6]; s3 += a7 * V[i + 7];
+            }
+            for (; i < r; i++) s0 += B[(size_t)i * d + j] * V[i];
+            P[j] = bk * ((s0 + s1) + (s2 + s3));
+        }
+        __syncthreads();
+        part = 0.0;
+        for (int i = tid; i < r; i += 256) part += P[i] * V[i];
+        const double K = 0.5 * bk * block_sum_256w(part, red);
+        for (int i = tid; i < r; i += 256) W[i] = P[i] - K * V[i];
+        __syncthreads();
+        for (int j = tid; j < r; j += 256) { // B -= v w^T + w v^T
+            const double vj = V[j], wj = W[j];
+            double *col = const_cast<double *>(B) + j;
+            int i = 0;
+            for (; i + 7 < r; i += 8) {
+                double a[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) a[q] = col[(size_t)(i + q) * d];
+#pragma unroll
+                for (int q = 0; q < 8; q++) col[(size_t)(i + q) * d] = a[q] - (V[i + q] * wj + W[i + q] * vj);
+            }
+            for (; i < r; i++) col[(size_t)i * d] -= V[i] * wj + W[i] * vj;
+        }
+        for (int i = tid + 1; i < r; i += 256) A[(size_t)k * d + o + i] = V[i]; // keep the reflector in row k (v[0] = 1 implicit)
+        __syncthreads();
+    }
+    for (int i = tid; i < d; i += 256) diag[i] = A[(size_t)i * d + i];
+    if (tid == 0) off[d - 2] = A[(size_t)(d - 2) * d + (d - 1)];
+    __syncthreads();
+    // ---- Gershgorin bounds ---------------------------------------------------------------------------
+    double glo = 1e300, ghi = -1e300, gn = 0.0;
+    for (int i = tid; i < d; i += 256) {
+        const double rad = (i > 0 ? fabs(off[i - 1]) : 0.0) + (i + 1 < d ? fabs(off[i]) : 0.0);
+        glo = fmin(glo, diag[i] - rad);
+        ghi = fmax(ghi, diag[i] + rad);
+        gn = fmax(gn, fabs(diag[i]) + rad);
+    }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        glo = fmin(glo, __shfl_xor(glo, o2));
+        ghi = fmax(ghi, __shfl_xor(ghi, o2));
+        gn = fmax(gn, __shfl_xor(gn, o2));
+    }
+    double *gs = red + 8;
+    if (lane == 0) { gs[wv * 3] = glo; gs[wv * 3 + 1] = ghi; gs[wv * 3 + 2] = gn; }
+    __syncthreads();
+    glo = fmin(fmin(gs[0], gs[3]), fmin(gs[6], gs[9]));
+    ghi = fmax(fmax(gs[1], gs[4]), fmax(gs[7], gs[10]));
+    gn = fmax(fmax(gs[2], gs[5]), fmax(gs[8], gs[11]));
+    const double tiny = fmax(gn, 2.2250738585072014e-308) * 2.220446049250313e-16;
+    // ---- largest eigenvalue: 64-way multisection on the Sturm count (wave 0) ------------------------------
+    if (tid < 64) {
+        double lo = glo, hi = ghi + tiny;
+        for (int it = 0; it < 64; it++) {
+            const double x = lo + (hi - lo) * ((double)(tid + 1) / 65.0);
+            int cnt = 0;
+            double q = diag[0] - x;
+            if (q < 0) cnt++;
+            for (int i = 1; i < d; i++) {
+                if (q == 0.0) q = tiny;
+                q = diag[i] - x - (off[i - 1] * off[i - 1]) * fast_rcp(q);
+                if (q < 0) cnt++;
+            }
+            const unsigned long long mask = __ballot(cnt >= d);
+            double nlo, nhi;
+            if (mask == 0ULL) {
+                nlo = __shfl(x, 63);
+                nhi = hi;
+            } else {
+                const int f = __ffsll((long long)mask) - 1;
+                nhi = __shfl(x, f);
+                nlo = (f > 0) ? __shfl(x, f - 1) : lo;
+            }
+            if (!(nhi > nlo) || (nlo == lo && nhi == hi)) break;
+            lo = fmax(lo, nlo);
+            hi = fmin(hi, nhi);
+        }
+        if (tid == 0) red[4] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    // ---- inverse iteration (lane 0 of wave 0 runs the recurrences, the wave the element-wise parts) -----------------
+    if (wv == 0) {
+        const double lam = red[4];
+        double *dl = tri, *dd = tri + d, *du = tri + 2 * d, *du2 = tri + 3 * d;
+        double *y = V;
+        unsigned char *swp = reinterpret_cast<unsigned char *>(W); // pivot flags
+        for (int i = lane; i < d; i += 64) {
+            dd[i] = diag[i] - lam;
+            dl[i] = du[i] = (i + 1 < d) ? off[i] : 0.0;
+            du2[i] = 0.0;
+            swp[i] = 0;
+            y[i] = 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) { // LU with partial pivoting of the shifted tridiagonal matrix
+            double di = dd[0], ui = du[0];
+            for (int i = 0; i + 1 < d; i++) {
+                const double li = dl[i], dn = dd[i + 1], un = du[i + 1];
+                if (fabs(di) >= fabs(li)) {
+                    if (di == 0.0) di = tiny;
+                    const double f = li * fast_rcp(di);
+                    dd[i] = di;
+                    dl[i] = f;
+                    du[i] = ui;
+                    di = dn - f * ui;
+                    ui = un;
+                } else {
+                    const double f = di * fast_rcp(li);
+                    dd[i] = li;
+                    dl[i] = f;
+                    du[i] = dn;
+                    di = ui - f * dn;
+                    if (i + 2 < d) du2[i] = un;
+                    ui = -f * un;
+                    swp[i] = 1;
+                }
+            }
+            if (di == 0.0) di = tiny;
+            dd[d - 1] = di;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < d; i += 64) dd[i] = fast_rcp(dd[i]);
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < 3; it++) {
+            if (lane == 0) {
+                double yi = y[0];
+                for (int i = 0; i + 1 < d; i++) {
+                    const bool sw = swp[i] != 0;
+                    const double yn = y[i + 1], li = dl[i];
+                    y[i] = sw ? yn : yi;
+                    yi = sw ? yi - li * yn : yn - li * yi;
+                }
+                double y1 = yi * dd[d - 1];
+                y[d - 1] = y1;
+                double y0 = (y[d - 2] - du[d - 2] * y1) * dd[d - 2];
+                y[d - 2] = y0;
+                for (int i = d - 3; i >= 0; i--) {
+                    const double t = (y[i] - du[i] * y0 - du2[i] * y1) * dd[i];
+                    y[i] = t;
+                    y1 = y0;
+                    y0 = t;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            double amax = 0.0;
+            for (int i = lane; i < d; i += 64) amax = fmax(amax, fabs(y[i]));
+            for (int o2 = 32; o2 > 0; o2 >>= 1) amax = fmax(amax, __shfl_xor(amax, o2));
+            if (!(amax > 0.0) || !(amax < 1e300)) {
+                for (int i = lane; i < d; i += 64) y[i] = (i == 0) ? 1.0 : 0.0;
+                __builtin_amdgcn_wave_barrier();
+                break;
+            }
+            const double ra = 1.0 / amax;
+            double part = 0.0;
+            for (int i = lane; i < d; i += 64) { const double t = y[i] * ra; part += t * t; }
+            const double rn = ra / sqrt(wave_allsum(part));
+            for (int i = lane; i < d; i += 64) y[i] *= rn;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    // ---- back-transformation x = H_0 H_1 ... H_{d-3} y ------------------------------------------------------------
+    for (int k = d - 3; k >= 0; k--) {
+        const double bk = beta[k];
+        if (bk == 0.0) continue; // uniform
+        const int r = d - k - 1, o = k + 1;
+        double part = 0.0;
+        for (int i = tid; i < r; i += 256) {
+            const double vk = (i == 0) ? 1.0 : A[(size_t)k * d + o + i];
+            part += vk * V[o + i];
+        }
+        const double sc = bk * block_sum_256w(part, red);
+        for (int i = tid; i < r; i += 256) {
+            const double vk = (i == 0) ? 1.0 : A[(size_t)k * d + o + i];
+            V[o + i] -= sc * vk;
+        }
+        __syncthreads();
+    }
+    // normalise; sign: the component of largest magnitude (the first one on ties) is positive
+    double part = 0.0, best = -1.0;
+    int bi = 0;
+    for (int i = tid; i < d; i += 256) {
+        const double t = V[i];
+        part += t * t;
+        if (fabs(t) > best) { best = fabs(t); bi = i; }
+    }
+    double nrm = sqrt(block_sum_256w(part, red));
+    const bool degenerate = !(nrm > 0.0) || !(nrm < 1e300);
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        const double ob = __shfl_xor(best, o2);
+        const int oi = __shfl_xor(bi, o2);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { red[16 + 2 * wv] = best; red[16 + 2 * wv + 1] = (double)bi; }
+    __syncthreads();
+    best = red[16];
+    bi = (int)red[17];
+    for (int q = 1; q < 4; q++) {
+        const double ob = red[16 + 2 * q];
+        const int oi = (int)red[16 + 2 * q + 1];
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (degenerate) {
+        for (int i = tid; i < d; i += 256) out[i] = (i == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double sg = ((V[bi] < 0.0) ? -1.0 : 1.0) / nrm;
+    for (int i = tid; i < d; i += 256) out[i] = V[i] * sg;
+}
 bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec) {
-    if (d > 128) return false; // beyond the register block: the caller uses the host solver
+    if (d > 512) return false; // beyond the LDS budget of the wide solver: the caller uses the host solver
+    if (d > 128) { // the matrix stays in global memory and is overwritten
+        ScopedKernelTimer t(c, "group_eig");
+        const size_t lds = (size_t)(10 * d + 32) * sizeof(double);
+        hipLaunchKernelGGL(group_eig_wide_kernel, dim3((unsigned)n_tasks), dim3(256), lds, c->stream, const_cast<double *>(cov),
+                           (int)d, vec);
+        return true;
+    }
     ScopedKernelTimer t(c, "group_eig");
     static const int diag_stage = getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0; // 0 = normal
     const dim3 grid((unsigned)n_tasks), block(256);

@@ -12,7 +12,7 @@
 // The reference splits strictly one group at a time.  Here the nodes of the split tree that can still be
 // popped are split speculatively in batches and the heap is then REPLAYED in the reference's order from the
 // cached results, so ids (= positions in the heap array, :337-342) come out identical while the device sees
-// hundreds of groups per launch.  host_eig_top below is the d > 128 fallback of the device eigen-solver.
+// hundreds of groups per launch.  host_eig_top below is the d > 512 fallback of the device eigen-solvers.
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
@@ -826,7 +826,7 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
                 k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                             c->ls_mean.p, c->ls_part.p, c->ls_cov.p);
             }
-            if (!k_group_eig(c, c->ls_cov.p, T, d, c->ls_vec.p)) { // d > 128: host solver on a worker pool
+            if (!k_group_eig(c, c->ls_cov.p, T, d, c->ls_vec.p)) { // d > 512: host solver on a worker pool
                 std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d);
                 HIP_CHECK(hipMemcpyAsync(cov.data(), c->ls_cov.p, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));

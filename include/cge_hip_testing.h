@@ -12,7 +12,8 @@ int cge_host_eig_top(const double *A, int64_t d, double *v);
 /* the sampler's counter-based draw of positive rows: pos_idx[k] in 1..m (no device work) */
 int cge_host_pos_draw(int64_t seed, int64_t stream_id, int64_t S, int64_t m, int64_t *pos_idx);
 /* kernel-level hook (needs the GPU): principal eigenvectors of T symmetric d x d matrices (row-major, back to
- * back) by the batched device solver that landmarks uses for d <= 128; returns CGE_E_ARG for d > 128 */
+ * back) by the batched device solvers that landmarks uses (d <= 128: register-resident; d <= 512: global-memory
+ * resident); returns CGE_E_ARG for d > 512 */
 int cge_group_eig(void *ctx, const double *A, int64_t T, int64_t d, double *v);
 #ifdef __cplusplus
 }
