@@ -172,8 +172,8 @@ def test_group_eig_kernel(ctx, d):
 
 @pytest.mark.parametrize("d,method", [(200, "rss"), (256, "size"), (96, "diameter"), (65, "rss2")])
 def test_landmarks_parity_wide_embeddings(ctx, orc, d, method):
-    """Embedding dimensions beyond one MFMA tile / one LDS-resident covariance: host eigen-solver fallback
-    (d > 128), multi-tile MFMA SYRK, dimensions that are not multiples of 8/16/128.  (The oracle's Jacobi solver
+    """Embedding dimensions beyond one MFMA tile / one register-resident covariance: the global-memory eigen-solver
+    (128 < d <= 512), multi-tile MFMA SYRK, dimensions that are not multiples of 8/16/128.  (The oracle's Jacobi solver
     costs O(d^3) per sweep, so the oracle-checked cases stop at d = 256; d = 512 is covered below.)"""
     import cge.jl_amd as cg
     from cge.jl_amd import api, synth
