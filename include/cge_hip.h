@@ -196,6 +196,8 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             instead of the dependency counters (undirected only).  Same iterates and iteration counts in all
  *             modes; sums are grouped differently between the launch-per-iteration and the persistent forms
  *             (last-bit differences of the score vector).
+ * "speculation_pct": 1..100 (default 40): share of the pops still missing that one round of runsplit's global phase
+ *             may split ahead of the heap; tuning only -- the replay makes the result independent of it.
  * "fit_persistent_test_timeout": testing hook, 1 = every persistent launch gives up at once (the host then
  *             restores the iterate and falls back to one launch per iteration).                              */
 int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
