@@ -137,6 +137,26 @@ def test_landmarks_duplicate_rows_ties(ctx, orc, method):
     _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
 
 
+@pytest.mark.parametrize("method", ["rss", "size"])
+def test_landmarks_independent_of_speculation(ctx, synth20k, method):
+    """How much of the split tree is expanded ahead of the heap is a tuning knob: the replay pops in the reference's
+    order whatever was precomputed, so landmark ids and everything derived from them must not move."""
+    import cge.jl_amd as cg
+
+    a = synth20k
+    args = (a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], a["embedding"], False, 300, 2, method, False)
+    out = {}
+    try:
+        for pct in (100, 40, 3):
+            ctx.set_option("speculation_pct", pct)
+            out[pct] = cg.landmarks(*args, ctx=ctx)
+    finally:
+        ctx.set_option("speculation_pct", 40)
+    for pct in (40, 3):
+        for x, y in zip(out[100], out[pct]):
+            assert np.array_equal(x, y), pct
+
+
 @pytest.mark.parametrize("d", [2, 3, 5, 17, 32, 33, 64, 65, 100, 127, 128, 129, 200, 256, 333, 512])
 def test_group_eig_kernel(ctx, d):
     """The batched device eigen-solver (register-resident Householder tridiagonalisation, Sturm multisection,
