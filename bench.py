@@ -215,6 +215,11 @@ def main():
                            "one launch = the whole fit of one alpha; algorithmic bytes = iterations x 8 B per unordered "
                            "landmark pair (what one launch per iteration streams); the matrix is read once and stays in "
                            "registers, so the measured traffic is far below this"),
+        "group_stats": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", None,
+                        "covariance SYRK: 2 d^2 flop per row of the batch on the full tile (36 of its 64 blocks are computed, "
+                        "the rest mirrored); the timer also covers the means gather and the chunk reduction"),
+        "group_project": ("hbm", HBM_PEAK_GBS, "GB/s", None, "projection z: one 8d-byte row read per row of the batch"),
+        "sorted_prefix": ("hbm", HBM_PEAK_GBS, "GB/s", None, "WSSE scan along sorted z: one 8d-byte row read per row of the batch"),
         "edge_scatter": ("hbm", HBM_PEAK_GBS, "GB/s", 24.0 * g["m"] / world,
                          "C x C cluster-pair scatter-add, 24 B per edge (2 x Int64 + Float64 as the reference stores them)"),
     }
@@ -226,6 +231,10 @@ def main():
             bound, peak, unit, w, note = work[name]
             if name == "pair_list":
                 w = 2.0 * d * 128 * 128 * cand_tiles / max(1, l_ / steps_prof)
+            if name in ("group_stats", "group_project", "sorted_prefix"):  # average batch of the last runsplit
+                rows = ctx.get_stat("landmark_batch_rows") / max(1, ctx.get_stat("landmark_batches"))
+                w = 2.0 * d * d * rows if name == "group_stats" else 8.0 * d * rows
+                ent["rows_per_launch"] = rows
             if name == "fit_persistent":  # iterations of the last step's sweep / its launches
                 w = 8.0 * N * (N + 1) / 2 * ctx.get_stat("fit_iterations") / max(1, l_ / steps_prof)
                 ent["iterations_per_launch"] = ctx.get_stat("fit_iterations") / max(1, l_ / steps_prof)

@@ -878,6 +878,9 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "diameter_refs")) *value = c->stat_nref;
     else if (!strcmp(key, "fit_persistent_alphas")) *value = c->stat_fit_persistent;
     else if (!strcmp(key, "fit_iterations")) *value = c->stat_fit_iters;
+    else if (!strcmp(key, "landmark_batches")) *value = c->stat_lm_batches;
+    else if (!strcmp(key, "landmark_batch_rows")) *value = c->stat_lm_rows;
+    else if (!strcmp(key, "landmark_splits")) *value = c->stat_lm_splits;
     else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`
     else return CGE_E_ARG;
     return CGE_OK;

@@ -251,6 +251,7 @@ struct cge_ctx {
                                 // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
     int opt_speculation_pct = 40;  // global phase: share of the still missing pops that one round may split speculatively
     int opt_fit_test_timeout = 0; // testing: the persistent fit gives up at once, so the fallback path runs
+    i64 stat_lm_batches = 0, stat_lm_rows = 0, stat_lm_splits = 0; // last runsplit: device batches, their rows, groups split
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
     bool fit_persistent_broken = false; // a grid barrier timed out once (e.g. another process holds CUs): not tried again // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)

@@ -805,6 +805,9 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             upload_batch(c, B);
         }
         const i64 R = B.R, NC = B.NC;
+        c->stat_lm_batches++;
+        c->stat_lm_rows += R;
+        c->stat_lm_splits += T;
         c->ls_mean.ensure((size_t)T * d); c->ls_sw.ensure(T); c->ls_cov.ensure((size_t)T * d * d);
         c->ls_vec.ensure((size_t)T * d); c->ls_z.ensure(R);
         {
@@ -1007,6 +1010,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     const i64 total = cl_off[ncl];
     c->lm_arena_used = 0;
     c->lm_means_used = 0;
+    c->stat_lm_batches = c->stat_lm_rows = c->stat_lm_splits = 0;
     {
         c->pin_rows[0].ensure(total);
         i32 *stage = c->pin_rows[0].p;

@@ -204,7 +204,8 @@ int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
 /* "landmarks" (N of the last run, no side effects), "diameter_path" (1 brute / 2 pruned), "diameter_candidate_pairs", "diameter_candidate_tiles", "diameter_refs" (reference points) of the last run;
  * "diameter_bits" = the bit pattern of the last `hi` (reinterpret the int64 as a double);
  * "fit_persistent_alphas" = alphas of the last sweep fitted by a persistent launch, "fit_iterations" = Chung-Lu
- * iterations of the last sweep (all alphas)                                                          */
+ * iterations of the last sweep (all alphas); "landmark_batches" / "landmark_batch_rows" / "landmark_splits" =
+ * device batches of the last runsplit, the rows they covered, the groups they split                     */
 int cge_get_stat(cge_ctx *ctx, const char *key, int64_t *value);
 
 /* ---- profiling ------------------------------------------------------------------------------ */
