@@ -1745,25 +1745,52 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
 }
 
 // projection z_j = sum_c ((x_jc - mu_c) * sqrt(w_j)) * v_c ; one wave per row
-__global__ void group_project_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
-                                     const i32 *__restrict__ rows, const i32 *__restrict__ row_task, i64 n_rows, i64 d,
-                                     const double *__restrict__ mean, const double *__restrict__ vec,
-                                     double *__restrict__ z) {
-    const i64 j = ((i64)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+__global__ __launch_bounds__(256) void group_project_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                                            const i32 *__restrict__ rows, const i32 *__restrict__ row_task,
+                                                            i64 n_rows, i64 d, const double *__restrict__ mean,
+                                                            const double *__restrict__ vec, double *__restrict__ z) {
+    // one wave per PR consecutive rows, their loads in flight together; per row the same lane-strided sum as ever
+    constexpr int PR = 4;
+    const i64 j0 = (((i64)blockIdx.x * blockDim.x + threadIdx.x) / WAVE) * PR;
     const int lane = threadIdx.x & 63;
-    if (j >= n_rows) return;
-    const i64 v = rows[j];
-    const i64 t = row_task[j];
-    const double sq = sqrt(vw[v]);
-    const double *x = Xr + v * d, *mu = mean + t * d, *ev = vec + t * d;
-    double s = 0.0;
-    for (i64 col = lane; col < d; col += WAVE) s = fma((x[col] - mu[col]) * sq, ev[col], s);
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane == 0) z[j] = s;
+    if (j0 >= n_rows) return;
+    if (d <= 128) { // two columns per lane: everything fits registers
+        double xa[PR], xb[PR], ma[PR], mb[PR], ea[PR], eb[PR], sq[PR];
+        const bool hb = lane + 64 < d, ha = lane < d;
+#pragma unroll
+        for (int u = 0; u < PR; u++) {
+            const i64 j = (j0 + u < n_rows) ? j0 + u : j0;
+            const i64 v = rows[j], t = row_task[j];
+            sq[u] = sqrt(vw[v]);
+            const double *x = Xr + v * d, *mu = mean + t * d, *ev = vec + t * d;
+            xa[u] = ha ? x[lane] : 0.0; ma[u] = ha ? mu[lane] : 0.0; ea[u] = ha ? ev[lane] : 0.0;
+            xb[u] = hb ? x[lane + 64] : 0.0; mb[u] = hb ? mu[lane + 64] : 0.0; eb[u] = hb ? ev[lane + 64] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < PR; u++) {
+            double s = 0.0;
+            if (ha) s = fma((xa[u] - ma[u]) * sq[u], ea[u], s);
+            if (hb) s = fma((xb[u] - mb[u]) * sq[u], eb[u], s);
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+            if (lane == 0 && j0 + u < n_rows) z[j0 + u] = s;
+        }
+        return;
+    }
+    for (int u = 0; u < PR && j0 + u < n_rows; u++) {
+        const i64 j = j0 + u;
+        const i64 v = rows[j];
+        const i64 t = row_task[j];
+        const double sq = sqrt(vw[v]);
+        const double *x = Xr + v * d, *mu = mean + t * d, *ev = vec + t * d;
+        double s = 0.0;
+        for (i64 col = lane; col < d; col += WAVE) s = fma((x[col] - mu[col]) * sq, ev[col], s);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if (lane == 0) z[j] = s;
+    }
 }
 void k_group_project(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *row_task, i64 n_rows,
                      i64 d, const double *mean, const double *vec, double *z) {
-    i64 threads = n_rows * WAVE;
+    i64 threads = (n_rows + 3) / 4 * WAVE; // one wave per 4 rows
     hipLaunchKernelGGL(group_project_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, Xr, vw,
                        rows, row_task, n_rows, d, mean, vec, z);
 }
