@@ -1814,7 +1814,19 @@ __global__ __launch_bounds__(256) void landmark_aggregate_kernel(const double *_
     for (i32 t = b; t < e; t++) lw = __dadd_rn(lw, vw[mem[t]]);
     for (i64 col = threadIdx.x; col < d; col += blockDim.x) {
         double acc = 0.0;
-        for (i32 t = b; t < e; t++) {
+        i32 t = b;
+        for (; t + 7 < e; t += 8) { // 8 member rows in flight; the additions keep the member order
+            double wv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const i64 v = mem[t + u];
+                wv[u] = vw[v];
+                xv[u] = Xr[v * d + col];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = __dadd_rn(acc, __dmul_rn(wv[u], xv[u]));
+        }
+        for (; t < e; t++) {
             const i64 v = mem[t];
             acc = __dadd_rn(acc, __dmul_rn(vw[v], Xr[v * d + col]));
         }
