@@ -959,3 +959,6 @@ int cge_group_eig(void *ctx, const double *A, int64_t T, int64_t d, double *v) {
 }
 
 } // extern "C"
+
+// for the other translation units (diameter_host.cpp)
+void cge_allreduce_dev(cge_ctx *c, double *dev, i64 count, int op) { allreduce(c, dev, count, op); }

@@ -413,8 +413,9 @@ void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *
                  double *out);
 void k_diameter_layout(cge_ctx *c, const i32 *mem_off, const i32 *mem, const i32 *soff, i64 N, i32 *pos2node, i32 *sub_land,
                        i64 n_sub);
+void cge_allreduce_dev(cge_ctx *c, double *dev, i64 count, int op /*0 sum, 1 max*/); // no-op without collectives
 void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, const double *Ms, const double *mnorm,
-             i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P);
+             i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P, int part = 0, int nparts = 1);
 void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,
                  i64 ntiles, double *best_val, i64 *best_i, i64 *best_j);
 i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *mu_ref, i64 N, i64 nref, i64 d, double L,

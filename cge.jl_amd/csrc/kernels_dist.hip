@@ -233,14 +233,14 @@ __global__ __launch_bounds__(256, 2) void pcent_kernel(const double *__restrict_
                                                        i64 lds_rows, const double *__restrict__ Ms,
                                                        const double *__restrict__ mnorm, i64 ldm, i64 N, i64 dpad,
                                                        const i32 *__restrict__ sub_land,
-                                                       unsigned long long *__restrict__ P) {
+                                                       unsigned long long *__restrict__ P, i64 I0, i64 I1) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4, c2 = lane * 2;
-    const i64 nTI = lds_rows / MP_BM, nTJ = ldm / MP_BN;
+    const i64 nTJ = ldm / MP_BN;
     const i64 nchunk = dpad / MP_BK;
-    for (i64 t = blockIdx.x; t < nTI * nTJ; t += gridDim.x) {
-        const i64 I = t / nTJ, J = t - I * nTJ; // consecutive workgroups share the row tile
+    for (i64 t = blockIdx.x; t < (I1 - I0) * nTJ; t += gridDim.x) { // this rank's row tiles [I0, I1)
+        const i64 I = I0 + t / nTJ, J = t % nTJ; // consecutive workgroups share the row tile
         const i64 i0 = I * MP_BM, j0 = J * MP_BN;
         d4 acc[4][4];
         gram_tile_128(Xs + (i64)wave * lds_rows + i0 + c2, Ms + (i64)wave * ldm + j0 + c2, lds_rows, ldm, nchunk, lds,
@@ -338,12 +338,14 @@ void k_max_pair(cge_ctx *c, const double *Xc, const double *rnorm, i64 n, i64 ld
 
 // P is (number of landmarks) x nref, row stride nref: P[a][r] = max over the rows of landmark a of ||x - ref_r||^2
 void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, const double *Ms, const double *mnorm,
-             i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P) {
+             i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P, int part, int nparts) {
     HIP_CHECK(hipMemsetAsync(P, 0, sizeof(double) * n_land * N, c->stream));
     ScopedKernelTimer t(c, "pcent");
-    const i64 ntiles = (lds_rows / MP_BM) * (ldm / MP_BN);
+    const i64 nTI = lds_rows / MP_BM, I0 = nTI * part / nparts, I1 = nTI * (part + 1) / nparts;
+    const i64 ntiles = (I1 - I0) * (ldm / MP_BN);
+    if (ntiles <= 0) return;
     hipLaunchKernelGGL(pcent_kernel, dim3((unsigned)std::min<i64>(ntiles, 2048)), dim3(256), MP_LDS_BYTES, c->stream, Xs,
-                       rns, lds_rows, Ms, mnorm, ldm, N, dpad, sub_land, reinterpret_cast<unsigned long long *>(P));
+                       rns, lds_rows, Ms, mnorm, ldm, N, dpad, sub_land, reinterpret_cast<unsigned long long *>(P), I0, I1);
 }
 
 void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,
