@@ -25,6 +25,13 @@ def diameter_shard(n_super_rows: int, rank: int, world: int):
     return [si for si in range(n_super_rows) if si % world == rank]
 
 
+def centroid_tile_shard(n_vertex_tiles: int, rank: int, world: int):
+    """Vertex tiles (128 rows each) of the diameter's centroid pass owned by `rank`
+    (kernels_dist.hip: k_pcent, I0 = T*part/nparts, I1 = T*(part+1)/nparts); the per-landmark maxima are then
+    combined by an all-reduce(max)."""
+    return n_vertex_tiles * rank // world, n_vertex_tiles * (rank + 1) // world
+
+
 def candidate_tile_shard(n_tiles: int, rank: int, world: int):
     """Candidate tiles owned by `rank` in the pruned diameter (diameter_host.cpp: global_tile % nparts == part)."""
     return list(range(rank, n_tiles, world))

@@ -61,6 +61,18 @@ def _worker(rank, world, port, q):
         assert set().union(*owned) == set(range(nS)) and sum(map(len, owned)) == nS
         tiles = [set(cd.candidate_tile_shard(1001, r, world)) for r in range(world)]
         assert set().union(*tiles) == set(range(1001)) and sum(map(len, tiles)) == 1001
+        # 2b. the centroid pass: contiguous vertex-tile ranges that cover all tiles; max over vertices of the distance to
+        #     every reference point = max over ranks of the per-shard maxima
+        nT = (n + 127) // 128
+        spans = [cd.centroid_tile_shard(nT, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == nT and all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+        refs = g["embedding"][:: max(1, n // 7)][:7]
+        t0, t1 = spans[rank]
+        part = g["embedding"][128 * t0: min(n, 128 * t1)]
+        q_loc = np.array([((part - r_) ** 2).sum(1).max() if len(part) else 0.0 for r_ in refs])
+        q_all = cd.allreduce_numpy(q_loc.copy(), "max")
+        q_ref = np.array([((g["embedding"] - r_) ** 2).sum(1).max() for r_ in refs])
+        assert np.array_equal(q_all, q_ref)
         X = g["embedding"]
         rows = np.arange(n)
         mine = rows[rows % world == rank]
