@@ -1,9 +1,9 @@
-// kernels_fitp.hip -- the undirected Chung-Lu fixed point (src/divergence.jl:150-168) as ONE persistent launch
-// per alpha: the upper triangle of GD = (1 - D)^alpha lives in REGISTERS for the whole fit.
+// kernels_fitp.hip -- the Chung-Lu fixed points of wGCL / wGCL_directed (src/divergence.jl:150-168, :434-467) as ONE
+// persistent launch per alpha: the upper triangle of GD = (1 - D)^alpha lives in REGISTERS for the whole fit.
 //
 // Why: one iteration streams 8*N*(N+1)/2 algorithmic bytes (64 MB at N = 4000) for 2 flops per byte, a thousand
-// times per score.  As one launch per iteration that is ~20 us of Infinity-Cache traffic plus a launch boundary;
-// here the matrix is read once per alpha and an iteration costs two grid barriers plus a few KB of exchange.
+// times per score.  As one launch per iteration that is ~27 us (the matrix from the Infinity Cache plus a launch
+// boundary); here the matrix is read once per alpha and an iteration costs a few KB of exchange between workgroups.
 //
 // Layout.  The matrix is cut into 64 x 64 tiles; tile (I, J), I <= J, belongs to one wave (tile t -> wave t mod 4G,
 // slot t / 4G; G workgroups of 4 waves, at most TPW slots per wave).  Inside a tile lane l = 8*rq + cq holds the
@@ -12,16 +12,18 @@
 // product, src/divergence.jl:155-158).  The 8 partial rows / columns of a lane are combined across the 8 lanes that
 // share rq / cq by a transposing butterfly (4 + 2 + 1 exchanges), which leaves one finished row (column) per lane.
 //
-// An iteration:  A) every wave: tile products -> partial vectors P[block][other block][64] (write-through stores);
-//                   grid barrier;
+// An iteration:  A) every wave: tile products -> partial vectors P[block][other block][64];
 //                B) workgroup sb (one 16-row quarter of a block): S_i = sum of the block's Nt partial vectors in a
-//                   fixed order, T_i += eps*T_i*(w_i/S_i - 1), f = max|w_i - S_i| (:160-166); grid barrier;
-//                C) every workgroup reloads T (N doubles) and the G per-workgroup maxima; `while f > delta`.
-// Every value that crosses workgroups is stored and loaded with agent-scope relaxed atomics (sc1: write-through
-// stores, L1-bypassing loads), every storing wave drains its stores before its workgroup signals
-// (cdna_hip_programming.md, Guideline 16); the barrier is one monotonic counter.  Every spin is bounded: on a
-// timeout the launch sets `fail`, every workgroup leaves, and the host falls back to one launch per iteration.
-// All sums have a fixed order: a run is bitwise reproducible.
+//                   fixed order, T_i += eps*T_i*(w_i/S_i - 1), f = max|w_i - S_i| (:160-166);
+//                C) `while f > delta`, decided by every workgroup from the same maxima.
+// Three kernels share this scheme.  fit_dataflow_kernel (the default) and fit_dataflow_dir_kernel (directed) order A, B
+// and C by per-block dependency counters: nobody waits for the whole grid.  fit_persistent_kernel (option 3) separates
+// them by two XCD-hierarchical grid barriers per iteration.  Every value that crosses workgroups is stored and loaded
+// with agent-scope relaxed atomics (sc1: write-through stores, L1-bypassing loads), every storing wave drains its stores
+// before one lane of its workgroup signals, and a consumer puts a workgroup barrier between its poll and its loads
+// (cdna_hip_programming.md, Guideline 16).  Every spin is bounded: on a timeout the launch sets `fail`, every workgroup
+// leaves, and the host falls back to one launch per iteration.  All sums have a fixed order: a run is bitwise
+// reproducible.
 #include "common.hpp"
 
 namespace {
