@@ -92,6 +92,30 @@ def load_library():
     return _lib
 
 
+def read_table(path, column_major=True, n_threads=0):
+    """Numeric text table -> float64 array (rows, cols) through the library's parallel reader
+    (include/cge_hip.h: cge_text_table_*; replaces `readdlm`, src/auxilary.jl:80-168).  Needs no GPU.
+    Returns (array, header_skipped)."""
+    L = load_library()
+    L.cge_text_table_close.argtypes = [C.c_void_p]
+    L.cge_text_table_close.restype = None
+    rows, cols, hdr, h = C.c_int64(), C.c_int64(), C.c_int(), C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = L.cge_text_table_open(os.fsencode(path), C.c_int(n_threads), C.byref(rows), C.byref(cols), C.byref(hdr),
+                               C.byref(h), err, C.c_int64(512))
+    if rc != 0:
+        raise CGEError(rc, err.value.decode() or f"cannot read {path}")
+    try:
+        out = np.empty((rows.value, cols.value), dtype=np.float64, order="F" if column_major else "C")
+        rc = L.cge_text_table_parse(h, out.ctypes.data_as(C.c_void_p), C.c_int(1 if column_major else 0), err,
+                                    C.c_int64(512))
+        if rc != 0:
+            raise CGEError(rc, err.value.decode() or f"cannot parse {path}")
+    finally:
+        L.cge_text_table_close(h)
+    return out, bool(hdr.value)
+
+
 def _method_code(method):
     if isinstance(method, _SplitRule):
         return method.code

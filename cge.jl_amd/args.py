@@ -1,7 +1,8 @@
 """Host-side mirror of ``parseargs()`` (reference: src/auxilary.jl:61-247).
 
-Same flags, same defaults, same 14-tuple (src/auxilary.jl:220), 1-based ids.  File parsing is
-the *boundary* of the hot path: it is plain numpy here and is never timed.
+Same flags, same defaults, same 14-tuple (src/auxilary.jl:220), 1-based ids.  The three input files are read by the
+library's parallel text reader (csrc/textio.cpp) -- `readdlm` of a multi-GB embedding would
+otherwise take longer than the scoring pass it feeds.  Parsing is still never part of the timed region.
 """
 from __future__ import annotations
 
@@ -41,8 +42,14 @@ USAGE = (
 )
 
 
-def _readdlm(path, skiprows=0):
-    return np.loadtxt(path, dtype=np.float64, ndmin=2, skiprows=skiprows)
+def _readdlm(path):
+    """(table, header_skipped): every numeric field of the file; a node2vec "n d" header line is skipped."""
+    from . import api
+
+    try:
+        return api.read_table(path, column_major=False)
+    except api.CGEError as e:
+        raise AssertionError(str(e)) from e
 
 
 def _flag_value(argv, flag):
@@ -73,7 +80,7 @@ def parseargs(argv=None, exit_on_error=True):
         fn_edges = _flag_value(argv, "-g")
         if not os.path.isfile(fn_edges):
             raise AssertionError(f"{fn_edges} is not a file")
-        raw = _readdlm(fn_edges)
+        raw, _ = _readdlm(fn_edges)
         rows, no_cols = raw.shape
         if no_cols not in (2, 3):
             raise AssertionError("Expected 2 or 3 columns in edgelist file")
@@ -93,7 +100,10 @@ def parseargs(argv=None, exit_on_error=True):
             raise AssertionError(
                 "communities file (-c) is required: Louvain clustering (src/clustering.jl) is outside the hot path"
             )
-        comm = np.loadtxt(_flag_value(argv, "-c"), dtype=np.int64, ndmin=2)
+        comm_raw, _ = _readdlm(_flag_value(argv, "-c"))
+        if not np.all(comm_raw == np.floor(comm_raw)):
+            raise AssertionError("Communities file must hold integers")
+        comm = comm_raw.astype(np.int64)
         comm_rows, ccols = comm.shape
         if comm_rows != no_vertices:
             raise AssertionError(f"No. communities ({comm_rows}) differ from no. nodes ({no_vertices})")
@@ -113,10 +123,7 @@ def parseargs(argv=None, exit_on_error=True):
         fn_embed = _flag_value(argv, "-e")
         if not os.path.isfile(fn_embed):
             raise AssertionError(f"{fn_embed} is not a file")
-        try:
-            embedding = _readdlm(fn_embed)
-        except ValueError:  # node2vec header line (:151-156)
-            embedding = _readdlm(fn_embed, skiprows=1)
+        embedding, _ = _readdlm(fn_embed)  # a node2vec header line (:151-156) is skipped by the reader
         if embedding.shape[0] != no_vertices:
             raise AssertionError("No. rows in embedding and no. vertices in a graph differ.")
         first = embedding[:, 0]

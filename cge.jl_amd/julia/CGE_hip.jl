@@ -142,4 +142,25 @@ wGCL_directed(edges::Array{Int,2}, eweights::Vector{Float64}, comm::Matrix{Int},
     _wgcl(true, edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges,
           init_eweights, init_embed, split, seed, auc_samples, verbose)
 
+"""
+    read_table(fn) -> Matrix{Float64}
+
+Stand-in for `readdlm(fn, Float64)` in `parseargs` (src/auxilary.jl:80-168): parallel reader of the library, header
+line (node2vec's "n d") skipped as the reference's retry with `skipstart = 1` does.  Needs no GPU.
+"""
+function read_table(fn::AbstractString; threads::Integer = 0)
+    rows, cols, hdr, h = Ref{Int64}(0), Ref{Int64}(0), Ref{Cint}(0), Ref{Ptr{Cvoid}}(C_NULL)
+    err = zeros(UInt8, 512)
+    rc = ccall((:cge_text_table_open, LIB), Cint,
+               (Cstring, Cint, Ref{Int64}, Ref{Int64}, Ref{Cint}, Ref{Ptr{Cvoid}}, Ptr{UInt8}, Int64),
+               fn, threads, rows, cols, hdr, h, err, length(err))
+    rc == 0 || throw(ArgumentError(unsafe_string(pointer(err))))
+    M = Matrix{Float64}(undef, rows[], cols[])
+    rc = ccall((:cge_text_table_parse, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Ptr{UInt8}, Int64),
+               h[], M, 1, err, length(err))
+    ccall((:cge_text_table_close, LIB), Cvoid, (Ptr{Cvoid},), h[])
+    rc == 0 || throw(ArgumentError(unsafe_string(pointer(err))))
+    return M
+end
+
 end # module

@@ -208,6 +208,20 @@ int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
  * device batches of the last runsplit, the rows they covered, the groups they split                     */
 int cge_get_stat(cge_ctx *ctx, const char *key, int64_t *value);
 
+/* ---- text tables (the step right before the path: `readdlm` at src/auxilary.jl:80-168) -------------------------
+ * Parallel reader of a whitespace-delimited numeric table (edge list, community file, embedding): the file is
+ * mapped, cut at line boundaries into one piece per thread and parsed with exactly-rounded conversions.  Blank lines
+ * are skipped; a first line whose field count differs from the second line's is taken as a header (node2vec's
+ * "n d") and skipped, as the reference's retry with skipstart = 1 does (:151-156).  Needs no GPU and no context.
+ * n_threads <= 0: one per hardware thread (at most 32).  `err` (optional) receives the message of a failure.
+ * open: map the file, find the shape (one pass that counts lines).  parse: convert straight into the caller's matrix,
+ * row-major or column-major (Julia's Matrix{Float64}), `out` = rows*cols doubles; no intermediate copy is held, so
+ * a table of B bytes of text costs rows*cols*8 bytes of memory and nothing else.                                    */
+int cge_text_table_open(const char *path, int n_threads, int64_t *rows, int64_t *cols, int *header_skipped, void **handle,
+                        char *err, int64_t err_len);
+int cge_text_table_parse(void *handle, double *out, int column_major, char *err, int64_t err_len);
+void cge_text_table_close(void *handle);
+
 /* ---- profiling ------------------------------------------------------------------------------ */
 /* When enabled, every launch of the named kernels is bracketed by hipEvents on the ctx stream.   */
 int cge_profile_enable(cge_ctx *ctx, int on);
