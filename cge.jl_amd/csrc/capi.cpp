@@ -63,6 +63,7 @@ int cge_create(cge_ctx **out, int device, void *stream) {
         HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&c->sweep_ev[i], hipEventDisableTiming));
         unsigned hc = std::thread::hardware_concurrency();
         c->n_threads = (int)std::max(1u, std::min(hc ? hc : 8u, 16u));
         c->pool = new ThreadPool(c->n_threads - 1);
@@ -85,6 +86,8 @@ void cge_destroy(cge_ctx *c) {
     c->event_pool.clear();
     if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    for (int i = 0; i < 2; i++)
+        if (c->sweep_ev[i]) (void)hipEventDestroy(c->sweep_ev[i]);
     delete c->pool;
     c->pool = nullptr;
     delete c;
@@ -853,8 +856,8 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_diameter = (int)value;
         return CGE_OK;
     }
-    if (!strcmp(key, "fit_persistent")) { // 0 auto, 1 never, 2 whenever the score graph fits the register file, 3 = 2 with grid barriers
-        if (value < 0 || value > 3) return CGE_E_ARG;
+    if (!strcmp(key, "fit_persistent")) { // 0 auto, 1 never, 2 whenever the score graph fits the register file, 3 / 4 = 2 with grid barriers / counters
+        if (value < 0 || value > 4) return CGE_E_ARG;
         c->opt_fit_persistent = (int)value;
         return CGE_OK;
     }

@@ -435,6 +435,243 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
     }
 }
 
+// ---- the fit with the data as its own signal ------------------------------------------------------------------------
+// Same tiles, same sums and the same order of additions as fit_dataflow_kernel, but no counters: a slot that has not
+// been delivered yet holds SENTINEL (a NaN payload that arithmetic never produces), and a consumer polls the values it
+// needs until none of them is the sentinel.  A hand-off is then one write-through store and one L1-bypassing load --
+// the producer neither drains its stores nor signals, the consumer needs no barrier between a poll and its loads.
+// Slots are re-armed by their consumer, off the critical path:
+//   T      ring of 4 vectors; T_{k+1} goes to ring[(k+1)&3].  The reducer of a quarter block arms ring[(k+3)&3] (it
+//          held T_{k-1}, whose readers have all delivered P_k) while it publishes T_{k+1}; tiles poll that slot for
+//          T_{k+3} only after they consumed T_{k+2}, which the same wave stored after an `s_waitcnt vmcnt(0)` that
+//          covers the arming store.  T_0 is read from the caller's vector, the result is written to `Tout`.
+//   P      two buffers by the parity of k; the reducer arms the entries it has just read, and the tile that rewrites
+//          them two iterations later has by then consumed a T_{k+2} stored after the arming stores were drained.
+//   f      three buffers (k mod 3): f_k is stored with T_{k+1}, read by every reducer in iteration k+1, armed again by
+//          its writer in iteration k+2 -- one iteration before the next value lands there.
+// Everything is armed by a fill before the launch.  `done` / `fail` work as in fit_dataflow_kernel (looked at every 64
+// polls); a poll never sees a stale value, only the sentinel or the value it waits for.
+#define FLOW_SENTINEL_WORD 0x7FF8DEADu
+#define FLOW_SENTINEL 0x7FF8DEAD7FF8DEADull
+__device__ __forceinline__ bool armed(double v) { return (unsigned long long)__double_as_longlong(v) == FLOW_SENTINEL; }
+__device__ __forceinline__ double sentinel() { return __longlong_as_double((long long)FLOW_SENTINEL); }
+// every 64th unsuccessful poll: 1 = the fit is over, 2 = abandoned (wave-uniform)
+__device__ __forceinline__ int flow_check(unsigned &spins, unsigned *fail, unsigned *done, long long deadline) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 63u) != 0) return 0;
+    if (__hip_atomic_load(done, RLX_AGENT) != 0u) return 1;
+    if (wall_clock64() > deadline || __hip_atomic_load(fail, RLX_AGENT) != 0u) {
+        __hip_atomic_store(fail, 1u, RLX_AGENT);
+        return 2;
+    }
+    return 0;
+}
+template <int TPW>
+__global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict__ GD, i64 N, int Nt, const double *T0,
+                                                       double *Tout, i64 Tld, const double *__restrict__ w, double eps,
+                                                       double delta, int max_iters, double *ring, double *P, double *fq,
+                                                       unsigned *sync, int *flags, long long timeout_ticks) {
+    constexpr int NSB = 2; // quarter blocks per workgroup at most (4*Nt <= 2*G, checked by the host)
+    __shared__ double red[16][17];
+    __shared__ double fred[4];
+    __shared__ double tsh[4][2][64]; // per wave: the T values of the tile's row block and column block
+    __shared__ int lds_exit;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
+    const int rq = lane >> 3, cq = lane & 7;
+    const int NT = Nt * (Nt + 1) / 2;
+    const i64 Psz = (i64)Nt * Nt * 64;
+    unsigned *fail = sync + 1, *done = sync + 2;
+    const long long deadline = wall_clock64() + timeout_ticks;
+
+    double g[TPW][8][8];
+    int tI[TPW], tJ[TPW];
+#pragma unroll
+    for (int s = 0; s < TPW; s++) {
+        const int t = (wg * 4 + wave) + s * 4 * G;
+        tI[s] = -1;
+        tJ[s] = -1;
+        if (t < NT) {
+            int I = 0, rem = t;
+            while (rem >= Nt - I) { rem -= Nt - I; I++; }
+            tI[s] = I;
+            tJ[s] = I + rem;
+        }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const i64 row = (i64)64 * tI[s] + 8 * rq + a;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const i64 col = (i64)64 * tJ[s] + 8 * cq + b;
+                g[s][a][b] = (tI[s] >= 0 && row < N && col < N) ? GD[row * N + col] : 0.0;
+            }
+        }
+    }
+    // the rows this thread updates (threads 0..15 only): the current iterate and the target stay in registers
+    const int r16 = tid & 15, qg = tid >> 4;
+    double tcur[NSB], wrow[NSB];
+#pragma unroll
+    for (int i = 0; i < NSB; i++) {
+        const int sb = wg + i * G;
+        const i64 row = (i64)64 * (sb >> 2) + 16 * (sb & 3) + r16;
+        const bool mine = sb < 4 * Nt && qg == 0 && row < N;
+        tcur[i] = mine ? T0[row] : 0.0;
+        wrow[i] = mine ? w[row] : 0.0;
+    }
+    if (tid == 0) lds_exit = 0;
+    __syncthreads();
+
+    int k = 0, converged = 0, failed = 0;
+    if (timeout_ticks <= 0) max_iters = 0; // test hook: abandon at once
+    for (;;) {
+        if (k >= max_iters) { failed = 1; break; }
+        const double *Tk = (k == 0) ? T0 : ring + (i64)(k & 3) * Tld;
+        double *Pk = P + (i64)(k & 1) * Psz;
+        int bad = 0; // wave-uniform: 1 = over, 2 = abandoned
+        // ---- 1. tile products with T_k, each wave on its own -----------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < TPW; s++) {
+            if (tI[s] < 0 || bad) continue; // uniform per wave
+            const int I = tI[s], J = tJ[s];
+            double vi, vj;
+            unsigned spins = 0;
+            for (;;) {
+                vi = ld_sc1(Tk + 64 * I + lane);
+                vj = ld_sc1(Tk + 64 * J + lane);
+                if (__all(!armed(vi) && !armed(vj))) break;
+                bad = flow_check(spins, fail, done, deadline);
+                if (bad) break;
+            }
+            if (bad) continue;
+            tsh[wave][0][lane] = vi;
+            tsh[wave][1][lane] = vj;
+            __builtin_amdgcn_wave_barrier();
+            double ti[8], tj[8], pr[8], pc[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                ti[q] = tsh[wave][0][8 * rq + q];
+                tj[q] = tsh[wave][1][8 * cq + q];
+                pr[q] = 0.0;
+                pc[q] = 0.0;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const double p = (ti[a] * tj[b]) * g[s][a][b];
+                    pr[a] += p;
+                    pc[b] += p;
+                }
+            const double rsum = transpose_reduce8<0>(pr, lane);
+            st_sc1(Pk + ((i64)I * Nt + J) * 64 + lane, rsum);
+            if (I != J) {
+                const double csum = transpose_reduce8<3>(pc, lane);
+                st_sc1(Pk + ((i64)J * Nt + I) * 64 + 8 * cq + rq, csum);
+            }
+        }
+        // ---- 2. the quarter blocks this workgroup reduces -----------------------------------------------------------------
+        bool stop = false;
+#pragma unroll
+        for (int i = 0; i < NSB; i++) {
+            const int sb = wg + i * G;
+            if (sb >= 4 * Nt) break; // uniform
+            const int b = sb >> 2, rib = 16 * (sb & 3) + r16;
+            const bool fcheck = k > 0 && i == 0; // `while diff > delta` on f of iteration k-1
+            double pv[4] = {0.0, 0.0, 0.0, 0.0}, fv = 0.0;
+            if (!bad) {
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int q = qg + 16 * u;
+                        if (q < Nt) {
+                            pv[u] = ld_sc1(Pk + ((i64)b * Nt + q) * 64 + rib);
+                            ok = ok && !armed(pv[u]);
+                        }
+                    }
+                    if (__all(ok)) break;
+                    bad = flow_check(spins, fail, done, deadline);
+                    if (bad) break;
+                }
+            }
+            if (!bad && fcheck) {
+                const double *fp = fq + (i64)((k - 1) % 3) * 4 * Nt;
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+                    fv = 0.0;
+                    for (int q = tid; q < 4 * Nt; q += 256) {
+                        const double x = ld_sc1(fp + q);
+                        ok = ok && !armed(x);
+                        fv = fmax(fv, x);
+                    }
+                    if (__all(ok)) break;
+                    bad = flow_check(spins, fail, done, deadline);
+                    if (bad) break;
+                }
+            }
+            if (bad && lane == 0) atomicOr(&lds_exit, bad);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the arming stores of the previous iteration have landed
+            if (fcheck) {
+                for (int off = 32; off > 0; off >>= 1) fv = fmax(fv, __shfl_xor(fv, off));
+                if (lane == 0) fred[wave] = fv;
+            }
+            red[qg][r16] = ((pv[0] + pv[1]) + pv[2]) + pv[3];
+            __syncthreads();
+            const int ex = lds_exit;
+            if (ex) { failed = (ex & 2) != 0; converged = !failed; stop = true; break; } // uniform
+            if (fcheck) {
+                const double f = fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3]));
+                if (!(f > delta)) { converged = 1; stop = true; break; } // uniform; nothing of iteration k is published
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { // arm the entries just read (their next writer is two iterations away)
+                const int q = qg + 16 * u;
+                if (q < Nt) st_sc1(Pk + ((i64)b * Nt + q) * 64 + rib, sentinel());
+            }
+            if (qg == 0) { // lanes 0..15 of wave 0
+                double S = red[0][r16];
+#pragma unroll
+                for (int u = 1; u < 16; u++) S += red[u][r16];
+                const i64 row = (i64)64 * b + rib;
+                double fr = 0.0, tnew = 0.0;
+                if (row < N) {
+                    tnew = tcur[i] + (eps * tcur[i]) * (wrow[i] / S - 1.0);
+                    fr = fabs(wrow[i] - S);
+                }
+                st_sc1(ring + (i64)((k + 1) & 3) * Tld + row, tnew);
+                tcur[i] = tnew;
+                for (int off = 8; off > 0; off >>= 1) fr = fmax(fr, __shfl_xor(fr, off));
+                if (r16 == 0) st_sc1(fq + (i64)(k % 3) * 4 * Nt + sb, fr);
+                st_sc1(ring + (i64)((k + 3) & 3) * Tld + row, sentinel());
+                if (r16 == 0) st_sc1(fq + (i64)((k + 1) % 3) * 4 * Nt + sb, sentinel());
+            }
+            __syncthreads(); // red / fred are free again
+        }
+        if (wg >= 4 * Nt && bad) break; // no quarter block, no barrier in the loop: each wave leaves on its own
+        if (stop) {
+            if (converged && tid == 0) __hip_atomic_store(done, 1u, RLX_AGENT);
+            break;
+        }
+        k++;
+    }
+    if (converged && qg == 0) { // T_k: every reducer holds its rows
+#pragma unroll
+        for (int i = 0; i < NSB; i++) {
+            const int sb = wg + i * G;
+            const i64 row = (i64)64 * (sb >> 2) + 16 * (sb & 3) + r16;
+            if (sb < 4 * Nt && row < N) Tout[row] = tcur[i];
+        }
+    }
+    if (wg == 0 && tid == 0) {
+        flags[0] = converged;
+        flags[1] = k; // iterations done: T_k is final
+        flags[2] = failed || !converged;
+        flags[3] = 0;
+    }
+}
+
 // ---- the directed fit (src/divergence.jl:434-467) in the same dataflow form ----------------------------------------
 // Sin_i = sum_j (Tin_i*Tout_j)*g_ij, Sout_i = sum_j (Tin_j*Tout_i)*g_ij, the diagonal term counted twice (:439-449).
 // A tile element feeds four sums: e1 = (Tin_i*Tout_j)*g goes to Sin_i and Sout_j, e2 = (Tin_j*Tout_i)*g to Sout_i and
@@ -620,8 +857,57 @@ static hipError_t launch_plain(const void *fn, int G, void **args, size_t lds, h
 // Runs the fit of one alpha from T = Tbuf[parity] (two buffers of `Tld` doubles, zero beyond N).  Returns false when the
 // persistent path does not apply or was abandoned (nothing usable was written: the caller restarts the fit with the
 // launch-per-iteration path from its own copy of T); otherwise *iters / *final_parity describe the converged state.
+// The default form of the undirected fit (fit_flow_kernel), enqueue only: T_0 = Tbuf[parity] is left alone, the result goes
+// to Tbuf[parity ^ 1], the kernel's verdict {converged, iterations, failed, -} is copied to `host_flags` (pinned) behind
+// the launch.  Nothing is waited for.  false = this form does not apply (nothing was enqueued).
+bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
+                        double delta, int *host_flags) {
+    const int Nt = (int)((N + 63) / 64);
+    const i64 NT = (i64)Nt * (Nt + 1) / 2;
+    int dev = 0, cus = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0 || Tld < (i64)Nt * 64) return false;
+    const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
+    const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
+    // three tiles per wave: the counter form keeps the matrix without spills; a workgroup reduces at most two quarter blocks
+    if (tpw > 2 || 4 * Nt > 2 * G) return false;
+    const size_t psz = (size_t)Nt * Nt * 64, n_ring = (size_t)4 * Tld, n_fq = (size_t)3 * 4 * Nt;
+    c->fp_flow.ensure(n_ring + n_fq + 2 * psz);
+    c->fp_sync.ensure(DF_WORDS);
+    c->fp_flags.ensure(4);
+    const void *fn = tpw == 1 ? (const void *)fit_flow_kernel<1> : (const void *)fit_flow_kernel<2>;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        return false;
+    }
+    hipStream_t st = c->stream;
+    HIP_CHECK(hipMemsetAsync(c->fp_sync.p, 0, sizeof(unsigned) * 64, st));
+    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->fp_flow.p, (int)FLOW_SENTINEL_WORD, 2 * (n_ring + n_fq + 2 * psz), st));
+    const double *aGD = GD, *aT0 = Tbuf + (i64)parity * Tld, *aW = w;
+    double *aTout = Tbuf + (i64)(parity ^ 1) * Tld, *aRing = c->fp_flow.p, *aFq = c->fp_flow.p + n_ring,
+           *aP = c->fp_flow.p + n_ring + n_fq;
+    i64 aN = N, aTld = Tld;
+    int aNt = Nt, aMax = 2000000;
+    double aEps = eps, aDelta = delta;
+    unsigned *aSync = c->fp_sync.p;
+    int *aFlags = c->fp_flags.p;
+    long long aTicks = c->opt_fit_test_timeout ? 0LL : 300000000LL; // 3 s of the 100 MHz wall clock (0: the test hook)
+    void *args[] = {&aGD, &aN, &aNt, &aT0, &aTout, &aTld, &aW, &aEps, &aDelta, &aMax, &aRing, &aP, &aFq, &aSync, &aFlags, &aTicks};
+    hipError_t e;
+    {
+        ScopedKernelTimer tm(c, "fit_persistent");
+        e = launch_plain(fn, G, args, 0, st);
+    }
+    if (e != hipSuccess) CGE_THROW(CGE_E_HIP, "fit launch failed: %s", hipGetErrorString(e));
+    HIP_CHECK(hipMemcpyAsync(host_flags, c->fp_flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    return true;
+}
+
+// variant: 0 = grid barriers, 1 = dependency counters, 2 = the data as its own signal (default)
 bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
-                      double delta, i64 *iters, int *final_parity, bool dataflow) {
+                      double delta, i64 *iters, int *final_parity, int variant) {
     const int Nt = (int)((N + 63) / 64);
     const i64 NT = (i64)Nt * (Nt + 1) / 2;
     int dev = 0, cus = 0;
@@ -631,6 +917,21 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
     const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
     const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
     if (tpw > 3) return false; // beyond the register file: N > ~4900 on 256 CUs
+    if (variant == 2) {
+        c->pin_fitflags.ensure(8);
+        if (k_fit_flow_enqueue(c, GD, N, Tbuf, Tld, parity, w, eps, delta, c->pin_fitflags.p)) {
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            const int *hf = c->pin_fitflags.p;
+            if (hf[2] || !hf[0]) { // a wait timed out (or the iteration cap was reached)
+                if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
+                return false;
+            }
+            *iters = hf[1];
+            *final_parity = parity ^ 1;
+            return true;
+        }
+    }
+    bool dataflow = variant >= 1;
     const size_t lds = (size_t)Nt * 64 * sizeof(double);
     if (lds > 48 * 1024) return false;
     c->fp_P.ensure((size_t)Nt * Nt * 64);

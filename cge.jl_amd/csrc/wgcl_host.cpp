@@ -284,8 +284,27 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     if (trace) trace->n_alpha = 0;
     const i64 n_alpha_total = (i64)std::floor((AlphaMax + delta) / AlphaStep + 1e-9);
     i64 prev_iters = 16;
-    for (i64 ia = 1; ia <= n_alpha_total; ia++) {
+    // An alpha is a chain on the stream: pow, the fit, AUC, vect_B, JS, scalars -> pinned host memory, an event.  With the
+    // enqueue-only persistent fit (undirected) nothing in the chain needs the host, so the chain of alpha i+1 is
+    // enqueued before the host waits for alpha i -- unless the sweep may end at alpha i (both patience counters at their
+    // last value), so nothing is ever computed in vain.  T alternates between the two halves of TT; the scalars and the
+    // fit's verdict of an alpha land in slot (alpha index mod 2).
+    struct AlphaSlot {
+        bool fit_async = false, did_auc = false, did_div = false;
+        int t0_par = 0;  // the half of TT that held T_0 of this alpha
+        i64 iters = 0;
+    } slots[2];
+    c->pin_scal.ensure(16);
+    c->pin_fitflags.ensure(8);
+    c->fp_Tsave.ensure((size_t)2 * N);
+    const int fit_variant = c->opt_fit_persistent == 3 ? 0 : (c->opt_fit_persistent == 4 ? 1 : 2);
+    auto enqueue_alpha = [&](i64 ia, bool want_auc, bool want_div) {
+        AlphaSlot &sl = slots[ia & 1];
+        const int slot = (int)(ia & 1);
         const double alpha = AlphaStep * (double)ia;
+        sl = AlphaSlot();
+        sl.did_auc = want_auc;
+        sl.did_div = want_div;
         // the undirected persistent fit and vect_B read the upper triangle only; the exact-mode AUC, the directed vect_B
         // and the launch-per-iteration fits read whole rows
         const bool gd_upper = landmarks && !directed && use_persistent;
@@ -299,18 +318,29 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         i64 batch = std::max<i64>(4, std::min<i64>(prev_iters, 128));
         if (!directed) {
             bool fitted = false;
+            sl.t0_par = tpar;
             if (use_persistent) { // the whole fit in one launch, GD's upper triangle in registers (kernels_fitp.hip)
-                HIP_CHECK(hipMemcpyAsync(c->fp_Tsave.p, TT.p + (i64)tpar * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
-                int fpar = tpar;
-                fitted = k_fit_persistent(c, GD.p, N, TT.p, Tld, tpar, G.vw, 0.25, delta, &iters, &fpar, c->opt_fit_persistent != 3);
-                if (fitted) {
-                    tpar = fpar;
-                    c->stat_fit_persistent++;
-                } else { // not co-resident / timed out: restore T and use one launch per iteration from here on
-                    use_persistent = false;
-                    if (gd_upper) k_pow_matrix(c, D.p, N, alpha, GD.p, false);
-                    HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
-                    HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
+                HIP_CHECK(hipMemcpyAsync(c->fp_Tsave.p + (i64)slot * N, TT.p + (i64)tpar * Tld, sizeof(double) * N,
+                                         hipMemcpyDeviceToDevice, st));
+                if (fit_variant == 2 &&
+                    k_fit_flow_enqueue(c, GD.p, N, TT.p, Tld, tpar, G.vw, 0.25, delta, c->pin_fitflags.p + 4 * slot)) {
+                    sl.fit_async = true; // the verdict is looked at when the alpha is collected
+                    fitted = true;
+                    tpar ^= 1;
+                } else {
+                    int fpar = tpar;
+                    fitted = k_fit_persistent(c, GD.p, N, TT.p, Tld, tpar, G.vw, 0.25, delta, &iters, &fpar,
+                                              fit_variant == 2 ? 1 : fit_variant);
+                    if (fitted) {
+                        tpar = fpar;
+                        c->stat_fit_persistent++;
+                    } else { // not co-resident / timed out: restore T and use one launch per iteration from here on
+                        use_persistent = false;
+                        if (gd_upper) k_pow_matrix(c, D.p, N, alpha, GD.p, false);
+                        HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p + (i64)slot * N, sizeof(double) * N,
+                                                 hipMemcpyDeviceToDevice, st));
+                        HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
+                    }
                 }
             }
             if (!fitted) {
@@ -360,12 +390,11 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             if (iters > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g", alpha);
             batch = std::max<i64>(4, std::min<i64>(batch, 32));
         }
-        prev_iters = iters;
-        c->stat_fit_iters += iters;
+        sl.iters = iters;
+        if (!sl.fit_async) prev_iters = iters;
 
-        double auc_val = NAN, div_val = NAN, div_int = 0.0, div_ext = 0.0;
         const double *Ta = directed ? Tout : Tcur, *Tb = directed ? Tin : Tcur;
-        if (!skip_auc) {
+        if (want_auc) {
             const DevSamples &ds = dsets[smp.n_sets == 1 ? 0 : ia - 1];
             if (landmarks)
                 k_auc_landmark(c, Ta, Tb, orig->v2l, orig->vw, orig->lweight, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p,
@@ -373,7 +402,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             else
                 k_auc_exact(c, GD.p, Ta, Tb, N, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p, ds.wts.p, S, scal.p);
         }
-        if (!skip_div) {
+        if (want_div) {
             k_bvec(c, GD.p, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
             if (!split)
                 k_js(c, G.vectC, vectB.p, vlen, C, directed, 0, scal.p + 2);
@@ -382,9 +411,45 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
                 k_js(c, G.vectC, vectB.p, vlen, C, directed, 2, scal.p + 4);
             }
         }
-        double hs[5];
-        HIP_CHECK(hipMemcpyAsync(hs, scal.p, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipMemcpyAsync(c->pin_scal.p + 8 * slot, scal.p, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventRecord(c->sweep_ev[slot], st));
+    };
+
+    i64 next_enqueue = 1;
+    for (i64 ia = 1; ia <= n_alpha_total; ia++) {
+        const double alpha = AlphaStep * (double)ia;
+        AlphaSlot &sl = slots[ia & 1];
+        if (next_enqueue == ia) {
+            enqueue_alpha(ia, !skip_auc, !skip_div);
+            next_enqueue = ia + 1;
+        }
+        const bool may_end_here = (skip_div || alpha_div_counter == 1) && (skip_auc || alpha_auc_counter == 1);
+        if (sl.fit_async && !may_end_here && ia < n_alpha_total) { // keep the device busy while the host reads alpha ia
+            enqueue_alpha(ia + 1, !skip_auc, !skip_div);
+            next_enqueue = ia + 2;
+        }
+        HIP_CHECK(hipEventSynchronize(c->sweep_ev[ia & 1]));
+        if (sl.fit_async) {
+            const int *hf = c->pin_fitflags.p + 4 * (ia & 1);
+            if (hf[2] || !hf[0]) { // a wait timed out: drain what was enqueued behind it, restore T_0 of this alpha and
+                HIP_CHECK(hipStreamSynchronize(st)); // redo it with one launch per iteration (as every later alpha)
+                if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
+                use_persistent = false;
+                tpar = sl.t0_par;
+                HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p + (i64)(ia & 1) * N, sizeof(double) * N,
+                                         hipMemcpyDeviceToDevice, st));
+                next_enqueue = ia;
+                ia--;
+                continue;
+            }
+            sl.iters = hf[1];
+            prev_iters = sl.iters;
+            c->stat_fit_persistent++;
+        }
+        const i64 iters = sl.iters;
+        c->stat_fit_iters += iters;
+        double auc_val = NAN, div_val = NAN, div_int = 0.0, div_ext = 0.0;
+        const double *hs = c->pin_scal.p + 8 * (ia & 1);
         if (!skip_auc) {
             const double auc = 1.0 - hs[0] / hs[1]; // :213
             auc_val = auc;

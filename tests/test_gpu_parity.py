@@ -301,15 +301,16 @@ def test_fit_persistent_kernel_matches_stepwise_and_oracle(ctx, orc, n):
     args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
     out = {}
     try:
-        for mode in (1, 2, 3):  # one launch per iteration / persistent with dependency counters / with grid barriers
+        # one launch per iteration / persistent: the data as its own signal / grid barriers / dependency counters
+        for mode in (1, 2, 3, 4):
             ctx.set_option("fit_persistent", mode)
             out[mode] = cg.wGCL(*args, samples=smp, trace=True, ctx=ctx)
             assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode >= 2)
     finally:
         ctx.set_option("fit_persistent", 0)
-    (r1, t1), (r2, t2), (r3, t3) = out[1], out[2], out[3]
-    assert t1["iters"] == t2["iters"] == t3["iters"]
-    assert np.array_equal(r2, r3)  # the two persistent variants add in the same order
+    (r1, t1), (r2, t2), (r3, t3), (r4, t4) = out[1], out[2], out[3], out[4]
+    assert t1["iters"] == t2["iters"] == t3["iters"] == t4["iters"]
+    assert np.array_equal(r2, r3) and np.array_equal(r2, r4)  # the persistent variants add in the same order
     assert np.allclose(r1, r2, rtol=1e-11, atol=1e-13)
     assert np.allclose(t1["div"], t2["div"], rtol=1e-11, equal_nan=True)
     if n <= 700:
@@ -385,6 +386,10 @@ def test_fit_persistent_handoffs_under_varied_geometry(ctx):
             ctx.set_option("fit_persistent", 2)
             runs = [fn(*args, samples=smp, trace=True, ctx=ctx) for _ in range(3)]
             assert ctx.get_stat("fit_persistent_alphas") > 0
+            if not directed:  # the counter form of the same fit
+                ctx.set_option("fit_persistent", 4)
+                runs.append(fn(*args, samples=smp, trace=True, ctx=ctx))
+                assert ctx.get_stat("fit_persistent_alphas") > 0
         finally:
             ctx.set_option("fit_persistent", 0)
         for res, tr in runs:
@@ -430,7 +435,7 @@ def test_fit_persistent_kernel_headline_landmark_count(ctx):
     ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
     res = {}
     try:
-        for mode in (1, 2, 3):
+        for mode in (1, 2, 3, 4):
             ctx.set_option("fit_persistent", mode)
             res[mode] = ctx.score(g["clusters"], 4000, 4, "rss", seed=3, auc_samples=5000)
             assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode >= 2)
@@ -438,7 +443,7 @@ def test_fit_persistent_kernel_headline_landmark_count(ctx):
         ctx.set_option("fit_persistent", 0)
     assert res[1][0] == res[2][0] and res[1][4] == res[2][4]
     assert np.allclose(res[1], res[2], rtol=1e-10, atol=1e-13)
-    assert np.array_equal(res[2], res[3])
+    assert np.array_equal(res[2], res[3]) and np.array_equal(res[2], res[4])
 
 
 def test_wgcl_landmark_mode_readme_known_answer(ctx, orc, example10k):
