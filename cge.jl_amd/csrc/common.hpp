@@ -247,8 +247,7 @@ struct cge_ctx {
     DevBuf<double> fp_T, fp_Tsave, fp_P, fp_fpart, fp_fq, fp_Td, fp_flow;
     DevBuf<unsigned> fp_sync;
     DevBuf<int> fp_flags;
-    PinBuf<int> pin_fitflags;   // the verdicts of enqueued persistent fits (two alphas in flight)
-    PinBuf<double> pin_scal;    // the scalars of an alpha (AUC sums, divergences), two alphas in flight
+    PinBuf<double> pin_scal;    // the scalars of an alpha (AUC sums, divergences, the fit's verdict), two alphas in flight
     hipEvent_t sweep_ev[2] = {nullptr, nullptr};
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it
                                 // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
@@ -433,8 +432,8 @@ void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, 
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD, bool upper_only = false);
 bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
                       double delta, i64 *iters, int *final_parity, int variant);
-bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
-                        double delta, int *host_flags);
+bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,
+                        double eps, double delta, int *dev_flags);
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
                           const double *deg_out, double eps0, double f0, double delta, i64 *iters);
 void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,

@@ -466,15 +466,46 @@ __device__ __forceinline__ int flow_check(unsigned &spins, unsigned *fail, unsig
     }
     return 0;
 }
-template <int TPW>
-__global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict__ GD, i64 N, int Nt, const double *T0,
-                                                       double *Tout, i64 Tld, const double *__restrict__ w, double eps,
-                                                       double delta, int max_iters, double *ring, double *P, double *fq,
-                                                       unsigned *sync, int *flags, long long timeout_ticks) {
+// max over a row of 16 lanes / over the wave, by DPP (no LDS crossbar); every lane gets the result
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double row16_max(double v) {
+    v = fmax(v, dpp_mov64<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_mov64<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_mov64<0x141>(v)); // row_half_mirror
+    v = fmax(v, dpp_mov64<0x140>(v)); // row_mirror
+    return v;
+}
+__device__ __forceinline__ double readlane64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)b, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_max(double v) {
+    v = row16_max(v);
+    return fmax(fmax(readlane64(v, 0), readlane64(v, 16)), fmax(readlane64(v, 32), readlane64(v, 48)));
+}
+// NW waves per workgroup.  With 8 waves of one tile each (two waves per SIMD, 256 registers apiece) the whole tile sits in
+// architectural VGPRs and the two waves of a SIMD hide each other's latencies; with 4 waves of two tiles half of the
+// matrix lives in accumulation registers and is copied back before use.  The quarter blocks are always reduced by the
+// first 256 threads, with the additions of fit_dataflow_kernel in the same order.
+#define FLOW_RLD 66 // row stride (doubles) of the transposing-reduction scratch: 16-byte accesses of 8 lanes hit 8 banks groups
+template <int TPW, int NW>
+__global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restrict__ GD, i64 N, int Nt, const double *T0,
+                                                            double *Tout, i64 Tld, const double *__restrict__ w, double eps,
+                                                            double delta, int max_iters, double *ring, double *P, double *fq,
+                                                            unsigned *sync, int *flags, long long timeout_ticks) {
     constexpr int NSB = 2; // quarter blocks per workgroup at most (4*Nt <= 2*G, checked by the host)
-    __shared__ double red[16][17];
-    __shared__ double fred[4];
-    __shared__ double tsh[4][2][64]; // per wave: the T values of the tile's row block and column block
+    __shared__ double red[2][NSB][16][17]; // by the parity of k: no barrier is needed to recycle it
+    __shared__ double fred[2][4];
+    __shared__ __attribute__((aligned(16))) double tsh[NW][2][64];     // per wave: T of the tile's row block / column block
+    __shared__ __attribute__((aligned(16))) double rsh[NW][2][8][FLOW_RLD]; // per wave: the two transposing reductions
     __shared__ int lds_exit;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
     const int rq = lane >> 3, cq = lane & 7;
@@ -487,7 +518,7 @@ __global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict_
     int tI[TPW], tJ[TPW];
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
-        const int t = (wg * 4 + wave) + s * 4 * G;
+        const int t = (wg * NW + wave) + s * NW * G;
         tI[s] = -1;
         tJ[s] = -1;
         if (t < NT) {
@@ -507,13 +538,14 @@ __global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict_
         }
     }
     // the rows this thread updates (threads 0..15 only): the current iterate and the target stay in registers
-    const int r16 = tid & 15, qg = tid >> 4;
+    const int r16 = tid & 15, qg = (tid >> 4) & 15;
+    const bool reducer = tid < 256;
     double tcur[NSB], wrow[NSB];
 #pragma unroll
     for (int i = 0; i < NSB; i++) {
         const int sb = wg + i * G;
         const i64 row = (i64)64 * (sb >> 2) + 16 * (sb & 3) + r16;
-        const bool mine = sb < 4 * Nt && qg == 0 && row < N;
+        const bool mine = sb < 4 * Nt && tid < 16 && row < N;
         tcur[i] = mine ? T0[row] : 0.0;
         wrow[i] = mine ? w[row] : 0.0;
     }
@@ -527,6 +559,9 @@ __global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict_
         const double *Tk = (k == 0) ? T0 : ring + (i64)(k & 3) * Tld;
         double *Pk = P + (i64)(k & 1) * Psz;
         int bad = 0; // wave-uniform: 1 = over, 2 = abandoned
+        // The arming stores of the previous iteration (and its T) have landed before anything of this iteration is stored:
+        // waited for here, where the wave would otherwise only wait for the other workgroups' T to become visible.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ---- 1. tile products with T_k, each wave on its own -----------------------------------------------------------
 #pragma unroll
         for (int s = 0; s < TPW; s++) {
@@ -553,7 +588,6 @@ __global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict_
                 pr[q] = 0.0;
                 pc[q] = 0.0;
             }
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int a = 0; a < 8; a++)
 #pragma unroll
@@ -562,11 +596,29 @@ __global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict_
                     pr[a] += p;
                     pc[b] += p;
                 }
-            const double rsum = transpose_reduce8<0>(pr, lane);
+            // The transposing reductions of transpose_reduce8 (same pairs, same bits) through LDS: the partial of lane
+            // (rq, cq) for row 8*rq + a goes to R[cq][8*rq + a], lane l then adds the eight partials of row l as
+            // ((u0+u4)+(u2+u6)) + ((u1+u5)+(u3+u7)); the same for the columns with the roles of rq and cq exchanged.
+            double(*R)[FLOW_RLD] = rsh[wave][0];
+            double(*Cc)[FLOW_RLD] = rsh[wave][1];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                R[cq][8 * rq + q] = pr[q];
+                Cc[rq][8 * cq + q] = pc[q];
+            }
+            __builtin_amdgcn_wave_barrier();
+            double u[8], v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                u[q] = R[q][lane];
+                v[q] = Cc[q][lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double rsum = ((u[0] + u[4]) + (u[2] + u[6])) + ((u[1] + u[5]) + (u[3] + u[7]));
             st_sc1(Pk + ((i64)I * Nt + J) * 64 + lane, rsum);
             if (I != J) {
-                const double csum = transpose_reduce8<3>(pc, lane);
-                st_sc1(Pk + ((i64)J * Nt + I) * 64 + 8 * cq + rq, csum);
+                const double csum = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+                st_sc1(Pk + ((i64)J * Nt + I) * 64 + lane, csum);
             }
         }
         // ---- 2. the quarter blocks this workgroup reduces -----------------------------------------------------------------
@@ -577,8 +629,14 @@ __global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict_
             if (sb >= 4 * Nt) break; // uniform
             const int b = sb >> 2, rib = 16 * (sb & 3) + r16;
             const bool fcheck = k > 0 && i == 0; // `while diff > delta` on f of iteration k-1
-            double pv[4] = {0.0, 0.0, 0.0, 0.0}, fv = 0.0;
-            if (!bad) {
+            double pv[4] = {0.0, 0.0, 0.0, 0.0}, fv = 0.0, fx[2] = {0.0, 0.0};
+            const double *fp = fq + (i64)((k + 2) % 3) * 4 * Nt; // f of iteration k-1
+            if (!bad && fcheck && reducer) { // stored an iteration ago: asked for ahead of the partial vectors
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    if (tid + 256 * u < 4 * Nt) fx[u] = ld_sc1(fp + tid + 256 * u);
+            }
+            if (!bad && reducer) {
                 unsigned spins = 0;
                 for (;;) {
                     bool ok = true;
@@ -595,45 +653,37 @@ __global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict_
                     if (bad) break;
                 }
             }
-            if (!bad && fcheck) {
-                const double *fp = fq + (i64)((k - 1) % 3) * 4 * Nt;
+            if (!bad && fcheck && reducer) {
                 unsigned spins = 0;
                 for (;;) {
-                    bool ok = true;
-                    fv = 0.0;
-                    for (int q = tid; q < 4 * Nt; q += 256) {
-                        const double x = ld_sc1(fp + q);
-                        ok = ok && !armed(x);
-                        fv = fmax(fv, x);
-                    }
-                    if (__all(ok)) break;
+                    if (__all(!armed(fx[0]) && !armed(fx[1]))) break;
                     bad = flow_check(spins, fail, done, deadline);
                     if (bad) break;
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        if (tid + 256 * u < 4 * Nt) fx[u] = ld_sc1(fp + tid + 256 * u);
                 }
+                fv = fmax(fx[0], fx[1]);
             }
             if (bad && lane == 0) atomicOr(&lds_exit, bad);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the arming stores of the previous iteration have landed
-            if (fcheck) {
-                for (int off = 32; off > 0; off >>= 1) fv = fmax(fv, __shfl_xor(fv, off));
-                if (lane == 0) fred[wave] = fv;
+            if (reducer) {
+                if (fcheck) {
+                    fv = wave_max(fv);
+                    if (lane == 0) fred[k & 1][wave] = fv;
+                }
+                red[k & 1][i][qg][r16] = ((pv[0] + pv[1]) + pv[2]) + pv[3];
             }
-            red[qg][r16] = ((pv[0] + pv[1]) + pv[2]) + pv[3];
             __syncthreads();
             const int ex = lds_exit;
             if (ex) { failed = (ex & 2) != 0; converged = !failed; stop = true; break; } // uniform
             if (fcheck) {
-                const double f = fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3]));
+                const double f = fmax(fmax(fred[k & 1][0], fred[k & 1][1]), fmax(fred[k & 1][2], fred[k & 1][3]));
                 if (!(f > delta)) { converged = 1; stop = true; break; } // uniform; nothing of iteration k is published
             }
+            if (tid < 16) { // the update first: it is what the other workgroups wait for
+                double S = red[k & 1][i][0][r16];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { // arm the entries just read (their next writer is two iterations away)
-                const int q = qg + 16 * u;
-                if (q < Nt) st_sc1(Pk + ((i64)b * Nt + q) * 64 + rib, sentinel());
-            }
-            if (qg == 0) { // lanes 0..15 of wave 0
-                double S = red[0][r16];
-#pragma unroll
-                for (int u = 1; u < 16; u++) S += red[u][r16];
+                for (int u = 1; u < 16; u++) S += red[k & 1][i][u][r16];
                 const i64 row = (i64)64 * b + rib;
                 double fr = 0.0, tnew = 0.0;
                 if (row < N) {
@@ -642,12 +692,18 @@ __global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict_
                 }
                 st_sc1(ring + (i64)((k + 1) & 3) * Tld + row, tnew);
                 tcur[i] = tnew;
-                for (int off = 8; off > 0; off >>= 1) fr = fmax(fr, __shfl_xor(fr, off));
+                fr = row16_max(fr);
                 if (r16 == 0) st_sc1(fq + (i64)(k % 3) * 4 * Nt + sb, fr);
                 st_sc1(ring + (i64)((k + 3) & 3) * Tld + row, sentinel());
                 if (r16 == 0) st_sc1(fq + (i64)((k + 1) % 3) * 4 * Nt + sb, sentinel());
             }
-            __syncthreads(); // red / fred are free again
+            if (reducer) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) { // arm the entries just read (their next writer is two iterations away)
+                    const int q = qg + 16 * u;
+                    if (q < Nt) st_sc1(Pk + ((i64)b * Nt + q) * 64 + rib, sentinel());
+                }
+            }
         }
         if (wg >= 4 * Nt && bad) break; // no quarter block, no barrier in the loop: each wave leaves on its own
         if (stop) {
@@ -656,7 +712,7 @@ __global__ __launch_bounds__(256) void fit_flow_kernel(const double *__restrict_
         }
         k++;
     }
-    if (converged && qg == 0) { // T_k: every reducer holds its rows
+    if (converged && tid < 16) { // T_k: every reducer holds its rows
 #pragma unroll
         for (int i = 0; i < NSB; i++) {
             const int sb = wg + i * G;
@@ -857,55 +913,60 @@ static hipError_t launch_plain(const void *fn, int G, void **args, size_t lds, h
 // Runs the fit of one alpha from T = Tbuf[parity] (two buffers of `Tld` doubles, zero beyond N).  Returns false when the
 // persistent path does not apply or was abandoned (nothing usable was written: the caller restarts the fit with the
 // launch-per-iteration path from its own copy of T); otherwise *iters / *final_parity describe the converged state.
-// The default form of the undirected fit (fit_flow_kernel), enqueue only: T_0 = Tbuf[parity] is left alone, the result goes
-// to Tbuf[parity ^ 1], the kernel's verdict {converged, iterations, failed, -} is copied to `host_flags` (pinned) behind
-// the launch.  Nothing is waited for.  false = this form does not apply (nothing was enqueued).
-bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
-                        double delta, int *host_flags) {
+// The default form of the undirected fit (fit_flow_kernel), enqueue only: T_0 is left alone, the result goes to `Tout`
+// (both Tld doubles, zero beyond N), the kernel's verdict {converged, iterations, failed, -} to `dev_flags`.  Nothing is
+// waited for.  false = this form does not apply (nothing was enqueued).
+bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,
+                        double eps, double delta, int *dev_flags) {
     const int Nt = (int)((N + 63) / 64);
     const i64 NT = (i64)Nt * (Nt + 1) / 2;
     int dev = 0, cus = 0;
     HIP_CHECK(hipGetDevice(&dev));
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (cus <= 0 || Tld < (i64)Nt * 64) return false;
-    const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
-    const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
+    // one tile per wave when 4 or 8 waves per CU cover the triangle, else two tiles on each of 4 waves
+    const int nw = (NT <= (i64)4 * cus) ? 4 : 8;
+    const int G = (int)std::min<i64>(cus, std::max<i64>((NT + nw - 1) / nw, (i64)4 * Nt));
+    int tpw = (int)((NT + (i64)nw * G - 1) / ((i64)nw * G));
+    int NW = nw;
+    if (tpw > 1) { // 8 waves cannot hold two tiles each
+        NW = 4;
+        tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
+    }
     // three tiles per wave: the counter form keeps the matrix without spills; a workgroup reduces at most two quarter blocks
     if (tpw > 2 || 4 * Nt > 2 * G) return false;
     const size_t psz = (size_t)Nt * Nt * 64, n_ring = (size_t)4 * Tld, n_fq = (size_t)3 * 4 * Nt;
-    c->fp_flow.ensure(n_ring + n_fq + 2 * psz);
-    c->fp_sync.ensure(DF_WORDS);
-    c->fp_flags.ensure(4);
-    const void *fn = tpw == 1 ? (const void *)fit_flow_kernel<1> : (const void *)fit_flow_kernel<2>;
+    const size_t n_sync = 32; // fail / done words, armed with everything else
+    c->fp_flow.ensure(n_sync + n_ring + n_fq + 2 * psz);
+    const void *fn = NW == 8 ? (const void *)fit_flow_kernel<1, 8>
+                             : (tpw == 1 ? (const void *)fit_flow_kernel<1, 4> : (const void *)fit_flow_kernel<2, 4>);
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NW, 0) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         return false;
     }
     hipStream_t st = c->stream;
-    HIP_CHECK(hipMemsetAsync(c->fp_sync.p, 0, sizeof(unsigned) * 64, st));
-    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->fp_flow.p, (int)FLOW_SENTINEL_WORD, 2 * (n_ring + n_fq + 2 * psz), st));
-    const double *aGD = GD, *aT0 = Tbuf + (i64)parity * Tld, *aW = w;
-    double *aTout = Tbuf + (i64)(parity ^ 1) * Tld, *aRing = c->fp_flow.p, *aFq = c->fp_flow.p + n_ring,
-           *aP = c->fp_flow.p + n_ring + n_fq;
+    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->fp_flow.p, (int)FLOW_SENTINEL_WORD,
+                                2 * (n_sync + n_ring + n_fq + 2 * psz), st));
+    const double *aGD = GD, *aT0 = T0, *aW = w;
+    double *aTout = Tout, *aRing = c->fp_flow.p + n_sync, *aFq = aRing + n_ring, *aP = aFq + n_fq;
     i64 aN = N, aTld = Tld;
     int aNt = Nt, aMax = 2000000;
     double aEps = eps, aDelta = delta;
-    unsigned *aSync = c->fp_sync.p;
-    int *aFlags = c->fp_flags.p;
+    unsigned *aSync = (unsigned *)c->fp_flow.p;
+    int *aFlags = dev_flags;
     long long aTicks = c->opt_fit_test_timeout ? 0LL : 300000000LL; // 3 s of the 100 MHz wall clock (0: the test hook)
     void *args[] = {&aGD, &aN, &aNt, &aT0, &aTout, &aTld, &aW, &aEps, &aDelta, &aMax, &aRing, &aP, &aFq, &aSync, &aFlags, &aTicks};
     hipError_t e;
     {
         ScopedKernelTimer tm(c, "fit_persistent");
-        e = launch_plain(fn, G, args, 0, st);
+        e = hipLaunchKernel(fn, dim3((unsigned)G), dim3(64 * NW), args, 0, st);
     }
     if (e != hipSuccess) CGE_THROW(CGE_E_HIP, "fit launch failed: %s", hipGetErrorString(e));
-    HIP_CHECK(hipMemcpyAsync(host_flags, c->fp_flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
     return true;
 }
 
-// variant: 0 = grid barriers, 1 = dependency counters, 2 = the data as its own signal (default)
+// variant: 0 = grid barriers, 1 = dependency counters (the default form is k_fit_flow_enqueue)
 bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
                       double delta, i64 *iters, int *final_parity, int variant) {
     const int Nt = (int)((N + 63) / 64);
@@ -917,20 +978,6 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
     const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
     const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
     if (tpw > 3) return false; // beyond the register file: N > ~4900 on 256 CUs
-    if (variant == 2) {
-        c->pin_fitflags.ensure(8);
-        if (k_fit_flow_enqueue(c, GD, N, Tbuf, Tld, parity, w, eps, delta, c->pin_fitflags.p)) {
-            HIP_CHECK(hipStreamSynchronize(c->stream));
-            const int *hf = c->pin_fitflags.p;
-            if (hf[2] || !hf[0]) { // a wait timed out (or the iteration cap was reached)
-                if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
-                return false;
-            }
-            *iters = hf[1];
-            *final_parity = parity ^ 1;
-            return true;
-        }
-    }
     bool dataflow = variant >= 1;
     const size_t lds = (size_t)Nt * 64 * sizeof(double);
     if (lds > 48 * 1024) return false;

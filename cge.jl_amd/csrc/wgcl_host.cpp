@@ -207,13 +207,14 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     HIP_CHECK(hipMemcpyAsync(T2.p, hT2.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipStreamSynchronize(st));
     const double *Tin = T1.p, *Tout = T2.p; // directed
-    // undirected: T alternates between the two halves of TT (Tld doubles each, zero beyond N); Tcur = the current iterate
+    // undirected: T rotates through the three parts of TT (Tld doubles each, zero beyond N); Tcur = the current iterate.
+    // Three, so that T_0 of an alpha survives the fit of the next alpha, which may be enqueued before this one is checked.
     DevBuf<double> &TT = c->fp_T;
     const i64 Tld = (N + 63) / 64 * 64;
     int tpar = 0;
-    TT.ensure((size_t)2 * Tld);
+    TT.ensure((size_t)3 * Tld);
     c->fp_Tsave.ensure(N);
-    HIP_CHECK(hipMemsetAsync(TT.p, 0, sizeof(double) * 2 * Tld, st));
+    HIP_CHECK(hipMemsetAsync(TT.p, 0, sizeof(double) * 3 * Tld, st));
     HIP_CHECK(hipMemcpyAsync(TT.p, T1.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
     double *Tcur = TT.p;
     bool use_persistent = !directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
@@ -294,9 +295,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         int t0_par = 0;  // the half of TT that held T_0 of this alpha
         i64 iters = 0;
     } slots[2];
-    c->pin_scal.ensure(16);
-    c->pin_fitflags.ensure(8);
-    c->fp_Tsave.ensure((size_t)2 * N);
+    c->pin_scal.ensure(32);
     const int fit_variant = c->opt_fit_persistent == 3 ? 0 : (c->opt_fit_persistent == 4 ? 1 : 2);
     auto enqueue_alpha = [&](i64 ia, bool want_auc, bool want_div) {
         AlphaSlot &sl = slots[ia & 1];
@@ -309,7 +308,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         // and the launch-per-iteration fits read whole rows
         const bool gd_upper = landmarks && !directed && use_persistent;
         k_pow_matrix(c, D.p, N, alpha, GD.p, gd_upper);
-        HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
+        if (directed || !use_persistent) HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
         if (directed) {
             const double init[2] = {0.9, 1.0}; // epsilon, diff (:434-435)
             HIP_CHECK(hipMemcpyAsync(fitstate.p, init, sizeof(init), hipMemcpyHostToDevice, st));
@@ -320,25 +319,29 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             bool fitted = false;
             sl.t0_par = tpar;
             if (use_persistent) { // the whole fit in one launch, GD's upper triangle in registers (kernels_fitp.hip)
-                HIP_CHECK(hipMemcpyAsync(c->fp_Tsave.p + (i64)slot * N, TT.p + (i64)tpar * Tld, sizeof(double) * N,
-                                         hipMemcpyDeviceToDevice, st));
-                if (fit_variant == 2 &&
-                    k_fit_flow_enqueue(c, GD.p, N, TT.p, Tld, tpar, G.vw, 0.25, delta, c->pin_fitflags.p + 4 * slot)) {
+                const int tnext = (tpar + 1) % 3;
+                if (fit_variant == 2 && k_fit_flow_enqueue(c, GD.p, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld, Tld, G.vw,
+                                                           0.25, delta, (int *)(scal.p + 8))) {
                     sl.fit_async = true; // the verdict is looked at when the alpha is collected
                     fitted = true;
-                    tpar ^= 1;
-                } else {
-                    int fpar = tpar;
-                    fitted = k_fit_persistent(c, GD.p, N, TT.p, Tld, tpar, G.vw, 0.25, delta, &iters, &fpar,
+                    tpar = tnext;
+                } else { // the counter / barrier forms work on two adjacent buffers and are waited for
+                    if (tpar == 2) {
+                        HIP_CHECK(hipMemcpyAsync(TT.p, TT.p + 2 * Tld, sizeof(double) * Tld, hipMemcpyDeviceToDevice, st));
+                        tpar = 0;
+                        sl.t0_par = 0;
+                    }
+                    HIP_CHECK(hipMemcpyAsync(c->fp_Tsave.p, TT.p + (i64)tpar * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+                    int fpar = 0;
+                    fitted = k_fit_persistent(c, GD.p, N, TT.p + (i64)tpar * Tld, Tld, 0, G.vw, 0.25, delta, &iters, &fpar,
                                               fit_variant == 2 ? 1 : fit_variant);
                     if (fitted) {
-                        tpar = fpar;
+                        tpar += fpar;
                         c->stat_fit_persistent++;
                     } else { // not co-resident / timed out: restore T and use one launch per iteration from here on
                         use_persistent = false;
                         if (gd_upper) k_pow_matrix(c, D.p, N, alpha, GD.p, false);
-                        HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p + (i64)slot * N, sizeof(double) * N,
-                                                 hipMemcpyDeviceToDevice, st));
+                        HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
                         HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
                     }
                 }
@@ -346,7 +349,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             if (!fitted) {
                 // one launch per iteration (kernels_fit.hip: fit_step_kernel); T alternates between the two buffers
                 HIP_CHECK(hipMemsetAsync(c->sw_fring.p, 0, sizeof(unsigned long long) * 4, st));
-                double *Tb2[2] = {TT.p + (i64)tpar * Tld, TT.p + (i64)(tpar ^ 1) * Tld};
+                double *Tb2[2] = {TT.p + (i64)tpar * Tld, TT.p + (i64)((tpar + 1) % 3) * Tld};
                 i64 k = 0;
                 for (;;) {
                     for (i64 b = 0; b < batch; b++, k++)
@@ -365,7 +368,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
                     if (iters > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g", alpha);
                     batch = std::max<i64>(4, std::min<i64>(batch, 32));
                 }
-                tpar = (int)((tpar + iters) & 1);
+                if (iters & 1) tpar = (tpar + 1) % 3;
             }
             Tcur = TT.p + (i64)tpar * Tld;
         } else if (use_persistent_dir &&
@@ -411,7 +414,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
                 k_js(c, G.vectC, vectB.p, vlen, C, directed, 2, scal.p + 4);
             }
         }
-        HIP_CHECK(hipMemcpyAsync(c->pin_scal.p + 8 * slot, scal.p, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+        // the scalars and (behind them) the verdict of an enqueued fit, one copy
+        HIP_CHECK(hipMemcpyAsync(c->pin_scal.p + 16 * slot, scal.p, sizeof(double) * (sl.fit_async ? 10 : 5), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipEventRecord(c->sweep_ev[slot], st));
     };
 
@@ -430,14 +434,12 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         }
         HIP_CHECK(hipEventSynchronize(c->sweep_ev[ia & 1]));
         if (sl.fit_async) {
-            const int *hf = c->pin_fitflags.p + 4 * (ia & 1);
-            if (hf[2] || !hf[0]) { // a wait timed out: drain what was enqueued behind it, restore T_0 of this alpha and
-                HIP_CHECK(hipStreamSynchronize(st)); // redo it with one launch per iteration (as every later alpha)
+            const int *hf = (const int *)(c->pin_scal.p + 16 * (ia & 1) + 8);
+            if (hf[2] || !hf[0]) { // a wait timed out: drain what was enqueued behind it and redo this alpha from its T_0
+                HIP_CHECK(hipStreamSynchronize(st)); // (still in place) with one launch per iteration, as every later alpha
                 if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
                 use_persistent = false;
                 tpar = sl.t0_par;
-                HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p + (i64)(ia & 1) * N, sizeof(double) * N,
-                                         hipMemcpyDeviceToDevice, st));
                 next_enqueue = ia;
                 ia--;
                 continue;
@@ -449,7 +451,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         const i64 iters = sl.iters;
         c->stat_fit_iters += iters;
         double auc_val = NAN, div_val = NAN, div_int = 0.0, div_ext = 0.0;
-        const double *hs = c->pin_scal.p + 8 * (ia & 1);
+        const double *hs = c->pin_scal.p + 16 * (ia & 1);
         if (!skip_auc) {
             const double auc = 1.0 - hs[0] / hs[1]; // :213
             auc_val = auc;
