@@ -227,15 +227,37 @@ __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict
     const double *row = GD + i * N;
     const i64 j0 = directed ? 0 : i;
     if (STAGED) {
-        if (j0 > 0) {
-            for (i64 j = threadIdx.x; j < N; j += 256) prod[j] = 0.0;
-            __syncthreads();
+        i32 ob[2], oe[2]; // the member ranges of this thread's first two communities: asked for ahead of the barrier
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const i64 cc = threadIdx.x + 256 * it;
+            ob[it] = cc < C ? cm_off[cc] : 0;
+            oe[it] = cc < C ? cm_off[cc + 1] : 0;
         }
-        for (i64 j = j0 + threadIdx.x; j < N; j += 256) prod[cm_pos[j]] = (ti * Tb[j]) * row[j];
+        // one pass, eight elements per thread in flight: the skipped j < i store the 0.0 that leaves a sum's bits alone
+        const i64 jlo = j0 & ~(i64)255;
+        for (i64 j = threadIdx.x; j < jlo; j += 256) prod[cm_pos[j]] = 0.0;
+        for (i64 base = jlo; base < N; base += 8 * 256) {
+            double r[8], t[8];
+            i32 pos[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const i64 j = base + 256 * u + threadIdx.x;
+                const bool in = j < N, live = in && j >= j0;
+                pos[u] = in ? cm_pos[j] : 0;
+                r[u] = live ? row[j] : 0.0;
+                t[u] = live ? Tb[j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const i64 j = base + 256 * u + threadIdx.x;
+                if (j < N) prod[pos[u]] = (j >= j0) ? (ti * t[u]) * r[u] : 0.0;
+            }
+        }
         __syncthreads();
-        for (i64 cc = threadIdx.x; cc < C; cc += 256) {
+        for (i64 cc = threadIdx.x, it = 0; cc < C; cc += 256, it++) {
             double s = 0.0;
-            const i32 b = cm_off[cc], e = cm_off[cc + 1];
+            const i32 b = it < 2 ? ob[it] : cm_off[cc], e = it < 2 ? oe[it] : cm_off[cc + 1];
             for (i32 t = b; t < e; t++) s += prod[t];
             rowbins[i * C + cc] = s;
         }
@@ -256,12 +278,47 @@ __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict
 // unordered community pair), Z[c1][c1] on the diagonal; the directed vector is Z itself.
 __global__ __launch_bounds__(256) void bvec_zsum_kernel(const double *__restrict__ rowbins, const i32 *__restrict__ cm_off,
                                                         const i32 *__restrict__ cm_mem, i64 C, double *__restrict__ Z) {
+    __shared__ i32 mem[256];
     const i64 c1 = blockIdx.x;
     const i32 b = cm_off[c1], e = cm_off[c1 + 1];
+    if (C <= 512) { // columns threadIdx.x and threadIdx.x + 256: the member ids once per workgroup, eight rows in flight
+        double s[2] = {0.0, 0.0};
+        for (i32 base = b; base < e; base += 256) {
+            __syncthreads();
+            if (base + (i32)threadIdx.x < e) mem[threadIdx.x] = cm_mem[base + threadIdx.x];
+            __syncthreads();
+            const int cnt = min(256, e - base);
+            for (int t0 = 0; t0 < cnt; t0 += 8) {
+                double v[2][8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const bool in = t0 + u < cnt;
+                    const double *r = rowbins + (i64)mem[in ? t0 + u : 0] * C;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const i64 c2 = threadIdx.x + 256 * h;
+                        v[h][u] = (in && c2 < C) ? r[c2] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (t0 + u < cnt) { // member order: the additions of the plain loop
+                        s[0] += v[0][u];
+                        s[1] += v[1][u];
+                    }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const i64 c2 = threadIdx.x + 256 * h;
+            if (c2 < C) Z[c1 * C + c2] = s[h];
+        }
+        return;
+    }
     for (i64 c2 = threadIdx.x; c2 < C; c2 += 256) {
-        double s = 0.0;
-        for (i32 t = b; t < e; t++) s += rowbins[(i64)cm_mem[t] * C + c2];
-        Z[c1 * C + c2] = s;
+        double a = 0.0;
+        for (i32 t = b; t < e; t++) a += rowbins[(i64)cm_mem[t] * C + c2];
+        Z[c1 * C + c2] = a;
     }
 }
 __global__ void bvec_fold_kernel(const double *__restrict__ Z, i64 C, int directed, double *__restrict__ vectB) {
@@ -341,10 +398,12 @@ __global__ __launch_bounds__(256) void js_terms_kernel(const double *__restrict_
     f = block_sum_256(f, sh);
     if (threadIdx.x == 0) fpart[blockIdx.x] = f;
 }
-__global__ void js_final_kernel(const double *__restrict__ fpart, double *__restrict__ out) {
+__global__ void js_final_kernel(const double *__restrict__ fpart, double *__restrict__ out) { // one wave
+    const double v = fpart[threadIdx.x]; // JS_BLOCKS == 64: one load per lane, then the sum in block order
     double f = 0.0;
-    for (int b = 0; b < JS_BLOCKS; b++) f += fpart[b];
-    *out = f / 2.0;
+#pragma unroll
+    for (int b = 0; b < JS_BLOCKS; b++) f += __shfl(v, b);
+    if (threadIdx.x == 0) *out = f / 2.0;
 }
 void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int directed, int mode, double *out) {
     c->js_part.ensure(4 * JS_BLOCKS);
@@ -353,7 +412,7 @@ void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int di
                        c->js_part.p);
     hipLaunchKernelGGL(js_terms_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, vC, vB, len, C, directed, mode,
                        c->js_part.p, c->js_part.p + 3 * JS_BLOCKS);
-    hipLaunchKernelGGL(js_final_kernel, dim3(1), dim3(1), 0, c->stream, c->js_part.p + 3 * JS_BLOCKS, out);
+    hipLaunchKernelGGL(js_final_kernel, dim3(1), dim3(64), 0, c->stream, c->js_part.p + 3 * JS_BLOCKS, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -406,11 +465,15 @@ __global__ __launch_bounds__(256) void auc_exact_kernel(const double *__restrict
     den = block_sum_256(den, sh);
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = num; part[2 * blockIdx.x + 1] = den; }
 }
-__global__ void auc_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ out2) {
+__global__ void auc_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ out2) { // one wave
+    const int lane = threadIdx.x; // nb <= 64: one pair of loads per lane, then the sums in block order
+    const double a = lane < nb ? part[2 * lane] : 0.0, b2 = lane < nb ? part[2 * lane + 1] : 0.0;
     double num = 0.0, den = 0.0;
-    for (int b = 0; b < nb; b++) { num += part[2 * b]; den += part[2 * b + 1]; }
-    out2[0] = num;
-    out2[1] = den;
+    for (int b = 0; b < nb; b++) { num += __shfl(a, b); den += __shfl(b2, b); }
+    if (lane == 0) {
+        out2[0] = num;
+        out2[1] = den;
+    }
 }
 static double *auc_partials(cge_ctx *c) {
     c->auc_part.ensure(2 * AUC_BLOCKS);
@@ -422,14 +485,14 @@ void k_auc_landmark(cge_ctx *c, const double *Ta, const double *Tb, const i32 *v
     double *part = auc_partials(c);
     hipLaunchKernelGGL(auc_landmark_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, Ta, Tb, v2l, vw_orig, lweight,
                        pi, pj, ni, nj, dpos, dneg, wts, S, alpha, part);
-    hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, c->stream, part, AUC_BLOCKS, out2);
+    hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(64), 0, c->stream, part, AUC_BLOCKS, out2);
 }
 void k_auc_exact(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, i64 N, const i32 *pi,
                  const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, double *out2) {
     double *part = auc_partials(c);
     hipLaunchKernelGGL(auc_exact_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, GD, Ta, Tb, N, pi, pj, ni, nj, wts,
                        S, part);
-    hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(1), 0, c->stream, part, AUC_BLOCKS, out2);
+    hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(64), 0, c->stream, part, AUC_BLOCKS, out2);
 }
 
 // ------------------------------------------------------------------------------------------------
