@@ -213,8 +213,9 @@ def main():
                      "8 B per unordered landmark pair per Chung-Lu iteration"),
         "fit_persistent": ("hbm", HBM_PEAK_GBS, "GB/s", None,
                            "one launch = the whole fit of one alpha; algorithmic bytes = iterations x 8 B per unordered "
-                           "landmark pair (what one launch per iteration streams); the matrix is read once and stays in "
-                           "registers, so the measured traffic is far below this"),
+                           "landmark pair (what one launch per iteration streams from HBM); the matrix is read once and stays "
+                           "in registers, so the measured traffic is far below this and frac may exceed 1: the kernel is then "
+                           "bound by its two cross-workgroup hand-offs per iteration (DESIGN.md section 4), not by HBM"),
         "group_stats": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", None,
                         "covariance SYRK: 2 d^2 flop per row of the batch on the full tile (36 of its 64 blocks are computed, "
                         "the rest mirrored); the timer also covers the means gather and the chunk reduction"),
@@ -245,7 +246,7 @@ def main():
         kernels[name] = ent
     # HBM traffic per launch from the committed PMC passes of this same command (profiles/run_profiles.sh)
     pmc, pmc_file = {}, os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    kernel_of = {"fit_symv": "fit_step_kernel", "fit_persistent": "fit_dataflow_kernel", "pcent": "pcent_kernel", "pair_list": "pair_list_kernel",
+    kernel_of = {"fit_symv": "fit_step_kernel", "fit_persistent": "fit_flow_kernel", "pcent": "pcent_kernel", "pair_list": "pair_list_kernel",
                  "edge_scatter": "edge_scatter_kernel", "max_pair_dist": "max_pair_kernel"}
     if os.path.exists(pmc_file) and args.workload == "headline" and world == 1:
         try:

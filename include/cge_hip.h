@@ -189,13 +189,14 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
 /* "diameter": 0 = auto (exact landmark-pair pruning, brute-force MFMA kernel when pruning is weak),
  *             1 = always brute force, 2 = always pruned.  All three return the same exact value.
  * "fit_persistent": how the Chung-Lu fixed point (src/divergence.jl:150-168, :434-467) is launched.
- *             0 = auto: one persistent launch per alpha (the matrix register-resident, per-block dependency
- *                 counters) for score graphs of >= 512 vertices that fit the register file (N <= ~4900 undirected,
- *                 ~4000 directed on 256 CUs), else one launch per iteration;
- *             1 = always one launch per iteration; 2 = persistent whenever it fits; 3 = 2 with grid barriers
- *             instead of the dependency counters (undirected only).  Same iterates and iteration counts in all
- *             modes; sums are grouped differently between the launch-per-iteration and the persistent forms
- *             (last-bit differences of the score vector).
+ *             0 = auto: one persistent launch per alpha (the matrix register-resident, the workgroups exchanging
+ *                 partial sums and iterates by polling the data itself) for score graphs of >= 512 vertices that fit
+ *                 the register file (N <= ~4900 undirected, ~4000 directed on 256 CUs), else one launch per iteration;
+ *             1 = always one launch per iteration; 2 = persistent whenever it fits; 3 / 4 = 2 with grid barriers /
+ *             with per-block dependency counters instead (undirected only; the directed fit always uses counters).
+ *             Same iterates and iteration counts in all modes, identical bits among 2, 3 and 4; sums are grouped
+ *             differently between the launch-per-iteration and the persistent forms (last-bit differences of the
+ *             score vector).
  * "speculation_pct": 1..100 (default 40): share of the pops still missing that one round of runsplit's global phase
  *             may split ahead of the heap; tuning only -- the replay makes the result independent of it.
  * "fit_persistent_test_timeout": testing hook, 1 = every persistent launch gives up at once (the host then
