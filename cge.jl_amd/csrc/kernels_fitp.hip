@@ -16,14 +16,16 @@
 //                B) workgroup sb (one 16-row quarter of a block): S_i = sum of the block's Nt partial vectors in a
 //                   fixed order, T_i += eps*T_i*(w_i/S_i - 1), f = max|w_i - S_i| (:160-166);
 //                C) `while f > delta`, decided by every workgroup from the same maxima.
-// Three kernels share this scheme.  fit_dataflow_kernel (the default) and fit_dataflow_dir_kernel (directed) order A, B
-// and C by per-block dependency counters: nobody waits for the whole grid.  fit_persistent_kernel (option 3) separates
-// them by two XCD-hierarchical grid barriers per iteration.  Every value that crosses workgroups is stored and loaded
-// with agent-scope relaxed atomics (sc1: write-through stores, L1-bypassing loads), every storing wave drains its stores
-// before one lane of its workgroup signals, and a consumer puts a workgroup barrier between its poll and its loads
-// (cdna_hip_programming.md, Guideline 16).  Every spin is bounded: on a timeout the launch sets `fail`, every workgroup
-// leaves, and the host falls back to one launch per iteration.  All sums have a fixed order: a run is bitwise
-// reproducible.
+// Four kernels share this scheme.  fit_flow_kernel (the default, undirected) uses the data as its own signal: a slot that
+// has not been delivered holds a sentinel and consumers poll the values they need (its header has the re-arming argument).
+// fit_dataflow_kernel (option 4) and fit_dataflow_dir_kernel (directed) order A, B and C by per-block dependency counters;
+// fit_persistent_kernel (option 3) separates them by two XCD-hierarchical grid barriers per iteration.  In all of them
+// every value that crosses workgroups is stored and loaded with agent-scope relaxed atomics (sc1: write-through stores,
+// L1-bypassing loads); in the counter / barrier forms every storing wave drains its stores before one lane of its
+// workgroup signals, and a consumer puts a workgroup barrier between its poll and its loads (cdna_hip_programming.md,
+// Guideline 16).  Every spin is bounded: on a timeout the launch sets `fail`, every workgroup leaves, and the host falls
+// back to one launch per iteration.  All sums have a fixed order: a run is bitwise reproducible, and the forms give
+// identical bits.
 #include "common.hpp"
 
 namespace {
@@ -199,14 +201,14 @@ __global__ __launch_bounds__(256) void fit_persistent_kernel(const double *__res
         double fmine = 0.0;
         for (int sb = wg; sb < 4 * Nt; sb += G) {
             const int b = sb >> 2, r = tid & 15, qg = tid >> 4, rib = 16 * (sb & 3) + r;
-            double pv[4];
+            double pv[5]; // up to 80 partial vectors (three tiles per wave on 256 CUs: Nt <= 77)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 5; u++) {
                 const int q = qg + 16 * u;
                 pv[u] = (q < Nt) ? ld_sc1(P + ((i64)b * Nt + q) * 64 + rib) : 0.0;
             }
             __syncthreads(); // red is free again
-            red[qg][r] = ((pv[0] + pv[1]) + pv[2]) + pv[3];
+            red[qg][r] = (((pv[0] + pv[1]) + pv[2]) + pv[3]) + pv[4]; // pv[4] = 0.0 up to 64 blocks: the bits of the shorter sum
             __syncthreads();
             if (qg == 0) {
                 double S = red[0][r];
@@ -379,9 +381,9 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
             __syncthreads();
             const int pr_ = lds_flag;
             if (pr_ != 0) { failed = (pr_ == 2); converged = (pr_ == 1); stop = true; break; } // uniform
-            double pv[4];
+            double pv[5]; // up to 80 partial vectors (three tiles per wave on 256 CUs: Nt <= 77)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 5; u++) {
                 const int q = qg + 16 * u;
                 pv[u] = (q < Nt) ? ld_sc1(P + ((i64)b * Nt + q) * 64 + rib) : 0.0;
             }
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
                 if (!(f > delta)) { converged = 1; stop = true; break; } // uniform
             }
             __syncthreads(); // red and lds_flag are free again
-            red[qg][r] = ((pv[0] + pv[1]) + pv[2]) + pv[3];
+            red[qg][r] = (((pv[0] + pv[1]) + pv[2]) + pv[3]) + pv[4]; // pv[4] = 0.0 up to 64 blocks: the bits of the shorter sum
             __syncthreads();
             if (qg == 0) { // lanes 0..15 of wave 0
                 double S = red[0][r];
@@ -934,7 +936,7 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
         tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
     }
     // three tiles per wave: the counter form keeps the matrix without spills; a workgroup reduces at most two quarter blocks
-    if (tpw > 2 || 4 * Nt > 2 * G) return false;
+    if (tpw > 2 || Nt > 64 || 4 * Nt > 2 * G) return false; // (a reducer adds up to 64 partial vectors)
     const size_t psz = (size_t)Nt * Nt * 64, n_ring = (size_t)4 * Tld, n_fq = (size_t)3 * 4 * Nt;
     const size_t n_sync = 32; // fail / done words, armed with everything else
     c->fp_flow.ensure(n_sync + n_ring + n_fq + 2 * psz);
@@ -977,7 +979,7 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
     if (cus <= 0 || Tld < (i64)Nt * 64) return false;
     const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
     const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
-    if (tpw > 3) return false; // beyond the register file: N > ~4900 on 256 CUs
+    if (tpw > 3 || Nt > 80) return false; // beyond the register file: N > ~4900 on 256 CUs (a reducer adds up to 80 partial vectors)
     bool dataflow = variant >= 1;
     const size_t lds = (size_t)Nt * 64 * sizeof(double);
     if (lds > 48 * 1024) return false;
@@ -1058,7 +1060,7 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
     if (cus <= 0) return false;
     const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
     const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
-    if (tpw > 2 || 4096 + 32 * Nt > DF_WORDS) return false; // the directed tile role needs more registers: N <= ~4000
+    if (tpw > 2 || Nt > 64 || 4096 + 32 * Nt > DF_WORDS) return false; // the directed tile role needs more registers: N <= ~4000
     c->fp_P.ensure((size_t)2 * Nt * Nt * 64);
     c->fp_Td.ensure((size_t)4 * Tld);
     c->fp_sync.ensure(DF_WORDS);

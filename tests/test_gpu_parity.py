@@ -361,8 +361,9 @@ def test_fit_persistent_handoffs_under_varied_geometry(ctx):
     from cge.jl_amd import api, synth
 
     empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    # 4100: two tiles on each of 4 waves and workgroups with two quarter blocks; 4600: three tiles per wave (counter form)
     for n, directed in [(513, False), (640, True), (1000, False), (1337, True), (2049, False), (3100, False),
-                        (3977, False), (2500, True)]:
+                        (3977, False), (2500, True), (4100, False), (4600, False)]:
         g = synth.abcd_like(n, 5 * n, max(2, n // 80), 6, seed=3 * n + 1, directed=directed)
         if n % 2 == 1 and not directed:  # weighted edges (dyadic: the per-edge scatter's float atomics stay exact, so
             rng = np.random.default_rng(n)  # run-to-run bits can be compared), vertex weights = weighted degrees
