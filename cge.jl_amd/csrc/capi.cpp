@@ -866,6 +866,10 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_speculation_pct = (int)value;
         return CGE_OK;
     }
+    if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget
+        c->opt_test_bvec_plain = value != 0;
+        return CGE_OK;
+    }
     if (!strcmp(key, "fit_persistent_test_timeout")) { // testing: 1 = the persistent fit abandons every launch at once
         c->opt_fit_test_timeout = value != 0;
         return CGE_OK;

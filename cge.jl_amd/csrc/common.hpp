@@ -249,6 +249,7 @@ struct cge_ctx {
     DevBuf<int> fp_flags;
     PinBuf<double> pin_scal;    // the scalars of an alpha (AUC sums, divergences, the fit's verdict), two alphas in flight
     hipEvent_t sweep_ev[2] = {nullptr, nullptr};
+    int opt_test_bvec_plain = 0; // testing: vect_B without LDS staging / rows in flight (the forms of very large score graphs)
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it
                                 // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
     int opt_speculation_pct = 40;  // global phase: share of the still missing pops that one round may split speculatively

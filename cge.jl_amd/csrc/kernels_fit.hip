@@ -277,11 +277,12 @@ __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict
 // rowbins, coalesced.  Stage 2b: vect_B[c1, c2] = Z[c1][c2] + Z[c2][c1] for c1 < c2 (both orientations of an
 // unordered community pair), Z[c1][c1] on the diagonal; the directed vector is Z itself.
 __global__ __launch_bounds__(256) void bvec_zsum_kernel(const double *__restrict__ rowbins, const i32 *__restrict__ cm_off,
-                                                        const i32 *__restrict__ cm_mem, i64 C, double *__restrict__ Z) {
+                                                        const i32 *__restrict__ cm_mem, i64 C, double *__restrict__ Z,
+                                                        int plain) {
     __shared__ i32 mem[256];
     const i64 c1 = blockIdx.x;
     const i32 b = cm_off[c1], e = cm_off[c1 + 1];
-    if (C <= 512) { // columns threadIdx.x and threadIdx.x + 256: the member ids once per workgroup, eight rows in flight
+    if (C <= 512 && !plain) { // columns threadIdx.x and threadIdx.x + 256: the member ids once per workgroup, eight rows in flight
         double s[2] = {0.0, 0.0};
         for (i32 base = b; base < e; base += 256) {
             __syncthreads();
@@ -333,14 +334,16 @@ __global__ void bvec_fold_kernel(const double *__restrict__ Z, i64 C, int direct
 void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_pos, const i32 *cm_off,
             const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB) {
     ScopedKernelTimer t(c, "bvec");
-    if (N * sizeof(double) <= 64 * 1024)
+    const int plain = c->opt_test_bvec_plain; // testing: the forms for score graphs beyond the LDS budget / 512 communities
+    if (N * sizeof(double) <= 64 * 1024 && !plain)
         hipLaunchKernelGGL((bvec_rows_kernel<true>), dim3((unsigned)N), dim3(256), N * sizeof(double), c->stream, GD, Ta,
                            Tb, cm_off, cm_mem, cm_pos, N, C, directed, rowbins);
     else
         hipLaunchKernelGGL((bvec_rows_kernel<false>), dim3((unsigned)N), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off,
                            cm_mem, cm_pos, N, C, directed, rowbins);
     c->sw_zsum.ensure((size_t)C * C);
-    hipLaunchKernelGGL(bvec_zsum_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, rowbins, cm_off, cm_mem, C, c->sw_zsum.p);
+    hipLaunchKernelGGL(bvec_zsum_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, rowbins, cm_off, cm_mem, C, c->sw_zsum.p,
+                       plain);
     hipLaunchKernelGGL(bvec_fold_kernel, dim3(grid_for(C * C, 256)), dim3(256), 0, c->stream, c->sw_zsum.p, C, directed,
                        vectB);
 }

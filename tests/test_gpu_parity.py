@@ -399,6 +399,32 @@ def test_fit_persistent_handoffs_under_varied_geometry(ctx):
             assert np.allclose(res, ref, rtol=1e-10, atol=1e-13), (n, directed)
 
 
+def test_vect_b_plain_kernels_give_the_same_bits(ctx, test115):
+    """vect_B of score graphs beyond the LDS budget (N > 8192) or with more than 512 communities goes through kernels
+    without staging; forced here on small inputs: same additions in the same order, so the same score bits (undirected,
+    directed, landmark mode)."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    for n, directed in [(700, False), (333, True)]:
+        g = synth.abcd_like(n, 6 * n, max(2, n // 40), 8, seed=n, directed=directed)
+        ctx.set_graph(g["edges"], g["eweights"], n)
+        if directed:
+            p1, ni, nj = api.draw_samples(ctx, 5, 500, directed=True)
+            smp, fn = (p1, ni, nj, p1), cg.wGCL_directed
+        else:
+            smp, fn = api.draw_samples(ctx, 5, 500), cg.wGCL
+        args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
+        try:
+            ref, tref = fn(*args, samples=smp, trace=True, ctx=ctx)
+            ctx.set_option("test_bvec_plain", 1)
+            res, tr = fn(*args, samples=smp, trace=True, ctx=ctx)
+        finally:
+            ctx.set_option("test_bvec_plain", 0)
+        assert np.array_equal(res, ref) and np.array_equal(tr["div"], tref["div"], equal_nan=True), (n, directed)
+
+
 def test_fit_persistent_abandoned_launch_falls_back(ctx):
     """A persistent launch that gives up (here: forced through the testing option; in production a wait that timed
     out) leaves T untouched for the host, which restores it and fits the alpha with one launch per iteration."""
