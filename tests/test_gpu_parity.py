@@ -473,6 +473,37 @@ def test_fit_persistent_kernel_headline_landmark_count(ctx):
     assert np.array_equal(res[2], res[3]) and np.array_equal(res[2], res[4])
 
 
+@pytest.mark.parametrize("directed", [False, True])
+def test_split_global_and_weighted_edges_at_scale(ctx, orc, directed):
+    """`--split-global` (internal / external JS, src/divergence.jl:235-246) on a weighted
+    edge list (3-column file, src/auxilary.jl:105), 20 000 vertices / 200 000 edges through landmarks() + wGCL() in landmark
+    mode: landmark ids bit-exact, the 7-vector with non-zero internal and external parts equal to the oracle's."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    n = 20000
+    g = synth.abcd_like(n, 200000, 25, 24, seed=11, directed=directed)
+    rng = np.random.default_rng(3)
+    ew = rng.integers(1, 33, size=len(g["eweights"])) / 8.0  # dyadic weights: the per-edge scatter stays order-free
+    vw = np.zeros(n)
+    np.add.at(vw, g["edges"][:, 0] - 1, ew)
+    np.add.at(vw, g["edges"][:, 1] - 1, ew)  # vweights as parseargs computes them for a weighted file (both ends)
+    args_lm = (g["edges"], ew, vw, g["clusters"], g["comm"], g["embedding"], False, 300, 2, "rss", directed)
+    lm, ref = cg.landmarks(*args_lm, ctx=ctx), orc.landmarks(*args_lm)
+    _check_landmarks(lm, ref, unit_weights=False)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+    if directed:
+        p1, ni, nj = api.draw_samples(ctx, 9, 5000, directed=True)
+        smp, fn, ofn = (p1, ni, nj, p1), cg.wGCL_directed, orc.wGCL_directed
+    else:
+        smp, fn, ofn = api.draw_samples(ctx, 9, 5000), cg.wGCL, orc.wGCL
+    wargs = (ledges, lw, lcomm, lemb, dii, lweight, vw, v2l, g["edges"], ew, g["embedding"], True)
+    res, tr = fn(*wargs, 9, 5000, samples=smp, trace=True, ctx=ctx)
+    exp, etr = ofn(*wargs, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+    assert res[2] > 0.0 and res[3] > 0.0 and res[1] == pytest.approx((res[2] + res[3]) / 2.0, rel=1e-12)
+
+
 def test_wgcl_landmark_mode_readme_known_answer(ctx, orc, example10k):
     """README.md:88-100 end to end through landmarks() + wGCL() in landmark mode."""
     import cge.jl_amd as cg
