@@ -346,6 +346,13 @@ class Context:
         self._check(self.L.cge_group_eig(self.h, _p(A), C.c_int64(T), C.c_int64(d), _p(v)))
         return v
 
+    def pow_test(self, x, alpha, method):
+        """Testing hook: (1 - x)^alpha on the device; method 0 = library pow, 1 = the sweep's exp2(alpha * log2(1 - x))."""
+        x = _f64(x)
+        out = np.empty_like(x)
+        self._check(self.L.cge_pow_test(self.h, _p(x), C.c_int64(x.size), C.c_double(alpha), C.c_int(method), _p(out)))
+        return out
+
     def js(self, vC, vB, vI=None, internal=True):
         vC, vB = _f64(vC), _f64(vB)
         vi = None if vI is None or len(vI) == 0 else np.ascontiguousarray(vI, dtype=np.uint8)

@@ -866,6 +866,10 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_speculation_pct = (int)value;
         return CGE_OK;
     }
+    if (!strcmp(key, "pow_exp2")) { // 1 (default): (1 - D)^alpha from log2(1 - D) kept per score; 0: the library pow per alpha
+        c->opt_pow_exp2 = value != 0;
+        return CGE_OK;
+    }
     if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;
@@ -962,6 +966,14 @@ int cge_group_eig(void *ctx, const double *A, int64_t T, int64_t d, double *v) {
     k_group_eig(c, dA.p, T, d, dv.p);
     HIP_CHECK(hipMemcpyAsync(v, dv.p, sizeof(double) * T * d, hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    CGE_CATCH(c)
+}
+
+int cge_pow_test(void *ctx, const double *x, int64_t n, double alpha, int method, double *out) {
+    cge_ctx *c = (cge_ctx *)ctx;
+    if (!c || !x || !out || n <= 0) return CGE_E_ARG;
+    CGE_TRY(c)
+    k_pow_test(c, x, n, alpha, method, out);
     CGE_CATCH(c)
 }
 

@@ -249,6 +249,11 @@ struct cge_ctx {
     DevBuf<int> fp_flags;
     PinBuf<double> pin_scal;    // the scalars of an alpha (AUC sums, divergences, the fit's verdict), two alphas in flight
     hipEvent_t sweep_ev[2] = {nullptr, nullptr};
+    int opt_pow_exp2 = 1; // (1 - D)^alpha as exp2(alpha * log2(1 - D)) with the logarithm computed once per score
+    i64 pow_logs_N = 0;   // log2(1 - D) of the current sweep is in sw_Lh / sw_Ll (0: not prepared)
+    bool pow_logs_upper = false;
+    DevBuf<double> sw_Lh;
+    DevBuf<float> sw_Ll;
     int opt_test_bvec_plain = 0; // testing: vect_B without LDS staging / rows in flight (the forms of very large score graphs)
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it
                                 // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
@@ -430,7 +435,9 @@ void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean);
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
                         double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad);
 // alpha sweep
+void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only);
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD, bool upper_only = false);
+void k_pow_test(cge_ctx *c, const double *x, i64 n, double alpha, int method, double *out);
 bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
                       double delta, i64 *iters, int *final_parity, int variant);
 bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,

@@ -419,6 +419,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         HIP_CHECK(hipEventRecord(c->sweep_ev[slot], st));
     };
 
+    // log2(1 - D) once for the whole sweep (the upper tiles only when every alpha reads only those); a fallback of the
+    // persistent fit in mid-sweep makes k_pow_matrix use the library pow for the whole rows it then needs
+    k_pow_prepare(c, D.p, N, landmarks && !directed && use_persistent);
     i64 next_enqueue = 1;
     for (i64 ia = 1; ia <= n_alpha_total; ia++) {
         const double alpha = AlphaStep * (double)ia;

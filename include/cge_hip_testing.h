@@ -15,6 +15,9 @@ int cge_host_pos_draw(int64_t seed, int64_t stream_id, int64_t S, int64_t m, int
  * back) by the batched device solvers that landmarks uses (d <= 128: register-resident; d <= 512: global-memory
  * resident); returns CGE_E_ARG for d > 512 */
 int cge_group_eig(void *ctx, const double *A, int64_t T, int64_t d, double *v);
+/* out[i] = (1 - x[i])^alpha on the device (host vectors): method 0 = the library pow, 1 = exp2(alpha * log2(1 - x)) with
+ * the logarithm in double + float parts, as the alpha sweep computes GD = (1 - D)^alpha (src/divergence.jl:142-148) */
+int cge_pow_test(void *ctx, const double *x, int64_t n, double alpha, int method, double *out);
 #ifdef __cplusplus
 }
 #endif

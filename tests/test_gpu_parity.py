@@ -399,6 +399,53 @@ def test_fit_persistent_handoffs_under_varied_geometry(ctx):
             assert np.allclose(res, ref, rtol=1e-10, atol=1e-13), (n, directed)
 
 
+def test_pow_from_stored_logarithm_is_within_one_ulp(ctx):
+    """GD = (1 - D)^alpha (src/divergence.jl:142-148) as exp2(alpha * log2(1 - D)) with the logarithm kept per score as
+    double + float: against numpy's pow (glibc, < 1 ulp) on the whole alpha grid -- at most 1 ulp apart, exact at the
+    ends (0 and 1), NaN kept; the library pow of the device for comparison."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.random(200000), 1.0 - np.exp(-rng.random(100000) * 36.0), rng.random(50000) * 1e-9,
+                        [0.0, 1.0, 0.5, 1.0 - 2.0 ** -53, 2.0 ** -53, np.nan]])
+    worst = 0.0
+    for alpha in np.arange(1, 41) * 0.25:
+        ref = np.power(1.0 - x, alpha)
+        got = ctx.pow_test(x, alpha, 1)
+        lib = ctx.pow_test(x, alpha, 0)
+        fin = np.isfinite(ref) & (ref > 0)
+        ulp = np.spacing(ref[fin])
+        err = np.abs(got[fin] - ref[fin]) / ulp
+        worst = max(worst, err.max())
+        assert err.max() <= 1.0, (alpha, err.max(), x[fin][err.argmax()])
+        assert np.abs(lib[fin] - ref[fin]).max() <= 2.0 * ulp.max() or True  # informational only
+        assert got[-6] == 1.0 and got[-5] == 0.0 and np.isnan(got[-1])
+        assert np.array_equal(got[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)])  # exact zeros (underflow) agree
+    assert worst <= 1.0
+
+
+def test_pow_methods_give_the_same_sweep(ctx, orc, test115):
+    """The alpha sweep with the stored-logarithm pow and with the library pow: same iteration counts, scores equal to
+    rounding, both equal to the oracle."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    n = 900
+    g = synth.abcd_like(n, 7 * n, 12, 8, seed=4)
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    ctx.set_graph(g["edges"], g["eweights"], n)
+    smp = api.draw_samples(ctx, 3, 2000)
+    args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
+    try:
+        ctx.set_option("pow_exp2", 0)
+        r0, t0 = cg.wGCL(*args, samples=smp, trace=True, ctx=ctx)
+        ctx.set_option("pow_exp2", 1)
+        r1, t1 = cg.wGCL(*args, samples=smp, trace=True, ctx=ctx)
+    finally:
+        ctx.set_option("pow_exp2", 1)
+    assert t0["iters"] == t1["iters"] and np.allclose(r0, r1, rtol=1e-12, atol=1e-14)
+    exp, etr = orc.wGCL(*args, smp, trace=True)
+    _cmp_result(r1, exp, t1, etr)
+
+
 def test_vect_b_plain_kernels_give_the_same_bits(ctx, test115):
     """vect_B of score graphs beyond the LDS budget (N > 8192) or with more than 512 communities goes through kernels
     without staging; forced here on small inputs: same additions in the same order, so the same score bits (undirected,
