@@ -88,6 +88,10 @@ def cpu_baseline(g, wl, budget_vertices=60000):
                       f"wGCL(v_to_l=Int[]) on the landmark graph, {A} alphas, {t:.1f} s"}
 
 
+ROOFLINE_KERNELS = ("fit_persistent", "fit_symv", "group_stats", "group_project", "sorted_prefix", "pcent", "pair_list",
+                    "max_pair_dist", "edge_scatter")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="event timers around every kernel family (default: only the kernels priced against a roofline)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--diameter", type=int, default=0, help="0 auto (pruned, brute-force fallback), 1 brute force, 2 pruned")
     args = ap.parse_args()
@@ -168,6 +174,9 @@ def main():
     res = None
     for _ in range(args.warmup):
         res = step()
+    # live HIP-event timers over the timed region: the kernels that carry a roofline entry (every timer is a pair of
+    # events on the stream, about 4 us of serialisation each; --profile-all brackets every kernel family)
+    ctx.profile_select(() if args.profile_all else ROOFLINE_KERNELS)
     ctx.profile_enable(True)
     ctx.profile_reset()
     fence()

@@ -392,6 +392,10 @@ class Context:
     def profile_enable(self, on=True):
         self._check(self.L.cge_profile_enable(self.h, C.c_int(int(on))))
 
+    def profile_select(self, names=()):
+        """Time only the named kernels (empty: all) -- every timer is a pair of events on the stream."""
+        self._check(self.L.cge_profile_select(self.h, ",".join(names).encode()))
+
     def profile_reset(self):
         self._check(self.L.cge_profile_reset(self.h))
 

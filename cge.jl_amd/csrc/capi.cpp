@@ -903,6 +903,20 @@ int cge_profile_enable(cge_ctx *c, int on) {
     c->profiling = on != 0;
     return CGE_OK;
 }
+int cge_profile_select(cge_ctx *c, const char *names) {
+    if (!c) return CGE_E_ARG;
+    c->profile_only.clear();
+    std::string cur;
+    for (const char *p = names ? names : ""; ; p++) {
+        if (*p == ',' || *p == 0) {
+            if (!cur.empty()) c->profile_only.push_back(cur);
+            cur.clear();
+            if (*p == 0) break;
+        } else
+            cur.push_back(*p);
+    }
+    return CGE_OK;
+}
 int cge_profile_reset(cge_ctx *c) {
     if (!c) return CGE_E_ARG;
     flush_timers(c);

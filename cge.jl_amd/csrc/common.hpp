@@ -309,6 +309,7 @@ struct cge_ctx {
 
     // ---- profiling -------------------------------------------------------------------------
     bool profiling = false;
+    std::vector<std::string> profile_only; // empty: every timer
     std::map<std::string, KernelTimer> timers;
     Phase phases;
 };
@@ -320,6 +321,11 @@ struct ScopedKernelTimer {
     hipEvent_t a = nullptr, b = nullptr;
     ScopedKernelTimer(cge_ctx *ctx, const char *name) : c(ctx) {
         if (!c->profiling) return;
+        if (!c->profile_only.empty()) {
+            bool hit = false;
+            for (const std::string &n : c->profile_only) hit = hit || n == name;
+            if (!hit) return;
+        }
         t = &c->timers[name];
         a = take_event();
         b = take_event();

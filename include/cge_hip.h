@@ -231,6 +231,8 @@ void cge_text_table_close(void *handle);
 /* When enabled, every launch of the named kernels is bracketed by hipEvents on the ctx stream.   */
 int cge_profile_enable(cge_ctx *ctx, int on);
 int cge_profile_reset(cge_ctx *ctx);
+/* restrict the timers to the comma-separated names (NULL or "": every timer); fewer event pairs on the stream        */
+int cge_profile_select(cge_ctx *ctx, const char *names);
 /* name: "edge_scatter", "max_pair_dist", "fit_symv", ...; returns launches and total milliseconds */
 int cge_profile_get(cge_ctx *ctx, const char *name, int64_t *launches, double *total_ms);
 int cge_profile_names(cge_ctx *ctx, char *buf, int64_t buf_len); /* comma-separated */
