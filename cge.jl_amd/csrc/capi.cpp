@@ -326,7 +326,7 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
                                int method, int directed, bool need_wedges) {
     if (!c->Xr.p || !c->vw.p || !c->comm.p || !c->src.p) CGE_THROW(CGE_E_ARG, "landmarks: graph, embedding and vertex data must be resident");
     if (method < 0 || method > 3) CGE_THROW(CGE_E_ARG, "unknown split method %d", method);
-    const i64 n = c->n, d = c->d;
+    const i64 d = c->d;
     hipStream_t st = c->stream;
     double t0 = now_ms();
     land = clamp_to_unique_rows(c, land, &c->lm_truncated);
@@ -338,8 +338,7 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
     t0 = now_ms();
     const i64 N = (i64)c->h_mem_off.size() - 1; // every group is non-empty
     c->N = N;
-    c->h_v2l.resize(n);
-    for (i64 i = 0; i < n; i++) c->h_v2l[i] = gid[i] + 1; // :379
+    c->h_v2l.clear(); // v_to_l (:379) is read back from the device by landmarks_fetch
     c->lemb.ensure((size_t)N * d);
     c->lweight.ensure(N);
     c->dii.ensure(N);
@@ -455,7 +454,12 @@ int cge_landmarks_fetch(cge_ctx *c, double *dii, double *embed, int64_t *cluster
                 }
             }
     }
-    if (v_to_l) memcpy(v_to_l, c->h_v2l.data(), sizeof(i64) * n);
+    if (v_to_l) { // 1-based landmark of every vertex (:379), from the device copy the score path works on
+        std::vector<i32> v0(n);
+        HIP_CHECK(hipMemcpyAsync(v0.data(), c->v2l.p, sizeof(i32) * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (i64 i = 0; i < n; i++) v_to_l[i] = (i64)v0[i] + 1;
+    }
     CGE_CATCH(c)
 }
 
@@ -749,8 +753,9 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         t0 = now_ms();
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
         ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
-        std::vector<i32> lcomm0(N); // community of a landmark = community of any member (landmarks never span two)
-        for (i64 l = 0; l < N; l++) lcomm0[l] = c->h_comm[c->h_mem[c->h_mem_off[l]]];
+        std::vector<i32> lcomm0(N); // community of a landmark = community of any member (landmarks never span two): :427
+        HIP_CHECK(hipMemcpyAsync(lcomm0.data(), c->lcomm.p, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
         double hi = resident_diameter_lm(c, c->lemb.p, c->lweight.p, lcomm0, C, N, c->has_coll ? c->coll.rank : 0,
                                          c->has_coll ? c->coll.world : 1);
         hi = allreduce_scalar_max(c, hi);

@@ -53,6 +53,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
         const i32 *d_off = c->lm_memoff.p, *d_mem = c->lm_mem.p;
         if (!(c->lm_index_on_device && mem_off.data() == c->h_mem_off.data())) {
             // index not produced by the landmark phase of this context (exact-mode callers): upload it
+            if ((i64)mem.size() != n) return false; // no member lists on the host: the caller takes the brute-force path
             c->dm_memoff.ensure(N + 1);
             c->dm_mem.ensure(n);
             HIP_CHECK(hipMemcpyAsync(c->dm_memoff.p, mem_off.data(), sizeof(i32) * (N + 1), hipMemcpyHostToDevice, st));

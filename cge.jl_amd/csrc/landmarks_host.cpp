@@ -1098,13 +1098,15 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     const i64 unassigned = k_groups_to_index(c, c->lm_arena.p, c->lm_goff.p, c->lm_glen.p, NG, n, c->v2l.p, c->lm_mem.p);
     if (unassigned != 0 || c->h_mem_off[NG] != n)
         CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids)"); // :343
+    c->lm_index_on_device = want_index;
+    c->h_mem.clear(); // the member lists stay on the device (c->lm_mem); host copies are made by whoever asks for them
+    if (want_index) { // the fused path: v2l stays on the device too (landmarks_fetch copies it when it is asked for)
+        HIP_CHECK(hipStreamSynchronize(st)); // goff / glen are pinned staging of this call
+        group_ids.clear();
+        return;
+    }
     c->h_v2l0.resize(n);
     HIP_CHECK(hipMemcpyAsync(c->h_v2l0.data(), c->v2l.p, sizeof(i32) * n, hipMemcpyDeviceToHost, st));
-    c->lm_index_on_device = want_index;
-    if (want_index) {
-        c->h_mem.resize(n);
-        HIP_CHECK(hipMemcpyAsync(c->h_mem.data(), c->lm_mem.p, sizeof(i32) * n, hipMemcpyDeviceToHost, st));
-    }
     HIP_CHECK(hipStreamSynchronize(st));
     group_ids.resize(n);
     parallel_for(c, 64, [&](i64 part) {
