@@ -5,6 +5,7 @@
 //                   extrema(full_graph_D), never materialised)             src/divergence.jl:104-113
 //   k_pair_dist   : distances of sampled pairs                              src/divergence.jl:189,198
 #include "common.hpp"
+#include <type_traits>
 #include "mfma_tile.hpp"
 
 #define WAVE 64
@@ -424,33 +425,55 @@ i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *m
     return cnt;
 }
 
-// farthest vertex from row `src` of Xr (exact dist() arithmetic is not needed: this only seeds a lower bound)
+// farthest vertex from row `src` of Xr (exact dist() arithmetic is not needed: this only seeds a lower bound).
+// A quarter wave (one DPP row of 16 lanes) per vertex, two vertices per quarter in flight: eight rows per wave and
+// iteration, the 16 partial sums of a row combined inside the DPP row (no LDS crossbar).
+__device__ __forceinline__ double row16_sum(double v) {
+    const auto mv = [](double x, auto ctrl) {
+        const long long b = __double_as_longlong(x);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, decltype(ctrl)::value, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), decltype(ctrl)::value, 0xf, 0xf, false);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    };
+    v += mv(v, std::integral_constant<int, 0xB1>());  // quad_perm [1,0,3,2]
+    v += mv(v, std::integral_constant<int, 0x4E>());  // quad_perm [2,3,0,1]
+    v += mv(v, std::integral_constant<int, 0x141>()); // row_half_mirror
+    v += mv(v, std::integral_constant<int, 0x140>()); // row_mirror
+    return v;
+}
 __global__ __launch_bounds__(256) void farthest_kernel(const double *__restrict__ Xr, i64 n, i64 d, i64 src,
                                                        MaxRec *__restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, sub = lane & 15, quarter = lane >> 4;
     const i64 wave_global = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
     const double *s = Xr + src * d;
     double best = -1.0;
     i64 bi = 0;
-    for (i64 i = wave_global; i < n; i += nwaves) {
-        const double *x = Xr + i * d;
-        double acc = 0.0;
+    for (i64 base = wave_global * 8; base < n; base += nwaves * 8) {
+        const i64 i0 = base + quarter, i1 = base + 4 + quarter;
+        const bool in0 = i0 < n, in1 = i1 < n;
+        const double *x0 = Xr + (in0 ? i0 : 0) * d, *x1 = Xr + (in1 ? i1 : 0) * d;
+        double a0 = 0.0, a1 = 0.0;
         if ((d & 1) == 0) { // 16-byte loads
-            const d2 *x2 = reinterpret_cast<const d2 *>(x), *s2 = reinterpret_cast<const d2 *>(s);
-            for (i64 k = lane; k < (d >> 1); k += 64) {
-                const d2 xv = x2[k], sv = s2[k];
-                const double t0 = xv.x - sv.x, t1 = xv.y - sv.y;
-                acc += t0 * t0 + t1 * t1;
+            const d2 *p0 = reinterpret_cast<const d2 *>(x0), *p1 = reinterpret_cast<const d2 *>(x1),
+                     *s2 = reinterpret_cast<const d2 *>(s);
+            for (i64 k = sub; k < (d >> 1); k += 16) {
+                const d2 sv = s2[k], v0 = p0[k], v1 = p1[k];
+                const double t0 = v0.x - sv.x, t1 = v0.y - sv.y, u0 = v1.x - sv.x, u1 = v1.y - sv.y;
+                a0 += t0 * t0 + t1 * t1;
+                a1 += u0 * u0 + u1 * u1;
             }
         } else
-            for (i64 k = lane; k < d; k += 64) {
-                const double t = x[k] - s[k];
-                acc += t * t;
+            for (i64 k = sub; k < d; k += 16) {
+                const double t = x0[k] - s[k], u = x1[k] - s[k];
+                a0 += t * t;
+                a1 += u * u;
             }
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (acc > best) { best = acc; bi = i; }
+        a0 = row16_sum(a0);
+        a1 = row16_sum(a1);
+        if (in0 && a0 > best) { best = a0; bi = i0; }
+        if (in1 && a1 > best) { best = a1; bi = i1; }
     }
     reduce_best(best, bi, src, lds, recs);
 }
