@@ -906,6 +906,268 @@ __global__ __launch_bounds__(256) void fit_dataflow_dir_kernel(const double *__r
     }
 }
 
+// ---- the directed fit with the data as its own signal (the scheme of fit_flow_kernel) -------------------------------------
+// Per tile four partial vectors (e1 = (Tin_i*Tout_j)*g feeds Sin_i and Sout_j, e2 = (Tin_j*Tout_i)*g feeds Sout_i and
+// Sin_j, the diagonal term twice), computed in two passes over the register block so that a wave of 256 registers holds
+// the tile; the same additions in the same order as fit_dataflow_dir_kernel.  T ring: 4 x (Tin, Tout); P: 2 parities x
+// (Sin, Sout) x Nt x Nt x 64; f: 3 x 4Nt.  T_0 = T0 (Tin, Tout: Tld doubles each, zero beyond N); on convergence the
+// reducers write their rows of the final iterate to Tin_out / Tout_out (N doubles each), otherwise nothing is written.
+template <int NW, int NSB> // NSB: quarter blocks a workgroup may have to reduce (1 when 4*Nt <= G)
+__global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__restrict__ GD, i64 N, int Nt, const double *T0,
+                                                                double *Tin_out, double *Tout_out, i64 Tld,
+                                                                const double *__restrict__ deg_in,
+                                                                const double *__restrict__ deg_out, double eps0, double f0,
+                                                                double delta, int max_iters, double *ring, double *P,
+                                                                double *fq, unsigned *sync, int *flags,
+                                                                long long timeout_ticks) {
+    __shared__ double red[2][NSB][2][16][17]; // [parity of k][quarter block][Sin / Sout]
+    __shared__ double fred[2][4];
+    __shared__ __attribute__((aligned(16))) double tsh[NW][4][64];          // Tin_I, Tout_I, Tin_J, Tout_J
+    __shared__ __attribute__((aligned(16))) double rsh[NW][2][8][FLOW_RLD]; // one pass: a row and a column reduction
+    __shared__ int lds_exit;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
+    const int rq = lane >> 3, cq = lane & 7;
+    const int NT = Nt * (Nt + 1) / 2;
+    const i64 Pstride = (i64)Nt * Nt * 64, Psz = 2 * Pstride;
+    unsigned *fail = sync + 1, *done = sync + 2;
+    const long long deadline = wall_clock64() + timeout_ticks;
+
+    double g[8][8];
+    int tI = -1, tJ = -1;
+    {
+        const int t = wg * NW + wave;
+        if (t < NT) {
+            int I = 0, rem = t;
+            while (rem >= Nt - I) { rem -= Nt - I; I++; }
+            tI = I;
+            tJ = I + rem;
+        }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const i64 row = (i64)64 * tI + 8 * rq + a;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const i64 col = (i64)64 * tJ + 8 * cq + b;
+                g[a][b] = (tI >= 0 && row < N && col < N) ? GD[row * N + col] : 0.0;
+            }
+        }
+    }
+    const int r16 = tid & 15, qg = (tid >> 4) & 15;
+    const bool reducer = tid < 256;
+    double tin_cur[NSB], tout_cur[NSB], din[NSB], dout[NSB];
+#pragma unroll
+    for (int i = 0; i < NSB; i++) {
+        const int sb = wg + i * G;
+        const i64 row = (i64)64 * (sb >> 2) + 16 * (sb & 3) + r16;
+        const bool mine = sb < 4 * Nt && tid < 16 && row < N;
+        tin_cur[i] = mine ? T0[row] : 0.0;
+        tout_cur[i] = mine ? T0[Tld + row] : 0.0;
+        din[i] = mine ? deg_in[row] : 0.0;
+        dout[i] = mine ? deg_out[row] : 0.0;
+    }
+    if (tid == 0) lds_exit = 0;
+    __syncthreads();
+
+    int k = 0, converged = 0, failed = 0;
+    double eps = eps0, fprev = f0;
+    if (timeout_ticks <= 0) max_iters = 0; // test hook: abandon at once
+    for (;;) {
+        if (k >= max_iters) { failed = 1; break; }
+        const double *Tk = (k == 0) ? T0 : ring + (i64)(k & 3) * 2 * Tld; // Tin at Tk, Tout at Tk + Tld
+        double *Pk = P + (i64)(k & 1) * Psz;
+        int bad = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the arming stores of the previous iteration have landed
+        // ---- 1. tile products with T_k ---------------------------------------------------------------------------------
+        if (tI >= 0) {
+            const int I = tI, J = tJ;
+            double v0, v1, v2, v3;
+            unsigned spins = 0;
+            for (;;) {
+                v0 = ld_sc1(Tk + 64 * I + lane);
+                v1 = ld_sc1(Tk + Tld + 64 * I + lane);
+                v2 = ld_sc1(Tk + 64 * J + lane);
+                v3 = ld_sc1(Tk + Tld + 64 * J + lane);
+                if (__all(!armed(v0) && !armed(v1) && !armed(v2) && !armed(v3))) break;
+                bad = flow_check(spins, fail, done, deadline);
+                if (bad) break;
+            }
+            if (!bad) {
+                tsh[wave][0][lane] = v0;
+                tsh[wave][1][lane] = v1;
+                tsh[wave][2][lane] = v2;
+                tsh[wave][3][lane] = v3;
+                __builtin_amdgcn_wave_barrier();
+                const bool diag_tile = I == J;
+                double(*R)[FLOW_RLD] = rsh[wave][0];
+                double(*Cc)[FLOW_RLD] = rsh[wave][1];
+#pragma unroll 1
+                for (int pass = 0; pass < 2; pass++) { // one copy of the code: the two passes share their registers
+                    // pass 0: e1 = (Tin_i*Tout_j)*g -> rows: Sin partial, columns: Sout partial
+                    // pass 1: e2 = (Tin_j*Tout_i)*g -> rows: Sout partial, columns: Sin partial
+                    const double *trow = tsh[wave][pass], *tcol = tsh[wave][3 - pass]; // Tin_i, Tout_j / Tout_i, Tin_j
+                    double ta[8], tb[8], pr[8], pc[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        ta[q] = trow[8 * rq + q];
+                        tb[q] = tcol[8 * cq + q];
+                        pr[q] = 0.0;
+                        pc[q] = 0.0;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 8; a++)
+#pragma unroll
+                        for (int b = 0; b < 8; b++) {
+                            double e = (ta[a] * tb[b]) * g[a][b];
+                            if (diag_tile && rq == cq && a == b) e += e; // the j == i term counts twice
+                            pr[a] += e;
+                            pc[b] += e;
+                        }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        R[cq][8 * rq + q] = pr[q];
+                        Cc[rq][8 * cq + q] = pc[q];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    double u[8], v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        u[q] = R[q][lane];
+                        v[q] = Cc[q][lane];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const double rsum = ((u[0] + u[4]) + (u[2] + u[6])) + ((u[1] + u[5]) + (u[3] + u[7]));
+                    // pass 0 rows -> Sin of block I (plane 0), pass 1 rows -> Sout of block I (plane 1)
+                    st_sc1(Pk + (i64)pass * Pstride + ((i64)I * Nt + J) * 64 + lane, rsum);
+                    if (!diag_tile) { // pass 0 columns -> Sout of block J (plane 1), pass 1 columns -> Sin of block J (plane 0)
+                        const double csum = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+                        st_sc1(Pk + (i64)(1 - pass) * Pstride + ((i64)J * Nt + I) * 64 + lane, csum);
+                    }
+                }
+            }
+        }
+        // ---- 2. the quarter blocks this workgroup reduces -----------------------------------------------------------------
+        bool stop = false;
+#pragma unroll
+        for (int i = 0; i < NSB; i++) {
+            const int sb = wg + i * G;
+            if (sb >= 4 * Nt) break; // uniform
+            const int b = sb >> 2, rib = 16 * (sb & 3) + r16;
+            const bool fcheck = k > 0 && i == 0;
+            double pi[4] = {0.0, 0.0, 0.0, 0.0}, po[4] = {0.0, 0.0, 0.0, 0.0}, fv = 0.0, fx[2] = {0.0, 0.0};
+            const double *fp = fq + (i64)((k + 2) % 3) * 4 * Nt; // f of iteration k-1
+            if (!bad && fcheck && reducer) {
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    if (tid + 256 * u < 4 * Nt) fx[u] = ld_sc1(fp + tid + 256 * u);
+            }
+            if (!bad && reducer) {
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int q = qg + 16 * u;
+                        if (q < Nt) {
+                            pi[u] = ld_sc1(Pk + ((i64)b * Nt + q) * 64 + rib);
+                            po[u] = ld_sc1(Pk + Pstride + ((i64)b * Nt + q) * 64 + rib);
+                            ok = ok && !armed(pi[u]) && !armed(po[u]);
+                        }
+                    }
+                    if (__all(ok)) break;
+                    bad = flow_check(spins, fail, done, deadline);
+                    if (bad) break;
+                }
+            }
+            if (!bad && fcheck && reducer) {
+                unsigned spins = 0;
+                for (;;) {
+                    if (__all(!armed(fx[0]) && !armed(fx[1]))) break;
+                    bad = flow_check(spins, fail, done, deadline);
+                    if (bad) break;
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        if (tid + 256 * u < 4 * Nt) fx[u] = ld_sc1(fp + tid + 256 * u);
+                }
+                fv = fmax(fx[0], fx[1]);
+            }
+            if (bad && lane == 0) atomicOr(&lds_exit, bad);
+            if (reducer) {
+                if (fcheck) {
+                    fv = wave_max(fv);
+                    if (lane == 0) fred[k & 1][wave] = fv;
+                }
+                red[k & 1][i][0][qg][r16] = ((pi[0] + pi[1]) + pi[2]) + pi[3];
+                red[k & 1][i][1][qg][r16] = ((po[0] + po[1]) + po[2]) + po[3];
+            }
+            __syncthreads();
+            const int ex = lds_exit;
+            if (ex) { failed = (ex & 2) != 0; converged = !failed; stop = true; break; } // uniform
+            if (fcheck) { // the step-size rule replayed from the same f history by every workgroup, then `while diff > delta`
+                const double f = fmax(fmax(fred[k & 1][0], fred[k & 1][1]), fmax(fred[k & 1][2], fred[k & 1][3]));
+                if (f > fprev) eps *= 0.99;
+                fprev = f;
+                if (!(f > delta)) { converged = 1; stop = true; break; }
+            }
+            if (tid < 16) {
+                double Si = red[k & 1][i][0][0][r16], So = red[k & 1][i][1][0][r16];
+#pragma unroll
+                for (int u = 1; u < 16; u++) { Si += red[k & 1][i][0][u][r16]; So += red[k & 1][i][1][u][r16]; }
+                const i64 row = (i64)64 * b + rib;
+                double fr = 0.0, nin = 0.0, nout = 0.0;
+                if (row < N) {
+                    nin = tin_cur[i];
+                    nout = tout_cur[i];
+                    if (din[i] > 0) { nin = tin_cur[i] + (eps * tin_cur[i]) * (din[i] / Si - 1.0); fr = fmax(fr, fabs(din[i] - Si)); }
+                    if (dout[i] > 0) { nout = tout_cur[i] + (eps * tout_cur[i]) * (dout[i] / So - 1.0); fr = fmax(fr, fabs(dout[i] - So)); }
+                }
+                double *Tn = ring + (i64)((k + 1) & 3) * 2 * Tld, *Ta = ring + (i64)((k + 3) & 3) * 2 * Tld;
+                st_sc1(Tn + row, nin);
+                st_sc1(Tn + Tld + row, nout);
+                tin_cur[i] = nin;
+                tout_cur[i] = nout;
+                fr = row16_max(fr);
+                if (r16 == 0) st_sc1(fq + (i64)(k % 3) * 4 * Nt + sb, fr);
+                st_sc1(Ta + row, sentinel());
+                st_sc1(Ta + Tld + row, sentinel());
+                if (r16 == 0) st_sc1(fq + (i64)((k + 1) % 3) * 4 * Nt + sb, sentinel());
+            }
+            if (reducer) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = qg + 16 * u;
+                    if (q < Nt) {
+                        st_sc1(Pk + ((i64)b * Nt + q) * 64 + rib, sentinel());
+                        st_sc1(Pk + Pstride + ((i64)b * Nt + q) * 64 + rib, sentinel());
+                    }
+                }
+            }
+        }
+        if (wg >= 4 * Nt && bad) break;
+        if (stop) {
+            if (converged && tid == 0) __hip_atomic_store(done, 1u, RLX_AGENT);
+            break;
+        }
+        k++;
+    }
+    if (converged && tid < 16) {
+#pragma unroll
+        for (int i = 0; i < NSB; i++) {
+            const int sb = wg + i * G;
+            const i64 row = (i64)64 * (sb >> 2) + 16 * (sb & 3) + r16;
+            if (sb < 4 * Nt && row < N) {
+                Tin_out[row] = tin_cur[i];
+                Tout_out[row] = tout_cur[i];
+            }
+        }
+    }
+    if (wg == 0 && tid == 0) {
+        flags[0] = converged;
+        flags[1] = k;
+        flags[2] = failed || !converged;
+        flags[3] = 0;
+    }
+}
+
 } // namespace
 
 static hipError_t launch_plain(const void *fn, int G, void **args, size_t lds, hipStream_t st) {
@@ -1051,22 +1313,69 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
 // Directed fit of one alpha from Tin / Tout (N doubles each, updated in place on success).  Returns false when the
 // persistent path does not apply or was abandoned; Tin / Tout are then untouched.
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
-                          const double *deg_out, double eps0, double f0, double delta, i64 *iters) {
+                          const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant) {
     const int Nt = (int)((N + 63) / 64);
     const i64 NT = (i64)Nt * (Nt + 1) / 2, Tld = (i64)Nt * 64;
     int dev = 0, cus = 0;
     HIP_CHECK(hipGetDevice(&dev));
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (cus <= 0) return false;
+    hipStream_t st = c->stream;
+    c->fp_Td.ensure((size_t)4 * Tld);
+    if (variant == 2 && Nt <= 64) { // the data as its own signal: one tile per wave on 4 or 8 waves per CU
+        const int NW = (NT <= (i64)4 * cus) ? 4 : 8;
+        const int Gf = (int)std::min<i64>(cus, std::max<i64>((NT + NW - 1) / NW, (i64)4 * Nt));
+        if (NT <= (i64)NW * Gf && 4 * Nt <= 2 * Gf) {
+            const bool one = 4 * Nt <= Gf; // every workgroup reduces at most one quarter block
+            const void *fn = NW == 8 ? (one ? (const void *)fit_flow_dir_kernel<8, 1> : (const void *)fit_flow_dir_kernel<8, 2>)
+                                     : (one ? (const void *)fit_flow_dir_kernel<4, 1> : (const void *)fit_flow_dir_kernel<4, 2>);
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NW, 0) == hipSuccess && per_cu >= 1) {
+                const size_t pstride = (size_t)Nt * Nt * 64, n_sync = 32, n_ring = (size_t)8 * Tld, n_fq = (size_t)3 * 4 * Nt,
+                             n_p = 4 * pstride;
+                c->fp_flow.ensure(n_sync + n_ring + n_fq + n_p);
+                c->fp_flags.ensure(4);
+                HIP_CHECK(hipMemsetAsync(c->fp_Td.p, 0, sizeof(double) * 2 * Tld, st));
+                HIP_CHECK(hipMemcpyAsync(c->fp_Td.p, Tin, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+                HIP_CHECK(hipMemcpyAsync(c->fp_Td.p + Tld, Tout, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+                HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->fp_flow.p, (int)FLOW_SENTINEL_WORD,
+                                            2 * (n_sync + n_ring + n_fq + n_p), st));
+                const double *aGD = GD, *aT0 = c->fp_Td.p, *aDi = deg_in, *aDo = deg_out;
+                double *aTi = Tin, *aTo = Tout, *aRing = c->fp_flow.p + n_sync, *aFq = aRing + n_ring, *aP = aFq + n_fq;
+                i64 aN = N, aTld = Tld;
+                int aNt = Nt, aMax = 2000000;
+                double aEps = eps0, aF0 = f0, aDelta = delta;
+                unsigned *aSync = (unsigned *)c->fp_flow.p;
+                int *aFlags = c->fp_flags.p;
+                long long aTicks = c->opt_fit_test_timeout ? 0LL : 300000000LL;
+                void *args[] = {&aGD, &aN, &aNt, &aT0, &aTi, &aTo, &aTld, &aDi, &aDo, &aEps, &aF0, &aDelta, &aMax, &aRing, &aP, &aFq,
+                                &aSync, &aFlags, &aTicks};
+                hipError_t e;
+                {
+                    ScopedKernelTimer tm(c, "fit_persistent");
+                    e = hipLaunchKernel(fn, dim3((unsigned)Gf), dim3(64 * NW), args, 0, st);
+                }
+                if (e != hipSuccess) CGE_THROW(CGE_E_HIP, "directed fit launch failed: %s", hipGetErrorString(e));
+                int hf[4];
+                HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (hf[2] || !hf[0]) { // abandoned: Tin / Tout are untouched
+                    if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
+                    return false;
+                }
+                *iters = hf[1];
+                return true;
+            }
+            (void)hipGetLastError();
+        }
+    }
     const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
     const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
     if (tpw > 2 || Nt > 64 || 4096 + 32 * Nt > DF_WORDS) return false; // the directed tile role needs more registers: N <= ~4000
     c->fp_P.ensure((size_t)2 * Nt * Nt * 64);
-    c->fp_Td.ensure((size_t)4 * Tld);
     c->fp_sync.ensure(DF_WORDS);
     c->fp_fq.ensure((size_t)2 * 4 * Nt);
     c->fp_flags.ensure(4);
-    hipStream_t st = c->stream;
     HIP_CHECK(hipMemsetAsync(c->fp_Td.p, 0, sizeof(double) * 4 * Tld, st));
     HIP_CHECK(hipMemcpyAsync(c->fp_Td.p, Tin, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->fp_Td.p + Tld, Tout, sizeof(double) * N, hipMemcpyDeviceToDevice, st));

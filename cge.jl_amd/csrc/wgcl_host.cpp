@@ -372,7 +372,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             }
             Tcur = TT.p + (i64)tpar * Tld;
         } else if (use_persistent_dir &&
-                   k_fit_persistent_dir(c, GD.p, N, T1.p, T2.p, G.deg_in, G.deg_out, 0.9, 1.0, delta, &iters)) {
+                   k_fit_persistent_dir(c, GD.p, N, T1.p, T2.p, G.deg_in, G.deg_out, 0.9, 1.0, delta, &iters, fit_variant)) {
             c->stat_fit_persistent++; // the whole directed fit in one launch (kernels_fitp.hip)
         } else
         for (;;) {

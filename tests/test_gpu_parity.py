@@ -334,10 +334,12 @@ def test_fit_persistent_directed_matches_stepwise_and_oracle(ctx, orc, n):
     args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
     out = {}
     try:
-        for mode in (1, 2):
+        for mode in (1, 2, 4):  # launch pair per iteration / persistent: the data as its own signal / dependency counters
             ctx.set_option("fit_persistent", mode)
             out[mode] = cg.wGCL_directed(*args, samples=smp, trace=True, ctx=ctx)
-            assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode == 2)
+            assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode >= 2)
+        assert np.array_equal(out[2][0], out[4][0]) and out[2][1]["iters"] == out[4][1]["iters"]  # same additions, same order
+        ctx.set_option("fit_persistent", 2)
         ctx.set_option("fit_persistent_test_timeout", 1)  # abandoned launches: the iterates must be untouched
         out[3] = cg.wGCL_directed(*args, samples=smp, trace=True, ctx=ctx)
         assert ctx.get_stat("fit_persistent_alphas") == 0
@@ -387,7 +389,7 @@ def test_fit_persistent_handoffs_under_varied_geometry(ctx):
             ctx.set_option("fit_persistent", 2)
             runs = [fn(*args, samples=smp, trace=True, ctx=ctx) for _ in range(3)]
             assert ctx.get_stat("fit_persistent_alphas") > 0
-            if not directed:  # the counter form of the same fit
+            if True:  # the counter form of the same fit
                 ctx.set_option("fit_persistent", 4)
                 runs.append(fn(*args, samples=smp, trace=True, ctx=ctx))
                 assert ctx.get_stat("fit_persistent_alphas") > 0
