@@ -493,6 +493,20 @@ static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_d
     smp.S = S;
     smp.n_sets = (seed != -1) ? 1 : n_alpha;
     const i64 base = (seed != -1) ? seed : 0x5eedc0de;
+    if (sampler_uses_device(c)) { // large resident graph: drawn, rejected and kept on the device (the same stream of draws)
+        smp.on_device = true;
+        smp.d_pos.ensure(smp.n_sets * S); smp.d_ni.ensure(smp.n_sets * S); smp.d_nj.ensure(smp.n_sets * S);
+        for (i64 t = 0; t < smp.n_sets; t++)
+            k_draw_samples_dev(c, base, t, S, directed, smp.d_pos.p + t * S, smp.d_ni.p + t * S, smp.d_nj.p + t * S);
+        if (exact_directed) { // the un-reseeded second positive draw of :510 (its non-edges are not used)
+            smp.d_pos2.ensure(smp.n_sets * S);
+            DevBuf<i32> di, dj;
+            di.ensure(S); dj.ensure(S);
+            for (i64 t = 0; t < smp.n_sets; t++)
+                k_draw_samples_dev(c, base + 0x7777, 1000 + t, S, directed, smp.d_pos2.p + t * S, di.p, dj.p);
+        }
+        return;
+    }
     smp.pos_idx.resize(smp.n_sets * S);
     smp.neg_i.resize(smp.n_sets * S);
     smp.neg_j.resize(smp.n_sets * S);

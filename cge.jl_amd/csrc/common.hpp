@@ -481,10 +481,40 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
 // wgcl_host.cpp
 struct SampleSet {
     i64 S = 0, n_sets = 0;
-    std::vector<i64> pos_idx, neg_i, neg_j, pos_idx2; // 1-based
+    std::vector<i64> pos_idx, neg_i, neg_j, pos_idx2; // 1-based (caller-provided draws, small graphs)
+    // library-drawn samples of a large resident graph stay on the device (0-based, n_sets * S each)
+    bool on_device = false;
+    DevBuf<i32> d_pos, d_ni, d_nj, d_pos2;
 };
+// ---- counter-based RNG of the sampler (splitmix64 finaliser over a 4-word counter): the same stream on host and device
+__host__ __device__ inline uint64_t cge_sm64(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline uint64_t cge_ctr_rand(uint64_t seed, uint64_t stream, uint64_t k, uint64_t attempt, uint64_t which) {
+    uint64_t h = cge_sm64(seed ^ 0x6a09e667f3bcc909ULL);
+    h = cge_sm64(h ^ (stream * 0xd1342543de82ef95ULL + 1));
+    h = cge_sm64(h ^ (k * 0x2545f4914f6cdd1dULL + 2));
+    h = cge_sm64(h ^ (attempt * 0x9e6c63d0676a9a99ULL + 3));
+    return cge_sm64(h ^ (which + 4));
+}
+// uniform integer in [0, range): multiply-high (bias < range / 2^64)
+__host__ __device__ inline uint64_t cge_bounded(uint64_t r, uint64_t range) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(r, range);
+#else
+    return (uint64_t)(((__uint128_t)r * range) >> 64);
+#endif
+}
+// positive / non-edge draws of one sample set on the device (kernels_fit.hip); 0-based i32 outputs of S entries
+void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i32 *d_pos, i32 *d_ni, i32 *d_nj);
+void k_prep_samples(cge_ctx *c, const i32 *pos, const i32 *pos_pairs, const i32 *ni_in, const i32 *nj_in, const i32 *e_src,
+                    const i32 *e_dst, const double *e_w, i64 S, int directed, i32 *pi, i32 *pj, i32 *ni, i32 *nj, double *wts);
 void host_draw_samples(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i64 *pos_idx, i64 *neg_i, i64 *neg_j);
 void host_pos_draw(i64 seed, i64 stream_id, i64 S, i64 m, i64 *pos_idx);
+bool sampler_uses_device(const cge_ctx *c); // large resident graph: the sampler runs on the device
 struct OrigView { // original graph pieces needed in landmark mode (device, 0-based)
     i64 n = 0, m = 0;
     const double *Xr = nullptr;

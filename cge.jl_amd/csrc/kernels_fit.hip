@@ -696,6 +696,112 @@ void k_mark_edge_hits(cge_ctx *c, const i32 *src, const i32 *dst, i64 m, int dir
 }
 
 // ------------------------------------------------------------------------------------------------
+// The sampler on the device (`sample(E, S)` / `sample(NE, S)`, src/divergence.jl:185-210): the counter-based draws of
+// common.hpp, non-edges by rejection -- the candidate pairs of a round go into an open-addressing table, one pass over
+// the resident edge list marks the candidates that ARE edges (mark_edge_hits_kernel), those are drawn again with the
+// next attempt number.  A sample depends only on (seed, stream, k, attempt): the result does not depend on the order in
+// which threads insert or re-queue.
+__global__ void draw_pos_kernel(uint64_t seed, uint64_t stream, i64 S, i64 m, i32 *__restrict__ pos) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < S) pos[k] = (i32)cge_bounded(cge_ctr_rand(seed, stream, (uint64_t)k, 0, 0), (uint64_t)m);
+}
+__global__ void draw_neg_kernel(uint64_t seed, uint64_t stream, i64 n, int directed, const i32 *__restrict__ todo, i64 cnt,
+                                const unsigned *__restrict__ attempt, i32 *__restrict__ ni, i32 *__restrict__ nj,
+                                unsigned long long *__restrict__ table, i64 mask) {
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cnt) return;
+    const i64 k = todo ? todo[idx] : idx;
+    const uint64_t a = attempt[k];
+    uint64_t i = cge_bounded(cge_ctr_rand(seed, stream, (uint64_t)k, a, 1), (uint64_t)n);
+    uint64_t j = cge_bounded(cge_ctr_rand(seed, stream, (uint64_t)k, a, 2), (uint64_t)(n - 1));
+    if (j >= i) j++; // uniform over ordered pairs i != j
+    if (!directed && i > j) { const uint64_t t = i; i = j; j = t; }
+    ni[k] = (i32)i;
+    nj[k] = (i32)j;
+    const unsigned long long key = (i << 32) | j;
+    i64 slot = (i64)(mixk(key) & (uint64_t)mask);
+    for (;;) {
+        const unsigned long long old = atomicCAS(&table[slot], ~0ULL, key);
+        if (old == ~0ULL || old == key) break;
+        slot = (slot + 1) & mask;
+    }
+}
+__global__ void check_neg_kernel(const i32 *__restrict__ todo, i64 cnt, const i32 *__restrict__ ni, const i32 *__restrict__ nj,
+                                 const unsigned long long *__restrict__ table, i64 mask, const i32 *__restrict__ hit,
+                                 unsigned *__restrict__ attempt, i32 *__restrict__ next, unsigned long long *__restrict__ next_cnt) {
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cnt) return;
+    const i64 k = todo ? todo[idx] : idx;
+    const unsigned long long key = ((unsigned long long)(uint32_t)ni[k] << 32) | (unsigned long long)(uint32_t)nj[k];
+    i64 slot = (i64)(mixk(key) & (uint64_t)mask);
+    while (table[slot] != key) slot = (slot + 1) & mask; // present: inserted by draw_neg_kernel
+    if (hit[slot]) {
+        attempt[k] += 1;
+        next[atomicAdd(next_cnt, 1ULL)] = (i32)k;
+    }
+}
+void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i32 *d_pos, i32 *d_ni, i32 *d_nj) {
+    const i64 n = c->n, m = c->m;
+    hipStream_t st = c->stream;
+    const unsigned nb = (unsigned)((S + 255) / 256);
+    hipLaunchKernelGGL(draw_pos_kernel, dim3(nb), dim3(256), 0, st, (uint64_t)seed, (uint64_t)stream_id, S, m, d_pos);
+    DevBuf<unsigned> attempt;
+    DevBuf<i32> todo_a, todo_b, hit;
+    DevBuf<unsigned long long> table, count;
+    attempt.ensure(S); todo_a.ensure(S); todo_b.ensure(S); count.ensure(1);
+    HIP_CHECK(hipMemsetAsync(attempt.p, 0, sizeof(unsigned) * S, st));
+    i64 cnt = S;
+    const i32 *todo = nullptr; // round 0: every sample
+    i32 *next = todo_a.p;
+    for (int round = 0; round < 64 && cnt > 0; round++) {
+        i64 tsize = 1024;
+        while (tsize < 4 * cnt) tsize <<= 1;
+        table.ensure(tsize);
+        hit.ensure(tsize);
+        HIP_CHECK(hipMemsetAsync(table.p, 0xFF, sizeof(unsigned long long) * tsize, st));
+        HIP_CHECK(hipMemsetAsync(hit.p, 0, sizeof(i32) * tsize, st));
+        HIP_CHECK(hipMemsetAsync(count.p, 0, sizeof(unsigned long long), st));
+        const unsigned g = (unsigned)((cnt + 255) / 256);
+        hipLaunchKernelGGL(draw_neg_kernel, dim3(g), dim3(256), 0, st, (uint64_t)seed, (uint64_t)stream_id, n, directed, todo, cnt,
+                           attempt.p, d_ni, d_nj, table.p, tsize - 1);
+        k_mark_edge_hits(c, c->src.p, c->dst.p, m, directed, reinterpret_cast<const uint64_t *>(table.p), tsize, hit.p);
+        hipLaunchKernelGGL(check_neg_kernel, dim3(g), dim3(256), 0, st, todo, cnt, d_ni, d_nj, table.p, tsize - 1, hit.p, attempt.p,
+                           next, count.p);
+        unsigned long long hc = 0;
+        HIP_CHECK(hipMemcpyAsync(&hc, count.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        cnt = (i64)hc;
+        todo = next;
+        next = (next == todo_a.p) ? todo_b.p : todo_a.p;
+    }
+    if (cnt > 0) CGE_THROW(CGE_E_ARG, "draw_samples: could not find enough non-edges (graph too dense?)");
+}
+// sampled pairs -> what the AUC kernels read: the edge of every positive draw (canonical order when undirected) with the
+// weight of the FIRST draw (the directed exact-mode quirk of :510 overwrites the pairs, not the weights), the non-edges
+__global__ void prep_samples_kernel(const i32 *__restrict__ pos, const i32 *__restrict__ pos_pairs, const i32 *__restrict__ ni_in,
+                                    const i32 *__restrict__ nj_in, const i32 *__restrict__ e_src, const i32 *__restrict__ e_dst,
+                                    const double *__restrict__ e_w, i64 S, int directed, i32 *__restrict__ pi,
+                                    i32 *__restrict__ pj, i32 *__restrict__ ni, i32 *__restrict__ nj, double *__restrict__ wts) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S) return;
+    const i32 rp = pos_pairs[k];
+    i32 a = e_src[rp], b = e_dst[rp];
+    if (!directed && a > b) { const i32 t = a; a = b; b = t; } // E tuple (min,max) :133
+    pi[k] = a;
+    pj[k] = b;
+    wts[k] = e_w ? e_w[pos[k]] : 1.0;
+    i32 u = ni_in[k], v = nj_in[k];
+    if (!directed && u > v) { const i32 t = u; u = v; v = t; }
+    ni[k] = u;
+    nj[k] = v;
+}
+void k_prep_samples(cge_ctx *c, const i32 *pos, const i32 *pos_pairs, const i32 *ni_in, const i32 *nj_in, const i32 *e_src,
+                    const i32 *e_dst, const double *e_w, i64 S, int directed, i32 *pi, i32 *pj, i32 *ni, i32 *nj, double *wts) {
+    hipLaunchKernelGGL(prep_samples_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream, pos, pos_pairs, ni_in, nj_in,
+                       e_src, e_dst, e_w, S, directed, pi, pj, ni, nj, wts);
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ void gather_i32_kernel(const i32 *__restrict__ arr, const i32 *__restrict__ idx, i64 S,
                                   i32 *__restrict__ out) {
     const i64 stride = (i64)gridDim.x * blockDim.x;

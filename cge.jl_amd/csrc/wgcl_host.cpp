@@ -8,22 +8,11 @@
 
 #include "common.hpp"
 
-// ---- counter-based RNG (splitmix64 finaliser over a 4-word counter) ---------------------------------
-static inline uint64_t sm64(uint64_t x) {
-    x += 0x9e3779b97f4a7c15ULL;
-    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
-    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
-    return x ^ (x >> 31);
-}
+// the counter-based RNG of the sampler lives in common.hpp (the device draws the same stream)
 static inline uint64_t ctr_rand(uint64_t seed, uint64_t stream, uint64_t k, uint64_t attempt, uint64_t which) {
-    uint64_t h = sm64(seed ^ 0x6a09e667f3bcc909ULL);
-    h = sm64(h ^ (stream * 0xd1342543de82ef95ULL + 1));
-    h = sm64(h ^ (k * 0x2545f4914f6cdd1dULL + 2));
-    h = sm64(h ^ (attempt * 0x9e6c63d0676a9a99ULL + 3));
-    return sm64(h ^ (which + 4));
+    return cge_ctr_rand(seed, stream, k, attempt, which);
 }
-// uniform integer in [0, range): multiply-high (bias < range / 2^64)
-static inline uint64_t bounded(uint64_t r, uint64_t range) { return (uint64_t)(((__uint128_t)r * range) >> 64); }
+static inline uint64_t bounded(uint64_t r, uint64_t range) { return cge_bounded(r, range); }
 
 static inline uint64_t mixk_host(uint64_t x) { // must match mixk() in kernels_fit.hip
     x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
@@ -71,59 +60,20 @@ void host_draw_samples(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed,
         }
         return;
     }
-    std::vector<uint32_t> attempt(S, 0);
-    std::vector<i64> todo(S);
-    for (i64 k = 0; k < S; k++) todo[k] = k;
-    auto draw = [&](i64 k) {
-        const uint64_t a = attempt[k];
-        uint64_t i = bounded(ctr_rand(sd, st, (uint64_t)k, a, 1), (uint64_t)n);
-        uint64_t j = bounded(ctr_rand(sd, st, (uint64_t)k, a, 2), (uint64_t)(n - 1));
-        if (j >= i) j++; // uniform over ordered pairs i != j
-        if (!directed && i > j) std::swap(i, j);
-        neg_i[k] = (i64)i + 1;
-        neg_j[k] = (i64)j + 1;
-    };
-    for (i64 k = 0; k < S; k++) draw(k);
-    DevBuf<uint64_t> d_table;
-    DevBuf<i32> d_hit;
-    for (int round = 0; round < 64 && !todo.empty(); round++) {
-        i64 tsize = 1024;
-        while (tsize < 4 * (i64)todo.size()) tsize <<= 1;
-        std::vector<uint64_t> table(tsize, ~0ULL);
-        auto slot_of = [&](uint64_t key, bool insert) -> i64 {
-            i64 s = (i64)(mixk_host(key) & (uint64_t)(tsize - 1));
-            for (;;) {
-                if (table[s] == key) return s;
-                if (table[s] == ~0ULL) {
-                    if (!insert) return -1;
-                    table[s] = key;
-                    return s;
-                }
-                s = (s + 1) & (tsize - 1);
-            }
-        };
-        for (i64 k : todo) slot_of(((uint64_t)(neg_i[k] - 1) << 32) | (uint64_t)(neg_j[k] - 1), true);
-        d_table.ensure(tsize);
-        d_hit.ensure(tsize);
-        HIP_CHECK(hipMemcpyAsync(d_table.p, table.data(), sizeof(uint64_t) * tsize, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemsetAsync(d_hit.p, 0, sizeof(i32) * tsize, c->stream));
-        k_mark_edge_hits(c, c->src.p, c->dst.p, m, directed, d_table.p, tsize, d_hit.p);
-        std::vector<i32> hit(tsize);
-        HIP_CHECK(hipMemcpyAsync(hit.data(), d_hit.p, sizeof(i32) * tsize, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        std::vector<i64> again;
-        for (i64 k : todo) {
-            const i64 s = slot_of(((uint64_t)(neg_i[k] - 1) << 32) | (uint64_t)(neg_j[k] - 1), false);
-            if (s >= 0 && hit[s]) {
-                attempt[k]++;
-                draw(k);
-                again.push_back(k);
-            }
-        }
-        todo.swap(again);
+    // large graphs: drawn and rejected against the resident edge list on the device (kernels_fit.hip), copied back here
+    DevBuf<i32> d_pos, d_ni, d_nj;
+    d_pos.ensure(S); d_ni.ensure(S); d_nj.ensure(S);
+    k_draw_samples_dev(c, seed, stream_id, S, directed, d_pos.p, d_ni.p, d_nj.p);
+    std::vector<i32> hi_(S), hj_(S);
+    HIP_CHECK(hipMemcpyAsync(hi_.data(), d_ni.p, sizeof(i32) * S, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(hj_.data(), d_nj.p, sizeof(i32) * S, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (i64 k = 0; k < S; k++) {
+        neg_i[k] = (i64)hi_[k] + 1;
+        neg_j[k] = (i64)hj_[k] + 1;
     }
-    if (!todo.empty()) CGE_THROW(CGE_E_ARG, "draw_samples: could not find enough non-edges (graph too dense?)");
 }
+bool sampler_uses_device(const cge_ctx *c) { return (double)c->n * (double)(c->n - 1) > 33554432.0; }
 
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -231,7 +181,21 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     const double *e_hw = landmarks ? orig->h_w : ex_hw;
     const i64 e_m = landmarks ? orig->m : ex_m;
     std::vector<DevSamples> dsets(smp.n_sets);
-    {
+    if (smp.on_device) { // library-drawn samples of the resident graph: everything stays on the device
+        for (i64 t = 0; t < smp.n_sets; t++) {
+            DevSamples &ds = dsets[t];
+            ds.pi.ensure(S); ds.pj.ensure(S); ds.ni.ensure(S); ds.nj.ensure(S); ds.wts.ensure(S);
+            const i32 *pos = smp.d_pos.p + t * S;
+            const i32 *pos_pairs = (directed && !landmarks && smp.d_pos2.p) ? smp.d_pos2.p + t * S : pos; // the overwriting draw (:510)
+            k_prep_samples(c, pos, pos_pairs, smp.d_ni.p + t * S, smp.d_nj.p + t * S, e_src, e_dst, c->w.p, S, directed, ds.pi.p,
+                           ds.pj.p, ds.ni.p, ds.nj.p, ds.wts.p);
+            if (landmarks) { // full_graph_D of the sampled pairs, normalised by hi (lo == 0) :104-114
+                ds.dpos.ensure(S); ds.dneg.ensure(S);
+                k_pair_dist(c, orig->Xr, d, ds.pi.p, ds.pj.p, S, orig->hi, ds.dpos.p);
+                k_pair_dist(c, orig->Xr, d, ds.ni.p, ds.nj.p, S, orig->hi, ds.dneg.p);
+            }
+        }
+    } else {
         DevBuf<i32> d_idx, d_tmp;
         std::vector<i64> rows0(S);
         std::vector<i32> hs, hd, hs2, hd2;
