@@ -255,7 +255,7 @@ struct cge_ctx {
     DevBuf<double> sw_Lh;
     DevBuf<float> sw_Ll;
     int opt_test_bvec_plain = 0; // testing: vect_B without LDS staging / rows in flight (the forms of very large score graphs)
-    int opt_fit_persistent = 0; // 0 auto (score graphs of >= 512 vertices that fit the register file), 1 never, 2 whenever it
+    int opt_fit_persistent = 0; // 0 auto (score graphs of >= 128 vertices that fit the register file), 1 never, 2 whenever it
                                 // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
     int opt_speculation_pct = 40;  // global phase: share of the still missing pops that one round may split speculatively
     int opt_fit_test_timeout = 0; // testing: the persistent fit gives up at once, so the fallback path runs

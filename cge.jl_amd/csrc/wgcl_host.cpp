@@ -168,9 +168,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     HIP_CHECK(hipMemcpyAsync(TT.p, T1.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
     double *Tcur = TT.p;
     bool use_persistent = !directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
-                          (c->opt_fit_persistent >= 2 || N >= 512);
+                          (c->opt_fit_persistent >= 2 || N >= 128);
     bool use_persistent_dir = directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
-                              (c->opt_fit_persistent >= 2 || N >= 512);
+                              (c->opt_fit_persistent >= 2 || N >= 128);
     c->stat_fit_persistent = 0;
     c->stat_fit_iters = 0;
 

@@ -190,7 +190,7 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             1 = always brute force, 2 = always pruned.  All three return the same exact value.
  * "fit_persistent": how the Chung-Lu fixed point (src/divergence.jl:150-168, :434-467) is launched.
  *             0 = auto: one persistent launch per alpha (the matrix register-resident, the workgroups exchanging
- *                 partial sums and iterates by polling the data itself) for score graphs of >= 512 vertices that fit
+ *                 partial sums and iterates by polling the data itself) for score graphs of >= 128 vertices that fit
  *                 the register file (N <= ~4900 undirected, ~4000 directed on 256 CUs), else one launch per iteration;
  *             1 = always one launch per iteration; 2 = persistent whenever it fits; 3 / 4 = 2 with grid barriers /
  *             with per-block dependency counters instead (undirected only; the directed fit always uses counters).
