@@ -60,6 +60,8 @@ class TorchCollectives:
             off = (int(ptr) - self.base) // 8
             t = self.buf[off: off + int(count)]
             rop = self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM
+            if op == 2:  # the 8-byte words as integers: an exact gather of disjoint shards into zero-filled buffers
+                t = t.view(self.torch.int64)
             if t.is_cuda and self.dist.get_backend() == "gloo":  # rehearsal on one GPU: stage through the host
                 h = t.cpu()
                 self.dist.all_reduce(h, op=rop)

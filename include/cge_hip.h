@@ -65,7 +65,8 @@ int cge_set_host_threads(cge_ctx *ctx, int n_threads); /* host worker pool for e
 /* Cross-GPU hooks (optional).  `buf` is a DEVICE pointer into the ctx's exchange buffer (obtain it
  * with cge_exchange_buffer and wrap it once on the host side); count is in doubles.  The hook must
  * order itself after work already enqueued on the ctx stream and leave the reduced data in place
- * (stream-ordered or synchronous).  op: 0 = sum, 1 = max.                                        */
+ * (stream-ordered or synchronous).  op: 0 = sum, 1 = max, 2 = sum of the 8-byte words taken as
+ * int64 (an exact gather of disjoint shards written into zero-filled buffers).                       */
 typedef struct {
     int (*allreduce_f64)(void *user, void *buf, int64_t count, int op);
     void *user;

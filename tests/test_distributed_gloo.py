@@ -90,6 +90,15 @@ def _worker(rank, world, port, q):
         coll.buf[20] = float(10 + rank)
         assert coll._hook(None, coll.base + 20 * 8, 1, 1) == 0
         assert coll.buf[20].item() == 11.0 and coll.n_calls == 2 and coll.bytes == 40
+        # op 2: the words as int64 -- disjoint shards in zero-filled buffers are gathered bit for bit (-0.0, NaN payloads, packed ints)
+        coll.buf[30:34] = 0
+        mine = torch.tensor([-0.0, float("nan")], dtype=torch.float64) if rank == 0 else \
+            torch.tensor([123456789], dtype=torch.int64).view(torch.float64).repeat(2)
+        coll.buf[30 + 2 * rank: 32 + 2 * rank] = mine
+        assert coll._hook(None, coll.base + 30 * 8, 4, 2) == 0
+        got = coll.buf[30:34].view(torch.int64).tolist()
+        assert got[0] == -(2 ** 63) and got[1] == torch.tensor([float("nan")], dtype=torch.float64).view(torch.int64).item()
+        assert got[2] == got[3] == 123456789
         q.put((rank, "ok"))
     except Exception as e:  # surface the failure in the parent
         import traceback
