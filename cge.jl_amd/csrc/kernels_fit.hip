@@ -167,6 +167,15 @@ __global__ __launch_bounds__(256) void exp2_matrix_upper_kernel(const double *__
 void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only) {
     c->pow_logs_N = 0;
     if (!c->opt_pow_exp2) return;
+    { // 12 bytes per entry of D: only when they fit comfortably (exact mode at n ~ 10^5 keeps two n x n matrices already)
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)N * N * 12;
+        const size_t have = c->sw_Lh.n * sizeof(double) + c->sw_Ll.n * sizeof(float);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (need > have && need - have > free_b / 2)) {
+            (void)hipGetLastError();
+            return;
+        }
+    }
     c->sw_Lh.ensure((size_t)N * N);
     c->sw_Ll.ensure((size_t)N * N);
     ScopedKernelTimer t(c, "pow_log2");

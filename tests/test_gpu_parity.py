@@ -851,6 +851,33 @@ def test_larger_graph_invariants(ctx):
     assert hi >= np.sqrt(((g["embedding"][ii] - g["embedding"][jj]) ** 2).sum(1)).max()
 
 
+def test_exact_mode_beyond_the_reference_limit(ctx):
+    """`--force-exact` (v_to_l = Int[], N = n) at 20 000 vertices -- twice the size at which the
+    reference switches to landmarks because of its O(n^2) host objects (src/auxilary.jl:194-197).  Nothing O(n^2) lives on
+    the host here; D, GD and log2(1 - D) are device matrices.  Beyond the oracle's reach in test time: the run must be
+    bitwise reproducible, agree between the two power formulations and keep the sweep's invariants."""
+    from cge.jl_amd import synth
+
+    n = 20000
+    g = synth.abcd_like(n, 10 * n, 30, 16, seed=7)
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    r1 = ctx.score([], -1, seed=3, auc_samples=10000)
+    it1 = ctx.get_stat("fit_iterations")
+    r2 = ctx.score([], -1, seed=3, auc_samples=10000)
+    assert np.array_equal(r1, r2) and ctx.get_stat("fit_iterations") == it1
+    try:
+        ctx.set_option("pow_exp2", 0)
+        r3 = ctx.score([], -1, seed=3, auc_samples=10000)
+    finally:
+        ctx.set_option("pow_exp2", 1)
+    assert ctx.get_stat("fit_iterations") == it1 and np.allclose(r1, r3, rtol=1e-11, atol=1e-14)
+    assert len(r1) == 7 and np.all(np.isfinite(r1))
+    assert 0.25 <= r1[0] <= 10.0 and (r1[0] / 0.25) == round(r1[0] / 0.25) and 0.25 <= r1[4] <= 10.0
+    assert 0.0 < r1[1] < np.log(2.0) and r1[2] == 0.0 and r1[3] == 0.0 and 0.0 <= r1[5] <= 1.0
+    assert r1[6] == pytest.approx(1.96 * np.sqrt(r1[5] * (1.0 - r1[5]) / 10000), rel=1e-12)
+    assert ctx.get_stat("fit_persistent_alphas") == 0 and it1 > 100  # 20 000 vertices: one launch per iteration
+
+
 def test_headline_size_properties(ctx):
     """BASELINE.json's headline size (n = 10^6, m ~ 10^7, d = 128, -l 4000): no oracle can run here, so the
     size-independent properties of SURVEY.md §8c: partition validity, exact weight sums, centroids of sampled
