@@ -889,6 +889,10 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_pow_exp2 = value != 0;
         return CGE_OK;
     }
+    if (!strcmp(key, "shard_forced_phase")) { // N > 1 only: 1 (default) = communities of the forced phase split over the ranks
+        c->opt_shard_forced = value != 0;
+        return CGE_OK;
+    }
     if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;

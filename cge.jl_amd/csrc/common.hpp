@@ -254,6 +254,7 @@ struct cge_ctx {
     bool pow_logs_upper = false;
     DevBuf<double> sw_Lh;
     DevBuf<float> sw_Ll;
+    int opt_shard_forced = 1; // N > 1: the forced per-community phase of runsplit is split over the ranks
     int opt_test_bvec_plain = 0; // testing: vect_B without LDS staging / rows in flight (the forms of very large score graphs)
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 128 vertices that fit the register file), 1 never, 2 whenever it
                                 // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
@@ -441,6 +442,9 @@ void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean);
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
                         double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad);
 // alpha sweep
+void k_copy_segments(cge_ctx *c, const i32 *src, const i64 *seg, i64 nseg, i32 *dst);
+void k_gather_means_slots(cge_ctx *c, const double *arena, const i64 *off, const i64 *slot, i64 T, i64 d, i64 stride, i64 lead,
+                          double *dst);
 void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only);
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD, bool upper_only = false);
 void k_pow_test(cge_ctx *c, const double *x, i64 n, double alpha, int method, double *out);

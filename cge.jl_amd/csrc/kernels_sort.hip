@@ -245,6 +245,27 @@ __global__ void gather_means_kernel(const double *__restrict__ arena, const i64 
     const double *src = arena + off[t];
     for (i64 q = threadIdx.x; q < d; q += blockDim.x) mean[t * d + q] = src[q];
 }
+// dst[seg[3s+1] + j] = src[seg[3s] + j], j < seg[3s+2]: one workgroup per segment (member lists moved between ranges)
+__global__ void copy_segments_kernel(const i32 *__restrict__ src, const i64 *__restrict__ seg, i32 *__restrict__ dst) {
+    const i64 so = seg[3 * blockIdx.x], dof = seg[3 * blockIdx.x + 1], len = seg[3 * blockIdx.x + 2];
+    for (i64 j = threadIdx.x; j < len; j += blockDim.x) dst[dof + j] = src[so + j];
+}
+void k_copy_segments(cge_ctx *c, const i32 *src, const i64 *seg, i64 nseg, i32 *dst) {
+    if (nseg > 0) hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)nseg), dim3(256), 0, c->stream, src, seg, dst);
+}
+// dst[slot[t] * stride + lead + q] = arena[off[t] + q], q < d (means of groups into strided records)
+__global__ void gather_means_slots_kernel(const double *__restrict__ arena, const i64 *__restrict__ off,
+                                          const i64 *__restrict__ slot, i64 d, i64 stride, i64 lead, double *__restrict__ dst) {
+    const i64 t = blockIdx.x;
+    const double *src = arena + off[t];
+    double *out = dst + slot[t] * stride + lead;
+    for (i64 q = threadIdx.x; q < d; q += blockDim.x) out[q] = src[q];
+}
+void k_gather_means_slots(cge_ctx *c, const double *arena, const i64 *off, const i64 *slot, i64 T, i64 d, i64 stride, i64 lead,
+                          double *dst) {
+    if (T > 0)
+        hipLaunchKernelGGL(gather_means_slots_kernel, dim3((unsigned)T), dim3(128), 0, c->stream, arena, off, slot, d, stride, lead, dst);
+}
 void k_gather_means(cge_ctx *c, const double *arena, const i64 *off, i64 T, i64 d, double *mean) {
     hipLaunchKernelGGL(gather_means_kernel, dim3((unsigned)T), dim3(128), 0, c->stream, arena, off, d, mean);
 }

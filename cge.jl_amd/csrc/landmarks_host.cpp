@@ -1029,6 +1029,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     // ---- forced per-community phase (:282-313): every big community owns a local heap -----------
     struct Local { Heap h; i64 pos; };
     std::vector<Local> locals;
+    bool sharded_forced = false;
     // global-heap insertion order must follow the sorted community order, so first split all the
     // local heaps (independent of each other), then insert community by community.
     for (i64 q = 0; q < ncl; q++) {
@@ -1050,10 +1051,109 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             for (auto &L : locals) roots.push_back(L.h.top());
             device_group_values(c, roots);
         }
+        // N > 1: the local heaps are independent of each other, so every rank splits its share of the communities
+        // (balanced by rows) and the results -- member lists in pop order, lengths, heap values, means -- are gathered by ONE
+        // all-reduce into zero-filled buffers (op 2: integer sum of the words, exact).  Afterwards EVERY rank, owner or not,
+        // rebuilds the groups from the gathered data, so all ranks continue from identical state.
+        const i64 nbig = (i64)locals.size(), W = c->has_coll ? c->coll.world : 1;
+        const i64 s_words = (total + 1) / 2, m_per = 3 + d; // per group: length, value, mean flag, mean
+        const i64 x_need = s_words + nbig + nbig * forced * m_per;
+        const bool shard = W > 1 && c->opt_shard_forced && forced >= 2 && c->xptr && (size_t)x_need <= c->xcap;
+        std::vector<int> owner(nbig, 0);
+        if (shard) { // longest first, each to the least loaded rank (deterministic)
+            std::vector<i64> ord(nbig), load(W, 0);
+            for (i64 b = 0; b < nbig; b++) ord[b] = b;
+            std::stable_sort(ord.begin(), ord.end(), [&](i64 a, i64 b) { return locals[a].h.top()->len > locals[b].h.top()->len; });
+            for (i64 b : ord) {
+                const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                owner[b] = r;
+                load[r] += locals[b].h.top()->len;
+            }
+        }
+        const int me = shard ? c->coll.rank : 0;
         std::vector<Heap *> hs;
         std::vector<i64> tg;
-        for (auto &L : locals) { hs.push_back(&L.h); tg.push_back(forced); }
-        advance_heaps(c, hs, tg, method, pool, false);
+        for (i64 b = 0; b < nbig; b++)
+            if (owner[b] == me) { hs.push_back(&locals[b].h); tg.push_back(forced); }
+        if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false);
+        if (shard) {
+            PhaseAcc px(c, "lm_exchange");
+            double *X = c->xptr;
+            i32 *S = reinterpret_cast<i32 *>(X);
+            double *Mc = X + s_words, *Mg = Mc + nbig; // counts per community; per group {len, value, flag, mean[d]}
+            HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * x_need, st));
+            std::vector<i64> seg, moff;
+            std::vector<double> hc(nbig, 0.0), hg((size_t)nbig * forced * 3, 0.0);
+            std::vector<i64> gslot; // slot (b * forced + s) of every owned group, in the order of `moff`
+            for (i64 b = 0; b < nbig; b++) {
+                if (owner[b] != me) continue;
+                Heap &L = locals[b].h;
+                const i64 cidx = order[locals[b].pos];
+                i64 at = cl_off[cidx], s_ = 0;
+                if ((i64)L.len() > forced) CGE_THROW(CGE_E_ASSERT, "forced phase: a local heap grew beyond its target");
+                hc[b] = (double)L.len();
+                while (L.len() > 0) { // pop order = the order in which the global heap receives them (:309-312)
+                    Group *g = L.pop();
+                    seg.push_back(g->off); seg.push_back(at); seg.push_back(g->len);
+                    const size_t sl = (size_t)(b * forced + s_);
+                    hg[3 * sl] = (double)g->len;
+                    hg[3 * sl + 1] = g->value;
+                    hg[3 * sl + 2] = g->mean_off >= 0 ? 1.0 : 0.0;
+                    if (g->mean_off >= 0) { moff.push_back(g->mean_off); gslot.push_back((i64)sl); }
+                    at += g->len;
+                    s_++;
+                }
+                if (at != cl_off[cidx + 1]) CGE_THROW(CGE_E_ASSERT, "forced phase: groups do not cover their community");
+            }
+            // member lists -> their community's range of S; {len, value, flag} and the means -> Mg
+            DevBuf<i64> d_seg, d_moff;
+            if (!seg.empty()) {
+                d_seg.ensure(seg.size());
+                HIP_CHECK(hipMemcpyAsync(d_seg.p, seg.data(), sizeof(i64) * seg.size(), hipMemcpyHostToDevice, st));
+                k_copy_segments(c, c->lm_arena.p, d_seg.p, (i64)seg.size() / 3, S);
+            }
+            HIP_CHECK(hipMemcpyAsync(Mc, hc.data(), sizeof(double) * nbig, hipMemcpyHostToDevice, st));
+            // the three scalars of every slot (strided into Mg) and the means
+            HIP_CHECK(hipMemcpy2DAsync(Mg, sizeof(double) * m_per, hg.data(), sizeof(double) * 3, sizeof(double) * 3,
+                                       (size_t)nbig * forced, hipMemcpyHostToDevice, st));
+            if (!moff.empty()) {
+                d_moff.ensure(2 * moff.size());
+                HIP_CHECK(hipMemcpyAsync(d_moff.p, moff.data(), sizeof(i64) * moff.size(), hipMemcpyHostToDevice, st));
+                HIP_CHECK(hipMemcpyAsync(d_moff.p + moff.size(), gslot.data(), sizeof(i64) * gslot.size(), hipMemcpyHostToDevice, st));
+                k_gather_means_slots(c, c->lm_means.p, d_moff.p, d_moff.p + moff.size(), (i64)moff.size(), d, m_per, 3, Mg);
+            }
+            cge_allreduce_dev(c, X, x_need, 2);
+            // every rank: communities back into the start of the arena, one means block, fresh groups
+            HIP_CHECK(hipMemcpyAsync(c->lm_arena.p, S, sizeof(i32) * total, hipMemcpyDeviceToDevice, st));
+            c->lm_arena_used = total;
+            std::vector<double> all((size_t)nbig + (size_t)nbig * forced * m_per);
+            HIP_CHECK(hipMemcpyAsync(all.data(), Mc, sizeof(double) * all.size(), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            c->lm_means_used = 0;
+            const i64 mbase = means_alloc(c, nbig * forced * d);
+            HIP_CHECK(hipMemcpy2DAsync(c->lm_means.p + mbase, sizeof(double) * d, Mg + 3, sizeof(double) * m_per, sizeof(double) * d,
+                                       (size_t)nbig * forced, hipMemcpyDeviceToDevice, st));
+            for (i64 b = 0; b < nbig; b++) {
+                Heap &L = locals[b].h;
+                L = Heap(); // (an unsplit root of another rank's community, or empty after the pops above)
+                const i64 cidx = order[locals[b].pos], cnt = (i64)all[b];
+                i64 at = cl_off[cidx];
+                for (i64 s_ = 0; s_ < cnt; s_++) {
+                    const double *rec = &all[(size_t)nbig + (size_t)(b * forced + s_) * m_per];
+                    pool.emplace_back();
+                    Group *g = &pool.back();
+                    g->off = at;
+                    g->len = (i64)rec[0];
+                    g->value = rec[1];
+                    g->mean_off = rec[2] != 0.0 ? mbase + (b * forced + s_) * d : -1;
+                    at += g->len;
+                    L.a.push_back(g); // kept in pop order: the merge below reads the array front to back
+                }
+                if (at != cl_off[cidx + 1]) CGE_THROW(CGE_E_ASSERT, "forced phase: gathered groups do not cover their community");
+            }
+            HIP_CHECK(hipStreamSynchronize(st)); // seg / moff staging goes out of scope
+            sharded_forced = true;
+        }
     }
     PhaseAcc *pmerge = new PhaseAcc(c, "lm_merge");
     size_t li = 0;
@@ -1070,7 +1170,10 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             }
         } else {
             Heap &L = locals[li++].h;
-            while (L.len() > 0) H.put(L.pop()); // :309-312
+            if (sharded_forced) { // already in pop order
+                for (size_t q2 = 1; q2 < L.a.size(); q2++) H.put(L.a[q2]);
+            } else
+                while (L.len() > 0) H.put(L.pop()); // :309-312
         }
     }
     delete pmerge;

@@ -1,9 +1,11 @@
-"""Two ranks on the one GPU of the test box (gloo between them): the N > 1 path of the library itself -- edge shards,
-the sharded centroid pass and candidate tiles of the diameter, the three all-reduces through the collective hook --
+"""Two ranks on the one GPU of the test box (gloo between them): the N > 1 path of the library itself -- the forced
+per-community phase of runsplit split over the ranks, edge shards, the sharded centroid pass and candidate tiles of the
+diameter, the four all-reduces through the collective hook --
 must reproduce the one-rank score.  (RCCL over xGMI needs several GPUs; the driver's scaling run covers that.  Two
 processes cannot both keep a persistent grid resident on one GPU, so the ranks use the launch-per-iteration fit.)"""
 import os
 import socket
+import zlib
 
 import numpy as np
 import pytest
@@ -51,12 +53,13 @@ def _rank(rank, world, port, q):
         ctx.set_option("fit_persistent", 1)
         res = ctx.score(g["clusters"], 600, 2, "rss", seed=5, auc_samples=4000)
         hi = ctx.last_diameter()[0]
-        q.put((rank, res.tolist(), hi, coll.n_calls))
+        v2l = ctx.landmarks_fetch()[6]
+        q.put((rank, res.tolist(), hi, coll.n_calls, int(zlib.crc32(v2l.tobytes()))))
         ctx.close()
     except Exception as e:  # surface the failure in the parent
         import traceback
 
-        q.put((rank, traceback.format_exc() + repr(e), None, None))
+        q.put((rank, traceback.format_exc() + repr(e), None, None, None))
     finally:
         import torch.distributed as dist
 
@@ -73,6 +76,7 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx):
         ctx.set_option("fit_persistent", 1)
         ref = ctx.score(g["clusters"], 600, 2, "rss", seed=5, auc_samples=4000)
         hi_ref = ctx.last_diameter()[0]
+        crc_ref = int(zlib.crc32(ctx.landmarks_fetch()[6].tobytes()))
     finally:
         ctx.set_option("fit_persistent", 0)
     mpc = mp.get_context("spawn")
@@ -84,10 +88,13 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx):
     results = sorted(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(120)
-    for rank, res, hi, n_calls in results:
+    for rank, res, hi, n_calls, crc in results:
         assert hi is not None, res  # a traceback otherwise
+        assert crc == crc_ref  # v_to_l: the forced phase of runsplit split over the ranks gives the same landmark ids
         assert hi == hi_ref  # the exact diameter: a maximum over shards
         assert res[0] == ref[0] and res[4] == ref[4]
         assert np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
-        assert n_calls == 3  # vect_C (sum), the centroid bounds (max), the diameter (max)
+        # the forced phase's groups (gather), vect_C (sum), the centroid bounds (max), the diameter (max); the fetch above
+        # adds the landmark-pair matrix (sum)
+        assert n_calls == 5
     assert results[0][1] == results[1][1]  # both ranks hold the same bits
