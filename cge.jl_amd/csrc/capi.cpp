@@ -889,8 +889,9 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_pow_exp2 = value != 0;
         return CGE_OK;
     }
-    if (!strcmp(key, "shard_forced_phase")) { // N > 1 only: 1 (default) = communities of the forced phase split over the ranks
-        c->opt_shard_forced = value != 0;
+    if (!strcmp(key, "shard_runsplit")) { // N > 1 only: 0 = runsplit replicated, 1 (default) = forced phase and big batches of the
+        if (value < 0 || value > 2) return CGE_E_ARG; // global phase split over the ranks, 2 = every batch (tests)
+        c->opt_shard_forced = (int)value;
         return CGE_OK;
     }
     if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget

@@ -875,6 +875,108 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
     }
 }
 
+// N > 1, global phase: the groups of a batch are independent, so every rank cuts its share (longest first, each to the
+// least loaded rank) and the results -- status, cut position, children values, children member lists and means -- are
+// gathered by one all-reduce into zero-filled buffers (hook op 2, exact).  EVERY rank, owner or not, then re-allocates the
+// children ranges and means in the batch's order and takes the gathered values: all ranks stay in identical state.
+// Worth it only for batches with enough rows to outweigh the exchange.
+void compute_splits_sharded(cge_ctx *c, std::vector<Group *> &batch, int method) {
+    const i64 W = c->has_coll ? c->coll.world : 1, d = c->d, T = (i64)batch.size();
+    i64 R = 0;
+    for (Group *g : batch) R += g->len;
+    const i64 s_words = (R + 1) / 2, m_per = 5 + 2 * d; // per group: rc, nlow, vlow, vhigh, means flag, two means
+    const i64 x_need = s_words + T * m_per;
+    // (option value 2: every batch, whatever its size -- the tests)
+    if (W <= 1 || !c->opt_shard_forced || (c->opt_shard_forced == 1 && (T < 2 * W || R * d < ((i64)1 << 23))) || !c->xptr ||
+        (size_t)x_need > c->xcap) {
+        compute_splits(c, batch, method);
+        return;
+    }
+    hipStream_t st = c->stream;
+    std::vector<i64> ord(T), load(W, 0), prefix(T + 1, 0);
+    std::vector<int> owner(T, 0);
+    for (i64 t = 0; t < T; t++) { ord[t] = t; prefix[t + 1] = prefix[t] + batch[t]->len; }
+    std::stable_sort(ord.begin(), ord.end(), [&](i64 a, i64 b) { return batch[a]->len > batch[b]->len; });
+    for (i64 t : ord) {
+        const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        owner[t] = r;
+        load[r] += batch[t]->len;
+    }
+    const int me = c->coll.rank;
+    const i64 A0 = c->lm_arena_used, M0 = c->lm_means_used;
+    std::vector<Group *> mine;
+    for (i64 t = 0; t < T; t++)
+        if (owner[t] == me) mine.push_back(batch[t]);
+    if (!mine.empty()) compute_splits(c, mine, method);
+    PhaseAcc px(c, "lm_exchange");
+    double *X = c->xptr;
+    i32 *S = reinterpret_cast<i32 *>(X);
+    double *Mg = X + s_words;
+    HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * x_need, st));
+    std::vector<i64> seg, moff, mslot;
+    std::vector<double> hg((size_t)T * 5, 0.0);
+    for (i64 t = 0; t < T; t++) {
+        if (owner[t] != me) continue;
+        Group *g = batch[t];
+        hg[5 * t] = (double)g->rc;
+        if (g->rc != CGE_OK) continue;
+        hg[5 * t + 1] = (double)g->nlow;
+        hg[5 * t + 2] = g->vlow;
+        hg[5 * t + 3] = g->vhigh;
+        hg[5 * t + 4] = g->cmean_off >= 0 ? 1.0 : 0.0;
+        seg.push_back(g->coff); seg.push_back(prefix[t]); seg.push_back(g->len);
+        if (g->cmean_off >= 0) { // the two means are adjacent in the means arena: two rows of d for the gather kernel
+            moff.push_back(g->cmean_off); mslot.push_back(2 * t);
+            moff.push_back(g->cmean_off + d); mslot.push_back(2 * t + 1);
+        }
+    }
+    DevBuf<i64> d_seg, d_moff;
+    if (!seg.empty()) {
+        d_seg.ensure(seg.size());
+        HIP_CHECK(hipMemcpyAsync(d_seg.p, seg.data(), sizeof(i64) * seg.size(), hipMemcpyHostToDevice, st));
+        k_copy_segments(c, c->lm_arena.p, d_seg.p, (i64)seg.size() / 3, S);
+    }
+    HIP_CHECK(hipMemcpy2DAsync(Mg, sizeof(double) * m_per, hg.data(), sizeof(double) * 5, sizeof(double) * 5, (size_t)T,
+                               hipMemcpyHostToDevice, st));
+    if (!moff.empty()) { // slot q = 2t + (0 low / 1 high) -> Mg + t * m_per + 5 + (q & 1) * d: stride d over a view that starts at
+        // Mg + 5 only works when m_per == 2d; use the generic form: one record per HALF group of stride m_per / 2 is not
+        // integral, so the kernel gets (slot, stride, lead) per row through two launches (low halves, high halves)
+        std::vector<i64> off_lo, off_hi, slot_t;
+        for (size_t q = 0; q < moff.size(); q += 2) { off_lo.push_back(moff[q]); off_hi.push_back(moff[q + 1]); slot_t.push_back(mslot[q] / 2); }
+        const size_t nq = slot_t.size();
+        d_moff.ensure(3 * nq);
+        HIP_CHECK(hipMemcpyAsync(d_moff.p, off_lo.data(), sizeof(i64) * nq, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_moff.p + nq, off_hi.data(), sizeof(i64) * nq, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_moff.p + 2 * nq, slot_t.data(), sizeof(i64) * nq, hipMemcpyHostToDevice, st));
+        k_gather_means_slots(c, c->lm_means.p, d_moff.p, d_moff.p + 2 * nq, (i64)nq, d, m_per, 5, Mg);
+        k_gather_means_slots(c, c->lm_means.p, d_moff.p + nq, d_moff.p + 2 * nq, (i64)nq, d, m_per, 5 + d, Mg);
+        HIP_CHECK(hipStreamSynchronize(st)); // off_lo / off_hi / slot_t go out of scope
+    }
+    cge_allreduce_dev(c, X, x_need, 2);
+    // every rank: the same ranges and means in the batch's order, the gathered values
+    c->lm_arena_used = A0;
+    c->lm_means_used = M0;
+    const i64 base = arena_alloc(c, R), mbase = means_alloc(c, T * 2 * d);
+    HIP_CHECK(hipMemcpyAsync(c->lm_arena.p + base, S, sizeof(i32) * R, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpy2DAsync(c->lm_means.p + mbase, sizeof(double) * 2 * d, Mg + 5, sizeof(double) * m_per, sizeof(double) * 2 * d,
+                               (size_t)T, hipMemcpyDeviceToDevice, st));
+    std::vector<double> all((size_t)T * 5);
+    HIP_CHECK(hipMemcpy2DAsync(all.data(), sizeof(double) * 5, Mg, sizeof(double) * m_per, sizeof(double) * 5, (size_t)T,
+                               hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (i64 t = 0; t < T; t++) {
+        Group *g = batch[t];
+        g->has_split = true;
+        g->rc = (int)all[5 * t];
+        if (g->rc != CGE_OK) continue;
+        g->coff = base + prefix[t];
+        g->nlow = (i64)all[5 * t + 1];
+        g->vlow = all[5 * t + 2];
+        g->vhigh = all[5 * t + 3];
+        g->cmean_off = all[5 * t + 4] != 0.0 ? mbase + t * 2 * d : -1;
+    }
+}
+
 void throw_rc(int rc) {
     switch (rc) {
     case CGE_E_HOMOGENEOUS: CGE_THROW(rc, "Trying to split homogenous cluster");
@@ -979,7 +1081,8 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
         }
         delete ph;
         if (batch.empty()) break;
-        compute_splits(c, batch, method);
+        if (speculate) compute_splits_sharded(c, batch, method); // the global phase (N > 1: split over the ranks)
+        else compute_splits(c, batch, method);
         PhaseAcc pm(c, "lm_materialise");
         materialise_children(batch, pool, c->d);
     }

@@ -2,14 +2,15 @@
 (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
 
 What is sharded:
-  * the forced per-community phase of runsplit: every rank splits its share of the communities; one all-reduce (op 2:
-    integer sum of the words of zero-filled buffers, i.e. an exact gather) hands every rank all groups;
+  * runsplit: in the forced per-community phase and in the big batches of the global phase every rank cuts its share of
+    the groups; one all-reduce per phase / batch (op 2: integer sum of the words of zero-filled buffers, i.e. an exact
+    gather) hands every rank all results, and all ranks continue from identical state;
   * the per-edge scatter: rank r takes the edge rows [m*r/W, m*(r+1)/W); one all-reduce(sum) of the
     C x C cluster-pair vector vect_C (and of the N x N landmark-pair matrix when `landmarks_fetch` asks for it);
   * the point-set diameter: rank r takes its share of the vertex tiles of the centroid pass (one all-reduce(max) of
     the N x C bound matrix) and the candidate tiles t = r (mod W) / super-block rows SI = r (mod W) of the exact
     evaluation (one all-reduce(max) of a scalar);
-and what is replicated: the global phase of runsplit (bit-identical on every rank) and the alpha sweep (sequentially
+and what is replicated: the heap of runsplit and its small batches, and the alpha sweep (sequentially
 dependent iterations of a register-resident persistent fit that already uses every CU).  No other collective is issued.
 """
 from __future__ import annotations

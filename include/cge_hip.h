@@ -200,6 +200,9 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             score vector).
  * "speculation_pct": 1..100 (default 40): share of the pops still missing that one round of runsplit's global phase
  *             may split ahead of the heap; tuning only -- the replay makes the result independent of it.
+ * "shard_runsplit": with collectives set (N > 1): 1 (default) = the forced per-community phase of runsplit and the big
+ *             batches of its global phase are split over the ranks and gathered by one all-reduce each (hook op 2);
+ *             0 = runsplit replicated on every rank; 2 = every batch is split (tests).  Same landmark ids in all modes.
  * "pow_exp2": 1 (default) = GD = (1 - D)^alpha as exp2(alpha * log2(1 - D)) with log2 computed once per score to ~70
  *             bits (a double and a float per entry; below one ulp, like the library pow); 0 = the library pow per alpha.
  * "test_bvec_plain": testing hook, 1 = vect_B through the kernels that serve score graphs of more than 8192 vertices /

@@ -34,7 +34,7 @@ def _graph():
     return synth.abcd_like(30000, 300000, 30, 16, seed=21)
 
 
-def _rank(rank, world, port, q):
+def _rank(rank, world, port, q, mode, method="rss"):
     try:
         import torch
         import torch.distributed as dist
@@ -51,10 +51,13 @@ def _rank(rank, world, port, q):
         ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
         coll = TorchCollectives(ctx, 600 * 600 * 2 + 1024, torch.device("cuda", 0))
         ctx.set_option("fit_persistent", 1)
-        res = ctx.score(g["clusters"], 600, 2, "rss", seed=5, auc_samples=4000)
+        ctx.set_option("shard_runsplit", mode)  # 2: every batch of the global phase is split too, whatever its size
+        res = ctx.score(g["clusters"], 600, 2, method, seed=5, auc_samples=4000)
         hi = ctx.last_diameter()[0]
+        batches = ctx.get_stat("landmark_batches")
+        n0 = coll.n_calls
         v2l = ctx.landmarks_fetch()[6]
-        q.put((rank, res.tolist(), hi, coll.n_calls, int(zlib.crc32(v2l.tobytes()))))
+        q.put((rank, res.tolist(), hi, (n0, coll.n_calls - n0, batches), int(zlib.crc32(v2l.tobytes()))))
         ctx.close()
     except Exception as e:  # surface the failure in the parent
         import traceback
@@ -67,7 +70,8 @@ def _rank(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx):
+@pytest.mark.parametrize("mode", [1, 2, 0])
+def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx, mode):
     import torch.multiprocessing as mp
 
     g = _graph()
@@ -82,7 +86,7 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx):
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    procs = [mpc.Process(target=_rank, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=600) for _ in procs)
@@ -94,7 +98,39 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx):
         assert hi == hi_ref  # the exact diameter: a maximum over shards
         assert res[0] == ref[0] and res[4] == ref[4]
         assert np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
-        # the forced phase's groups (gather), vect_C (sum), the centroid bounds (max), the diameter (max); the fetch above
-        # adds the landmark-pair matrix (sum)
-        assert n_calls == 5
+        # vect_C (sum), the centroid bounds (max), the diameter (max); + the forced phase's groups (gather) + one gather per
+        # split batch of the global phase; the fetch adds the landmark-pair matrix (sum)
+        during, fetch, batches = n_calls
+        assert fetch == 1 and during >= 3 + (mode > 0)
+        if mode == 2:
+            assert during > 4  # batches of the global phase went through the exchange
+        if mode == 0:
+            assert during == 3
     assert results[0][1] == results[1][1]  # both ranks hold the same bits
+
+
+@pytest.mark.parametrize("method", ["rss2", "size", "diameter"])
+def test_two_ranks_other_split_rules(ctx, method):
+    """The same with every batch of runsplit split over the two ranks, for the other three split rules."""
+    import torch.multiprocessing as mp
+
+    g = _graph()
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    try:
+        ctx.set_option("fit_persistent", 1)
+        ref = ctx.score(g["clusters"], 600, 2, method, seed=5, auc_samples=4000)
+        crc_ref = int(zlib.crc32(ctx.landmarks_fetch()[6].tobytes()))
+    finally:
+        ctx.set_option("fit_persistent", 0)
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank, args=(r, 2, port, q, 2, method)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+    for rank, res, hi, n_calls, crc in results:
+        assert hi is not None, res
+        assert crc == crc_ref and np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
