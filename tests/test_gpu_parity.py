@@ -772,6 +772,28 @@ def test_diameter_pruned_equals_brute(ctx, orc, example10k, synth20k, which):
     assert got[1][2] == got[2][2] == got[0][2]  # identical score vectors
 
 
+def test_library_drawn_samples_equal_fetched_draws(ctx, synth20k):
+    """Seeded (one set) and unseeded (a fresh set per alpha) local scores with the samples drawn, rejected and prepared on
+    the device inside the call, against the same draws fetched through cge_draw_samples and handed in as host arrays (the
+    host preparation path): identical score vectors."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api
+
+    a = synth20k
+    lm = cg.landmarks(a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], a["embedding"], False, 300, 2,
+                      "rss", False, ctx=ctx)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+    args = (ledges, lw, lcomm, lemb, dii, lweight, a["vweights"], v2l, a["edges"], a["eweights"], a["embedding"], False)
+    S = 3000
+    seeded = cg.wGCL(*args, 77, S, ctx=ctx)
+    smp = api.draw_samples(ctx, 77, S)
+    assert np.array_equal(seeded, cg.wGCL(*args, 77, S, samples=smp, ctx=ctx))
+    unseeded = cg.wGCL(*args, -1, S, ctx=ctx)
+    smp40 = api.draw_samples(ctx, 0x5EEDC0DE, S, n_sets=40)  # the library's base seed when none is given
+    assert np.array_equal(unseeded, cg.wGCL(*args, -1, S, samples=smp40, ctx=ctx))
+    assert not np.array_equal(seeded[4:], unseeded[4:])  # another stream of samples
+
+
 def test_draw_samples_are_non_edges(ctx, synth20k):
     from cge.jl_amd import api
 
