@@ -665,6 +665,33 @@ def test_score_directed_device_resident(ctx, orc, test115):
     assert list(ctx.score([], -1, directed=True, seed=1, auc_samples=10)) == [-1.0, 0.0, 0.0, 0.0, 0.0, 0.0]
 
 
+def test_directed_exact_mode_device_sampler_with_the_second_draw(ctx):
+    """Directed exact mode on a graph large enough for the device sampler (n(n-1) > 2^25): the un-reseeded second positive
+    draw of src/divergence.jl:510 overwrites the pairs but not the weights -- the fused path (draws and preparation on the
+    device) equals wGCL_directed with the same four draws fetched and handed in as host arrays."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    n = 6000
+    g = synth.abcd_like(n, 8 * n, 12, 8, seed=19, directed=True)
+    rng = np.random.default_rng(2)
+    ew = rng.integers(1, 9, size=len(g["eweights"])) / 4.0  # weights matter: they come from the FIRST draw
+    vw = np.zeros(n)
+    np.add.at(vw, g["edges"][:, 0] - 1, ew)
+    np.add.at(vw, g["edges"][:, 1] - 1, ew)
+    ctx.set_inputs(g["edges"], ew, vw, g["comm"], g["embedding"])
+    res = ctx.score([], -1, directed=True, seed=5, auc_samples=5000)
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    p1, ni, nj = api.draw_samples(ctx, 5, 5000, directed=True)
+    p2 = ctx.draw_samples(5 + 0x7777, 5000, True, 1000)[0].reshape(1, -1)
+    exp = cg.wGCL_directed(g["edges"], ew, g["comm"], g["embedding"], np.zeros(n), vw, *empty, False,
+                           samples=(p1, ni, nj, p2), ctx=ctx)
+    assert np.array_equal(res, exp)
+    same = cg.wGCL_directed(g["edges"], ew, g["comm"], g["embedding"], np.zeros(n), vw, *empty, False,
+                            samples=(p1, ni, nj, p1), ctx=ctx)
+    assert not np.array_equal(res[4:], same[4:])  # the second draw is really used
+
+
 def test_wgcl_asserts_mirror_reference(ctx, test115):
     import cge.jl_amd as cg
     from cge.jl_amd import api
