@@ -1000,3 +1000,79 @@ def test_config1_force_exact_against_oracle_fixture(ctx, example10k):
     assert np.allclose(tr["auc"], gold["auc"], rtol=RTOL, atol=1e-12, equal_nan=True)
     assert res[0] == gold["result"][0] and res[4] == gold["result"][4]
     assert np.allclose(res, gold["result"], rtol=RTOL, atol=1e-12)
+
+
+@pytest.mark.parametrize("case", range(60))
+def test_randomised_parity_sweep(ctx, orc, case):
+    """A seeded sweep over the flag surface on small random graphs: size, dimension, number of communities, split rule,
+    forced splits, landmark count, directed, weighted, --split-global -- landmarks() bit-exact against the oracle, then
+    wGCL / wGCL_directed in landmark mode with the same samples (iteration counts, traces, the 7-vector)."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.integers(60, 1500))
+    d = int(rng.choice([2, 3, 5, 8, 17, 33, 64, 100]))
+    C = int(rng.integers(2, max(3, n // 25)))
+    method = ["rss", "rss2", "size", "diameter"][case % 4]
+    directed = bool(rng.integers(0, 2))
+    split = bool(rng.integers(0, 2))
+    forced = int(rng.choice([1, 2, 4]))
+    g = synth.abcd_like(n, int(rng.integers(3, 9)) * n, C, d, seed=500 + case, directed=directed)
+    land = int(min(n // 3, max(C * forced, rng.integers(C, 6 * C + 2))))
+    ew, vw = g["eweights"], g["vweights"]
+    if rng.integers(0, 2):  # weighted (dyadic: the per-edge scatter's float atomics stay exact)
+        ew = rng.integers(1, 17, size=len(ew)) / 4.0
+        vw = np.zeros(n)
+        np.add.at(vw, g["edges"][:, 0] - 1, ew)
+        np.add.at(vw, g["edges"][:, 1] - 1, ew)
+    args = (g["edges"], ew, vw, g["clusters"], g["comm"], g["embedding"], False, land, forced, method, directed)
+    got, ref = cg.landmarks(*args, ctx=ctx), orc.landmarks(*args)
+    _check_landmarks(got, ref, unit_weights=False)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = got
+    S = 1500
+    if directed:
+        p1, ni, nj = api.draw_samples(ctx, case, S, directed=True)
+        smp, fn, ofn = (p1, ni, nj, p1), cg.wGCL_directed, orc.wGCL_directed
+    else:
+        smp, fn, ofn = api.draw_samples(ctx, case, S), cg.wGCL, orc.wGCL
+    wargs = (ledges, lw, lcomm, lemb, dii, lweight, vw, v2l, g["edges"], ew, g["embedding"], split)
+    res, tr = fn(*wargs, case, S, samples=smp, trace=True, ctx=ctx)
+    exp, etr = ofn(*wargs, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_randomised_exact_mode_sweep(ctx, orc, case):
+    """The same for exact mode (v_to_l = Int[], the score graph is the graph itself): random sizes across the launch
+    forms of the fit (launch per iteration below 128 vertices, one tile per wave on 4 / 8 waves above), directed and
+    undirected, weighted, --split-global, seeded and unseeded samples."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    rng = np.random.default_rng(2000 + case)
+    n = int(rng.choice([40, 90, 127, 128, 200, 333, 520, 700]))
+    d = int(rng.choice([2, 4, 9, 16]))
+    C = int(rng.integers(2, max(3, n // 20)))
+    directed = bool(case % 2)
+    split = bool(rng.integers(0, 2))
+    g = synth.abcd_like(n, int(rng.integers(3, 8)) * n, C, d, seed=700 + case, directed=directed)
+    ew, vw = g["eweights"], g["vweights"]
+    if rng.integers(0, 2):
+        ew = rng.integers(1, 9, size=len(ew)) / 2.0
+        vw = np.zeros(n)
+        np.add.at(vw, g["edges"][:, 0] - 1, ew)
+        np.add.at(vw, g["edges"][:, 1] - 1, ew)
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    ctx.set_graph(g["edges"], ew, n)
+    S, n_sets = 800, (1 if case % 3 else 40)  # a fresh draw per alpha when unseeded
+    if directed:
+        p1, ni, nj = api.draw_samples(ctx, case, S, directed=True, n_sets=n_sets)
+        p2, _, _ = api.draw_samples(ctx, case + 99, S, directed=True, n_sets=n_sets)
+        smp, fn, ofn = (p1, ni, nj, p2), cg.wGCL_directed, orc.wGCL_directed
+    else:
+        smp, fn, ofn = api.draw_samples(ctx, case, S, n_sets=n_sets), cg.wGCL, orc.wGCL
+    args = (g["edges"], ew, g["comm"], g["embedding"], np.zeros(n), vw, *empty, split)
+    res, tr = fn(*args, samples=smp, trace=True, ctx=ctx)
+    exp, etr = ofn(*args, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
