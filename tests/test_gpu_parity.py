@@ -1076,3 +1076,25 @@ def test_randomised_exact_mode_sweep(ctx, orc, case):
     res, tr = fn(*args, samples=smp, trace=True, ctx=ctx)
     exp, etr = ofn(*args, smp, trace=True)
     _cmp_result(res, exp, tr, etr)
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_randomised_landmarks_sweep_mid_size(ctx, orc, case):
+    """landmarks() against the oracle on random mid-size graphs (3 000 - 9 000 vertices, up to 128 dimensions, hundreds of
+    landmarks; twelve cases up to 30 000 vertices passed when this test was written -- the oracle sets the pace): several rounds of the speculative tree expansion, long groups (two-pass sort) and short ones (segmented
+    sort), every split rule -- landmark ids, communities, edge lists bit-exact."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import synth
+
+    rng = np.random.default_rng(3000 + case)
+    n = int(rng.integers(3000, 9000))
+    d = int(rng.choice([8, 24, 64, 128]))
+    C = int(rng.integers(5, 60))
+    method = ["rss", "rss2", "size", "diameter"][case % 4]
+    forced = int(rng.choice([1, 2, 4, 6]))
+    land = int(rng.integers(C * forced, C * forced + 500))
+    directed = bool(rng.integers(0, 2))
+    g = synth.abcd_like(n, 6 * n, C, d, seed=900 + case, directed=directed)
+    args = (g["edges"], g["eweights"], g["vweights"], g["clusters"], g["comm"], g["embedding"], False, land, forced, method,
+            directed)
+    _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
