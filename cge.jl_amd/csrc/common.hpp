@@ -391,6 +391,7 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
                   i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals, double *cmeans /* [task][2][d] */);
 #define CGE_RR_MAXROUNDS 63
 #define CGE_CHUNK_ROWS 1024 // rows per chunk of a batch (build_batch); the rounds kernel uses r >> 10
+#define CGE_PARTIAL_BLOCKS 64 // block partials of the JS / AUC reductions (summed in block order)
 #define CGE_PREFIX_STRIDE 8 // the sorted-order WSSE prefix is stored every 8th row of a chunk (CGE_CHUNK_ROWS % 8 == 0)
 void k_gather_means(cge_ctx *c, const double *arena, const i64 *off, i64 T, i64 d, double *mean);
 void k_gather_rows(cge_ctx *c, const i32 *arena, const i32 *task_off, const i32 *task_row_off, const i32 *chunk_task,
@@ -464,12 +465,12 @@ void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, 
 void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_pos, const i32 *cm_off,
             const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB);
 void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int directed, int mode /*0 all,1 int,2 ext*/,
-          double *out);
+          double *out, double *partials = nullptr);
 void k_auc_landmark(cge_ctx *c, const double *Ta, const double *Tb, const i32 *v2l, const double *vw_orig,
                     const double *lweight, const i32 *pi, const i32 *pj, const i32 *ni, const i32 *nj,
-                    const double *dpos, const double *dneg, const double *wts, i64 S, double alpha, double *out2);
+                    const double *dpos, const double *dneg, const double *wts, i64 S, double alpha, double *out2, double *partials = nullptr);
 void k_auc_exact(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, i64 N, const i32 *pi,
-                 const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, double *out2);
+                 const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, double *out2, double *partials = nullptr);
 void k_mark_edge_hits(cge_ctx *c, const i32 *src, const i32 *dst, i64 m, int directed, const uint64_t *table,
                       i64 table_size, i32 *hit);
 

@@ -544,7 +544,7 @@ __device__ __forceinline__ bool js_selected(i64 k, i64 C, int directed, int mode
 // three small launches, every sum in a fixed order: (1) per-block partial (sum C, sum B, count),
 // (2) per-block partial of the divergence terms (each block first re-adds the stage-1 partials in block
 // order, so all blocks use identical normalisers), (3) the final sum.
-#define JS_BLOCKS 64
+#define JS_BLOCKS CGE_PARTIAL_BLOCKS
 __global__ __launch_bounds__(256) void js_sums_kernel(const double *__restrict__ vC, const double *__restrict__ vB,
                                                       i64 len, i64 C, int directed, int mode,
                                                       double *__restrict__ part /* [JS_BLOCKS][3] */) {
@@ -581,19 +581,23 @@ __global__ void js_final_kernel(const double *__restrict__ fpart, double *__rest
     for (int b = 0; b < JS_BLOCKS; b++) f += __shfl(v, b);
     if (threadIdx.x == 0) *out = f / 2.0;
 }
-void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int directed, int mode, double *out) {
+// `partials` != nullptr: the CGE_PARTIAL_BLOCKS block sums of the divergence terms go there and the caller adds them (in
+// block order, then / 2: what js_final_kernel does) -- the sweep does that on the host, behind the copy it makes anyway
+void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int directed, int mode, double *out,
+          double *partials) {
     c->js_part.ensure(4 * JS_BLOCKS);
     ScopedKernelTimer t(c, "js");
     hipLaunchKernelGGL(js_sums_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, vC, vB, len, C, directed, mode,
                        c->js_part.p);
+    double *fpart = partials ? partials : c->js_part.p + 3 * JS_BLOCKS;
     hipLaunchKernelGGL(js_terms_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, vC, vB, len, C, directed, mode,
-                       c->js_part.p, c->js_part.p + 3 * JS_BLOCKS);
-    hipLaunchKernelGGL(js_final_kernel, dim3(1), dim3(64), 0, c->stream, c->js_part.p + 3 * JS_BLOCKS, out);
+                       c->js_part.p, fpart);
+    if (!partials) hipLaunchKernelGGL(js_final_kernel, dim3(1), dim3(64), 0, c->stream, fpart, out);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Local score tallies: out2 = { sum_k [pos_k > neg_k] * w_k , sum_k w_k }  (:213 / :517)
-#define AUC_BLOCKS 64
+#define AUC_BLOCKS CGE_PARTIAL_BLOCKS
 __global__ __launch_bounds__(256) void auc_landmark_kernel(const double *__restrict__ Ta, const double *__restrict__ Tb,
                                                            const i32 *__restrict__ v2l,
                                                            const double *__restrict__ vw_orig,
@@ -657,18 +661,19 @@ static double *auc_partials(cge_ctx *c) {
 }
 void k_auc_landmark(cge_ctx *c, const double *Ta, const double *Tb, const i32 *v2l, const double *vw_orig,
                     const double *lweight, const i32 *pi, const i32 *pj, const i32 *ni, const i32 *nj,
-                    const double *dpos, const double *dneg, const double *wts, i64 S, double alpha, double *out2) {
-    double *part = auc_partials(c);
+                    const double *dpos, const double *dneg, const double *wts, i64 S, double alpha, double *out2,
+                    double *partials) {
+    double *part = partials ? partials : auc_partials(c); // partials: 2 * CGE_PARTIAL_BLOCKS block tallies, summed by the caller
     hipLaunchKernelGGL(auc_landmark_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, Ta, Tb, v2l, vw_orig, lweight,
                        pi, pj, ni, nj, dpos, dneg, wts, S, alpha, part);
-    hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(64), 0, c->stream, part, AUC_BLOCKS, out2);
+    if (!partials) hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(64), 0, c->stream, part, AUC_BLOCKS, out2);
 }
 void k_auc_exact(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, i64 N, const i32 *pi,
-                 const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, double *out2) {
-    double *part = auc_partials(c);
+                 const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, double *out2, double *partials) {
+    double *part = partials ? partials : auc_partials(c);
     hipLaunchKernelGGL(auc_exact_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, GD, Ta, Tb, N, pi, pj, ni, nj, wts,
                        S, part);
-    hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(64), 0, c->stream, part, AUC_BLOCKS, out2);
+    if (!partials) hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(64), 0, c->stream, part, AUC_BLOCKS, out2);
 }
 
 // ------------------------------------------------------------------------------------------------

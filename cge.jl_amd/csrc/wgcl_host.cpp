@@ -106,7 +106,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     T1.ensure(N); T2.ensure(N); S1.ensure(N); S2.ensure(N);
     rowbins.ensure((size_t)N * C);
     vectB.ensure(vlen);
-    scal.ensure(16);
+    scal.ensure(4 * CGE_PARTIAL_BLOCKS + 16); // per alpha: AUC block tallies, JS block sums (two modes), the fit's verdict
     lohi.ensure(2);
     fitstate.ensure(4);
     flags.ensure(4);
@@ -259,7 +259,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         int t0_par = 0;  // the half of TT that held T_0 of this alpha
         i64 iters = 0;
     } slots[2];
-    c->pin_scal.ensure(32);
+    constexpr i64 RES_AUC = 0, RES_JS = 2 * CGE_PARTIAL_BLOCKS, RES_FIT = 4 * CGE_PARTIAL_BLOCKS, RES_LEN = RES_FIT + 2,
+                  RES_STRIDE = RES_FIT + 16;
+    c->pin_scal.ensure(2 * RES_STRIDE);
     const int fit_variant = c->opt_fit_persistent == 3 ? 0 : (c->opt_fit_persistent == 4 ? 1 : 2);
     auto enqueue_alpha = [&](i64 ia, bool want_auc, bool want_div) {
         AlphaSlot &sl = slots[ia & 1];
@@ -285,7 +287,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             if (use_persistent) { // the whole fit in one launch, GD's upper triangle in registers (kernels_fitp.hip)
                 const int tnext = (tpar + 1) % 3;
                 if (fit_variant == 2 && k_fit_flow_enqueue(c, GD.p, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld, Tld, G.vw,
-                                                           0.25, delta, (int *)(scal.p + 8))) {
+                                                           0.25, delta, (int *)(scal.p + RES_FIT))) {
                     sl.fit_async = true; // the verdict is looked at when the alpha is collected
                     fitted = true;
                     tpar = tnext;
@@ -365,21 +367,22 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             const DevSamples &ds = dsets[smp.n_sets == 1 ? 0 : ia - 1];
             if (landmarks)
                 k_auc_landmark(c, Ta, Tb, orig->v2l, orig->vw, orig->lweight, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p,
-                               ds.dpos.p, ds.dneg.p, ds.wts.p, S, alpha, scal.p);
+                               ds.dpos.p, ds.dneg.p, ds.wts.p, S, alpha, nullptr, scal.p + RES_AUC);
             else
-                k_auc_exact(c, GD.p, Ta, Tb, N, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p, ds.wts.p, S, scal.p);
+                k_auc_exact(c, GD.p, Ta, Tb, N, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p, ds.wts.p, S, nullptr, scal.p + RES_AUC);
         }
         if (want_div) {
             k_bvec(c, GD.p, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
             if (!split)
-                k_js(c, G.vectC, vectB.p, vlen, C, directed, 0, scal.p + 2);
+                k_js(c, G.vectC, vectB.p, vlen, C, directed, 0, nullptr, scal.p + RES_JS);
             else {
-                k_js(c, G.vectC, vectB.p, vlen, C, directed, 1, scal.p + 3);
-                k_js(c, G.vectC, vectB.p, vlen, C, directed, 2, scal.p + 4);
+                k_js(c, G.vectC, vectB.p, vlen, C, directed, 1, nullptr, scal.p + RES_JS);
+                k_js(c, G.vectC, vectB.p, vlen, C, directed, 2, nullptr, scal.p + RES_JS + CGE_PARTIAL_BLOCKS);
             }
         }
-        // the scalars and (behind them) the verdict of an enqueued fit, one copy
-        HIP_CHECK(hipMemcpyAsync(c->pin_scal.p + 16 * slot, scal.p, sizeof(double) * (sl.fit_async ? 10 : 5), hipMemcpyDeviceToHost, st));
+        // the block partials of the alpha's reductions and (behind them) the verdict of an enqueued fit, one copy; the host
+        // adds the partials in block order -- what the one-thread "final" kernels did, without their launches
+        HIP_CHECK(hipMemcpyAsync(c->pin_scal.p + RES_STRIDE * slot, scal.p, sizeof(double) * RES_LEN, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipEventRecord(c->sweep_ev[slot], st));
     };
 
@@ -401,7 +404,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         }
         HIP_CHECK(hipEventSynchronize(c->sweep_ev[ia & 1]));
         if (sl.fit_async) {
-            const int *hf = (const int *)(c->pin_scal.p + 16 * (ia & 1) + 8);
+            const int *hf = (const int *)(c->pin_scal.p + RES_STRIDE * (ia & 1) + RES_FIT);
             if (hf[2] || !hf[0]) { // a wait timed out: drain what was enqueued behind it and redo this alpha from its T_0
                 HIP_CHECK(hipStreamSynchronize(st)); // (still in place) with one launch per iteration, as every later alpha
                 if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
@@ -418,7 +421,16 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         const i64 iters = sl.iters;
         c->stat_fit_iters += iters;
         double auc_val = NAN, div_val = NAN, div_int = 0.0, div_ext = 0.0;
-        const double *hs = c->pin_scal.p + 16 * (ia & 1);
+        const double *res = c->pin_scal.p + RES_STRIDE * (ia & 1);
+        double hs[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (!skip_auc)
+            for (int b = 0; b < CGE_PARTIAL_BLOCKS; b++) { hs[0] += res[RES_AUC + 2 * b]; hs[1] += res[RES_AUC + 2 * b + 1]; }
+        if (!skip_div) {
+            double fa = 0.0, fb = 0.0;
+            for (int b = 0; b < CGE_PARTIAL_BLOCKS; b++) { fa += res[RES_JS + b]; fb += res[RES_JS + CGE_PARTIAL_BLOCKS + b]; }
+            if (!split) hs[2] = fa / 2.0;
+            else { hs[3] = fa / 2.0; hs[4] = fb / 2.0; }
+        }
         if (!skip_auc) {
             const double auc = 1.0 - hs[0] / hs[1]; // :213
             auc_val = auc;
