@@ -14,13 +14,6 @@ static inline uint64_t ctr_rand(uint64_t seed, uint64_t stream, uint64_t k, uint
 }
 static inline uint64_t bounded(uint64_t r, uint64_t range) { return cge_bounded(r, range); }
 
-static inline uint64_t mixk_host(uint64_t x) { // must match mixk() in kernels_fit.hip
-    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
-    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
-    x ^= x >> 31;
-    return x;
-}
-
 void host_pos_draw(i64 seed, i64 stream_id, i64 S, i64 m, i64 *pos_idx) {
     for (i64 k = 0; k < S; k++)
         pos_idx[k] = (i64)bounded(ctr_rand((uint64_t)seed, (uint64_t)stream_id, (uint64_t)k, 0, 0), (uint64_t)m) + 1;
