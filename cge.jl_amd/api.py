@@ -8,9 +8,11 @@ raises ``CGEError``.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import sys
+import weakref
 
 import numpy as np
 
@@ -68,6 +70,22 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
 
 class Collectives(C.Structure):
     _fields_ = [("allreduce_f64", ALLREDUCE_FN), ("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int)]
+
+
+# Live contexts are closed from an `atexit` hook: it runs inside Py_Finalize, i.e. BEFORE the C-level exit handlers
+# of the HIP runtime and of a profiler's tool library.  A context that is still alive when those run leaves streams and
+# events behind that the runtime then destroys after the profiler has finalised its HSA hooks -- the exit-time SIGSEGV
+# recorded in round 1 (gpurun_out/prof_r01f/stats.err: exit -> a library's exit handler -> a second library).
+_live = weakref.WeakSet()
+_atexit_registered = False
+
+
+def _close_live_contexts():
+    for ctx in list(_live):
+        try:
+            ctx.close()
+        except Exception:
+            pass
 
 
 def library_path():
@@ -169,11 +187,17 @@ class Context:
         self.device = device
         self._keep = []  # objects the C side holds pointers to (collective hook)
         self.n = self.m = self.d = 0
+        global _atexit_registered
+        _live.add(self)
+        if not _atexit_registered and not os.environ.get("CGE_NO_ATEXIT_CLOSE"):
+            atexit.register(_close_live_contexts)
+            _atexit_registered = True
 
     def close(self):
         if getattr(self, "h", None):
             self.L.cge_destroy(self.h)
             self.h = None
+        _live.discard(self)
 
     def __del__(self):
         try:

@@ -37,7 +37,7 @@ METHODS = {
 
 USAGE = (
     "\n\nUsage:\n"
-    "\tcge_cli -g edgelist -e embedding [-c communities] [--seed seed] [--samples-local samples] [-v] [-d] "
+    "\tpython cge_cli.py -g edgelist -e embedding [-c communities] [--seed seed] [--samples-local samples] [-v] [-d] "
     "[--split-global] [-l [landmarks]] [-f [forced]] [--force-exact] [-m method]\n"
 )
 
@@ -93,8 +93,9 @@ def parseargs(argv=None, exit_on_error=True):
         eweights = np.ones(rows) if no_cols == 2 else np.ascontiguousarray(raw[:, 2])
         edges = np.asfortranarray(raw[:, :2].astype(np.int64))
         vweight = np.zeros(no_vertices)
-        np.add.at(vweight, edges[:, 0] - 1, eweights)  # :107-110 (sequential += in the reference)
-        np.add.at(vweight, edges[:, 1] - 1, eweights)
+        # :107-110: `vweight[u] += w; vweight[v] += w` edge by edge -- the interleaved index list keeps that order of
+        # additions (np.add.at is sequential), so non-dyadic weights round as in the reference
+        np.add.at(vweight, np.ascontiguousarray(edges).ravel() - 1, np.repeat(eweights, 2))
 
         if "-c" not in argv:
             raise AssertionError(

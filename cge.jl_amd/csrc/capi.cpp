@@ -39,6 +39,43 @@ static void flush_timers(cge_ctx *c) {
     }
 }
 
+// Pageable host memory -> device through two pinned staging buffers: the host workers convert / copy chunk k into one
+// buffer while chunk k-1 is on the wire from the other (a plain hipMemcpy from pageable memory is a single-threaded
+// bounce copy).  fill(dst, e0, e1) writes elements [e0, e1) of the output into `dst` (e1 - e0 <= chunk) and may be
+// called from several threads on disjoint sub-ranges.
+template <typename T, typename F>
+static void staged_upload(cge_ctx *c, T *dev, size_t total, F fill) {
+    const size_t chunk = CGE_STAGE_BYTES / sizeof(T);
+    for (int b = 0; b < 2; b++) c->stage[b].ensure(CGE_STAGE_BYTES);
+    const int nt = std::max(1, c->n_threads);
+    for (size_t off = 0, k = 0; off < total; off += chunk, k++) {
+        const int b = (int)(k & 1);
+        if (k >= 2) HIP_CHECK(hipEventSynchronize(c->stage_ev[b])); // the copy that last read this buffer is done
+        const size_t len = std::min(chunk, total - off);
+        T *dst = (T *)c->stage[b].p;
+        const size_t per = (len + nt - 1) / nt;
+        const std::function<void(i64)> job = [&](i64 t) {
+            const size_t a = std::min(len, (size_t)t * per), e = std::min(len, a + per);
+            if (e > a) fill(dst + a, off + a, off + e);
+        };
+        c->pool->run(nt, job);
+        HIP_CHECK(hipMemcpyAsync(dev + off, dst, sizeof(T) * len, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipEventRecord(c->stage_ev[b], c->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+// host mirror of the row-major embedding: only the generic round-based rss path (ties at the maximum of z, NaNs) and the
+// exact unique-row count read it, so it is fetched on first demand instead of at every upload (1 GB at the headline)
+void cge_ensure_host_embedding(cge_ctx *c) {
+    const size_t need = (size_t)c->n * (size_t)c->d;
+    if (c->h_Xr.size() == need) return;
+    if (!c->Xr.p || need == 0) CGE_THROW(CGE_E_ARG, "embedding not resident");
+    c->h_Xr.resize(need);
+    HIP_CHECK(hipMemcpyAsync(c->h_Xr.data(), c->Xr.p, sizeof(double) * need, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
 extern "C" {
 
 int cge_abi_version(void) { return CGE_ABI_VERSION; }
@@ -64,6 +101,7 @@ int cge_create(cge_ctx **out, int device, void *stream) {
         HIP_CHECK(hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&c->sweep_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
         unsigned hc = std::thread::hardware_concurrency();
         c->n_threads = (int)std::max(1u, std::min(hc ? hc : 8u, 16u));
         c->pool = new ThreadPool(c->n_threads - 1);
@@ -88,6 +126,8 @@ void cge_destroy(cge_ctx *c) {
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     for (int i = 0; i < 2; i++)
         if (c->sweep_ev[i]) (void)hipEventDestroy(c->sweep_ev[i]);
+    for (int i = 0; i < 2; i++)
+        if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
     delete c->pool;
     c->pool = nullptr;
     delete c;
@@ -138,31 +178,57 @@ int cge_set_graph(cge_ctx *c, const int64_t *src, const int64_t *dst, const doub
     if (!c || !src || !dst || m <= 0 || n <= 0 || n >= (1LL << 31)) return CGE_E_ARG;
     CGE_TRY(c)
     HIP_CHECK(hipSetDevice(c->device));
-    std::vector<i32> s(m), t(m);
-    for (i64 e = 0; e < m; e++) {
-        if (src[e] < 1 || src[e] > n || dst[e] < 1 || dst[e] > n) CGE_THROW(CGE_E_ARG, "edge %lld has a vertex id outside 1..%lld", (long long)e + 1, (long long)n);
-        s[e] = (i32)(src[e] - 1);
-        t[e] = (i32)(dst[e] - 1);
-    }
-    c->h_w.assign(m, 1.0);
-    bool unit = true;
-    if (w)
-        for (i64 e = 0; e < m; e++) {
-            c->h_w[e] = w[e];
-            unit = unit && (w[e] == 1.0);
-        }
-    c->unit_weights = unit;
     c->src.alloc_exact(m);
     c->dst.alloc_exact(m);
-    c->w.alloc_exact(m);
-    HIP_CHECK(hipMemcpyAsync(c->src.p, s.data(), sizeof(i32) * m, hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipMemcpyAsync(c->dst.p, t.data(), sizeof(i32) * m, hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipMemcpyAsync(c->w.p, c->h_w.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    // ids: validated and narrowed to 0-based int32 by the host workers on their way into the staging buffers
+    std::atomic<i64> bad{-1};
+    for (int col = 0; col < 2; col++) {
+        const int64_t *h = col ? dst : src;
+        staged_upload<i32>(c, col ? c->dst.p : c->src.p, (size_t)m, [&](i32 *o, size_t e0, size_t e1) {
+            for (size_t e = e0; e < e1; e++) {
+                const int64_t v = h[e];
+                if (v < 1 || v > n) { i64 exp = -1; bad.compare_exchange_strong(exp, (i64)e); }
+                o[e - e0] = (i32)(v - 1);
+            }
+        });
+    }
+    if (bad.load() >= 0) {
+        c->src.release(); c->dst.release(); c->m = 0;
+        CGE_THROW(CGE_E_ARG, "edge %lld has a vertex id outside 1..%lld", (long long)bad.load() + 1, (long long)n);
+    }
+    // weights: all ones (an unweighted list, src/auxilary.jl:105) => neither a device copy nor a host mirror is kept
+    bool unit = true;
+    if (w) {
+        const int nt = std::max(1, c->n_threads);
+        std::vector<char> nonunit(nt, 0);
+        const i64 per = (m + nt - 1) / nt;
+        const std::function<void(i64)> job = [&](i64 t) {
+            const i64 a = std::min<i64>(m, t * per), e = std::min<i64>(m, a + per);
+            char f = 0;
+            for (i64 k = a; k < e && !f; k++) f = w[k] != 1.0;
+            nonunit[t] = f;
+        };
+        c->pool->run(nt, job);
+        for (char f : nonunit) unit = unit && !f;
+    }
+    c->unit_weights = unit;
+    c->h_w.clear();
+    c->w.release();
+    if (!unit) {
+        c->h_w.assign(w, w + m); // mirror: weights of host-side sample draws
+        c->w.alloc_exact(m);
+        staged_upload<double>(c, c->w.p, (size_t)m, [&](double *o, size_t e0, size_t e1) { memcpy(o, w + e0, sizeof(double) * (e1 - e0)); });
+    }
     c->m = m;
-    if (c->n && c->n != n) { c->h_Xr.clear(); c->h_vw.clear(); c->h_comm.clear(); c->d = 0; }
+    if (c->n && c->n != n) { // another vertex set: nothing that was sized for the old one may survive (stale or short buffers)
+        c->h_Xr.clear(); c->h_vw.clear(); c->h_comm.clear();
+        c->Xr.release(); c->Xc.release(); c->rnorm.release(); c->vw.release(); c->comm.release(); c->comm16.release();
+        c->d = 0;
+        c->centred_ready = false;
+    }
     c->n = n;
     c->lm_ready = false;
+    c->blocked_ready = false; // the blocked copy of the edge list is rebuilt by the first edge pass
     CGE_CATCH(c)
 }
 
@@ -173,11 +239,11 @@ int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
     if (c->n && c->n != n) CGE_THROW(CGE_E_ASSERT, "No. rows in embedding and no. vertices in a graph differ.");
     DevBuf<double> col;
     col.alloc_exact((size_t)n * d);
-    HIP_CHECK(hipMemcpyAsync(col.p, X, sizeof(double) * n * d, hipMemcpyHostToDevice, c->stream));
+    staged_upload<double>(c, col.p, (size_t)n * d, [&](double *o, size_t e0, size_t e1) { memcpy(o, X + e0, sizeof(double) * (e1 - e0)); });
     c->Xr.alloc_exact((size_t)n * d);
     k_transpose_to_rowmajor(c, col.p, c->Xr.p, n, d);
-    c->h_Xr.resize((size_t)n * d);
-    HIP_CHECK(hipMemcpyAsync(c->h_Xr.data(), c->Xr.p, sizeof(double) * n * d, hipMemcpyDeviceToHost, c->stream));
+    c->h_Xr.clear();
+    c->h_Xr.shrink_to_fit();
     HIP_CHECK(hipStreamSynchronize(c->stream));
     col.release();
     c->n = n;
@@ -215,10 +281,11 @@ int cge_set_vertex_data(cge_ctx *c, const int64_t *comm, const double *vw, int64
         HIP_CHECK(hipMemcpyAsync(c->comm.p, c->h_comm.data(), sizeof(i32) * n, hipMemcpyHostToDevice, c->stream));
         c->comm16.release();
         if (cmax < 65536) {
-            std::vector<unsigned short> c16(n);
+            const i64 npad = (n + CGE_COMM16_PAD - 1) / CGE_COMM16_PAD * CGE_COMM16_PAD; // whole vertex blocks (edge pass)
+            std::vector<unsigned short> c16(npad, 0);
             for (i64 i = 0; i < n; i++) c16[i] = (unsigned short)c->h_comm[i];
-            c->comm16.alloc_exact(n);
-            HIP_CHECK(hipMemcpyAsync(c->comm16.p, c16.data(), sizeof(unsigned short) * n, hipMemcpyHostToDevice, c->stream));
+            c->comm16.alloc_exact(npad);
+            HIP_CHECK(hipMemcpyAsync(c->comm16.p, c16.data(), sizeof(unsigned short) * npad, hipMemcpyHostToDevice, c->stream));
             HIP_CHECK(hipStreamSynchronize(c->stream)); // c16 goes out of scope
         }
     }
@@ -263,6 +330,7 @@ static i64 clamp_to_unique_rows(cge_ctx *c, i64 land, int *truncated) {
     // fewer distinct hashes than `land`: count bitwise-distinct rows exactly
     std::vector<i64> ix(n);
     for (i64 i = 0; i < n; i++) ix[i] = i;
+    cge_ensure_host_embedding(c);
     const double *X = c->h_Xr.data();
     auto cmp = [&](i64 a, i64 b) { return memcmp(X + a * d, X + b * d, sizeof(double) * d) < 0; };
     std::sort(ix.begin(), ix.end(), cmp);
@@ -300,6 +368,17 @@ static double allreduce_scalar_max(cge_ctx *c, double v) {
 }
 
 static void build_landmark_index(cge_ctx *c, const std::vector<i32> &v2l0, i64 N);
+// the resident inputs a landmark / score run reads: all present and all sized for the same vertex set
+static void check_resident(cge_ctx *c, const char *who) {
+    if (!c->Xr.p || !c->vw.p || !c->comm.p || !c->src.p)
+        CGE_THROW(CGE_E_ARG, "%s: graph, embedding and vertex data must be resident (cge_set_graph / cge_set_embedding / "
+                             "cge_set_vertex_data; a cge_wgcl call in exact mode replaces the resident graph)", who);
+    const size_t n = (size_t)c->n;
+    if (c->n <= 0 || c->d <= 0 || c->m <= 0 || c->Xr.n < n * (size_t)c->d || c->vw.n < n || c->comm.n < n ||
+        c->src.n < (size_t)c->m || c->dst.n < (size_t)c->m)
+        CGE_THROW(CGE_E_ARG, "%s: resident inputs are inconsistent (n = %lld, d = %lld, m = %lld): upload them again", who,
+                  (long long)c->n, (long long)c->d, (long long)c->m);
+}
 // per-edge scatter of the resident graph into the landmark-pair matrix (and its positive-entry count)
 static void scatter_wedges(cge_ctx *c, int directed) {
     const i64 N = c->N;
@@ -322,9 +401,24 @@ static void scatter_wedges(cge_ctx *c, int directed) {
     c->wedges_ready = true;
 }
 
+// vect_C of the resident graph (src/divergence.jl:59-63 / :337-345 on the original edges): the blocked two-pass form
+// (kernels_scatter.hip) where it applies, else the gather + atomics kernel; this rank's share, then the all-reduce
+static void scatter_vectC_resident(cge_ctx *c, i64 C, int directed, double *vectC) {
+    const i64 vlen = directed ? C * C : packed_len(C);
+    const int rank = c->has_coll ? c->coll.rank : 0, world = c->has_coll ? c->coll.world : 1;
+    if (k_edge_scatter_blocked_applies(c, C) && (c->blocked_ready || k_build_blocked_edges(c))) {
+        k_edge_scatter_blocked(c, c->be_nchunks * rank / world, c->be_nchunks * (rank + 1) / world, C, directed, vectC);
+    } else {
+        HIP_CHECK(hipMemsetAsync(vectC, 0, sizeof(double) * vlen, c->stream));
+        k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, c->m * rank / world, c->m * (rank + 1) / world,
+                       nullptr, c->comm.p, 1, C, directed, nullptr, vectC);
+    }
+    if (c->has_coll) allreduce(c, vectC, vlen, 0);
+}
+
 static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 land, i64 forced,
                                int method, int directed, bool need_wedges) {
-    if (!c->Xr.p || !c->vw.p || !c->comm.p || !c->src.p) CGE_THROW(CGE_E_ARG, "landmarks: graph, embedding and vertex data must be resident");
+    check_resident(c, "landmarks");
     if (method < 0 || method > 3) CGE_THROW(CGE_E_ARG, "unknown split method %d", method);
     const i64 d = c->d;
     hipStream_t st = c->stream;
@@ -357,15 +451,7 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
     const i64 C = c->n_comm_max;
     const i64 vlen = directed ? C * C : packed_len(C);
     c->vectC.ensure(vlen);
-    HIP_CHECK(hipMemsetAsync(c->vectC.p, 0, sizeof(double) * vlen, st));
-    i64 e0 = 0, e1 = c->m;
-    if (c->has_coll) { // edge shard of this rank
-        e0 = c->m * c->coll.rank / c->coll.world;
-        e1 = c->m * (c->coll.rank + 1) / c->coll.world;
-    }
-    k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, nullptr, c->comm.p, N, C,
-                   directed, nullptr, c->vectC.p);
-    if (c->has_coll) allreduce(c, c->vectC.p, vlen, 0);
+    scatter_vectC_resident(c, C, directed, c->vectC.p);
     c->lm_directed = directed;
     c->wedges_ready = false;
     c->n_ledges = -1;
@@ -692,7 +778,7 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
             build_landmark_index(c, v2l0, N);
         }
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p;
-        ov.lweight = c->s_vw.p; ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
+        ov.lweight = c->s_vw.p; ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.empty() ? nullptr : c->h_w.data();
         std::vector<i32> lcomm0(N);
         for (i64 i = 0; i < N; i++) lcomm0[i] = (i32)(a->comm[i] - 1);
         double hi = resident_diameter_lm(c, c->s_emb.p, c->s_vw.p, lcomm0, C, N, c->has_coll ? c->coll.rank : 0,
@@ -716,7 +802,7 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
         if (a->pos_idx2) smp.pos_idx2.assign(a->pos_idx2, a->pos_idx2 + tot);
     } else
         make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
-    host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.data(), c->m, directed, a->split, smp,
+    host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.empty() ? nullptr : c->h_w.data(), c->m, directed, a->split, smp,
                     out, out_len, trace);
     flush_timers(c);
     CGE_CATCH(c)
@@ -727,7 +813,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     CGE_TRY(c)
     HIP_CHECK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    if (!c->Xr.p || !c->vw.p || !c->comm.p || !c->src.p) CGE_THROW(CGE_E_ARG, "score: graph, embedding and vertex data must be resident");
+    check_resident(c, "score");
     c->phases.ms.clear();
     const int directed = a->directed;
     const i64 d = c->d;
@@ -766,7 +852,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         }
         t0 = now_ms();
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
-        ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.data();
+        ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.empty() ? nullptr : c->h_w.data();
         std::vector<i32> lcomm0(N); // community of a landmark = community of any member (landmarks never span two): :427
         HIP_CHECK(hipMemcpyAsync(lcomm0.data(), c->lcomm.p, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -782,9 +868,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         HIP_CHECK(hipMemsetAsync(zeros.p, 0, sizeof(double) * N, st)); // distances = zeros (CGE_CLI.jl:4)
         const i64 vlen = directed ? C * C : packed_len(C);
         c->vectC.ensure(vlen);
-        HIP_CHECK(hipMemsetAsync(c->vectC.p, 0, sizeof(double) * vlen, st));
-        k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, 0, c->m, nullptr, c->comm.p, N, C,
-                       directed, nullptr, c->vectC.p);
+        scatter_vectC_resident(c, C, directed, c->vectC.p);
         G.N = N; G.d = d; G.C = C;
         G.emb = c->Xr.p; G.dist = zeros.p; G.vw = c->vw.p; G.comm = c->comm.p; G.vectC = c->vectC.p;
         if (directed) {
@@ -806,7 +890,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
     c->phases.ms["samples"] = now_ms() - t0;
     t0 = now_ms();
-    host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.data(), c->m, directed, a->split, smp,
+    host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.empty() ? nullptr : c->h_w.data(), c->m, directed, a->split, smp,
                     out, out_len, trace);
     HIP_CHECK(hipStreamSynchronize(st));
     c->phases.ms["sweep"] = now_ms() - t0;
@@ -858,8 +942,12 @@ int cge_edge_scatter(cge_ctx *c, const int64_t *v_to_l, int64_t N, int64_t C, in
         dc.ensure(vlen);
         HIP_CHECK(hipMemsetAsync(dc.p, 0, sizeof(double) * vlen, st));
     }
-    k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, v_to_l ? dv.p : nullptr,
-                   c->comm.p, N, C, directed, wedges_out ? dw.p : nullptr, vect_C_out ? dc.p : nullptr);
+    if (!wedges_out && vect_C_out && e0 == 0 && e1 == c->m && C == c->n_comm_max && !c->has_coll &&
+        k_edge_scatter_blocked_applies(c, C) && (c->blocked_ready || k_build_blocked_edges(c)))
+        k_edge_scatter_blocked(c, 0, c->be_nchunks, C, directed, dc.p); // the score path's form of the whole-list pass
+    else
+        k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, v_to_l ? dv.p : nullptr,
+                       c->comm.p, N, C, directed, wedges_out ? dw.p : nullptr, vect_C_out ? dc.p : nullptr);
     if (wedges_out) HIP_CHECK(hipMemcpyAsync(wedges_out, dw.p, sizeof(double) * N * N, hipMemcpyDeviceToHost, st));
     if (vect_C_out) HIP_CHECK(hipMemcpyAsync(vect_C_out, dc.p, sizeof(double) * vlen, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -913,6 +1001,7 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "diameter_refs")) *value = c->stat_nref;
     else if (!strcmp(key, "fit_persistent_alphas")) *value = c->stat_fit_persistent;
     else if (!strcmp(key, "fit_iterations")) *value = c->stat_fit_iters;
+    else if (!strcmp(key, "fit_persistent_fallbacks")) *value = c->stat_fit_fallbacks;
     else if (!strcmp(key, "landmark_batches")) *value = c->stat_lm_batches;
     else if (!strcmp(key, "landmark_batch_rows")) *value = c->stat_lm_rows;
     else if (!strcmp(key, "landmark_splits")) *value = c->stat_lm_splits;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -189,6 +190,8 @@ struct cge_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<hipEvent_t> event_pool; // recycled kernel-timer events
+    PinBuf<unsigned char> stage[2];    // pinned staging of the uploads (cge_set_graph / cge_set_embedding)
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr; // device->host result copies that overlap the kernels queued behind them
     hipEvent_t copy_ev = nullptr, copy_done = nullptr;
     std::string err;
@@ -203,6 +206,7 @@ struct cge_ctx {
     // ---- resident original graph --------------------------------------------------------
     i64 n = 0, m = 0, d = 0;
     bool unit_weights = false;
+    bool blocked_ready = false; // blocked copy of the edge list (edge pass) matches src/dst
     DevBuf<i32> src, dst;     // 0-based
     DevBuf<double> w;         // edge weights
     DevBuf<double> Xr;        // n x d row-major (node-major)
@@ -213,6 +217,13 @@ struct cge_ctx {
     DevBuf<i32> comm;         // n, 0-based
     DevBuf<unsigned short> comm16; // the same as uint16 when C < 65536 (2 MB at n = 10^6: L2-resident gather table)
     DevBuf<double> vw;        // n
+    // blocked copy of the edge list for the cluster-pair scatter (kernels_scatter.hip)
+    DevBuf<unsigned> be_edge;           // m words (u mod 32768) << 16 | (v mod 32768), grouped by (block of u, block of v)
+    DevBuf<double> be_w, be_wkeys, be_diag; // weights in that order (weighted lists); pass-1 outputs
+    DevBuf<i32> be_chunk;               // be_nchunks x {block of u, block of v, first edge, edges}
+    i64 be_nchunks = 0;
+    DevBuf<unsigned short> be_keys, be_runoff;
+    DevBuf<unsigned> be_base, be_cursor;
     std::vector<double> h_Xr; // host mirror, row-major (cut rules + RSS run on the host)
     std::vector<i32> h_comm;
     std::vector<double> h_vw;
@@ -263,7 +274,13 @@ struct cge_ctx {
     i64 stat_lm_batches = 0, stat_lm_rows = 0, stat_lm_splits = 0; // last runsplit: device batches, their rows, groups split
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
-    bool fit_persistent_broken = false; // a grid barrier timed out once (e.g. another process holds CUs): not tried again // f = max|w - S| of the last three Chung-Lu iterations (bit patterns)
+    // A hand-off of a persistent fit timed out (e.g. another process holds CUs): the rest of THIS sweep runs one launch per
+    // iteration.  Not latched for the life of the context: the next sweep tries the persistent form again, backing off
+    // (1, 3, 7, ... sweeps skipped) while the time-outs repeat; stat "fit_persistent_fallbacks" counts them.
+    bool fit_persistent_broken = false;
+    i64 stat_fit_fallbacks = 0;
+    int fit_fallback_streak = 0;
+    i64 fit_skip_sweeps = 0;
     DevBuf<i32> sw_cm_off, sw_cm_mem, sw_cm_pos; // community -> members CSR of the score graph and its inverse
     DevBuf<double> sw_zeros, sw_zsum;
     // diameter scratch
@@ -350,6 +367,23 @@ struct ScopedKernelTimer {
     }
 };
 
+#define CGE_FIT_TIMEOUT_TICKS 100000000LL // 1 s of the 100 MHz wall clock, re-armed at every Chung-Lu iteration
+static inline void note_fit_fallback(cge_ctx *c) {
+    if (c->opt_fit_test_timeout) return; // the testing hook abandons on purpose
+    c->fit_persistent_broken = true;
+    if (c->stat_fit_fallbacks++ == 0)
+        fprintf(stderr, "libcge_hip: a persistent Chung-Lu fit timed out waiting for another workgroup (is the GPU shared?); "
+                        "falling back to one launch per iteration for this sweep (stat fit_persistent_fallbacks)\n");
+    c->fit_fallback_streak = std::min(c->fit_fallback_streak + 1, 6);
+    c->fit_skip_sweeps = (1LL << (c->fit_fallback_streak - 1)) - 1;
+}
+// called at the start of a sweep: decide whether the persistent form is tried again
+static inline void fit_sweep_begin(cge_ctx *c) {
+    if (!c->fit_persistent_broken) return;
+    if (c->fit_skip_sweeps > 0) { c->fit_skip_sweeps--; return; }
+    c->fit_persistent_broken = false;
+}
+
 static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -364,6 +398,9 @@ static inline unsigned grid_for(i64 work, int block, i64 cap = 256 * 8) {
     if (g > cap) g = cap;
     return (unsigned)g;
 }
+
+#define CGE_STAGE_BYTES ((size_t)16 << 20) // one staging buffer of the uploads
+void cge_ensure_host_embedding(cge_ctx *c); // capi.cpp: fetch the host mirror of Xr on first demand
 
 // ---- kernels_*.hip entry points (host launchers) ---------------------------------------------
 // layout
@@ -413,6 +450,11 @@ void k_group_project(cge_ctx *c, const double *Xr, const double *vw, const i32 *
 void k_landmark_aggregate(cge_ctx *c, const double *Xr, const double *vw, const i32 *comm, const i32 *mem_off,
                           const i32 *mem, i64 N, i64 d, double *lemb, double *lweight, double *dii, i32 *lcomm);
 // per-edge scatter
+bool k_edge_scatter_blocked_applies(const cge_ctx *c, i64 C);
+bool k_build_blocked_edges(cge_ctx *c);
+void k_edge_scatter_blocked(cge_ctx *c, i64 c0, i64 c1, i64 C, int directed, double *vectC);
+void k_edge_scatter_blocked_init();
+#define CGE_COMM16_PAD 32768 // the uint16 community table is padded to a multiple of the edge pass's vertex block
 void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 e0, i64 e1, const i32 *v2l,
                     const i32 *comm, i64 N, i64 C, int directed, double *wedges, double *vectC);
 void k_edge_degrees(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 m, double *deg_out,

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void fit_persistent_kernel(const double *__res
     int par = parity, k = 0, converged = 0, failed = 0;
     if (timeout_ticks <= 0 || !gs.init(sync, wall_clock64() + timeout_ticks, &lds_ok)) { failed = 1; max_iters = 0; }
     while (k < max_iters) {
+        gs.deadline = wall_clock64() + timeout_ticks; // per iteration, as in the other forms
         // ---- A: tile products ----------------------------------------------------------------------------------
 #pragma unroll
         for (int s = 0; s < TPW; s++) {
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
     const int rq = lane >> 3, cq = lane & 7;
     const int NT = Nt * (Nt + 1) / 2;
     unsigned *fail = sync + 1, *done = sync + 2, *cntP = sync + 64, *cntT = sync + 4096;
-    const long long deadline = wall_clock64() + timeout_ticks;
+    long long deadline = wall_clock64() + timeout_ticks; // re-armed at every iteration: it bounds one hand-off, not the whole fit
 
     double g[TPW][8][8];
     int tI[TPW], tJ[TPW];
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
     int par = parity, k = 0, converged = 0, failed = 0;
     if (timeout_ticks <= 0) max_iters = 0; // test hook: abandon at once (exercises the host's restore-and-fall-back path)
     for (;;) {
+        deadline = wall_clock64() + timeout_ticks;
         if (k >= max_iters) { failed = 1; break; }
         // ---- 1. wait for T_k of the blocks this workgroup's tiles read (published by iteration k-1) --------------
         if (k > 0) {
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
     const int NT = Nt * (Nt + 1) / 2;
     const i64 Psz = (i64)Nt * Nt * 64;
     unsigned *fail = sync + 1, *done = sync + 2;
-    const long long deadline = wall_clock64() + timeout_ticks;
+    long long deadline = wall_clock64() + timeout_ticks; // re-armed at every iteration: it bounds one hand-off, not the whole fit
 
     double g[TPW][8][8];
     int tI[TPW], tJ[TPW];
@@ -557,6 +559,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
     int k = 0, converged = 0, failed = 0;
     if (timeout_ticks <= 0) max_iters = 0; // test hook: abandon at once
     for (;;) {
+        deadline = wall_clock64() + timeout_ticks;
         if (k >= max_iters) { failed = 1; break; }
         const double *Tk = (k == 0) ? T0 : ring + (i64)(k & 3) * Tld;
         double *Pk = P + (i64)(k & 1) * Psz;
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(256) void fit_dataflow_dir_kernel(const double *__r
     const int rq = lane >> 3, cq = lane & 7;
     const int NT = Nt * (Nt + 1) / 2;
     unsigned *fail = sync + 1, *done = sync + 2, *cntP = sync + 64, *cntT = sync + 4096;
-    const long long deadline = wall_clock64() + timeout_ticks;
+    long long deadline = wall_clock64() + timeout_ticks; // re-armed at every iteration: it bounds one hand-off, not the whole fit
     const i64 Pstride = (i64)Nt * Nt * 64;
 
     double g[TPW][8][8];
@@ -789,6 +792,7 @@ __global__ __launch_bounds__(256) void fit_dataflow_dir_kernel(const double *__r
     double eps = eps0, fprev = f0;
     if (timeout_ticks <= 0) max_iters = 0; // test hook
     for (;;) {
+        deadline = wall_clock64() + timeout_ticks;
         if (k >= max_iters) { failed = 1; break; }
         if (k > 0) { // 1. T_k of the blocks this workgroup's tiles read
             if (wave == 0) {
@@ -930,7 +934,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__r
     const int NT = Nt * (Nt + 1) / 2;
     const i64 Pstride = (i64)Nt * Nt * 64, Psz = 2 * Pstride;
     unsigned *fail = sync + 1, *done = sync + 2;
-    const long long deadline = wall_clock64() + timeout_ticks;
+    long long deadline = wall_clock64() + timeout_ticks; // re-armed at every iteration: it bounds one hand-off, not the whole fit
 
     double g[8][8];
     int tI = -1, tJ = -1;
@@ -972,6 +976,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__r
     double eps = eps0, fprev = f0;
     if (timeout_ticks <= 0) max_iters = 0; // test hook: abandon at once
     for (;;) {
+        deadline = wall_clock64() + timeout_ticks;
         if (k >= max_iters) { failed = 1; break; }
         const double *Tk = (k == 0) ? T0 : ring + (i64)(k & 3) * 2 * Tld; // Tin at Tk, Tout at Tk + Tld
         double *Pk = P + (i64)(k & 1) * Psz;
@@ -1219,7 +1224,7 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
     double aEps = eps, aDelta = delta;
     unsigned *aSync = (unsigned *)c->fp_flow.p;
     int *aFlags = dev_flags;
-    long long aTicks = c->opt_fit_test_timeout ? 0LL : 300000000LL; // 3 s of the 100 MHz wall clock (0: the test hook)
+    long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS; // per iteration (0: the test hook)
     void *args[] = {&aGD, &aN, &aNt, &aT0, &aTout, &aTld, &aW, &aEps, &aDelta, &aMax, &aRing, &aP, &aFq, &aSync, &aFlags, &aTicks};
     hipError_t e;
     {
@@ -1265,7 +1270,7 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
         double aEps = eps, aDelta = delta;
         unsigned *aSync = c->fp_sync.p;
         int *aFlags = c->fp_flags.p;
-        long long aTicks = c->opt_fit_test_timeout ? 0LL : 300000000LL; // 3 s of the 100 MHz wall clock (0: the test hook)
+        long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS; // per iteration (0: the test hook)
         void *args[] = {&aGD, &aN, &aNt, &aT, &aTld, &aPar, &aW, &aEps, &aDelta, &aMax, &aP, &aF, &aSync, &aFlags, &aTicks};
         const void *fn = dataflow ? (tpw == 1   ? (const void *)fit_dataflow_kernel<1>
                                      : tpw == 2 ? (const void *)fit_dataflow_kernel<2>
@@ -1295,7 +1300,7 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
         HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (hf[2]) { // a wait timed out
-            if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
+            note_fit_fallback(c);
             return false;
         }
         total += hf[1];
@@ -1347,7 +1352,7 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
                 double aEps = eps0, aF0 = f0, aDelta = delta;
                 unsigned *aSync = (unsigned *)c->fp_flow.p;
                 int *aFlags = c->fp_flags.p;
-                long long aTicks = c->opt_fit_test_timeout ? 0LL : 300000000LL;
+                long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS;
                 void *args[] = {&aGD, &aN, &aNt, &aT0, &aTi, &aTo, &aTld, &aDi, &aDo, &aEps, &aF0, &aDelta, &aMax, &aRing, &aP, &aFq,
                                 &aSync, &aFlags, &aTicks};
                 hipError_t e;
@@ -1360,7 +1365,7 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
                 HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));
                 if (hf[2] || !hf[0]) { // abandoned: Tin / Tout are untouched
-                    if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
+                    note_fit_fallback(c);
                     return false;
                 }
                 *iters = hf[1];
@@ -1388,7 +1393,7 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
     double aEps = eps0, aF0 = f0, aDelta = delta;
     unsigned *aSync = c->fp_sync.p;
     int *aFlags = c->fp_flags.p;
-    long long aTicks = c->opt_fit_test_timeout ? 0LL : 300000000LL;
+    long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS;
     void *args[] = {&aGD, &aN, &aNt, &aT, &aTld, &aPar, &aDi, &aDo, &aEps, &aF0, &aDelta, &aMax, &aP, &aF, &aSync, &aFlags, &aTicks};
     const void *fn = tpw == 1 ? (const void *)fit_dataflow_dir_kernel<1> : (const void *)fit_dataflow_dir_kernel<2>;
     int per_cu = 0;
@@ -1409,7 +1414,7 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
     HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (hf[2] || !hf[0]) {
-        if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
+        note_fit_fallback(c);
         return false;
     }
     const int par = hf[3];

@@ -94,6 +94,16 @@ void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 
                        status);
 }
 
+// device-wide radix sort of (uint32 key, int32 value) pairs on the low `bits` bits (stable)
+void k_sort_pairs_u32(cge_ctx *c, const unsigned *keys_in, unsigned *keys_out, const i32 *vals_in, i32 *vals_out, i64 n,
+                      int bits) {
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits, c->stream));
+    c->sort_tmp.ensure(bytes);
+    HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits,
+                                        c->stream));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Member lists on the device.  A group is a range of the member arena (vertex ids, 0-based, in the reference's
 // order); a split writes its two children behind each other into a fresh range, low first.

@@ -477,6 +477,7 @@ struct RssState {
 };
 void rule_rss_batched(cge_ctx *c, const Batch &B, Group *const *groups, const double *z, std::vector<RssState> &st) {
     const i64 T = B.T, d = c->d, width = 2 * (2 * d + 1);
+    cge_ensure_host_embedding(c); // generic round-based path only (ties at the maximum of z, NaNs)
     const double *hX = c->h_Xr.data(), *hw = c->h_vw.data();
     st.assign(T, RssState());
     parallel_for(c, T, [&](i64 t) {
@@ -1097,7 +1098,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                    std::vector<i64> &group_ids, bool want_index) {
     const i64 n = c->n, d = c->d;
     hipStream_t st = c->stream;
-    if ((i64)c->h_Xr.size() != n * d || (i64)c->h_vw.size() != n)
+    if (!c->Xr.p || c->Xr.n < (size_t)(n * d) || (i64)c->h_vw.size() != n)
         CGE_THROW(CGE_E_ARG, "runsplit: embedding / vertex weights are not resident");
     std::deque<Group> pool;
     Heap H;

@@ -160,6 +160,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     HIP_CHECK(hipMemsetAsync(TT.p, 0, sizeof(double) * 3 * Tld, st));
     HIP_CHECK(hipMemcpyAsync(TT.p, T1.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
     double *Tcur = TT.p;
+    fit_sweep_begin(c);
     bool use_persistent = !directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
                           (c->opt_fit_persistent >= 2 || N >= 128);
     bool use_persistent_dir = directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
@@ -400,7 +401,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
             const int *hf = (const int *)(c->pin_scal.p + RES_STRIDE * (ia & 1) + RES_FIT);
             if (hf[2] || !hf[0]) { // a wait timed out: drain what was enqueued behind it and redo this alpha from its T_0
                 HIP_CHECK(hipStreamSynchronize(st)); // (still in place) with one launch per iteration, as every later alpha
-                if (!c->opt_fit_test_timeout) c->fit_persistent_broken = true;
+                note_fit_fallback(c);
                 use_persistent = false;
                 tpar = sl.t0_par;
                 next_enqueue = ia;
@@ -469,6 +470,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     out[0] = best_alpha; out[1] = best_div; out[2] = best_div_ext; out[3] = best_div_int;
     out[4] = best_alpha_auc; out[5] = best_auc; out[6] = best_auc_err; // :256
     *out_len = 7;
+    if (c->stat_fit_persistent > 0 && !c->fit_persistent_broken) c->fit_fallback_streak = 0; // a clean persistent sweep
 }
 
 // ---- small helpers ---------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 # CGE_hip.jl -- the Julia side of the drop-in: same exported names and positional signatures as
 # CGE.jl's hot path (src/CGE.jl:11-21), each a thin `ccall` into libcge_hip.so (include/cge_hip.h).
 #
-# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no `julia` binary (DESIGN.md, "Boundary").
+# UNTESTED -- NEVER EXECUTED IN THIS REPOSITORY'S CI: the build image has no `julia` binary (DESIGN.md, "Boundary").
 # The Python mirror (cge.jl_amd/api.py) binds the identical C-ABI and is what the parity tests drive;
 # this file is the stub a CGE.jl maintainer would add.  Julia arrays are passed as they are: Int64
 # 1-based ids, column-major matrices -- the C-ABI was laid out for exactly that.
@@ -12,13 +12,21 @@ export landmarks, wGCL, wGCL_directed, split_cluster_rss, split_cluster_rss2, sp
 
 const LIB = get(ENV, "CGE_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "build", "libcge_hip.so"))
 
-# the reference passes the split rule as a function (src/auxilary.jl:64-67); the C-ABI takes an enum
+# The reference passes the split rule as a function (src/auxilary.jl:64-67); the C-ABI takes an enum.  The rule
+# is mapped BY NAME, so `CGE.split_cluster_rss` (what CGE's own `parseargs` returns) and the placeholders below
+# both work.  Use `using CGE: parseargs` next to `using CGE_hip` (a plain `using CGE` would clash on the exported
+# `landmarks`, `wGCL`, `wGCL_directed`).
 split_cluster_rss() = nothing
 split_cluster_rss2() = nothing
 split_cluster_size() = nothing
 split_cluster_diameter() = nothing
-const METHOD_CODE = IdDict{Function,Cint}(split_cluster_rss => 0, split_cluster_rss2 => 1,
-                                          split_cluster_size => 2, split_cluster_diameter => 3)
+const METHOD_CODE = Dict{String,Cint}("split_cluster_rss" => 0, "split_cluster_rss2" => 1,
+                                      "split_cluster_size" => 2, "split_cluster_diameter" => 3)
+function method_code(method::Function)
+    name = string(nameof(method))
+    haskey(METHOD_CODE, name) || throw(ArgumentError("unknown split rule $name (expected one of $(collect(keys(METHOD_CODE))))"))
+    return METHOD_CODE[name]
+end
 
 mutable struct Ctx
     h::Ptr{Cvoid}
@@ -27,13 +35,21 @@ mutable struct Ctx
         rc = ccall((:cge_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cvoid}), ref, device, C_NULL)
         rc == 0 || error("cge_create failed with code $rc (no MI355X visible? there is no CPU fallback)")
         c = new(ref[])
-        finalizer(x -> ccall((:cge_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), c)
+        finalizer(x -> (x.h != C_NULL && ccall((:cge_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h); x.h = C_NULL), c)
         return c
     end
 end
 
 const DEFAULT = Ref{Union{Nothing,Ctx}}(nothing)
-ctx() = (DEFAULT[] === nothing && (DEFAULT[] = Ctx()); DEFAULT[])
+function ctx()
+    if DEFAULT[] === nothing
+        DEFAULT[] = Ctx()
+        # tear the context down while the HIP runtime is still alive (streams and events must not outlive it)
+        atexit(() -> (c = DEFAULT[]; c !== nothing && c.h != C_NULL &&
+                      (ccall((:cge_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.h); c.h = C_NULL)))
+    end
+    return DEFAULT[]
+end
 
 lasterr(c::Ctx) = unsafe_string(ccall((:cge_last_error, LIB), Cstring, (Ptr{Cvoid},), c.h))
 
@@ -76,7 +92,7 @@ function landmarks(edges::Array{Int,2}, weights::Vector{Float64}, vweights::Vect
     N, ne, trunc = Ref{Int64}(0), Ref{Int64}(0), Ref{Cint}(0)
     check(c, ccall((:cge_landmarks_run, LIB), Cint,
                    (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Int64, Int64, Cint, Cint, Ref{Int64}, Ref{Int64}, Ref{Cint}),
-                   c.h, flat, off, length(clusters), land, forced, METHOD_CODE[method], directed, N, ne, trunc))
+                   c.h, flat, off, length(clusters), land, forced, method_code(method), directed, N, ne, trunc))
     trunc[] != 0 && @warn "Requested number of clusters larger than unique no. embeddings. Truncating to $(N[]) landmarks."
     verbose && println("Landmarks generated"); verbose && println("Using $(N[]) landmarks")
     n, d = size(embedding)
@@ -86,6 +102,15 @@ function landmarks(edges::Array{Int,2}, weights::Vector{Float64}, vweights::Vect
                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}),
                    c.h, dii, embed, cluster, ledges, lw, lweight, v_to_l))
     return dii, embed, reshape(cluster, :, 1), ledges, lw, lweight, v_to_l
+end
+
+# mirrors `cge_trace` (include/cge_hip.h): n_alpha, iters[64], div[64], auc[64]
+mutable struct Trace
+    n_alpha::Int64
+    iters::NTuple{64,Int64}
+    div::NTuple{64,Float64}
+    auc::NTuple{64,Float64}
+    Trace() = new(0, ntuple(_ -> 0, 64), ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 64))
 end
 
 # mirrors `cge_wgcl_args` (include/cge_hip.h) field for field
@@ -117,11 +142,12 @@ function _wgcl(directed::Bool, edges, eweights, comm, embed, distances, vweights
                      pointer(init_eweights), isempty(init_embed) ? C_NULL : pointer(init_embed),
                      split, seed, auc_samples, verbose, directed,
                      C_NULL, C_NULL, C_NULL, C_NULL, 0)     # samples: drawn by the library (pass arrays to own the RNG)
-        rc = ccall((:cge_wgcl, LIB), Cint, (Ptr{Cvoid}, Ref{WgclArgs}, Ptr{Float64}, Ref{Cint}, Ptr{Cvoid}),
-                   c.h, Ref(a), out, olen, C_NULL)
+        tr = Trace()
+        rc = ccall((:cge_wgcl, LIB), Cint, (Ptr{Cvoid}, Ref{WgclArgs}, Ptr{Float64}, Ref{Cint}, Ref{Trace}),
+                   c.h, Ref(a), out, olen, tr)
         check(c, rc)
     end
-    write(stderr, "\n")                                  # src/divergence.jl:255
+    write(stderr, "."^tr.n_alpha, "\n")                  # one "." per alpha (src/divergence.jl:140) and the newline (:255)
     return out[1:olen[]]
 end
 

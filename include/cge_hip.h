@@ -77,7 +77,10 @@ int cge_exchange_buffer(cge_ctx *ctx, int64_t min_doubles, void **dev_ptr, int64
 /* or hand the library a caller-owned device buffer (e.g. a torch tensor) to use as exchange buffer */
 int cge_set_exchange_buffer(cge_ctx *ctx, void *dev_ptr, int64_t capacity_doubles);
 
-/* ---- resident inputs (the ORIGINAL graph; uploaded once, H2D + layout change) --------------- */
+/* ---- resident inputs (the ORIGINAL graph; uploaded once, H2D + layout change) ---------------
+ * Calling cge_set_graph with another vertex count drops the resident embedding and vertex data (they were sized for the
+ * old vertex set); cge_landmarks_run / cge_score check that all resident inputs agree and fail with CGE_E_ARG otherwise.
+ * cge_wgcl in exact mode (empty v_to_l) makes ITS graph the resident one (the sampler rejects against it).             */
 /* src/dst: the two columns of the reference's `edges::Matrix{Int}` (src/auxilary.jl:106); w: eweights */
 int cge_set_graph(cge_ctx *ctx, const int64_t *src, const int64_t *dst, const double *w, int64_t m, int64_t n);
 /* embedding::Matrix{Float64} n x d column-major (src/auxilary.jl:164) */
@@ -212,7 +215,7 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
 int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
 /* "landmarks" (N of the last run, no side effects), "diameter_path" (1 brute / 2 pruned), "diameter_candidate_pairs", "diameter_candidate_tiles", "diameter_refs" (reference points) of the last run;
  * "diameter_bits" = the bit pattern of the last `hi` (reinterpret the int64 as a double);
- * "fit_persistent_alphas" = alphas of the last sweep fitted by a persistent launch, "fit_iterations" = Chung-Lu
+ * "fit_persistent_alphas" = alphas of the last sweep fitted by a persistent launch, "fit_persistent_fallbacks" = persistent fits abandoned since the context was created, "fit_iterations" = Chung-Lu
  * iterations of the last sweep (all alphas); "landmark_batches" / "landmark_batch_rows" / "landmark_splits" =
  * device batches of the last runsplit, the rows they covered, the groups they split                     */
 int cge_get_stat(cge_ctx *ctx, const char *key, int64_t *value);

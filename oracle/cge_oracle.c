@@ -732,6 +732,17 @@ double orc_max_pair_dist(const double *emb, i64 n, i64 d) {
     return sqrt(best);
 }
 
+/* Full-size fixtures only (tests/golden/make_oracle_fixture_fullsize.py): at n = 10^6 the loop above is ~10^14
+ * flop, so the fixture generator hands in the diameter instead -- found by an independent exact method (triangle-
+ * inequality branch and bound over community pairs in numpy, tests/diameter_ref.py, the arg-max pair re-evaluated with
+ * orc_dist's own arithmetic) that tests/test_oracle_golden.py checks against orc_max_pair_dist where the loop can run.
+ * 0 (the default) = run the reference's loop.  Nothing else in the oracle changes.                                    */
+static double orc_known_diameter = 0.0;
+void orc_set_known_diameter(double hi) { orc_known_diameter = hi; }
+static double orc_diameter(const double *emb, i64 n, i64 d) {
+    return orc_known_diameter > 0.0 ? orc_known_diameter : orc_max_pair_dist(emb, n, d);
+}
+
 /* Sampled pairs for the local score.  The reference draws them with
  * Random.seed!/StatsBase.sample (src/divergence.jl:184-210); the stream cannot
  * be reproduced without Julia, so the oracle takes the draws as input:
@@ -799,7 +810,7 @@ int orc_wgcl(const i64 *edges, i64 m, const double *eweights, const i64 *comm, i
     double fhi = 1.0;
     if (landmarks) {
         adj_n = n_init; adj_edges = init_edges; adj_ew = init_eweights; adj_m = m_init;
-        fhi = orc_max_pair_dist(init_embed, adj_n, d); /* :104-114, lo == 0 */
+        fhi = orc_diameter(init_embed, adj_n, d); /* :104-114, lo == 0 */
     }
     double *T = (double *)malloc(sizeof(double) * (size_t)N), *S = (double *)malloc(sizeof(double) * (size_t)N);
     for (i64 i = 0; i < N; i++) T[i] = 1.0; /* :118 */
@@ -982,7 +993,7 @@ int orc_wgcl_directed(const i64 *edges, i64 m, const double *eweights, const i64
     double fhi = 1.0;
     if (landmarks) {
         adj_n = n_init; adj_edges = init_edges; adj_ew = init_eweights; adj_m = m_init;
-        fhi = orc_max_pair_dist(init_embed, adj_n, d); /* :386-397 */
+        fhi = orc_diameter(init_embed, adj_n, d); /* :386-397 */
     }
     double *Tin = (double *)malloc(sizeof(double) * (size_t)N), *Tout = (double *)malloc(sizeof(double) * (size_t)N);
     double *Sin = (double *)malloc(sizeof(double) * (size_t)N), *Sout = (double *)malloc(sizeof(double) * (size_t)N);

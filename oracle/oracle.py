@@ -105,6 +105,12 @@ def max_pair_dist(embedding):
     return lib().orc_max_pair_dist(_ptr(ef), C.c_int64(e.shape[0]), C.c_int64(e.shape[1]))
 
 
+def set_known_diameter(hi):
+    """Full-size fixtures only: hand the point-set diameter to wGCL / wGCL_directed in landmark mode instead of running
+    the O(n^2 d) loop of src/divergence.jl:104-113 (0 = run the loop).  See the comment in cge_oracle.c."""
+    lib().orc_set_known_diameter(C.c_double(float(hi)))
+
+
 def unique_rows(embedding):
     e, ef = _f(embedding)
     return lib().orc_unique_rows(_ptr(ef), C.c_int64(e.shape[0]), C.c_int64(e.shape[1]))

@@ -752,6 +752,33 @@ def test_edge_scatter_kernel(ctx, synth20k, directed):
     assert np.array_equal(w1 + w2, exp) and np.array_equal(c1 + c2, expc)
 
 
+@pytest.mark.parametrize("directed", [False, True])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_edge_scatter_blocked_two_pass_form(ctx, directed, weighted):
+    """The score path's form of the per-edge cluster-pair scatter (kernels_scatter.hip: blocked edge list, community
+    slices in LDS, off-diagonal pairs bucketed by row, no global atomics) against numpy: several vertex blocks, chunks
+    that split a tile, unit and dyadic weights, packed (undirected) and C x C (directed) outputs; repeated calls reuse the
+    blocked copy; a graph with more communities than the path holds falls back to the gather kernel with the same result."""
+    from cge.jl_amd import synth
+
+    rng = np.random.default_rng(11)
+    for n, m, C in ((150_000, 1_600_000, 37), (40_000, 300_000, 1500), (3_000, 20_000, 5)):
+        g = synth.abcd_like(n, m, C, 4, seed=23, directed=directed)
+        w = (rng.integers(1, 9, size=g["m"]) / 4.0) if weighted else g["eweights"]
+        ctx.set_graph(g["edges"], w, g["n"])
+        ctx.set_vertex_data(g["comm"], g["vweights"])
+        comm = g["comm"][:, 0] - 1
+        ca, cb = comm[g["edges"][:, 0] - 1], comm[g["edges"][:, 1] - 1]
+        if directed:
+            exp = np.bincount(ca * C + cb, weights=w, minlength=C * C)
+        else:
+            lo, hi = np.minimum(ca, cb), np.maximum(ca, cb)
+            exp = np.bincount(C * lo - lo * (lo - 1) // 2 + (hi - lo), weights=w, minlength=C * (C + 1) // 2)
+        for _ in range(2):
+            _, vc = ctx.edge_scatter(None, 1, C, directed, want_wedges=False)
+            assert np.array_equal(vc, exp) and vc.sum() == w.sum()
+
+
 @pytest.mark.parametrize("n,d", [(10000, 32), (2999, 37), (777, 128), (130, 5)])
 def test_max_pair_dist_kernel(ctx, orc, example10k, n, d):
     """fp64-MFMA diameter kernel vs the O(n^2 d) brute force (src/divergence.jl:104-113)."""

@@ -101,3 +101,46 @@ def test_runsplit_forced_count(test115):
     gid = orc.runsplit(a["embedding"], a["vweights"], a["clusters"], 1, 4, "rss")
     sizes = [len(c) for c in a["clusters"]]
     assert gid.max() + 1 == sum(min(s, 4) for s in sizes)  # N_eff = sum_c min(|c|, f) when l is small
+
+
+@pytest.mark.parametrize("n,m,C,d,seed", [(3000, 20000, 7, 16, 1), (12000, 100000, 20, 32, 1), (6000, 40000, 40, 128, 3)])
+def test_diameter_reference_equals_the_oracle_loop(n, m, C, d, seed):
+    """tests/diameter_ref.py (the exact branch and bound that stands in for the O(n^2 d) loop in the full-size fixtures)
+    returns the BITS of orc_max_pair_dist (src/divergence.jl:104-113) wherever the loop can run, and a pair attaining it;
+    also with labels that carry no information and with a single group (no pruning at all)."""
+    from cge.jl_amd import synth
+    from diameter_ref import dist_seq, exact_diameter
+
+    g = synth.abcd_like(n, m, C, d, seed=seed)
+    X = g["embedding"]
+    ref = orc.max_pair_dist(X)
+    hi, i, j, st = exact_diameter(X, g["comm"][:, 0])
+    assert hi == ref and i < j and dist_seq(X[i], X[j])[0] == ref
+    assert st["pairs_evaluated"] < 0.01 * n * n  # it really prunes on a graph with community structure
+    sub = X[:2500]
+    rng = np.random.default_rng(seed)
+    ref = orc.max_pair_dist(sub)
+    assert exact_diameter(sub, rng.integers(0, 9, len(sub)))[0] == ref
+    assert exact_diameter(sub, np.zeros(len(sub), dtype=int))[0] == ref
+
+
+def test_known_diameter_hook_changes_nothing_else(example10k):
+    """oracle.set_known_diameter (full-size fixtures): with the true diameter handed in, landmark-mode wGCL returns the
+    bits it returns with its own loop; with a wrong one only the local score (elements 5-7) moves."""
+    from diameter_ref import exact_diameter
+
+    a = example10k
+    lm = orc.landmarks(a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], a["embedding"], False, 200, 4,
+                       "rss", False)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+    smp = random_samples(np.random.default_rng(3), len(a["eweights"]), len(a["vweights"]), 3000)
+    args = (ledges, lw, lcomm, lemb, dii, lweight, a["vweights"], v2l, a["edges"], a["eweights"], a["embedding"], False, smp)
+    base = orc.wGCL(*args)
+    try:
+        orc.set_known_diameter(exact_diameter(a["embedding"], a["comm"][:, 0])[0])
+        assert np.array_equal(orc.wGCL(*args), base)
+        orc.set_known_diameter(3.0 * orc.max_pair_dist(a["embedding"]))
+        other = orc.wGCL(*args)
+        assert np.array_equal(other[:4], base[:4]) and not np.array_equal(other[4:], base[4:])
+    finally:
+        orc.set_known_diameter(0.0)
