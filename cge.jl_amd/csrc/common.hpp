@@ -222,6 +222,7 @@ struct cge_ctx {
     DevBuf<double> be_w, be_wkeys, be_diag; // weights in that order (weighted lists); pass-1 outputs
     DevBuf<i32> be_chunk;               // be_nchunks x {block of u, block of v, first edge, edges}
     i64 be_nchunks = 0;
+    int be_per = 16;                    // edges per thread of the edge pass the chunks were cut for (kernels_scatter.hip)
     DevBuf<unsigned short> be_keys, be_runoff;
     DevBuf<unsigned> be_base, be_cursor;
     std::vector<double> h_Xr; // host mirror, row-major (cut rules + RSS run on the host)

@@ -3,49 +3,55 @@
 // from a table in memory.
 //
 // Data layout (built once per resident graph, by the first edge pass after cge_set_graph):
-//   * the edge list is kept a second time BLOCKED: vertices in blocks of 32768, edges grouped by (block of u, block of v)
-//     and stored as one 32-bit word (u mod 32768) << 16 | (v mod 32768) -- 4 bytes per edge instead of the reference's
-//     16 (two Int64), plus the weight (8 bytes) only for a weighted list.  A group is cut into chunks of <= 16384 edges.
+//   * the edge list is kept a second time BLOCKED: edges grouped by (block of 131072 source vertices, block of 32768
+//     target vertices), sorted by source inside a group, one 32-bit word (u mod 131072) << 15 | (v mod 32768) per edge --
+//     4 bytes instead of the reference's 16 (two Int64), plus the weight (8 bytes) only for a weighted list.  A group is
+//     cut into chunks of <= 16384 edges.
 //   * the community table is uint16 (C <= 1024 on this path), padded to a multiple of 32768 entries.
-// Pass 1 (edge_pass_kernel, one 1024-thread workgroup per chunk): the two 64 KB slices of the community table that the
-//   chunk can touch are copied into LDS (coalesced 16-byte loads), so the 2 m community look-ups are LDS reads; intra-
-//   community edges (the bulk of a graph with community structure) are summed in LDS per community; the others are
-//   counted per row (= smaller community), the workgroup claims a contiguous piece of a key array with ONE atomic, and
-//   writes its off-diagonal edges there grouped by row (the column as uint16 + the weight when weighted), with the
-//   per-row offsets beside it.
-// Pass 2 (edge_row_reduce_kernel, one workgroup per row of the C x C matrix): walks the row's piece of every chunk,
-//   accumulates the row in LDS, adds the diagonal partials of all chunks in a fixed order and writes the row with plain
-//   stores -- every output bin is written exactly once (no memset, no atomics to memory).
-// Unit weights: all sums are exact integers, results are bitwise reproducible.  Weighted lists: the LDS additions of one
-// bin are unordered (last-bit differences for non-dyadic weights), as with the atomics this replaces.
+// Pass 1 (edge_pass_kernel, one 1024-thread workgroup per chunk, two per CU): the 64 KB slice of the community table that
+//   the chunk's TARGETS can touch is copied into LDS (coalesced 16-byte loads); the communities of the SOURCES come from
+//   memory with ascending addresses (the chunk is sorted by source: a wave's loads fall into a few cache lines).  Intra-
+//   community edges (the bulk of a graph with community structure) are counted / summed in LDS per community; the others
+//   are counted per row (= smaller community), then written grouped by row (the column as uint16, staged in LDS and
+//   copied out coalesced; the weight beside it when weighted) into the chunk's own piece of a key array, with the per-row
+//   offsets beside it.
+// Pass 2 (edge_row_reduce_kernel, grid = rows x batches of 256 chunks, one chunk per thread): adds the chunk's keys of the
+//   row into the workgroup's LDS copy of the row and the workgroup adds that into vect_C with contiguous atomics.
+// No per-edge atomic ever leaves the CU.  Unit weights: all sums are exact integers, results are bitwise reproducible.
+// Weighted lists: additions of one bin are unordered (last-bit differences for non-dyadic weights), as with the per-edge
+// atomics this replaces.
 #include "common.hpp"
 
-#define EB_BLOCK_BITS 15
-#define EB_BLOCK (1 << EB_BLOCK_BITS)   // vertices per block
-#define EB_THREADS 1024
-#define EB_PER_THREAD 16
-#define EB_CHUNK (EB_THREADS * EB_PER_THREAD) // edges per chunk at most
 #define EB_MAXC 1024
 #define EB_NONE 0xFFFFFFFFu
+#define EB_RBATCH 256 // chunks per workgroup of the row reduction (one per thread)
+#define EB_RKEYS 16   // keys a thread of the row reduction requests at once
 
-__global__ void eb_tile_keys_kernel(const i32 *__restrict__ src, const i32 *__restrict__ dst, i64 m, unsigned nb,
+#define EB_UBITS 17 // source block: 131072 vertices
+#define EB_VBITS 15 // target block: 32768 vertices (a 64 KB uint16 slice in LDS)
+#define EB_THREADS 1024
+
+// sort key of an edge: (tile, source inside the tile); the value is the edge's row in the list
+__global__ void eb_tile_keys_kernel(const i32 *__restrict__ src, const i32 *__restrict__ dst, i64 m, unsigned nbv,
                                     unsigned *__restrict__ keys, i32 *__restrict__ idx) {
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += stride) {
-        keys[e] = ((unsigned)src[e] >> EB_BLOCK_BITS) * nb + ((unsigned)dst[e] >> EB_BLOCK_BITS);
+        const unsigned u = (unsigned)src[e], v = (unsigned)dst[e];
+        keys[e] = (((u >> EB_UBITS) * nbv + (v >> EB_VBITS)) << EB_UBITS) | (u & ((1u << EB_UBITS) - 1u));
         idx[e] = (i32)e;
     }
 }
-// blocked words (and weights) in tile order; first position of every tile that occurs
+// blocked words (and weights) in sorted order; first position of every tile that occurs
 __global__ void eb_gather_kernel(const i32 *__restrict__ src, const i32 *__restrict__ dst, const double *__restrict__ w,
                                  const unsigned *__restrict__ skeys, const i32 *__restrict__ sidx, i64 m,
                                  unsigned *__restrict__ bedge, double *__restrict__ bw, i32 *__restrict__ tile_first) {
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
         const i32 e = sidx[k];
-        bedge[k] = (((unsigned)src[e] & (EB_BLOCK - 1)) << 16) | ((unsigned)dst[e] & (EB_BLOCK - 1));
+        bedge[k] = (((unsigned)src[e] & ((1u << EB_UBITS) - 1u)) << EB_VBITS) | ((unsigned)dst[e] & ((1u << EB_VBITS) - 1u));
         if (bw) bw[k] = w[e];
-        if (k == 0 || skeys[k] != skeys[k - 1]) tile_first[skeys[k]] = (i32)k;
+        const unsigned t = skeys[k] >> EB_UBITS;
+        if (k == 0 || t != (skeys[k - 1] >> EB_UBITS)) tile_first[t] = (i32)k;
     }
 }
 
@@ -53,21 +59,33 @@ void k_sort_pairs_u32(cge_ctx *c, const unsigned *keys_in, unsigned *keys_out, c
                       int bits); // kernels_sort.hip (rocPRIM)
 
 // Build the blocked copy of the resident edge list.  Returns false when this path does not apply (the caller then uses
-// the gather + atomics kernel): more than 64 vertex blocks (n > 2 097 152) or no uint16 community table.
+// the gather + atomics kernel): more than 2^21 vertices or an edge count beyond int32.
 bool k_build_blocked_edges(cge_ctx *c) {
     const i64 n = c->n, m = c->m;
-    const i64 nb = (n + EB_BLOCK - 1) >> EB_BLOCK_BITS;
-    if (nb > 64 || m <= 0 || m >= (1LL << 31)) return false;
+    const i64 nbu = (n + (1 << EB_UBITS) - 1) >> EB_UBITS, nbv = (n + (1 << EB_VBITS) - 1) >> EB_VBITS;
+    if (nbu > 16 || nbv > 64 || m <= 0 || m >= (1LL << 31)) return false;
     hipStream_t st = c->stream;
-    const i64 T = nb * nb;
+    const i64 T = nbu * nbv;
+    // edges per thread of the edge pass: the smallest of 16 / 20 / 24 with which the chunks fit ONE round of the chip's
+    // 2 x CUs workgroup slots (a second, half-empty round costs a whole latency chain); 16 when even 24 needs two rounds
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    static const int env_per = getenv("CGE_EB_PER") ? atoi(getenv("CGE_EB_PER")) : 0; // tuning only
+    int per_thread = 16;
+    for (int cand : {16, 20, 24})
+        if ((m + (i64)EB_THREADS * cand - 1) / ((i64)EB_THREADS * cand) + T / 2 <= (i64)2 * cus) { per_thread = cand; break; }
+    if (env_per == 16 || env_per == 20 || env_per == 24) per_thread = env_per;
+    c->be_per = per_thread;
+    const i64 EB_CHUNK = (i64)EB_THREADS * per_thread;
     DevBuf<unsigned> keys, skeys;
     DevBuf<i32> idx, sidx, tfirst;
     keys.ensure(m); skeys.ensure(m); idx.ensure(m); sidx.ensure(m); tfirst.ensure(T + 1);
-    hipLaunchKernelGGL(eb_tile_keys_kernel, dim3(grid_for(m, 256)), dim3(256), 0, st, c->src.p, c->dst.p, m, (unsigned)nb,
-                       keys.p, idx.p);
+    hipLaunchKernelGGL(eb_tile_keys_kernel, dim3(grid_for(m, 256)), dim3(256), 0, st, c->src.p, c->dst.p, m, (unsigned)nbv, keys.p,
+                       idx.p);
     int bits = 1;
     while (((i64)1 << bits) < T) bits++;
-    k_sort_pairs_u32(c, keys.p, skeys.p, idx.p, sidx.p, m, bits);
+    k_sort_pairs_u32(c, keys.p, skeys.p, idx.p, sidx.p, m, bits + EB_UBITS);
     c->be_edge.alloc_exact(m);
     if (!c->unit_weights) c->be_w.alloc_exact(m); else c->be_w.release();
     HIP_CHECK(hipMemsetAsync(tfirst.p, 0xFF, sizeof(i32) * (T + 1), st));
@@ -86,23 +104,24 @@ bool k_build_blocked_edges(cge_ctx *c) {
         if (len <= 0) continue;
         const i64 parts = (len + EB_CHUNK - 1) / EB_CHUNK, per = (len + parts - 1) / parts; // equal pieces
         for (i64 s = 0; s < len; s += per) {
-            ch.push_back((i32)(t / nb)); ch.push_back((i32)(t % nb));
+            ch.push_back((i32)(t / nbv)); ch.push_back((i32)(t % nbv));
             ch.push_back((i32)(tf[t] + s)); ch.push_back((i32)std::min(per, len - s));
         }
     }
     c->be_nchunks = (i64)ch.size() / 4;
     c->be_chunk.alloc_exact(ch.size());
     HIP_CHECK(hipMemcpyAsync(c->be_chunk.p, ch.data(), sizeof(i32) * ch.size(), hipMemcpyHostToDevice, st));
+    c->be_keys.ensure(m + 64); // + a readable tail (the row reduction clamps empty runs to their start)
+    if (!c->unit_weights) c->be_wkeys.ensure(m + 64);
     HIP_CHECK(hipStreamSynchronize(st));
-    c->be_keys.ensure(m);
-    if (!c->unit_weights) c->be_wkeys.ensure(m);
-    c->be_cursor.ensure(1);
     c->blocked_ready = true;
     return true;
 }
 
-// exclusive prefix sum of cnt[0..C) (C <= 1024, one entry per thread) -> returned; total in *tot (LDS word)
-__device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsigned *wave_sums, unsigned *tot) {
+// exclusive scan over the THREADS threads of a workgroup; returns the exclusive value, *total (LDS) = block sum
+template <int THREADS>
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *wave_sums, unsigned *total) {
+    constexpr int NW = THREADS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned inc = v;
 #pragma unroll
@@ -112,179 +131,255 @@ __device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned v, unsign
     }
     if (lane == 63) wave_sums[wave] = inc;
     __syncthreads();
-    if (wave == 0) {
-        unsigned s = lane < EB_THREADS / 64 ? wave_sums[lane] : 0u, si = s;
+    unsigned before = 0, all = 0;
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const unsigned t = __shfl_up(si, off);
-            if (lane >= off) si += t;
-        }
-        if (lane < EB_THREADS / 64) wave_sums[lane] = si - s; // exclusive wave offsets
-        if (lane == EB_THREADS / 64 - 1) *tot = si;
+    for (int w = 0; w < NW; w++) {
+        const unsigned x = wave_sums[w];
+        if (w < wave) before += x;
+        all += x;
     }
+    if (threadIdx.x == 0) *total = all;
     __syncthreads();
-    return wave_sums[wave] + inc - v;
+    return before + inc - v;
 }
 
-template <bool WEIGHTED, bool DIRECTED>
-__global__ __launch_bounds__(EB_THREADS) void edge_pass_kernel(const unsigned *__restrict__ bedge,
-                                                               const double *__restrict__ bw,
+// ---- pass 1 ------------------------------------------------------------------------------------------------------------
+// LDS: sv (32768 uint16: communities of the target block; reused as the key staging area once the look-ups are done) |
+//      dsum[Cpad] f64 (weighted lists: intra-community sums) | cnt[2 Cpad] u32: [0, Cpad) off-diagonal edges per row (then
+//      the row cursors), [Cpad, 2 Cpad) intra-community edge counts (unit weights) | wave sums, total
+template <int EB_PER, bool WEIGHTED, bool DIRECTED>
+__global__ __launch_bounds__(EB_THREADS, WEIGHTED ? 4 : 8) void edge_pass_kernel(const unsigned *__restrict__ bedge, const double *__restrict__ bw,
                                                                const i32 *__restrict__ chunks, int chunk0,
-                                                               const unsigned short *__restrict__ comm16, int C,
-                                                               unsigned *__restrict__ cursor,
-                                                               unsigned short *__restrict__ keys,
-                                                               double *__restrict__ wkeys,
+                                                               const unsigned short *__restrict__ comm16, int C, int Cpad,
+                                                               unsigned short *__restrict__ keys, double *__restrict__ wkeys,
                                                                unsigned short *__restrict__ runoff,
-                                                               unsigned *__restrict__ base_out,
-                                                               double *__restrict__ diag_out) {
+                                                               double *__restrict__ diag_out, double *__restrict__ vectC,
+                                                               i64 vlen, int stop /* timing diagnostics only */) {
+    constexpr int VBLOCK = 1 << EB_VBITS, EPT = EB_MAXC / EB_THREADS > 0 ? EB_MAXC / EB_THREADS : 1;
+    static_assert(VBLOCK >= EB_THREADS * EB_PER, "the key staging area reuses the slice");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned short *su = (unsigned short *)lds;          // communities of the block of u
-    unsigned short *sv = su + EB_BLOCK;                   // ... of the block of v (aliases su on a diagonal tile)
-    double *diag = (double *)(lds + 4 * EB_BLOCK);        // [EB_MAXC] intra-community sums
-    unsigned *cnt = (unsigned *)(diag + EB_MAXC);         // [EB_MAXC] off-diagonal edges per row, then the row cursors
-    unsigned *wave_sums = cnt + EB_MAXC;                  // [16]
-    unsigned *misc = wave_sums + 16;                      // [0] total, [1] base
-    const int tid = threadIdx.x, wg = blockIdx.x;
+    unsigned short *sv = (unsigned short *)lds;
+    unsigned short *stage = sv;
+    double *dsum = (double *)(lds + 2 * VBLOCK);
+    unsigned *cnt = (unsigned *)(dsum + (WEIGHTED ? Cpad : 0));
+    unsigned *wave_sums = cnt + 2 * Cpad;
+    unsigned *misc = wave_sums + 16; // [0] total
+    const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
     const i32 *ch = chunks + 4 * (i64)(chunk0 + wg);
     const int bu = ch[0], bv = ch[1], start = ch[2], len = ch[3];
-    {
-        const uint4 *gu = (const uint4 *)(comm16 + (i64)bu * EB_BLOCK);
-        uint4 *lu = (uint4 *)su;
+    // All the edge words of a thread are requested up front, ahead of the table slice (a load under `if (e < len)` would
+    // wait for each in turn), and the source communities right behind them.
+    unsigned packed[EB_PER];
+    double wv[WEIGHTED ? EB_PER : 1];
 #pragma unroll
-        for (int i = 0; i < EB_BLOCK / 8 / EB_THREADS; i++) lu[tid + i * EB_THREADS] = gu[tid + i * EB_THREADS];
-        if (bv != bu) {
-            const uint4 *gv = (const uint4 *)(comm16 + (i64)bv * EB_BLOCK);
-            uint4 *lv = (uint4 *)sv;
-#pragma unroll
-            for (int i = 0; i < EB_BLOCK / 8 / EB_THREADS; i++) lv[tid + i * EB_THREADS] = gv[tid + i * EB_THREADS];
-        } else
-            sv = su;
-    }
-    diag[tid] = 0.0;
-    cnt[tid] = 0u;
-    __syncthreads();
-    // sweep 1: communities of every edge of the chunk; intra-community mass and per-row counts
-    unsigned packed[EB_PER_THREAD];
-    double wv[WEIGHTED ? EB_PER_THREAD : 1];
-#pragma unroll
-    for (int k = 0; k < EB_PER_THREAD; k++) {
+    for (int k = 0; k < EB_PER; k++) {
         const int e = tid + k * EB_THREADS;
-        packed[k] = EB_NONE;
-        if (e < len) {
-            const unsigned be = bedge[start + e];
-            unsigned cu = su[be >> 16], cv = sv[be & 0xFFFFu];
-            if (!DIRECTED && cu > cv) { const unsigned t = cu; cu = cv; cv = t; }
-            const double we = WEIGHTED ? bw[start + e] : 1.0;
-            if (WEIGHTED) wv[k] = we;
-            if (cu == cv)
-                unsafeAtomicAdd(&diag[cu], we);
-            else {
-                atomicAdd(&cnt[cu], 1u);
-                packed[k] = (cu << 16) | cv;
+        const int ec = e < len ? e : len - 1;
+        packed[k] = bedge[start + ec];
+        if (WEIGHTED) wv[k] = bw[start + ec];
+    }
+    {
+        const uint4 *gv = (const uint4 *)(comm16 + (i64)bv * VBLOCK);
+        uint4 *lv = (uint4 *)sv;
+        for (int i = tid; i < VBLOCK / 8; i += EB_THREADS) lv[i] = gv[i];
+    }
+    for (int k = tid; k < 2 * Cpad; k += EB_THREADS) cnt[k] = 0u;
+    if (WEIGHTED)
+        for (int k = tid; k < Cpad; k += EB_THREADS) dsum[k] = 0.0;
+    { // this workgroup's share of zeroing the output (the row reduction adds into it)
+        const i64 per = (vlen + nwg - 1) / nwg, z0 = per * wg, z1 = min(vlen, z0 + per);
+        for (i64 k = z0 + tid; k < z1; k += EB_THREADS) vectC[k] = 0.0;
+    }
+    const unsigned short *cu_tab = comm16 + ((i64)bu << EB_UBITS);
+    unsigned cus[EB_PER];
+#pragma unroll
+    for (int k = 0; k < EB_PER; k++) cus[k] = cu_tab[packed[k] >> EB_VBITS]; // ascending addresses across a wave
+    __syncthreads();
+    if (stop == 1) { if (cus[0] == 0x12345u && (!WEIGHTED || wv[0] == 1.5)) keys[0] = 1; return; }
+    // sweep 1: communities of every edge of the chunk; intra-community mass and per-row counts
+#pragma unroll
+    for (int k = 0; k < EB_PER; k++) {
+        unsigned cu = cus[k], cv = sv[packed[k] & (VBLOCK - 1)];
+        if (!DIRECTED && cu > cv) { const unsigned t = cu; cu = cv; cv = t; }
+        packed[k] = (cu << 16) | cv;
+    }
+    if (stop == 2) { unsigned x = 0; for (int k = 0; k < EB_PER; k++) x ^= packed[k]; if (x == 0x12345u) keys[0] = 1; return; }
+#pragma unroll
+    for (int k = 0; k < EB_PER; k++) {
+        const int e = tid + k * EB_THREADS;
+        const unsigned cu = packed[k] >> 16, cv = packed[k] & 0xFFFFu;
+        const bool intra = cu == cv;
+        if (e >= len)
+            packed[k] = EB_NONE;
+        else if (WEIGHTED && intra) {
+            unsafeAtomicAdd(&dsum[cu], wv[k]);
+            packed[k] = EB_NONE;
+        } else { // one 32-bit LDS add per edge: a row count, or (unit weights) an intra-community count
+            atomicAdd(&cnt[cu + (intra ? Cpad : 0)], 1u);
+            if (intra) packed[k] = EB_NONE;
+        }
+    }
+    __syncthreads(); // all look-ups are done: sv becomes the staging area
+    if (stop == 3) { if (cnt[tid % Cpad] == 0x12345u) keys[0] = 1; return; }
+    // row offsets inside the chunk's own piece of the key array, keys[start ..) (a thread owns EPT consecutive rows)
+    unsigned loc[EPT], mine = 0;
+#pragma unroll
+    for (int q = 0; q < EPT; q++) {
+        const int r = tid * EPT + q;
+        loc[q] = r < Cpad ? cnt[r] : 0u;
+        mine += loc[q];
+    }
+    unsigned off = block_exclusive_scan<EB_THREADS>(mine, wave_sums, &misc[0]);
+    unsigned short *ro = runoff + (i64)wg * (C + 1);
+#pragma unroll
+    for (int q = 0; q < EPT; q++) {
+        const int r = tid * EPT + q;
+        if (r < Cpad) cnt[r] = off;
+        if (r < C) ro[r] = (unsigned short)off;
+        off += loc[q];
+    }
+    __syncthreads();
+    const unsigned total = misc[0];
+    if (tid == 0) ro[C] = (unsigned short)total;
+    if (stop == 4) return;
+    // sweep 2: the columns of the off-diagonal edges, grouped by row, staged in LDS (weights go straight to memory)
+#pragma unroll
+    for (int k = 0; k < EB_PER; k++) {
+        if (packed[k] != EB_NONE) {
+            const unsigned pos = atomicAdd(&cnt[packed[k] >> 16], 1u);
+            stage[pos] = (unsigned short)(packed[k] & 0xFFFFu);
+            if (WEIGHTED) wkeys[start + pos] = wv[k];
+        }
+    }
+    if (stop == 5) { __syncthreads(); if (stage[tid] == 0xFFFF) keys[0] = 1; return; }
+    for (int k = tid; k < C; k += EB_THREADS) diag_out[(i64)wg * C + k] = WEIGHTED ? dsum[k] : (double)cnt[Cpad + k];
+    __syncthreads();
+    for (unsigned k = tid; k < total; k += EB_THREADS) keys[start + k] = stage[k]; // coalesced
+}
+
+// ---- pass 2 ------------------------------------------------------------------------------------------------------------
+// grid (C rows, batches of EB_RBATCH chunks).  Thread t fetches where chunk batch * EB_RBATCH + t keeps its keys of the row;
+// then 8 lanes share a chunk and read its (contiguous) keys as aligned 16-byte windows of 8 keys, all windows of all chunks
+// in flight together.  Keys are counted (unit weights) / summed (weighted) into the workgroup's LDS copy of the row, which is
+// added into vect_C with contiguous atomics (exact for unit weights).
+template <bool WEIGHTED, bool DIRECTED>
+__global__ __launch_bounds__(EB_RBATCH) void edge_row_reduce_kernel(const unsigned short *__restrict__ keys,
+                                                                    const double *__restrict__ wkeys,
+                                                                    const unsigned short *__restrict__ runoff,
+                                                                    const i32 *__restrict__ chunks, int chunk0,
+                                                                    const double *__restrict__ diag, int nwg, int C,
+                                                                    double *__restrict__ vectC) {
+    static_assert(EB_RBATCH == 256, "8 steps of 32 eight-lane groups");
+    __shared__ double accd[WEIGHTED ? EB_MAXC : 1];
+    __shared__ unsigned accu[WEIGHTED ? 1 : EB_MAXC];
+    __shared__ double red[4];
+    __shared__ unsigned saddr[EB_RBATCH], slen[EB_RBATCH];
+    const int r = blockIdx.x, tid = threadIdx.x, wg = blockIdx.y * EB_RBATCH + tid;
+    for (int k = tid; k < C; k += EB_RBATCH) {
+        if (WEIGHTED) accd[k] = 0.0; else accu[k] = 0u;
+    }
+    unsigned len = 0, a = 0;
+    double dg = 0.0;
+    if (wg < nwg) {
+        const unsigned short *ro = runoff + (i64)wg * (C + 1) + r;
+        const unsigned b = ro[0], e = ro[1];
+        a = (unsigned)chunks[4 * (i64)(chunk0 + wg) + 2] + b;
+        len = e - b;
+        dg = diag[(i64)wg * C + r];
+    }
+    saddr[tid] = a;
+    slen[tid] = len;
+    __syncthreads();
+    const int g = tid >> 3, l8 = tid & 7;
+    unsigned A[8], L[8], maxwin = 0; // window = 8 keys = one aligned 16-byte load
+#pragma unroll
+    for (int st = 0; st < 8; st++) {
+        A[st] = saddr[st * 32 + g];
+        L[st] = slen[st * 32 + g];
+        maxwin = max(maxwin, L[st] ? ((A[st] & 7u) + L[st] + 7u) >> 3 : 0u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxwin = max(maxwin, (unsigned)__shfl_xor((int)maxwin, off)); // wave-uniform
+    for (unsigned w0 = 0; w0 < maxwin; w0 += 8) { // one trip unless a run is longer than ~60 keys
+        uint4 K[8];
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            const unsigned nwin = L[st] ? ((A[st] & 7u) + L[st] + 7u) >> 3 : 0u, w = w0 + l8;
+            K[st] = *(const uint4 *)(keys + ((A[st] & ~7u) + 8u * (w < nwin ? w : 0u))); // the array has a readable tail
+        }
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            const unsigned p0 = (A[st] & ~7u) + 8u * (w0 + l8), lo = A[st], hi = A[st] + L[st];
+            const unsigned kw[4] = {K[st].x, K[st].y, K[st].z, K[st].w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const unsigned p = p0 + i, key = (kw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                if (p >= lo && p < hi) {
+                    if (WEIGHTED) unsafeAtomicAdd(&accd[key], wkeys[p]);
+                    else atomicAdd(&accu[key], 1u);
+                }
             }
         }
     }
-    __syncthreads();
-    // row offsets inside this workgroup's piece of the key array; one atomic claims the piece
-    const unsigned mine = cnt[tid];
-    const unsigned off = block_exclusive_scan_1024(mine, wave_sums, &misc[0]);
-    if (tid == 0) misc[1] = misc[0] ? atomicAdd(cursor, misc[0]) : 0u;
-    cnt[tid] = off;
-    unsigned short *ro = runoff + (i64)wg * (C + 1);
-    if (tid < C) ro[tid] = (unsigned short)off;
-    __syncthreads();
-    if (tid == 0) {
-        ro[C] = (unsigned short)misc[0];
-        base_out[wg] = misc[1];
-    }
-    const unsigned base = misc[1];
-    // sweep 2: the off-diagonal edges, grouped by row
+    // diagonal partials of the batch: in-wave butterfly, then the four wave sums in order (a fixed tree)
+    double dsum = dg;
 #pragma unroll
-    for (int k = 0; k < EB_PER_THREAD; k++) {
-        if (packed[k] != EB_NONE) {
-            const unsigned pos = base + atomicAdd(&cnt[packed[k] >> 16], 1u);
-            keys[pos] = (unsigned short)(packed[k] & 0xFFFFu);
-            if (WEIGHTED) wkeys[pos] = wv[k];
-        }
-    }
-    if (tid < C) diag_out[(i64)wg * C + tid] = diag[tid];
-}
-
-template <bool WEIGHTED, bool DIRECTED>
-__global__ __launch_bounds__(256) void edge_row_reduce_kernel(const unsigned short *__restrict__ keys,
-                                                              const double *__restrict__ wkeys,
-                                                              const unsigned short *__restrict__ runoff,
-                                                              const unsigned *__restrict__ base,
-                                                              const double *__restrict__ diag, int nwg, int C,
-                                                              double *__restrict__ vectC) {
-    __shared__ double acc[EB_MAXC];
-    __shared__ double red[256];
-    const int r = blockIdx.x, tid = threadIdx.x;
-    for (int k = tid; k < C; k += 256) acc[k] = 0.0;
-    __syncthreads();
-    double dsum = 0.0;
-    for (int wg = tid; wg < nwg; wg += 256) { // a thread's chunks in ascending order: a fixed order of additions
-        const unsigned short *ro = runoff + (i64)wg * (C + 1);
-        const unsigned b = ro[r], e = ro[r + 1], bs = base[wg];
-        for (unsigned k = b; k < e; k++) unsafeAtomicAdd(&acc[keys[bs + k]], WEIGHTED ? wkeys[bs + k] : 1.0);
-        dsum += diag[(i64)wg * C + r];
-    }
-    red[tid] = dsum;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    const double dtot = red[0];
+    for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
+    if ((tid & 63) == 0) red[tid >> 6] = dsum;
+    __syncthreads(); // also: every LDS add has been issued
+    const double dtot = ((red[0] + red[1]) + red[2]) + red[3];
     const i64 rowbase = DIRECTED ? (i64)r * C : ((i64)C * r - (i64)r * (r - 1) / 2 - r); // + cv
-    for (int cv = tid; cv < C; cv += 256)
-        if (DIRECTED || cv >= r) vectC[rowbase + cv] = cv == r ? dtot : acc[cv];
+    for (int cv = tid; cv < C; cv += EB_RBATCH) {
+        const double v = cv == r ? dtot : (WEIGHTED ? accd[cv] : (double)accu[cv]);
+        if (v != 0.0 && (DIRECTED || cv >= r)) unsafeAtomicAdd(&vectC[rowbase + cv], v);
+    }
 }
 
 // vect_C of chunks [c0, c1) of the blocked resident edge list (all of them: c0 = 0, c1 = be_nchunks).
 void k_edge_scatter_blocked(cge_ctx *c, i64 c0, i64 c1, i64 C, int directed, double *vectC) {
     const i64 nwg = c1 - c0;
     hipStream_t st = c->stream;
+    const i64 vlen = directed ? C * C : packed_len(C);
     if (nwg <= 0) { // an empty shard still owes zeros
-        HIP_CHECK(hipMemsetAsync(vectC, 0, sizeof(double) * (directed ? C * C : packed_len(C)), st));
+        HIP_CHECK(hipMemsetAsync(vectC, 0, sizeof(double) * vlen, st));
         return;
     }
-    k_edge_scatter_blocked_init();
     c->be_runoff.ensure((size_t)nwg * (C + 1));
-    c->be_base.ensure(nwg);
     c->be_diag.ensure((size_t)nwg * C);
     ScopedKernelTimer t(c, "edge_scatter");
-    HIP_CHECK(hipMemsetAsync(c->be_cursor.p, 0, sizeof(unsigned), st));
-    const size_t lds = 4 * EB_BLOCK + sizeof(double) * EB_MAXC + sizeof(unsigned) * (EB_MAXC + 16 + 2);
+    const int Cpad = (int)((C + 63) / 64 * 64);
     const bool wt = !c->unit_weights;
-#define EB_LAUNCH_A(W, D)                                                                                              \
-    hipLaunchKernelGGL((edge_pass_kernel<W, D>), dim3((unsigned)nwg), dim3(EB_THREADS), lds, st, c->be_edge.p, c->be_w.p,   \
-                       c->be_chunk.p, (int)c0, c->comm16.p, (int)C, c->be_cursor.p, c->be_keys.p, c->be_wkeys.p,         \
-                       c->be_runoff.p, c->be_base.p, c->be_diag.p)
-#define EB_LAUNCH_B(W, D)                                                                                              \
-    hipLaunchKernelGGL((edge_row_reduce_kernel<W, D>), dim3((unsigned)C), dim3(256), 0, st, c->be_keys.p, c->be_wkeys.p,  \
-                       c->be_runoff.p, c->be_base.p, c->be_diag.p, (int)nwg, (int)C, vectC)
-    if (wt && directed) { EB_LAUNCH_A(true, true); EB_LAUNCH_B(true, true); }
-    else if (wt) { EB_LAUNCH_A(true, false); EB_LAUNCH_B(true, false); }
-    else if (directed) { EB_LAUNCH_A(false, true); EB_LAUNCH_B(false, true); }
-    else { EB_LAUNCH_A(false, false); EB_LAUNCH_B(false, false); }
-#undef EB_LAUNCH_A
-#undef EB_LAUNCH_B
+    const size_t lds = (size_t)2 * (1 << EB_VBITS) + (wt ? (size_t)8 * Cpad : 0) + (size_t)8 * Cpad + sizeof(unsigned) * 18;
+    const dim3 gridB((unsigned)C, (unsigned)((nwg + EB_RBATCH - 1) / EB_RBATCH));
+    static const int stop = getenv("CGE_EB_STOP") ? atoi(getenv("CGE_EB_STOP")) : 0; // timing diagnostics (wrong results)
+#define EB_GO(W, D)                                                                                                        \
+    do {                                                                                                                   \
+        if (c->be_per == 24) EB_GO2(24, W, D);                                                                             \
+        else if (c->be_per == 20) EB_GO2(20, W, D);                                                                        \
+        else EB_GO2(16, W, D);                                                                                             \
+    } while (0)
+#define EB_GO2(P, W, D)                                                                                                    \
+    do {                                                                                                                   \
+        auto kern = edge_pass_kernel<P, W, D>;                                                                              \
+        static bool attr = false;                                                                                          \
+        if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(EB_THREADS), lds, st, c->be_edge.p, c->be_w.p, c->be_chunk.p, (int)c0, \
+                           c->comm16.p, (int)C, Cpad, c->be_keys.p, c->be_wkeys.p, c->be_runoff.p, c->be_diag.p, vectC, vlen,  \
+                           stop);                                                                                          \
+        hipLaunchKernelGGL((edge_row_reduce_kernel<W, D>), gridB, dim3(EB_RBATCH), 0, st, c->be_keys.p, c->be_wkeys.p,       \
+                           c->be_runoff.p, c->be_chunk.p, (int)c0, c->be_diag.p, (int)nwg, (int)C, vectC);                  \
+    } while (0)
+    if (wt && directed) EB_GO(true, true);
+    else if (wt) EB_GO(true, false);
+    else if (directed) EB_GO(false, true);
+    else EB_GO(false, false);
+#undef EB_GO
+#undef EB_GO2
 }
 
-// one-time attribute: the edge pass uses ~145 KB of dynamic LDS
-void k_edge_scatter_blocked_init() {
-    static bool done = false;
-    if (done) return;
-    const int lds = 4 * EB_BLOCK + (int)sizeof(double) * EB_MAXC + (int)sizeof(unsigned) * (EB_MAXC + 16 + 2);
-    (void)hipFuncSetAttribute((const void *)edge_pass_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)edge_pass_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)edge_pass_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)edge_pass_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    done = true;
-}
+void k_edge_scatter_blocked_init() {}
 
 bool k_edge_scatter_blocked_applies(const cge_ctx *c, i64 C) {
     static const bool off = getenv("CGE_SCATTER_GATHER") != nullptr; // A/B switch: force the gather + atomics kernel
-    return !off && c->comm16.p && C >= 1 && C <= EB_MAXC && c->n <= (i64)64 * EB_BLOCK && c->m < (1LL << 31);
+    return !off && c->comm16.p && C >= 1 && C <= EB_MAXC && c->n <= (i64)16 * (1 << EB_UBITS) && c->m < (1LL << 31);
 }
