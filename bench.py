@@ -151,11 +151,23 @@ def main():
     ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
     t_upload = time.perf_counter() - t0
     ctx.set_option("diameter", args.diameter)
-    coll = None
+    coll, coll_backend = None, None
     if world > 1:
-        from cge.jl_amd.dist import TorchCollectives
+        # default: the library's own RCCL communicator (ncclAllReduce on its stream, no host synchronisation per exchange);
+        # CGE_COLLECTIVES=torch (or a failed init, or the one-GPU rehearsal) -> the torch.distributed hook
+        if os.environ.get("CGE_COLLECTIVES", "rccl") == "rccl" and not rehearsal:
+            try:
+                ids = [api.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                ctx.init_rccl(ids[0], rank, world)
+                coll_backend = "in-library RCCL (ncclAllReduce on the ctx stream)"
+            except Exception as e:
+                log(f"[bench] rank {rank}: in-library RCCL unavailable ({e!r}); using the torch.distributed hook")
+        if coll_backend is None:
+            from cge.jl_amd.dist import TorchCollectives
 
-        coll = TorchCollectives(ctx, wl["land"] * wl["land"] * 2 + 1024, dev)
+            coll = TorchCollectives(ctx, wl["land"] * wl["land"] * 2 + 1024, dev)
+            coll_backend = "torch.distributed hook (" + dist.get_backend() + ")"
 
     def step():
         return ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=args.seed,
@@ -300,9 +312,11 @@ def main():
                      "all_landmark_pairs": N * (N + 1) // 2, "all_tiles": ((n + 127) // 128) * ((n + 127) // 128 + 1) // 2},
         "result": [float(x) for x in res],
     }
-    if coll is not None:
-        out["collectives"] = {"allreduce_calls_per_step": coll.n_calls / (args.steps + args.warmup),
-                              "bytes_per_step": coll.bytes / (args.steps + args.warmup)}
+    if world > 1:
+        calls = coll.n_calls if coll is not None else ctx.get_stat("collective_calls")
+        nbytes = coll.bytes if coll is not None else ctx.get_stat("collective_bytes")
+        out["collectives"] = {"backend": coll_backend, "allreduce_calls_per_step": calls / (args.steps + args.warmup),
+                              "bytes_per_step": nbytes / (args.steps + args.warmup)}
     if world == 1 and not args.no_cpu_baseline and not directed:
         try:
             out["cpu_baseline"] = cpu_baseline(g, wl)

@@ -397,6 +397,19 @@ class Context:
         self._keep = [cb, coll]
         self._check(self.L.cge_set_collectives(self.h, C.byref(coll)))
 
+    def init_rccl(self, unique_id: bytes, rank: int, world: int):
+        """In-library collectives (include/cge_hip.h: cge_comm_init_rccl): every rank calls this with rank 0's id."""
+        assert len(unique_id) == 128
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.L.cge_comm_init_rccl(self.h, buf, C.c_int(rank), C.c_int(world)))
+
+    def rccl_selftest(self, arr, op=0):
+        """Testing hook: all-reduce `arr` (float64, or int64 for op 2) through the context's communicator."""
+        a = np.ascontiguousarray(arr).copy()
+        assert a.dtype.itemsize == 8
+        self._check(self.L.cge_rccl_selftest(self.h, _p(a), C.c_int64(a.size), C.c_int(op)))
+        return a
+
     def set_option(self, key, value):
         self._check(self.L.cge_set_option(self.h, key.encode(), C.c_int64(int(value))))
 
@@ -452,6 +465,15 @@ def default_context():
     if _default_ctx is None:
         _default_ctx = Context(0)
     return _default_ctx
+
+
+def rccl_unique_id() -> bytes:
+    """Rank 0: the 128-byte id every rank passes to Context.init_rccl (include/cge_hip.h: cge_rccl_unique_id)."""
+    buf = C.create_string_buffer(128)
+    rc = load_library().cge_rccl_unique_id(buf)
+    if rc:
+        raise CGEError(rc, "cge_rccl_unique_id failed (is librccl installed and a GPU visible?)")
+    return buf.raw
 
 
 def idx(n, i, j):

@@ -118,6 +118,7 @@ void cge_destroy(cge_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     flush_timers(c);
+    (void)cge_comm_finalize(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -346,6 +347,10 @@ static i64 clamp_to_unique_rows(cge_ctx *c, i64 land, int *truncated) {
 
 static void allreduce(cge_ctx *c, double *dev, i64 count, int op) {
     if (!c->has_coll) return;
+    if (c->rccl_comm) { // in-library RCCL: stream-ordered, in place, no host synchronisation
+        cge_rccl_allreduce(c, dev, count, op);
+        return;
+    }
     // the hook works on the ctx exchange buffer (the host side wrapped that pointer once)
     if (!c->xptr || (size_t)count > c->xcap)
         CGE_THROW(CGE_E_COLLECTIVE, "exchange buffer too small: need %lld doubles, have %lld", (long long)count, (long long)c->xcap);
@@ -359,7 +364,7 @@ static void allreduce(cge_ctx *c, double *dev, i64 count, int op) {
 
 static double allreduce_scalar_max(cge_ctx *c, double v) {
     if (!c->has_coll) return v;
-    if (!c->xptr || c->xcap < 1) CGE_THROW(CGE_E_COLLECTIVE, "no exchange buffer set");
+    if (!cge_exchange_fits(c, 1)) CGE_THROW(CGE_E_COLLECTIVE, "no exchange buffer set");
     HIP_CHECK(hipMemcpyAsync(c->xptr, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
     allreduce(c, c->xptr, 1, 1);
     HIP_CHECK(hipMemcpyAsync(&v, c->xptr, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1005,6 +1010,8 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "landmark_batches")) *value = c->stat_lm_batches;
     else if (!strcmp(key, "landmark_batch_rows")) *value = c->stat_lm_rows;
     else if (!strcmp(key, "landmark_splits")) *value = c->stat_lm_splits;
+    else if (!strcmp(key, "collective_calls")) *value = c->stat_coll_calls;
+    else if (!strcmp(key, "collective_bytes")) *value = c->stat_coll_bytes;
     else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`
     else return CGE_E_ARG;
     return CGE_OK;
@@ -1105,6 +1112,15 @@ int cge_pow_test(void *ctx, const double *x, int64_t n, double alpha, int method
 }
 
 } // extern "C"
+
+bool cge_exchange_fits(cge_ctx *c, size_t need) {
+    if (c->xptr && need <= c->xcap) return true;
+    if (!c->rccl_comm || (c->xptr && c->xptr != c->xown.p)) return false;
+    c->xown.alloc_exact(std::max<size_t>(need + need / 4, 1 << 20));
+    c->xptr = c->xown.p;
+    c->xcap = c->xown.n;
+    return true;
+}
 
 // for the other translation units (diameter_host.cpp)
 void cge_allreduce_dev(cge_ctx *c, double *dev, i64 count, int op) { allreduce(c, dev, count, op); }

@@ -1,0 +1,137 @@
+// collectives.cpp -- in-library cross-GPU exchange: RCCL (the ROCm build of NCCL) over xGMI, bound at run time.
+//
+// One process (one cge_ctx) per GPU.  The exchange steps of the path (vect_C and the landmark-pair
+// matrix of the per-edge scatter, the gathers of the sharded runsplit, the bound matrix and the scalar of the diameter) are
+// all-reduces of 8-byte words; with a communicator set they are issued by the library itself on the ctx stream -- no host
+// synchronisation per call, no callback into the host language, so any host (Julia, C, Python) gets them.  The caller only
+// distributes the 128-byte id of rank 0 (MPI, a file, torch.distributed ...).  librccl is opened with dlopen, so the
+// library loads (and single-GPU runs work) where no RCCL is installed; the hook of cge_set_collectives stays available
+// (it is what the gloo tests on the CPU use).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "common.hpp"
+
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+RcclApi &rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api;
+    tried = true;
+    const char *names[] = {getenv("CGE_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        if (!nm || !*nm) continue;
+        api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+        api.err = dlerror();
+    }
+    if (!api.lib) return api;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) {
+        api.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+        dlclose(api.lib);
+        api.lib = nullptr;
+    }
+    return api;
+}
+const char *rccl_str(ncclResult_t r) {
+    RcclApi &a = rccl();
+    return a.GetErrorString ? a.GetErrorString(r) : "rccl error";
+}
+} // namespace
+
+// all-reduce of `count` 8-byte words in place on the ctx stream: op 0 = sum of doubles, 1 = max of doubles, 2 = sum of int64
+void cge_rccl_allreduce(cge_ctx *c, void *dev, i64 count, int op) {
+    RcclApi &a = rccl();
+    if (!a.lib || !c->rccl_comm) CGE_THROW(CGE_E_COLLECTIVE, "no RCCL communicator on this context");
+    const ncclDataType_t dt = op == 2 ? ncclInt64 : ncclFloat64;
+    const ncclRedOp_t ro = op == 1 ? ncclMax : ncclSum;
+    const ncclResult_t r = a.AllReduce(dev, dev, (size_t)count, dt, ro, (ncclComm_t)c->rccl_comm, c->stream);
+    if (r != ncclSuccess) CGE_THROW(CGE_E_COLLECTIVE, "ncclAllReduce failed: %s", rccl_str(r));
+    c->stat_coll_calls++;
+    c->stat_coll_bytes += 8 * count;
+}
+
+extern "C" {
+
+int cge_rccl_unique_id(void *id_out) {
+    if (!id_out) return CGE_E_ARG;
+    RcclApi &a = rccl();
+    if (!a.lib) return CGE_E_COLLECTIVE;
+    static_assert(sizeof(ncclUniqueId) == CGE_RCCL_ID_BYTES, "cge_hip.h: CGE_RCCL_ID_BYTES");
+    ncclUniqueId id;
+    if (a.GetUniqueId(&id) != ncclSuccess) return CGE_E_COLLECTIVE;
+    memcpy(id_out, &id, sizeof(id));
+    return CGE_OK;
+}
+
+int cge_comm_init_rccl(cge_ctx *c, const void *id_in, int rank, int world) {
+    if (!c || !id_in || world < 1 || rank < 0 || rank >= world) return CGE_E_ARG;
+    try {
+        RcclApi &a = rccl();
+        if (!a.lib) CGE_THROW(CGE_E_COLLECTIVE, "librccl could not be opened: %s", a.err.c_str());
+        HIP_CHECK(hipSetDevice(c->device));
+        if (c->rccl_comm) { (void)a.CommDestroy((ncclComm_t)c->rccl_comm); c->rccl_comm = nullptr; }
+        ncclUniqueId id;
+        memcpy(&id, id_in, sizeof(id));
+        ncclComm_t comm = nullptr;
+        const ncclResult_t r = a.CommInitRank(&comm, world, id, rank);
+        if (r != ncclSuccess) CGE_THROW(CGE_E_COLLECTIVE, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl_str(r));
+        c->rccl_comm = comm;
+        c->coll.allreduce_f64 = nullptr;
+        c->coll.user = nullptr;
+        c->coll.rank = rank;
+        c->coll.world = world;
+        c->has_coll = world > 1; // a one-rank communicator is legal (self test) but shards nothing
+    } catch (const CgeError &e) {
+        c->err = e.msg;
+        return e.code;
+    }
+    return CGE_OK;
+}
+
+int cge_comm_finalize(cge_ctx *c) {
+    if (!c) return CGE_E_ARG;
+    if (c->rccl_comm) {
+        (void)hipStreamSynchronize(c->stream);
+        RcclApi &a = rccl();
+        if (a.lib) (void)a.CommDestroy((ncclComm_t)c->rccl_comm);
+        c->rccl_comm = nullptr;
+        c->has_coll = false;
+    }
+    return CGE_OK;
+}
+
+// testing hook (include/cge_hip_testing.h): host array -> device -> in-library all-reduce -> host
+int cge_rccl_selftest(void *ctx, double *host_inout, int64_t count, int op) {
+    cge_ctx *c = (cge_ctx *)ctx;
+    if (!c || !host_inout || count <= 0) return CGE_E_ARG;
+    try {
+        HIP_CHECK(hipSetDevice(c->device));
+        DevBuf<double> d;
+        d.ensure((size_t)count);
+        HIP_CHECK(hipMemcpyAsync(d.p, host_inout, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+        cge_rccl_allreduce(c, d.p, count, op);
+        HIP_CHECK(hipMemcpyAsync(host_inout, d.p, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    } catch (const CgeError &e) {
+        c->err = e.msg;
+        return e.code;
+    }
+    return CGE_OK;
+}
+
+} // extern "C"

@@ -199,6 +199,8 @@ struct cge_ctx {
     ThreadPool *pool = nullptr; // persistent host workers (n_threads - 1 + caller)
     cge_collectives coll{};
     bool has_coll = false;
+    void *rccl_comm = nullptr;           // in-library communicator (collectives.cpp); takes precedence over the hook
+    i64 stat_coll_calls = 0, stat_coll_bytes = 0; // all-reduces issued since the context was created
     DevBuf<double> xown;  // library-owned exchange buffer (cge_exchange_buffer)
     double *xptr = nullptr; // exchange buffer in use (library- or caller-owned)
     size_t xcap = 0;
@@ -473,6 +475,10 @@ void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *
 void k_diameter_layout(cge_ctx *c, const i32 *mem_off, const i32 *mem, const i32 *soff, i64 N, i32 *pos2node, i32 *sub_land,
                        i64 n_sub);
 void cge_allreduce_dev(cge_ctx *c, double *dev, i64 count, int op /*0 sum, 1 max*/); // no-op without collectives
+void cge_rccl_allreduce(cge_ctx *c, void *dev, i64 count, int op); // collectives.cpp: in place, on the ctx stream
+// can the exchange buffer hold `need` doubles?  With the in-library communicator a library-owned buffer grows on demand
+// (contents are not preserved); a caller-provided one (cge_set_exchange_buffer, the hook path) is what it is.
+bool cge_exchange_fits(cge_ctx *c, size_t need);
 void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, const double *Ms, const double *mnorm,
              i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P, int part = 0, int nparts = 1);
 void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,

@@ -103,7 +103,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     k_gather_centre_fm(c, mu_ref, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, nref, d, ldm, dpad);
     // Q is a maximum over vertices: with several ranks each takes its share of the vertex tiles and the maxima are
     // combined by one all-reduce(max) (only when the exchange buffer can hold N x nref doubles)
-    const bool shard_q = nparts > 1 && c->has_coll && c->xptr && (size_t)(N * nref) <= c->xcap;
+    const bool shard_q = nparts > 1 && c->has_coll && (c->rccl_comm || (c->xptr && (size_t)(N * nref) <= c->xcap));
     k_pcent(c, c->Xs.p, c->rns.p, lds_rows, c->Ms.p, c->mnorm.p, ldm, N, nref, dpad, c->sub_land.p, c->Pm.p,
             shard_q ? part : 0, shard_q ? nparts : 1);
     if (shard_q) cge_allreduce_dev(c, c->Pm.p, N * nref, 1);

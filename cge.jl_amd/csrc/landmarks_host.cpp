@@ -888,8 +888,8 @@ void compute_splits_sharded(cge_ctx *c, std::vector<Group *> &batch, int method)
     const i64 s_words = (R + 1) / 2, m_per = 5 + 2 * d; // per group: rc, nlow, vlow, vhigh, means flag, two means
     const i64 x_need = s_words + T * m_per;
     // (option value 2: every batch, whatever its size -- the tests)
-    if (W <= 1 || !c->opt_shard_forced || (c->opt_shard_forced == 1 && (T < 2 * W || R * d < ((i64)1 << 23))) || !c->xptr ||
-        (size_t)x_need > c->xcap) {
+    if (W <= 1 || !c->opt_shard_forced || (c->opt_shard_forced == 1 && (T < 2 * W || R * d < ((i64)1 << 23))) ||
+        !cge_exchange_fits(c, (size_t)x_need)) {
         compute_splits(c, batch, method);
         return;
     }
@@ -1162,7 +1162,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         const i64 nbig = (i64)locals.size(), W = c->has_coll ? c->coll.world : 1;
         const i64 s_words = (total + 1) / 2, m_per = 3 + d; // per group: length, value, mean flag, mean
         const i64 x_need = s_words + nbig + nbig * forced * m_per;
-        const bool shard = W > 1 && c->opt_shard_forced && forced >= 2 && c->xptr && (size_t)x_need <= c->xcap;
+        const bool shard = W > 1 && c->opt_shard_forced && forced >= 2 && cge_exchange_fits(c, (size_t)x_need);
         std::vector<int> owner(nbig, 0);
         if (shard) { // longest first, each to the least loaded rank (deterministic)
             std::vector<i64> ord(nbig), load(W, 0);

@@ -77,6 +77,17 @@ int cge_exchange_buffer(cge_ctx *ctx, int64_t min_doubles, void **dev_ptr, int64
 /* or hand the library a caller-owned device buffer (e.g. a torch tensor) to use as exchange buffer */
 int cge_set_exchange_buffer(cge_ctx *ctx, void *dev_ptr, int64_t capacity_doubles);
 
+/* In-library collectives: RCCL over xGMI, one rank per GPU (csrc/collectives.cpp; librccl is opened at run time).  Rank 0
+ * calls cge_rccl_unique_id and hands the CGE_RCCL_ID_BYTES bytes to every rank by whatever means the host has (MPI, a file,
+ * torch.distributed); every rank then calls cge_comm_init_rccl on its context (collective: all ranks must call it).  From
+ * then on the exchange steps of the path are ncclAllReduce calls issued by the library on the ctx stream -- no callback, no
+ * host synchronisation per step, no exchange buffer to provide.  Takes precedence over a hook set with
+ * cge_set_collectives.  cge_comm_finalize (also done by cge_destroy) releases the communicator.                       */
+#define CGE_RCCL_ID_BYTES 128
+int cge_rccl_unique_id(void *id_out);
+int cge_comm_init_rccl(cge_ctx *ctx, const void *id, int rank, int world);
+int cge_comm_finalize(cge_ctx *ctx);
+
 /* ---- resident inputs (the ORIGINAL graph; uploaded once, H2D + layout change) ---------------
  * Calling cge_set_graph with another vertex count drops the resident embedding and vertex data (they were sized for the
  * old vertex set); cge_landmarks_run / cge_score check that all resident inputs agree and fail with CGE_E_ARG otherwise.
@@ -214,6 +225,7 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             restores the iterate and falls back to one launch per iteration).                              */
 int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
 /* "landmarks" (N of the last run, no side effects), "diameter_path" (1 brute / 2 pruned), "diameter_candidate_pairs", "diameter_candidate_tiles", "diameter_refs" (reference points) of the last run;
+ * "collective_calls" / "collective_bytes" = all-reduces issued by the in-library RCCL path since cge_create;
  * "diameter_bits" = the bit pattern of the last `hi` (reinterpret the int64 as a double);
  * "fit_persistent_alphas" = alphas of the last sweep fitted by a persistent launch, "fit_persistent_fallbacks" = persistent fits abandoned since the context was created, "fit_iterations" = Chung-Lu
  * iterations of the last sweep (all alphas); "landmark_batches" / "landmark_batch_rows" / "landmark_splits" =

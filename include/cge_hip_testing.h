@@ -18,6 +18,9 @@ int cge_group_eig(void *ctx, const double *A, int64_t T, int64_t d, double *v);
 /* out[i] = (1 - x[i])^alpha on the device (host vectors): method 0 = the library pow, 1 = exp2(alpha * log2(1 - x)) with
  * the logarithm in double + float parts, as the alpha sweep computes GD = (1 - D)^alpha (src/divergence.jl:142-148) */
 int cge_pow_test(void *ctx, const double *x, int64_t n, double alpha, int method, double *out);
+/* needs the GPU and a communicator (cge_comm_init_rccl; one rank is enough): host array -> device -> the in-library
+ * ncclAllReduce (op 0 sum / 1 max of doubles, 2 sum of the words as int64) -> host */
+int cge_rccl_selftest(void *ctx, double *host_inout, int64_t count, int op);
 #ifdef __cplusplus
 }
 #endif
