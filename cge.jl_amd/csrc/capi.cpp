@@ -968,6 +968,10 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_diameter = (int)value;
         return CGE_OK;
     }
+    if (!strcmp(key, "diameter_f32")) { // 1 (default): point-to-reference maxima of the pruned diameter by fp32 MFMA (upper bounds); 0: fp64 MFMA
+        c->opt_diameter_f32 = value != 0;
+        return CGE_OK;
+    }
     if (!strcmp(key, "fit_persistent")) { // 0 auto, 1 never, 2 whenever the score graph fits the register file, 3 / 4 = 2 with grid barriers / counters
         if (value < 0 || value > 4) return CGE_E_ARG;
         c->opt_fit_persistent = (int)value;

@@ -293,6 +293,8 @@ struct cge_ctx {
     DevBuf<i32> mp_lref, mp_refoff, mp_refmem;
     DevBuf<double> gmean;    // global feature mean (the centre used by Xc)
     DevBuf<double> Xs, rns, Ms, mnorm, Pm; // landmark-sorted centred copy, centroids, P matrix
+    DevBuf<float> Xs32, Ms32;              // fp32 copies: operands of the fp32-MFMA bound pass (upper bounds only)
+    int opt_diameter_f32 = 1;              // 1: the point-to-reference maxima by fp32 MFMA with a rigorous error margin
     DevBuf<i32> pos2node, sub_land, dm_soff, dm_memoff, dm_mem;
     DevBuf<double> bound_list;             // BoundRec records (2 doubles each)
     DevBuf<i32> tile_list;
@@ -490,7 +492,9 @@ void k_ref_centroids(cge_ctx *c, const double *mu, const double *lw, const i32 *
 void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i);
 void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean);
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
-                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad);
+                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32 = nullptr);
+void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows, const float *Ms32, const double *mnorm,
+                 i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P, int part = 0, int nparts = 1);
 // alpha sweep
 void k_copy_segments(cge_ctx *c, const i32 *src, const i64 *seg, i64 nseg, i32 *dst);
 void k_gather_means_slots(cge_ctx *c, const double *arena, const i64 *off, const i64 *slot, i64 T, i64 d, i64 stride, i64 lead,

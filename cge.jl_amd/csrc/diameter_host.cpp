@@ -99,13 +99,22 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     c->Ms.ensure((size_t)ldm * dpad);
     c->mnorm.ensure(ldm);
     c->Pm.ensure((size_t)N * nref);
-    k_gather_centre_fm(c, c->Xr.p, c->pos2node.p, c->gmean.p, c->Xs.p, c->rns.p, npos, d, lds_rows, dpad);
-    k_gather_centre_fm(c, mu_ref, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, nref, d, ldm, dpad);
+    const bool f32 = c->opt_diameter_f32 != 0; // the maxima as fp32-MFMA upper bounds (kernels_dist.hip, (2b))
+    if (f32) {
+        c->Xs32.ensure((size_t)lds_rows * dpad);
+        c->Ms32.ensure((size_t)ldm * dpad);
+    }
+    k_gather_centre_fm(c, c->Xr.p, c->pos2node.p, c->gmean.p, c->Xs.p, c->rns.p, npos, d, lds_rows, dpad, f32 ? c->Xs32.p : nullptr);
+    k_gather_centre_fm(c, mu_ref, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, nref, d, ldm, dpad, f32 ? c->Ms32.p : nullptr);
     // Q is a maximum over vertices: with several ranks each takes its share of the vertex tiles and the maxima are
     // combined by one all-reduce(max) (only when the exchange buffer can hold N x nref doubles)
     const bool shard_q = nparts > 1 && c->has_coll && (c->rccl_comm || (c->xptr && (size_t)(N * nref) <= c->xcap));
-    k_pcent(c, c->Xs.p, c->rns.p, lds_rows, c->Ms.p, c->mnorm.p, ldm, N, nref, dpad, c->sub_land.p, c->Pm.p,
-            shard_q ? part : 0, shard_q ? nparts : 1);
+    if (f32)
+        k_pcent_f32(c, c->Xs32.p, c->rns.p, lds_rows, c->Ms32.p, c->mnorm.p, ldm, N, nref, dpad, c->sub_land.p, c->Pm.p,
+                    shard_q ? part : 0, shard_q ? nparts : 1);
+    else
+        k_pcent(c, c->Xs.p, c->rns.p, lds_rows, c->Ms.p, c->mnorm.p, ldm, N, nref, dpad, c->sub_land.p, c->Pm.p,
+                shard_q ? part : 0, shard_q ? nparts : 1);
     if (shard_q) cge_allreduce_dev(c, c->Pm.p, N * nref, 1);
     lap("dm_refs_pcent");
     // ---- lower bound from farthest-point sweeps ----------------------------------------------------------

@@ -76,7 +76,7 @@ __global__ void colsum_final_kernel(const double *__restrict__ part, i64 nb, i64
 // dst[k*ld + p] = src[idx ? idx[p] : p][k] - mean[k]  (row-major rows -> centred feature-major, 32x32 LDS tiles)
 __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i32 *__restrict__ idx,
                                         const double *__restrict__ mean, double *__restrict__ dst, i64 npos, i64 d,
-                                        i64 ld) {
+                                        i64 ld, float *__restrict__ dst32) {
     __shared__ double tile[32][33];
     i64 p0 = (i64)blockIdx.x * 32, k0 = (i64)blockIdx.y * 32;
     int tx = threadIdx.x, ty = threadIdx.y;
@@ -87,7 +87,10 @@ __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i3
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         i64 p = p0 + tx, k = k0 + r;
-        if (p < npos && k < d) dst[k * ld + p] = tile[tx][r];
+        if (p < npos && k < d) {
+            dst[k * ld + p] = tile[tx][r];
+            if (dst32) dst32[k * ld + p] = (float)tile[tx][r]; // operand of the fp32-MFMA bound pass
+        }
     }
 }
 __global__ void rownorm_kernel(const double *__restrict__ Xc, i64 n, i64 d, i64 ldn, double *__restrict__ rnorm) {
@@ -111,12 +114,13 @@ void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean) {
 }
 // Centred, zero-padded feature-major copy (dpad x ld) of npos gathered rows + squared row norms (ld entries).
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
-                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad) {
+                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32) {
     HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(ld * dpad), c->stream));
+    if (dst32) HIP_CHECK(hipMemsetAsync(dst32, 0, sizeof(float) * (size_t)(ld * dpad), c->stream));
     HIP_CHECK(hipMemsetAsync(rnorm, 0, sizeof(double) * (size_t)ld, c->stream));
     dim3 grid((unsigned)((npos + 31) / 32), (unsigned)((d + 31) / 32));
     hipLaunchKernelGGL(gather_centre_fm_kernel, grid, dim3(32, 8), 0, c->stream, src_rowmajor, idx, mean, dst, npos, d,
-                       ld);
+                       ld, dst32);
     hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, c->stream, dst, npos, d, ld,
                        rnorm);
 }

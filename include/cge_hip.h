@@ -203,6 +203,10 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
 /* ---- options / statistics --------------------------------------------------------------------- */
 /* "diameter": 0 = auto (exact landmark-pair pruning, brute-force MFMA kernel when pruning is weak),
  *             1 = always brute force, 2 = always pruned.  All three return the same exact value.
+ * "diameter_f32": 1 (default) = the point-to-reference maxima that bound the landmark pairs of the pruned diameter are
+ *             computed by fp32 MFMA (v_mfma_f32_32x32x2_f32) as rigorous UPPER bounds (fp64 norms, error margin
+ *             (K + 2) 2^-24 on the fp32 dot products); the surviving pairs are evaluated in fp64 as always, so the diameter
+ *             keeps its bits.  0 = those maxima by fp64 MFMA.
  * "fit_persistent": how the Chung-Lu fixed point (src/divergence.jl:150-168, :434-467) is launched.
  *             0 = auto: one persistent launch per alpha (the matrix register-resident, the workgroups exchanging
  *                 partial sums and iterates by polling the data itself) for score graphs of >= 128 vertices that fit
