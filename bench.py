@@ -31,9 +31,14 @@ WORKLOADS = {
     # configs[3]: directed 1M-node graph, d=128, --samples-local 1000000, automatic landmarks max(4 sqrt(n), 4C)
     "cfg4": dict(n=1_000_000, m=10_000_000, C=500, d=128, land=4000, forced=4, method="rss", samples=1_000_000,
                  directed=True),
+    # configs[4]: ABCD 10M nodes / 200M edges, d=512, -l 12000 (fp32-MFMA bound pass of the diameter).  The 41 GB embedding
+    # is generated on the device and handed over as a device pointer (cge_set_embedding_device); --scale shrinks n and m.
+    "cfg5": dict(n=10_000_000, m=200_000_000, C=1500, d=512, land=12000, forced=4, method="rss", samples=10000,
+                 device_embedding=True),
     "small": dict(n=50_000, m=500_000, C=25, d=128, land=200, forced=4, method="rss", samples=10000),
 }
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; MI355X_MICROARCH.md lists no f64 row)
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector peak (155 TF measured)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -102,6 +107,7 @@ def main():
     ap.add_argument("--profile-all", action="store_true",
                     help="event timers around every kernel family (default: only the kernels priced against a roofline)")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--scale", type=float, default=1.0, help="scale the workload's n and m (the line says the actual sizes)")
     ap.add_argument("--diameter", type=int, default=0, help="0 auto (pruned, brute-force fallback), 1 brute force, 2 pruned")
     args = ap.parse_args()
 
@@ -140,16 +146,38 @@ def main():
             ge.build()
         if world > 1:
             dist.barrier()
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.scale != 1.0:
+        wl["n"], wl["m"] = max(1000, int(wl["n"] * args.scale)), max(10000, int(wl["m"] * args.scale))
     t0 = time.perf_counter()
     directed = bool(wl.get("directed", False))
-    g = synth.abcd_like(wl["n"], int(wl["m"] * 1.05), wl["C"], wl["d"], seed=args.seed, directed=directed)
+    dev_emb = bool(wl.get("device_embedding", False))
+    g = synth.abcd_like(wl["n"], int(wl["m"] * 1.05), wl["C"], 1 if dev_emb else wl["d"], seed=args.seed, directed=directed)
     if rank == 0:
-        log(f"[bench] synthetic ABCD-like graph: n={g['n']} m={g['m']} d={g['d']} C={g['C']} ({time.perf_counter()-t0:.1f} s)")
+        log(f"[bench] synthetic ABCD-like graph: n={g['n']} m={g['m']} d={wl['d']} C={g['C']} ({time.perf_counter()-t0:.1f} s)")
     ctx = api.Context(local_rank)
-    t0 = time.perf_counter()
-    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
-    t_upload = time.perf_counter() - t0
+    if dev_emb:  # community centre + isotropic noise, as synth.abcd_like builds it, but in HBM (fp64, row-major)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(args.seed)
+        centres = torch.randn(g["C"], wl["d"], generator=gen, device=dev, dtype=torch.float64) * 2.0
+        comm_dev = torch.from_numpy(g["comm"][:, 0] - 1).to(dev)
+        X = torch.empty(g["n"], wl["d"], dtype=torch.float64, device=dev)
+        for a in range(0, g["n"], 1 << 20):
+            b = min(g["n"], a + (1 << 20))
+            X[a:b] = centres[comm_dev[a:b]] + torch.randn(b - a, wl["d"], generator=gen, device=dev, dtype=torch.float64) * 0.5
+        torch.cuda.synchronize()
+        g["d"], g["embedding"] = wl["d"], None
+        t0 = time.perf_counter()
+        ctx.set_graph(g["edges"], g["eweights"], g["n"])
+        ctx.set_embedding_device(X.data_ptr(), g["n"], wl["d"], row_major=True)
+        ctx.set_vertex_data(g["comm"], g["vweights"])
+        t_upload = time.perf_counter() - t0
+        del X, comm_dev
+        torch.cuda.empty_cache()
+    else:
+        t0 = time.perf_counter()
+        ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+        t_upload = time.perf_counter() - t0
     ctx.set_option("diameter", args.diameter)
     coll, coll_backend = None, None
     if world > 1:
@@ -226,8 +254,9 @@ def main():
     work = {  # name -> (bound, peak, unit, algorithmic work per launch, note)
         "max_pair_dist": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", 2.0 * d * (n * (n - 1) / 2) / world,
                           "fp64 MFMA, 2d flop per unordered vertex pair, all pairs"),
-        "pcent": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", 2.0 * d * n * max(1, ctx.get_stat("diameter_refs")),
-                  "fp64 MFMA, 2d flop per (vertex, reference point) pair; reference points = community centroids"),
+        "pcent": ("mfma", F32_MFMA_PEAK_TFLOPS, "TFLOP/s", 2.0 * d * n * max(1, ctx.get_stat("diameter_refs")),
+                  "fp32 MFMA (v_mfma_f32_32x32x2_f32) upper bounds, 2d flop per (vertex, reference point) pair; reference "
+                  "points = community centroids; priced against the f32-input MFMA peak"),
         "pair_list": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", None,
                       "fp64 MFMA, 2d flop per vertex pair of the candidate 128x128 tiles"),
         "fit_symv": ("hbm", HBM_PEAK_GBS, "GB/s", 8.0 * N * (N + 1) / 2,
@@ -301,7 +330,8 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: ABCD-like n={n} m={g['m']} d={d} C={g['C']}, -l {wl['land']} "
                                f"-f {wl['forced']} -m {wl['method']} --seed {args.seed} --samples-local {wl['samples']}; "
-                               f"landmarks() + wGCL() in landmark mode, inputs resident in HBM",
+                               f"landmarks() + wGCL{'_directed' if directed else ''}() in landmark mode, inputs resident in HBM"
+                               + (" (embedding generated on the device)" if dev_emb else ""),
                    "n": n, "m": g["m"], "d": d, "communities": g["C"], "landmarks": N,
                    "alphas_evaluated": A, "parallelism": f"edges+pair-tiles sharded over {world} GPU(s)"},
         # SURVEY 8(d) puts the H2D copies inside T; the bench contract wants `value` with inputs already resident in HBM.
@@ -317,7 +347,7 @@ def main():
         nbytes = coll.bytes if coll is not None else ctx.get_stat("collective_bytes")
         out["collectives"] = {"backend": coll_backend, "allreduce_calls_per_step": calls / (args.steps + args.warmup),
                               "bytes_per_step": nbytes / (args.steps + args.warmup)}
-    if world == 1 and not args.no_cpu_baseline and not directed:
+    if world == 1 and not args.no_cpu_baseline and not directed and not dev_emb:
         try:
             out["cpu_baseline"] = cpu_baseline(g, wl)
         except Exception as e:  # the baseline is reported, never required for the GPU number

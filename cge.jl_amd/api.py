@@ -225,6 +225,12 @@ class Context:
         self._check(self.L.cge_set_embedding(self.h, _p(ef), C.c_int64(e.shape[0]), C.c_int64(e.shape[1])))
         self.d = e.shape[1]
 
+    def set_embedding_device(self, dev_ptr: int, n: int, d: int, row_major: bool = True):
+        """An (n, d) float64 embedding that already lives in this GPU's memory (e.g. `tensor.data_ptr()`)."""
+        self._check(self.L.cge_set_embedding_device(self.h, C.c_void_p(dev_ptr), C.c_int64(n), C.c_int64(d),
+                                                    C.c_int(1 if row_major else 0)))
+        self.d = d
+
     def set_vertex_data(self, comm, vweights):
         cm = None if comm is None else _i64(np.asarray(comm).ravel())
         vw = None if vweights is None else _f64(vweights)

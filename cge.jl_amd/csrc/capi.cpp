@@ -233,6 +233,33 @@ int cge_set_graph(cge_ctx *c, const int64_t *src, const int64_t *dst, const doub
     CGE_CATCH(c)
 }
 
+// what every form of embedding upload ends with: sizes, the global feature mean (the centre of the diameter kernels'
+// operands).  The centred feature-major copy of the brute-force diameter kernel is built on first use (it is as large as
+// the embedding and the pruned path never reads it).
+static void embedding_resident(cge_ctx *c, i64 n, i64 d) {
+    c->h_Xr.clear();
+    c->h_Xr.shrink_to_fit();
+    c->n = n;
+    c->d = d;
+    c->ldn = (n + 127) / 128 * 128;
+    c->dpad = (d + 15) / 16 * 16;
+    c->Xc.release();
+    c->rnorm.release();
+    c->gmean.alloc_exact((size_t)d);
+    k_col_mean(c, c->Xr.p, n, d, c->gmean.p);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->centred_ready = false;
+    c->lm_ready = false;
+}
+static void ensure_centred(cge_ctx *c) {
+    if (c->centred_ready) return;
+    if (!c->Xr.p || c->d <= 0) CGE_THROW(CGE_E_ARG, "diameter: embedding not resident");
+    c->Xc.alloc_exact((size_t)c->ldn * c->dpad);
+    c->rnorm.alloc_exact((size_t)c->ldn);
+    k_gather_centre_fm(c, c->Xr.p, nullptr, c->gmean.p, c->Xc.p, c->rnorm.p, c->n, c->d, c->ldn, c->dpad);
+    c->centred_ready = true;
+}
+
 int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
     if (!c || !X || n <= 0 || d <= 0) return CGE_E_ARG;
     CGE_TRY(c)
@@ -243,23 +270,29 @@ int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
     staged_upload<double>(c, col.p, (size_t)n * d, [&](double *o, size_t e0, size_t e1) { memcpy(o, X + e0, sizeof(double) * (e1 - e0)); });
     c->Xr.alloc_exact((size_t)n * d);
     k_transpose_to_rowmajor(c, col.p, c->Xr.p, n, d);
-    c->h_Xr.clear();
-    c->h_Xr.shrink_to_fit();
     HIP_CHECK(hipStreamSynchronize(c->stream));
     col.release();
-    c->n = n;
-    c->d = d;
-    // centred feature-major copy + row norms for the diameter kernel (layout prep, part of the upload)
-    c->ldn = (n + 127) / 128 * 128;
-    c->dpad = (d + 15) / 16 * 16;
-    c->Xc.alloc_exact((size_t)c->ldn * c->dpad);
-    c->rnorm.alloc_exact((size_t)c->ldn);
-    c->gmean.alloc_exact((size_t)d);
-    k_col_mean(c, c->Xr.p, n, d, c->gmean.p);
-    k_gather_centre_fm(c, c->Xr.p, nullptr, c->gmean.p, c->Xc.p, c->rnorm.p, n, d, c->ldn, c->dpad);
-    HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->centred_ready = true;
-    c->lm_ready = false;
+    embedding_resident(c, n, d);
+    CGE_CATCH(c)
+}
+
+int cge_set_embedding_device(cge_ctx *c, const double *X_dev, int64_t n, int64_t d, int row_major) {
+    if (!c || !X_dev || n <= 0 || d <= 0) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    if (c->n && c->n != n) CGE_THROW(CGE_E_ASSERT, "No. rows in embedding and no. vertices in a graph differ.");
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, X_dev) != hipSuccess || at.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        CGE_THROW(CGE_E_ARG, "set_embedding_device: the pointer is not device memory");
+    }
+    c->Xr.alloc_exact((size_t)n * d);
+    if (row_major)
+        HIP_CHECK(hipMemcpyAsync(c->Xr.p, X_dev, sizeof(double) * (size_t)n * d, hipMemcpyDeviceToDevice, c->stream));
+    else
+        k_transpose_to_rowmajor(c, X_dev, c->Xr.p, n, d);
+    HIP_CHECK(hipStreamSynchronize(c->stream)); // the caller may free or reuse its buffer on return
+    embedding_resident(c, n, d);
     CGE_CATCH(c)
 }
 
@@ -628,7 +661,7 @@ static double exact_pair_distance(cge_ctx *c, i64 bi, i64 bj) {
 
 // diameter of the resident embedding (this rank's share), brute force over all pair tiles
 static double resident_diameter(cge_ctx *c, int part, int nparts, i64 *ai, i64 *aj) {
-    if (!c->centred_ready) CGE_THROW(CGE_E_ARG, "diameter: embedding not resident");
+    ensure_centred(c);
     double bv;
     i64 bi, bj;
     k_max_pair(c, c->Xc.p, c->rnorm.p, c->n, c->ldn, c->dpad, part, nparts, &bv, &bi, &bj);

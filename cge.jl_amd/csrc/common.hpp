@@ -293,6 +293,7 @@ struct cge_ctx {
     DevBuf<i32> mp_lref, mp_refoff, mp_refmem;
     DevBuf<double> gmean;    // global feature mean (the centre used by Xc)
     DevBuf<double> Xs, rns, Ms, mnorm, Pm; // landmark-sorted centred copy, centroids, P matrix
+    DevBuf<double> pc_groups;              // per (16-row group, reference point) maxima of the bound pass
     DevBuf<float> Xs32, Ms32;              // fp32 copies: operands of the fp32-MFMA bound pass (upper bounds only)
     int opt_diameter_f32 = 1;              // 1: the point-to-reference maxima by fp32 MFMA with a rigorous error margin
     DevBuf<i32> pos2node, sub_land, dm_soff, dm_memoff, dm_mem;
@@ -482,7 +483,7 @@ void cge_rccl_allreduce(cge_ctx *c, void *dev, i64 count, int op); // collective
 // (contents are not preserved); a caller-provided one (cge_set_exchange_buffer, the hook path) is what it is.
 bool cge_exchange_fits(cge_ctx *c, size_t need);
 void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, const double *Ms, const double *mnorm,
-             i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P, int part = 0, int nparts = 1);
+             i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *soff, double *P, int part = 0, int nparts = 1);
 void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,
                  i64 ntiles, double *best_val, i64 *best_i, i64 *best_j);
 i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *mu_ref, i64 N, i64 nref, i64 d, double L,

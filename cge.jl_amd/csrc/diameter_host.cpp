@@ -110,7 +110,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     // combined by one all-reduce(max) (only when the exchange buffer can hold N x nref doubles)
     const bool shard_q = nparts > 1 && c->has_coll && (c->rccl_comm || (c->xptr && (size_t)(N * nref) <= c->xcap));
     if (f32)
-        k_pcent_f32(c, c->Xs32.p, c->rns.p, lds_rows, c->Ms32.p, c->mnorm.p, ldm, N, nref, dpad, c->sub_land.p, c->Pm.p,
+        k_pcent_f32(c, c->Xs32.p, c->rns.p, lds_rows, c->Ms32.p, c->mnorm.p, ldm, N, nref, dpad, c->dm_soff.p, c->Pm.p,
                     shard_q ? part : 0, shard_q ? nparts : 1);
     else
         k_pcent(c, c->Xs.p, c->rns.p, lds_rows, c->Ms.p, c->mnorm.p, ldm, N, nref, dpad, c->sub_land.p, c->Pm.p,

@@ -287,15 +287,24 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256, 2) void pcent_f32_kernel(const float *__restrict__ Xs, const double *__restrict__ rns,
                                                            i64 lds_rows, const float *__restrict__ Ms,
                                                            const double *__restrict__ mnorm, i64 ldm, i64 N, i64 dpad,
-                                                           const i32 *__restrict__ sub_land,
-                                                           unsigned long long *__restrict__ P, i64 I0, i64 I1, double e1) {
+                                                           double *__restrict__ G, i64 I0, i64 I1, double e1) {
     extern __shared__ __attribute__((aligned(16))) float ldsf[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, l32 = lane & 31, lh = lane >> 5;
     const int krow = tid >> 4, seg = (tid & 15) * 8; // staging: 16 k-rows x 128 floats per operand and chunk
     const i64 nTJ = ldm / 128, nchunk = dpad / PF_BK;
     const size_t stage = (size_t)2 * PF_BK * 128;
-    for (i64 t = blockIdx.x; t < (I1 - I0) * nTJ; t += gridDim.x) {
+    const i64 ntile = (I1 - I0) * nTJ;
+    float4 ra0, ra1, rb0, rb1; // named scalars: as arrays they end up in scratch memory
+    if ((i64)blockIdx.x < ntile) { // first chunk of the first tile
+        const i64 I = I0 + (i64)blockIdx.x / nTJ, J = (i64)blockIdx.x % nTJ;
+        const float *pa = Xs + (i64)krow * lds_rows + I * 128 + seg, *pb = Ms + (i64)krow * ldm + J * 128 + seg;
+        ra0 = *reinterpret_cast<const float4 *>(pa);
+        ra1 = *reinterpret_cast<const float4 *>(pa + 4);
+        rb0 = *reinterpret_cast<const float4 *>(pb);
+        rb1 = *reinterpret_cast<const float4 *>(pb + 4);
+    }
+    for (i64 t = blockIdx.x; t < ntile; t += gridDim.x) {
         const i64 I = I0 + t / nTJ, J = t % nTJ; // consecutive workgroups share the row tile
         const i64 i0 = I * 128, j0 = J * 128;
         const float *pa = Xs + (i64)krow * lds_rows + i0 + seg, *pb = Ms + (i64)krow * ldm + j0 + seg;
@@ -306,18 +315,13 @@ __global__ __launch_bounds__(256, 2) void pcent_f32_kernel(const float *__restri
             for (int b = 0; b < 2; b++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-        float4 ra[2], rb[2];
-        ra[0] = *reinterpret_cast<const float4 *>(pa);
-        ra[1] = *reinterpret_cast<const float4 *>(pa + 4);
-        rb[0] = *reinterpret_cast<const float4 *>(pb);
-        rb[1] = *reinterpret_cast<const float4 *>(pb + 4);
         __syncthreads(); // the previous tile's readers are done with both stages
         {
             float *As = ldsf + krow * 128 + seg, *Bs = As + PF_BK * 128;
-            *reinterpret_cast<float4 *>(As) = ra[0];
-            *reinterpret_cast<float4 *>(As + 4) = ra[1];
-            *reinterpret_cast<float4 *>(Bs) = rb[0];
-            *reinterpret_cast<float4 *>(Bs + 4) = rb[1];
+            *reinterpret_cast<float4 *>(As) = ra0;
+            *reinterpret_cast<float4 *>(As + 4) = ra1;
+            *reinterpret_cast<float4 *>(Bs) = rb0;
+            *reinterpret_cast<float4 *>(Bs + 4) = rb1;
         }
         __syncthreads();
         for (i64 kc = 0; kc < nchunk; kc++) {
@@ -325,10 +329,10 @@ __global__ __launch_bounds__(256, 2) void pcent_f32_kernel(const float *__restri
             const bool more = kc + 1 < nchunk;
             if (more) { // the next chunk's global loads land while the MFMAs run
                 const float *qa = pa + (kc + 1) * PF_BK * lds_rows, *qb = pb + (kc + 1) * PF_BK * ldm;
-                ra[0] = *reinterpret_cast<const float4 *>(qa);
-                ra[1] = *reinterpret_cast<const float4 *>(qa + 4);
-                rb[0] = *reinterpret_cast<const float4 *>(qb);
-                rb[1] = *reinterpret_cast<const float4 *>(qb + 4);
+                ra0 = *reinterpret_cast<const float4 *>(qa);
+                ra1 = *reinterpret_cast<const float4 *>(qa + 4);
+                rb0 = *reinterpret_cast<const float4 *>(qb);
+                rb1 = *reinterpret_cast<const float4 *>(qb + 4);
             }
             const float *As = ldsf + (size_t)s * stage, *Bs = As + PF_BK * 128;
 #pragma unroll
@@ -345,27 +349,34 @@ __global__ __launch_bounds__(256, 2) void pcent_f32_kernel(const float *__restri
             }
             if (more) {
                 float *An = ldsf + (size_t)(s ^ 1) * stage + krow * 128 + seg, *Bn = An + PF_BK * 128;
-                *reinterpret_cast<float4 *>(An) = ra[0];
-                *reinterpret_cast<float4 *>(An + 4) = ra[1];
-                *reinterpret_cast<float4 *>(Bn) = rb[0];
-                *reinterpret_cast<float4 *>(Bn + 4) = rb[1];
+                *reinterpret_cast<float4 *>(An) = ra0;
+                *reinterpret_cast<float4 *>(An + 4) = ra1;
+                *reinterpret_cast<float4 *>(Bn) = rb0;
+                *reinterpret_cast<float4 *>(Bn + 4) = rb1;
             }
             __syncthreads();
         }
+        if (t + gridDim.x < ntile) { // the next tile's first chunk is requested before this tile's epilogue
+            const i64 tn = t + gridDim.x, In = I0 + tn / nTJ, Jn = tn % nTJ;
+            const float *qa = Xs + (i64)krow * lds_rows + In * 128 + seg, *qb = Ms + (i64)krow * ldm + Jn * 128 + seg;
+            ra0 = *reinterpret_cast<const float4 *>(qa);
+            ra1 = *reinterpret_cast<const float4 *>(qa + 4);
+            rb0 = *reinterpret_cast<const float4 *>(qb);
+            rb1 = *reinterpret_cast<const float4 *>(qb + 4);
+        }
         // C/D layout of 32x32x2: lane l, register 4g + j -> row 8g + 4 (l >> 5) + j, column l & 31.  A landmark owns whole
-        // 16-row groups: group h of a 32-row block = registers g in {2h, 2h+1} of both lane halves.
+        // 16-row groups: group h of a 32-row block = registers g in {2h, 2h+1} of both lane halves.  One value per (group,
+        // reference point) goes out with a plain 256-byte store per half wave; the groups of a landmark are combined by
+        // pcent_groups_kernel (per-element atomic maxima on P would be ~3 x 10^7 memory-side read-modify-writes).
 #pragma unroll
         for (int b = 0; b < 2; b++) {
             const i64 col = j0 + wc * 64 + b * 32 + l32;
             const double mn = mnorm[col] * e1;
-            double cur = 0.0;
-            int curland = -1;
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const i64 r0 = i0 + wr * 64 + a * 32 + 16 * h;
-                    const int land = sub_land[r0 >> 4]; // wave-uniform
                     double v = -1e300;
 #pragma unroll
                     for (int gg = 0; gg < 2; gg++)
@@ -373,17 +384,21 @@ __global__ __launch_bounds__(256, 2) void pcent_f32_kernel(const float *__restri
                         for (int j = 0; j < 4; j++)
                             v = fmax(v, rns[r0 + 8 * gg + 4 * lh + j] * e1 - 2.0 * (double)acc[a][b][4 * (2 * h + gg) + j]);
                     v = fmax(v, __shfl_xor(v, 32));
-                    if (land != curland) {
-                        if (curland >= 0 && lh == 0 && col < N)
-                            atomicMax(&P[(i64)curland * N + col], (unsigned long long)__double_as_longlong(fmax(cur + mn, 0.0)));
-                        curland = land;
-                        cur = v;
-                    } else
-                        cur = fmax(cur, v);
+                    if (lh == 0) G[(r0 >> 4) * ldm + col] = fmax(v + mn, 0.0);
                 }
-            if (curland >= 0 && lh == 0 && col < N)
-                atomicMax(&P[(i64)curland * N + col], (unsigned long long)__double_as_longlong(fmax(cur + mn, 0.0)));
         }
+    }
+}
+
+// P[a][r] = max over the 16-row groups of landmark a (groups goff[a] .. goff[a+1], from the landmark-sorted layout)
+__global__ void pcent_groups_kernel(const double *__restrict__ G, const i32 *__restrict__ soff, i64 ldm, i64 N,
+                                    double *__restrict__ P) {
+    const i64 a = blockIdx.x;
+    const i32 g0 = soff[a] >> 4, g1 = soff[a + 1] >> 4;
+    for (i64 col = threadIdx.x; col < N; col += blockDim.x) {
+        double v = 0.0;
+        for (i32 g = g0; g < g1; g++) v = fmax(v, G[(i64)g * ldm + col]);
+        P[a * N + col] = v;
     }
 }
 
@@ -461,16 +476,22 @@ void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, cons
                        rns, lds_rows, Ms, mnorm, ldm, N, dpad, sub_land, reinterpret_cast<unsigned long long *>(P), I0, I1);
 }
 
+// `soff` = device copy of the landmark offsets of the sorted layout (N_land + 1 entries, multiples of 16).  With several
+// ranks every rank fills the groups of its own row tiles; the groups of the others stay 0 and the all-reduce(max) of P
+// combines them.
 void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows, const float *Ms32, const double *mnorm,
-                 i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P, int part, int nparts) {
-    HIP_CHECK(hipMemsetAsync(P, 0, sizeof(double) * n_land * N, c->stream));
+                 i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *soff, double *P, int part, int nparts) {
+    const i64 ngroups = lds_rows / 16;
+    c->pc_groups.ensure((size_t)ngroups * ldm);
+    if (nparts > 1) HIP_CHECK(hipMemsetAsync(c->pc_groups.p, 0, sizeof(double) * (size_t)ngroups * ldm, c->stream));
     ScopedKernelTimer t(c, "pcent");
     const i64 nTI = lds_rows / 128, I0 = nTI * part / nparts, I1 = nTI * (part + 1) / nparts;
     const i64 ntiles = (I1 - I0) * (ldm / 128);
-    if (ntiles <= 0) return;
     const double e1 = 1.0 + 1.01 * (double)(dpad + 2) * 5.9604644775390625e-08; // 1 + e, e = 1.01 (K + 2) 2^-24
-    hipLaunchKernelGGL(pcent_f32_kernel, dim3((unsigned)std::min<i64>(ntiles, 2048)), dim3(256), PF_LDS_BYTES, c->stream, Xs32,
-                       rns, lds_rows, Ms32, mnorm, ldm, N, dpad, sub_land, reinterpret_cast<unsigned long long *>(P), I0, I1, e1);
+    if (ntiles > 0)
+        hipLaunchKernelGGL(pcent_f32_kernel, dim3((unsigned)std::min<i64>(ntiles, 2048)), dim3(256), PF_LDS_BYTES, c->stream,
+                           Xs32, rns, lds_rows, Ms32, mnorm, ldm, N, dpad, c->pc_groups.p, I0, I1, e1);
+    hipLaunchKernelGGL(pcent_groups_kernel, dim3((unsigned)n_land), dim3(256), 0, c->stream, c->pc_groups.p, soff, ldm, N, P);
 }
 
 void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,

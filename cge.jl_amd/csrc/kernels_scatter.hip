@@ -66,16 +66,8 @@ bool k_build_blocked_edges(cge_ctx *c) {
     if (nbu > 16 || nbv > 64 || m <= 0 || m >= (1LL << 31)) return false;
     hipStream_t st = c->stream;
     const i64 T = nbu * nbv;
-    // edges per thread of the edge pass: the smallest of 16 / 20 / 24 with which the chunks fit ONE round of the chip's
-    // 2 x CUs workgroup slots (a second, half-empty round costs a whole latency chain); 16 when even 24 needs two rounds
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    static const int env_per = getenv("CGE_EB_PER") ? atoi(getenv("CGE_EB_PER")) : 0; // tuning only
-    int per_thread = 16;
-    for (int cand : {16, 20, 24})
-        if ((m + (i64)EB_THREADS * cand - 1) / ((i64)EB_THREADS * cand) + T / 2 <= (i64)2 * cus) { per_thread = cand; break; }
-    if (env_per == 16 || env_per == 20 || env_per == 24) per_thread = env_per;
+    // 16 edges per thread: with 20 or 24 the edge pass no longer fits 64 registers (two workgroups per CU) and spills
+    const int per_thread = 16;
     c->be_per = per_thread;
     const i64 EB_CHUNK = (i64)EB_THREADS * per_thread;
     DevBuf<unsigned> keys, skeys;
@@ -354,9 +346,7 @@ void k_edge_scatter_blocked(cge_ctx *c, i64 c0, i64 c1, i64 C, int directed, dou
     static const int stop = getenv("CGE_EB_STOP") ? atoi(getenv("CGE_EB_STOP")) : 0; // timing diagnostics (wrong results)
 #define EB_GO(W, D)                                                                                                        \
     do {                                                                                                                   \
-        if (c->be_per == 24) EB_GO2(24, W, D);                                                                             \
-        else if (c->be_per == 20) EB_GO2(20, W, D);                                                                        \
-        else EB_GO2(16, W, D);                                                                                             \
+        EB_GO2(16, W, D);                                                                                             \
     } while (0)
 #define EB_GO2(P, W, D)                                                                                                    \
     do {                                                                                                                   \

@@ -96,6 +96,10 @@ int cge_comm_finalize(cge_ctx *ctx);
 int cge_set_graph(cge_ctx *ctx, const int64_t *src, const int64_t *dst, const double *w, int64_t m, int64_t n);
 /* embedding::Matrix{Float64} n x d column-major (src/auxilary.jl:164) */
 int cge_set_embedding(cge_ctx *ctx, const double *X_colmajor, int64_t n, int64_t d);
+/* The same for an embedding that already lives in THIS GPU's memory (a host framework's tensor; 41 GB at configuration 5
+ * would otherwise cross PCIe): n x d doubles, row-major (row_major = 1: a vertex's d features contiguous) or column-major
+ * like Julia's Matrix (0).  Copied (the caller keeps ownership and may free the buffer on return).                      */
+int cge_set_embedding_device(cge_ctx *ctx, const double *X_dev, int64_t n, int64_t d, int row_major);
 /* comm::Matrix{Int} n x 1 (src/auxilary.jl:122-139) and vweight (src/auxilary.jl:104-110) */
 int cge_set_vertex_data(cge_ctx *ctx, const int64_t *comm, const double *vweights, int64_t n);
 

@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch first: it bundles its own HIP runtime, and whichever copy is loaded first serves the whole process -- a test that
+    import torch  # noqa: F401  # hands a torch tensor to libcge_hip.so needs both to share one runtime (as in bench.py)
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -176,3 +176,60 @@ def test_config4_directed_million_samples_against_oracle_fixture(ctx):
                      auc_samples=S, directed=True, samples=(pos.reshape(1, -1), ni.reshape(1, -1), nj.reshape(1, -1)),
                      use_resident_original=True)
     assert np.array_equal(res, res_h)
+
+
+def test_config5_d512_twelve_thousand_landmarks(ctx):
+    """configs[4] (ABCD 10M / 200M, d = 512, -l 12000) at the shape the test budget allows: n = 200 000 vertices, 4.2M edges,
+    1500 communities, d = 512, 12 000 landmarks, i.e. the code paths of that configuration (the batched eigen-solver for
+    128 < d <= 512, the fp32-MFMA bound pass at K = 512, 12 000-landmark sweep on the launch-per-iteration fit) -- the
+    full-size run is `bench.py --workload cfg5` (the 41 GB embedding is generated in HBM).  No oracle can do 12 000 splits
+    at d = 512 in test time, so: the reference's invariants, the exact diameter against the CPU branch and bound,
+    pruned == brute force, fp32 bound pass == fp64 bound pass, host upload == device-pointer upload, reproducible bits."""
+    import torch
+
+    from cge.jl_amd import synth
+    from diameter_ref import exact_diameter
+
+    n, d, C, land = 200_000, 512, 1500, 12000
+    g = synth.abcd_like(n, 4_200_000, C, d, seed=42)
+    m = g["m"]
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    res = ctx.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000)
+    tr = ctx.last_trace
+    hi, path, pairs, tiles = ctx.last_diameter()
+    ref_hi, hi_i, hi_j, _ = exact_diameter(g["embedding"], g["comm"][:, 0])
+    assert hi == ref_hi, (hi, ref_hi, path)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = ctx.landmarks_fetch()
+    N = len(dii)
+    assert N == land and v2l.min() == 1 and v2l.max() == N
+    comm = g["comm"][:, 0]
+    first = np.zeros(N + 1, dtype=np.int64)
+    first[v2l] = comm
+    assert np.array_equal(first[v2l], comm) and np.array_equal(lcomm[:, 0], first[1:])  # landmarks nest in communities
+    assert lw.sum() == m and lweight.sum() == 2 * m and np.array_equal(np.bincount(v2l, weights=g["vweights"])[1:], lweight)
+    for l in np.random.default_rng(1).integers(1, N + 1, 25):
+        mem = np.flatnonzero(v2l == l)
+        w = g["vweights"][mem]
+        cen = (g["embedding"][mem] * w[:, None]).sum(0) / w.sum()
+        assert np.allclose(lemb[l - 1], cen, rtol=1e-12, atol=1e-14)
+        assert dii[l - 1] == pytest.approx(np.sqrt(((g["embedding"][mem] - lemb[l - 1]) ** 2).sum() / w.sum()), rel=1e-12)
+    assert np.all(np.isfinite(res)) and 0.25 <= res[0] <= 10 and 0 < res[1] <= math.log(2) and 0 <= res[5] <= 1
+    best = int(np.nanargmin(tr["div"]))
+    assert res[1] == tr["div"][best] and res[0] == 0.25 * (best + 1) and all(it >= 1 for it in tr["iters"])
+    assert np.array_equal(res, ctx.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000))
+    try:  # bound pass in fp64, then brute force: the same diameter bits, the same score
+        ctx.set_option("diameter_f32", 0)
+        assert np.array_equal(res, ctx.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000))
+        assert ctx.last_diameter()[0] == hi
+        ctx.set_option("diameter", 1)
+        assert np.array_equal(res, ctx.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000))
+        assert ctx.last_diameter()[:2] == (hi, "brute")
+    finally:
+        ctx.set_option("diameter", 0)
+        ctx.set_option("diameter_f32", 1)
+    # the embedding handed over as a device pointer (row-major torch tensor), as bench.py --workload cfg5 does
+    X = torch.from_numpy(np.ascontiguousarray(g["embedding"])).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx.set_embedding_device(X.data_ptr(), n, d, row_major=True)
+    del X
+    assert np.array_equal(res, ctx.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000))
