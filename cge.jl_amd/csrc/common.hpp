@@ -330,6 +330,8 @@ struct cge_ctx {
     DevBuf<unsigned char> sort_tmp;
 
     DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;
+    DevBuf<double> r2_F, r2_ck; // rss2: RSS of every prefix / suffix along sorted z, block checkpoints of the two chains
+    i64 r2_rows = 0;            // rows of the batch the rss2 kernels are about to see
 
     // ---- profiling -------------------------------------------------------------------------
     bool profiling = false;

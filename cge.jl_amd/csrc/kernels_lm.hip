@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(64) void rss2_walk_kernel(const double *__restrict_
         vals[2 * t + 1] = -fh;
     }
 }
-void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
+void k_rss2_walk_one_kernel(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
                  i32 *meta, double *vals, double *cmeans) {
     if (d > 64 * RR_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * RR_SLOTS);
     ScopedKernelTimer t(c, "rss2_walk");
@@ -1028,6 +1028,289 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
     else if (ns == 4) CGE_RSS2_LAUNCH(4);
     else CGE_RSS2_LAUNCH(8);
 #undef CGE_RSS2_LAUNCH
+}
+
+// ---- split_cluster_rss2 in two kernels ---------------------------------------------------------------------------------
+// The walk of :105-117 compares sum(wsse, rss_low) with sum(wsse, rss_high); the first depends only on how many rows
+// the low side has absorbed (its additions run in rank order whatever the high side does), the second only on the high
+// side.  So  FL[i] = RSS of ranks 0..i  and  FH[j] = RSS of ranks k-1-j..k-1  can be produced for ALL i, j by two
+// independent chains with the reference's own additions in the reference's order (rss2_chain_kernel: one workgroup per
+// task and direction; every wave runs the cheap chain of additions over all rows, but pays the divisions and the
+// 64-lane reduction only for every fourth block of 16 rows), and the walk becomes a scalar merge of two arrays
+// (rss2_merge_kernel).  Same bits as rss2_walk_kernel: the same additions in the same order, the same reduction tree.
+#define R2_BR 16 // rows per block of the chain
+template <int NS>
+__global__ __launch_bounds__(256) void rss2_chain_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                                         const i32 *__restrict__ srows,
+                                                         const i32 *__restrict__ task_row_off, i64 d, i64 R,
+                                                         double *__restrict__ F /* [2][R] */,
+                                                         double *__restrict__ ck /* [2][slots][2 NS 64 + 64] */, i64 slots) {
+    __shared__ double tile[4][R2_BR][65]; // per wave: part[q] of every lane, transposed for the row-wise tree sums
+    const i64 t = blockIdx.x;
+    const int dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    const i32 *p = srows + o;
+    const i64 nblk = (k + R2_BR - 1) / R2_BR, slot0 = o / R2_BR + t;
+    double *Fo = F + (i64)dir * R + o;
+    double *cko = ck + ((i64)dir * slots + slot0) * (2 * NS * 64 + 64);
+    double ss[NS], s1[NS], wacc = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
+    // Four register sets of 16 rows each rotate through the loop: 64 rows are in flight while 16 are absorbed (one set in
+    // flight leaves the chain waiting on memory for most of every block).  A lane keeps the weight of row `lane` of a set.
+    auto load_block = [&](i64 b, double (&x)[R2_BR][NS], double &wl) {
+        const i64 q = b * R2_BR + lane;
+        const bool ok = lane < R2_BR && q < k;
+        const int vq = ok ? p[dir ? k - 1 - q : q] : p[0]; // slots past the end: a valid row with weight 0
+        wl = ok ? vw[vq] : 0.0;
+#pragma unroll
+        for (int u = 0; u < R2_BR; u++) {
+            const i64 v = __builtin_amdgcn_readlane(vq, u);
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const i64 c = lane + 64 * s;
+                x[u][s] = (c < d) ? Xr[v * d + c] : 0.0;
+            }
+        }
+    };
+    auto process = [&](i64 b, const double (&x)[R2_BR][NS], const double wl) {
+        const bool mine = (int)(b & 3) == wave;
+        if (mine) { // checkpoint: the triple before this block
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                cko[b * (2 * NS * 64 + 64) + (2 * s) * 64 + lane] = ss[s];
+                cko[b * (2 * NS * 64 + 64) + (2 * s + 1) * 64 + lane] = s1[s];
+            }
+            if (lane == 0) cko[b * (2 * NS * 64 + 64) + 2 * NS * 64] = wacc;
+        }
+#pragma unroll
+        for (int q = 0; q < R2_BR; q++) {
+            const double w = lane_value(wl, q);
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const double xv = x[q][s];
+                ss[s] += w * (xv * xv);
+                s1[s] += w * xv;
+            }
+            wacc += w;
+            if (mine) {
+                double acc = 0.0;
+#pragma unroll
+                for (int s = 0; s < NS; s++) acc += ss[s] - s1[s] * s1[s] / wacc; // padded columns are 0
+                tile[wave][q][lane] = acc;
+            }
+        }
+        if (mine) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane < R2_BR) { // wave_allsum's tree: adjacent pairs inside each row of 16 lanes, then ((R0 + R1) + R2) + R3
+                const double *v = tile[wave][lane];
+                double r16[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const double *u = v + 16 * g;
+                    const double a0 = (u[0] + u[1]) + (u[2] + u[3]), a1 = (u[4] + u[5]) + (u[6] + u[7]);
+                    const double a2 = (u[8] + u[9]) + (u[10] + u[11]), a3 = (u[12] + u[13]) + (u[14] + u[15]);
+                    r16[g] = (a0 + a1) + (a2 + a3);
+                }
+                const i64 q = b * R2_BR + lane;
+                if (q < k) Fo[q] = ((r16[0] + r16[1]) + r16[2]) + r16[3];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    double x0[R2_BR][NS], x1[R2_BR][NS], x2[R2_BR][NS], x3[R2_BR][NS], w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+    load_block(0, x0, w0);
+    if (1 < nblk) load_block(1, x1, w1);
+    if (2 < nblk) load_block(2, x2, w2);
+    if (3 < nblk) load_block(3, x3, w3);
+    for (i64 b = 0; b < nblk; b += 4) {
+        process(b, x0, w0);
+        if (b + 4 < nblk) load_block(b + 4, x0, w0);
+        if (b + 1 < nblk) {
+            process(b + 1, x1, w1);
+            if (b + 5 < nblk) load_block(b + 5, x1, w1);
+        }
+        if (b + 2 < nblk) {
+            process(b + 2, x2, w2);
+            if (b + 6 < nblk) load_block(b + 6, x2, w2);
+        }
+        if (b + 3 < nblk) {
+            process(b + 3, x3, w3);
+            if (b + 7 < nblk) load_block(b + 7, x3, w3);
+        }
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void rss2_merge_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                                        const i32 *__restrict__ srows,
+                                                        const i32 *__restrict__ task_row_off, i64 d, i64 R,
+                                                        const double *__restrict__ F, const double *__restrict__ ck,
+                                                        i64 slots, i32 *__restrict__ meta, double *__restrict__ vals,
+                                                        double *__restrict__ cmeans) {
+    const i64 t = blockIdx.x;
+    const int lane = threadIdx.x;
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    const i32 *p = srows + o;
+    const double *FL = F + o, *FH = F + R + o; // FL[i]: low side holds ranks 0..i; FH[j]: high side holds ranks k-1-j..k-1
+    // ---- the walk: i + j goes from 0 to k - 2, low advances when FL[i] < FH[j] ------------------------------------------
+    // Both arrays non-decreasing (the usual case): the walk is the merge of two sorted lists, its end point a bisection.
+    bool mono = true;
+    for (i64 q = lane; q + 1 < k; q += 64) mono = mono && FL[q] <= FL[q + 1] && FH[q] <= FH[q + 1];
+    mono = __all(mono);
+    const i64 S = k - 2;
+    i64 li; // rows the low side has taken beyond rank 0 when the walk ends
+    if (mono) {
+        // smallest i in [0, S] such that the walk does NOT take an (i+1)-th low step before its j-th high step, j = S - i:
+        // low step i+1 (comparing FL[i]) comes before high step j (comparing FH[j-1]) iff FL[i] < FH[j-1]
+        i64 lo_ = 0, hi_ = S;
+        while (lo_ < hi_) {
+            const i64 mid = (lo_ + hi_) >> 1, j = S - mid;
+            if (j >= 1 && FL[mid] < FH[j - 1]) lo_ = mid + 1; else hi_ = mid;
+        }
+        li = lo_;
+    } else { // the reference's loop as it stands: scalar, the two arrays in 64-entry register windows (next one in flight)
+        int i = 0, j = 0, bi = 0, bj = 0;
+        const int Sn = (int)S, kn = (int)k;
+        double cl = FL[min(kn - 1, lane)], ch = FH[min(kn - 1, lane)];
+        double nl = FL[min(kn - 1, 64 + lane)], nh = FH[min(kn - 1, 64 + lane)];
+        double fl0 = lane_value(cl, 0), fh0 = lane_value(ch, 0);
+        while (i + j < Sn) {
+            if (fl0 < fh0) {
+                i++;
+                if (i - bi == 64) { cl = nl; bi += 64; nl = FL[min(kn - 1, bi + 64 + lane)]; }
+                fl0 = lane_value(cl, __builtin_amdgcn_readfirstlane(i - bi));
+            } else {
+                j++;
+                if (j - bj == 64) { ch = nh; bj += 64; nh = FH[min(kn - 1, bj + 64 + lane)]; }
+                fh0 = lane_value(ch, __builtin_amdgcn_readfirstlane(j - bj));
+            }
+        }
+        li = i;
+    }
+    i64 lo = li, hi = k - 1 - (S - li);
+    double fl = FL[lo], fh = FH[k - 1 - hi];
+    // ---- the two WSSE triples at the meeting point: checkpoint of the block + its first rows again, in order ----------------
+    const i64 slot0 = o / R2_BR + t, stride = 2 * NS * 64 + 64;
+    double l_ss[NS], l_s[NS], h_ss[NS], h_s[NS], l_w, h_w;
+    auto restore = [&](int dir, i64 q_last, double (&ss)[NS], double (&s1)[NS], double &w) {
+        const i64 b = q_last / R2_BR;
+        const double *c0 = ck + ((i64)dir * slots + slot0 + b) * stride;
+#pragma unroll
+        for (int s = 0; s < NS; s++) { ss[s] = c0[(2 * s) * 64 + lane]; s1[s] = c0[(2 * s + 1) * 64 + lane]; }
+        w = c0[2 * NS * 64];
+        for (i64 q = b * R2_BR; q <= q_last; q++) {
+            const i64 v = p[dir ? k - 1 - q : q];
+            const double wv = vw[v];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const i64 c = lane + 64 * s;
+                const double xv = (c < d) ? Xr[v * d + c] : 0.0;
+                ss[s] += wv * (xv * xv);
+                s1[s] += wv * xv;
+            }
+            w += wv;
+        }
+    };
+    restore(0, lo, l_ss, l_s, l_w);
+    restore(1, k - 1 - hi, h_ss, h_s, h_w);
+    auto term = [&](i64 rank, double (&ss)[NS], double (&s1)[NS], double &w) { // WSSE(m[p[rank], :], w[p[rank]])
+        const i64 v = p[rank];
+        w = vw[v];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const i64 c = lane + 64 * s;
+            const double x = (c < d) ? Xr[v * d + c] : 0.0;
+            ss[s] = w * (x * x);
+            s1[s] = w * x;
+        }
+    };
+    auto fsum = [&](const double (&ss)[NS], const double (&s1)[NS], double w) {
+        double acc = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc += ss[s] - s1[s] * s1[s] / w;
+        return wave_allsum(acc);
+    };
+    // boundary adjustment (:118-150): move the last low row up, or the first high row down, while the larger RSS shrinks
+    bool moved_low = false;
+    double a_ss[NS], a_s[NS], t_ss[NS], t_s[NS], u_ss[NS], u_s[NS], aw;
+    while (lo > 0) {
+        term(lo, a_ss, a_s, aw);
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            t_ss[s] = l_ss[s] - a_ss[s]; t_s[s] = l_s[s] - a_s[s];
+            u_ss[s] = h_ss[s] + a_ss[s]; u_s[s] = h_s[s] + a_s[s];
+        }
+        const double tw = l_w - aw, uw = h_w + aw;
+        const double ft = fsum(t_ss, t_s, tw), fu = fsum(u_ss, u_s, uw);
+        if (fmax(ft, fu) < fmax(fl, fh)) {
+            moved_low = true;
+            lo--; hi--;
+#pragma unroll
+            for (int s = 0; s < NS; s++) { l_ss[s] = t_ss[s]; l_s[s] = t_s[s]; h_ss[s] = u_ss[s]; h_s[s] = u_s[s]; }
+            l_w = tw; h_w = uw; fl = ft; fh = fu;
+        } else
+            break;
+    }
+    if (!moved_low)
+        while (hi < k - 1) {
+            term(hi, a_ss, a_s, aw);
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                t_ss[s] = l_ss[s] + a_ss[s]; t_s[s] = l_s[s] + a_s[s];
+                u_ss[s] = h_ss[s] - a_ss[s]; u_s[s] = h_s[s] - a_s[s];
+            }
+            const double tw = l_w + aw, uw = h_w - aw;
+            const double ft = fsum(t_ss, t_s, tw), fu = fsum(u_ss, u_s, uw);
+            if (fmax(ft, fu) < fmax(fl, fh)) {
+                lo++; hi++;
+#pragma unroll
+                for (int s = 0; s < NS; s++) { l_ss[s] = t_ss[s]; l_s[s] = t_s[s]; h_ss[s] = u_ss[s]; h_s[s] = u_s[s]; }
+                l_w = tw; h_w = uw; fl = ft; fh = fu;
+            } else
+                break;
+        }
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const i64 c = lane + 64 * s;
+        if (c < d) {
+            cmeans[(2 * t) * d + c] = l_s[s] / l_w;
+            cmeans[(2 * t + 1) * d + c] = h_s[s] / h_w;
+        }
+    }
+    if (lane == 0) {
+        meta[2 * t] = (i32)lo;
+        meta[2 * t + 1] = (i32)hi;
+        vals[2 * t] = -fl;
+        vals[2 * t + 1] = -fh;
+    }
+}
+
+void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
+                 i32 *meta, double *vals, double *cmeans) {
+    if (d > 64 * RR_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * RR_SLOTS);
+    static const bool old_form = getenv("CGE_RSS2_ONE_KERNEL") != nullptr; // A/B switch: the one-wave-per-task walk
+    const int ns0 = d <= 64 ? 1 : d <= 128 ? 2 : d <= 256 ? 4 : 8;
+    if (!old_form && ns0 <= 2 && c->r2_rows > 0) { // chain + merge (the register blocks of the chain allow d <= 128)
+        ScopedKernelTimer t(c, "rss2_walk");
+        const i64 R = c->r2_rows, slots = R / R2_BR + n_tasks + 2, stride = 2 * ns0 * 64 + 64;
+        c->r2_F.ensure((size_t)2 * R);
+        c->r2_ck.ensure((size_t)2 * slots * stride);
+        const dim3 gridA((unsigned)n_tasks, 2);
+        if (ns0 == 1) {
+            hipLaunchKernelGGL((rss2_chain_kernel<1>), gridA, dim3(256), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
+                               c->r2_ck.p, slots);
+            hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+                               d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+        } else {
+            hipLaunchKernelGGL((rss2_chain_kernel<2>), gridA, dim3(256), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
+                               c->r2_ck.p, slots);
+            hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+                               d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+        }
+        return;
+    }
+    k_rss2_walk_one_kernel(c, Xr, vw, srows, task_row_off, n_tasks, d, meta, vals, cmeans);
 }
 
 // split_cluster_size / split_cluster_diameter (src/landmarks.jl:212-262): the 1-D cut of z at its median

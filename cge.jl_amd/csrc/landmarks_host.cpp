@@ -638,6 +638,7 @@ void rule_rss2_device(cge_ctx *c, const Batch &B, Group *const *groups, i64 base
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                        c->sp_srows.p, c->sp_status.p);
     HIP_CHECK(hipMemcpyAsync(c->lm_arena.p + base, c->sp_srows.p, sizeof(i32) * R, hipMemcpyDeviceToDevice, st));
+    c->r2_rows = R;
     k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->lm_means.p + mbase);
     std::vector<i32> meta(2 * T);
     std::vector<double> vals(2 * T);
