@@ -1024,6 +1024,11 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_shard_forced = (int)value;
         return CGE_OK;
     }
+    if (!strcmp(key, "shard_samples")) { // N > 1: 0 = tallies replicated, 1 (default) = split from 10^5 samples on with the in-library communicator, 2 = always
+        if (value < 0 || value > 2) return CGE_E_ARG;
+        c->opt_shard_samples = (int)value;
+        return CGE_OK;
+    }
     if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;

@@ -268,6 +268,7 @@ struct cge_ctx {
     bool pow_logs_upper = false;
     DevBuf<double> sw_Lh;
     DevBuf<float> sw_Ll;
+    int opt_shard_samples = 1; // N > 1: 1 = local-score tallies split over the ranks from 10^5 samples on (in-library RCCL), 2 = always, 0 = never
     int opt_shard_forced = 1; // N > 1: the forced per-community phase of runsplit is split over the ranks
     int opt_test_bvec_plain = 0; // testing: vect_B without LDS staging / rows in flight (the forms of very large score graphs)
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 128 vertices that fit the register file), 1 never, 2 whenever it

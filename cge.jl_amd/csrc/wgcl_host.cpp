@@ -160,6 +160,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     HIP_CHECK(hipMemsetAsync(TT.p, 0, sizeof(double) * 3 * Tld, st));
     HIP_CHECK(hipMemcpyAsync(TT.p, T1.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
     double *Tcur = TT.p;
+    // sample tallies split over the ranks: with the in-library communicator (stream-ordered, no host synchronisation in the
+    // enqueued chain) from 10^5 samples on; option "shard_samples" = 2 forces it (tests, also through the hook), 0 disables
+    const bool shard_samples = c->has_coll && smp.S >= c->coll.world &&
+                               (c->opt_shard_samples == 2 || (c->opt_shard_samples == 1 && c->rccl_comm && smp.S >= 100000));
     fit_sweep_begin(c);
     bool use_persistent = !directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
                           (c->opt_fit_persistent >= 2 || N >= 128);
@@ -359,11 +363,18 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         const double *Ta = directed ? Tout : Tcur, *Tb = directed ? Tin : Tcur;
         if (want_auc) {
             const DevSamples &ds = dsets[smp.n_sets == 1 ? 0 : ia - 1];
+            // N > 1 with many samples: rank r tallies the samples [S r / W, S (r + 1) / W) and the block tallies
+            // are summed over the ranks -- the same array on every rank afterwards, so all ranks take the same early stops
+            const i64 s0 = shard_samples ? S * c->coll.rank / c->coll.world : 0;
+            const i64 s1 = shard_samples ? S * (c->coll.rank + 1) / c->coll.world : S;
             if (landmarks)
-                k_auc_landmark(c, Ta, Tb, orig->v2l, orig->vw, orig->lweight, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p,
-                               ds.dpos.p, ds.dneg.p, ds.wts.p, S, alpha, nullptr, scal.p + RES_AUC);
+                k_auc_landmark(c, Ta, Tb, orig->v2l, orig->vw, orig->lweight, ds.pi.p + s0, ds.pj.p + s0, ds.ni.p + s0,
+                               ds.nj.p + s0, ds.dpos.p + s0, ds.dneg.p + s0, ds.wts.p + s0, s1 - s0, alpha, nullptr,
+                               scal.p + RES_AUC);
             else
-                k_auc_exact(c, GD.p, Ta, Tb, N, ds.pi.p, ds.pj.p, ds.ni.p, ds.nj.p, ds.wts.p, S, nullptr, scal.p + RES_AUC);
+                k_auc_exact(c, GD.p, Ta, Tb, N, ds.pi.p + s0, ds.pj.p + s0, ds.ni.p + s0, ds.nj.p + s0, ds.wts.p + s0, s1 - s0,
+                            nullptr, scal.p + RES_AUC);
+            if (shard_samples) cge_allreduce_dev(c, scal.p + RES_AUC, 2 * CGE_PARTIAL_BLOCKS, 0);
         }
         if (want_div) {
             k_bvec(c, GD.p, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);

@@ -225,6 +225,10 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  * "shard_runsplit": with collectives set (N > 1): 1 (default) = the forced per-community phase of runsplit and the big
  *             batches of its global phase are split over the ranks and gathered by one all-reduce each (hook op 2);
  *             0 = runsplit replicated on every rank; 2 = every batch is split (tests).  Same landmark ids in all modes.
+ * "shard_samples": with collectives set (N > 1): 1 (default) = from 10^5 local-score samples on, and with the in-library
+ *             RCCL communicator, rank r tallies the samples [S r / W, S (r + 1) / W) of every alpha and the block tallies are
+ *             all-reduced (2 x 64 doubles per alpha, on the stream); 2 = always (also through the hook; tests); 0 = never.
+ *             The sums are grouped differently from a one-rank run (last-bit differences of elements 5-7).
  * "pow_exp2": 1 (default) = GD = (1 - D)^alpha as exp2(alpha * log2(1 - D)) with log2 computed once per score to ~70
  *             bits (a double and a float per entry; below one ulp, like the library pow); 0 = the library pow per alpha.
  * "test_bvec_plain": testing hook, 1 = vect_B through the kernels that serve score graphs of more than 8192 vertices /

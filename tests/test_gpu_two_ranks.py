@@ -34,7 +34,7 @@ def _graph():
     return synth.abcd_like(30000, 300000, 30, 16, seed=21)
 
 
-def _rank(rank, world, port, q, mode, method="rss"):
+def _rank(rank, world, port, q, mode, method="rss", shard_samples=1):
     try:
         import torch
         import torch.distributed as dist
@@ -52,6 +52,7 @@ def _rank(rank, world, port, q, mode, method="rss"):
         coll = TorchCollectives(ctx, 600 * 600 * 2 + 1024, torch.device("cuda", 0))
         ctx.set_option("fit_persistent", 1)
         ctx.set_option("shard_runsplit", mode)  # 2: every batch of the global phase is split too, whatever its size
+        ctx.set_option("shard_samples", shard_samples)  # 2: the local-score tallies of every alpha are split over the ranks
         res = ctx.score(g["clusters"], 600, 2, method, seed=5, auc_samples=4000)
         hi = ctx.last_diameter()[0]
         batches = ctx.get_stat("landmark_batches")
@@ -111,7 +112,9 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx, mode):
 
 @pytest.mark.parametrize("method", ["rss2", "size", "diameter"])
 def test_two_ranks_other_split_rules(ctx, method):
-    """The same with every batch of runsplit split over the two ranks, for the other three split rules."""
+    """The same with every batch of runsplit split over the two ranks, for the other three split rules -- and with the
+    local-score tallies of every alpha split over the ranks (S / W samples per rank, an all-reduce of the block
+    tallies per alpha; unit weights, so the sums are exact whatever their grouping)."""
     import torch.multiprocessing as mp
 
     g = _graph()
@@ -125,7 +128,7 @@ def test_two_ranks_other_split_rules(ctx, method):
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_rank, args=(r, 2, port, q, 2, method)) for r in range(2)]
+    procs = [mpc.Process(target=_rank, args=(r, 2, port, q, 2, method, 2)) for r in range(2)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=600) for _ in procs)
@@ -134,3 +137,5 @@ def test_two_ranks_other_split_rules(ctx, method):
     for rank, res, hi, n_calls, crc in results:
         assert hi is not None, res
         assert crc == crc_ref and np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
+        assert n_calls[0] > 3 + 10  # ... plus one all-reduce of the tallies per alpha with a local score
+    assert results[0][1] == results[1][1]
