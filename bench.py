@@ -94,7 +94,7 @@ def cpu_baseline(g, wl, budget_vertices=60000):
 
 
 ROOFLINE_KERNELS = ("fit_persistent", "fit_symv", "group_stats", "group_project", "sorted_prefix", "pcent", "pair_list",
-                    "max_pair_dist", "edge_scatter")
+                    "max_pair_dist", "edge_scatter", "rss2_walk", "group_eig")
 
 
 def main():
@@ -275,7 +275,15 @@ def main():
         "group_project": ("hbm", HBM_PEAK_GBS, "GB/s", None, "projection z: one 8d-byte row read per row of the batch"),
         "sorted_prefix": ("hbm", HBM_PEAK_GBS, "GB/s", None, "WSSE scan along sorted z: one 8d-byte row read per row of the batch"),
         "edge_scatter": ("hbm", HBM_PEAK_GBS, "GB/s", 24.0 * g["m"] / world,
-                         "C x C cluster-pair scatter-add, 24 B per edge (2 x Int64 + Float64 as the reference stores them)"),
+                         "C x C cluster-pair scatter-add (edge pass + row reduction, kernels_scatter.hip), 24 B per edge "
+                         "(2 x Int64 + Float64 as the reference stores them; the blocked device copy is 4 B per edge)"),
+        "rss2_walk": ("hbm", HBM_PEAK_GBS, "GB/s", None,
+                      "rss2 rule (prefix / suffix RSS chains + merge): 2 x 8d bytes per row of the batch; the chains are "
+                      "sequential in the rows of a group (the reference's order of additions) and pay an IEEE division per "
+                      "row and column -- latency-bound by the longest group, not by HBM"),
+        "group_eig": ("hbm", HBM_PEAK_GBS, "GB/s", None,
+                      "batched principal eigenvector (Householder tridiagonalisation, matrix in registers for d <= 128): "
+                      "8 d^2 bytes per matrix; 126 dependent steps per matrix -- latency-bound, not HBM-bound"),
     }
     kernels = {}
     for name in prof:
@@ -285,9 +293,13 @@ def main():
             bound, peak, unit, w, note = work[name]
             if name == "pair_list":
                 w = 2.0 * d * 128 * 128 * cand_tiles / max(1, l_ / steps_prof)
-            if name in ("group_stats", "group_project", "sorted_prefix"):  # average batch of the last runsplit
+            if name in ("group_stats", "group_project", "sorted_prefix", "rss2_walk", "group_eig"):  # average batch of the last runsplit
                 rows = ctx.get_stat("landmark_batch_rows") / max(1, ctx.get_stat("landmark_batches"))
                 w = 2.0 * d * d * rows if name == "group_stats" else 8.0 * d * rows
+                if name == "rss2_walk":
+                    w = 16.0 * d * rows
+                if name == "group_eig":
+                    w = 8.0 * d * d * ctx.get_stat("landmark_splits") / max(1, ctx.get_stat("landmark_batches"))
                 ent["rows_per_launch"] = rows
             if name == "fit_persistent":  # iterations of the last step's sweep / its launches
                 its = ctx.get_stat("fit_iterations") / max(1, l_ / steps_prof)
@@ -304,17 +316,18 @@ def main():
     # HBM traffic per launch from the committed PMC passes of this same command (profiles/run_profiles.sh)
     pmc = {}
     pmc_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (2, 1)) if os.path.exists(f)), "")
-    kernel_of = {"fit_symv": "fit_step_kernel", "fit_persistent": "fit_flow_kernel", "pcent": "pcent_kernel", "pair_list": "pair_list_kernel",
-                 "edge_scatter": "edge_scatter_kernel", "max_pair_dist": "max_pair_kernel"}
+    kernel_of = {"fit_symv": ("fit_step_kernel",), "fit_persistent": ("fit_flow_kernel",), "pcent": ("pcent_f32_kernel", "pcent_groups_kernel"),
+                 "pair_list": ("pair_list_kernel",), "edge_scatter": ("edge_pass_kernel", "edge_row_reduce_kernel"),
+                 "max_pair_dist": ("max_pair_kernel",)}
     if os.path.exists(pmc_file) and args.workload == "headline" and world == 1:
         try:
             pmc = json.load(open(pmc_file))["kernels"]
         except Exception:
             pmc = {}
-    for name, kname in kernel_of.items():  # template instances carry a <...> suffix in the profile
-        hit = [k for k in pmc if k == kname or k.startswith(kname + "<")]
+    for name, knames in kernel_of.items():  # template instances carry a <...> suffix in the profile; a timer may span two kernels
+        hit = [k for k in pmc for kn in knames if k == kn or k.startswith(kn + "<")]
         if name in kernels and hit:
-            kernels[name]["traffic"] = pmc[hit[0]]["hbm_bytes_per_launch"]
+            kernels[name]["traffic"] = sum(pmc[k]["hbm_bytes_per_launch"] for k in hit)
     ranked = sorted((k for k in kernels if "frac" in kernels[k]), key=lambda k: -kernels[k]["total_ms_per_step"])
     dom = ranked[0] if ranked else None
     roofline = None
