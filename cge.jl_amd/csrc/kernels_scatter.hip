@@ -7,7 +7,7 @@
 //     target vertices), sorted by source inside a group, one 32-bit word (u mod 131072) << 15 | (v mod 32768) per edge --
 //     4 bytes instead of the reference's 16 (two Int64), plus the weight (8 bytes) only for a weighted list.  A group is
 //     cut into chunks of <= 16384 edges.
-//   * the community table is uint16 (C <= 1024 on this path), padded to a multiple of 32768 entries.
+//   * the community table is uint16 (C <= 2048 on this path), padded to a multiple of 32768 entries.
 // Pass 1 (edge_pass_kernel, one 1024-thread workgroup per chunk, two per CU): the 64 KB slice of the community table that
 //   the chunk's TARGETS can touch is copied into LDS (coalesced 16-byte loads); the communities of the SOURCES come from
 //   memory with ascending addresses (the chunk is sorted by source: a wave's loads fall into a few cache lines).  Intra-
@@ -22,7 +22,7 @@
 // atomics this replaces.
 #include "common.hpp"
 
-#define EB_MAXC 1024
+#define EB_MAXC 2048
 #define EB_NONE 0xFFFFFFFFu
 #define EB_RBATCH 256 // chunks per workgroup of the row reduction (one per thread)
 #define EB_RKEYS 16   // keys a thread of the row reduction requests at once
@@ -59,11 +59,11 @@ void k_sort_pairs_u32(cge_ctx *c, const unsigned *keys_in, unsigned *keys_out, c
                       int bits); // kernels_sort.hip (rocPRIM)
 
 // Build the blocked copy of the resident edge list.  Returns false when this path does not apply (the caller then uses
-// the gather + atomics kernel): more than 2^21 vertices or an edge count beyond int32.
+// the gather + atomics kernel): more than 32768 tiles (n > ~1.4e7) or an edge count beyond int32.
 bool k_build_blocked_edges(cge_ctx *c) {
     const i64 n = c->n, m = c->m;
     const i64 nbu = (n + (1 << EB_UBITS) - 1) >> EB_UBITS, nbv = (n + (1 << EB_VBITS) - 1) >> EB_VBITS;
-    if (nbu > 16 || nbv > 64 || m <= 0 || m >= (1LL << 31)) return false;
+    if (nbu * nbv > 32768 || m <= 0 || m >= (1LL << 31)) return false; // the sort key (tile, u mod 131072) has 32 bits
     hipStream_t st = c->stream;
     const i64 T = nbu * nbv;
     // 16 edges per thread: with 20 or 24 the edge pass no longer fits 64 registers (two workgroups per CU) and spills
@@ -371,5 +371,6 @@ void k_edge_scatter_blocked_init() {}
 
 bool k_edge_scatter_blocked_applies(const cge_ctx *c, i64 C) {
     static const bool off = getenv("CGE_SCATTER_GATHER") != nullptr; // A/B switch: force the gather + atomics kernel
-    return !off && c->comm16.p && C >= 1 && C <= EB_MAXC && c->n <= (i64)16 * (1 << EB_UBITS) && c->m < (1LL << 31);
+    return !off && c->comm16.p && C >= 1 && C <= EB_MAXC && c->m < (1LL << 31) &&
+           ((c->n + (1 << EB_UBITS) - 1) >> EB_UBITS) * ((c->n + (1 << EB_VBITS) - 1) >> EB_VBITS) <= 32768; // n <= ~1.4e7
 }

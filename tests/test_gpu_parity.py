@@ -758,11 +758,11 @@ def test_edge_scatter_blocked_two_pass_form(ctx, directed, weighted):
     """The score path's form of the per-edge cluster-pair scatter (kernels_scatter.hip: blocked edge list, community
     slices in LDS, off-diagonal pairs bucketed by row, no global atomics) against numpy: several vertex blocks, chunks
     that split a tile, unit and dyadic weights, packed (undirected) and C x C (directed) outputs; repeated calls reuse the
-    blocked copy; a graph with more communities than the path holds falls back to the gather kernel with the same result."""
+    blocked copy; 1500 communities (config 5) still take this path, 2500 fall back to the gather kernel with the same result."""
     from cge.jl_amd import synth
 
     rng = np.random.default_rng(11)
-    for n, m, C in ((150_000, 1_600_000, 37), (40_000, 300_000, 1500), (3_000, 20_000, 5)):
+    for n, m, C in ((150_000, 1_600_000, 37), (40_000, 300_000, 1500), (60_000, 400_000, 2500), (3_000, 20_000, 5)):
         g = synth.abcd_like(n, m, C, 4, seed=23, directed=directed)
         w = (rng.integers(1, 9, size=g["m"]) / 4.0) if weighted else g["eweights"]
         ctx.set_graph(g["edges"], w, g["n"])
@@ -966,6 +966,51 @@ def test_exact_mode_beyond_the_reference_limit(ctx):
     assert 0.0 < r1[1] < np.log(2.0) and r1[2] == 0.0 and r1[3] == 0.0 and 0.0 <= r1[5] <= 1.0
     assert r1[6] == pytest.approx(1.96 * np.sqrt(r1[5] * (1.0 - r1[5]) / 10000), rel=1e-12)
     assert ctx.get_stat("fit_persistent_alphas") == 0 and it1 > 100  # 20 000 vertices: one launch per iteration
+
+
+def test_exact_mode_thirty_thousand_vertices_against_oracle_fixture(ctx):
+    """`--force-exact` at 30 000 vertices -- three times the reference's switch to landmarks --
+    against the CPU oracle's full run (tests/golden/oracle_exact30k.npz, an hour of one core; the test is skipped while
+    that file has not been generated): iteration counts, per-alpha traces, the 7-vector."""
+    import zlib
+
+    import cge.jl_amd as cg
+    from cge.jl_amd import synth
+    from conftest import random_samples
+
+    path = os.path.join(GOLDEN, "oracle_exact30k.npz")
+    if not os.path.exists(path):
+        pytest.skip("oracle_exact30k.npz not generated (tests/golden/make_oracle_fixture_exact30k.py)")
+    fx = np.load(path)
+    n = int(fx["n"])
+    g = synth.abcd_like(n, 10 * n, 40, 16, seed=7)
+    assert g["m"] == int(fx["m"]) and zlib.crc32(np.ascontiguousarray(g["edges"]).tobytes()) == int(fx["edges_crc"])
+    smp = random_samples(np.random.default_rng(7), g["m"], n, 10000)
+    empty = ([], [], np.zeros((0, 2), np.int64), [], np.zeros((0, 0)))
+    res, tr = cg.wGCL(g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False,
+                      samples=smp, trace=True, ctx=ctx)
+    assert tr["iters"] == fx["iters"].tolist()
+    assert np.allclose(tr["div"], fx["div"], rtol=RTOL, equal_nan=True)
+    assert np.allclose(tr["auc"], fx["auc"], rtol=RTOL, atol=1e-12, equal_nan=True)
+    assert res[0] == fx["result"][0] and res[4] == fx["result"][4] and np.allclose(res, fx["result"], rtol=RTOL, atol=1e-12)
+
+
+def test_exact_mode_sixty_thousand_vertices(ctx):
+    """Exact mode at 60 000 vertices (D and GD are 28.8 GB each on the device; nothing O(n^2) on the host): the sweep's
+    invariants.  `profiles/r02_exact_mode_probe.txt` records the same at 100 000 vertices (160 GB, 33 s per score)."""
+    from cge.jl_amd import synth
+
+    n = 60000
+    g = synth.abcd_like(n, 10 * n, 80, 16, seed=7)
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    r = ctx.score([], -1, seed=3, auc_samples=10000)
+    tr = ctx.last_trace
+    assert len(r) == 7 and np.all(np.isfinite(r)) and tr["n_alpha"] <= 40 and all(it >= 1 for it in tr["iters"])
+    assert 0.25 <= r[0] <= 10.0 and 0.25 <= r[4] <= 10.0 and 0.0 < r[1] < np.log(2.0) and 0.0 <= r[5] <= 1.0
+    best = int(np.nanargmin(tr["div"]))
+    assert r[1] == tr["div"][best] and r[0] == 0.25 * (best + 1)
+    assert r[6] == pytest.approx(1.96 * np.sqrt(r[5] * (1.0 - r[5]) / 10000), rel=1e-12)
+    assert ctx.get_stat("fit_persistent_alphas") == 0  # one launch per iteration at this size
 
 
 def test_headline_size_properties(ctx):
