@@ -15,4 +15,8 @@ def __getattr__(name):  # lazy: importing the package must not need the GPU libr
         from . import api
 
         return getattr(api, name)
+    if name == "louvain_clust":  # src/CGE.jl:21
+        from .clustering import louvain_clust
+
+        return louvain_clust
     raise AttributeError(name)

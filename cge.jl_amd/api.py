@@ -416,6 +416,13 @@ class Context:
         self._check(self.L.cge_rccl_selftest(self.h, _p(a), C.c_int64(a.size), C.c_int(op)))
         return a
 
+    def louvain(self):
+        """Level-1 Louvain communities of the resident graph: (comm 0-based (n,), n_comm, modularity, rounds)."""
+        out = np.zeros(self.n, dtype=np.int64)
+        nc, q, rounds = C.c_int64(), C.c_double(), C.c_int64()
+        self._check(self.L.cge_louvain(self.h, _p(out), C.byref(nc), C.byref(q), C.byref(rounds)))
+        return out, nc.value, q.value, rounds.value
+
     def set_option(self, key, value):
         self._check(self.L.cge_set_option(self.h, key.encode(), C.c_int64(int(value))))
 

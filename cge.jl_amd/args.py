@@ -97,11 +97,17 @@ def parseargs(argv=None, exit_on_error=True):
         # additions (np.add.at is sequential), so non-dyadic weights round as in the reference
         np.add.at(vweight, np.ascontiguousarray(edges).ravel() - 1, np.repeat(eweights, 2))
 
-        if "-c" not in argv:
-            raise AssertionError(
-                "communities file (-c) is required: Louvain clustering (src/clustering.jl) is outside the hot path"
-            )
-        comm_raw, _ = _readdlm(_flag_value(argv, "-c"))
+        if "-c" in argv:
+            fn_comm = _flag_value(argv, "-c")
+        else:  # :115-121: no -c => Louvain communities (level 1) of the graph itself, written to <edgelist>.ecg
+            from .clustering import louvain_clust
+
+            if no_cols == 2:
+                louvain_clust(float(v_min), fn_edges)
+            else:
+                louvain_clust(fn_edges, edges, eweights)
+            fn_comm = fn_edges + ".ecg"
+        comm_raw, _ = _readdlm(fn_comm)
         if not np.all(comm_raw == np.floor(comm_raw)):
             raise AssertionError("Communities file must hold integers")
         comm = comm_raw.astype(np.int64)

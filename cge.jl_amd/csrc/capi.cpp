@@ -993,6 +993,16 @@ int cge_edge_scatter(cge_ctx *c, const int64_t *v_to_l, int64_t N, int64_t C, in
     CGE_CATCH(c)
 }
 
+// ---- louvain_clust (src/clustering.jl:14-68): level-1 communities of the resident graph -------------------------------
+int cge_louvain(cge_ctx *c, int64_t *comm_out, int64_t *n_comm, double *modularity, int64_t *rounds) {
+    if (!c || !comm_out) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    if (!c->src.p || c->m <= 0 || c->n <= 0) CGE_THROW(CGE_E_ARG, "louvain: no resident graph (cge_set_graph)");
+    k_louvain_level1(c, comm_out, n_comm, modularity, rounds);
+    CGE_CATCH(c)
+}
+
 // ---- options / statistics ---------------------------------------------------------------------------
 int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return CGE_E_ARG;

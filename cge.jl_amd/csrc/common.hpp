@@ -470,6 +470,7 @@ void k_edge_degrees(cge_ctx *c, const i32 *src, const i32 *dst, const double *w,
                     double *deg_in, i32 *star);
 void k_wedge_degrees(cge_ctx *c, const double *wedges, i64 N, double *deg_out, double *deg_in, i32 *star);
 void k_compact_count(cge_ctx *c, const double *wedges, i64 N, int directed, i64 *count);
+void k_louvain_level1(cge_ctx *c, i64 *comm_out_host, i64 *n_comm, double *quality, i64 *rounds); // kernels_louvain.hip
 // distances
 void k_dist_matrix(cge_ctx *c, const double *emb, const double *diag, i64 N, i64 d, double *D);
 void k_minmax_upper(cge_ctx *c, const double *D, i64 N, double *lo_hi);

@@ -187,6 +187,13 @@ typedef struct {
 } cge_score_args;
 int cge_score(cge_ctx *ctx, const cge_score_args *args, double out[7], int *out_len, cge_trace *trace);
 
+/* ---- louvain_clust(): src/clustering.jl:14-68 (called by parseargs when `-c` is omitted, src/auxilary.jl:115-121) ----
+ * The communities the reference writes to <file>.ecg: LEVEL 1 of Louvain (`hierarchy -l 1`: the partition after the first
+ * pass of local moving), here computed on the resident graph (cge_set_graph; weights honoured) by synchronous rounds on
+ * the device.  comm_out[v] (v = 0 .. n-1) in 0 .. *n_comm-1; *modularity = modularity of that partition.  The reference
+ * visits the vertices in an unseeded random order, so partitions are comparable in quality, not in identity.            */
+int cge_louvain(cge_ctx *ctx, int64_t *comm_out, int64_t *n_comm, double *modularity, int64_t *rounds);
+
 /* ---- small helpers (same arithmetic as the reference helpers, host side) -------------------- */
 int64_t cge_idx(int64_t n, int64_t i, int64_t j);                                   /* src/auxilary.jl:57-59 */
 int cge_js(cge_ctx *ctx, const double *vC, const double *vB, int64_t len, const uint8_t *vI, int internal,

@@ -1138,3 +1138,91 @@ int orc_eig_top(const double *A, i64 d, double *v) {
     free(B);
     return rc;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Louvain, level 1 -- what `louvain_clust` (src/clustering.jl:14-68) writes to <file>.ecg.
+ * The reference shells out to three executables of louvain_jll (no version pin: Project.toml has no [compat]; the
+ * package wraps the "generic Louvain" code of Blondel, Guillaume, Lambiotte, Lefebvre, v0.3): `convert` (edge list ->
+ * binary graph, every edge in both directions), `louvain -l -1 -q 0` (all levels, modularity), `hierarchy -l 1` (the
+ * partition after the FIRST pass of local moving).  This is a restatement of that published algorithm (one_level() of
+ * louvain.cpp): nodes in turn are taken out of their community and put into the neighbouring community of largest gain
+ * dnc - tot[c] * k / m2 (own community first, so ties stay), passes repeat while nodes move and the modularity improves
+ * by more than 1e-6; communities are then renumbered 0.. in ascending order of their old id.  UNPINNED: the executable
+ * visits the nodes in a rand()-shuffled order seeded from time and pid, so no two runs of the reference agree; here the
+ * order is 0..n-1.  edges: m x 2 column-major, 1-based; weights may be NULL (unit).  comm_out: n entries, 0-based.   */
+int orc_louvain_level1(const i64 *edges, const double *weights, i64 m, i64 n, i64 *comm_out, i64 *n_comm, double *quality) {
+    i64 *deg = (i64 *)calloc((size_t)n + 1, sizeof(i64));
+    for (i64 e = 0; e < m; e++) {
+        const i64 u = edges[e] - 1, v = edges[e + m] - 1;
+        deg[u + 1]++;
+        if (u != v) deg[v + 1]++;
+    }
+    for (i64 i = 0; i < n; i++) deg[i + 1] += deg[i];
+    i64 *adj = (i64 *)malloc(sizeof(i64) * (size_t)(deg[n] > 0 ? deg[n] : 1));
+    double *aw = (double *)malloc(sizeof(double) * (size_t)(deg[n] > 0 ? deg[n] : 1));
+    i64 *cur = (i64 *)malloc(sizeof(i64) * (size_t)n);
+    for (i64 i = 0; i < n; i++) cur[i] = deg[i];
+    for (i64 e = 0; e < m; e++) {
+        const i64 u = edges[e] - 1, v = edges[e + m] - 1;
+        const double w = weights ? weights[e] : 1.0;
+        adj[cur[u]] = v; aw[cur[u]++] = w;
+        if (u != v) { adj[cur[v]] = u; aw[cur[v]++] = w; }
+    }
+    double *k = (double *)calloc((size_t)n, sizeof(double)), *tot = (double *)malloc(sizeof(double) * (size_t)n);
+    double *in = (double *)calloc((size_t)n, sizeof(double)), *nw = (double *)malloc(sizeof(double) * (size_t)n);
+    i64 *n2c = (i64 *)malloc(sizeof(i64) * (size_t)n), *npos = (i64 *)malloc(sizeof(i64) * (size_t)n);
+    double m2 = 0.0;
+    for (i64 i = 0; i < n; i++) {
+        for (i64 q = deg[i]; q < deg[i + 1]; q++) { k[i] += aw[q]; if (adj[q] == i) in[i] += aw[q]; }
+        m2 += k[i];
+        tot[i] = k[i];
+        n2c[i] = i;
+        nw[i] = -1.0;
+    }
+    double cur_q = 0.0, new_q = 0.0;
+    for (i64 c = 0; c < n; c++) if (m2 > 0 && tot[c] > 0) new_q += in[c] / m2 - (tot[c] / m2) * (tot[c] / m2);
+    i64 moves;
+    do {
+        cur_q = new_q;
+        moves = 0;
+        for (i64 node = 0; node < n; node++) {
+            const i64 own = n2c[node];
+            i64 nlast = 1;
+            npos[0] = own;
+            nw[own] = 0.0;
+            double self = 0.0;
+            for (i64 q = deg[node]; q < deg[node + 1]; q++) {
+                const i64 v = adj[q];
+                if (v == node) { self += aw[q]; continue; }
+                const i64 c = n2c[v];
+                if (nw[c] == -1.0) { nw[c] = 0.0; npos[nlast++] = c; }
+                nw[c] += aw[q];
+            }
+            tot[own] -= k[node];
+            in[own] -= 2.0 * nw[own] + self;
+            i64 best = own;
+            double best_w = nw[own], best_inc = m2 > 0 ? nw[own] - tot[own] * k[node] / m2 : 0.0;
+            for (i64 q = 1; q < nlast; q++) {
+                const i64 c = npos[q];
+                const double inc = m2 > 0 ? nw[c] - tot[c] * k[node] / m2 : 0.0;
+                if (inc > best_inc) { best = c; best_w = nw[c]; best_inc = inc; }
+            }
+            tot[best] += k[node];
+            in[best] += 2.0 * best_w + self;
+            n2c[node] = best;
+            if (best != own) moves++;
+            for (i64 q = 0; q < nlast; q++) nw[npos[q]] = -1.0;
+        }
+        new_q = 0.0;
+        for (i64 c = 0; c < n; c++) if (m2 > 0 && tot[c] > 0) new_q += in[c] / m2 - (tot[c] / m2) * (tot[c] / m2);
+    } while (moves > 0 && new_q - cur_q > 1e-6);
+    for (i64 i = 0; i < n; i++) npos[i] = -1;
+    for (i64 i = 0; i < n; i++) npos[n2c[i]] = 0;
+    i64 nc = 0;
+    for (i64 c = 0; c < n; c++) if (npos[c] == 0) npos[c] = nc++;
+    for (i64 i = 0; i < n; i++) comm_out[i] = npos[n2c[i]];
+    if (n_comm) *n_comm = nc;
+    if (quality) *quality = new_q;
+    free(deg); free(adj); free(aw); free(cur); free(k); free(tot); free(in); free(nw); free(n2c); free(npos);
+    return ORC_OK;
+}

@@ -273,3 +273,17 @@ def wGCL_directed(edges, eweights, comm, embed, distances, vweights, init_vweigh
     """src/divergence.jl:282-561.  `samples` = (pos_idx, neg_i, neg_j[, pos_idx2])."""
     return _wgcl_common(lib().orc_wgcl_directed, edges, eweights, comm, embed, distances, vweights, init_vweights,
                         v_to_l, init_edges, init_eweights, init_embed, split, samples, trace, True)
+
+
+def louvain_level1(edges, weights, n):
+    """Level 1 of Louvain (what src/clustering.jl:14-68 writes to <file>.ecg), nodes visited in the order 0..n-1 (the
+    reference's executable shuffles them with an unseeded rand()).  Returns (comm 0-based (n,), n_comm, modularity)."""
+    ed, edf = _i(edges)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    out = np.zeros(n, dtype=np.int64)
+    nc, q = C.c_int64(), C.c_double()
+    rc = lib().orc_louvain_level1(_ptr(edf), None if w is None else _ptr(w), C.c_int64(ed.shape[0]), C.c_int64(n), _ptr(out),
+                                  C.byref(nc), C.byref(q))
+    if rc:
+        raise OracleError(rc)
+    return out, nc.value, q.value

@@ -144,3 +144,25 @@ def test_known_diameter_hook_changes_nothing_else(example10k):
         assert np.array_equal(other[:4], base[:4]) and not np.array_equal(other[4:], base[4:])
     finally:
         orc.set_known_diameter(0.0)
+
+
+def test_louvain_level1_restatement_against_networkx(test115):
+    """oracle.louvain_level1 (the published one_level() of generic Louvain, nodes in natural order) on the reference's
+    115-vertex fixture and on a graph with planted communities: a valid partition whose modularity, recomputed by networkx,
+    is the value the oracle reports, and which is as good as networkx's own first Louvain level."""
+    nx = pytest.importorskip("networkx")
+    from cge.jl_amd import synth
+
+    for edges, n, truth in ((test115["edges"], len(test115["vweights"]), None),) + tuple(
+            (g["edges"], g["n"], g["comm"][:, 0]) for g in (synth.abcd_like(5000, 40000, 12, 4, seed=3),)):
+        comm, nc, q = orc.louvain_level1(edges, None, n)
+        assert comm.min() == 0 and comm.max() == nc - 1 and len(np.unique(comm)) == nc
+        G = nx.Graph()
+        G.add_nodes_from(range(n))
+        G.add_edges_from((np.asarray(edges) - 1).tolist())
+        parts = [set(np.flatnonzero(comm == c).tolist()) for c in range(nc)]
+        assert nx.community.modularity(G, parts) == pytest.approx(q, abs=1e-12)
+        lv1 = next(iter(nx.community.louvain_partitions(G, seed=1)))
+        assert q >= nx.community.modularity(G, lv1) - 0.05
+        if truth is not None:  # found communities lie inside planted ones
+            assert sum(np.bincount(truth[list(p)]).max() for p in parts) / n > 0.98
