@@ -335,18 +335,22 @@ __global__ __launch_bounds__(256, 2) void pcent_f32_kernel(const float *__restri
                 rb1 = *reinterpret_cast<const float4 *>(qb + 4);
             }
             const float *As = ldsf + (size_t)s * stage, *Bs = As + PF_BK * 128;
+            float af[PF_BK / 2][2], bf[PF_BK / 2][2]; // all fragments of the chunk first: the 32 MFMAs then issue back to back
 #pragma unroll
             for (int ks = 0; ks < PF_BK / 2; ks++) {
-                float af[2], bf[2];
 #pragma unroll
-                for (int a = 0; a < 2; a++) af[a] = As[(2 * ks + lh) * 128 + wr * 64 + a * 32 + l32];
+                for (int a = 0; a < 2; a++) af[ks][a] = As[(2 * ks + lh) * 128 + wr * 64 + a * 32 + l32];
 #pragma unroll
-                for (int b = 0; b < 2; b++) bf[b] = Bs[(2 * ks + lh) * 128 + wc * 64 + b * 32 + l32];
+                for (int b = 0; b < 2; b++) bf[ks][b] = Bs[(2 * ks + lh) * 128 + wc * 64 + b * 32 + l32];
+            }
+            __builtin_amdgcn_sched_barrier(0); // keep the reads ahead of the MFMA block (the scheduler sinks them otherwise)
+#pragma unroll
+            for (int ks = 0; ks < PF_BK / 2; ks++)
 #pragma unroll
                 for (int a = 0; a < 2; a++)
 #pragma unroll
-                    for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-            }
+                    for (int b = 0; b < 2; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
             if (more) {
                 float *An = ldsf + (size_t)(s ^ 1) * stage + krow * 128 + seg, *Bn = An + PF_BK * 128;
                 *reinterpret_cast<float4 *>(An) = ra0;
@@ -386,6 +390,106 @@ __global__ __launch_bounds__(256, 2) void pcent_f32_kernel(const float *__restri
                     v = fmax(v, __shfl_xor(v, 32));
                     if (lh == 0) G[(r0 >> 4) * ldm + col] = fmax(v + mn, 0.0);
                 }
+        }
+    }
+}
+
+// The same for K = dpad <= 128 with the 128-row tile of X RESIDENT in LDS (64 KB): a workgroup takes a row tile, loads it
+// once and sweeps all column tiles of the reference points against it, so X is read from memory exactly once (the form
+// above re-reads a row tile once per column tile: 4x at C = 500); only the small reference operand is streamed (from L2).
+__global__ __launch_bounds__(256, 2) void pcent_f32_rowres_kernel(const float *__restrict__ Xs, const double *__restrict__ rns,
+                                                                  i64 lds_rows, const float *__restrict__ Ms,
+                                                                  const double *__restrict__ mnorm, i64 ldm, i64 N, i64 dpad,
+                                                                  double *__restrict__ G, i64 I0, i64 I1, double e1) {
+    extern __shared__ __attribute__((aligned(16))) float ldsf[];
+    float *Afull = ldsf;                      // [dpad][128]
+    float *Bst = ldsf + (size_t)dpad * 128;   // [2][PF_BK][128]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1, l32 = lane & 31, lh = lane >> 5;
+    const int krow = tid >> 4, seg = (tid & 15) * 8;
+    const i64 nTJ = ldm / 128, nchunk = dpad / PF_BK, nstep = nTJ * nchunk; // (column tile, k chunk) pairs of a row tile
+    for (i64 I = I0 + blockIdx.x; I < I1; I += gridDim.x) {
+        const i64 i0 = I * 128;
+        __syncthreads(); // the previous row tile's readers are done
+        for (i64 kr = krow; kr < dpad; kr += 16) { // the whole row tile, all k
+            const float *pa = Xs + kr * lds_rows + i0 + seg;
+            const float4 v0 = *reinterpret_cast<const float4 *>(pa), v1 = *reinterpret_cast<const float4 *>(pa + 4);
+            *reinterpret_cast<float4 *>(Afull + kr * 128 + seg) = v0;
+            *reinterpret_cast<float4 *>(Afull + kr * 128 + seg + 4) = v1;
+        }
+        float4 rb0, rb1;
+        {
+            const float *pb = Ms + (i64)krow * ldm + seg; // step 0: column tile 0, chunk 0
+            rb0 = *reinterpret_cast<const float4 *>(pb);
+            rb1 = *reinterpret_cast<const float4 *>(pb + 4);
+            *reinterpret_cast<float4 *>(Bst + krow * 128 + seg) = rb0;
+            *reinterpret_cast<float4 *>(Bst + krow * 128 + seg + 4) = rb1;
+        }
+        __syncthreads();
+        f16v acc[2][2];
+        for (i64 stp = 0; stp < nstep; stp++) {
+            const i64 J = stp / nchunk, kc = stp - J * nchunk;
+            const int s = (int)(stp & 1);
+            if (kc == 0) {
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+            }
+            const bool more = stp + 1 < nstep;
+            if (more) { // the next (column tile, chunk) of the reference operand lands while the MFMAs run
+                const i64 Jn = (stp + 1) / nchunk, kn = (stp + 1) - Jn * nchunk;
+                const float *qb = Ms + (kn * PF_BK + krow) * ldm + Jn * 128 + seg;
+                rb0 = *reinterpret_cast<const float4 *>(qb);
+                rb1 = *reinterpret_cast<const float4 *>(qb + 4);
+            }
+            const float *As = Afull + (size_t)kc * PF_BK * 128, *Bs = Bst + (size_t)s * PF_BK * 128;
+            float af[PF_BK / 2][2], bf[PF_BK / 2][2]; // all fragments of the chunk first: the 32 MFMAs then issue back to back
+#pragma unroll
+            for (int ks = 0; ks < PF_BK / 2; ks++) {
+#pragma unroll
+                for (int a = 0; a < 2; a++) af[ks][a] = As[(2 * ks + lh) * 128 + wr * 64 + a * 32 + l32];
+#pragma unroll
+                for (int b = 0; b < 2; b++) bf[ks][b] = Bs[(2 * ks + lh) * 128 + wc * 64 + b * 32 + l32];
+            }
+            __builtin_amdgcn_sched_barrier(0); // keep the reads ahead of the MFMA block (the scheduler sinks them otherwise)
+#pragma unroll
+            for (int ks = 0; ks < PF_BK / 2; ks++)
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
+            if (more) {
+                float *Bn = Bst + (size_t)(s ^ 1) * PF_BK * 128 + krow * 128 + seg;
+                *reinterpret_cast<float4 *>(Bn) = rb0;
+                *reinterpret_cast<float4 *>(Bn + 4) = rb1;
+            }
+            if (kc == nchunk - 1) { // epilogue of column tile J (see pcent_f32_kernel)
+                const i64 j0 = J * 128;
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const i64 col = j0 + wc * 64 + b * 32 + l32;
+                    const double mn = mnorm[col] * e1;
+#pragma unroll
+                    for (int a = 0; a < 2; a++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const i64 r0 = i0 + wr * 64 + a * 32 + 16 * h;
+                            double v = -1e300;
+#pragma unroll
+                            for (int gg = 0; gg < 2; gg++)
+#pragma unroll
+                                for (int j = 0; j < 4; j++)
+                                    v = fmax(v, rns[r0 + 8 * gg + 4 * lh + j] * e1 - 2.0 * (double)acc[a][b][4 * (2 * h + gg) + j]);
+                            v = fmax(v, __shfl_xor(v, 32));
+                            if (lh == 0) G[(r0 >> 4) * ldm + col] = fmax(v + mn, 0.0);
+                        }
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -488,7 +592,14 @@ void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows,
     const i64 nTI = lds_rows / 128, I0 = nTI * part / nparts, I1 = nTI * (part + 1) / nparts;
     const i64 ntiles = (I1 - I0) * (ldm / 128);
     const double e1 = 1.0 + 1.01 * (double)(dpad + 2) * 5.9604644775390625e-08; // 1 + e, e = 1.01 (K + 2) 2^-24
-    if (ntiles > 0)
+    static const bool no_rowres = getenv("CGE_PCENT_NO_ROWRES") != nullptr; // A/B switch
+    if (ntiles > 0 && dpad <= 128 && !no_rowres) { // the row tile of X stays in LDS: X is read once
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void *)pcent_f32_rowres_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        const size_t lds = ((size_t)dpad * 128 + 2 * PF_BK * 128) * sizeof(float);
+        hipLaunchKernelGGL(pcent_f32_rowres_kernel, dim3((unsigned)std::min<i64>(I1 - I0, 512)), dim3(256), lds, c->stream, Xs32, rns,
+                           lds_rows, Ms32, mnorm, ldm, N, dpad, c->pc_groups.p, I0, I1, e1);
+    } else if (ntiles > 0)
         hipLaunchKernelGGL(pcent_f32_kernel, dim3((unsigned)std::min<i64>(ntiles, 2048)), dim3(256), PF_LDS_BYTES, c->stream,
                            Xs32, rns, lds_rows, Ms32, mnorm, ldm, N, dpad, c->pc_groups.p, I0, I1, e1);
     hipLaunchKernelGGL(pcent_groups_kernel, dim3((unsigned)n_land), dim3(256), 0, c->stream, c->pc_groups.p, soff, ldm, N, P);
