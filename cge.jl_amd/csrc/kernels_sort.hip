@@ -7,6 +7,22 @@
 
 #include <rocprim/rocprim.hpp>
 
+// rocPRIM hands any sort of <= 1 Mi items to its merge sort, which compares whole keys (begin/end bit ignored) in ~log2(n/1024)
+// small launches.  For the 64-bit z keys that is the faster choice (8 onesweep passes otherwise); the few-bit key sorts of
+// this path (task ids, tile keys, community ids) are one or two onesweep passes instead: headline landmarks phase 17.4 ->
+// 16.4 ms.  CGE_SORT_RADIX (bit 0: the few-bit sorts, bit 1: the z sort; default 1) is the A/B switch.
+using RadixOnly = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+static int sort_radix_mask() {
+    static const int v = getenv("CGE_SORT_RADIX") ? atoi(getenv("CGE_SORT_RADIX")) : 1;
+    return v;
+}
+template <class K, class V>
+static hipError_t radix_pairs(void *tmp, size_t &bytes, const K *ki, K *ko, const V *vi, V *vo, size_t n, int b0, int b1,
+                              hipStream_t st) {
+    if (sort_radix_mask() & (sizeof(K) > 4 ? 2 : 1))
+        return rocprim::radix_sort_pairs<RadixOnly>(tmp, bytes, ki, ko, vi, vo, n, b0, b1, st);
+    return rocprim::radix_sort_pairs(tmp, bytes, ki, ko, vi, vo, n, b0, b1, st);
+}
 __global__ void iota_local_kernel(const i32 *__restrict__ row_task, const i32 *__restrict__ task_row_off, i64 R,
                                   i32 *__restrict__ idx) {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,19 +79,19 @@ void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 
         c->sort_k32b.ensure(R);
         hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, c->stream, c->sort_idx.p, R);
         size_t bytes = 0;
-        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, z, zs, c->sort_idx.p, c->sort_idx2.p, (size_t)R, 0, 64, c->stream));
+        HIP_CHECK(radix_pairs(nullptr, bytes, z, zs, c->sort_idx.p, c->sort_idx2.p, (size_t)R, 0, 64, c->stream));
         c->sort_tmp.ensure(bytes);
-        HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, z, zs, c->sort_idx.p, c->sort_idx2.p, (size_t)R, 0, 64,
+        HIP_CHECK(radix_pairs(c->sort_tmp.p, bytes, z, zs, c->sort_idx.p, c->sort_idx2.p, (size_t)R, 0, 64,
                                             c->stream));
         hipLaunchKernelGGL(gather_task_keys_kernel, dim3(nb), dim3(256), 0, c->stream, c->sort_idx2.p, row_task, R,
                            (unsigned *)c->sort_keys32.p);
         int bits = 1;
         while (((i64)1 << bits) < T) bits++;
         bytes = 0;
-        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned *)c->sort_keys32.p, (unsigned *)c->sort_k32b.p,
+        HIP_CHECK(radix_pairs(nullptr, bytes, (const unsigned *)c->sort_keys32.p, (unsigned *)c->sort_k32b.p,
                                             c->sort_idx2.p, c->sort_idx.p, (size_t)R, 0, bits, c->stream));
         c->sort_tmp.ensure(bytes);
-        HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, (const unsigned *)c->sort_keys32.p,
+        HIP_CHECK(radix_pairs(c->sort_tmp.p, bytes, (const unsigned *)c->sort_keys32.p,
                                             (unsigned *)c->sort_k32b.p, c->sort_idx2.p, c->sort_idx.p, (size_t)R, 0, bits,
                                             c->stream));
         hipLaunchKernelGGL(finish_two_pass_kernel, dim3(nb), dim3(256), 0, c->stream, c->sort_idx.p, z, row_task,
@@ -98,9 +114,9 @@ void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 
 void k_sort_pairs_u32(cge_ctx *c, const unsigned *keys_in, unsigned *keys_out, const i32 *vals_in, i32 *vals_out, i64 n,
                       int bits) {
     size_t bytes = 0;
-    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits, c->stream));
+    HIP_CHECK(radix_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits, c->stream));
     c->sort_tmp.ensure(bytes);
-    HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits,
+    HIP_CHECK(radix_pairs(c->sort_tmp.p, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits,
                                         c->stream));
 }
 
@@ -237,10 +253,10 @@ i64 k_groups_to_index(cge_ctx *c, const i32 *arena, const i32 *goff, const i32 *
     int bits = 1;
     while (((i64)1 << bits) < N) bits++;
     size_t bytes = 0;
-    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned *)v2l, (unsigned *)c->sort_keys32.p, c->sort_idx.p, mem,
+    HIP_CHECK(radix_pairs(nullptr, bytes, (const unsigned *)v2l, (unsigned *)c->sort_keys32.p, c->sort_idx.p, mem,
                                         (size_t)n, 0, bits, st));
     c->sort_tmp.ensure(bytes);
-    HIP_CHECK(rocprim::radix_sort_pairs(c->sort_tmp.p, bytes, (const unsigned *)v2l, (unsigned *)c->sort_keys32.p,
+    HIP_CHECK(radix_pairs(c->sort_tmp.p, bytes, (const unsigned *)v2l, (unsigned *)c->sort_keys32.p,
                                         c->sort_idx.p, mem, (size_t)n, 0, bits, st));
     i32 bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, c->sort_cnt.p, sizeof(i32), hipMemcpyDeviceToHost, st));
