@@ -2010,10 +2010,354 @@ __global__ __launch_bounds__(256) void group_eig_wide_kernel(double *__restrict_
     const double sg = ((V[bi] < 0.0) ? -1.0 : 1.0) / nrm;
     for (int i = tid; i < d; i += 256) out[i] = V[i] * sg;
 }
+// ---- 128 < d <= 512, panel form.  The kernel above sweeps the trailing matrix three times per Householder step (one
+// read for B v, a read and a write for the rank-2 update): 8 d^3 bytes per matrix, 1.07 GB at d = 512, and a batch of a few
+// thousand 2 MB matrices is far beyond any cache -- the solver is bound by HBM.  Here the rank-2 updates of EWP_NB
+// consecutive steps are deferred (LAPACK's dlatrd idea): the panel's reflectors v_s and vectors w_s stay in LDS, column k
+// and B v of the *current* matrix are formed as "stored matrix minus the panel's corrections"
+//     a_k = A0[:,k] - sum_s (v_s w_s[k] + w_s v_s[k]),      B v = A0 v - sum_s (v_s (w_s.v) + w_s (v_s.v)),
+// and the trailing matrix is rewritten once per panel (A0 -= V W^T + W V^T).  Traffic: one read per step + one read and
+// write per panel = (1 + 2/NB)/3 of the above.  Same reflector convention (v[0] = 1, kept in row k right of the
+// sub-diagonal), same Sturm / inverse iteration / back-transformation.  diag[k], beta[k], off[k] are parked in the dead part
+// of column k (A[k][k], A[k+1][k], A[k+2][k]) until the tridiagonal solve collects them.
+// 512 threads: thread t owns index t of every O(d) vector; for the O(d^2) sweeps the threads are re-mapped every step to
+// (column, row slice) over the 64-aligned window of live columns, so that all of them keep loading as the block shrinks.
+constexpr int EWP_NB = 8, EWP_T = 512;
+__device__ __forceinline__ double block_sum_512(double v, double *red8) {
+    v = wave_allsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red8[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red8[0] + red8[1]) + (red8[2] + red8[3])) + ((red8[4] + red8[5]) + (red8[6] + red8[7]));
+}
+__global__ __launch_bounds__(EWP_T, 4) void group_eig_panel_kernel(double *__restrict__ cov, int d, double *__restrict__ vec) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *Vp = sh;                // [NB][d] reflectors of the open panel (zero above their sub-diagonal)
+    double *Wp = Vp + EWP_NB * d;   // [NB][d]
+    double *v = Wp + EWP_NB * d;    // [d] the current reflector; later the iterate of the inverse iteration
+    double *P = v + d;              // [EWP_T] column sums per row slice
+    double *red = P + EWP_T;        // 8
+    double *wpart = red + 8;        // [8 waves][2 NB]
+    double *gh = wpart + 8 * 2 * EWP_NB; // [2 NB]
+    double *misc = gh + 2 * EWP_NB; // 32
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *A = cov + (size_t)blockIdx.x * d * d;
+    double *out = vec + (size_t)blockIdx.x * d;
+    for (int i = tid; i < 2 * EWP_NB * d; i += EWP_T) Vp[i] = 0.0;
+    __syncthreads();
+    int q = 0;
+    for (int k = 0; k + 2 < d; k++) {
+        const int o = k + 1;
+        // window of live columns [jbase, jbase + CW), jbase 64-aligned; NS row slices
+        const int jbase = o & ~63, CW = ((d - jbase) + 63) & ~63, NS = EWP_T / CW;
+        const int sl = tid / CW, j = jbase + (tid - sl * CW);
+        const bool active = sl < NS && j >= o && j < d;
+        // column k of the current matrix (row k of the stored one, it is symmetric)
+        double ai = 0.0;
+        if (tid >= k && tid < d) {
+            ai = A[k * d + tid];
+#pragma unroll
+            for (int s = 0; s < EWP_NB; s++)
+                if (s < q) ai -= Vp[s * d + tid] * Wp[s * d + k] + Wp[s * d + tid] * Vp[s * d + k];
+        }
+        if (tid == k) A[k * d + k] = ai; // diag[k]
+        if (tid == o) misc[0] = ai;
+        const double sigma = block_sum_512((tid > o && tid < d) ? ai * ai : 0.0, red);
+        const double alpha = misc[0];
+        if (sigma == 0.0) { // uniform: no reflection; the panel column stays zero
+            if (tid == 0) { A[o * d + k] = 0.0; A[(o + 1) * d + k] = alpha; }
+        } else {
+            const double mu = sqrt(alpha * alpha + sigma);
+            const double v0 = (alpha <= 0.0) ? alpha - mu : -sigma / (alpha + mu);
+            const double bk = 2.0 * v0 * v0 / (sigma + v0 * v0);
+            const double vi = (tid == o) ? 1.0 : ((tid > o && tid < d) ? ai / v0 : 0.0);
+            if (tid < d) { v[tid] = vi; Vp[q * d + tid] = vi; }
+            if (tid > o && tid < d) A[k * d + tid] = vi; // the reflector stays in row k (v[0] = 1 implicit)
+            if (tid == 0) { A[o * d + k] = bk; A[(o + 1) * d + k] = mu; }
+#pragma unroll
+            for (int s = 0; s < EWP_NB; s++) {
+                if (s < q) { // g_s = w_s . v, h_s = v_s . v
+                    const double g = wave_allsum(tid < d ? Wp[s * d + tid] * vi : 0.0);
+                    const double h = wave_allsum(tid < d ? Vp[s * d + tid] * vi : 0.0);
+                    if (lane == 0) { wpart[wv * 2 * EWP_NB + 2 * s] = g; wpart[wv * 2 * EWP_NB + 2 * s + 1] = h; }
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * q) {
+                double t = wpart[tid];
+                for (int w2 = 1; w2 < 8; w2++) t += wpart[w2 * 2 * EWP_NB + tid];
+                gh[tid] = t;
+            }
+            { // column sums of the stored trailing block times v, per row slice
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                if (active) {
+                    const double *col = A + j;
+                    int i = o + sl;
+                    for (; i + 7 * NS < d; i += 8 * NS) {
+                        double a[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) a[u] = col[(i + u * NS) * d];
+                        s0 = fma(a[0], v[i], s0); s1 = fma(a[1], v[i + NS], s1);
+                        s2 = fma(a[2], v[i + 2 * NS], s2); s3 = fma(a[3], v[i + 3 * NS], s3);
+                        s0 = fma(a[4], v[i + 4 * NS], s0); s1 = fma(a[5], v[i + 5 * NS], s1);
+                        s2 = fma(a[6], v[i + 6 * NS], s2); s3 = fma(a[7], v[i + 7 * NS], s3);
+                    }
+                    for (; i < d; i += NS) s0 = fma(col[i * d], v[i], s0);
+                }
+                P[tid] = (s0 + s1) + (s2 + s3);
+            }
+            __syncthreads();
+            double pi = 0.0;
+            if (tid >= o && tid < d) {
+                const int ci = tid - jbase;
+                double t = P[ci];
+                for (int s2 = 1; s2 < NS; s2++) t += P[s2 * CW + ci];
+#pragma unroll
+                for (int s = 0; s < EWP_NB; s++)
+                    if (s < q) t -= Vp[s * d + tid] * gh[2 * s] + Wp[s * d + tid] * gh[2 * s + 1];
+                pi = bk * t;
+            }
+            const double K = 0.5 * bk * block_sum_512(pi * vi, red);
+            if (tid < d) Wp[q * d + tid] = (tid >= o) ? pi - K * vi : 0.0;
+        }
+        q++;
+        __syncthreads();
+        if (q == EWP_NB || k + 3 >= d) { // close the panel: the stored trailing block catches up
+            if (active) {
+                double vj[EWP_NB], wj[EWP_NB];
+#pragma unroll
+                for (int s = 0; s < EWP_NB; s++) { vj[s] = Vp[s * d + j]; wj[s] = Wp[s * d + j]; }
+                double *col = A + j;
+                int i = o + sl;
+                for (; i + 3 * NS < d; i += 4 * NS) {
+                    double a[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a[u] = col[(i + u * NS) * d];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int iu = i + u * NS;
+#pragma unroll
+                        for (int s = 0; s < EWP_NB; s++) a[u] -= Vp[s * d + iu] * wj[s] + Wp[s * d + iu] * vj[s];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) col[(i + u * NS) * d] = a[u];
+                }
+                for (; i < d; i += NS) {
+                    double a = col[i * d];
+#pragma unroll
+                    for (int s = 0; s < EWP_NB; s++) a -= Vp[s * d + i] * wj[s] + Wp[s * d + i] * vj[s];
+                    col[i * d] = a;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < 2 * EWP_NB * d; i += EWP_T) Vp[i] = 0.0;
+            q = 0;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // the tridiagonal matrix -> LDS (the panel storage is free now)
+    double *diag = sh, *off = diag + d, *beta = off + d, *tri = beta + d; // tri: 4 d
+    unsigned char *swp = reinterpret_cast<unsigned char *>(tri + 4 * d);
+    for (int i = tid; i < d; i += EWP_T) {
+        diag[i] = A[i * d + i];
+        off[i] = (i + 2 < d) ? A[(i + 2) * d + i] : ((i == d - 2) ? A[i * d + i + 1] : 0.0);
+        beta[i] = (i + 2 < d) ? A[(i + 1) * d + i] : 0.0;
+    }
+    __syncthreads();
+    // ---- Gershgorin bounds ---------------------------------------------------------------------------
+    double glo = 1e300, ghi = -1e300, gn = 0.0;
+    for (int i = tid; i < d; i += EWP_T) {
+        const double rad = (i > 0 ? fabs(off[i - 1]) : 0.0) + (i + 1 < d ? fabs(off[i]) : 0.0);
+        glo = fmin(glo, diag[i] - rad);
+        ghi = fmax(ghi, diag[i] + rad);
+        gn = fmax(gn, fabs(diag[i]) + rad);
+    }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        glo = fmin(glo, __shfl_xor(glo, o2));
+        ghi = fmax(ghi, __shfl_xor(ghi, o2));
+        gn = fmax(gn, __shfl_xor(gn, o2));
+    }
+    if (lane == 0) { misc[wv * 3] = glo; misc[wv * 3 + 1] = ghi; misc[wv * 3 + 2] = gn; }
+    __syncthreads();
+    for (int w2 = 0; w2 < 8; w2++) {
+        glo = fmin(glo, misc[w2 * 3]);
+        ghi = fmax(ghi, misc[w2 * 3 + 1]);
+        gn = fmax(gn, misc[w2 * 3 + 2]);
+    }
+    const double tiny = fmax(gn, 2.2250738585072014e-308) * 2.220446049250313e-16;
+    // ---- largest eigenvalue: 64-way multisection on the Sturm count (wave 0) ------------------------------
+    if (tid < 64) {
+        double lo = glo, hi = ghi + tiny;
+        for (int it = 0; it < 64; it++) {
+            const double x = lo + (hi - lo) * ((double)(tid + 1) / 65.0);
+            int cnt = 0;
+            double qq = diag[0] - x;
+            if (qq < 0) cnt++;
+            for (int i = 1; i < d; i++) {
+                if (qq == 0.0) qq = tiny;
+                qq = diag[i] - x - (off[i - 1] * off[i - 1]) * fast_rcp(qq);
+                if (qq < 0) cnt++;
+            }
+            const unsigned long long mask = __ballot(cnt >= d);
+            double nlo, nhi;
+            if (mask == 0ULL) {
+                nlo = __shfl(x, 63);
+                nhi = hi;
+            } else {
+                const int f = __ffsll((long long)mask) - 1;
+                nhi = __shfl(x, f);
+                nlo = (f > 0) ? __shfl(x, f - 1) : lo;
+            }
+            if (!(nhi > nlo) || (nlo == lo && nhi == hi)) break;
+            lo = fmax(lo, nlo);
+            hi = fmin(hi, nhi);
+        }
+        if (tid == 0) red[4] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    // ---- inverse iteration (lane 0 of wave 0 runs the recurrences, the wave the element-wise parts) -----------------
+    if (wv == 0) {
+        const double lam = red[4];
+        double *dl = tri, *dd = tri + d, *du = tri + 2 * d, *du2 = tri + 3 * d;
+        double *y = v;
+        for (int i = lane; i < d; i += 64) {
+            dd[i] = diag[i] - lam;
+            dl[i] = du[i] = (i + 1 < d) ? off[i] : 0.0;
+            du2[i] = 0.0;
+            swp[i] = 0;
+            y[i] = 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) { // LU with partial pivoting of the shifted tridiagonal matrix
+            double di = dd[0], ui = du[0];
+            for (int i = 0; i + 1 < d; i++) {
+                const double li = dl[i], dn = dd[i + 1], un = du[i + 1];
+                if (fabs(di) >= fabs(li)) {
+                    if (di == 0.0) di = tiny;
+                    const double f = li * fast_rcp(di);
+                    dd[i] = di;
+                    dl[i] = f;
+                    du[i] = ui;
+                    di = dn - f * ui;
+                    ui = un;
+                } else {
+                    const double f = di * fast_rcp(li);
+                    dd[i] = li;
+                    dl[i] = f;
+                    du[i] = dn;
+                    di = ui - f * dn;
+                    if (i + 2 < d) du2[i] = un;
+                    ui = -f * un;
+                    swp[i] = 1;
+                }
+            }
+            if (di == 0.0) di = tiny;
+            dd[d - 1] = di;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < d; i += 64) dd[i] = fast_rcp(dd[i]);
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < 3; it++) {
+            if (lane == 0) {
+                double yi = y[0];
+                for (int i = 0; i + 1 < d; i++) {
+                    const bool sw = swp[i] != 0;
+                    const double yn = y[i + 1], li = dl[i];
+                    y[i] = sw ? yn : yi;
+                    yi = sw ? yi - li * yn : yn - li * yi;
+                }
+                double y1 = yi * dd[d - 1];
+                y[d - 1] = y1;
+                double y0 = (y[d - 2] - du[d - 2] * y1) * dd[d - 2];
+                y[d - 2] = y0;
+                for (int i = d - 3; i >= 0; i--) {
+                    const double t = (y[i] - du[i] * y0 - du2[i] * y1) * dd[i];
+                    y[i] = t;
+                    y1 = y0;
+                    y0 = t;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            double amax = 0.0;
+            for (int i = lane; i < d; i += 64) amax = fmax(amax, fabs(y[i]));
+            for (int o2 = 32; o2 > 0; o2 >>= 1) amax = fmax(amax, __shfl_xor(amax, o2));
+            if (!(amax > 0.0) || !(amax < 1e300)) {
+                for (int i = lane; i < d; i += 64) y[i] = (i == 0) ? 1.0 : 0.0;
+                __builtin_amdgcn_wave_barrier();
+                break;
+            }
+            const double ra = 1.0 / amax;
+            double part = 0.0;
+            for (int i = lane; i < d; i += 64) { const double t = y[i] * ra; part += t * t; }
+            const double rn = ra / sqrt(wave_allsum(part));
+            for (int i = lane; i < d; i += 64) y[i] *= rn;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    // ---- back-transformation x = H_0 H_1 ... H_{d-3} y (thread t owns component t) ---------------------------------
+    {
+        double yt = (tid < d) ? v[tid] : 0.0;
+        double vnext = (d >= 3 && tid > d - 2 && tid < d) ? A[(d - 3) * d + tid] : 0.0; // reflector d-3, prefetched
+        for (int k = d - 3; k >= 0; k--) {
+            const int o = k + 1;
+            const double vk = (tid == o) ? 1.0 : ((tid > o && tid < d) ? vnext : 0.0);
+            if (k > 0) vnext = (tid > k && tid < d) ? A[(k - 1) * d + tid] : 0.0;
+            const double bk = beta[k];
+            if (bk == 0.0) continue; // uniform
+            const double sc = bk * block_sum_512(vk * yt, red);
+            yt -= sc * vk;
+        }
+        __syncthreads();
+        if (tid < d) v[tid] = yt;
+        __syncthreads();
+    }
+    // normalise; sign: the component of largest magnitude (the first one on ties) is positive
+    double part = 0.0, best = -1.0;
+    int bi = 0;
+    for (int i = tid; i < d; i += EWP_T) {
+        const double t = v[i];
+        part += t * t;
+        if (fabs(t) > best) { best = fabs(t); bi = i; }
+    }
+    double nrm = sqrt(block_sum_512(part, red));
+    const bool degenerate = !(nrm > 0.0) || !(nrm < 1e300);
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        const double ob = __shfl_xor(best, o2);
+        const int oi = __shfl_xor(bi, o2);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { misc[2 * wv] = best; misc[2 * wv + 1] = (double)bi; }
+    __syncthreads();
+    best = misc[0];
+    bi = (int)misc[1];
+    for (int w2 = 1; w2 < 8; w2++) {
+        const double ob = misc[2 * w2];
+        const int oi = (int)misc[2 * w2 + 1];
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (degenerate) {
+        for (int i = tid; i < d; i += EWP_T) out[i] = (i == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double sg = ((v[bi] < 0.0) ? -1.0 : 1.0) / nrm;
+    for (int i = tid; i < d; i += EWP_T) out[i] = v[i] * sg;
+}
 bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec) {
     if (d > 512) return false; // beyond the LDS budget of the wide solver: the caller uses the host solver
     if (d > 128) { // the matrix stays in global memory and is overwritten
         ScopedKernelTimer t(c, "group_eig");
+        static const bool one_step = getenv("CGE_EIG_WIDE_UNBLOCKED") && atoi(getenv("CGE_EIG_WIDE_UNBLOCKED")) != 0; // A/B
+        if (!one_step) {
+            const size_t plds = (size_t)(2 * EWP_NB * d + d + EWP_T + 8 + 8 * 2 * EWP_NB + 2 * EWP_NB + 32) * sizeof(double);
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void *)group_eig_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(group_eig_panel_kernel, dim3((unsigned)n_tasks), dim3(EWP_T), plds, c->stream,
+                               const_cast<double *>(cov), (int)d, vec);
+            return true;
+        }
         const size_t lds = (size_t)(10 * d + 32) * sizeof(double);
         hipLaunchKernelGGL(group_eig_wide_kernel, dim3((unsigned)n_tasks), dim3(256), lds, c->stream, const_cast<double *>(cov),
                            (int)d, vec);
