@@ -341,7 +341,14 @@ __global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4, c2 = lane * 2;
     const i64 ch = blockIdx.x;
     i64 ta, tb; // tile pair: all of them, or (SAME) the diagonal ones
-    if (SAME) { ta = tb = blockIdx.y; } else { ta = blockIdx.y / nT; tb = blockIdx.y % nT; if (ta == tb) return; }
+    if (SAME) {
+        ta = tb = blockIdx.y;
+    } else { // tile pairs above the diagonal only (the reduction mirrors them): blockIdx.y -> (ta < tb)
+        i64 rem = blockIdx.y;
+        ta = 0;
+        while (rem >= nT - 1 - ta) { rem -= nT - 1 - ta; ta++; }
+        tb = ta + 1 + rem;
+    }
     const i64 a0 = ta * 128, b0 = tb * 128;
     const i32 beg = chunk_beg[ch];
     const i64 len = chunk_end[ch] - beg, len16 = (len + 15) / 16 * 16;
@@ -411,14 +418,19 @@ __global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__
                 if (ia < d && ib < d) out[ia * d + ib] = acc[a][b][r];
             }
 }
-__global__ void group_cov_final_kernel(const double *__restrict__ part, const i32 *__restrict__ task_chunk_off, i64 dd,
-                                       double *__restrict__ cov) {
-    const i64 t = blockIdx.y;
+// `tiled` (d > 128, MFMA path): the chunk partials hold the 128 x 128 tiles on and above the diagonal only; the tiles
+// below it are the mirror images, written from the reduced sums.
+__global__ void group_cov_final_kernel(const double *__restrict__ part, const i32 *__restrict__ task_chunk_off, i64 d,
+                                       int tiled, double *__restrict__ cov) {
+    const i64 t = blockIdx.y, dd = d * d;
     const i32 c0 = task_chunk_off[t], c1 = task_chunk_off[t + 1];
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < dd; e += (i64)gridDim.x * blockDim.x) {
+        const i64 i = e / d, j = e - i * d;
+        if (tiled && (i >> 7) > (j >> 7)) continue;
         double s = 0.0;
         for (i32 ch = c0; ch < c1; ch++) s += part[(i64)ch * dd + e];
         cov[t * dd + e] = s;
+        if (tiled && (i >> 7) < (j >> 7)) cov[t * dd + j * d + i] = s;
     }
 }
 void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
@@ -431,7 +443,7 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
         hipLaunchKernelGGL((group_cov_mfma_kernel<true>), dim3((unsigned)n_chunks, (unsigned)nT), block, stage, c->stream,
                            Xr, vw, rows, chunk_task, chunk_beg, chunk_end, d, nT, mean, part);
         if (nT > 1)
-            hipLaunchKernelGGL((group_cov_mfma_kernel<false>), dim3((unsigned)n_chunks, (unsigned)(nT * nT)), block,
+            hipLaunchKernelGGL((group_cov_mfma_kernel<false>), dim3((unsigned)n_chunks, (unsigned)(nT * (nT - 1) / 2)), block,
                                2 * stage, c->stream, Xr, vw, rows, chunk_task, chunk_beg, chunk_end, d, nT, mean, part);
     } else {
         const int dpv = (int)((d + 7) / 8 * 8);
@@ -450,7 +462,8 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
     }
     const i64 dd = d * d;
     dim3 g2((unsigned)std::min<i64>((dd + 255) / 256, 64), (unsigned)n_tasks);
-    hipLaunchKernelGGL(group_cov_final_kernel, g2, dim3(256), 0, c->stream, part, task_chunk_off, dd, cov);
+    hipLaunchKernelGGL(group_cov_final_kernel, g2, dim3(256), 0, c->stream, part, task_chunk_off, d, (int)(d > 128),
+                       cov);
 }
 
 // ------------------------------------------------------------------------------------------------
