@@ -184,13 +184,31 @@ def main():
         # default: the library's own RCCL communicator (ncclAllReduce on its stream, no host synchronisation per exchange);
         # CGE_COLLECTIVES=torch (or a failed init, or the one-GPU rehearsal) -> the torch.distributed hook
         if os.environ.get("CGE_COLLECTIVES", "rccl") == "rccl" and not rehearsal:
+            # Every rank must take the same branch (ncclCommInitRank is collective): first agree that librccl loads and
+            # hands out ids everywhere, then create the communicator, then agree that it exists everywhere.
+            def all_ok(ok):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return bool(flag.item())
+
+            uid, err = None, None
             try:
-                ids = [api.rccl_unique_id() if rank == 0 else None]
+                uid = api.rccl_unique_id()
+            except Exception as e:  # library missing / symbol missing
+                err = e
+            if all_ok(uid is not None):
+                ids = [uid if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
-                ctx.init_rccl(ids[0], rank, world)
-                coll_backend = "in-library RCCL (ncclAllReduce on the ctx stream)"
-            except Exception as e:
-                log(f"[bench] rank {rank}: in-library RCCL unavailable ({e!r}); using the torch.distributed hook")
+                try:
+                    ctx.init_rccl(ids[0], rank, world)
+                except Exception as e:
+                    err = e
+                if all_ok(err is None):
+                    coll_backend = "in-library RCCL (ncclAllReduce on the ctx stream)"
+                elif err is None:
+                    ctx.finalize_rccl()
+            if coll_backend is None:
+                log(f"[bench] rank {rank}: in-library RCCL unavailable ({err!r}); using the torch.distributed hook")
         if coll_backend is None:
             from cge.jl_amd.dist import TorchCollectives
 

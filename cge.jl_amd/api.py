@@ -409,6 +409,10 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self.L.cge_comm_init_rccl(self.h, buf, C.c_int(rank), C.c_int(world)))
 
+    def finalize_rccl(self):
+        """Release the in-library communicator (cge_comm_finalize); collectives go back to the hook, if one is set."""
+        self._check(self.L.cge_comm_finalize(self.h))
+
     def rccl_selftest(self, arr, op=0):
         """Testing hook: all-reduce `arr` (float64, or int64 for op 2) through the context's communicator."""
         a = np.ascontiguousarray(arr).copy()

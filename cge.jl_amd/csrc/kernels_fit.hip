@@ -655,24 +655,57 @@ __global__ void auc_final_kernel(const double *__restrict__ part, int nb, double
         out2[1] = den;
     }
 }
+// Many samples (config 4: 10^6 per alpha, two pow() each): AUC_WIDE x as many workgroups tally, and one wave folds
+// AUC_WIDE consecutive block tallies into each of the AUC_BLOCKS slots the callers expect, in a fixed order.
+#define AUC_WIDE 16
+#define AUC_WIDE_MIN_SAMPLES 65536
+__global__ void auc_fold_kernel(const double *__restrict__ wide, double *__restrict__ part) { // one wave, AUC_BLOCKS <= 64
+    const int s = threadIdx.x;
+    if (s >= AUC_BLOCKS) return;
+    double num = 0.0, den = 0.0;
+    for (int q = 0; q < AUC_WIDE; q++) {
+        num += wide[2 * (s * AUC_WIDE + q)];
+        den += wide[2 * (s * AUC_WIDE + q) + 1];
+    }
+    part[2 * s] = num;
+    part[2 * s + 1] = den;
+}
 static double *auc_partials(cge_ctx *c) {
-    c->auc_part.ensure(2 * AUC_BLOCKS);
+    c->auc_part.ensure(2 * AUC_BLOCKS + 2 * AUC_BLOCKS * AUC_WIDE);
     return c->auc_part.p;
 }
 void k_auc_landmark(cge_ctx *c, const double *Ta, const double *Tb, const i32 *v2l, const double *vw_orig,
                     const double *lweight, const i32 *pi, const i32 *pj, const i32 *ni, const i32 *nj,
                     const double *dpos, const double *dneg, const double *wts, i64 S, double alpha, double *out2,
                     double *partials) {
-    double *part = partials ? partials : auc_partials(c); // partials: 2 * CGE_PARTIAL_BLOCKS block tallies, summed by the caller
-    hipLaunchKernelGGL(auc_landmark_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, Ta, Tb, v2l, vw_orig, lweight,
-                       pi, pj, ni, nj, dpos, dneg, wts, S, alpha, part);
+    ScopedKernelTimer t(c, "auc_tally");
+    double *own = auc_partials(c);
+    double *part = partials ? partials : own; // partials: 2 * CGE_PARTIAL_BLOCKS block tallies, summed by the caller
+    if (S >= AUC_WIDE_MIN_SAMPLES) {
+        double *wide = own + 2 * AUC_BLOCKS;
+        hipLaunchKernelGGL(auc_landmark_kernel, dim3(AUC_BLOCKS * AUC_WIDE), dim3(256), 0, c->stream, Ta, Tb, v2l, vw_orig,
+                           lweight, pi, pj, ni, nj, dpos, dneg, wts, S, alpha, wide);
+        hipLaunchKernelGGL(auc_fold_kernel, dim3(1), dim3(64), 0, c->stream, wide, part);
+    } else {
+        hipLaunchKernelGGL(auc_landmark_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, Ta, Tb, v2l, vw_orig, lweight,
+                           pi, pj, ni, nj, dpos, dneg, wts, S, alpha, part);
+    }
     if (!partials) hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(64), 0, c->stream, part, AUC_BLOCKS, out2);
 }
 void k_auc_exact(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, i64 N, const i32 *pi,
                  const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, double *out2, double *partials) {
-    double *part = partials ? partials : auc_partials(c);
-    hipLaunchKernelGGL(auc_exact_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, GD, Ta, Tb, N, pi, pj, ni, nj, wts,
-                       S, part);
+    ScopedKernelTimer t(c, "auc_tally");
+    double *own = auc_partials(c);
+    double *part = partials ? partials : own;
+    if (S >= AUC_WIDE_MIN_SAMPLES) {
+        double *wide = own + 2 * AUC_BLOCKS;
+        hipLaunchKernelGGL(auc_exact_kernel, dim3(AUC_BLOCKS * AUC_WIDE), dim3(256), 0, c->stream, GD, Ta, Tb, N, pi, pj, ni,
+                           nj, wts, S, wide);
+        hipLaunchKernelGGL(auc_fold_kernel, dim3(1), dim3(64), 0, c->stream, wide, part);
+    } else {
+        hipLaunchKernelGGL(auc_exact_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, GD, Ta, Tb, N, pi, pj, ni, nj, wts,
+                           S, part);
+    }
     if (!partials) hipLaunchKernelGGL(auc_final_kernel, dim3(1), dim3(64), 0, c->stream, part, AUC_BLOCKS, out2);
 }
 
