@@ -101,6 +101,7 @@ int cge_create(cge_ctx **out, int device, void *stream) {
         HIP_CHECK(hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&c->sweep_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&c->tab_ev[i], hipEventDisableTiming));
         for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
         unsigned hc = std::thread::hardware_concurrency();
         c->n_threads = (int)std::max(1u, std::min(hc ? hc : 8u, 16u));
@@ -125,8 +126,10 @@ void cge_destroy(cge_ctx *c) {
     c->event_pool.clear();
     if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
         if (c->sweep_ev[i]) (void)hipEventDestroy(c->sweep_ev[i]);
+        if (c->tab_ev[i]) (void)hipEventDestroy(c->tab_ev[i]);
+    }
     for (int i = 0; i < 2; i++)
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
     delete c->pool;

@@ -324,6 +324,12 @@ struct cge_ctx {
     i64 lm_means_used = 0;
     DevBuf<i64> ls_moff;
     PinBuf<i64> pin_moff;
+    // small host <-> device tables of a landmark batch travel packed: one pinned staging area, one copy, one kernel that
+    // scatters (gathers) the 4-byte words to (from) their device arrays (landmarks_host.cpp: WordPacker)
+    PinBuf<i32> pin_tab[2], pin_res;
+    DevBuf<i32> dev_tab, dev_res;
+    hipEvent_t tab_ev[2] = {nullptr, nullptr};
+    int tab_slot = 0;
     bool lm_index_on_device = false; // lm_memoff / lm_mem mirror h_mem_off / h_mem (set by runsplit, cleared when the host rebuilds the index)
     DevBuf<i32> ls_toff, ls_nlow, lm_goff, lm_glen, lm_mem, lm_memoff; // task arena offsets, low-child counts, final groups, landmark index
     DevBuf<unsigned char> ls_keys;
@@ -502,6 +508,8 @@ void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows,
                  i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P, int part = 0, int nparts = 1);
 // alpha sweep
 void k_copy_segments(cge_ctx *c, const i32 *src, const i64 *seg, i64 nseg, i32 *dst);
+#define CGE_WORD_SEGS 8
+void k_copy_words(cge_ctx *c, int nseg, void *const *dst, const void *const *src, const i64 *words); // 4-byte words, nseg <= 8
 void k_gather_means_slots(cge_ctx *c, const double *arena, const i64 *off, const i64 *slot, i64 T, i64 d, i64 stride, i64 lead,
                           double *dst);
 void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only);

@@ -1408,6 +1408,41 @@ void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Up to CGE_WORD_SEGS runs of 4-byte words copied device to device by one launch: the small tables of a landmark batch
+// are staged through ONE pinned buffer (a copy per table costs ~20 us of idle stream each).
+struct WordSegs {
+    unsigned *dst[CGE_WORD_SEGS];
+    const unsigned *src[CGE_WORD_SEGS];
+    long long end[CGE_WORD_SEGS]; // running totals
+};
+__global__ void copy_words_kernel(WordSegs s, int n) {
+    const long long total = s.end[n - 1];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long beg = 0;
+#pragma unroll
+        for (int q = 0; q < CGE_WORD_SEGS; q++) {
+            if (q < n && i >= beg && i < s.end[q]) s.dst[q][i - beg] = s.src[q][i - beg];
+            if (q < n) beg = s.end[q];
+        }
+    }
+}
+void k_copy_words(cge_ctx *c, int nseg, void *const *dst, const void *const *src, const i64 *words) {
+    if (nseg <= 0) return;
+    if (nseg > CGE_WORD_SEGS) CGE_THROW(CGE_E_ARG, "k_copy_words: %d segments", nseg);
+    WordSegs s;
+    long long tot = 0;
+    for (int q = 0; q < CGE_WORD_SEGS; q++) {
+        s.dst[q] = q < nseg ? (unsigned *)dst[q] : nullptr;
+        s.src[q] = q < nseg ? (const unsigned *)src[q] : nullptr;
+        if (q < nseg) tot += words[q];
+        s.end[q] = tot;
+    }
+    if (tot == 0) return;
+    const unsigned nb = (unsigned)std::min<long long>((tot + 255) / 256, 1024);
+    hipLaunchKernelGGL(copy_words_kernel, dim3(nb), dim3(256), 0, c->stream, s, nseg);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Batched principal eigenvector, one workgroup per d x d covariance, d <= 128.  Same algorithm as
 // host_eig_top (landmarks_host.cpp): Householder tridiagonalisation, largest eigenvalue by (64-way)
 // multisection on the Sturm count, inverse iteration with a pivoted tridiagonal LU, back-transformation,

@@ -358,19 +358,96 @@ void batch_tables(Batch &B, const std::vector<i64> &lens) {
     B.task_chunk_off[T] = (i32)B.chunk_task.size();
     B.NC = (i64)B.chunk_task.size();
 }
-void upload_tables(cge_ctx *c, const Batch &B) { // grow-only scratch owned by the ctx
-    hipStream_t st = c->stream;
+// Several small host arrays -> their device arrays with ONE copy: the words are packed into a pinned staging buffer
+// (two of them alternate, each guarded by an event), copied to a device staging area and scattered by one kernel.
+// Every copy of its own from pageable memory costs ~20 us of idle stream; a batch has seven of them.
+struct WordPacker {
+    cge_ctx *c;
+    std::vector<void *> dst;
+    std::vector<const void *> src;
+    std::vector<i64> words;
+    explicit WordPacker(cge_ctx *c_) : c(c_) {}
+    template <class T>
+    void add(T *device, const T *host, i64 count) {
+        static_assert(sizeof(T) % 4 == 0, "4-byte words");
+        if (count <= 0) return;
+        dst.push_back(device);
+        src.push_back(host);
+        words.push_back(count * (i64)(sizeof(T) / 4));
+    }
+    void flush() {
+        if (dst.empty()) return;
+        i64 tot = 0;
+        for (i64 w : words) tot += w + (w & 1); // keep 8-byte items aligned
+        const int slot = c->tab_slot;
+        c->tab_slot ^= 1;
+        HIP_CHECK(hipEventSynchronize(c->tab_ev[slot])); // the copy that last read this staging buffer is done
+        c->pin_tab[slot].ensure((size_t)tot);
+        c->dev_tab.ensure((size_t)tot);
+        i32 *h = c->pin_tab[slot].p;
+        std::vector<const void *> dsrc(dst.size());
+        i64 pos = 0;
+        for (size_t q = 0; q < dst.size(); q++) {
+            std::memcpy(h + pos, src[q], (size_t)words[q] * 4);
+            dsrc[q] = c->dev_tab.p + pos;
+            pos += words[q] + (words[q] & 1);
+        }
+        HIP_CHECK(hipMemcpyAsync(c->dev_tab.p, h, sizeof(i32) * (size_t)tot, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipEventRecord(c->tab_ev[slot], c->stream));
+        for (size_t q0 = 0; q0 < dst.size(); q0 += CGE_WORD_SEGS) {
+            const int n = (int)std::min<size_t>(CGE_WORD_SEGS, dst.size() - q0);
+            k_copy_words(c, n, &dst[q0], &dsrc[q0], &words[q0]);
+        }
+        dst.clear(); src.clear(); words.clear();
+    }
+};
+// The other direction: device arrays -> one device staging area (one kernel) -> pinned memory (one copy).  fetch()
+// synchronises the stream; the pointers returned by add() are valid until the next gatherer is used.
+struct WordGatherer {
+    cge_ctx *c;
+    std::vector<void *> ddst;
+    std::vector<const void *> dsrc;
+    std::vector<i64> words, offs;
+    i64 tot = 0;
+    explicit WordGatherer(cge_ctx *c_) : c(c_) {}
+    template <class T>
+    size_t add(const T *device, i64 count) { // returns the index of the item
+        static_assert(sizeof(T) % 4 == 0, "4-byte words");
+        dsrc.push_back(device);
+        const i64 w = count * (i64)(sizeof(T) / 4);
+        words.push_back(w);
+        offs.push_back(tot);
+        tot += w + (w & 1);
+        return words.size() - 1;
+    }
+    void fetch() {
+        c->pin_res.ensure((size_t)std::max<i64>(tot, 1));
+        c->dev_res.ensure((size_t)std::max<i64>(tot, 1));
+        ddst.resize(dsrc.size());
+        for (size_t q = 0; q < dsrc.size(); q++) ddst[q] = c->dev_res.p + offs[q];
+        for (size_t q0 = 0; q0 < dsrc.size(); q0 += CGE_WORD_SEGS) {
+            const int n = (int)std::min<size_t>(CGE_WORD_SEGS, dsrc.size() - q0);
+            k_copy_words(c, n, &ddst[q0], &dsrc[q0], &words[q0]);
+        }
+        if (tot > 0)
+            HIP_CHECK(hipMemcpyAsync(c->pin_res.p, c->dev_res.p, sizeof(i32) * (size_t)tot, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    template <class T>
+    const T *get(size_t item) const { return reinterpret_cast<const T *>(c->pin_res.p + offs[item]); }
+};
+void upload_tables(cge_ctx *c, const Batch &B, WordPacker &pk) { // grow-only scratch owned by the ctx
     const i64 d = c->d;
     c->ls_rows.ensure(B.R); c->ls_row_task.ensure(B.R); c->ls_ct.ensure(B.NC); c->ls_cb.ensure(B.NC);
     c->ls_ce.ensure(B.NC); c->ls_tco.ensure(B.T + 1); c->sp_tro.ensure(B.T + 1);
     c->ls_part.ensure((size_t)B.NC * std::max(d * d, 2 * (2 * d + 1)));
     c->ls_side.ensure(B.R);
     c->ls_sums.ensure((size_t)B.T * 2 * (2 * d + 1));
-    HIP_CHECK(hipMemcpyAsync(c->ls_ct.p, B.chunk_task.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->ls_cb.p, B.chunk_beg.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->ls_ce.p, B.chunk_end.data(), sizeof(i32) * B.NC, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->ls_tco.p, B.task_chunk_off.data(), sizeof(i32) * (B.T + 1), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->sp_tro.p, B.task_row_off.data(), sizeof(i32) * (B.T + 1), hipMemcpyHostToDevice, st));
+    pk.add(c->ls_ct.p, B.chunk_task.data(), B.NC);
+    pk.add(c->ls_cb.p, B.chunk_beg.data(), B.NC);
+    pk.add(c->ls_ce.p, B.chunk_end.data(), B.NC);
+    pk.add(c->ls_tco.p, B.task_chunk_off.data(), B.T + 1);
+    pk.add(c->sp_tro.p, B.task_row_off.data(), B.T + 1);
 }
 // the usual batch: rows gathered on the device from the groups' arena ranges
 void build_batch(cge_ctx *c, Group *const *groups, i64 T, Batch &B) {
@@ -382,10 +459,17 @@ void build_batch(cge_ctx *c, Group *const *groups, i64 T, Batch &B) {
     }
     batch_tables(B, lens);
 }
-void upload_batch(cge_ctx *c, const Batch &B) {
-    upload_tables(c, B);
+// `moff` (optional): the groups' offsets into the means arena, for k_gather_means -- it rides along
+void upload_batch(cge_ctx *c, const Batch &B, const i64 *moff = nullptr) {
+    WordPacker pk(c);
+    upload_tables(c, B, pk);
     c->ls_toff.ensure(B.T);
-    HIP_CHECK(hipMemcpyAsync(c->ls_toff.p, B.task_off.data(), sizeof(i32) * B.T, hipMemcpyHostToDevice, c->stream));
+    pk.add(c->ls_toff.p, B.task_off.data(), B.T);
+    if (moff) {
+        c->ls_moff.ensure(B.T);
+        pk.add(c->ls_moff.p, moff, B.T);
+    }
+    pk.flush();
     k_gather_rows(c, c->lm_arena.p, c->ls_toff.p, c->sp_tro.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_rows.p,
                   c->ls_row_task.p);
 }
@@ -408,7 +492,9 @@ void build_batch_host(cge_ctx *c, Group *const *groups, i64 T, Batch &B) {
     });
 }
 void upload_batch_host(cge_ctx *c, const Batch &B) {
-    upload_tables(c, B);
+    WordPacker pk(c);
+    upload_tables(c, B, pk);
+    pk.flush();
     HIP_CHECK(hipMemcpyAsync(c->ls_rows.p, B.rows, sizeof(i32) * B.R, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipMemcpyAsync(c->ls_row_task.p, B.row_task, sizeof(i32) * B.R, hipMemcpyHostToDevice, c->stream));
 }
@@ -592,7 +678,6 @@ struct CutResult {
 // Tasks the rank-range argument does not cover (a tie at the maximum of z, NaNs) are left to the generic path.
 void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, i64 base, CutResult &out) {
     const i64 T = B.T, R = B.R, d = c->d, W = 2 * d + 1;
-    hipStream_t st = c->stream;
     c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
     c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W);
     c->sp_prefix.ensure((size_t)(R / CGE_PREFIX_STRIDE + B.NC + 1) * W);
@@ -608,13 +693,13 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, i64 base,
     k_rss_child_keys(c, c->sp_perm.p, c->ls_row_task.p, c->sp_tro.p, c->sp_meta.p, c->sp_rounds.p, R, T, c->ls_keys.p,
                      c->ls_nlow.p);
     k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + base);
-    std::vector<i32> status(T), meta(2 * T);
-    std::vector<double> vals(2 * T);
-    HIP_CHECK(hipMemcpyAsync(status.data(), c->sp_status.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(meta.data(), c->sp_meta.p, sizeof(i32) * 2 * T, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(out.nlow.data(), c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    WordGatherer wg(c);
+    const size_t i_status = wg.add(c->sp_status.p, T), i_meta = wg.add(c->sp_meta.p, 2 * T), i_vals = wg.add(c->sp_vals.p, 2 * T),
+                 i_nlow = wg.add(c->ls_nlow.p, T);
+    wg.fetch();
+    const i32 *status = wg.get<i32>(i_status), *meta = wg.get<i32>(i_meta);
+    const double *vals = wg.get<double>(i_vals);
+    std::memcpy(out.nlow.data(), wg.get<i32>(i_nlow), sizeof(i32) * T);
     for (i64 t = 0; t < T; t++) {
         Group *g = groups[t];
         if (status[t] == 2) { g->rc = CGE_E_HOMOGENEOUS; out.done[t] = 1; continue; }
@@ -640,11 +725,11 @@ void rule_rss2_device(cge_ctx *c, const Batch &B, Group *const *groups, i64 base
     HIP_CHECK(hipMemcpyAsync(c->lm_arena.p + base, c->sp_srows.p, sizeof(i32) * R, hipMemcpyDeviceToDevice, st));
     c->r2_rows = R;
     k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->lm_means.p + mbase);
-    std::vector<i32> meta(2 * T);
-    std::vector<double> vals(2 * T);
-    HIP_CHECK(hipMemcpyAsync(meta.data(), c->sp_meta.p, sizeof(i32) * 2 * T, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(vals.data(), c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    WordGatherer wg(c);
+    const size_t i_meta = wg.add(c->sp_meta.p, 2 * T), i_vals = wg.add(c->sp_vals.p, 2 * T);
+    wg.fetch();
+    const i32 *meta = wg.get<i32>(i_meta);
+    const double *vals = wg.get<double>(i_vals);
     for (i64 t = 0; t < T; t++) {
         Group *g = groups[t];
         out.nlow[t] = meta[2 * t] + 1; // low = ranks [0, lo], high = ranks [hi, k) with hi == lo + 1
@@ -671,8 +756,10 @@ void rule_cut_device(cge_ctx *c, const Batch &B, Group *const *groups, bool use_
     k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p);
     k_side_counts(c, c->ls_side.p, c->sp_tro.p, T, c->ls_nlow.p);
     k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + base);
-    HIP_CHECK(hipMemcpyAsync(out.nlow.data(), c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
+    c->pin_res.ensure((size_t)T); // pinned: the copy does not stall the host, the synchronisation below covers it
+    HIP_CHECK(hipMemcpyAsync(c->pin_res.p, c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
     const double *sums = side_sums_resident(c, B); // synchronises the stream
+    std::memcpy(out.nlow.data(), c->pin_res.p, sizeof(i32) * T);
     const i64 mbase = means_alloc(c, 2 * T * d);
     c->pin_cmeans.ensure((size_t)2 * T * d);
     parallel_for(c, T, [&](i64 t) {
@@ -800,11 +887,18 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
         hipStream_t st = c->stream;
         Batch B;
         i64 base;
+        bool have_means = true; // known from the parents' splits: gathered from the means arena, no pass over the rows
+        for (i64 t = 0; t < T && have_means; t++) have_means = groups[t]->mean_off >= 0;
         {
             PhaseAcc pa(c, "lm_pack");
             build_batch(c, groups, T, B);
             base = arena_alloc(c, B.R); // the children of task t: [base + task_row_off[t], + len)
-            upload_batch(c, B);
+            std::vector<i64> moff;
+            if (have_means) {
+                moff.resize(T);
+                for (i64 t = 0; t < T; t++) moff[t] = groups[t]->mean_off;
+            }
+            upload_batch(c, B, have_means ? moff.data() : nullptr);
         }
         const i64 R = B.R, NC = B.NC;
         c->stat_lm_batches++;
@@ -816,16 +910,9 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             PhaseAcc pa(c, "lm_pca_dev");
             {
                 ScopedKernelTimer tm(c, "group_stats");
-                bool have_means = true;
-                for (i64 t = 0; t < T && have_means; t++) have_means = groups[t]->mean_off >= 0;
-                if (have_means) { // known from the parents' splits: gathered from the means arena, no pass over the rows
-                    c->pin_moff.ensure(T); // pinned and owned by the ctx: no wait for the copy (the next batch's fill comes
-                    i64 *moff = c->pin_moff.p; // after at least one synchronisation of this batch)
-                    for (i64 t = 0; t < T; t++) moff[t] = groups[t]->mean_off;
-                    c->ls_moff.ensure(T);
-                    HIP_CHECK(hipMemcpyAsync(c->ls_moff.p, moff, sizeof(i64) * T, hipMemcpyHostToDevice, st));
+                if (have_means) // the offsets went up with the batch's tables
                     k_gather_means(c, c->lm_means.p, c->ls_moff.p, T, d, c->ls_mean.p);
-                } else
+                else
                     k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                                  c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
                 k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
