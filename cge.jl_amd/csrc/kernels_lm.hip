@@ -363,31 +363,32 @@ __global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__
     const double ma0 = ca < d ? mu[ca] : 0.0, ma1 = ca + 1 < d ? mu[ca + 1] : 0.0;
     const double mb0 = (!SAME && cb < d) ? mu[cb] : 0.0, mb1 = (!SAME && cb + 1 < d) ? mu[cb + 1] : 0.0;
     __syncthreads();
-    auto load = [&](i64 kc, int q, i64 col, double m0, double m1) {
-        const i64 kr = kc * MP_BK + wave + 4 * q;
-        d2 y = (d2){0.0, 0.0};
-        if (kr < len) {
-            const double *x = Xr + (i64)s_row[kr] * d + col;
-            const double sq = s_sq[kr];
-            if (pair_ok && col + 1 < d) {
-                const d2 xv = *reinterpret_cast<const d2 *>(x);
-                y = (d2){(xv[0] - m0) * sq, (xv[1] - m1) * sq};
-            } else {
-                if (col < d) y[0] = (x[0] - m0) * sq;
-                if (col + 1 < d) y[1] = (x[1] - m1) * sq;
-            }
-        }
-        return y;
+    // The loader only LOADS (from clamped, always valid addresses: rows beyond the chunk read its first row with a zero
+    // scale, columns beyond d read column 0 and are masked), the centring and scaling happen when the pair is staged.
+    struct RawRow { d2 x; double sq; };
+    auto load = [&](i64 kc, int q, i64 col) {
+        const i64 kr = kc * MP_BK + wave + 4 * q, krc = kr < len ? kr : 0;
+        const double *x = Xr + (i64)s_row[krc] * d;
+        const i64 e0 = col < d ? col : 0, e1 = col + 1 < d ? col + 1 : 0;
+        RawRow r;
+        r.sq = kr < len ? s_sq[krc] : 0.0;
+        if (pair_ok) r.x = *reinterpret_cast<const d2 *>(x + e0); // d even, col even: e1 == e0 + 1 whenever col < d
+        else r.x = (d2){x[e0], x[e1]};
+        return r;
+    };
+    auto finish = [&](const RawRow &r, i64 col, double m0, double m1) {
+        return (d2){col < d ? (r.x[0] - m0) * r.sq : 0.0, col + 1 < d ? (r.x[1] - m1) * r.sq : 0.0};
     };
     double *out = part + ch * d * d;
     if (SAME) { // upper-triangular blocks only, mirrored on the way out
         d4 acc[9];
-        auto la = [&](i64 kc, int q) { return load(kc, q, ca, ma0, ma1); };
+        auto la = [&](i64 kc, int q) { return load(kc, q, ca); };
+        auto fa = [&](const RawRow &r) { return finish(r, ca, ma0, ma1); };
         switch (wave) {
-        case 0: syrk_tile_128_wave<0>(la, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
-        case 1: syrk_tile_128_wave<1>(la, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
-        case 2: syrk_tile_128_wave<2>(la, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
-        default: syrk_tile_128_wave<3>(la, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
+        case 0: syrk_tile_128_wave<0>(la, fa, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
+        case 1: syrk_tile_128_wave<1>(la, fa, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
+        case 2: syrk_tile_128_wave<2>(la, fa, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
+        default: syrk_tile_128_wave<3>(la, fa, len16 / MP_BK, lds, acc, wave, c2, lr, lk); break;
         }
 #pragma unroll
         for (int q = 0; q < 9; q++) {
@@ -405,8 +406,9 @@ __global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__
         return;
     }
     d4 acc[4][4];
-    gram_tile_128_ld<false>([&](i64 kc, int q) { return load(kc, q, ca, ma0, ma1); },
-                            [&](i64 kc, int q) { return load(kc, q, cb, mb0, mb1); }, len16 / MP_BK, lds, acc, wave, c2, wr,
+    gram_tile_128_ld<false>([&](i64 kc, int q) { return load(kc, q, ca); }, [&](i64 kc, int q) { return load(kc, q, cb); },
+                            [&](const RawRow &r) { return finish(r, ca, ma0, ma1); },
+                            [&](const RawRow &r) { return finish(r, cb, mb0, mb1); }, len16 / MP_BK, lds, acc, wave, c2, wr,
                             wc, lr, lk);
 #pragma unroll
     for (int a = 0; a < 4; a++)

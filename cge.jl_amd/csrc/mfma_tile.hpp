@@ -19,15 +19,19 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // loader functors: la(kc, q) / lb(kc, q) return this thread's two adjacent elements (columns c2, c2+1 of the
 // tile) of k-row kc*MP_BK + wave + 4q.  SAME = true: B is A (a diagonal tile of a SYRK) -- staged once.
 // LDS: 2 stages x (A[,B]) x MP_BK x MP_LD doubles.  All 256 threads must call it (barriers inside).
-template <bool SAME, class LA, class LB>
-__device__ __forceinline__ void gram_tile_128_ld(LA la, LB lb, i64 nchunk, double *lds, d4 (&acc)[4][4], int wave,
-                                                 int c2, int wr, int wc, int lr, int lk) {
+// fa / fb turn what a loader returned into the staged pair at the moment it is stored to LDS, i.e. AFTER the MFMAs of
+// the chunk in between: arithmetic on a loaded value inside the loader itself puts an `s_waitcnt vmcnt(0)` right behind
+// the load and the prefetch is gone (the covariance kernel did that: half of its wave cycles were spent parked).
+template <bool SAME, class LA, class LB, class FA, class FB>
+__device__ __forceinline__ void gram_tile_128_ld(LA la, LB lb, FA fa, FB fb, i64 nchunk, double *lds, d4 (&acc)[4][4],
+                                                 int wave, int c2, int wr, int wc, int lr, int lk) {
     const size_t stage_doubles = (size_t)(SAME ? 1 : 2) * MP_BK * MP_LD;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-    d2 ra[4], rb[4];
+    decltype(la((i64)0, 0)) ra[4];
+    decltype(lb((i64)0, 0)) rb[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         ra[q] = la((i64)0, q);
@@ -38,8 +42,8 @@ __device__ __forceinline__ void gram_tile_128_ld(LA la, LB lb, i64 nchunk, doubl
         double *As = lds, *Bs = lds + (size_t)MP_BK * MP_LD;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            *reinterpret_cast<d2 *>(As + (wave + 4 * q) * MP_LD + c2) = ra[q];
-            if (!SAME) *reinterpret_cast<d2 *>(Bs + (wave + 4 * q) * MP_LD + c2) = rb[q];
+            *reinterpret_cast<d2 *>(As + (wave + 4 * q) * MP_LD + c2) = fa(ra[q]);
+            if (!SAME) *reinterpret_cast<d2 *>(Bs + (wave + 4 * q) * MP_LD + c2) = fb(rb[q]);
         }
     }
     __syncthreads();
@@ -73,8 +77,8 @@ __device__ __forceinline__ void gram_tile_128_ld(LA la, LB lb, i64 nchunk, doubl
             double *Bn = An + (size_t)MP_BK * MP_LD;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                *reinterpret_cast<d2 *>(An + (wave + 4 * q) * MP_LD + c2) = ra[q];
-                if (!SAME) *reinterpret_cast<d2 *>(Bn + (wave + 4 * q) * MP_LD + c2) = rb[q];
+                *reinterpret_cast<d2 *>(An + (wave + 4 * q) * MP_LD + c2) = fa(ra[q]);
+                if (!SAME) *reinterpret_cast<d2 *>(Bn + (wave + 4 * q) * MP_LD + c2) = fb(rb[q]);
             }
         }
         __syncthreads();
@@ -86,28 +90,29 @@ __device__ __forceinline__ void gram_tile_128_ld(LA la, LB lb, i64 nchunk, doubl
 __device__ __forceinline__ void gram_tile_128(const double *__restrict__ pa, const double *__restrict__ pb, i64 lda,
                                               i64 ldb, i64 nchunk, double *lds, d4 (&acc)[4][4], int wave, int c2,
                                               int wr, int wc, int lr, int lk) {
+    auto same = [](d2 v) { return v; };
     gram_tile_128_ld<false>(
         [&](i64 kc, int q) { return *reinterpret_cast<const d2 *>(pa + (kc * MP_BK + 4 * q) * lda); },
-        [&](i64 kc, int q) { return *reinterpret_cast<const d2 *>(pb + (kc * MP_BK + 4 * q) * ldb); }, nchunk, lds, acc,
-        wave, c2, wr, wc, lr, lk);
+        [&](i64 kc, int q) { return *reinterpret_cast<const d2 *>(pb + (kc * MP_BK + 4 * q) * ldb); }, same, same, nchunk,
+        lds, acc, wave, c2, wr, wc, lr, lk);
 }
 
 // The diagonal tile of a SYRK, G = A_tile * A_tile^T: only the 36 upper-triangular 16x16 blocks of the 8x8 block
 // grid are computed.  Wave w owns block-rows w and 7-w (8-w + w+1 = 9 blocks each way: the four waves are balanced);
 // slot q < 8-w is block (w, w+q), slot q >= 8-w is block (7-w, 7-w + q-(8-w)).  Same staging as gram_tile_128_ld
 // with SAME = true.  acc[q] has the MFMA C/D layout of its block: lane l, register r -> row (l>>4)+4r, col l&15.
-template <int W, class LA>
-__device__ __forceinline__ void syrk_tile_128_wave(LA la, i64 nchunk, double *lds, d4 (&acc)[9], int wave, int c2, int lr,
-                                                   int lk) {
+template <int W, class LA, class FA>
+__device__ __forceinline__ void syrk_tile_128_wave(LA la, FA fa, i64 nchunk, double *lds, d4 (&acc)[9], int wave, int c2,
+                                                   int lr, int lk) {
     const size_t stage_doubles = (size_t)MP_BK * MP_LD;
 #pragma unroll
     for (int q = 0; q < 9; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
-    d2 ra[4];
+    decltype(la((i64)0, 0)) ra[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) ra[q] = la((i64)0, q);
     __syncthreads(); // the previous tile's readers are done with both stages
 #pragma unroll
-    for (int q = 0; q < 4; q++) *reinterpret_cast<d2 *>(lds + (wave + 4 * q) * MP_LD + c2) = ra[q];
+    for (int q = 0; q < 4; q++) *reinterpret_cast<d2 *>(lds + (wave + 4 * q) * MP_LD + c2) = fa(ra[q]);
     __syncthreads();
     for (i64 kc = 0; kc < nchunk; kc++) {
         const int s = (int)(kc & 1);
@@ -132,7 +137,7 @@ __device__ __forceinline__ void syrk_tile_128_wave(LA la, i64 nchunk, double *ld
         if (more) {
             double *An = lds + (size_t)(s ^ 1) * stage_doubles;
 #pragma unroll
-            for (int q = 0; q < 4; q++) *reinterpret_cast<d2 *>(An + (wave + 4 * q) * MP_LD + c2) = ra[q];
+            for (int q = 0; q < 4; q++) *reinterpret_cast<d2 *>(An + (wave + 4 * q) * MP_LD + c2) = fa(ra[q]);
         }
         __syncthreads();
     }
