@@ -317,7 +317,20 @@ def main():
                 if name == "rss2_walk":
                     w = 16.0 * d * rows
                 if name == "group_eig":
-                    w = 8.0 * d * d * ctx.get_stat("landmark_splits") / max(1, ctx.get_stat("landmark_batches"))
+                    mats = ctx.get_stat("landmark_splits") / max(1, ctx.get_stat("landmark_batches"))
+                    w = 8.0 * d * d * mats
+                    if d > 128:  # panel form, matrix in memory: one read of the trailing block per step + one read and one
+                        # write per panel of 8 steps = 8 B x d^3/3 x (1 + 2/8) per matrix -- this one IS bound by HBM
+                        w = 8.0 * d ** 3 / 3.0 * 1.25 * mats
+                        note = ("batched principal eigenvector, 128 < d <= 512: panel-blocked Householder tridiagonalisation with "
+                                "the matrix in HBM; algorithmic bytes = one read of the trailing block per step + one read and one "
+                                "write per panel of 8 steps = 8 B x d^3/3 x 1.25 per matrix")
+                if name == "group_stats" and d > 128:  # 128 x 128 tiles on and above the diagonal; diagonal ones do 36 of 64 blocks
+                    nT = (d + 127) // 128
+                    w = 2.0 * 128 * 128 * rows * (nT * (nT - 1) / 2 + nT * 36.0 / 64.0)
+                    note = ("covariance SYRK: the 128 x 128 tiles on and above the diagonal (the diagonal ones compute 36 of "
+                            "their 64 blocks), 2 x 128^2 flop per row and tile; the timer also covers the means gather and "
+                            "the chunk reduction")
                 ent["rows_per_launch"] = rows
             if name == "fit_persistent":  # iterations of the last step's sweep / its launches
                 its = ctx.get_stat("fit_iterations") / max(1, l_ / steps_prof)
@@ -334,7 +347,7 @@ def main():
     # HBM traffic per launch from the committed PMC passes of this same command (profiles/run_profiles.sh)
     pmc = {}
     pmc_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (2, 1)) if os.path.exists(f)), "")
-    kernel_of = {"fit_symv": ("fit_step_kernel",), "fit_persistent": ("fit_flow_kernel",), "pcent": ("pcent_f32_kernel", "pcent_groups_kernel"),
+    kernel_of = {"fit_symv": ("fit_step_kernel",), "fit_persistent": ("fit_flow_kernel",), "pcent": ("pcent_f32_rowres_kernel", "pcent_f32_kernel", "pcent_groups_kernel"),
                  "pair_list": ("pair_list_kernel",), "edge_scatter": ("edge_pass_kernel", "edge_row_reduce_kernel"),
                  "max_pair_dist": ("max_pair_kernel",)}
     if os.path.exists(pmc_file) and args.workload == "headline" and world == 1:
