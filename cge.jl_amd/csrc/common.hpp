@@ -259,6 +259,9 @@ struct cge_ctx {
     DevBuf<unsigned long long> sw_fring;
     // persistent Chung-Lu fit (kernels_fitp.hip): T double buffer, partial vectors, per-workgroup maxima, barrier words
     DevBuf<double> fp_T, fp_Tsave, fp_P, fp_fpart, fp_fq, fp_Td, fp_flow;
+    bool bvec_contig = false;            // the score graph of the running sweep has contiguous communities (relabelled)
+    DevBuf<i32> sw_rl_order, sw_rl_comm; // exact mode, N > 8192: the score graph relabelled by community (wgcl_host.cpp)
+    DevBuf<double> sw_rl_emb, sw_rl_vec;
     DevBuf<unsigned> fp_sync;
     DevBuf<int> fp_flags;
     PinBuf<double> pin_scal;    // the scalars of an alpha (AUC sums, divergences, the fit's verdict), two alphas in flight
@@ -508,6 +511,9 @@ void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows,
                  i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P, int part = 0, int nparts = 1);
 // alpha sweep
 void k_copy_segments(cge_ctx *c, const i32 *src, const i64 *seg, i64 nseg, i32 *dst);
+void k_permute_rows(cge_ctx *c, const double *src, const i32 *order, i64 n, i64 width, double *dst); // dst[q] = src[order[q]]
+void k_permute_i32(cge_ctx *c, const i32 *src, const i32 *order, i64 n, i32 *dst);
+void k_remap_i32(cge_ctx *c, i32 *idx, const i32 *map, i64 n); // idx[k] = map[idx[k]]
 #define CGE_WORD_SEGS 8
 void k_copy_words(cge_ctx *c, int nseg, void *const *dst, const void *const *src, const i64 *words); // 4-byte words, nseg <= 8
 void k_gather_means_slots(cge_ctx *c, const double *arena, const i64 *off, const i64 *slot, i64 T, i64 d, i64 stride, i64 lead,
@@ -522,6 +528,9 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
                           const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant);
 void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
+                double delta, int k, unsigned long long *fring, int *done, int *iters);
+// the same iteration over the upper 64 x 64 tiles only (kernels_fitp.hip): half the matrix traffic
+void k_fit_sym_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
                 double delta, int k, unsigned long long *fring, int *done, int *iters);
 void k_fit_symv_dir(cge_ctx *c, const double *GD, const double *Tin, const double *Tout, i64 N, double *Sin,
                     double *Sout, const int *done);

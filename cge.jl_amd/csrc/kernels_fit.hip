@@ -381,6 +381,34 @@ void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// relabelling of a score graph (exact mode, wgcl_host.cpp): rows / entries in a new order, index arrays through a map
+__global__ void permute_rows_kernel(const double *__restrict__ src, const i32 *__restrict__ order, i64 n, i64 width,
+                                    double *__restrict__ dst) {
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * width) return;
+    const i64 q = e / width, col = e - q * width;
+    dst[e] = src[(i64)order[q] * width + col];
+}
+__global__ void permute_i32_kernel(const i32 *__restrict__ src, const i32 *__restrict__ order, i64 n, i32 *__restrict__ dst) {
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) dst[q] = src[order[q]];
+}
+__global__ void remap_i32_kernel(i32 *__restrict__ idx, const i32 *__restrict__ map, i64 n) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) idx[k] = map[idx[k]];
+}
+void k_permute_rows(cge_ctx *c, const double *src, const i32 *order, i64 n, i64 width, double *dst) {
+    hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)((n * width + 255) / 256)), dim3(256), 0, c->stream, src, order, n,
+                       width, dst);
+}
+void k_permute_i32(cge_ctx *c, const i32 *src, const i32 *order, i64 n, i32 *dst) {
+    hipLaunchKernelGGL(permute_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, order, n, dst);
+}
+void k_remap_i32(cge_ctx *c, i32 *idx, const i32 *map, i64 n) {
+    hipLaunchKernelGGL(remap_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, idx, map, n);
+}
+
+// ------------------------------------------------------------------------------------------------
 // vect_B.  Stage 1: rowbins[i][c] = sum over the members j of community c (ascending; j >= i when
 // undirected) of (Ta_i*Tb_j)*GD_ij.  Stage 2: sum the rows of each community, then fold the two orientations.
 // The row is streamed once, coalesced, into LDS as the products (Ta_i*Tb_j)*GD_ij (only j >= i when undirected),
@@ -388,7 +416,10 @@ void k_fit_update_dir(cge_ctx *c, double *Tin, double *Tout, const double *Sin, 
 // the sum of community c is then a contiguous LDS range in member (= ascending j) order -- the same additions in the
 // same order as a direct gather from the row (the skipped j < i hold 0.0, which leaves a sum's bits alone), without
 // scattered global reads or dependent index loads.  STAGED = false: rows beyond the LDS budget.
-template <bool STAGED>
+// MODE 1 (STAGED): the whole row fits the LDS budget.  MODE 0: the plain gather (rows beyond it whose communities are not
+// ranges of consecutive vertices, and the testing option).  Exact mode with N > 8192 relabels the score graph so that
+// every community IS a range (wgcl_host.cpp) and uses bvec_rows_contig_kernel below.
+template <int MODE>
 __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
                                                         const double *__restrict__ Tb,
                                                         const i32 *__restrict__ cm_off, const i32 *__restrict__ cm_mem,
@@ -399,7 +430,7 @@ __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict
     const double ti = Ta[i];
     const double *row = GD + i * N;
     const i64 j0 = directed ? 0 : i;
-    if (STAGED) {
+    if (MODE == 1) {
         i32 ob[2], oe[2]; // the member ranges of this thread's first two communities: asked for ahead of the barrier
 #pragma unroll
         for (int it = 0; it < 2; it++) {
@@ -444,6 +475,35 @@ __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict
             if (j >= j0) s += (ti * Tb[j]) * row[j];
         }
         rowbins[i * C + cc] = s;
+    }
+}
+// Rows of a score graph whose communities are ranges of consecutive vertices [cm_off[c], cm_off[c+1]): rowbins[i][c] is a
+// sum over a contiguous piece of row i.  One workgroup per row, the four waves take the communities in turn: lane-strided
+// partial sums (ascending j per lane) and a fixed xor tree -- coalesced, no staging, no dependent index loads; a thread per
+// community walking its members one by one (the forms above) is bound by the largest community (1.1 ms per row at
+// n = 60 000 with communities of a few thousand members).
+__global__ __launch_bounds__(256) void bvec_rows_contig_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
+                                                               const double *__restrict__ Tb,
+                                                               const i32 *__restrict__ cm_off, i64 N, i64 C, int directed,
+                                                               double *__restrict__ rowbins) {
+    const i64 i = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double ti = Ta[i];
+    const double *row = GD + i * N;
+    const i64 j0 = directed ? 0 : i;
+    for (i64 cc = wave; cc < C; cc += 4) {
+        const i64 b = max((i64)cm_off[cc], j0), e = cm_off[cc + 1];
+        double s0 = 0.0, s1 = 0.0;
+        i64 j = b + lane;
+        for (; j + 64 < e; j += 128) { // two independent loads per operand in flight
+            const double g0 = row[j], g1 = row[j + 64], t0 = Tb[j], t1 = Tb[j + 64];
+            s0 += (ti * t0) * g0;
+            s1 += (ti * t1) * g1;
+        }
+        if (j < e) s0 += (ti * Tb[j]) * row[j];
+        double sv = s0 + s1;
+        for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off);
+        if (lane == 0) rowbins[i * C + cc] = sv;
     }
 }
 // Stage 2a: Z[c1][c2] = sum over the members i of community c1 (ascending) of rowbins[i][c2] -- whole rows of
@@ -509,10 +569,13 @@ void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, co
     ScopedKernelTimer t(c, "bvec");
     const int plain = c->opt_test_bvec_plain; // testing: the forms for score graphs beyond the LDS budget / 512 communities
     if (N * sizeof(double) <= 64 * 1024 && !plain)
-        hipLaunchKernelGGL((bvec_rows_kernel<true>), dim3((unsigned)N), dim3(256), N * sizeof(double), c->stream, GD, Ta,
+        hipLaunchKernelGGL((bvec_rows_kernel<1>), dim3((unsigned)N), dim3(256), N * sizeof(double), c->stream, GD, Ta,
                            Tb, cm_off, cm_mem, cm_pos, N, C, directed, rowbins);
+    else if (c->bvec_contig && !plain)
+        hipLaunchKernelGGL(bvec_rows_contig_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off, N, C,
+                           directed, rowbins);
     else
-        hipLaunchKernelGGL((bvec_rows_kernel<false>), dim3((unsigned)N), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off,
+        hipLaunchKernelGGL((bvec_rows_kernel<0>), dim3((unsigned)N), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off,
                            cm_mem, cm_pos, N, C, directed, rowbins);
     c->sw_zsum.ensure((size_t)C * C);
     hipLaunchKernelGGL(bvec_zsum_kernel, dim3((unsigned)C), dim3(256), 0, c->stream, rowbins, cm_off, cm_mem, C, c->sw_zsum.p,

@@ -33,6 +33,7 @@ namespace {
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 __device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, RLX_AGENT); }
+typedef double dbl2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, RLX_AGENT); }
 
 // combine v[0..8) across the 8 lanes that differ in lane bits SH, SH+1, SH+2: afterwards the lane whose three bits
@@ -733,6 +734,120 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
     }
 }
 
+// ---- one Chung-Lu iteration per launch pair, over the UPPER tiles only --------------------------------------------
+// For landmark counts beyond the register file (N > ~4900: config 5 has 12 000, exact mode N = n) the fit is one
+// launch (pair) per iteration and bound by the matrix it streams.  fit_step_kernel (kernels_fit.hip) reads whole rows,
+// 8 N^2 bytes per iteration; this form reads every 64 x 64 tile on or above the diagonal once and uses it for both
+// products of the symmetric pair, exactly as the persistent kernels do with their register-resident tiles: same lane
+// layout (lane 8*rq + cq holds the 8 x 8 block), same transposing reductions, partial vectors P[block][other block][64].
+// The second kernel adds a block's Nt partial vectors (four interleaved sequential sums, then ((s0+s1)+s2)+s3 -- a fixed
+// order for any Nt), updates T and publishes f with the protocol of fit_step_kernel (fring / done / iters), so the host
+// loop is the same.  Traffic per iteration: 4 N^2 (+ N^2 / 4 for the partial vectors) instead of 8 N^2 bytes.
+__global__ __launch_bounds__(256) void fit_symtile_kernel(const double *__restrict__ GD, const double *__restrict__ T, i64 N,
+                                                          int Nt, i64 NT, double delta, int k,
+                                                          const unsigned long long *__restrict__ fring,
+                                                          const int *__restrict__ done, double *__restrict__ P) {
+    if (*done) return;
+    if (k > 0) {
+        const double fprev = __longlong_as_double((long long)fring[(k - 1) % 3]);
+        if (!(fprev > delta)) return; // the fit ended with iteration k - 1 (the reduce kernel records it)
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rq = lane >> 3, cq = lane & 7;
+    const i64 t = (i64)blockIdx.x * 4 + wave;
+    if (t >= NT) return;
+    // tile t of the row-major upper triangle: start(I) = I*Nt - I*(I-1)/2
+    const double bb = 2.0 * Nt + 1.0;
+    i64 I = (i64)((bb - sqrt(bb * bb - 8.0 * (double)t)) * 0.5);
+    if (I < 0) I = 0;
+    if (I > Nt - 1) I = Nt - 1;
+    while (I + 1 < Nt && (I + 1) * Nt - (I + 1) * I / 2 <= t) I++;
+    while (I > 0 && I * Nt - I * (I - 1) / 2 > t) I--;
+    const i64 J = I + (t - (I * Nt - I * (I - 1) / 2));
+    const i64 r0 = 64 * I + 8 * rq, c0 = 64 * J + 8 * cq;
+    double g[8][8];
+    if ((N & 1) == 0 && r0 + 8 <= N && c0 + 8 <= N) { // the common case: 16-byte loads, no guards
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const dbl2f *row = reinterpret_cast<const dbl2f *>(GD + (r0 + a) * N + c0);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const dbl2f v = row[b];
+                g[a][2 * b] = v.x;
+                g[a][2 * b + 1] = v.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int b = 0; b < 8; b++) g[a][b] = (r0 + a < N && c0 + b < N) ? GD[(r0 + a) * N + c0 + b] : 0.0;
+    }
+    double ti[8], tj[8], pr[8], pc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        ti[q] = r0 + q < N ? T[r0 + q] : 0.0;
+        tj[q] = c0 + q < N ? T[c0 + q] : 0.0;
+        pr[q] = 0.0;
+        pc[q] = 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const double p = (ti[a] * tj[b]) * g[a][b];
+            pr[a] += p;
+            pc[b] += p;
+        }
+    const double rsum = transpose_reduce8<0>(pr, lane); // row 8*rq + cq of the tile
+    P[(I * Nt + J) * 64 + lane] = rsum;
+    if (I != J) {
+        const double csum = transpose_reduce8<3>(pc, lane); // column 8*cq + rq of the tile
+        P[(J * Nt + I) * 64 + 8 * cq + rq] = csum;
+    }
+}
+__global__ __launch_bounds__(256) void fit_symreduce_kernel(const double *__restrict__ P, const double *__restrict__ T,
+                                                            double *__restrict__ Tout, const double *__restrict__ w, i64 N,
+                                                            int Nt, double eps, double delta, int k,
+                                                            unsigned long long *__restrict__ fring, int *__restrict__ done,
+                                                            int *__restrict__ iters) {
+    __shared__ double red[4][64];
+    if (*done) return;
+    if (k > 0) {
+        const double fprev = __longlong_as_double((long long)fring[(k - 1) % 3]);
+        if (!(fprev > delta)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) { *iters = k; *done = 1; }
+            return;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { fring[(k + 1) % 3] = 0ULL; *iters = k + 1; }
+    const int r = threadIdx.x & 63, u = threadIdx.x >> 6;
+    const i64 b = blockIdx.x;
+    const double *Pb = P + b * Nt * 64 + r;
+    double acc = 0.0;
+    int q = u;
+    for (; q + 12 < Nt; q += 16) { // four loads in flight; the additions stay in q order
+        const double p0 = Pb[(i64)q * 64], p1 = Pb[(i64)(q + 4) * 64], p2 = Pb[(i64)(q + 8) * 64], p3 = Pb[(i64)(q + 12) * 64];
+        acc += p0; acc += p1; acc += p2; acc += p3;
+    }
+    for (; q < Nt; q += 4) acc += Pb[(i64)q * 64];
+    red[u][r] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const i64 row = 64 * b + r;
+        double f = 0.0;
+        if (row < N) {
+            const double S = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
+            const double ti = T[row], wi = w[row];
+            Tout[row] = ti + (eps * ti) * (wi / S - 1.0);
+            f = fabs(wi - S);
+        }
+        f = wave_max(f);
+        if (r == 0) {
+            const unsigned long long fb = (unsigned long long)__double_as_longlong(f);
+            if (fb > __hip_atomic_load(&fring[k % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&fring[k % 3], fb);
+        }
+    }
+}
 // ---- the directed fit (src/divergence.jl:434-467) in the same dataflow form ----------------------------------------
 // Sin_i = sum_j (Tin_i*Tout_j)*g_ij, Sout_i = sum_j (Tin_j*Tout_i)*g_ij, the diagonal term counted twice (:439-449).
 // A tile element feeds four sums: e1 = (Tin_i*Tout_j)*g goes to Sin_i and Sout_j, e2 = (Tin_j*Tout_i)*g to Sout_i and
@@ -1174,6 +1289,18 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__r
 }
 
 } // namespace
+
+void k_fit_sym_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
+                    double delta, int k, unsigned long long *fring, int *done, int *iters) {
+    const int Nt = (int)((N + 63) / 64);
+    const i64 NT = (i64)Nt * (Nt + 1) / 2;
+    c->fp_P.ensure((size_t)Nt * Nt * 64);
+    ScopedKernelTimer t(c, "fit_symv");
+    hipLaunchKernelGGL(fit_symtile_kernel, dim3((unsigned)((NT + 3) / 4)), dim3(256), 0, c->stream, GD, Tin, N, Nt, NT, delta, k,
+                       fring, done, c->fp_P.p);
+    hipLaunchKernelGGL(fit_symreduce_kernel, dim3((unsigned)Nt), dim3(256), 0, c->stream, c->fp_P.p, Tin, Tout, w, N, Nt, eps,
+                       delta, k, fring, done, iters);
+}
 
 static hipError_t launch_plain(const void *fn, int G, void **args, size_t lds, hipStream_t st) {
     return hipLaunchKernel(fn, dim3((unsigned)G), dim3(256), args, lds, st);

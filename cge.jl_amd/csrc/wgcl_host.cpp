@@ -81,10 +81,11 @@ struct DevSamples { // one sample set on the device (0-based)
 static void gather_rows(cge_ctx *c, const i32 *d_arr, const std::vector<i64> &rows0, std::vector<i32> &out,
                         DevBuf<i32> &d_idx, DevBuf<i32> &d_out);
 
-void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, const i32 *ex_src, const i32 *ex_dst,
+void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, const i32 *ex_src, const i32 *ex_dst,
                      const double *ex_hw, i64 ex_m, int directed, int split, const SampleSet &smp, double out[7],
                      int *out_len, cge_trace *trace) {
     const double delta = 0.001, AlphaMax = 10.0, AlphaStep = 0.25; // :35-37 / :288-290
+    ScoreGraph G = G_in; // the per-vertex arrays may be replaced by community-sorted copies (below)
     const i64 N = G.N, C = G.C, d = G.d;
     hipStream_t st = c->stream;
     const i64 vlen = directed ? C * C : packed_len(C);
@@ -105,11 +106,6 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
     flags.ensure(4);
     c->sw_fring.ensure(4);
 
-    // D and its normalisation (:79-93 / :359-375)
-    k_dist_matrix(c, G.emb, G.dist, N, d, D.p);
-    k_minmax_upper(c, D.p, N, lohi.p);
-    k_normalise(c, D.p, N, lohi.p);
-
     // community -> members CSR of the score graph
     std::vector<i32> hcomm(N);
     HIP_CHECK(hipMemcpyAsync(hcomm.data(), G.comm, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
@@ -124,6 +120,42 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         std::vector<i32> cur(cm_off.begin(), cm_off.end() - 1);
         for (i64 i = 0; i < N; i++) cm_mem[cur[hcomm[i]]++] = (i32)i;
     }
+    // Exact mode beyond the LDS-staged vect_B (N > 8192): the score graph is RELABELLED so that every community is a range
+    // of consecutive vertices (members keep their ascending order, so every community sum adds in the reference's order).
+    // vect_B then reads its members as contiguous runs of a row -- with the vertex ids of a real graph (no relation to
+    // the communities) it was a 8-byte gather per element, 93 ms per alpha at n = 60 000 against 3 ms for the stream.
+    // Only what is indexed by vertex moves: embedding rows, weights / degrees, communities, the sampled pairs.
+    DevBuf<i32> d_old2new;
+    const bool relabel = orig == nullptr && N > 8192;
+    c->bvec_contig = relabel;
+    if (relabel) {
+        DevBuf<i32> &d_order = c->sw_rl_order;
+        d_order.ensure(N);
+        d_old2new.ensure(N);
+        std::vector<i32> old2new(N);
+        for (i64 q = 0; q < N; q++) old2new[cm_mem[q]] = (i32)q;
+        HIP_CHECK(hipMemcpyAsync(d_order.p, cm_mem.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_old2new.p, old2new.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+        c->sw_rl_emb.ensure((size_t)N * d);
+        c->sw_rl_vec.ensure((size_t)4 * N);
+        c->sw_rl_comm.ensure(N);
+        k_permute_rows(c, G.emb, d_order.p, N, d, c->sw_rl_emb.p);
+        G.emb = c->sw_rl_emb.p;
+        double *v = c->sw_rl_vec.p;
+        if (G.dist) { k_permute_rows(c, G.dist, d_order.p, N, 1, v); G.dist = v; }
+        if (G.vw) { k_permute_rows(c, G.vw, d_order.p, N, 1, v + N); G.vw = v + N; }
+        if (G.deg_in) { k_permute_rows(c, G.deg_in, d_order.p, N, 1, v + 2 * N); G.deg_in = v + 2 * N; }
+        if (G.deg_out) { k_permute_rows(c, G.deg_out, d_order.p, N, 1, v + 3 * N); G.deg_out = v + 3 * N; }
+        k_permute_i32(c, G.comm, d_order.p, N, c->sw_rl_comm.p);
+        G.comm = c->sw_rl_comm.p;
+        HIP_CHECK(hipStreamSynchronize(st)); // old2new goes out of scope
+        for (i64 q = 0; q < N; q++) cm_mem[q] = (i32)q; // the member lists in the new numbering
+    }
+
+    // D and its normalisation (:79-93 / :359-375)
+    k_dist_matrix(c, G.emb, G.dist, N, d, D.p);
+    k_minmax_upper(c, D.p, N, lohi.p);
+    k_normalise(c, D.p, N, lohi.p);
     DevBuf<i32> &d_cm_off = c->sw_cm_off, &d_cm_mem = c->sw_cm_mem;
     d_cm_off.ensure(C + 1);
     d_cm_mem.ensure(N);
@@ -169,6 +201,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
                           (c->opt_fit_persistent >= 2 || N >= 128);
     bool use_persistent_dir = directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
                               (c->opt_fit_persistent >= 2 || N >= 128);
+    // one launch (pair) per iteration, when the register-resident form does not apply: over the upper tiles only
+    // (kernels_fitp.hip: k_fit_sym_step); CGE_FIT_ROWS=1 keeps the whole-row kernel for A/B
+    static const bool fit_rows_env = getenv("CGE_FIT_ROWS") && atoi(getenv("CGE_FIT_ROWS")) != 0;
+    const bool sym_fit = !directed && !fit_rows_env;
     c->stat_fit_persistent = 0;
     c->stat_fit_iters = 0;
 
@@ -238,6 +274,14 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         }
     }
 
+    if (relabel) // the sampled pairs index the score graph: into the new numbering (GD is a full symmetric matrix here)
+        for (DevSamples &ds : dsets) {
+            k_remap_i32(c, ds.pi.p, d_old2new.p, S);
+            k_remap_i32(c, ds.pj.p, d_old2new.p, S);
+            k_remap_i32(c, ds.ni.p, d_old2new.p, S);
+            k_remap_i32(c, ds.nj.p, d_old2new.p, S);
+        }
+
     // ---- alpha sweep ---------------------------------------------------------------------------
     int alpha_div_counter = 5, alpha_auc_counter = 5; // :38
     bool skip_div = false, skip_auc = false;
@@ -270,7 +314,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
         sl.did_div = want_div;
         // the undirected persistent fit and vect_B read the upper triangle only; the exact-mode AUC, the directed vect_B
         // and the launch-per-iteration fits read whole rows
-        const bool gd_upper = landmarks && !directed && use_persistent;
+        const bool gd_upper = landmarks && !directed && (use_persistent || sym_fit);
         k_pow_matrix(c, D.p, N, alpha, GD.p, gd_upper);
         if (directed || !use_persistent) HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
         if (directed) {
@@ -304,7 +348,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
                         c->stat_fit_persistent++;
                     } else { // not co-resident / timed out: restore T and use one launch per iteration from here on
                         use_persistent = false;
-                        if (gd_upper) k_pow_matrix(c, D.p, N, alpha, GD.p, false);
+                        if (gd_upper && !sym_fit) k_pow_matrix(c, D.p, N, alpha, GD.p, false);
                         HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
                         HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
                     }
@@ -317,8 +361,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
                 i64 k = 0;
                 for (;;) {
                     for (i64 b = 0; b < batch; b++, k++)
-                        k_fit_step(c, GD.p, Tb2[k & 1], Tb2[(k + 1) & 1], G.vw, N, 0.25, delta, (int)k, c->sw_fring.p, flags.p,
-                                   flags.p + 1);
+                        (sym_fit ? k_fit_sym_step : k_fit_step)(c, GD.p, Tb2[k & 1], Tb2[(k + 1) & 1], G.vw, N, 0.25, delta, (int)k,
+                                                                c->sw_fring.p, flags.p, flags.p + 1);
                     int hf[2];
                     unsigned long long hr[3];
                     HIP_CHECK(hipMemcpyAsync(hf, flags.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
@@ -393,7 +437,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, cons
 
     // log2(1 - D) once for the whole sweep (the upper tiles only when every alpha reads only those); a fallback of the
     // persistent fit in mid-sweep makes k_pow_matrix use the library pow for the whole rows it then needs
-    k_pow_prepare(c, D.p, N, landmarks && !directed && use_persistent);
+    k_pow_prepare(c, D.p, N, landmarks && !directed && (use_persistent || sym_fit));
     i64 next_enqueue = 1;
     for (i64 ia = 1; ia <= n_alpha_total; ia++) {
         const double alpha = AlphaStep * (double)ia;
