@@ -183,7 +183,9 @@ def main():
     if world > 1:
         # default: the library's own RCCL communicator (ncclAllReduce on its stream, no host synchronisation per exchange);
         # CGE_COLLECTIVES=torch (or a failed init, or the one-GPU rehearsal) -> the torch.distributed hook
-        if os.environ.get("CGE_COLLECTIVES", "rccl") == "rccl" and not rehearsal:
+        # (CGE_REHEARSAL_TRY_RCCL=1: the one-GPU rehearsal walks through the handshake too -- RCCL refuses two ranks on one
+        # device, so it exercises the agreed fall-back to the hook)
+        if os.environ.get("CGE_COLLECTIVES", "rccl") == "rccl" and (not rehearsal or os.environ.get("CGE_REHEARSAL_TRY_RCCL") == "1"):
             # Every rank must take the same branch (ncclCommInitRank is collective): first agree that librccl loads and
             # hands out ids everywhere, then create the communicator, then agree that it exists everywhere.
             def all_ok(ok):
