@@ -321,12 +321,14 @@ def main():
                 if name == "group_eig":
                     mats = ctx.get_stat("landmark_splits") / max(1, ctx.get_stat("landmark_batches"))
                     w = 8.0 * d * d * mats
-                    if d > 128:  # panel form, matrix in memory: one read of the trailing block per step + one read and one
-                        # write per panel of 8 steps = 8 B x d^3/3 x (1 + 2/8) per matrix -- this one IS bound by HBM
-                        w = 8.0 * d ** 3 / 3.0 * 1.25 * mats
+                    if d > 128:  # panel form, matrix in memory: the 32 x 32 tiles on and below the diagonal are read once per
+                        # step (both products of the symmetric pair from one read) and read + written once per panel of
+                        # 8 steps = 8 B x d^3/3 x (1/2 + 1/8) per matrix -- this one IS bound by HBM
+                        w = 8.0 * d ** 3 / 3.0 * 0.625 * mats
                         note = ("batched principal eigenvector, 128 < d <= 512: panel-blocked Householder tridiagonalisation with "
-                                "the matrix in HBM; algorithmic bytes = one read of the trailing block per step + one read and one "
-                                "write per panel of 8 steps = 8 B x d^3/3 x 1.25 per matrix")
+                                "the matrix in HBM; algorithmic bytes = half a read of the trailing block per step (lower tiles, "
+                                "each serving both products of the symmetric pair) + half a read and write per panel of 8 steps "
+                                "= 8 B x d^3/3 x 0.625 per matrix")
                 if name == "group_stats" and d > 128:  # 128 x 128 tiles on and above the diagonal; diagonal ones do 36 of 64 blocks
                     nT = (d + 127) // 128
                     w = 2.0 * 128 * 128 * rows * (nT * (nT - 1) / 2 + nT * 36.0 / 64.0)

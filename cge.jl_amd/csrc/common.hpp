@@ -259,6 +259,7 @@ struct cge_ctx {
     DevBuf<unsigned long long> sw_fring;
     // persistent Chung-Lu fit (kernels_fitp.hip): T double buffer, partial vectors, per-workgroup maxima, barrier words
     DevBuf<double> fp_T, fp_Tsave, fp_P, fp_fpart, fp_fq, fp_Td, fp_flow;
+    DevBuf<double> ls_eigscr;            // wide eigen-solver: partial vectors of its tile sweeps (kernels_lm.hip)
     bool bvec_contig = false;            // the score graph of the running sweep has contiguous communities (relabelled)
     DevBuf<i32> sw_rl_order, sw_rl_comm; // exact mode, N > 8192: the score graph relabelled by community (wgcl_host.cpp)
     DevBuf<double> sw_rl_emb, sw_rl_vec;

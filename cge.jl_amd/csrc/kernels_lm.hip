@@ -2066,13 +2066,30 @@ __global__ __launch_bounds__(256) void group_eig_wide_kernel(double *__restrict_
 // consecutive steps are deferred (LAPACK's dlatrd idea): the panel's reflectors v_s and vectors w_s stay in LDS, column k
 // and B v of the *current* matrix are formed as "stored matrix minus the panel's corrections"
 //     a_k = A0[:,k] - sum_s (v_s w_s[k] + w_s v_s[k]),      B v = A0 v - sum_s (v_s (w_s.v) + w_s (v_s.v)),
-// and the trailing matrix is rewritten once per panel (A0 -= V W^T + W V^T).  Traffic: one read per step + one read and
-// write per panel = (1 + 2/NB)/3 of the above.  Same reflector convention (v[0] = 1, kept in row k right of the
+// and the trailing matrix is rewritten once per panel (A0 -= V W^T + W V^T).  Both sweeps touch the 32 x 32 tiles on and
+// below the diagonal only (B v reads a tile once for both products of the symmetric pair).  Traffic: half a read per step
+// + half a read and write per panel = (1/2 + 1/NB)/3 of the above.  Same reflector convention (v[0] = 1, kept in row k right of the
 // sub-diagonal), same Sturm / inverse iteration / back-transformation.  diag[k], beta[k], off[k] are parked in the dead part
 // of column k (A[k][k], A[k+1][k], A[k+2][k]) until the tridiagonal solve collects them.
 // 512 threads: thread t owns index t of every O(d) vector; for the O(d^2) sweeps the threads are re-mapped every step to
 // (column, row slice) over the 64-aligned window of live columns, so that all of them keep loading as the block shrinks.
+// v[0..4) combined across the 8 lanes that differ in lane bits SH, SH+1, SH+2: afterwards the lane whose bits SH+1, SH
+// spell q holds the sum over the 8 lanes of v[q] (the two lanes that differ in bit SH+2 hold the same value).  Fixed tree.
+template <int SH>
+__device__ __forceinline__ double transpose_reduce4(const double (&v)[4], int lane) {
+    const bool h1 = (lane >> (SH + 1)) & 1, h0 = (lane >> SH) & 1;
+    double w2[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const double keep = h1 ? v[q + 2] : v[q], send = h1 ? v[q] : v[q + 2];
+        w2[q] = keep + __shfl_xor(send, 2 << SH);
+    }
+    const double keep = h0 ? w2[1] : w2[0], send = h0 ? w2[0] : w2[1];
+    const double w1 = keep + __shfl_xor(send, 1 << SH);
+    return w1 + __shfl_xor(w1, 4 << SH);
+}
 constexpr int EWP_NB = 8, EWP_T = 512;
+constexpr int EWP_SCR = 16 * 16 * 32; // partial vectors of the 32 x 32 tile sweep: [row block][other block][32]
 __device__ __forceinline__ double block_sum_512(double v, double *red8) {
     v = wave_allsum(v);
     __syncthreads();
@@ -2080,19 +2097,21 @@ __device__ __forceinline__ double block_sum_512(double v, double *red8) {
     __syncthreads();
     return ((red8[0] + red8[1]) + (red8[2] + red8[3])) + ((red8[4] + red8[5]) + (red8[6] + red8[7]));
 }
-__global__ __launch_bounds__(EWP_T, 4) void group_eig_panel_kernel(double *__restrict__ cov, int d, double *__restrict__ vec) {
+__global__ __launch_bounds__(EWP_T, 4) void group_eig_panel_kernel(double *__restrict__ cov, int d, double *__restrict__ vec,
+                                                                   double *__restrict__ scratch /* [task][EWP_SCR] */) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *Vp = sh;                // [NB][d] reflectors of the open panel (zero above their sub-diagonal)
     double *Wp = Vp + EWP_NB * d;   // [NB][d]
     double *v = Wp + EWP_NB * d;    // [d] the current reflector; later the iterate of the inverse iteration
-    double *P = v + d;              // [EWP_T] column sums per row slice
-    double *red = P + EWP_T;        // 8
+    double *red = v + d;            // 8
     double *wpart = red + 8;        // [8 waves][2 NB]
     double *gh = wpart + 8 * 2 * EWP_NB; // [2 NB]
     double *misc = gh + 2 * EWP_NB; // 32
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *A = cov + (size_t)blockIdx.x * d * d;
     double *out = vec + (size_t)blockIdx.x * d;
+    double *Pt = scratch + (size_t)blockIdx.x * EWP_SCR;
+    const int rq = lane >> 3, cq = lane & 7;
     for (int i = tid; i < 2 * EWP_NB * d; i += EWP_T) Vp[i] = 0.0;
     __syncthreads();
     int q = 0;
@@ -2105,7 +2124,9 @@ __global__ __launch_bounds__(EWP_T, 4) void group_eig_panel_kernel(double *__res
         // column k of the current matrix (row k of the stored one, it is symmetric)
         double ai = 0.0;
         if (tid >= k && tid < d) {
-            ai = A[k * d + tid];
+            // the stored matrix is kept current on and below the diagonal 32 x 32 tiles only: row k inside k's own tile,
+            // column k (stride d) below it
+            ai = ((tid >> 5) == (k >> 5)) ? A[k * d + tid] : A[tid * d + k];
 #pragma unroll
             for (int s = 0; s < EWP_NB; s++)
                 if (s < q) ai -= Vp[s * d + tid] * Wp[s * d + k] + Wp[s * d + tid] * Vp[s * d + k];
@@ -2138,30 +2159,63 @@ __global__ __launch_bounds__(EWP_T, 4) void group_eig_panel_kernel(double *__res
                 for (int w2 = 1; w2 < 8; w2++) t += wpart[w2 * 2 * EWP_NB + tid];
                 gh[tid] = t;
             }
-            { // column sums of the stored trailing block times v, per row slice
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                if (active) {
-                    const double *col = A + j;
-                    int i = o + sl;
-                    for (; i + 7 * NS < d; i += 8 * NS) {
-                        double a[8];
+            // B v over the 32 x 32 tiles on and below the diagonal of the stored trailing block (32-grid from jb): every
+            // tile is read ONCE and serves both products of the symmetric pair -- its row sums go to the row block, its
+            // column sums to the column block (a diagonal tile is read whole and gives row sums only).  Lane 8*rq + cq
+            // holds the 4 x 4 block (rows 4rq.., columns 4cq..); the four row (column) partials of a lane are combined over
+            // the 8 lanes that share rq (cq) by a transposing butterfly.  v is zero left of column o, so whatever is parked
+            // there (reflectors, diag / beta / off) drops out.  Partial vectors Pt[row block][other block][32] in this
+            // workgroup's scratch; thread i then adds its block's Gb partials in order.
+            const int jb = o & ~31, Gb = (d - jb + 31) >> 5, ntile = Gb * (Gb + 1) / 2;
+            for (int t = wv; t < ntile; t += 8) {
+                int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while ((I + 1) * (I + 2) / 2 <= t) I++;
+                while (I * (I + 1) / 2 > t) I--;
+                const int J = t - I * (I + 1) / 2;
+                const int r0 = jb + 32 * I + 4 * rq, c0 = jb + 32 * J + 4 * cq;
+                double g[4][4];
+                if ((d & 1) == 0 && jb + 32 * I + 32 <= d) { // whole tile inside: 16-byte loads
 #pragma unroll
-                        for (int u = 0; u < 8; u++) a[u] = col[(i + u * NS) * d];
-                        s0 = fma(a[0], v[i], s0); s1 = fma(a[1], v[i + NS], s1);
-                        s2 = fma(a[2], v[i + 2 * NS], s2); s3 = fma(a[3], v[i + 3 * NS], s3);
-                        s0 = fma(a[4], v[i + 4 * NS], s0); s1 = fma(a[5], v[i + 5 * NS], s1);
-                        s2 = fma(a[6], v[i + 6 * NS], s2); s3 = fma(a[7], v[i + 7 * NS], s3);
+                    for (int a = 0; a < 4; a++) {
+                        const d2 *rowp = reinterpret_cast<const d2 *>(A + (r0 + a) * d + c0);
+                        const d2 x0 = rowp[0], x1 = rowp[1];
+                        g[a][0] = x0[0]; g[a][1] = x0[1]; g[a][2] = x1[0]; g[a][3] = x1[1];
                     }
-                    for (; i < d; i += NS) s0 = fma(col[i * d], v[i], s0);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b2 = 0; b2 < 4; b2++) g[a][b2] = (r0 + a < d && c0 + b2 < d) ? A[(r0 + a) * d + c0 + b2] : 0.0;
                 }
-                P[tid] = (s0 + s1) + (s2 + s3);
+                double tr[4], tc[4], pr[4], pc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    tr[u] = r0 + u < d ? v[r0 + u] : 0.0;
+                    tc[u] = c0 + u < d ? v[c0 + u] : 0.0;
+                    pr[u] = 0.0;
+                    pc[u] = 0.0;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; b2++) {
+                        pr[a] = fma(g[a][b2], tc[b2], pr[a]);
+                        pc[b2] = fma(g[a][b2], tr[a], pc[b2]);
+                    }
+                const double rsum = transpose_reduce4<0>(pr, lane); // row 4*rq + (cq & 3) of the tile
+                if (cq < 4) Pt[(I * Gb + J) * 32 + 4 * rq + cq] = rsum;
+                if (I != J) {
+                    const double csum = transpose_reduce4<3>(pc, lane); // column 4*cq + (rq & 3) of the tile
+                    if (rq < 4) Pt[(J * Gb + I) * 32 + 4 * cq + rq] = csum;
+                }
             }
             __syncthreads();
             double pi = 0.0;
             if (tid >= o && tid < d) {
-                const int ci = tid - jbase;
-                double t = P[ci];
-                for (int s2 = 1; s2 < NS; s2++) t += P[s2 * CW + ci];
+                const int bi = (tid - jb) >> 5, li = (tid - jb) & 31;
+                const double *pp = Pt + bi * Gb * 32 + li;
+                double t = pp[0];
+                for (int q2 = 1; q2 < Gb; q2++) t += pp[q2 * 32];
 #pragma unroll
                 for (int s = 0; s < EWP_NB; s++)
                     if (s < q) t -= Vp[s * d + tid] * gh[2 * s] + Wp[s * d + tid] * gh[2 * s + 1];
@@ -2178,7 +2232,7 @@ __global__ __launch_bounds__(EWP_T, 4) void group_eig_panel_kernel(double *__res
 #pragma unroll
                 for (int s = 0; s < EWP_NB; s++) { vj[s] = Vp[s * d + j]; wj[s] = Wp[s * d + j]; }
                 double *col = A + j;
-                int i = o + sl;
+                int i = max(o, j & ~31) + sl; // rows of the tiles on and below the diagonal (the sweep reads nothing else)
                 for (; i + 3 * NS < d; i += 4 * NS) {
                     double a[4];
 #pragma unroll
@@ -2211,7 +2265,7 @@ __global__ __launch_bounds__(EWP_T, 4) void group_eig_panel_kernel(double *__res
     unsigned char *swp = reinterpret_cast<unsigned char *>(tri + 4 * d);
     for (int i = tid; i < d; i += EWP_T) {
         diag[i] = A[i * d + i];
-        off[i] = (i + 2 < d) ? A[(i + 2) * d + i] : ((i == d - 2) ? A[i * d + i + 1] : 0.0);
+        off[i] = (i + 2 < d) ? A[(i + 2) * d + i] : ((i == d - 2) ? A[(i + 1) * d + i] : 0.0); // the element below the diagonal
         beta[i] = (i + 2 < d) ? A[(i + 1) * d + i] : 0.0;
     }
     __syncthreads();
@@ -2401,11 +2455,12 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
         ScopedKernelTimer t(c, "group_eig");
         static const bool one_step = getenv("CGE_EIG_WIDE_UNBLOCKED") && atoi(getenv("CGE_EIG_WIDE_UNBLOCKED")) != 0; // A/B
         if (!one_step) {
-            const size_t plds = (size_t)(2 * EWP_NB * d + d + EWP_T + 8 + 8 * 2 * EWP_NB + 2 * EWP_NB + 32) * sizeof(double);
+            const size_t plds = (size_t)(2 * EWP_NB * d + d + 8 + 8 * 2 * EWP_NB + 2 * EWP_NB + 32) * sizeof(double);
             static bool attr = false;
             if (!attr) { (void)hipFuncSetAttribute((const void *)group_eig_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            c->ls_eigscr.ensure((size_t)n_tasks * EWP_SCR);
             hipLaunchKernelGGL(group_eig_panel_kernel, dim3((unsigned)n_tasks), dim3(EWP_T), plds, c->stream,
-                               const_cast<double *>(cov), (int)d, vec);
+                               const_cast<double *>(cov), (int)d, vec, c->ls_eigscr.p);
             return true;
         }
         const size_t lds = (size_t)(10 * d + 32) * sizeof(double);
