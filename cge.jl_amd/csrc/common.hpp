@@ -527,7 +527,8 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
 bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,
                         double eps, double delta, int *dev_flags);
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
-                          const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant);
+                          const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant, int *dev_flags = nullptr,
+                          bool *enqueued_only = nullptr);
 void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
                 double delta, int k, unsigned long long *fring, int *done, int *iters);
 // the same iteration over the upper 64 x 64 tiles only (kernels_fitp.hip): half the matrix traffic

@@ -1445,7 +1445,8 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
 // Directed fit of one alpha from Tin / Tout (N doubles each, updated in place on success).  Returns false when the
 // persistent path does not apply or was abandoned; Tin / Tout are then untouched.
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
-                          const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant) {
+                          const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant, int *dev_flags, bool *enqueued_only) {
+    if (enqueued_only) *enqueued_only = false;
     const int Nt = (int)((N + 63) / 64);
     const i64 NT = (i64)Nt * (Nt + 1) / 2, Tld = (i64)Nt * 64;
     int dev = 0, cus = 0;
@@ -1478,7 +1479,7 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
                 int aNt = Nt, aMax = 2000000;
                 double aEps = eps0, aF0 = f0, aDelta = delta;
                 unsigned *aSync = (unsigned *)c->fp_flow.p;
-                int *aFlags = c->fp_flags.p;
+                int *aFlags = dev_flags ? dev_flags : c->fp_flags.p;
                 long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS;
                 void *args[] = {&aGD, &aN, &aNt, &aT0, &aTi, &aTo, &aTld, &aDi, &aDo, &aEps, &aF0, &aDelta, &aMax, &aRing, &aP, &aFq,
                                 &aSync, &aFlags, &aTicks};
@@ -1488,6 +1489,11 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
                     e = hipLaunchKernel(fn, dim3((unsigned)Gf), dim3(64 * NW), args, 0, st);
                 }
                 if (e != hipSuccess) CGE_THROW(CGE_E_HIP, "directed fit launch failed: %s", hipGetErrorString(e));
+                if (dev_flags) { // enqueue only: the caller reads the verdict (flags) behind whatever it queues after the fit
+                    *enqueued_only = true;
+                    *iters = 0;
+                    return true;
+                }
                 int hf[4];
                 HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));

@@ -322,6 +322,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             HIP_CHECK(hipMemcpyAsync(fitstate.p, init, sizeof(init), hipMemcpyHostToDevice, st));
         }
         i64 iters = 0;
+        bool dir_async = false;
         i64 batch = std::max<i64>(4, std::min<i64>(prev_iters, 128));
         if (!directed) {
             bool fitted = false;
@@ -380,8 +381,13 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             }
             Tcur = TT.p + (i64)tpar * Tld;
         } else if (use_persistent_dir &&
-                   k_fit_persistent_dir(c, GD.p, N, T1.p, T2.p, G.deg_in, G.deg_out, 0.9, 1.0, delta, &iters, fit_variant)) {
-            c->stat_fit_persistent++; // the whole directed fit in one launch (kernels_fitp.hip)
+                   k_fit_persistent_dir(c, GD.p, N, T1.p, T2.p, G.deg_in, G.deg_out, 0.9, 1.0, delta, &iters, fit_variant,
+                                        fit_variant == 2 ? (int *)(scal.p + RES_FIT) : nullptr, &dir_async)) {
+            // the whole directed fit in one launch (kernels_fitp.hip).  The default form is only enqueued: the rest of the
+            // alpha's chain is queued behind it and its verdict arrives with the alpha's scalars (Tin / Tout are written
+            // on success only, so a failed launch is redone from the same iterates with one launch pair per iteration).
+            if (dir_async) sl.fit_async = true;
+            else c->stat_fit_persistent++;
         } else
         for (;;) {
             if (use_persistent_dir) { // abandoned: T1 / T2 are untouched; one launch pair per iteration from here on
@@ -447,7 +453,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             next_enqueue = ia + 1;
         }
         const bool may_end_here = (skip_div || alpha_div_counter == 1) && (skip_auc || alpha_auc_counter == 1);
-        if (sl.fit_async && !may_end_here && ia < n_alpha_total) { // keep the device busy while the host reads alpha ia
+        // (directed: Tin / Tout are updated in place, so the next alpha is not queued before this one's verdict is known)
+        if (sl.fit_async && !directed && !may_end_here && ia < n_alpha_total) { // keep the device busy while the host reads alpha ia
             enqueue_alpha(ia + 1, !skip_auc, !skip_div);
             next_enqueue = ia + 2;
         }
@@ -457,8 +464,11 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             if (hf[2] || !hf[0]) { // a wait timed out: drain what was enqueued behind it and redo this alpha from its T_0
                 HIP_CHECK(hipStreamSynchronize(st)); // (still in place) with one launch per iteration, as every later alpha
                 note_fit_fallback(c);
-                use_persistent = false;
-                tpar = sl.t0_par;
+                if (directed) use_persistent_dir = false;
+                else {
+                    use_persistent = false;
+                    tpar = sl.t0_par;
+                }
                 next_enqueue = ia;
                 ia--;
                 continue;
