@@ -1042,6 +1042,10 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_shard_samples = (int)value;
         return CGE_OK;
     }
+    if (!strcmp(key, "exact_relabel")) { // exact mode beyond 8192 vertices: 1 (default) = score graph relabelled by community, 0 = as given (A/B, tests)
+        c->opt_exact_relabel = value != 0;
+        return CGE_OK;
+    }
     if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;

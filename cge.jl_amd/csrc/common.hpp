@@ -272,6 +272,7 @@ struct cge_ctx {
     bool pow_logs_upper = false;
     DevBuf<double> sw_Lh;
     DevBuf<float> sw_Ll;
+    bool opt_exact_relabel = true; // exact mode, N > 8192: relabel the score graph by community (wgcl_host.cpp)
     int opt_shard_samples = 1; // N > 1: 1 = local-score tallies split over the ranks from 10^5 samples on (in-library RCCL), 2 = always, 0 = never
     int opt_shard_forced = 1; // N > 1: the forced per-community phase of runsplit is split over the ranks
     int opt_test_bvec_plain = 0; // testing: vect_B without LDS staging / rows in flight (the forms of very large score graphs)

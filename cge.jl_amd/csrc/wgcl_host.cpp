@@ -126,7 +126,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     // the communities) it was a 8-byte gather per element, 93 ms per alpha at n = 60 000 against 3 ms for the stream.
     // Only what is indexed by vertex moves: embedding rows, weights / degrees, communities, the sampled pairs.
     DevBuf<i32> d_old2new;
-    const bool relabel = orig == nullptr && N > 8192;
+    const bool relabel = orig == nullptr && N > 8192 && c->opt_exact_relabel;
     c->bvec_contig = relabel;
     if (relabel) {
         DevBuf<i32> &d_order = c->sw_rl_order;

@@ -240,6 +240,9 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             bits (a double and a float per entry; below one ulp, like the library pow); 0 = the library pow per alpha.
  * "test_bvec_plain": testing hook, 1 = vect_B through the kernels that serve score graphs of more than 8192 vertices /
  *             512 communities (no LDS staging); same additions in the same order, hence the same bits.
+ * "exact_relabel": exact mode (v_to_l empty) beyond 8192 vertices: 1 (default) = the score graph is relabelled by community
+ *             inside the sweep, so that vect_B's row sums are contiguous pieces of a row; 0 = vertices as given (A/B and
+ *             tests; same iteration counts, scores equal up to the rounding of the fit's summation order).
  * "fit_persistent_test_timeout": testing hook, 1 = every persistent launch gives up at once (the host then
  *             restores the iterate and falls back to one launch per iteration).                              */
 int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);

@@ -968,6 +968,33 @@ def test_exact_mode_beyond_the_reference_limit(ctx):
     assert ctx.get_stat("fit_persistent_alphas") == 0 and it1 > 100  # 20 000 vertices: one launch per iteration
 
 
+@pytest.mark.parametrize("directed", [False, True])
+def test_exact_mode_relabelled_score_graph_agrees_with_the_plain_one(ctx, directed):
+    """Exact mode beyond 8192 vertices relabels the score graph by community inside the sweep (contiguous vect_B row
+    sums, wgcl_host.cpp).  Nothing index-free may notice: with the option off (vertices as given, plain gather kernels)
+    the same graph -- shuffled ids, non-unit dyadic edge weights, directed and undirected -- must give the same iteration
+    counts and the same scores up to the rounding of a different summation order in the fit."""
+    from cge.jl_amd import synth
+
+    n = 9000
+    g = synth.abcd_like(n, 8 * n, 40, 12, seed=11, directed=directed)
+    rng = np.random.default_rng(5)
+    ew = rng.choice([0.5, 1.0, 2.0, 4.0], size=len(g["eweights"]))
+    ctx.set_inputs(g["edges"], ew, g["vweights"], g["comm"], g["embedding"])
+    out = {}
+    try:
+        for opt in (1, 0):
+            ctx.set_option("exact_relabel", opt)
+            r = ctx.score([], -1, directed=directed, seed=3, auc_samples=4000)
+            out[opt] = (np.array(r), ctx.get_stat("fit_iterations"), np.array(ctx.last_trace["div"]), np.array(ctx.last_trace["auc"]))
+    finally:
+        ctx.set_option("exact_relabel", 1)
+    assert out[1][1] == out[0][1] and out[1][1] > 50
+    assert np.allclose(out[1][0], out[0][0], rtol=1e-10, atol=1e-13)
+    assert np.allclose(out[1][2], out[0][2], rtol=1e-10, atol=1e-13, equal_nan=True)
+    assert np.allclose(out[1][3], out[0][3], rtol=1e-10, atol=1e-13, equal_nan=True)
+
+
 def test_exact_mode_thirty_thousand_vertices_against_oracle_fixture(ctx):
     """`--force-exact` at 30 000 vertices -- three times the reference's switch to landmarks --
     against the CPU oracle's full run (tests/golden/oracle_exact30k.npz, an hour of one core; the test is skipped while
