@@ -262,7 +262,7 @@ struct cge_ctx {
     DevBuf<double> ls_eigscr;            // wide eigen-solver: partial vectors of its tile sweeps (kernels_lm.hip)
     bool bvec_contig = false;            // the score graph of the running sweep has contiguous communities (relabelled)
     DevBuf<i32> sw_rl_order, sw_rl_comm; // exact mode, N > 8192: the score graph relabelled by community (wgcl_host.cpp)
-    DevBuf<double> sw_rl_emb, sw_rl_vec;
+    DevBuf<double> sw_rl_emb, sw_rl_vec, sw_rl_T;
     DevBuf<unsigned> fp_sync;
     DevBuf<int> fp_flags;
     PinBuf<double> pin_scal;    // the scalars of an alpha (AUC sums, divergences, the fit's verdict), two alphas in flight

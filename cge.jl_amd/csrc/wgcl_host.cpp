@@ -126,8 +126,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     // the communities) it was a 8-byte gather per element, 93 ms per alpha at n = 60 000 against 3 ms for the stream.
     // Only what is indexed by vertex moves: embedding rows, weights / degrees, communities, the sampled pairs.
     DevBuf<i32> d_old2new;
-    const bool relabel = orig == nullptr && N > 8192 && c->opt_exact_relabel;
-    c->bvec_contig = relabel;
+    // (also the landmark graph of a landmark-mode score with more than 8192 landmarks -- config 5 has 12 000; the local
+    // score then reads T through the landmark ids of the original numbering, see the un-permuted copy in the sweep)
+    const bool relabel = N > 8192 && c->opt_exact_relabel;
+    c->bvec_contig = relabel && N >= 64 * C; // a wave per (row, community) pays off for communities of a wave's width or more
     if (relabel) {
         DevBuf<i32> &d_order = c->sw_rl_order;
         d_order.ensure(N);
@@ -274,7 +276,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         }
     }
 
-    if (relabel) // the sampled pairs index the score graph: into the new numbering (GD is a full symmetric matrix here)
+    if (relabel && !landmarks) // the sampled pairs index the score graph: into the new numbering (GD is a full symmetric matrix here)
         for (DevSamples &ds : dsets) {
             k_remap_i32(c, ds.pi.p, d_old2new.p, S);
             k_remap_i32(c, ds.pj.p, d_old2new.p, S);
@@ -411,6 +413,16 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         if (!sl.fit_async) prev_iters = iters;
 
         const double *Ta = directed ? Tout : Tcur, *Tb = directed ? Tin : Tcur;
+        const double *Ta_auc = Ta, *Tb_auc = Tb;
+        if (want_auc && relabel && landmarks) { // v_to_l holds the landmark ids of the original numbering
+            c->sw_rl_T.ensure((size_t)2 * N);
+            k_permute_rows(c, Ta, d_old2new.p, N, 1, c->sw_rl_T.p);
+            Ta_auc = Tb_auc = c->sw_rl_T.p;
+            if (directed) {
+                k_permute_rows(c, Tb, d_old2new.p, N, 1, c->sw_rl_T.p + N);
+                Tb_auc = c->sw_rl_T.p + N;
+            }
+        }
         if (want_auc) {
             const DevSamples &ds = dsets[smp.n_sets == 1 ? 0 : ia - 1];
             // N > 1 with many samples: rank r tallies the samples [S r / W, S (r + 1) / W) and the block tallies
@@ -418,7 +430,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             const i64 s0 = shard_samples ? S * c->coll.rank / c->coll.world : 0;
             const i64 s1 = shard_samples ? S * (c->coll.rank + 1) / c->coll.world : S;
             if (landmarks)
-                k_auc_landmark(c, Ta, Tb, orig->v2l, orig->vw, orig->lweight, ds.pi.p + s0, ds.pj.p + s0, ds.ni.p + s0,
+                k_auc_landmark(c, Ta_auc, Tb_auc, orig->v2l, orig->vw, orig->lweight, ds.pi.p + s0, ds.pj.p + s0, ds.ni.p + s0,
                                ds.nj.p + s0, ds.dpos.p + s0, ds.dneg.p + s0, ds.wts.p + s0, s1 - s0, alpha, nullptr,
                                scal.p + RES_AUC);
             else
