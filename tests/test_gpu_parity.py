@@ -1123,9 +1123,13 @@ def test_randomised_parity_sweep(ctx, orc, case):
     import cge.jl_amd as cg
     from cge.jl_amd import api, synth
 
+    # CGE_STRESS_OFFSET / CGE_STRESS_WIDE: other seeds / embedding widths of the memory-resident eigen-solver too (offline
+    # stress runs; the defaults are the committed cases)
+    case += int(os.environ.get("CGE_STRESS_OFFSET", "0"))
     rng = np.random.default_rng(1000 + case)
     n = int(rng.integers(60, 1500))
-    d = int(rng.choice([2, 3, 5, 8, 17, 33, 64, 100]))
+    dims = [2, 3, 5, 8, 17, 33, 64, 100] + ([129, 130, 160, 192, 257, 300] if os.environ.get("CGE_STRESS_WIDE") else [])
+    d = int(rng.choice(dims))
     C = int(rng.integers(2, max(3, n // 25)))
     method = ["rss", "rss2", "size", "diameter"][case % 4]
     directed = bool(rng.integers(0, 2))
