@@ -1344,7 +1344,13 @@ __global__ __launch_bounds__(64) void cut_sides_kernel(const double *__restrict_
         cut = (k & 1) ? zs[o + k / 2] : zs[o + k / 2 - 1] / 2.0 + zs[o + k / 2] / 2.0;
     else {
         double lo = z[o], hi = z[o];
-        for (i64 j = lane; j < k; j += 64) {
+        i64 j = lane;
+        for (; j + 192 < k; j += 256) { // four loads in flight: one wave walks the whole task
+            const double v0 = z[o + j], v1 = z[o + j + 64], v2 = z[o + j + 128], v3 = z[o + j + 192];
+            lo = fmin(fmin(lo, v0), fmin(fmin(v1, v2), v3));
+            hi = fmax(fmax(hi, v0), fmax(fmax(v1, v2), v3));
+        }
+        for (; j < k; j += 64) {
             const double v = z[o + j];
             lo = fmin(lo, v);
             hi = fmax(hi, v);
@@ -1356,10 +1362,24 @@ __global__ __launch_bounds__(64) void cut_sides_kernel(const double *__restrict_
         cut = (lo + hi) / 2.0;
     }
     i64 nlow = 0, nhigh = 0;
-    for (i64 base = 0; base < k; base += 64) {
+    double znext[4]; // the next four 64-row chunks are requested while the current ones are settled
+#pragma unroll
+    for (int u = 0; u < 4; u++) znext[u] = (64 * u + lane < k) ? z[o + 64 * u + lane] : 0.0;
+    for (i64 base0 = 0; base0 < k; base0 += 256) {
+        double zcur[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            zcur[u] = znext[u];
+            const i64 jn = base0 + 256 + 64 * u + lane;
+            znext[u] = jn < k ? z[o + jn] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+        const i64 base = base0 + 64 * u;
+        if (base >= k) break; // uniform
         const i64 j = base + lane;
         const bool valid = j < k;
-        const double zj = valid ? z[o + j] : 0.0;
+        const double zj = zcur[u];
         const bool isl = valid && zj < cut, ise = valid && zj == cut, ish = valid && !isl && !ise;
         const unsigned long long ml = __ballot(isl), mh = __ballot(ish);
         unsigned long long me = __ballot(ise), al = 0ULL; // al: ties that go low
@@ -1374,6 +1394,7 @@ __global__ __launch_bounds__(64) void cut_sides_kernel(const double *__restrict_
         if (valid) side[o + j] = (isl || (ise && ((al >> lane) & 1ULL))) ? 1 : 2;
         nlow += __popcll(ml) + el;
         nhigh += __popcll(mh) + eh;
+        }
     }
 }
 void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
