@@ -2568,7 +2568,17 @@ __global__ __launch_bounds__(256) void landmark_aggregate_kernel(const double *_
     const i64 l = blockIdx.x;
     const i32 b = mem_off[l], e = mem_off[l + 1];
     double lw = 0.0;
-    for (i32 t = b; t < e; t++) lw = __dadd_rn(lw, vw[mem[t]]);
+    {
+        i32 t = b;
+        for (; t + 7 < e; t += 8) { // eight (dependent index -> weight) loads in flight; the additions keep the member order
+            double wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) wv[u] = vw[mem[t + u]];
+#pragma unroll
+            for (int u = 0; u < 8; u++) lw = __dadd_rn(lw, wv[u]);
+        }
+        for (; t < e; t++) lw = __dadd_rn(lw, vw[mem[t]]);
+    }
     for (i64 col = threadIdx.x; col < d; col += blockDim.x) {
         double acc = 0.0;
         i32 t = b;
