@@ -179,6 +179,8 @@ def main():
         ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
         t_upload = time.perf_counter() - t0
     ctx.set_option("diameter", args.diameter)
+    if os.environ.get("CGE_SPEC_PCT"):  # tuning probe: share of the missing pops one round of runsplit may split ahead
+        ctx.set_option("speculation_pct", int(os.environ["CGE_SPEC_PCT"]))
     coll, coll_backend = None, None
     if world > 1:
         # default: the library's own RCCL communicator (ncclAllReduce on its stream, no host synchronisation per exchange);

@@ -1023,8 +1023,8 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_fit_persistent = (int)value;
         return CGE_OK;
     }
-    if (!strcmp(key, "speculation_pct")) { // tuning: 1..100 (results do not depend on it)
-        if (value < 1 || value > 100) return CGE_E_ARG;
+    if (!strcmp(key, "speculation_pct")) { // tuning: 1..100, 0 = by split rule (results do not depend on it)
+        if (value < 0 || value > 100) return CGE_E_ARG;
         c->opt_speculation_pct = (int)value;
         return CGE_OK;
     }

@@ -151,7 +151,7 @@ def test_landmarks_independent_of_speculation(ctx, synth20k, method):
             ctx.set_option("speculation_pct", pct)
             out[pct] = cg.landmarks(*args, ctx=ctx)
     finally:
-        ctx.set_option("speculation_pct", 40)
+        ctx.set_option("speculation_pct", 0)  # back to the default: by split rule
     for pct in (40, 3):
         for x, y in zip(out[100], out[pct]):
             assert np.array_equal(x, y), pct
