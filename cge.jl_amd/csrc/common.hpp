@@ -279,8 +279,9 @@ struct cge_ctx {
     int opt_fit_persistent = 0; // 0 auto (score graphs of >= 128 vertices that fit the register file), 1 never, 2 whenever it
                                 // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
     int opt_speculation_pct = 0;   // global phase: share (%) of the still missing pops that one round may split speculatively;
-                                   // 0 = by split rule: 40 for rss / rss2, 10 for size / diameter (their cuts are unbalanced, a
-                                   // speculative split is wasted more often: config 3 68.4 -> 63.8 ms per step)
+                                   // 0 = by split rule: 40 for rss / rss2 (25 when d > 128: config 5 1.51 -> 1.43 s), 10 for
+                                   // size / diameter (their cuts are unbalanced, a speculative split is wasted more often:
+                                   // config 3 68.4 -> 63.8 ms per step)
     int opt_fit_test_timeout = 0; // testing: the persistent fit gives up at once, so the fallback path runs
     i64 stat_lm_batches = 0, stat_lm_rows = 0, stat_lm_splits = 0; // last runsplit: device batches, their rows, groups split
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep

@@ -1157,7 +1157,8 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
             // eigen-problems of the rest; what is left over is reconsidered, with more known, in the next round.
             // (never fewer than 256 at a time: the last pops would otherwise trickle through many tiny rounds)
             const int spec_pct = c->opt_speculation_pct > 0 ? c->opt_speculation_pct
-                                 : (method == CGE_METHOD_SIZE || method == CGE_METHOD_DIAMETER) ? 10 : 40;
+                                 : (method == CGE_METHOD_SIZE || method == CGE_METHOD_DIAMETER) ? 10
+                                 : (c->d > 128 ? 25 : 40); // wide embeddings: a wasted split costs a memory-resident eigen-problem
             const i64 take = std::max<i64>(std::min<i64>(remaining, 256), (i64)((double)remaining * spec_pct / 100.0));
             if ((i64)frontier.size() > take) {
                 std::nth_element(frontier.begin(), frontier.begin() + (take - 1), frontier.end(),

@@ -227,7 +227,7 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             Same iterates and iteration counts in all modes, identical bits among 2, 3 and 4; sums are grouped
  *             differently between the launch-per-iteration and the persistent forms (last-bit differences of the
  *             score vector).
- * "speculation_pct": 1..100, or 0 (default) = by split rule (40 for rss / rss2, 10 for size / diameter): share of the pops
+ * "speculation_pct": 1..100, or 0 (default) = by split rule (40 for rss / rss2 -- 25 when d > 128 --, 10 for size / diameter): share of the pops
  *             still missing that one round of runsplit's global phase may split ahead of the heap; tuning only -- the
  *             replay makes the result independent of it.
  * "shard_runsplit": with collectives set (N > 1): 1 (default) = the forced per-community phase of runsplit and the big
