@@ -439,7 +439,7 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
                  const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
                  i64 d, const double *mean, double *part, double *cov) {
     dim3 grid((unsigned)n_chunks), block(256);
-    if (d >= 96) { // fp64 MFMA SYRK
+    if (d >= 48) { // fp64 MFMA SYRK (below a full tile too: a chunk is bound by its latency chain, not by the flops of the padding)
         const i64 nT = (d + 127) / 128;
         const size_t stage = (size_t)2 * MP_BK * MP_LD * sizeof(double);
         hipLaunchKernelGGL((group_cov_mfma_kernel<true>), dim3((unsigned)n_chunks, (unsigned)nT), block, stage, c->stream,
