@@ -100,8 +100,8 @@ ROOFLINE_KERNELS = ("fit_persistent", "fit_symv", "group_stats", "group_project"
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)  # a step is ~33 ms at the headline: ten of them average out most of the jitter
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true",
