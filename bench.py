@@ -28,6 +28,8 @@ WORKLOADS = {
     "cfg2": dict(n=100_000, m=1_000_000, C=50, d=64, land=400, forced=4, method="rss2", samples=10000),
     # configs[2]: ABCD 1M nodes / 20M edges, d=128, -l 4000 -m diameter (its 8-GPU sharding is the driver's N=8 run)
     "cfg3": dict(n=1_000_000, m=20_000_000, C=500, d=128, land=4000, forced=4, method="diameter", samples=10000),
+    # config 3's graph under the `size` rule (the fourth split rule at full size; parity fixture oracle_cfg3_size.npz)
+    "cfg3_size": dict(n=1_000_000, m=20_000_000, C=500, d=128, land=4000, forced=4, method="size", samples=10000),
     # configs[3]: directed 1M-node graph, d=128, --samples-local 1000000, automatic landmarks max(4 sqrt(n), 4C)
     "cfg4": dict(n=1_000_000, m=10_000_000, C=500, d=128, land=4000, forced=4, method="rss", samples=1_000_000,
                  directed=True),
@@ -94,7 +96,29 @@ def cpu_baseline(g, wl, budget_vertices=60000):
 
 
 ROOFLINE_KERNELS = ("fit_persistent", "fit_symv", "group_stats", "group_project", "sorted_prefix", "pcent", "pair_list",
-                    "max_pair_dist", "edge_scatter", "rss2_walk", "group_eig")
+                    "max_pair_dist", "edge_scatter", "edge_scatter_wedges", "rss2_walk", "group_eig")
+
+
+def full_size_oracle(workload):
+    """The oracle's own FULL-SIZE run of this workload, as recorded in the provenance of its committed fixture
+    (tests/golden/oracle_<workload>.npz, written by make_oracle_fixture_*.py on the build container, one core): seconds of
+    landmarks() + wGCL*() and the evals/s they amount to.  Not timed here (7-13 CPU-minutes); reported beside the bounded
+    sample that is."""
+    import re
+
+    path = os.path.join(ROOT, "tests", "golden", f"oracle_{workload}.npz")
+    if not os.path.exists(path):
+        return None
+    fx = np.load(path, allow_pickle=False)
+    prov = str(fx["provenance"])
+    mt = re.search(r"landmarks (\d+) s(?:,| \+) (?:score|wGCL) (\d+) s", prov)
+    if not mt:
+        return None
+    t_lm, t_sc = float(mt.group(1)), float(mt.group(2))
+    A, m = len(fx["iters"]), int(fx["m"])
+    return {"landmarks_s": t_lm, "wgcl_s": t_sc, "alphas": A, "m": m, "value": m * A / (t_lm + t_sc),
+            "where": "build container, 1 core, oracle/cge_oracle.c; diameter handed in from tests/diameter_ref.py where the "
+                     "provenance says so (the reference's O(n^2 d) loop is not runnable at this size)", "provenance": prov}
 
 
 def main():
@@ -109,6 +133,11 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--scale", type=float, default=1.0, help="scale the workload's n and m (the line says the actual sizes)")
     ap.add_argument("--diameter", type=int, default=0, help="0 auto (pruned, brute-force fallback), 1 brute force, 2 pruned")
+    ap.add_argument("--lazy-landmark-edges", action="store_true",
+                    help="leave the N x N landmark-pair matrix / landmark edge count of landmarks() (src/landmarks.jl:433-463) out "
+                         "of the timed step (an undirected score does not read it); default: the step builds it")
+    ap.add_argument("--serial-diameter", action="store_true",
+                    help="A/B: clamp, sample draws and diameter in line on the main stream instead of the side context")
     args = ap.parse_args()
 
     import torch
@@ -179,6 +208,8 @@ def main():
         ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
         t_upload = time.perf_counter() - t0
     ctx.set_option("diameter", args.diameter)
+    ctx.set_option("landmark_edges", 0 if args.lazy_landmark_edges else 1)
+    ctx.set_option("early_diameter", 0 if args.serial_diameter else 1)
     if os.environ.get("CGE_SPEC_PCT"):  # tuning probe: share of the missing pops one round of runsplit may split ahead
         ctx.set_option("speculation_pct", int(os.environ["CGE_SPEC_PCT"]))
     coll, coll_backend = None, None
@@ -292,13 +323,19 @@ def main():
                            "fraction; `streaming_equivalent_gbs` = what a launch-per-iteration SYMV (SURVEY 8d(5): 8 B per "
                            "pair per iteration) would have to stream to match it -- a speed-up figure, not a roofline"),
         "group_stats": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", None,
-                        "covariance SYRK: 2 d^2 flop per row of the batch on the full tile (36 of its 64 blocks are computed, "
-                        "the rest mirrored); the timer also covers the means gather and the chunk reduction"),
+                        "covariance SYRK, priced as SURVEY 8(d)(3): |c| d^2 flop per split (the symmetric half at 2 flop per "
+                        "entry) summed over the groups of a batch = rows x d^2; the timer also covers the means gather and the "
+                        "chunk reduction"),
         "group_project": ("hbm", HBM_PEAK_GBS, "GB/s", None, "projection z: one 8d-byte row read per row of the batch"),
         "sorted_prefix": ("hbm", HBM_PEAK_GBS, "GB/s", None, "WSSE scan along sorted z: one 8d-byte row read per row of the batch"),
         "edge_scatter": ("hbm", HBM_PEAK_GBS, "GB/s", 24.0 * g["m"] / world,
                          "C x C cluster-pair scatter-add (edge pass + row reduction, kernels_scatter.hip), 24 B per edge "
-                         "(2 x Int64 + Float64 as the reference stores them; the blocked device copy is 4 B per edge)"),
+                         "(2 x Int64 + Float64 as the reference stores them; the blocked device copy is 4 B per edge).  Steady "
+                         "state on the blocked copy of the resident edge list: `first_call_ms` adds its one-off build "
+                         "(`layout_build_ms`: key kernel + radix sort + gather + chunk table) paid by the first score of a graph"),
+        "edge_scatter_wedges": ("hbm", HBM_PEAK_GBS, "GB/s", 24.0 * g["m"] / world,
+                                "N x N landmark-pair scatter-add of landmarks() (src/landmarks.jl:433-451) incl. zeroing / writing "
+                                "the N x N output and counting its positive entries: 24 B per edge as the reference stores them"),
         "rss2_walk": ("hbm", HBM_PEAK_GBS, "GB/s", None,
                       "rss2 rule (prefix / suffix RSS chains + merge): 2 x 8d bytes per row of the batch; the chains are "
                       "sequential in the rows of a group (the reference's order of additions) and pay an IEEE division per "
@@ -317,7 +354,7 @@ def main():
                 w = 2.0 * d * 128 * 128 * cand_tiles / max(1, l_ / steps_prof)
             if name in ("group_stats", "group_project", "sorted_prefix", "rss2_walk", "group_eig"):  # average batch of the last runsplit
                 rows = ctx.get_stat("landmark_batch_rows") / max(1, ctx.get_stat("landmark_batches"))
-                w = 2.0 * d * d * rows if name == "group_stats" else 8.0 * d * rows
+                w = 1.0 * d * d * rows if name == "group_stats" else 8.0 * d * rows
                 if name == "rss2_walk":
                     w = 16.0 * d * rows
                 if name == "group_eig":
@@ -331,12 +368,6 @@ def main():
                                 "the matrix in HBM; algorithmic bytes = half a read of the trailing block per step (lower tiles, "
                                 "each serving both products of the symmetric pair) + half a read and write per panel of 8 steps "
                                 "= 8 B x d^3/3 x 0.625 per matrix")
-                if name == "group_stats" and d > 128:  # 128 x 128 tiles on and above the diagonal; diagonal ones do 36 of 64 blocks
-                    nT = (d + 127) // 128
-                    w = 2.0 * 128 * 128 * rows * (nT * (nT - 1) / 2 + nT * 36.0 / 64.0)
-                    note = ("covariance SYRK: the 128 x 128 tiles on and above the diagonal (the diagonal ones compute 36 of "
-                            "their 64 blocks), 2 x 128^2 flop per row and tile; the timer also covers the means gather and "
-                            "the chunk reduction")
                 ent["rows_per_launch"] = rows
             if name == "fit_persistent":  # iterations of the last step's sweep / its launches
                 its = ctx.get_stat("fit_iterations") / max(1, l_ / steps_prof)
@@ -352,9 +383,11 @@ def main():
         kernels[name] = ent
     # HBM traffic per launch from the committed PMC passes of this same command (profiles/run_profiles.sh)
     pmc = {}
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (2, 1)) if os.path.exists(f)), "")
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (3, 2, 1)) if os.path.exists(f)), "")
     kernel_of = {"fit_symv": ("fit_step_kernel",), "fit_persistent": ("fit_flow_kernel",), "pcent": ("pcent_f32_rowres_kernel", "pcent_f32_kernel", "pcent_groups_kernel"),
                  "pair_list": ("pair_list_kernel",), "edge_scatter": ("edge_pass_kernel", "edge_row_reduce_kernel"),
+                 "edge_scatter_wedges": ("wedge_pass_kernel", "wedge_tile_kernel"),
+                 "group_stats": ("group_cov_mfma_kernel", "group_cov_final_kernel", "gather_means_kernel"), "group_eig": ("group_eig_kernel",),
                  "max_pair_dist": ("max_pair_kernel",)}
     if os.path.exists(pmc_file) and args.workload == "headline" and world == 1:
         try:
@@ -365,6 +398,10 @@ def main():
         hit = [k for k in pmc for kn in knames if k == kn or k.startswith(kn + "<")]
         if name in kernels and hit:
             kernels[name]["traffic"] = sum(pmc[k]["hbm_bytes_per_launch"] for k in hit)
+    if "edge_scatter" in kernels:  # what the FIRST score of a resident graph pays on top: the blocked copy of the edge list
+        build_ms = ctx.get_stat("edge_layout_build_us") / 1e3
+        kernels["edge_scatter"]["layout_build_ms"] = build_ms
+        kernels["edge_scatter"]["first_call_ms"] = kernels["edge_scatter"]["avg_launch_ms"] + build_ms
     ranked = sorted((k for k in kernels if "frac" in kernels[k]), key=lambda k: -kernels[k]["total_ms_per_step"])
     dom = ranked[0] if ranked else None
     roofline = None
@@ -375,13 +412,19 @@ def main():
                     "launches": e["launches"],
                     "algorithmic_work_per_launch": e["algorithmic_work_per_launch"], "note": e["note"]}
     out = {
+        # `value`: m A / T with the inputs already resident in HBM when the timed region starts (the bench contract);
+        # `value_incl_h2d`: SURVEY 8(d)'s T, which also pays one upload of the inputs (host arrays -> HBM) per score
         "metric": "edge_alpha_evals_per_sec", "value": value, "unit": "edge-alpha evals/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: ABCD-like n={n} m={g['m']} d={d} C={g['C']}, -l {wl['land']} "
                                f"-f {wl['forced']} -m {wl['method']} --seed {args.seed} --samples-local {wl['samples']}; "
-                               f"landmarks() + wGCL{'_directed' if directed else ''}() in landmark mode, inputs resident in HBM"
-                               + (" (embedding generated on the device)" if dev_emb else ""),
+                               f"landmarks() [clamp + runsplit + aggregation + per-edge scatter"
+                               + (" + N x N landmark-pair matrix and its edge count" if (directed or not args.lazy_landmark_edges)
+                                  else "; the N x N landmark-pair matrix of src/landmarks.jl:433-463 is NOT built (lazy)")
+                               + f"; the landmark edge list stays on the device] + wGCL{'_directed' if directed else ''}() in "
+                               "landmark mode [diameter of the original embedding, sample draws, D, 40-step alpha sweep], inputs "
+                               "resident in HBM" + (" (embedding generated on the device)" if dev_emb else ""),
                    "n": n, "m": g["m"], "d": d, "communities": g["C"], "landmarks": N,
                    "alphas_evaluated": A, "parallelism": f"edges+pair-tiles sharded over {world} GPU(s)"},
         # SURVEY 8(d) puts the H2D copies inside T; the bench contract wants `value` with inputs already resident in HBM.
@@ -400,6 +443,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline and not directed and not dev_emb:
         try:
             out["cpu_baseline"] = cpu_baseline(g, wl)
+            fs = full_size_oracle(args.workload) if args.scale == 1.0 else None
+            if fs:
+                out["cpu_baseline"]["full_size_oracle"] = fs
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "edge-alpha evals/s", "cores": 1, "kind": "port",
                                    "sample": f"failed: {e!r}"}

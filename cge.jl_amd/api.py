@@ -516,7 +516,15 @@ def landmarks(edges, weights, vweights, clusters, comm, embedding, verbose, land
 def _wgcl(directed, edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges,
           init_eweights, init_embed, split, seed, auc_samples, verbose, samples, trace, ctx):
     ctx = ctx or default_context()
-    verbose and print(f"auc_samples: {auc_samples}")
+    if verbose:  # the reference's own lines, in its order (src/divergence.jl:43-52,75 / :296-305,354)
+        e = np.asarray(edges)
+        ie = np.asarray(init_edges) if init_edges is not None else np.zeros((0, 2), np.int64)
+        print(f"auc_samples: {auc_samples}")
+        print(f"Graph has {int(e.max())} vertices and {e.shape[0]} edges")
+        if v_to_l is not None and len(v_to_l) > 0 and ie.size:
+            print(f"Original graph has {int(ie.max())} vertices and {ie.shape[0]} edges")
+        print(f"Graph has {int(np.asarray(comm).max())} communities")
+        print(f"Embedding has {np.asarray(embed).shape[1]} dimensions")
     res = ctx.wgcl(edges, eweights, comm, embed, distances, vweights, init_vweights, v_to_l, init_edges,
                    init_eweights, init_embed, split, seed, auc_samples, verbose, directed, samples)
     sys.stderr.write("." * ctx.last_trace["n_alpha"] + "\n")  # src/divergence.jl:140,255

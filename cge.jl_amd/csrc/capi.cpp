@@ -1,6 +1,7 @@
 // capi.cpp -- the extern "C" surface declared in include/cge_hip.h.
 #include <algorithm>
 #include <cmath>
+#include <future>
 #include <thread>
 #include <unordered_set>
 
@@ -27,6 +28,15 @@ void k_gather_i32(cge_ctx *c, const i32 *arr, const i32 *idx, i64 S, i32 *out);
     return CGE_OK;
 
 static void flush_timers(cge_ctx *c) {
+    if (c->side) { // the side context's kernels are reported with the main context's
+        flush_timers(c->side);
+        for (auto &kv : c->side->timers) {
+            KernelTimer &t = c->timers[kv.first];
+            t.launches += kv.second.launches;
+            t.total_ms += kv.second.total_ms;
+        }
+        c->side->timers.clear();
+    }
     for (auto &kv : c->timers) {
         for (auto &pr : kv.second.pending) {
             float ms = 0.f;
@@ -117,10 +127,15 @@ int cge_create(cge_ctx **out, int device, void *stream) {
 void cge_destroy(cge_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     flush_timers(c);
-    (void)cge_comm_finalize(c);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->side) { // the shadow context of cge_score: own streams and scratch, borrowed views of the resident inputs
+        cge_ctx *sd = c->side;
+        c->side = nullptr;
+        cge_destroy(sd);
+    }
+    if (!c->is_side) (void)cge_comm_finalize(c);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->event_pool.clear();
@@ -197,7 +212,8 @@ int cge_set_graph(cge_ctx *c, const int64_t *src, const int64_t *dst, const doub
         });
     }
     if (bad.load() >= 0) {
-        c->src.release(); c->dst.release(); c->m = 0;
+        c->src.release(); c->dst.release(); c->m = 0; // (the previous resident graph is gone: cge_hip.h says so)
+        c->blocked_ready = false; c->be_nchunks = 0; c->lm_ready = false;
         CGE_THROW(CGE_E_ARG, "edge %lld has a vertex id outside 1..%lld", (long long)bad.load() + 1, (long long)n);
     }
     // weights: all ones (an unweighted list, src/auxilary.jl:105) => neither a device copy nor a host mirror is kept
@@ -425,18 +441,26 @@ static void scatter_wedges(cge_ctx *c, int directed) {
     const i64 N = c->N;
     hipStream_t st = c->stream;
     c->wedges.ensure((size_t)N * N);
-    HIP_CHECK(hipMemsetAsync(c->wedges.p, 0, sizeof(double) * N * N, st));
-    i64 e0 = 0, e1 = c->m;
-    if (c->has_coll) { // edge shard of this rank
-        e0 = c->m * c->coll.rank / c->coll.world;
-        e1 = c->m * (c->coll.rank + 1) / c->coll.world;
-    }
-    k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, c->v2l.p, c->comm.p, N,
-                   c->n_comm_max, directed, c->wedges.p, nullptr);
-    if (c->has_coll) allreduce(c, c->wedges.p, N * N, 0);
-    DevBuf<i64> cnt;
+    DevBuf<i64> &cnt = c->wed_cnt;
     cnt.ensure(1);
-    k_compact_count(c, c->wedges.p, N, directed, cnt.p);
+    const int rank = c->has_coll ? c->coll.rank : 0, world = c->has_coll ? c->coll.world : 1;
+    // the tiled two-pass form on the blocked copy of the edge list (kernels_scatter.hip): the tiles are written whole, the
+    // positive entries counted on the way (one rank) -- else the gather + atomics kernel into a zeroed matrix
+    bool tiled = (c->blocked_ready || (k_edge_scatter_blocked_applies(c, 1) && k_build_blocked_edges(c))) &&
+                 k_wedge_scatter_blocked(c, c->v2l.p, N, c->be_nchunks * rank / world, c->be_nchunks * (rank + 1) / world, directed,
+                                         c->wedges.p, cnt.p);
+    if (!tiled) {
+        HIP_CHECK(hipMemsetAsync(c->wedges.p, 0, sizeof(double) * N * N, st));
+        i64 e0 = 0, e1 = c->m;
+        if (c->has_coll) { // edge shard of this rank
+            e0 = c->m * c->coll.rank / c->coll.world;
+            e1 = c->m * (c->coll.rank + 1) / c->coll.world;
+        }
+        k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, c->v2l.p, c->comm.p, N,
+                       c->n_comm_max, directed, c->wedges.p, nullptr);
+    }
+    if (c->has_coll) allreduce(c, c->wedges.p, N * N, 0);
+    if (!tiled || c->has_coll) k_compact_count(c, c->wedges.p, N, directed, cnt.p);
     HIP_CHECK(hipMemcpyAsync(&c->n_ledges, cnt.p, sizeof(i64), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     c->wedges_ready = true;
@@ -457,17 +481,19 @@ static void scatter_vectC_resident(cge_ctx *c, i64 C, int directed, double *vect
     if (c->has_coll) allreduce(c, vectC, vlen, 0);
 }
 
+// `late_land` (optional): the `land` clamp of src/landmarks.jl:371-376 is being computed elsewhere (the side context of
+// cge_score); it is asked for when the forced per-community phase, which does not depend on it, is over
 static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 land, i64 forced,
-                               int method, int directed, bool need_wedges) {
+                               int method, int directed, bool need_wedges, const std::function<i64()> *late_land = nullptr) {
     check_resident(c, "landmarks");
     if (method < 0 || method > 3) CGE_THROW(CGE_E_ARG, "unknown split method %d", method);
     const i64 d = c->d;
     hipStream_t st = c->stream;
     double t0 = now_ms();
-    land = clamp_to_unique_rows(c, land, &c->lm_truncated);
+    if (!late_land) land = clamp_to_unique_rows(c, land, &c->lm_truncated);
     c->phases.ms["lm_unique"] = now_ms() - t0;
     std::vector<i64> gid;
-    host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, true); // leaves v2l and the landmark index on the device
+    host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, true, late_land); // leaves v2l and the landmark index on the device
     HIP_CHECK(hipStreamSynchronize(st));
     c->phases.ms["landmarks"] = now_ms() - t0;
     t0 = now_ms();
@@ -649,8 +675,8 @@ static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_d
 
 // exact distance of one vertex pair with dist()'s own arithmetic (src/auxilary.jl:14-20)
 static double exact_pair_distance(cge_ctx *c, i64 bi, i64 bj) {
-    DevBuf<i32> pij;
-    DevBuf<double> dd;
+    DevBuf<i32> &pij = c->epd_i;
+    DevBuf<double> &dd = c->epd_d;
     pij.ensure(2);
     dd.ensure(1);
     const i32 h[2] = {(i32)bi, (i32)bj};
@@ -670,6 +696,7 @@ static double resident_diameter(cge_ctx *c, int part, int nparts, i64 *ai, i64 *
     k_max_pair(c, c->Xc.p, c->rnorm.p, c->n, c->ldn, c->dpad, part, nparts, &bv, &bi, &bj);
     c->stat_diameter_path = 1;
     const double hi = bv >= 0.0 ? exact_pair_distance(c, bi, bj) : 0.0;
+    c->stat_hi_i = bi; c->stat_hi_j = bj;
     if (ai) *ai = bi + 1;
     if (aj) *aj = bj + 1;
     return hi;
@@ -683,6 +710,7 @@ static double resident_diameter_lm(cge_ctx *c, const double *mu, const double *l
         i64 bi, bj;
         if (host_diameter_pruned(c, mu, lw, lcomm, C, N, c->h_mem_off, c->h_mem, part, nparts, &d2, &bi, &bj)) {
             c->stat_diameter_path = 2;
+            c->stat_hi_i = bi; c->stat_hi_j = bj;
             return exact_pair_distance(c, bi, bj);
         }
     }
@@ -849,6 +877,142 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
     CGE_CATCH(c)
 }
 
+
+// ---- the side context of cge_score ------------------------------------------------------------------------------
+// In landmark mode three things of a score depend on the RESIDENT INPUTS only, not on the landmarks: the `land` clamp to the
+// number of unique embedding rows (src/landmarks.jl:371-376), the sample draws of the local score
+// (src/divergence.jl:184-194) and `hi` = maximum(full_graph_D) (:104-113), the diameter of the original point set.  The
+// reference computes them in line; here a second host thread drives them on a shadow context (own low-priority streams, own
+// scratch, borrowed views of the resident arrays) while the first runs runsplit -- a chain of short dependent kernels that
+// leaves most of the GPU idle.  The diameter's branch and bound is exact for ANY partition of the vertices (diameter_host.cpp:
+// only the amount of pruning depends on it), so it uses one that needs no landmarks: every cluster cut into runs of <= 256
+// members, reference points = the clusters' centroids.  `hi` itself is re-evaluated from the arg-max pair with dist()'s own
+// arithmetic, as before: the same bits as the landmark-based search (tests: all full-size fixtures).
+static cge_ctx *side_context(cge_ctx *c) {
+    if (!c->side) {
+        cge_ctx *sd = new cge_ctx();
+        c->side = sd; // owned from here on (cge_destroy)
+        sd->is_side = true;
+        sd->device = c->device;
+        sd->n_threads = 1;
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, least));
+        sd->own_stream = true;
+        HIP_CHECK(hipStreamCreateWithPriority(&sd->copy_stream, hipStreamNonBlocking, least));
+        HIP_CHECK(hipEventCreateWithFlags(&sd->copy_ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&sd->copy_done, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->sweep_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->tab_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->stage_ev[i], hipEventDisableTiming));
+    }
+    cge_ctx *sd = c->side;
+    // views are re-taken at every score: an upload may have replaced the buffers since the last one
+    sd->n = c->n; sd->m = c->m; sd->d = c->d; sd->ldn = c->ldn; sd->dpad = c->dpad;
+    sd->unit_weights = c->unit_weights; sd->n_comm_max = c->n_comm_max;
+    sd->Xr.borrow(c->Xr); sd->gmean.borrow(c->gmean); sd->vw.borrow(c->vw); sd->comm.borrow(c->comm);
+    sd->src.borrow(c->src); sd->dst.borrow(c->dst); sd->w.borrow(c->w);
+    sd->opt_diameter = c->opt_diameter; sd->opt_diameter_f32 = c->opt_diameter_f32;
+    sd->profiling = c->profiling; sd->profile_only = c->profile_only;
+    sd->h_Xr.clear(); // (a stale host mirror must not answer for a new embedding; it is fetched on demand)
+    return sd;
+}
+
+static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_directed, SampleSet &smp);
+
+namespace {
+struct SideJob {
+    std::thread th;
+    std::promise<i64> land; // the clamped landmark count (lm_truncated rides in `truncated`)
+    std::future<i64> land_f;
+    int truncated = 0;
+    bool samples_ok = false;
+    int dm_status = 0; // 1 = hi known, 2 = the pruned search declined (the caller takes the serial path), 3 = failed
+    double hi = 0.0, t_total = 0.0;
+    std::string err;
+    ~SideJob() { if (th.joinable()) th.join(); } // (an exception on the main path must not leave the thread running)
+};
+} // namespace
+
+static void side_job_body(cge_ctx *c, cge_ctx *sd, const cge_score_args *a, i64 land, bool want_diameter, SideJob *job) {
+    const double t0 = now_ms();
+    bool land_set = false;
+    try {
+        HIP_CHECK(hipSetDevice(sd->device));
+        sd->phases.ms.clear();
+        // (1) the clamp of `land` (a hash pass over a prefix of the rows, rarely more)
+        {
+            const i64 v = clamp_to_unique_rows(sd, land, &job->truncated);
+            sd->phases.ms["lm_unique"] = now_ms() - t0;
+            job->land.set_value(v);
+            land_set = true;
+        }
+        // (2) the sample draws (rejection against the resident edge list on the device, src/divergence.jl:184-194)
+        try {
+            const double ts = now_ms();
+            make_samples(sd, a->seed, a->auc_samples, a->directed, false, c->smp);
+            HIP_CHECK(hipStreamSynchronize(sd->stream));
+            sd->phases.ms["samples"] = now_ms() - ts;
+            job->samples_ok = true;
+        } catch (const CgeError &) { job->samples_ok = false; } // the main thread repeats the draw and reports the error
+        // (3) the diameter, from the clusters cut into runs of <= 256 members
+        if (want_diameter) {
+            const i64 n = sd->n, d = sd->d, ncl = a->n_clusters, G = 256;
+            const i64 *off = a->clusters_off, *flat = a->clusters_flat;
+            const i64 total = ncl > 0 ? off[ncl] : 0;
+            job->dm_status = 2;
+            bool ok = total == n && ncl >= 1; // an exact cover of the vertices (runsplit asserts it, src/landmarks.jl:343)
+            std::vector<i32> lcomm;
+            if (ok) {
+                sd->h_mem.resize(n);
+                sd->h_mem_off.clear();
+                sd->h_mem_off.push_back(0);
+                for (i64 q = 0; q < ncl && ok; q++) {
+                    const i64 b = off[q], e = off[q + 1];
+                    if (e < b) { ok = false; break; }
+                    for (i64 k = b; k < e; k++) {
+                        if (flat[k] < 1 || flat[k] > n) { ok = false; break; }
+                        sd->h_mem[k] = (i32)(flat[k] - 1);
+                    }
+                    for (i64 g0 = b; g0 < e; g0 += G) {
+                        sd->h_mem_off.push_back((i32)std::min(e, g0 + G));
+                        lcomm.push_back((i32)q);
+                    }
+                }
+            }
+            if (ok) {
+                const i64 Ng = (i64)lcomm.size();
+                hipStream_t st = sd->stream;
+                sd->lm_memoff.ensure(Ng + 1); sd->lm_mem.ensure(n);
+                sd->lemb.ensure((size_t)Ng * d); sd->lweight.ensure(Ng); sd->dii.ensure(Ng); sd->lcomm.ensure(Ng);
+                HIP_CHECK(hipMemcpyAsync(sd->lm_memoff.p, sd->h_mem_off.data(), sizeof(i32) * (Ng + 1), hipMemcpyHostToDevice, st));
+                HIP_CHECK(hipMemcpyAsync(sd->lm_mem.p, sd->h_mem.data(), sizeof(i32) * n, hipMemcpyHostToDevice, st));
+                sd->lm_index_on_device = true;
+                k_landmark_aggregate(sd, sd->Xr.p, sd->vw.p, sd->comm.p, sd->lm_memoff.p, sd->lm_mem.p, Ng, d, sd->lemb.p,
+                                     sd->lweight.p, sd->dii.p, sd->lcomm.p);
+                double d2;
+                i64 bi, bj;
+                if (host_diameter_pruned(sd, sd->lemb.p, sd->lweight.p, lcomm, ncl, Ng, sd->h_mem_off, sd->h_mem, 0, 1, &d2, &bi, &bj)) {
+                    job->hi = exact_pair_distance(sd, bi, bj);
+                    sd->stat_hi_i = bi; sd->stat_hi_j = bj;
+                    job->dm_status = 1;
+                }
+            }
+            sd->phases.ms["diameter_side"] = now_ms() - t0;
+        }
+    } catch (const CgeError &e) {
+        job->dm_status = 3;
+        job->err = e.msg;
+        if (!land_set) job->land.set_exception(std::current_exception());
+    } catch (const std::exception &e) {
+        job->dm_status = 3;
+        job->err = e.what();
+        if (!land_set) job->land.set_exception(std::current_exception());
+    }
+    (void)hipStreamSynchronize(sd->stream);
+    job->t_total = now_ms() - t0;
+}
+
 int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, cge_trace *trace) {
     if (!c || !a || !out || !out_len) return CGE_E_ARG;
     CGE_TRY(c)
@@ -863,7 +1027,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     const bool landmarks = a->land != -1;
     DevBuf<double> &zeros = c->sw_zeros;
     double t0;
-    DevBuf<i32> star;
+    DevBuf<i32> &star = c->s_star;
     auto star_exit = [&](i64 Nv) -> bool { // star-graph guard of wGCL_directed (src/divergence.jl:321-334)
         std::vector<i32> hstar(Nv);
         HIP_CHECK(hipMemcpyAsync(hstar.data(), star.p, sizeof(i32) * Nv, hipMemcpyDeviceToHost, st));
@@ -874,9 +1038,26 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         *out_len = 6;
         return true;
     };
+    SideJob job;
+    bool side_samples = false;
     if (landmarks) {
-        landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed,
-                           directed != 0);
+        // single rank: clamp, sample draws and diameter run beside runsplit on the side context (above)
+        const bool use_side = c->opt_early_diameter && !c->has_coll;
+        if (use_side) {
+            cge_ctx *sd = side_context(c);
+            c->smp.reset();
+            job.land_f = job.land.get_future();
+            job.th = std::thread(side_job_body, c, sd, a, (i64)a->land, c->opt_diameter != 1, &job);
+            const std::function<i64()> late = [&]() {
+                const i64 v = job.land_f.get(); // rethrows what the clamp threw
+                c->lm_truncated = job.truncated;
+                return v;
+            };
+            landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed,
+                               directed != 0 || c->opt_landmark_edges != 0, &late);
+        } else
+            landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed,
+                               directed != 0 || c->opt_landmark_edges != 0);
         const i64 N = c->N, C = c->n_comm_max;
         // wGCL's own `maximum(edges)` / size asserts (src/divergence.jl:41,50): the highest-numbered
         // landmark must carry an edge -- always true when every vertex has positive weight
@@ -894,15 +1075,37 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         t0 = now_ms();
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
         ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.empty() ? nullptr : c->h_w.data();
-        std::vector<i32> lcomm0(N); // community of a landmark = community of any member (landmarks never span two): :427
-        HIP_CHECK(hipMemcpyAsync(lcomm0.data(), c->lcomm.p, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        double hi = resident_diameter_lm(c, c->lemb.p, c->lweight.p, lcomm0, C, N, c->has_coll ? c->coll.rank : 0,
-                                         c->has_coll ? c->coll.world : 1);
-        hi = allreduce_scalar_max(c, hi);
+        double hi = 0.0;
+        bool have_hi = false;
+        if (use_side) {
+            job.th.join();
+            cge_ctx *sd = c->side;
+            for (auto &kv : sd->phases.ms) c->phases.ms[kv.first] = kv.second; // dm_*, samples, lm_unique: concurrent with `landmarks`
+            c->phases.ms["side_total"] = job.t_total;
+            side_samples = job.samples_ok;
+            if (job.dm_status == 1) {
+                hi = job.hi;
+                have_hi = true;
+                c->stat_cand_pairs = sd->stat_cand_pairs;
+                c->stat_cand_tiles = sd->stat_cand_tiles;
+                c->stat_nref = sd->stat_nref;
+                c->stat_hi_i = sd->stat_hi_i; c->stat_hi_j = sd->stat_hi_j;
+                c->stat_diameter_path = 2;
+                c->stat_diameter_side = 1;
+            }
+        }
+        if (!have_hi) { // N > 1, the brute-force option, or the side search declined: from the landmark partition, here
+            c->stat_diameter_side = 0;
+            std::vector<i32> lcomm0(N); // community of a landmark = community of any member (landmarks never span two): :427
+            HIP_CHECK(hipMemcpyAsync(lcomm0.data(), c->lcomm.p, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            hi = resident_diameter_lm(c, c->lemb.p, c->lweight.p, lcomm0, C, N, c->has_coll ? c->coll.rank : 0,
+                                      c->has_coll ? c->coll.world : 1);
+            hi = allreduce_scalar_max(c, hi);
+        }
         ov.hi = hi;
         c->stat_last_hi = hi;
-        c->phases.ms["diameter"] = now_ms() - t0;
+        c->phases.ms["diameter"] = now_ms() - t0; // what the main thread still waited for
     } else {
         const i64 N = c->n, C = c->n_comm_max;
         zeros.ensure(N);
@@ -927,9 +1130,12 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         }
     }
     t0 = now_ms();
-    SampleSet smp;
-    make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
-    c->phases.ms["samples"] = now_ms() - t0;
+    SampleSet &smp = c->smp;
+    if (!side_samples) {
+        smp.reset();
+        make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
+        c->phases.ms["samples"] = now_ms() - t0;
+    }
     t0 = now_ms();
     host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.empty() ? nullptr : c->h_w.data(), c->m, directed, a->split, smp,
                     out, out_len, trace);
@@ -1050,6 +1256,14 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;
     }
+    if (!strcmp(key, "early_diameter")) { // 1 (default): clamp, sample draws and diameter on the side context beside runsplit (single rank); 0: in line
+        c->opt_early_diameter = value != 0;
+        return CGE_OK;
+    }
+    if (!strcmp(key, "landmark_edges")) { // 1: cge_score also builds the landmark-pair matrix / edge count that landmarks() returns
+        c->opt_landmark_edges = value != 0; // (src/landmarks.jl:433-463; the undirected score itself does not read it); 0 (default): on first fetch
+        return CGE_OK;
+    }
     if (!strcmp(key, "fit_persistent_test_timeout")) { // testing: 1 = the persistent fit abandons every launch at once
         c->opt_fit_test_timeout = value != 0;
         return CGE_OK;
@@ -1063,12 +1277,16 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "diameter_candidate_pairs")) *value = c->stat_cand_pairs;
     else if (!strcmp(key, "diameter_candidate_tiles")) *value = c->stat_cand_tiles;
     else if (!strcmp(key, "diameter_refs")) *value = c->stat_nref;
+    else if (!strcmp(key, "diameter_arg_i")) *value = c->stat_hi_i + 1; // the arg-max pair of the last diameter (1-based vertex ids)
+    else if (!strcmp(key, "diameter_arg_j")) *value = c->stat_hi_j + 1;
+    else if (!strcmp(key, "diameter_on_side_context")) *value = c->stat_diameter_side;
     else if (!strcmp(key, "fit_persistent_alphas")) *value = c->stat_fit_persistent;
     else if (!strcmp(key, "fit_iterations")) *value = c->stat_fit_iters;
     else if (!strcmp(key, "fit_persistent_fallbacks")) *value = c->stat_fit_fallbacks;
     else if (!strcmp(key, "landmark_batches")) *value = c->stat_lm_batches;
     else if (!strcmp(key, "landmark_batch_rows")) *value = c->stat_lm_rows;
     else if (!strcmp(key, "landmark_splits")) *value = c->stat_lm_splits;
+    else if (!strcmp(key, "edge_layout_build_us")) *value = c->stat_layout_build_us;
     else if (!strcmp(key, "collective_calls")) *value = c->stat_coll_calls;
     else if (!strcmp(key, "collective_bytes")) *value = c->stat_coll_bytes;
     else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`

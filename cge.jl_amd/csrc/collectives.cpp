@@ -5,8 +5,8 @@
 // all-reduces of 8-byte words; with a communicator set they are issued by the library itself on the ctx stream -- no host
 // synchronisation per call, no callback into the host language, so any host (Julia, C, Python) gets them.  The caller only
 // distributes the 128-byte id of rank 0 (MPI, a file, torch.distributed ...).  librccl is opened with dlopen, so the
-// library loads (and single-GPU runs work) where no RCCL is installed; the hook of cge_set_collectives stays available
-// (it is what the gloo tests on the CPU use).
+// library loads (and single-GPU runs work) on a box whose run-time lacks librccl (the BUILD needs <rccl/rccl.h> for the
+// prototypes); the hook of cge_set_collectives stays available (it is what the gloo tests on the CPU use).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -28,12 +28,16 @@ RcclApi &rccl() {
     if (tried) return api;
     tried = true;
     const char *names[] = {getenv("CGE_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *nm : names) {
-        if (!nm || !*nm) continue;
-        api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (api.lib) break;
-        api.err = dlerror();
-    }
+    // A copy the process has already mapped (torch ships its own librccl) is reused: two RCCL instances in one process
+    // would each bring their own topology detection and proxy threads.  Otherwise the library is loaded privately
+    // (RTLD_LOCAL: its symbols must not be offered to libraries loaded later).
+    for (int pass = 0; pass < 2 && !api.lib; pass++)
+        for (const char *nm : names) {
+            if (!nm || !*nm) continue;
+            api.lib = dlopen(nm, pass == 0 ? (RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL) : (RTLD_NOW | RTLD_LOCAL));
+            if (api.lib) break;
+            if (pass == 1) api.err = dlerror();
+        }
     if (!api.lib) return api;
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -48,14 +49,23 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool borrowed = false; // a view of another context's buffer (the side context of cge_score): never freed here
     DevBuf() {}
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        borrowed = false;
+    }
+    void borrow(const DevBuf &o) {
+        if (p == o.p && n == o.n && borrowed) return;
+        release();
+        p = o.p;
+        n = o.n;
+        borrowed = o.p != nullptr;
     }
     // grow-only allocation (contents are NOT preserved)
     void ensure(size_t count) {
@@ -185,6 +195,23 @@ struct ScoreGraph {
     const double *deg_in = nullptr, *deg_out = nullptr; // directed only
 };
 
+struct SampleSet {
+    i64 S = 0, n_sets = 0;
+    std::vector<i64> pos_idx, neg_i, neg_j, pos_idx2; // 1-based (caller-provided draws, small graphs)
+    // library-drawn samples of a large resident graph stay on the device (0-based, n_sets * S each)
+    bool on_device = false;
+    DevBuf<i32> d_pos, d_ni, d_nj, d_pos2;
+    void reset() { // the device buffers are grow-only scratch: they stay
+        S = n_sets = 0;
+        on_device = false;
+        pos_idx.clear(); neg_i.clear(); neg_j.clear(); pos_idx2.clear();
+    }
+};
+struct DevSamples { // one sample set as the AUC kernels read it (device, 0-based)
+    DevBuf<i32> pi, pj, ni, nj;
+    DevBuf<double> wts, dpos, dneg;
+};
+
 struct cge_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -224,8 +251,10 @@ struct cge_ctx {
     DevBuf<double> be_w, be_wkeys, be_diag; // weights in that order (weighted lists); pass-1 outputs
     DevBuf<i32> be_chunk;               // be_nchunks x {block of u, block of v, first edge, edges}
     i64 be_nchunks = 0;
+    i64 stat_layout_build_us = 0;       // wall time of the last build of the blocked copy (one-off per resident graph)
     int be_per = 16;                    // edges per thread of the edge pass the chunks were cut for (kernels_scatter.hip)
     DevBuf<unsigned short> be_keys, be_runoff;
+    DevBuf<unsigned short> v2l16;       // uint16 landmark of every vertex (padded like comm16): table of the landmark-pair passes
     DevBuf<unsigned> be_base, be_cursor;
     std::vector<double> h_Xr; // host mirror, row-major (cut rules + RSS run on the host)
     std::vector<i32> h_comm;
@@ -314,6 +343,8 @@ struct cge_ctx {
     i64 stat_cand_pairs = 0, stat_cand_tiles = 0; // last pruned run
     int stat_diameter_path = 0;            // 1 brute, 2 pruned
     double stat_last_hi = 0.0;
+    i64 stat_hi_i = -1, stat_hi_j = -1; // its arg-max pair (0-based vertex ids)
+    int stat_diameter_side = 0;         // 1: the last score took `hi` from the side context's search
     i64 stat_nref = 0; // reference points of the last pruned diameter (communities or landmarks)
     // scratch of the batched split engine (landmarks_host.cpp)
     DevBuf<i32> ls_rows, ls_row_task, ls_ct, ls_cb, ls_ce, ls_tco;
@@ -347,6 +378,26 @@ struct cge_ctx {
     DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;
     DevBuf<double> r2_F, r2_ck; // rss2: RSS of every prefix / suffix along sorted z, block checkpoints of the two chains
     i64 r2_rows = 0;            // rows of the batch the rss2 kernels are about to see
+
+    // ---- the side context of cge_score (capi.cpp) ------------------------------------------------
+    // What a landmark-mode score needs besides the landmarks -- the point-set diameter of the ORIGINAL embedding and the
+    // local-score sample draws -- depends on the resident inputs only.  It runs on a second host thread that drives a shadow
+    // context: own (low-priority) streams, own scratch, borrowed views of the resident inputs.  Single rank only (the
+    // exchanges of an N > 1 score must be issued in one order).
+    cge_ctx *side = nullptr;
+    bool is_side = false;
+    int opt_landmark_edges = 0;  // 1: cge_score builds the N x N landmark-pair matrix too (what landmarks() returns)
+    int opt_early_diameter = 1; // 0: the diameter after landmarks(), from the landmark partition, on the main stream (A/B, tests)
+    // grow-only scratch of per-score helpers (no hipMalloc / hipFree inside a scoring call after the first: a hipFree waits
+    // for every stream of the device, the side context's included)
+    DevBuf<i32> epd_i, s_star;
+    DevBuf<double> epd_d;
+    DevBuf<i64> wed_cnt;
+    DevBuf<unsigned> samp_attempt;
+    DevBuf<i32> samp_todo_a, samp_todo_b, samp_hit;
+    DevBuf<unsigned long long> samp_table, samp_count;
+    SampleSet smp;                 // library-drawn samples of the running score
+    std::vector<std::unique_ptr<DevSamples>> dsets; // their device form (wgcl_host.cpp)
 
     // ---- profiling -------------------------------------------------------------------------
     bool profiling = false;
@@ -476,7 +527,8 @@ void k_landmark_aggregate(cge_ctx *c, const double *Xr, const double *vw, const 
 bool k_edge_scatter_blocked_applies(const cge_ctx *c, i64 C);
 bool k_build_blocked_edges(cge_ctx *c);
 void k_edge_scatter_blocked(cge_ctx *c, i64 c0, i64 c1, i64 C, int directed, double *vectC);
-void k_edge_scatter_blocked_init();
+// the N x N landmark-pair matrix by the tiled two-pass form (kernels_scatter.hip); false: does not apply
+bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, int directed, double *wedges, i64 *positive);
 #define CGE_COMM16_PAD 32768 // the uint16 community table is padded to a multiple of the edge pass's vertex block
 void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 e0, i64 e1, const i32 *v2l,
                     const i32 *comm, i64 N, i64 C, int directed, double *wedges, double *vectC);
@@ -533,6 +585,7 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
                           const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant, int *dev_flags = nullptr,
                           bool *enqueued_only = nullptr);
+void k_fit_verdict(cge_ctx *c, const int *flags, int async, double *out); // 1.0 when an enqueued fit was abandoned
 void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
                 double delta, int k, unsigned long long *fring, int *done, int *iters);
 // the same iteration over the upper 64 x 64 tiles only (kernels_fitp.hip): half the matrix traffic
@@ -558,20 +611,14 @@ void k_mark_edge_hits(cge_ctx *c, const i32 *src, const i32 *dst, i64 m, int dir
 // ---- host modules -----------------------------------------------------------------------------
 // landmarks_host.cpp
 void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
-                   std::vector<i64> &group_ids /*0-based*/, bool want_index = false); // also fills c->v2l / lm_mem / lm_memoff (device)
+                   std::vector<i64> &group_ids /*0-based*/, bool want_index = false, // also fills c->v2l / lm_mem / lm_memoff (device)
+                   const std::function<i64()> *late_nland = nullptr); // nland is asked for when the forced phase is over
 void host_eig_top(const double *A, i64 d, double *v); // largest-eigenvalue eigenvector, sign: max |.| component > 0
 // diameter_host.cpp
 bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const std::vector<i32> &lcomm, i64 C, i64 N,
                           const std::vector<i32> &mem_off, const std::vector<i32> &mem, int part, int nparts,
                           double *best_d2, i64 *bi, i64 *bj);
 // wgcl_host.cpp
-struct SampleSet {
-    i64 S = 0, n_sets = 0;
-    std::vector<i64> pos_idx, neg_i, neg_j, pos_idx2; // 1-based (caller-provided draws, small graphs)
-    // library-drawn samples of a large resident graph stay on the device (0-based, n_sets * S each)
-    bool on_device = false;
-    DevBuf<i32> d_pos, d_ni, d_nj, d_pos2;
-};
 // ---- counter-based RNG of the sampler (splitmix64 finaliser over a 4-word counter): the same stream on host and device
 __host__ __device__ inline uint64_t cge_sm64(uint64_t x) {
     x += 0x9e3779b97f4a7c15ULL;

@@ -855,9 +855,9 @@ void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed
     hipStream_t st = c->stream;
     const unsigned nb = (unsigned)((S + 255) / 256);
     hipLaunchKernelGGL(draw_pos_kernel, dim3(nb), dim3(256), 0, st, (uint64_t)seed, (uint64_t)stream_id, S, m, d_pos);
-    DevBuf<unsigned> attempt;
-    DevBuf<i32> todo_a, todo_b, hit;
-    DevBuf<unsigned long long> table, count;
+    DevBuf<unsigned> &attempt = c->samp_attempt; // grow-only scratch of the context
+    DevBuf<i32> &todo_a = c->samp_todo_a, &todo_b = c->samp_todo_b, &hit = c->samp_hit;
+    DevBuf<unsigned long long> &table = c->samp_table, &count = c->samp_count;
     attempt.ensure(S); todo_a.ensure(S); todo_b.ensure(S); count.ensure(1);
     HIP_CHECK(hipMemsetAsync(attempt.p, 0, sizeof(unsigned) * S, st));
     i64 cnt = S;
@@ -920,4 +920,16 @@ __global__ void gather_i32_kernel(const i32 *__restrict__ arr, const i32 *__rest
 void k_gather_i32(cge_ctx *c, const i32 *arr, const i32 *idx, i64 S, i32 *out) {
     if (S <= 0) return;
     hipLaunchKernelGGL(gather_i32_kernel, dim3(grid_for(S, 256)), dim3(256), 0, c->stream, arr, idx, S, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// N > 1 with the local-score tallies split over the ranks: the verdict of an enqueued persistent fit {converged,
+// iterations, failed} as ONE double next to the tallies, so that the all-reduce(sum) of the tallies carries it and every
+// rank redoes an alpha when any rank's fit was abandoned (wgcl_host.cpp).  `async` = 0: this alpha's fit was waited for
+// (or ran launch by launch): nothing to report.
+__global__ void fit_verdict_kernel(const int *__restrict__ flags, int async, double *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (async && (flags[2] != 0 || flags[0] == 0)) ? 1.0 : 0.0;
+}
+void k_fit_verdict(cge_ctx *c, const int *flags, int async, double *out) {
+    hipLaunchKernelGGL(fit_verdict_kernel, dim3(1), dim3(64), 0, c->stream, flags, async, out);
 }

@@ -65,6 +65,8 @@ bool k_build_blocked_edges(cge_ctx *c) {
     const i64 nbu = (n + (1 << EB_UBITS) - 1) >> EB_UBITS, nbv = (n + (1 << EB_VBITS) - 1) >> EB_VBITS;
     if (nbu * nbv > 32768 || m <= 0 || m >= (1LL << 31)) return false; // the sort key (tile, u mod 131072) has 32 bits
     hipStream_t st = c->stream;
+    HIP_CHECK(hipStreamSynchronize(st)); // so that the wall time below is the build's own (stat "edge_layout_build_us")
+    const double t_build0 = now_ms();
     const i64 T = nbu * nbv;
     // 16 edges per thread: with 20 or 24 the edge pass no longer fits 64 registers (two workgroups per CU) and spills
     const int per_thread = 16;
@@ -107,6 +109,7 @@ bool k_build_blocked_edges(cge_ctx *c) {
     if (!c->unit_weights) c->be_wkeys.ensure(m + 64);
     HIP_CHECK(hipStreamSynchronize(st));
     c->blocked_ready = true;
+    c->stat_layout_build_us = (i64)((now_ms() - t_build0) * 1e3);
     return true;
 }
 
@@ -367,7 +370,251 @@ void k_edge_scatter_blocked(cge_ctx *c, i64 c0, i64 c1, i64 C, int directed, dou
 #undef EB_GO2
 }
 
-void k_edge_scatter_blocked_init() {}
+
+// ======================================================================================================================
+// The N x N landmark-pair matrix of landmarks() (src/landmarks.jl:433-451: wedges[min(l_u,l_v), max] += w, directed
+// wedges[l_u, l_v] += w) in the same blocked two-pass form.  What changes against vect_C: a "row" of the output is N
+// doubles wide (N = 4000 ... 12000), so pass 2 keeps a TILE of R consecutive rows in LDS (R * N counters, 64 KB), one
+// workgroup per tile over ALL chunks -- the tile is then written out whole with plain coalesced stores: no memset of the
+// N x N output, no atomic ever reaches memory, and the count of positive entries (the length of the landmark edge list,
+// :454-461) falls out of the same sweep.  Pass 1 groups a chunk's keys by tile; the 16-bit key is (row inside the tile,
+// column).  The landmark table is uint16 (N <= 65535), built from v2l after runsplit.
+// ======================================================================================================================
+__global__ void wedge_table_kernel(const i32 *__restrict__ v2l, i64 n, i64 npad, unsigned short *__restrict__ t16) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += stride) t16[i] = i < n ? (unsigned short)v2l[i] : 0;
+}
+
+// LDS: sv (32768 uint16 landmarks of the target block; reused as the key staging area) | cnt[ntpad] u32 | wave sums, total
+template <int EB_PER, bool WEIGHTED, bool DIRECTED>
+__global__ __launch_bounds__(EB_THREADS) void wedge_pass_kernel(const unsigned *__restrict__ bedge, const double *__restrict__ bw,
+                                                                const i32 *__restrict__ chunks, int chunk0,
+                                                                const unsigned short *__restrict__ tab16, int ntile, int ntpad,
+                                                                int rshift, int colbits, unsigned short *__restrict__ keys,
+                                                                double *__restrict__ wkeys, unsigned short *__restrict__ runoff) {
+    constexpr int VBLOCK = 1 << EB_VBITS;
+    static_assert(VBLOCK >= EB_THREADS * EB_PER, "the key staging area reuses the slice");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned short *sv = (unsigned short *)lds;
+    unsigned short *stage = sv;
+    unsigned *cnt = (unsigned *)(lds + 2 * VBLOCK);
+    unsigned *wave_sums = cnt + ntpad;
+    unsigned *misc = wave_sums + 16;
+    const int tid = threadIdx.x, wg = blockIdx.x;
+    const i32 *ch = chunks + 4 * (i64)(chunk0 + wg);
+    const int bu = ch[0], bv = ch[1], start = ch[2], len = ch[3];
+    unsigned packed[EB_PER];
+    double wv[WEIGHTED ? EB_PER : 1];
+#pragma unroll
+    for (int k = 0; k < EB_PER; k++) {
+        const int e = tid + k * EB_THREADS;
+        const int ec = e < len ? e : len - 1;
+        packed[k] = bedge[start + ec];
+        if (WEIGHTED) wv[k] = bw[start + ec];
+    }
+    {
+        const uint4 *gv = (const uint4 *)(tab16 + (i64)bv * VBLOCK);
+        uint4 *lv = (uint4 *)sv;
+        for (int i = tid; i < VBLOCK / 8; i += EB_THREADS) lv[i] = gv[i];
+    }
+    for (int k = tid; k < ntpad; k += EB_THREADS) cnt[k] = 0u;
+    const unsigned short *lu_tab = tab16 + ((i64)bu << EB_UBITS);
+    unsigned lus[EB_PER];
+#pragma unroll
+    for (int k = 0; k < EB_PER; k++) lus[k] = lu_tab[packed[k] >> EB_VBITS]; // ascending addresses across a wave
+    __syncthreads();
+    const unsigned rmask = (1u << rshift) - 1u;
+#pragma unroll
+    for (int k = 0; k < EB_PER; k++) { // (tile << 16) | key, key = (row inside the tile) << colbits | column
+        const int e = tid + k * EB_THREADS;
+        unsigned lu = lus[k], lv = sv[packed[k] & (VBLOCK - 1)];
+        if (!DIRECTED && lu > lv) { const unsigned t = lu; lu = lv; lv = t; }
+        if (e < len) {
+            packed[k] = ((lu >> rshift) << 16) | ((lu & rmask) << colbits) | lv;
+            atomicAdd(&cnt[lu >> rshift], 1u);
+        } else
+            packed[k] = EB_NONE;
+    }
+    __syncthreads(); // all look-ups are done: sv becomes the staging area
+    // tile offsets inside the chunk's own piece of the key array (a thread owns `ept` consecutive tiles)
+    const int ept = ntpad / EB_THREADS;
+    unsigned mine = 0;
+    for (int q = 0; q < ept; q++) mine += cnt[tid * ept + q];
+    unsigned off = block_exclusive_scan<EB_THREADS>(mine, wave_sums, &misc[0]);
+    unsigned short *ro = runoff + (i64)wg * (ntile + 1);
+    for (int q = 0; q < ept; q++) {
+        const int r = tid * ept + q;
+        const unsigned v = cnt[r];
+        cnt[r] = off;
+        if (r < ntile) ro[r] = (unsigned short)off;
+        off += v;
+    }
+    __syncthreads();
+    const unsigned total = misc[0];
+    if (tid == 0) ro[ntile] = (unsigned short)total;
+#pragma unroll
+    for (int k = 0; k < EB_PER; k++) {
+        if (packed[k] != EB_NONE) {
+            const unsigned pos = atomicAdd(&cnt[packed[k] >> 16], 1u);
+            stage[pos] = (unsigned short)(packed[k] & 0xFFFFu);
+            if (WEIGHTED) wkeys[start + pos] = wv[k];
+        }
+    }
+    __syncthreads();
+    for (unsigned k = tid; k < total; k += EB_THREADS) keys[start + k] = stage[k]; // coalesced
+}
+
+// One workgroup per tile of R = 1 << rshift rows.  Thread t fetches where chunk (base + t) keeps its keys of the tile; 8 lanes
+// then share a chunk and read its (contiguous) keys as aligned 16-byte windows, all windows of 1024 chunks in flight; the
+// keys are counted (unit weights) / summed (weighted) into the LDS tile, which is finally written out whole.
+#define WT_THREADS 1024
+template <bool WEIGHTED>
+__global__ __launch_bounds__(WT_THREADS) void wedge_tile_kernel(const unsigned short *__restrict__ keys, const double *__restrict__ wkeys,
+                                                                const unsigned short *__restrict__ runoff,
+                                                                const i32 *__restrict__ chunks, int chunk0, int nwg, int ntile, int N,
+                                                                int rshift, int colbits, double *__restrict__ wedges,
+                                                                unsigned long long *__restrict__ positive) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int R = 1 << rshift, tid = threadIdx.x, tile = blockIdx.x;
+    double *accd = (double *)lds;
+    unsigned *accu = (unsigned *)lds;
+    unsigned *saddr = (unsigned *)(lds + (size_t)R * N * (WEIGHTED ? 8 : 4)), *slen = saddr + WT_THREADS;
+    unsigned *red = slen + WT_THREADS;
+    for (int k = tid; k < R * N; k += WT_THREADS) {
+        if (WEIGHTED) accd[k] = 0.0; else accu[k] = 0u;
+    }
+    const unsigned cmask = (1u << colbits) - 1u;
+    const int g = tid >> 3, l8 = tid & 7;
+    for (int base = 0; base < nwg; base += WT_THREADS) {
+        const int wg = base + tid;
+        unsigned len = 0, a = 0;
+        if (wg < nwg) {
+            const unsigned short *ro = runoff + (i64)wg * (ntile + 1) + tile;
+            const unsigned b = ro[0], e = ro[1];
+            a = (unsigned)chunks[4 * (i64)(chunk0 + wg) + 2] + b;
+            len = e - b;
+        }
+        __syncthreads(); // the previous batch's look-ups are done (and, first trip, the tile is zeroed)
+        saddr[tid] = a;
+        slen[tid] = len;
+        __syncthreads();
+        unsigned A[8], L[8], maxwin = 0; // window = 8 keys = one aligned 16-byte load
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            A[st] = saddr[st * 128 + g];
+            L[st] = slen[st * 128 + g];
+            maxwin = max(maxwin, L[st] ? ((A[st] & 7u) + L[st] + 7u) >> 3 : 0u);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) maxwin = max(maxwin, (unsigned)__shfl_xor((int)maxwin, off)); // wave-uniform
+        for (unsigned w0 = 0; w0 < maxwin; w0 += 8) {
+            uint4 K[8];
+#pragma unroll
+            for (int st = 0; st < 8; st++) {
+                const unsigned nwin = L[st] ? ((A[st] & 7u) + L[st] + 7u) >> 3 : 0u, w = w0 + l8;
+                K[st] = *(const uint4 *)(keys + ((A[st] & ~7u) + 8u * (w < nwin ? w : 0u))); // the array has a readable tail
+            }
+#pragma unroll
+            for (int st = 0; st < 8; st++) {
+                const unsigned p0 = (A[st] & ~7u) + 8u * (w0 + l8), lo = A[st], hi = A[st] + L[st];
+                const unsigned kw[4] = {K[st].x, K[st].y, K[st].z, K[st].w};
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const unsigned p = p0 + i, key = (kw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                    if (p >= lo && p < hi) {
+                        const unsigned cell = (key >> colbits) * (unsigned)N + (key & cmask);
+                        if (WEIGHTED) unsafeAtomicAdd(&accd[cell], wkeys[p]);
+                        else atomicAdd(&accu[cell], 1u);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // the tile, whole: rows [tile * R, ...) of the N x N output; entries > 0 are the landmark edges (src/landmarks.jl:461)
+    const i64 row0 = (i64)tile * R;
+    const int rows = min(R, N - (int)row0);
+    unsigned npos = 0;
+    for (int k = tid; k < rows * N; k += WT_THREADS) {
+        const double v = WEIGHTED ? accd[k] : (double)accu[k];
+        wedges[row0 * N + k] = v;
+        npos += v > 0.0 ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) npos += (unsigned)__shfl_xor((int)npos, off);
+    if ((tid & 63) == 0) red[tid >> 6] = npos;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < WT_THREADS / 64; w++) t += red[w];
+        if (t) atomicAdd(positive, t);
+    }
+}
+
+// geometry of the tiled form for N landmarks; false: it does not apply (the caller uses the gather + atomics kernel)
+static bool wedge_geometry(const cge_ctx *c, i64 N, i64 nchunks, int *rshift, int *colbits, i64 *ntile, size_t *lds2) {
+    static const bool off = getenv("CGE_SCATTER_GATHER") != nullptr;
+    if (off || N < 1 || N > 65535 || nchunks <= 0) return false;
+    const size_t elt = c->unit_weights ? 4 : 8, fixed = sizeof(unsigned) * (2 * WT_THREADS + 32);
+    int cb = 1;
+    while (((i64)1 << cb) < N) cb++;
+    int rs = 0;
+    while (rs + 1 + cb <= 16 && ((size_t)2 << rs) * N * elt <= (size_t)64 * 1024) rs++; // 64 KB tiles: two workgroups per CU
+    if (((size_t)1 << rs) * N * elt + fixed > (size_t)150 * 1024) return false;
+    const i64 nt = (N + ((i64)1 << rs) - 1) >> rs;
+    if (nchunks * (nt + 1) > ((i64)1 << 27)) return false; // the per-chunk tile offsets would outgrow what pass 2 can gather
+    *rshift = rs; *colbits = cb; *ntile = nt;
+    *lds2 = ((size_t)1 << rs) * N * elt + fixed;
+    return true;
+}
+
+// wedges (N x N, row-major [a * N + b]) and *positive (device counter) from chunks [c0, c1) of the blocked edge list;
+// returns false when the tiled form does not apply.  v2l: 0-based landmark of every vertex (device).
+bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, int directed, double *wedges, i64 *positive) {
+    const i64 nwg = c1 - c0;
+    int rshift, colbits;
+    i64 ntile;
+    size_t lds2;
+    if (!c->blocked_ready || !wedge_geometry(c, N, std::max<i64>(nwg, 1), &rshift, &colbits, &ntile, &lds2)) return false;
+    hipStream_t st = c->stream;
+    HIP_CHECK(hipMemsetAsync(positive, 0, sizeof(i64), st));
+    if (nwg <= 0) { // an empty shard still owes zeros
+        HIP_CHECK(hipMemsetAsync(wedges, 0, sizeof(double) * N * N, st));
+        return true;
+    }
+    const i64 npad = (c->n + CGE_COMM16_PAD - 1) / CGE_COMM16_PAD * CGE_COMM16_PAD;
+    c->v2l16.ensure(npad);
+    c->be_keys.ensure(c->m + 64);
+    if (!c->unit_weights) c->be_wkeys.ensure(c->m + 64);
+    c->be_runoff.ensure((size_t)nwg * (ntile + 1));
+    ScopedKernelTimer t(c, "edge_scatter_wedges");
+    hipLaunchKernelGGL(wedge_table_kernel, dim3(grid_for(npad, 256)), dim3(256), 0, st, v2l, c->n, npad, c->v2l16.p);
+    const int ntpad = (int)((ntile + EB_THREADS - 1) / EB_THREADS * EB_THREADS);
+    const size_t lds1 = (size_t)2 * (1 << EB_VBITS) + sizeof(unsigned) * ((size_t)ntpad + 18);
+    const bool wt = !c->unit_weights;
+#define WG_GO(W, D)                                                                                                        \
+    do {                                                                                                                   \
+        auto k1 = wedge_pass_kernel<16, W, D>;                                                                              \
+        auto k2 = wedge_tile_kernel<W>;                                                                                     \
+        static bool attr = false;                                                                                          \
+        if (!attr) {                                                                                                       \
+            (void)hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+            (void)hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(k1, dim3((unsigned)nwg), dim3(EB_THREADS), lds1, st, c->be_edge.p, c->be_w.p, c->be_chunk.p, (int)c0, \
+                           c->v2l16.p, (int)ntile, ntpad, rshift, colbits, c->be_keys.p, c->be_wkeys.p, c->be_runoff.p);    \
+        hipLaunchKernelGGL(k2, dim3((unsigned)ntile), dim3(WT_THREADS), lds2, st, c->be_keys.p, c->be_wkeys.p, c->be_runoff.p, \
+                           c->be_chunk.p, (int)c0, (int)nwg, (int)ntile, (int)N, rshift, colbits, wedges,                   \
+                           (unsigned long long *)positive);                                                                \
+    } while (0)
+    if (wt && directed) WG_GO(true, true);
+    else if (wt) WG_GO(true, false);
+    else if (directed) WG_GO(false, true);
+    else WG_GO(false, false);
+#undef WG_GO
+    return true;
+}
 
 bool k_edge_scatter_blocked_applies(const cge_ctx *c, i64 C) {
     static const bool off = getenv("CGE_SCATTER_GATHER") != nullptr; // A/B switch: force the gather + atomics kernel

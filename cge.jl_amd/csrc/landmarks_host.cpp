@@ -1186,7 +1186,7 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
 // and the landmark -> members index c->lm_memoff / c->lm_mem (ascending inside a landmark), mirrored in
 // c->h_mem_off / c->h_mem when `want_index`.
 void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
-                   std::vector<i64> &group_ids, bool want_index) {
+                   std::vector<i64> &group_ids, bool want_index, const std::function<i64()> *late_nland) {
     const i64 n = c->n, d = c->d;
     hipStream_t st = c->stream;
     if (!c->Xr.p || c->Xr.n < (size_t)(n * d) || (i64)c->h_vw.size() != n)
@@ -1374,6 +1374,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     delete pmerge;
     // ---- global phase (:316-335) ----------------------------------------------------------------------------
     {
+        if (late_nland) nland = (*late_nland)(); // the `land` clamp (src/landmarks.jl:371-376), computed beside the forced phase
         std::vector<Heap *> hs{&H};
         std::vector<i64> tg{nland};
         advance_heaps(c, hs, tg, method, pool, true);

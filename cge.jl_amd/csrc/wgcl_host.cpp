@@ -69,12 +69,6 @@ void host_draw_samples(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed,
 bool sampler_uses_device(const cge_ctx *c) { return (double)c->n * (double)(c->n - 1) > 33554432.0; }
 
 // ------------------------------------------------------------------------------------------------
-namespace {
-struct DevSamples { // one sample set on the device (0-based)
-    DevBuf<i32> pi, pj, ni, nj;
-    DevBuf<double> wts, dpos, dneg;
-};
-} // namespace
 
 // Endpoints / weights of sampled edge rows are gathered on the host from small D2H reads of the
 // resident edge arrays (S entries), so no host mirror of the edge list is needed.
@@ -100,7 +94,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     T1.ensure(N); T2.ensure(N); S1.ensure(N); S2.ensure(N);
     rowbins.ensure((size_t)N * C);
     vectB.ensure(vlen);
-    scal.ensure(4 * CGE_PARTIAL_BLOCKS + 16); // per alpha: AUC block tallies, JS block sums (two modes), the fit's verdict
+    scal.ensure(4 * CGE_PARTIAL_BLOCKS + 18); // per alpha: AUC block tallies (+ the shared verdict), JS block sums (two modes), the fit's verdict
     lohi.ensure(2);
     fitstate.ensure(4);
     flags.ensure(4);
@@ -216,10 +210,11 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     const i32 *e_src = landmarks ? orig->src : ex_src, *e_dst = landmarks ? orig->dst : ex_dst;
     const double *e_hw = landmarks ? orig->h_w : ex_hw;
     const i64 e_m = landmarks ? orig->m : ex_m;
-    std::vector<DevSamples> dsets(smp.n_sets);
+    std::vector<std::unique_ptr<DevSamples>> &dsets = c->dsets; // grow-only buffers kept by the context
+    while ((i64)dsets.size() < smp.n_sets) dsets.emplace_back(new DevSamples());
     if (smp.on_device) { // library-drawn samples of the resident graph: everything stays on the device
         for (i64 t = 0; t < smp.n_sets; t++) {
-            DevSamples &ds = dsets[t];
+            DevSamples &ds = *dsets[t];
             ds.pi.ensure(S); ds.pj.ensure(S); ds.ni.ensure(S); ds.nj.ensure(S); ds.wts.ensure(S);
             const i32 *pos = smp.d_pos.p + t * S;
             const i32 *pos_pairs = (directed && !landmarks && smp.d_pos2.p) ? smp.d_pos2.p + t * S : pos; // the overwriting draw (:510)
@@ -236,7 +231,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         std::vector<i64> rows0(S);
         std::vector<i32> hs, hd, hs2, hd2;
         for (i64 t = 0; t < smp.n_sets; t++) {
-            DevSamples &ds = dsets[t];
+            DevSamples &ds = *dsets[t];
             for (i64 k = 0; k < S; k++) {
                 rows0[k] = smp.pos_idx[t * S + k] - 1;
                 if (rows0[k] < 0 || rows0[k] >= e_m) CGE_THROW(CGE_E_ARG, "positive sample row out of range");
@@ -277,7 +272,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     }
 
     if (relabel && !landmarks) // the sampled pairs index the score graph: into the new numbering (GD is a full symmetric matrix here)
-        for (DevSamples &ds : dsets) {
+        for (i64 t = 0; t < smp.n_sets; t++) {
+            DevSamples &ds = *dsets[t];
             k_remap_i32(c, ds.pi.p, d_old2new.p, S);
             k_remap_i32(c, ds.pj.p, d_old2new.p, S);
             k_remap_i32(c, ds.ni.p, d_old2new.p, S);
@@ -300,11 +296,13 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     // fit's verdict of an alpha land in slot (alpha index mod 2).
     struct AlphaSlot {
         bool fit_async = false, did_auc = false, did_div = false;
+        bool shared_verdict = false; // N > 1, tallies split: the verdict of the fit travelled with the all-reduced tallies
         int t0_par = 0;  // the half of TT that held T_0 of this alpha
         i64 iters = 0;
     } slots[2];
-    constexpr i64 RES_AUC = 0, RES_JS = 2 * CGE_PARTIAL_BLOCKS, RES_FIT = 4 * CGE_PARTIAL_BLOCKS, RES_LEN = RES_FIT + 2,
-                  RES_STRIDE = RES_FIT + 16;
+    // RES_VERD sits right behind the tallies: one all-reduce(sum) covers both (the slot after it only keeps RES_JS 16-byte aligned)
+    constexpr i64 RES_AUC = 0, RES_VERD = 2 * CGE_PARTIAL_BLOCKS, RES_JS = RES_VERD + 2, RES_FIT = RES_JS + 2 * CGE_PARTIAL_BLOCKS,
+                  RES_LEN = RES_FIT + 2, RES_STRIDE = RES_FIT + 16;
     c->pin_scal.ensure(2 * RES_STRIDE);
     const int fit_variant = c->opt_fit_persistent == 3 ? 0 : (c->opt_fit_persistent == 4 ? 1 : 2);
     auto enqueue_alpha = [&](i64 ia, bool want_auc, bool want_div) {
@@ -424,7 +422,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             }
         }
         if (want_auc) {
-            const DevSamples &ds = dsets[smp.n_sets == 1 ? 0 : ia - 1];
+            const DevSamples &ds = *dsets[smp.n_sets == 1 ? 0 : ia - 1];
             // N > 1 with many samples: rank r tallies the samples [S r / W, S (r + 1) / W) and the block tallies
             // are summed over the ranks -- the same array on every rank afterwards, so all ranks take the same early stops
             const i64 s0 = shard_samples ? S * c->coll.rank / c->coll.world : 0;
@@ -436,7 +434,16 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             else
                 k_auc_exact(c, GD.p, Ta, Tb, N, ds.pi.p + s0, ds.pj.p + s0, ds.ni.p + s0, ds.nj.p + s0, ds.wts.p + s0, s1 - s0,
                             nullptr, scal.p + RES_AUC);
-            if (shard_samples) cge_allreduce_dev(c, scal.p + RES_AUC, 2 * CGE_PARTIAL_BLOCKS, 0);
+        }
+        if (shard_samples) {
+            // The verdict of an enqueued fit is rank-local (a hand-off may time out on one rank only), but a redo re-issues
+            // this exchange and changes what the rank enqueues from then on: the ranks must take it together.  So the verdict
+            // rides along as one more summand -- at EVERY alpha of a sweep with split tallies, with or without a local score --
+            // and every rank redoes the alpha when any rank's fit was abandoned: the ranks never leave lock-step.
+            k_fit_verdict(c, (const int *)(scal.p + RES_FIT), sl.fit_async ? 1 : 0, scal.p + RES_VERD);
+            sl.shared_verdict = true;
+            if (want_auc) cge_allreduce_dev(c, scal.p + RES_AUC, 2 * CGE_PARTIAL_BLOCKS + 1, 0);
+            else cge_allreduce_dev(c, scal.p + RES_VERD, 1, 0);
         }
         if (want_div) {
             k_bvec(c, GD.p, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
@@ -471,11 +478,14 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             next_enqueue = ia + 2;
         }
         HIP_CHECK(hipEventSynchronize(c->sweep_ev[ia & 1]));
+        const bool peer_failed = sl.shared_verdict && c->pin_scal.p[RES_STRIDE * (ia & 1) + RES_VERD] != 0.0;
+        if (peer_failed && !sl.fit_async) // cannot happen while the ranks are in lock-step (they enqueue the same form of fit)
+            CGE_THROW(CGE_E_COLLECTIVE, "another rank abandoned a persistent fit this rank did not enqueue: the ranks diverged");
         if (sl.fit_async) {
             const int *hf = (const int *)(c->pin_scal.p + RES_STRIDE * (ia & 1) + RES_FIT);
-            if (hf[2] || !hf[0]) { // a wait timed out: drain what was enqueued behind it and redo this alpha from its T_0
-                HIP_CHECK(hipStreamSynchronize(st)); // (still in place) with one launch per iteration, as every later alpha
-                note_fit_fallback(c);
+            if (hf[2] || !hf[0] || peer_failed) { // a wait timed out (here or on another rank): drain what was enqueued behind
+                HIP_CHECK(hipStreamSynchronize(st)); // it and redo this alpha from its T_0 (still in place) with one launch per
+                note_fit_fallback(c);                // iteration, as every later alpha
                 if (directed) use_persistent_dir = false;
                 else {
                     use_persistent = false;

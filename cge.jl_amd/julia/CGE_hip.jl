@@ -132,6 +132,13 @@ function _wgcl(directed::Bool, edges, eweights, comm, embed, distances, vweights
                init_edges, init_eweights, init_embed, split, seed, auc_samples, verbose)
     c = ctx()
     m, mi = size(edges, 1), size(init_edges, 1)
+    if verbose                                           # the reference's own lines (src/divergence.jl:43-52,75)
+        println("auc_samples: $auc_samples")
+        println("Graph has $(maximum(edges)) vertices and $m edges")
+        !isempty(v_to_l) && mi > 0 && println("Original graph has $(maximum(init_edges)) vertices and $mi edges")
+        println("Graph has $(maximum(comm)) communities")
+        println("Embedding has $(size(embed, 2)) dimensions")
+    end
     out, olen = zeros(7), Ref{Cint}(7)
     GC.@preserve edges eweights comm embed distances vweights init_vweights v_to_l init_edges init_eweights init_embed begin
         a = WgclArgs(pointer(edges), pointer(edges, m + 1), pointer(eweights), m,

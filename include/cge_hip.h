@@ -19,9 +19,12 @@
  *     (outputs excepted); outputs are caller-allocated;
  *   - every function returns an int status (0 = ok, <0 = error; cge_last_error() has the text);
  *     nothing throws or exits across the boundary;
- *   - a cge_ctx is bound to ONE GPU and is not re-entrant: one host thread drives it.  Multi-GPU
- *     runs are one process (one ctx) per GPU; the cross-GPU exchange steps go through the
- *     cge_collectives hooks (RCCL via torch.distributed in the Python host).
+ *   - a cge_ctx is bound to ONE GPU and is not re-entrant: one host thread drives it (cge_score
+ *     itself starts a second host thread on a shadow context of its own; nothing of that crosses
+ *     the boundary).  Multi-GPU runs are one process (one ctx) per GPU; the cross-GPU exchange
+ *     steps are issued by the library itself on an RCCL communicator (cge_rccl_unique_id +
+ *     cge_comm_init_rccl: ncclAllReduce on the ctx stream), or, where no RCCL communicator can be
+ *     made (gloo tests, two ranks on one GPU), go through the cge_collectives hook.
  *   - there is NO CPU fallback: without a gfx950 device cge_create fails with CGE_E_HIP.
  */
 #ifndef CGE_HIP_H
@@ -91,7 +94,9 @@ int cge_comm_finalize(cge_ctx *ctx);
 /* ---- resident inputs (the ORIGINAL graph; uploaded once, H2D + layout change) ---------------
  * Calling cge_set_graph with another vertex count drops the resident embedding and vertex data (they were sized for the
  * old vertex set); cge_landmarks_run / cge_score check that all resident inputs agree and fail with CGE_E_ARG otherwise.
- * cge_wgcl in exact mode (empty v_to_l) makes ITS graph the resident one (the sampler rejects against it).             */
+ * cge_wgcl in exact mode (empty v_to_l) makes ITS graph the resident one (the sampler rejects against it).
+ * The ids are validated while they stream into the (already re-allocated) device arrays: a call that fails on a vertex id
+ * outside 1..n leaves NO resident graph (the previous one is released, landmark state is invalidated); upload again.   */
 /* src/dst: the two columns of the reference's `edges::Matrix{Int}` (src/auxilary.jl:106); w: eweights */
 int cge_set_graph(cge_ctx *ctx, const int64_t *src, const int64_t *dst, const double *w, int64_t m, int64_t n);
 /* embedding::Matrix{Float64} n x d column-major (src/auxilary.jl:164) */

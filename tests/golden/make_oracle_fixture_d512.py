@@ -1,0 +1,76 @@
+"""Generates tests/golden/oracle_d512.npz: the oracle pin of config 5's code paths (BASELINE.json configs[4]: d = 512,
+fp32-MFMA distance) at a size the CPU ORACLE (oracle/cge_oracle.c; not the Julia reference -- there is no `julia` in the
+image) finishes offline: cyclic Jacobi on a 512 x 512 covariance per split (src/landmarks.jl:160-162) bounds it.
+
+Graph: `cge.jl_amd.synth.abcd_like(20000, 210000, 30, 512, seed=42)`; landmarks(-l 300 -f 4 -m rss), then wGCL() in
+landmark mode with `conftest.random_samples(default_rng(42), m, n, 10000)`; the diameter is the oracle's own O(n^2 d)
+loop (src/divergence.jl:104-113).  A second run with `-m diameter` pins the cut rules through the same wide eigen-solver.
+The GPU test regenerates graph and draws, so only expected OUTPUTS are stored (v_to_l in full: 20 000 ids).
+
+On the device this exercises what no other fixture reaches: group_eig_panel_kernel (128 < d <= 512), the tile-pair
+covariance (four 128-column tiles), the K = 512 fp32-MFMA bound pass of the diameter.
+
+usage: python tests/golden/make_oracle_fixture_d512.py
+"""
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from cge.jl_amd import synth  # noqa: E402
+from conftest import random_samples  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+D512 = dict(n=20_000, m=200_000, C=30, d=512, land=300, forced=4, samples=10000, seed=42)
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+def main():
+    c = D512
+    g = synth.abcd_like(c["n"], int(c["m"] * 1.05), c["C"], c["d"], seed=c["seed"])
+    print(f"graph n={g['n']} m={g['m']}", flush=True)
+    out = dict(n=g["n"], m=g["m"], edges_crc=crc(g["edges"]), emb_crc=crc(g["embedding"]))
+    t0 = time.time()
+    hi = orc.max_pair_dist(g["embedding"])
+    t_hi = time.time() - t0
+    print(f"hi = {hi!r} ({t_hi:.0f} s)", flush=True)
+    out["hi"] = hi
+    smp = random_samples(np.random.default_rng(42), g["m"], g["n"], c["samples"])
+    times = {}
+    for method in ("rss", "diameter"):
+        t0 = time.time()
+        dii, lemb, lcomm, ledges, lw, lweight, v2l = orc.landmarks(g["edges"], g["eweights"], g["vweights"],
+                                                                   g["clusters"], g["comm"], g["embedding"], False,
+                                                                   c["land"], c["forced"], method, False)
+        t_lm = time.time() - t0
+        print(f"[{method}] landmarks: N={len(dii)} ({t_lm:.0f} s)", flush=True)
+        t0 = time.time()
+        orc.set_known_diameter(hi)
+        res, tr = orc.wGCL(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, g["edges"], g["eweights"],
+                           g["embedding"], False, smp, trace=True)
+        t_sc = time.time() - t0
+        print(f"[{method}] wGCL: {list(map(float, res))} iters={tr['iters']} ({t_sc:.0f} s)", flush=True)
+        times[method] = (t_lm, t_sc)
+        p = method + "_"
+        out.update({p + "N": len(dii), p + "v_to_l": v2l.astype(np.int32), p + "dii": dii, p + "lweight": lweight,
+                    p + "lcomm": lcomm[:, 0], p + "lemb_crc": crc(lemb), p + "ledges_crc": crc(ledges),
+                    p + "lw_crc": crc(lw), p + "n_ledges": len(lw), p + "result": res, p + "iters": np.array(tr["iters"]),
+                    p + "div": np.array(tr["div"]), p + "auc": np.array(tr["auc"])})
+    np.savez_compressed(
+        os.path.join(ROOT, "tests", "golden", "oracle_d512.npz"),
+        provenance=np.array("oracle/cge_oracle.c (CPU restatement), tests/golden/make_oracle_fixture_d512.py; diameter "
+                            f"{t_hi:.0f} s; rss: landmarks {times['rss'][0]:.0f} s + wGCL {times['rss'][1]:.0f} s; diameter "
+                            f"rule: landmarks {times['diameter'][0]:.0f} s + wGCL {times['diameter'][1]:.0f} s; one core"),
+        **out)
+
+
+if __name__ == "__main__":
+    main()

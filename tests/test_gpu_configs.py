@@ -38,13 +38,19 @@ def ctx():
     c.close()
 
 
+_GRAPHS = {}  # the last generated graph (config 3 and its `size` twin share one: 75 s of numpy each otherwise)
+
+
 def _workload(name):
     import bench
     from cge.jl_amd import synth
 
     wl = bench.WORKLOADS[name]
-    g = synth.abcd_like(wl["n"], int(wl["m"] * 1.05), wl["C"], wl["d"], seed=42, directed=bool(wl.get("directed", False)))
-    return wl, g
+    key = (wl["n"], wl["m"], wl["C"], wl["d"], bool(wl.get("directed", False)))
+    if key not in _GRAPHS:
+        _GRAPHS.clear()
+        _GRAPHS[key] = synth.abcd_like(wl["n"], int(wl["m"] * 1.05), wl["C"], wl["d"], seed=42, directed=key[4])
+    return wl, _GRAPHS[key]
 
 
 def _fixture(name):
@@ -52,6 +58,22 @@ def _fixture(name):
     if not os.path.exists(path):
         pytest.skip(f"{path} not generated")
     return np.load(path, allow_pickle=False)
+
+
+class _Prefixed:
+    """A view of the keys `<prefix><name>` of a fixture that holds several runs (oracle_d512.npz)."""
+
+    def __init__(self, fx, prefix):
+        self.fx, self.prefix = fx, prefix
+
+    def _key(self, k):
+        return self.prefix + k if (self.prefix + k) in self.fx else k
+
+    def __contains__(self, k):
+        return self._key(k) in self.fx
+
+    def __getitem__(self, k):
+        return self.fx[self._key(k)]
 
 
 def _check_landmarks(ctx, fx):
@@ -101,12 +123,21 @@ def _run_config(ctx, name, check_host_flow=True):
     tr = ctx.last_trace
     hi, path, _, _ = ctx.last_diameter()
     assert hi == float(fx["hi"]), f"diameter {hi!r} ({path}) != exact CPU value {float(fx['hi'])!r}"
+    assert ctx.get_stat("diameter_on_side_context") == 1  # found beside runsplit, from a partition that needs no landmarks
     lm = _check_landmarks(ctx, fx)
     _check_sweep(res, tr, fx, same_samples=False)
     assert res[6] == pytest.approx(1.96 * math.sqrt(res[5] * (1 - res[5]) / wl["samples"]), rel=1e-9)
     res_again = ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=42,
                           auc_samples=wl["samples"])
     assert np.array_equal(res, res_again)  # bitwise reproducible (fixed summation orders; unit weights)
+    try:  # everything in line on the main stream, the diameter from the LANDMARK partition: the same bits
+        ctx.set_option("early_diameter", 0)
+        res_serial = ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=42,
+                               auc_samples=wl["samples"])
+        assert ctx.get_stat("diameter_on_side_context") == 0 and ctx.last_diameter()[0] == hi
+        assert np.array_equal(res, res_serial)
+    finally:
+        ctx.set_option("early_diameter", 1)
     if check_host_flow:
         # (2) the reference's call shape with the fixture's sample draws: the whole vector and every trace
         dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
@@ -151,6 +182,12 @@ def test_config3_diameter_rule_full_size_against_oracle_fixture(ctx):
     assert path_b == "brute" and hi_b == hi and np.array_equal(res, res_b)
 
 
+def test_config3_graph_size_rule_against_oracle_fixture(ctx):
+    """The `size` rule (median cuts, src/landmarks.jl:212-238) at full size: config 3's graph (10^6 vertices, 2*10^7 edges,
+    d = 128, -l 4000) with -m size -- the one split rule the BASELINE configurations themselves do not use."""
+    _run_config(ctx, "cfg3_size", check_host_flow=False)
+
+
 def test_config4_directed_million_samples_against_oracle_fixture(ctx):
     """configs[3]: directed 10^6-vertex graph, d = 128, --samples-local 1000000 (wGCL_directed, the device sampler with
     rejection against 10^7 resident edges, the C^2 form of vect_C)."""
@@ -176,6 +213,131 @@ def test_config4_directed_million_samples_against_oracle_fixture(ctx):
                      auc_samples=S, directed=True, samples=(pos.reshape(1, -1), ni.reshape(1, -1), nj.reshape(1, -1)),
                      use_resident_original=True)
     assert np.array_equal(res, res_h)
+
+
+@pytest.mark.parametrize("method", ["rss", "diameter"])
+def test_d512_against_oracle_fixture(ctx, method):
+    """The oracle pin of config 5's code paths (tests/golden/make_oracle_fixture_d512.py): d = 512, 20 000 vertices, 30
+    communities, -l 300 -f 4 -- group_eig_panel_kernel (128 < d <= 512), the tile-pair covariance and the K = 512 fp32-MFMA
+    bound pass against the CPU oracle's Jacobi eigenvectors and O(n^2 d) diameter loop: v_to_l, d_ii, weights and
+    communities bit for bit, centroid / landmark-edge checksums, the diameter's bits, iteration counts, the 7-vector and
+    every trace at 1e-9, for the rss rule and for a cut rule."""
+    from cge.jl_amd import synth
+
+    path = os.path.join(GOLDEN, "oracle_d512.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    fx0 = np.load(path, allow_pickle=False)
+    fx = _Prefixed(fx0, method + "_")
+    g = synth.abcd_like(20_000, 210_000, 30, 512, seed=42)
+    assert g["n"] == int(fx["n"]) and g["m"] == int(fx["m"])
+    assert crc(g["edges"]) == int(fx["edges_crc"]) and crc(g["embedding"]) == int(fx["emb_crc"])
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    ctx.set_option("diameter", 0)
+    res = ctx.score(g["clusters"], 300, 4, method, seed=42, auc_samples=10000)
+    tr = ctx.last_trace
+    hi, dpath, _, _ = ctx.last_diameter()
+    assert hi == float(fx["hi"]) and dpath == "pruned", (hi, float(fx["hi"]), dpath)
+    lm = _check_landmarks(ctx, fx)
+    _check_sweep(res, tr, fx, same_samples=False)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+    smp = random_samples(np.random.default_rng(42), g["m"], g["n"], 10000)
+    res2 = ctx.wgcl(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, None, None, None, False, auc_samples=10000,
+                    samples=smp, use_resident_original=True)
+    _check_sweep(res2, ctx.last_trace, fx, same_samples=True)
+    for opt, val in (("diameter_f32", 0), ("diameter", 1), ("early_diameter", 0)):  # fp64 bound pass / brute force / in line
+        try:
+            ctx.set_option(opt, val)
+            assert np.array_equal(res, ctx.score(g["clusters"], 300, 4, method, seed=42, auc_samples=10000))
+            assert ctx.last_diameter()[0] == hi
+        finally:
+            ctx.set_option(opt, 1 if opt != "diameter" else 0)
+
+
+def test_config5_full_size_ten_million_vertices():
+    """configs[4] AT ITS WORKLOAD: ABCD-like 10^7 vertices / 2*10^8 edges, d = 512, 1500 communities, -l 12000 -f 4 -m rss, the
+    41 GB embedding generated in HBM and handed over as a device pointer (bench.py --workload cfg5).  No CPU oracle can run
+    this (12 000 Jacobi problems at d = 512; 10^14 pair distances); its code paths are pinned by
+    test_d512_against_oracle_fixture.  Here: the reference's invariants at full size, the landmark statistics of sampled
+    landmarks against numpy, and the diameter three ways -- found on the side context from the cluster-chunk partition,
+    found in line from the landmark partition (another context), and the CPU branch and bound on a 10^5-row sample that
+    contains the arg-max pair: the same bits."""
+    import torch
+
+    import bench
+    from cge.jl_amd import api, synth
+    from diameter_ref import exact_diameter
+
+    wl = bench.WORKLOADS["cfg5"]
+    n, d, C, land = wl["n"], wl["d"], wl["C"], wl["land"]
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs ~190 GB of free HBM")
+    g = synth.abcd_like(n, int(wl["m"] * 1.05), C, 1, seed=42)
+    m = g["m"]
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42)
+    centres = torch.randn(C, d, generator=gen, device=dev, dtype=torch.float64) * 2.0
+    comm_dev = torch.from_numpy(g["comm"][:, 0] - 1).to(dev)
+    X = torch.empty(n, d, dtype=torch.float64, device=dev)
+    for a in range(0, n, 1 << 20):
+        b = min(n, a + (1 << 20))
+        X[a:b] = centres[comm_dev[a:b]] + torch.randn(b - a, d, generator=gen, device=dev, dtype=torch.float64) * 0.5
+    torch.cuda.synchronize()
+
+    def run(early):
+        c = api.Context(0)
+        try:
+            c.set_graph(g["edges"], g["eweights"], n)
+            c.set_embedding_device(X.data_ptr(), n, d, row_major=True)
+            c.set_vertex_data(g["comm"], g["vweights"])
+            c.set_option("early_diameter", early)
+            res = c.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000)
+            out = dict(res=res, tr=c.last_trace, hi=c.last_diameter(), side=c.get_stat("diameter_on_side_context"),
+                       pair=(c.get_stat("diameter_arg_i"), c.get_stat("diameter_arg_j")))
+            if early:
+                out["again"] = c.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000)
+                out["lm"] = c.landmarks_fetch()
+            return out
+        finally:
+            c.close()
+
+    r1 = run(1)
+    res, tr = r1["res"], r1["tr"]
+    hi, path, pairs, tiles = r1["hi"]
+    assert r1["side"] == 1 and path == "pruned" and np.array_equal(res, r1["again"])
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = r1["lm"]
+    N = len(dii)
+    assert N == land and v2l.min() == 1 and v2l.max() == N
+    comm = g["comm"][:, 0]
+    first = np.zeros(N + 1, dtype=np.int64)
+    first[v2l] = comm
+    assert np.array_equal(first[v2l], comm) and np.array_equal(lcomm[:, 0], first[1:])  # landmarks nest in communities
+    assert lw.sum() == m and lweight.sum() == 2 * m and np.array_equal(np.bincount(v2l, weights=g["vweights"])[1:], lweight)
+    order = np.argsort(v2l, kind="stable")
+    starts = np.concatenate([[0], np.cumsum(np.bincount(v2l)[1:])])
+    for l in np.random.default_rng(1).integers(1, N + 1, 25):
+        mem = order[starts[l - 1]:starts[l]]
+        rows = X[torch.from_numpy(mem).to(dev)].cpu().numpy()
+        w = g["vweights"][mem]
+        cen = (rows * w[:, None]).sum(0) / w.sum()
+        assert np.allclose(lemb[l - 1], cen, rtol=1e-12, atol=1e-14)
+        assert dii[l - 1] == pytest.approx(np.sqrt(((rows - lemb[l - 1]) ** 2).sum() / w.sum()), rel=1e-12)
+    assert np.all(np.isfinite(res)) and 0.25 <= res[0] <= 10 and 0 < res[1] <= math.log(2) and 0 <= res[5] <= 1
+    best = int(np.nanargmin(tr["div"]))
+    assert res[1] == tr["div"][best] and res[0] == 0.25 * (best + 1) and all(it >= 1 for it in tr["iters"])
+    # the diameter: a 10^5-row sample that contains the arg-max pair, through the CPU branch and bound (dist()'s own bits)
+    pi, pj = r1["pair"]
+    assert 1 <= pi <= n and 1 <= pj <= n and pi != pj
+    rows = np.unique(np.concatenate([np.random.default_rng(2).integers(0, n, 100_000), [pi - 1, pj - 1]]))
+    Xs = np.asfortranarray(X[torch.from_numpy(rows).to(dev)].cpu().numpy())
+    ref_hi, _, _, _ = exact_diameter(Xs, comm[rows])
+    assert ref_hi == hi, (ref_hi, hi)
+    del dii, lemb, lcomm, ledges, lw, lweight, r1
+    # in line, from the landmark partition, in a fresh context: the same diameter, the same score, bit for bit
+    r0 = run(0)
+    assert r0["side"] == 0 and r0["hi"][0] == hi and np.array_equal(r0["res"], res)
 
 
 def test_config5_d512_twelve_thousand_landmarks(ctx):

@@ -1159,6 +1159,69 @@ def test_randomised_parity_sweep(ctx, orc, case):
     _cmp_result(res, exp, tr, etr)
 
 
+def test_local_score_exact_ties_case_212(ctx, orc):
+    """DESIGN section 2 (iv), profiles/repro_parity_case.py 212 (an offline stress case, 170 vertices, directed): a sampled
+    edge (i, j) and a sampled non-edge (j, i) whose endpoints share ONE landmark give pos == neg in exact arithmetic
+    (Tout[l] Tin[l] w_i w_j / lw[l]^2 (1 - D_ij)^alpha both ways), so `pos > neg` (src/divergence.jl:517) is decided by the
+    rounding of two differently ordered products -- in the reference as here.  What IS guaranteed, and held in place by
+    this test: landmarks bit-exact, global score and iteration counts equal, every per-alpha local score within the weight
+    of those tied samples of the oracle's, and the best local alpha one of the alphas the oracle scores within that margin
+    of its best."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    case = 212
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.integers(60, 1500))
+    d = int(rng.choice([2, 3, 5, 8, 17, 33, 64, 100] + [129, 130, 160, 192, 257, 300]))
+    C = int(rng.integers(2, max(3, n // 25)))
+    method = ["rss", "rss2", "size", "diameter"][case % 4]
+    directed = bool(rng.integers(0, 2))
+    split = bool(rng.integers(0, 2))
+    forced = int(rng.choice([1, 2, 4]))
+    g = synth.abcd_like(n, int(rng.integers(3, 9)) * n, C, d, seed=500 + case, directed=directed)
+    land = int(min(n // 3, max(C * forced, rng.integers(C, 6 * C + 2))))
+    ew, vw = g["eweights"], g["vweights"]
+    if rng.integers(0, 2):
+        ew = rng.integers(1, 17, size=len(ew)) / 4.0
+        vw = np.zeros(n)
+        np.add.at(vw, g["edges"][:, 0] - 1, ew)
+        np.add.at(vw, g["edges"][:, 1] - 1, ew)
+    assert directed and n == 170, "the generator no longer reproduces stress case 212"
+    args = (g["edges"], ew, vw, g["clusters"], g["comm"], g["embedding"], False, land, forced, method, directed)
+    got, ref = cg.landmarks(*args, ctx=ctx), orc.landmarks(*args)
+    _check_landmarks(got, ref, unit_weights=False)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = got
+    S = 1500
+    p1, ni, nj = api.draw_samples(ctx, case, S, directed=True)
+    smp = (p1, ni, nj, p1)
+    # the tied samples: non-edge k is the reversal of edge k and both endpoints lie in one landmark
+    pi, pj = g["edges"][p1[0] - 1, 0], g["edges"][p1[0] - 1, 1]
+    tied = (pi == nj[0]) & (pj == ni[0]) & (v2l[pi - 1] == v2l[pj - 1])
+    wk = ew[p1[0] - 1]
+    margin = wk[tied].sum() / wk.sum()
+    assert tied.sum() >= 1, "case 212 no longer contains an exact tie"
+    wargs = (ledges, lw, lcomm, lemb, dii, lweight, vw, v2l, g["edges"], ew, g["embedding"], split)
+    exp, etr = orc.wGCL_directed(*wargs, smp, trace=True)
+    e_auc = np.array(etr["auc"])
+    for opt in (0, 1, 2, 3, 4):  # every form of the fit
+        ctx.set_option("fit_persistent", opt)
+        try:
+            res, tr = cg.wGCL_directed(*wargs, case, S, samples=smp, trace=True, ctx=ctx)
+        finally:
+            ctx.set_option("fit_persistent", 0)
+        k = min(len(tr["auc"]), len(e_auc))
+        assert tr["iters"][:k] == etr["iters"][:k]
+        assert np.allclose(tr["div"][:k], etr["div"][:k], rtol=RTOL, equal_nan=True)
+        assert res[0] == exp[0] and np.allclose(res[1:4], exp[1:4], rtol=RTOL, atol=1e-15)
+        a_got = np.array(tr["auc"][:k])
+        both = np.isfinite(a_got) & np.isfinite(e_auc[:k])
+        assert np.all(np.abs(a_got[both] - e_auc[:k][both]) <= margin + 1e-12), (a_got, e_auc, margin)
+        ia = int(round(res[4] / 0.25)) - 1  # the alpha this run calls best: the oracle scores it within the margin of its own best
+        assert 0 <= ia < k and e_auc[ia] <= np.nanmin(e_auc[:k]) + 2 * margin + 1e-12
+        assert res[5] == np.nanmin(a_got)  # (the patience counters may stop the two sweeps at different alphas after a flipped tie)
+
+
 @pytest.mark.parametrize("case", range(16))
 def test_randomised_exact_mode_sweep(ctx, orc, case):
     """The same for exact mode (v_to_l = Int[], the score graph is the graph itself): random sizes across the launch

@@ -34,7 +34,7 @@ def _graph():
     return synth.abcd_like(30000, 300000, 30, 16, seed=21)
 
 
-def _rank(rank, world, port, q, mode, method="rss", shard_samples=1):
+def _rank(rank, world, port, q, mode, method="rss", shard_samples=1, fit_persistent=1, timeout_rank=-1):
     try:
         import torch
         import torch.distributed as dist
@@ -50,7 +50,9 @@ def _rank(rank, world, port, q, mode, method="rss", shard_samples=1):
         ctx = api.Context(0)
         ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
         coll = TorchCollectives(ctx, 600 * 600 * 2 + 1024, torch.device("cuda", 0))
-        ctx.set_option("fit_persistent", 1)
+        ctx.set_option("fit_persistent", fit_persistent)
+        if rank == timeout_rank:  # this rank's persistent fits give up at once; the other rank's succeed
+            ctx.set_option("fit_persistent_test_timeout", 1)
         ctx.set_option("shard_runsplit", mode)  # 2: every batch of the global phase is split too, whatever its size
         ctx.set_option("shard_samples", shard_samples)  # 2: the local-score tallies of every alpha are split over the ranks
         res = ctx.score(g["clusters"], 600, 2, method, seed=5, auc_samples=4000)
@@ -58,7 +60,8 @@ def _rank(rank, world, port, q, mode, method="rss", shard_samples=1):
         batches = ctx.get_stat("landmark_batches")
         n0 = coll.n_calls
         v2l = ctx.landmarks_fetch()[6]
-        q.put((rank, res.tolist(), hi, (n0, coll.n_calls - n0, batches), int(zlib.crc32(v2l.tobytes()))))
+        q.put((rank, res.tolist(), hi, (n0, coll.n_calls - n0, batches, ctx.get_stat("fit_persistent_alphas")),
+               int(zlib.crc32(v2l.tobytes()))))
         ctx.close()
     except Exception as e:  # surface the failure in the parent
         import traceback
@@ -101,7 +104,7 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx, mode):
         assert np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
         # vect_C (sum), the centroid bounds (max), the diameter (max); + the forced phase's groups (gather) + one gather per
         # split batch of the global phase; the fetch adds the landmark-pair matrix (sum)
-        during, fetch, batches = n_calls
+        during, fetch, batches, _ = n_calls
         assert fetch == 1 and during >= 3 + (mode > 0)
         if mode == 2:
             assert during > 4  # batches of the global phase went through the exchange
@@ -139,3 +142,34 @@ def test_two_ranks_other_split_rules(ctx, method):
         assert crc == crc_ref and np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
         assert n_calls[0] > 3 + 10  # ... plus one all-reduce of the tallies per alpha with a local score
     assert results[0][1] == results[1][1]
+
+
+def test_two_ranks_fit_abandoned_on_one_rank_only(ctx):
+    """with the tallies split over the ranks every alpha carries an all-reduce, and the verdict of an ENQUEUED
+    persistent fit is rank-local.  Rank 0's persistent fits are made to give up at once (testing option), rank 1's succeed:
+    the verdict travels with the all-reduced tallies, so both ranks redo the first alpha together with one launch per
+    iteration, issue the same number of exchanges and end with the one-rank result (no hang, no mixed-up tallies)."""
+    import torch.multiprocessing as mp
+
+    g = _graph()
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    try:
+        ctx.set_option("fit_persistent", 1)
+        ref = ctx.score(g["clusters"], 600, 2, "rss", seed=5, auc_samples=4000)
+    finally:
+        ctx.set_option("fit_persistent", 0)
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank, args=(r, 2, port, q, 1, "rss", 2, 2, 0)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+    for rank, res, hi, n_calls, crc in results:
+        assert hi is not None, res
+        assert np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
+    assert results[0][1] == results[1][1]
+    assert results[0][3][0] == results[1][3][0]  # the same number of exchanges on both ranks
+    assert results[0][3][3] == 0 and results[1][3][3] == 0  # no alpha was taken from a persistent fit: both ranks fell back together
