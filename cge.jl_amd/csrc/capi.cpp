@@ -885,8 +885,8 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
 // reference computes them in line; here a second host thread drives them on a shadow context (own low-priority streams, own
 // scratch, borrowed views of the resident arrays) while the first runs runsplit -- a chain of short dependent kernels that
 // leaves most of the GPU idle.  The diameter's branch and bound is exact for ANY partition of the vertices (diameter_host.cpp:
-// only the amount of pruning depends on it), so it uses one that needs no landmarks: every cluster cut into runs of <= 256
-// members, reference points = the clusters' centroids.  `hi` itself is re-evaluated from the arg-max pair with dist()'s own
+// only the amount of pruning depends on it), so it uses one that needs no landmarks: every cluster cut into runs of about
+// n / (4 sqrt n) members (as many groups as the automatic landmark count), reference points = the clusters' centroids.  `hi` itself is re-evaluated from the arg-max pair with dist()'s own
 // arithmetic, as before: the same bits as the landmark-based search (tests: all full-size fixtures).
 static cge_ctx *side_context(cge_ctx *c) {
     if (!c->side) {
@@ -955,9 +955,12 @@ static void side_job_body(cge_ctx *c, cge_ctx *sd, const cge_score_args *a, i64 
             sd->phases.ms["samples"] = now_ms() - ts;
             job->samples_ok = true;
         } catch (const CgeError &) { job->samples_ok = false; } // the main thread repeats the draw and reports the error
-        // (3) the diameter, from the clusters cut into runs of <= 256 members
+        // (3) the diameter, from the clusters cut into runs of <= G members
         if (want_diameter) {
-            const i64 n = sd->n, d = sd->d, ncl = a->n_clusters, G = 256;
+            const i64 n = sd->n, d = sd->d, ncl = a->n_clusters;
+            // as many groups as the automatic landmark count, 4 sqrt(n) (src/auxilary.jl:194-195): the candidate list of the
+            // bound pass grows with the square of the group count
+            const i64 G = std::max<i64>(64, (i64)std::ceil((double)n / std::max(1.0, 4.0 * std::sqrt((double)n))));
             const i64 *off = a->clusters_off, *flat = a->clusters_flat;
             const i64 total = ncl > 0 ? off[ncl] : 0;
             job->dm_status = 2;
@@ -1082,6 +1085,8 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
             cge_ctx *sd = c->side;
             for (auto &kv : sd->phases.ms) c->phases.ms[kv.first] = kv.second; // dm_*, samples, lm_unique: concurrent with `landmarks`
             c->phases.ms["side_total"] = job.t_total;
+            c->stat_side_status = job.dm_status;
+            if (job.dm_status == 3) c->err = "side context: " + job.err; // (the in-line path below reports what it finds itself)
             side_samples = job.samples_ok;
             if (job.dm_status == 1) {
                 hi = job.hi;
@@ -1280,6 +1285,7 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "diameter_arg_i")) *value = c->stat_hi_i + 1; // the arg-max pair of the last diameter (1-based vertex ids)
     else if (!strcmp(key, "diameter_arg_j")) *value = c->stat_hi_j + 1;
     else if (!strcmp(key, "diameter_on_side_context")) *value = c->stat_diameter_side;
+    else if (!strcmp(key, "side_diameter_status")) *value = c->stat_side_status; // 1 found, 2 declined (candidate list / pruning too weak), 3 failed
     else if (!strcmp(key, "fit_persistent_alphas")) *value = c->stat_fit_persistent;
     else if (!strcmp(key, "fit_iterations")) *value = c->stat_fit_iters;
     else if (!strcmp(key, "fit_persistent_fallbacks")) *value = c->stat_fit_fallbacks;

@@ -344,6 +344,7 @@ struct cge_ctx {
     int stat_diameter_path = 0;            // 1 brute, 2 pruned
     double stat_last_hi = 0.0;
     i64 stat_hi_i = -1, stat_hi_j = -1; // its arg-max pair (0-based vertex ids)
+    int stat_side_status = 0;
     int stat_diameter_side = 0;         // 1: the last score took `hi` from the side context's search
     i64 stat_nref = 0; // reference points of the last pruned diameter (communities or landmarks)
     // scratch of the batched split engine (landmarks_host.cpp)

@@ -1820,6 +1820,358 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             if (lane + 64 * r < d) out[lane + 64 * r] = yv[r] * sg;
     }
 }
+// ---- the same solver, second form (default): columns dealt CYCLICALLY to the waves and dead work skipped -------------
+// Wave w owns the columns {w, w + NW, w + 2 NW, ...} (NC of them), lane l the rows l + 64 r.  At step k only the trailing
+// block (rows and columns > k) is live, and with the cyclic deal every wave's share of it shrinks in step: the two O(d^2)
+// loops of a step (B u and the rank-2 update) run over the wave's LIVE column groups of four only (a dead column inside a
+// live group multiplies u = w = 0: exact), and over the upper row block only once k has passed row 63.  On average a step
+// touches 28 % of the register block instead of all of it.  A finished column no longer needs to keep its reflector in
+// place (its owner is no longer one wave per 32 consecutive steps): wave 0 writes the reflector of every step to a scratch
+// row (d doubles, fire and forget) and runs the back-transformation from there with the loads of the next steps in flight.
+// The two divisions of a step are hardware reciprocals with one Newton step (the reflector is then orthogonal to ~1 ulp,
+// the level of the method's own rounding); same conventions and results to rounding as the first form
+// (tests: eigen-solver against LAPACK, landmark parity against the oracle).
+template <int NR, int NC, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void group_eigc_kernel(const double *__restrict__ cov, int d,
+                                                                double *__restrict__ vec, double *__restrict__ refl,
+                                                                int diag_stage) {
+    constexpr int DP = 64 * NR, G = 4; // padded dimension (rows held); NW * NC >= d columns held; column group
+    static_assert(NC % G == 0, "column groups of four");
+    __shared__ __attribute__((aligned(16))) double X[DP], U[DP], W[DP], Pp[NW][DP], V[DP];
+    __shared__ __attribute__((aligned(16))) double diag[DP], off[DP], beta[DP], tri[4 * DP], red[8 + 3 * NW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: the skips below are scalar branches
+    const double *src = cov + (size_t)blockIdx.x * d * d;
+    double *out = vec + (size_t)blockIdx.x * d;
+    double *rf = refl + (size_t)blockIdx.x * DP * DP; // row k: the reflector of step k (DP doubles)
+    if (d == 1) {
+        if (tid == 0) out[0] = 1.0;
+        return;
+    }
+    double a[NR][NC];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int row = lane + 64 * r;
+#pragma unroll
+        for (int jj = 0; jj < NC; jj++) {
+            const int col = NW * jj + wv;
+            a[r][jj] = (row < d && col < d) ? src[(size_t)col * d + row] : 0.0; // symmetric: coalesced along rows
+        }
+    }
+    // publish row kn of the matrix: X[col] = A[kn][col] (row instead of column: see the first form)
+    auto extract = [&](int kn) {
+        if (lane == (kn & 63)) {
+            if (NR > 1 && kn >= 64) {
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) X[NW * jj + wv] = a[NR - 1][jj];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) X[NW * jj + wv] = a[0][jj];
+            }
+        }
+    };
+    if (tid < DP) { beta[tid] = 0.0; off[tid] = 0.0; X[tid] = 0.0; }
+    __syncthreads();
+    extract(0);
+    // ---- tridiagonalisation ------------------------------------------------------------------------
+    for (int k = 0; k + 2 < d; k++) {
+        __syncthreads(); // (a) X of column k is visible; U, W, Pp of the previous step are dead
+        const int o = k + 1;
+        double x[NR], u[NR];
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int row = lane + 64 * r;
+            x[r] = (row > k) ? X[row] : 0.0;
+            part += (row > o) ? x[r] * x[r] : 0.0;
+        }
+        const double alpha = X[o];
+        if (tid == 0) diag[k] = X[k];
+        const double sigma = wave_allsum(part);
+        const bool refl_on = sigma != 0.0; // sigma == 0: no reflection; the step runs with u = w = 0
+        const double mu = sqrt(alpha * alpha + sigma);
+        const double v0r = (alpha <= 0.0) ? alpha - mu : -sigma * fast_rcp(alpha + mu);
+        const double v0 = refl_on ? v0r : 0.0;
+        const double bp = refl_on ? 2.0 * fast_rcp(sigma + v0r * v0r) : 0.0; // H = I - bp u u^T, u = (v0, x[o+1..])
+        if (tid == 0) { beta[k] = bp; off[k] = refl_on ? mu : alpha; }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int row = lane + 64 * r;
+            u[r] = (row == o) ? v0 : x[r];
+            U[row] = u[r]; // every wave writes the same values
+            if (wv == 0) rf[(size_t)k * DP + row] = u[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool low_live = NR == 1 || o < 64; // the rows of block 0 are all <= k once o >= 64
+        { // partial p = B u over the wave's live column groups
+            double s[NR];
+#pragma unroll
+            for (int r = 0; r < NR; r++) s[r] = 0.0;
+#pragma unroll
+            for (int g0 = 0; g0 < NC; g0 += G) {
+                if (NW * (g0 + G - 1) + wv >= o) { // the group's last column is live
+                    double uj[G];
+#pragma unroll
+                    for (int q = 0; q < G; q++) uj[q] = U[NW * (g0 + q) + wv];
+                    if (low_live) {
+#pragma unroll
+                        for (int q = 0; q < G; q++)
+#pragma unroll
+                            for (int r = 0; r < NR; r++) s[r] = fma(a[r][g0 + q], uj[q], s[r]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < G; q++) s[NR - 1] = fma(a[NR - 1][g0 + q], uj[q], s[NR - 1]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++) Pp[wv][lane + 64 * r] = s[r];
+        }
+        __syncthreads(); // (b)
+        double w[NR];
+        part = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int row = lane + 64 * r;
+            double t = Pp[0][row];
+#pragma unroll
+            for (int q = 1; q < NW; q++) t += Pp[q][row]; // fixed order
+            w[r] = bp * t;
+            w[r] = (row >= o) ? w[r] : 0.0; // (a skipped row block left nothing meaningful behind)
+            part += w[r] * u[r];
+        }
+        const double K = 0.5 * bp * wave_allsum(part);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int row = lane + 64 * r;
+            w[r] = (row >= o) ? w[r] - K * u[r] : 0.0; // finished rows / columns stay as they are
+            W[row] = w[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g0 = 0; g0 < NC; g0 += G) { // rank-2 update of the live column groups
+            if (NW * (g0 + G - 1) + wv >= o) {
+                double uj[G], wj[G];
+#pragma unroll
+                for (int q = 0; q < G; q++) { uj[q] = U[NW * (g0 + q) + wv]; wj[q] = W[NW * (g0 + q) + wv]; }
+                if (low_live) {
+#pragma unroll
+                    for (int q = 0; q < G; q++)
+#pragma unroll
+                        for (int r = 0; r < NR; r++) a[r][g0 + q] = fma(-u[r], wj[q], fma(-w[r], uj[q], a[r][g0 + q]));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < G; q++)
+                        a[NR - 1][g0 + q] = fma(-u[NR - 1], wj[q], fma(-w[NR - 1], uj[q], a[NR - 1][g0 + q]));
+                }
+            }
+        }
+        extract(k + 1);
+    }
+    __syncthreads();
+    if (tid == 0) { diag[d - 2] = X[d - 2]; off[d - 2] = X[d - 1]; } // row d-2 was the last one published
+    __syncthreads();
+    extract(d - 1);
+    __syncthreads();
+    if (tid == 0) diag[d - 1] = X[d - 1];
+    __syncthreads();
+    if (diag_stage == 1) { if (tid < d) out[tid] = diag[tid]; return; } // timing diagnostic only
+    // ---- Gershgorin bounds ---------------------------------------------------------------------------
+    double glo = 1e300, ghi = -1e300, gn = 0.0;
+    if (tid < d) {
+        const double rad = (tid > 0 ? fabs(off[tid - 1]) : 0.0) + (tid + 1 < d ? fabs(off[tid]) : 0.0);
+        glo = diag[tid] - rad;
+        ghi = diag[tid] + rad;
+        gn = fabs(diag[tid]) + rad;
+    }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        glo = fmin(glo, __shfl_xor(glo, o2));
+        ghi = fmax(ghi, __shfl_xor(ghi, o2));
+        gn = fmax(gn, __shfl_xor(gn, o2));
+    }
+    double *gs = red + 8;
+    if (lane == 0) { gs[wv * 3] = glo; gs[wv * 3 + 1] = ghi; gs[wv * 3 + 2] = gn; }
+    __syncthreads();
+    glo = gs[0]; ghi = gs[1]; gn = gs[2];
+#pragma unroll
+    for (int q = 1; q < NW; q++) { glo = fmin(glo, gs[3 * q]); ghi = fmax(ghi, gs[3 * q + 1]); gn = fmax(gn, gs[3 * q + 2]); }
+    const double tiny = fmax(gn, 2.2250738585072014e-308) * 2.220446049250313e-16;
+    // ---- largest eigenvalue: 64-way multisection on the Sturm count (wave 0) ------------------------------
+    if (tid < 64) {
+        double lo = glo, hi = ghi + tiny;
+        for (int it = 0; it < 64; it++) {
+            const double xq = lo + (hi - lo) * ((double)(tid + 1) / 65.0);
+            int cnt = 0;
+            double q = diag[0] - xq;
+            if (q < 0) cnt++;
+            for (int i = 1; i < d; i++) {
+                if (q == 0.0) q = tiny;
+                q = diag[i] - xq - (off[i - 1] * off[i - 1]) * fast_rcp(q);
+                if (q < 0) cnt++;
+            }
+            const unsigned long long mask = __ballot(cnt >= d);
+            double nlo, nhi;
+            if (mask == 0ULL) {
+                nlo = __shfl(xq, 63);
+                nhi = hi;
+            } else {
+                const int f = __ffsll((long long)mask) - 1;
+                nhi = __shfl(xq, f);
+                nlo = (f > 0) ? __shfl(xq, f - 1) : lo;
+            }
+            if (!(nhi > nlo) || (nlo == lo && nhi == hi)) break;
+            lo = fmax(lo, nlo);
+            hi = fmin(hi, nhi);
+        }
+        if (tid == 0) red[4] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    if (diag_stage == 2) { if (tid < d) out[tid] = red[4]; return; } // timing diagnostic only
+    // ---- inverse iteration, back-transformation, normalisation: wave 0 ----------------------------------------
+    if (wv == 0) {
+        const double lam = red[4];
+        double *dl = tri, *dd = tri + DP, *du = tri + 2 * DP, *du2 = tri + 3 * DP;
+        double *y = V;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = lane + 64 * r;
+            dd[i] = (i < d) ? diag[i] - lam : 1.0;
+            dl[i] = du[i] = (i + 1 < d) ? off[i] : 0.0;
+            du2[i] = 0.0;
+            y[i] = (i < d) ? 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0 : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long swp0 = 0ULL, swp1 = 0ULL; // pivot flags, d <= 128 (lane 0)
+        if (lane == 0) { // LU with partial pivoting of the shifted tridiagonal matrix
+            double di = dd[0], ui = du[0];
+            for (int i = 0; i + 1 < d; i++) {
+                const double li = dl[i], dn = dd[i + 1], un = du[i + 1];
+                if (fabs(di) >= fabs(li)) {
+                    if (di == 0.0) di = tiny;
+                    const double f = li * fast_rcp(di);
+                    dd[i] = di;
+                    dl[i] = f;
+                    du[i] = ui;
+                    di = dn - f * ui;
+                    ui = un;
+                } else {
+                    const double f = di * fast_rcp(li);
+                    dd[i] = li;
+                    dl[i] = f;
+                    du[i] = dn;
+                    di = ui - f * dn;
+                    if (i + 2 < d) du2[i] = un;
+                    ui = -f * un;
+                    if (i < 64) swp0 |= 1ULL << i; else swp1 |= 1ULL << (i - 64);
+                }
+            }
+            if (di == 0.0) di = tiny;
+            dd[d - 1] = di;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < NR; r++) { // the solves multiply by the reciprocal pivots
+            const int i = lane + 64 * r;
+            if (i < d) dd[i] = fast_rcp(dd[i]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < 3; it++) {
+            if (lane == 0) {
+                double yi = y[0];
+                for (int i = 0; i + 1 < d; i++) { // forward: L with the recorded row swaps
+                    const bool sw = (i < 64) ? ((swp0 >> i) & 1ULL) : ((swp1 >> (i - 64)) & 1ULL);
+                    const double yn = y[i + 1], li = dl[i];
+                    y[i] = sw ? yn : yi;
+                    yi = sw ? yi - li * yn : yn - li * yi;
+                }
+                double y1 = yi * dd[d - 1]; // backward: U with two super-diagonals
+                y[d - 1] = y1;
+                double y0 = (y[d - 2] - du[d - 2] * y1) * dd[d - 2];
+                y[d - 2] = y0;
+                for (int i = d - 3; i >= 0; i--) {
+                    const double t = (y[i] - du[i] * y0 - du2[i] * y1) * dd[i];
+                    y[i] = t;
+                    y1 = y0;
+                    y0 = t;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            double yv[NR], amax = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                yv[r] = y[lane + 64 * r];
+                amax = fmax(amax, fabs(yv[r]));
+            }
+            for (int o2 = 32; o2 > 0; o2 >>= 1) amax = fmax(amax, __shfl_xor(amax, o2));
+            if (!(amax > 0.0) || !(amax < 1e300)) { // uniform over the wave
+#pragma unroll
+                for (int r = 0; r < NR; r++) y[lane + 64 * r] = (lane + 64 * r == 0) ? 1.0 : 0.0;
+                __builtin_amdgcn_wave_barrier();
+                break;
+            }
+            const double ra = 1.0 / amax;
+            double part = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) { yv[r] *= ra; part += yv[r] * yv[r]; }
+            const double rn = 1.0 / sqrt(wave_allsum(part));
+#pragma unroll
+            for (int r = 0; r < NR; r++) y[lane + 64 * r] = yv[r] * rn;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (diag_stage == 3) { if (lane < 64) for (int r = 0; r < NR; r++) if (lane + 64 * r < d) out[lane + 64 * r] = V[lane + 64 * r]; return; }
+        // back-transformation x = H_0 H_1 ... H_{d-3} y from the scratch rows this wave wrote (two steps of loads in flight)
+        double yv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) yv[r] = V[lane + 64 * r];
+        double un[NR], un2[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            un[r] = rf[(size_t)(d - 3) * DP + lane + 64 * r];
+            un2[r] = d >= 4 ? rf[(size_t)(d - 4) * DP + lane + 64 * r] : 0.0;
+        }
+        for (int k = d - 3; k >= 0; k--) {
+            double uu[NR], part = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                uu[r] = un[r];
+                un[r] = un2[r];
+                un2[r] = k >= 2 ? rf[(size_t)(k - 2) * DP + lane + 64 * r] : 0.0;
+                part += uu[r] * yv[r];
+            }
+            const double sdot = beta[k] * wave_allsum(part); // beta == 0: no reflection at this step (u = 0 as well)
+#pragma unroll
+            for (int r = 0; r < NR; r++) yv[r] -= sdot * uu[r];
+        }
+        // normalise; sign: the component of largest magnitude (the first one on ties) is positive
+        double part = 0.0, best = -1.0;
+        int bi = 0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) { // rows >= d are zero
+            part += yv[r] * yv[r];
+            if (fabs(yv[r]) > best) { best = fabs(yv[r]); bi = lane + 64 * r; }
+        }
+        double nrm = sqrt(wave_allsum(part));
+        const bool degenerate = !(nrm > 0.0) || !(nrm < 1e300); // zero matrix: any unit vector is an eigenvector
+        if (degenerate) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) { yv[r] = (lane + 64 * r == 0) ? 1.0 : 0.0; }
+            nrm = 1.0;
+            best = (lane == 0) ? 1.0 : 0.0;
+            bi = lane;
+        }
+        double bv = best;
+        for (int o2 = 32; o2 > 0; o2 >>= 1) {
+            const double ob = __shfl_xor(bv, o2);
+            const int oi = __shfl_xor(bi, o2);
+            if (ob > bv || (ob == bv && oi < bi)) { bv = ob; bi = oi; }
+        }
+        const double lead = (bi >= 64 && NR > 1) ? lane_value(yv[NR - 1], bi & 63) : lane_value(yv[0], bi & 63);
+        const double sg = ((lead < 0.0) ? -1.0 : 1.0) / nrm;
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+            if (lane + 64 * r < d) out[lane + 64 * r] = yv[r] * sg;
+    }
+}
 // ---- the same solver for wider matrices (128 < d <= 512): the matrix stays in global memory (it is read and
 // written by one workgroup only, so it lives in that CU's L1/L2 path), the O(d) vectors in LDS.  Same algorithm and
 // conventions as above; thread j owns column j (and j + 256): for a fixed row the threads read consecutive addresses.
@@ -2491,13 +2843,37 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
     }
     ScopedKernelTimer t(c, "group_eig");
     static const int diag_stage = getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0; // 0 = normal
+    // A/B: CGE_EIG_FORM=0 the first form (blocked columns, reflectors in place), 4 (default) / 8: the cyclic form on 4 / 8 waves
+    static const int form = getenv("CGE_EIG_FORM") ? atoi(getenv("CGE_EIG_FORM")) : 4;
     const dim3 grid((unsigned)n_tasks), block(256);
-    if (d <= 32)
-        hipLaunchKernelGGL((group_eig_kernel<1, 8>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
-    else if (d <= 64)
-        hipLaunchKernelGGL((group_eig_kernel<1, 16>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
-    else
-        hipLaunchKernelGGL((group_eig_kernel<2, 32>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
+    if (form == 0) {
+        if (d <= 32)
+            hipLaunchKernelGGL((group_eig_kernel<1, 8>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
+        else if (d <= 64)
+            hipLaunchKernelGGL((group_eig_kernel<1, 16>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
+        else
+            hipLaunchKernelGGL((group_eig_kernel<2, 32>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
+        return true;
+    }
+    const i64 DP = d <= 64 ? 64 : 128;
+    c->ls_eigscr.ensure((size_t)n_tasks * DP * DP); // the reflectors of every step (read back by the back-transformation)
+    double *rf = c->ls_eigscr.p;
+    if (form == 8) {
+        const dim3 block8(512);
+        if (d <= 32)
+            hipLaunchKernelGGL((group_eigc_kernel<1, 4, 8>), grid, block8, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
+        else if (d <= 64)
+            hipLaunchKernelGGL((group_eigc_kernel<1, 8, 8>), grid, block8, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
+        else
+            hipLaunchKernelGGL((group_eigc_kernel<2, 16, 8>), grid, block8, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
+    } else {
+        if (d <= 32)
+            hipLaunchKernelGGL((group_eigc_kernel<1, 8, 4>), grid, block, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
+        else if (d <= 64)
+            hipLaunchKernelGGL((group_eigc_kernel<1, 16, 4>), grid, block, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
+        else
+            hipLaunchKernelGGL((group_eigc_kernel<2, 32, 4>), grid, block, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
+    }
     return true;
 }
 
