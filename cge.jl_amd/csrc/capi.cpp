@@ -28,14 +28,15 @@ void k_gather_i32(cge_ctx *c, const i32 *arr, const i32 *idx, i64 S, i32 *out);
     return CGE_OK;
 
 static void flush_timers(cge_ctx *c) {
-    if (c->side) { // the side context's kernels are reported with the main context's
-        flush_timers(c->side);
-        for (auto &kv : c->side->timers) {
+    for (cge_ctx *sh : {c->side, c->lane}) { // the shadow contexts' kernels are reported with the main context's
+        if (!sh) continue;
+        flush_timers(sh);
+        for (auto &kv : sh->timers) {
             KernelTimer &t = c->timers[kv.first];
             t.launches += kv.second.launches;
             t.total_ms += kv.second.total_ms;
         }
-        c->side->timers.clear();
+        sh->timers.clear();
     }
     for (auto &kv : c->timers) {
         for (auto &pr : kv.second.pending) {
@@ -129,10 +130,10 @@ void cge_destroy(cge_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     flush_timers(c);
-    if (c->side) { // the shadow context of cge_score: own streams and scratch, borrowed views of the resident inputs
-        cge_ctx *sd = c->side;
-        c->side = nullptr;
-        cge_destroy(sd);
+    for (cge_ctx **slot : {&c->side, &c->lane}) { // shadow contexts: own streams and scratch, borrowed views of the resident inputs
+        cge_ctx *sd = *slot;
+        *slot = nullptr;
+        if (sd) cge_destroy(sd);
     }
     if (!c->is_side) (void)cge_comm_finalize(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -888,35 +889,7 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
 // only the amount of pruning depends on it), so it uses one that needs no landmarks: every cluster cut into runs of about
 // n / (4 sqrt n) members (as many groups as the automatic landmark count), reference points = the clusters' centroids.  `hi` itself is re-evaluated from the arg-max pair with dist()'s own
 // arithmetic, as before: the same bits as the landmark-based search (tests: all full-size fixtures).
-static cge_ctx *side_context(cge_ctx *c) {
-    if (!c->side) {
-        cge_ctx *sd = new cge_ctx();
-        c->side = sd; // owned from here on (cge_destroy)
-        sd->is_side = true;
-        sd->device = c->device;
-        sd->n_threads = 1;
-        int least = 0, greatest = 0;
-        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_CHECK(hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, least));
-        sd->own_stream = true;
-        HIP_CHECK(hipStreamCreateWithPriority(&sd->copy_stream, hipStreamNonBlocking, least));
-        HIP_CHECK(hipEventCreateWithFlags(&sd->copy_ev, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&sd->copy_done, hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->sweep_ev[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->tab_ev[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->stage_ev[i], hipEventDisableTiming));
-    }
-    cge_ctx *sd = c->side;
-    // views are re-taken at every score: an upload may have replaced the buffers since the last one
-    sd->n = c->n; sd->m = c->m; sd->d = c->d; sd->ldn = c->ldn; sd->dpad = c->dpad;
-    sd->unit_weights = c->unit_weights; sd->n_comm_max = c->n_comm_max;
-    sd->Xr.borrow(c->Xr); sd->gmean.borrow(c->gmean); sd->vw.borrow(c->vw); sd->comm.borrow(c->comm);
-    sd->src.borrow(c->src); sd->dst.borrow(c->dst); sd->w.borrow(c->w);
-    sd->opt_diameter = c->opt_diameter; sd->opt_diameter_f32 = c->opt_diameter_f32;
-    sd->profiling = c->profiling; sd->profile_only = c->profile_only;
-    sd->h_Xr.clear(); // (a stale host mirror must not answer for a new embedding; it is fetched on demand)
-    return sd;
-}
+static cge_ctx *side_context(cge_ctx *c) { return cge_shadow_context(c, &c->side, true); }
 
 static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_directed, SampleSet &smp);
 
@@ -1261,6 +1234,11 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;
     }
+    if (!strcmp(key, "runsplit_lanes")) { // 2 (default): the batches of runsplit run as two half-batches on two streams, out of phase; 1: one stream
+        if (value < 1 || value > 2) return CGE_E_ARG;
+        c->opt_lanes = (int)value;
+        return CGE_OK;
+    }
     if (!strcmp(key, "early_diameter")) { // 1 (default): clamp, sample draws and diameter on the side context beside runsplit (single rank); 0: in line
         c->opt_early_diameter = value != 0;
         return CGE_OK;
@@ -1403,6 +1381,40 @@ bool cge_exchange_fits(cge_ctx *c, size_t need) {
     c->xptr = c->xown.p;
     c->xcap = c->xown.n;
     return true;
+}
+
+// A shadow context: own streams, events and scratch on the same device, borrowed views of the resident arrays.  `slot`
+// = &c->side (low-priority streams: the side job of cge_score) or &c->lane (the second lane of runsplit's batches).
+cge_ctx *cge_shadow_context(cge_ctx *c, cge_ctx **slot, bool low_priority) {
+    if (!*slot) {
+        cge_ctx *sd = new cge_ctx();
+        *slot = sd; // owned from here on (cge_destroy)
+        sd->is_side = true;
+        sd->root = c;
+        sd->device = c->device;
+        sd->n_threads = 1;
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prio = low_priority ? least : 0;
+        HIP_CHECK(hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, prio));
+        sd->own_stream = true;
+        HIP_CHECK(hipStreamCreateWithPriority(&sd->copy_stream, hipStreamNonBlocking, prio));
+        HIP_CHECK(hipEventCreateWithFlags(&sd->copy_ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&sd->copy_done, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->sweep_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->tab_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->stage_ev[i], hipEventDisableTiming));
+    }
+    cge_ctx *sd = *slot;
+    // views are re-taken at every use: an upload may have replaced the buffers since the last one
+    sd->n = c->n; sd->m = c->m; sd->d = c->d; sd->ldn = c->ldn; sd->dpad = c->dpad;
+    sd->unit_weights = c->unit_weights; sd->n_comm_max = c->n_comm_max;
+    sd->Xr.borrow(c->Xr); sd->gmean.borrow(c->gmean); sd->vw.borrow(c->vw); sd->comm.borrow(c->comm);
+    sd->src.borrow(c->src); sd->dst.borrow(c->dst); sd->w.borrow(c->w);
+    sd->opt_diameter = c->opt_diameter; sd->opt_diameter_f32 = c->opt_diameter_f32;
+    sd->profiling = c->profiling; sd->profile_only = c->profile_only;
+    sd->h_Xr.clear(); // (a stale host mirror must not answer for a new embedding; it is fetched on demand)
+    return sd;
 }
 
 // for the other translation units (diameter_host.cpp)

@@ -386,7 +386,10 @@ struct cge_ctx {
     // context: own (low-priority) streams, own scratch, borrowed views of the resident inputs.  Single rank only (the
     // exchanges of an N > 1 score must be issued in one order).
     cge_ctx *side = nullptr;
+    cge_ctx *lane = nullptr; // second lane of runsplit's batches (landmarks_host.cpp): normal priority, borrows the arenas too
+    cge_ctx *root = nullptr; // shadow contexts: the context they belong to
     bool is_side = false;
+    int opt_lanes = 2;       // runsplit: 2 = every batch as two half-batches on two streams, half a chain out of phase; 1 = one stream
     int opt_landmark_edges = 0;  // 1: cge_score builds the N x N landmark-pair matrix too (what landmarks() returns)
     int opt_early_diameter = 1; // 0: the diameter after landmarks(), from the landmark partition, on the main stream (A/B, tests)
     // grow-only scratch of per-score helpers (no hipMalloc / hipFree inside a scoring call after the first: a hipFree waits
@@ -476,6 +479,7 @@ static inline unsigned grid_for(i64 work, int block, i64 cap = 256 * 8) {
 
 #define CGE_STAGE_BYTES ((size_t)16 << 20) // one staging buffer of the uploads
 void cge_ensure_host_embedding(cge_ctx *c); // capi.cpp: fetch the host mirror of Xr on first demand
+cge_ctx *cge_shadow_context(cge_ctx *c, cge_ctx **slot, bool low_priority); // capi.cpp: create / refresh c->side or c->lane
 
 // ---- kernels_*.hip entry points (host launchers) ---------------------------------------------
 // layout

@@ -1547,10 +1547,19 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
         // leaves every register bit as it is) -- a branch around the update would make the compiler keep two copies
         // of the matrix block.
         const bool refl = sigma != 0.0;
-        const double mu = sqrt(alpha * alpha + sigma);
-        const double v0r = (alpha <= 0.0) ? alpha - mu : -sigma / (alpha + mu);
+        double mu, v0r, bpr;
+        if (diag_stage == 13) { mu = alpha + sigma; v0r = alpha - mu; bpr = sigma * 0.5; } // timing diagnostics (wrong results)
+        else if (diag_stage == 11) {
+            mu = sqrt(alpha * alpha + sigma);
+            v0r = (alpha <= 0.0) ? alpha - mu : -sigma * fast_rcp(alpha + mu);
+            bpr = 2.0 * fast_rcp(sigma + v0r * v0r);
+        } else {
+            mu = sqrt(alpha * alpha + sigma);
+            v0r = (alpha <= 0.0) ? alpha - mu : -sigma / (alpha + mu);
+            bpr = 2.0 / (sigma + v0r * v0r);
+        }
         const double v0 = refl ? v0r : 0.0;
-        const double bp = refl ? 2.0 / (sigma + v0r * v0r) : 0.0; // H = I - bp u u^T, u = (v0, x[o+1..])
+        const double bp = refl ? bpr : 0.0; // H = I - bp u u^T, u = (v0, x[o+1..])
         if (tid == 0) { beta[k] = bp; off[k] = refl ? mu : alpha; V0[k] = v0; }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -1559,7 +1568,7 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             U[row] = u[r]; // every wave writes the same values
         }
         __builtin_amdgcn_wave_barrier();
-        const bool live = NC * wv + NC > o; // this wave still owns unfinished columns
+        const bool live = NC * wv + NC > o && diag_stage != 10; // this wave still owns unfinished columns
         { // partial p = B u over the wave's columns
             double s[NR];
 #pragma unroll
@@ -1593,7 +1602,7 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             W[row] = w[r];
         }
         __builtin_amdgcn_wave_barrier();
-        { // rank-2 update; waves whose columns are all finished run it too (u = w = 0 there: nothing changes)
+        if (diag_stage != 10) { // rank-2 update; waves whose columns are all finished run it too (u = w = 0 there: nothing changes)
 #pragma unroll
             for (int jj = 0; jj < NC; jj++) {
                 if (jj % 8 == 0) asm volatile("" ::: "memory");
@@ -1874,8 +1883,11 @@ __global__ __launch_bounds__(64 * NW, 2) void group_eigc_kernel(const double *__
     __syncthreads();
     extract(0);
     // ---- tridiagonalisation ------------------------------------------------------------------------
+    // The barriers of a step order LDS traffic only: a plain __syncthreads() would also wait for the reflector stores of
+    // wave 0 to reach memory (a release fence), i.e. put a global-memory round trip into every step.
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     for (int k = 0; k + 2 < d; k++) {
-        __syncthreads(); // (a) X of column k is visible; U, W, Pp of the previous step are dead
+        lds_barrier(); // (a) X of column k is visible; U, W, Pp of the previous step are dead
         const int o = k + 1;
         double x[NR], u[NR];
         double part = 0.0;
@@ -1899,7 +1911,7 @@ __global__ __launch_bounds__(64 * NW, 2) void group_eigc_kernel(const double *__
             const int row = lane + 64 * r;
             u[r] = (row == o) ? v0 : x[r];
             U[row] = u[r]; // every wave writes the same values
-            if (wv == 0) rf[(size_t)k * DP + row] = u[r];
+            if (wv == 0 && diag_stage != 12) rf[(size_t)k * DP + row] = u[r];
         }
         __builtin_amdgcn_wave_barrier();
         const bool low_live = NR == 1 || o < 64; // the rows of block 0 are all <= k once o >= 64
@@ -1909,7 +1921,7 @@ __global__ __launch_bounds__(64 * NW, 2) void group_eigc_kernel(const double *__
             for (int r = 0; r < NR; r++) s[r] = 0.0;
 #pragma unroll
             for (int g0 = 0; g0 < NC; g0 += G) {
-                if (NW * (g0 + G - 1) + wv >= o) { // the group's last column is live
+                if (NW * (g0 + G - 1) + wv >= o && diag_stage != 10) { // the group's last column is live
                     double uj[G];
 #pragma unroll
                     for (int q = 0; q < G; q++) uj[q] = U[NW * (g0 + q) + wv];
@@ -1927,7 +1939,7 @@ __global__ __launch_bounds__(64 * NW, 2) void group_eigc_kernel(const double *__
 #pragma unroll
             for (int r = 0; r < NR; r++) Pp[wv][lane + 64 * r] = s[r];
         }
-        __syncthreads(); // (b)
+        lds_barrier(); // (b)
         double w[NR];
         part = 0.0;
 #pragma unroll
@@ -1950,7 +1962,7 @@ __global__ __launch_bounds__(64 * NW, 2) void group_eigc_kernel(const double *__
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int g0 = 0; g0 < NC; g0 += G) { // rank-2 update of the live column groups
-            if (NW * (g0 + G - 1) + wv >= o) {
+            if (NW * (g0 + G - 1) + wv >= o && diag_stage != 10) {
                 double uj[G], wj[G];
 #pragma unroll
                 for (int q = 0; q < G; q++) { uj[q] = U[NW * (g0 + q) + wv]; wj[q] = W[NW * (g0 + q) + wv]; }
@@ -2843,8 +2855,8 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
     }
     ScopedKernelTimer t(c, "group_eig");
     static const int diag_stage = getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0; // 0 = normal
-    // A/B: CGE_EIG_FORM=0 the first form (blocked columns, reflectors in place), 4 (default) / 8: the cyclic form on 4 / 8 waves
-    static const int form = getenv("CGE_EIG_FORM") ? atoi(getenv("CGE_EIG_FORM")) : 4;
+    // A/B: CGE_EIG_FORM=0 (default) the first form (blocked columns, reflectors in place), 4 / 8: the cyclic form on 4 / 8 waves
+    static const int form = getenv("CGE_EIG_FORM") ? atoi(getenv("CGE_EIG_FORM")) : 0;
     const dim3 grid((unsigned)n_tasks), block(256);
     if (form == 0) {
         if (d <= 32)

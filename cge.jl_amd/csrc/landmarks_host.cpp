@@ -52,39 +52,43 @@ struct Group {
     i64 mean_off = -1, cmean_off = -1;
 };
 
-// reserve `cnt` entries of the member arena (grows by copying: ranges handed out earlier stay valid as offsets)
-i64 arena_alloc(cge_ctx *c, i64 cnt) {
+// The arenas belong to the ROOT context; a lane (shadow context, below) sees them through borrowed views.
+inline cge_ctx *root_of(cge_ctx *x) { return x->root ? x->root : x; }
+inline void refresh_arena_views(cge_ctx *x) {
+    cge_ctx *c = root_of(x);
+    if (x == c) return;
+    x->lm_arena.borrow(c->lm_arena);
+    x->lm_means.borrow(c->lm_means);
+}
+// Growth copies the arena into a larger allocation: everything that may still read or write the old one has to be done.
+template <typename T>
+void arena_grow(cge_ctx *c, DevBuf<T> &buf, i64 used, i64 need) {
+    const i64 cap = std::max<i64>(need + need / 2, 1024);
+    T *fresh = nullptr;
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->lane) HIP_CHECK(hipStreamSynchronize(c->lane->stream));
+    HIP_CHECK(hipMalloc((void **)&fresh, (size_t)cap * sizeof(T)));
+    if (buf.p && used > 0) HIP_CHECK(hipMemcpyAsync(fresh, buf.p, sizeof(T) * used, hipMemcpyDeviceToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (buf.p) (void)hipFree(buf.p);
+    buf.p = fresh;
+    buf.n = (size_t)cap;
+    if (c->lane) refresh_arena_views(c->lane);
+}
+// reserve `cnt` entries of the member arena (ranges handed out earlier stay valid as offsets)
+i64 arena_alloc(cge_ctx *x, i64 cnt) {
+    cge_ctx *c = root_of(x);
     const i64 need = c->lm_arena_used + cnt;
-    if ((i64)c->lm_arena.n < need || !c->lm_arena.p) {
-        const i64 cap = std::max<i64>(need + need / 2, 1024);
-        i32 *fresh = nullptr;
-        HIP_CHECK(hipMalloc((void **)&fresh, (size_t)cap * sizeof(i32)));
-        if (c->lm_arena.p && c->lm_arena_used > 0)
-            HIP_CHECK(hipMemcpyAsync(fresh, c->lm_arena.p, sizeof(i32) * c->lm_arena_used, hipMemcpyDeviceToDevice, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        if (c->lm_arena.p) (void)hipFree(c->lm_arena.p);
-        c->lm_arena.p = fresh;
-        c->lm_arena.n = (size_t)cap;
-    }
+    if ((i64)c->lm_arena.n < need || !c->lm_arena.p) arena_grow(c, c->lm_arena, c->lm_arena_used, need);
     const i64 at = c->lm_arena_used;
     c->lm_arena_used = need;
     return at;
 }
-
 // reserve `cnt` doubles of the means arena (same growth rule as the member arena)
-i64 means_alloc(cge_ctx *c, i64 cnt) {
+i64 means_alloc(cge_ctx *x, i64 cnt) {
+    cge_ctx *c = root_of(x);
     const i64 need = c->lm_means_used + cnt;
-    if ((i64)c->lm_means.n < need || !c->lm_means.p) {
-        const i64 cap = std::max<i64>(need + need / 2, 1024);
-        double *fresh = nullptr;
-        HIP_CHECK(hipMalloc((void **)&fresh, (size_t)cap * sizeof(double)));
-        if (c->lm_means.p && c->lm_means_used > 0)
-            HIP_CHECK(hipMemcpyAsync(fresh, c->lm_means.p, sizeof(double) * c->lm_means_used, hipMemcpyDeviceToDevice, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        if (c->lm_means.p) (void)hipFree(c->lm_means.p);
-        c->lm_means.p = fresh;
-        c->lm_means.n = (size_t)cap;
-    }
+    if ((i64)c->lm_means.n < need || !c->lm_means.p) arena_grow(c, c->lm_means, c->lm_means_used, need);
     const i64 at = c->lm_means_used;
     c->lm_means_used = need;
     return at;
@@ -402,7 +406,8 @@ struct WordPacker {
     }
 };
 // The other direction: device arrays -> one device staging area (one kernel) -> pinned memory (one copy).  fetch()
-// synchronises the stream; the pointers returned by add() are valid until the next gatherer is used.
+// waits for its copy (fetch_async() + wait() split the two halves); the pointers returned by get() are valid until the next
+// gatherer of the same context is used.
 struct WordGatherer {
     cge_ctx *c;
     std::vector<void *> ddst;
@@ -421,6 +426,11 @@ struct WordGatherer {
         return words.size() - 1;
     }
     void fetch() {
+        fetch_async();
+        wait();
+    }
+    void wait() { HIP_CHECK(hipEventSynchronize(c->copy_done)); }
+    void fetch_async() { // ... and the event c->copy_done behind the copy
         c->pin_res.ensure((size_t)std::max<i64>(tot, 1));
         c->dev_res.ensure((size_t)std::max<i64>(tot, 1));
         ddst.resize(dsrc.size());
@@ -431,7 +441,7 @@ struct WordGatherer {
         }
         if (tot > 0)
             HIP_CHECK(hipMemcpyAsync(c->pin_res.p, c->dev_res.p, sizeof(i32) * (size_t)tot, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
+        HIP_CHECK(hipEventRecord(c->copy_done, c->stream));
     }
     template <class T>
     const T *get(size_t item) const { return reinterpret_cast<const T *>(c->pin_res.p + offs[item]); }
@@ -563,8 +573,9 @@ struct RssState {
 };
 void rule_rss_batched(cge_ctx *c, const Batch &B, Group *const *groups, const double *z, std::vector<RssState> &st) {
     const i64 T = B.T, d = c->d, width = 2 * (2 * d + 1);
-    cge_ensure_host_embedding(c); // generic round-based path only (ties at the maximum of z, NaNs)
-    const double *hX = c->h_Xr.data(), *hw = c->h_vw.data();
+    cge_ctx *hr = root_of(c); // the host mirrors live in the root context
+    cge_ensure_host_embedding(hr); // generic round-based path only (ties at the maximum of z, NaNs)
+    const double *hX = hr->h_Xr.data(), *hw = hr->h_vw.data();
     st.assign(T, RssState());
     parallel_for(c, T, [&](i64 t) {
         RssState &S = st[t];
@@ -671,42 +682,63 @@ struct CutResult {
     std::vector<char> done; // 0 = this task still needs the generic host path
 };
 
+// One (half) batch in flight on one context (the root or its second lane): everything from the batch tables to the
+// rule's cut is ENQUEUED on that context's stream without a host synchronisation (lane_enqueue), the results are read
+// when the host comes back for them (lane_collect).  Two of these run half a chain out of phase (compute_splits).
+struct LaneRun {
+    cge_ctx *x = nullptr; // where it runs
+    Group *const *groups = nullptr;
+    i64 T = 0;
+    int method = 0;
+    Batch B;
+    i64 base = 0, mbase = -1;
+    CutResult cr;
+    std::unique_ptr<WordGatherer> wg;
+    size_t i_status = 0, i_meta = 0, i_vals = 0, i_nlow = 0;
+};
+
 // split_cluster_rss on sorted order (kernels_lm.hip: k_sorted_prefix + k_rss_rounds; kernels_sort.hip): the device
 // sorts z per task, scans the WSSE terms along that order, runs all median-cut rounds of every task in one launch, and
 // writes the children's member lists in the reference's order (seed first, then every absorbed batch in ascending
 // original index, :163-164, :189, :194, :204-206) by one stable radix pass over per-row bucket keys.
 // Tasks the rank-range argument does not cover (a tie at the maximum of z, NaNs) are left to the generic path.
-void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, i64 base, CutResult &out) {
+void rule_rss_sorted_enqueue(LaneRun &L) {
+    cge_ctx *c = L.x;
+    const Batch &B = L.B;
     const i64 T = B.T, R = B.R, d = c->d, W = 2 * d + 1;
     c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
     c->sp_ctot.ensure((size_t)B.NC * W); c->sp_coff.ensure((size_t)B.NC * W);
     c->sp_prefix.ensure((size_t)(R / CGE_PREFIX_STRIDE + B.NC + 1) * W);
     c->sp_meta.ensure(2 * T); c->sp_rounds.ensure((size_t)T * 3 * CGE_RR_MAXROUNDS); c->sp_vals.ensure(2 * T);
     c->ls_keys.ensure(R); c->ls_nlow.ensure(T);
-    const i64 mbase = means_alloc(c, 2 * T * d); // the children's means stay on the device
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                        c->sp_srows.p, c->sp_status.p);
     k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
     k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->ls_tco.p, c->sp_prefix.p, c->sp_coff.p,
-                 T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p, c->lm_means.p + mbase);
+                 T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p, c->lm_means.p + L.mbase); // the children's means stay on the device
     k_rss_child_keys(c, c->sp_perm.p, c->ls_row_task.p, c->sp_tro.p, c->sp_meta.p, c->sp_rounds.p, R, T, c->ls_keys.p,
                      c->ls_nlow.p);
-    k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + base);
-    WordGatherer wg(c);
-    const size_t i_status = wg.add(c->sp_status.p, T), i_meta = wg.add(c->sp_meta.p, 2 * T), i_vals = wg.add(c->sp_vals.p, 2 * T),
-                 i_nlow = wg.add(c->ls_nlow.p, T);
-    wg.fetch();
-    const i32 *status = wg.get<i32>(i_status), *meta = wg.get<i32>(i_meta);
-    const double *vals = wg.get<double>(i_vals);
-    std::memcpy(out.nlow.data(), wg.get<i32>(i_nlow), sizeof(i32) * T);
+    k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + L.base);
+    L.wg.reset(new WordGatherer(c));
+    L.i_status = L.wg->add(c->sp_status.p, T); L.i_meta = L.wg->add(c->sp_meta.p, 2 * T);
+    L.i_vals = L.wg->add(c->sp_vals.p, 2 * T); L.i_nlow = L.wg->add(c->ls_nlow.p, T);
+    L.wg->fetch_async();
+}
+void rule_rss_sorted_collect(LaneRun &L) {
+    const i64 T = L.B.T, d = L.x->d;
+    CutResult &out = L.cr;
+    L.wg->wait();
+    const i32 *status = L.wg->get<i32>(L.i_status), *meta = L.wg->get<i32>(L.i_meta);
+    const double *vals = L.wg->get<double>(L.i_vals);
+    std::memcpy(out.nlow.data(), L.wg->get<i32>(L.i_nlow), sizeof(i32) * T);
     for (i64 t = 0; t < T; t++) {
-        Group *g = groups[t];
+        Group *g = L.groups[t];
         if (status[t] == 2) { g->rc = CGE_E_HOMOGENEOUS; out.done[t] = 1; continue; }
         if (status[t] == 1 || meta[2 * t + 1] != 0) { out.done[t] = 0; continue; }
         out.vlow[t] = vals[2 * t];
         out.vhigh[t] = vals[2 * t + 1];
-        g->cmean_off = mbase + 2 * t * d;
+        g->cmean_off = L.mbase + 2 * t * d;
         g->rc = CGE_OK;
         out.done[t] = 1;
     }
@@ -714,28 +746,34 @@ void rule_rss_sorted(cge_ctx *c, const Batch &B, Group *const *groups, i64 base,
 
 // split_cluster_rss2 on the device (kernels_lm.hip: rss2_walk_kernel).  The children are rank ranges of the sorted
 // order, in that order (`p[1:low]`, `p[high:end]`, src/landmarks.jl:151): the sorted rows ARE the two lists.
-void rule_rss2_device(cge_ctx *c, const Batch &B, Group *const *groups, i64 base, CutResult &out) {
+void rule_rss2_enqueue(LaneRun &L) {
+    cge_ctx *c = L.x;
+    const Batch &B = L.B;
     const i64 T = B.T, R = B.R, d = c->d;
     hipStream_t st = c->stream;
     c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
     c->sp_meta.ensure(2 * T); c->sp_vals.ensure(2 * T);
-    const i64 mbase = means_alloc(c, 2 * T * d);
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                        c->sp_srows.p, c->sp_status.p);
-    HIP_CHECK(hipMemcpyAsync(c->lm_arena.p + base, c->sp_srows.p, sizeof(i32) * R, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(c->lm_arena.p + L.base, c->sp_srows.p, sizeof(i32) * R, hipMemcpyDeviceToDevice, st));
     c->r2_rows = R;
-    k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->lm_means.p + mbase);
-    WordGatherer wg(c);
-    const size_t i_meta = wg.add(c->sp_meta.p, 2 * T), i_vals = wg.add(c->sp_vals.p, 2 * T);
-    wg.fetch();
-    const i32 *meta = wg.get<i32>(i_meta);
-    const double *vals = wg.get<double>(i_vals);
+    k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->lm_means.p + L.mbase);
+    L.wg.reset(new WordGatherer(c));
+    L.i_meta = L.wg->add(c->sp_meta.p, 2 * T); L.i_vals = L.wg->add(c->sp_vals.p, 2 * T);
+    L.wg->fetch_async();
+}
+void rule_rss2_collect(LaneRun &L) {
+    const i64 T = L.B.T, d = L.x->d;
+    CutResult &out = L.cr;
+    L.wg->wait();
+    const i32 *meta = L.wg->get<i32>(L.i_meta);
+    const double *vals = L.wg->get<double>(L.i_vals);
     for (i64 t = 0; t < T; t++) {
-        Group *g = groups[t];
+        Group *g = L.groups[t];
         out.nlow[t] = meta[2 * t] + 1; // low = ranks [0, lo], high = ranks [hi, k) with hi == lo + 1
         out.vlow[t] = vals[2 * t];
         out.vhigh[t] = vals[2 * t + 1];
-        g->cmean_off = mbase + 2 * t * d;
+        g->cmean_off = L.mbase + 2 * t * d;
         g->rc = CGE_OK;
         out.done[t] = 1;
     }
@@ -744,7 +782,9 @@ void rule_rss2_device(cge_ctx *c, const Batch &B, Group *const *groups, i64 base
 // split_cluster_size / split_cluster_diameter on the device (kernels_lm.hip: cut_sides_kernel): the side of every row,
 // the children's WSSE column sums (values and means) by the side-sums pass, and the two member lists -- the rows of
 // either side in the rows' own order -- by a stable one-bit sort.
-void rule_cut_device(cge_ctx *c, const Batch &B, Group *const *groups, bool use_median, i64 base, CutResult &out) {
+void rule_cut_enqueue(LaneRun &L, bool use_median) {
+    cge_ctx *c = L.x;
+    const Batch &B = L.B;
     const i64 T = B.T, R = B.R, d = c->d, width = 2 * (2 * d + 1);
     hipStream_t st = c->stream;
     if (use_median) { // the median needs the sorted projections
@@ -755,15 +795,25 @@ void rule_cut_device(cge_ctx *c, const Batch &B, Group *const *groups, bool use_
     c->ls_nlow.ensure(T);
     k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p);
     k_side_counts(c, c->ls_side.p, c->sp_tro.p, T, c->ls_nlow.p);
-    k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + base);
-    c->pin_res.ensure((size_t)T); // pinned: the copy does not stall the host, the synchronisation below covers it
+    k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + L.base);
+    c->pin_res.ensure((size_t)T); // pinned: the copies do not stall the host, the event below covers them
     HIP_CHECK(hipMemcpyAsync(c->pin_res.p, c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
-    const double *sums = side_sums_resident(c, B); // synchronises the stream
+    k_group_side_sums(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
+                      c->ls_part.p, c->ls_sums.p);
+    c->pin_sums.ensure((size_t)B.T * width);
+    HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->ls_sums.p, sizeof(double) * B.T * width, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(c->copy_done, st));
+}
+void rule_cut_collect(LaneRun &L) {
+    cge_ctx *c = L.x;
+    const i64 T = L.B.T, d = c->d, width = 2 * (2 * d + 1);
+    CutResult &out = L.cr;
+    HIP_CHECK(hipEventSynchronize(c->copy_done));
+    const double *sums = c->pin_sums.p;
     std::memcpy(out.nlow.data(), c->pin_res.p, sizeof(i32) * T);
-    const i64 mbase = means_alloc(c, 2 * T * d);
     c->pin_cmeans.ensure((size_t)2 * T * d);
     parallel_for(c, T, [&](i64 t) {
-        Group *g = groups[t];
+        Group *g = L.groups[t];
         const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
         out.vlow[t] = -rss_from_sums(q1, d);
         out.vhigh[t] = -rss_from_sums(q2, d);
@@ -772,11 +822,13 @@ void rule_cut_device(cge_ctx *c, const Batch &B, Group *const *groups, bool use_
             ml[c2] = q1[d + c2] / q1[2 * d];
             mh[c2] = q2[d + c2] / q2[2 * d];
         }
-        g->cmean_off = mbase + 2 * t * d;
+        g->cmean_off = L.mbase + 2 * t * d;
         g->rc = CGE_OK;
         out.done[t] = 1;
     });
-    HIP_CHECK(hipMemcpyAsync(c->lm_means.p + mbase, c->pin_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyHostToDevice, st));
+    // the next batch reads these means from either lane's stream: the copy has to be over before anything more is enqueued
+    HIP_CHECK(hipMemcpyAsync(c->lm_means.p + L.mbase, c->pin_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 
 // The generic round-based rss path for the tasks the sorted-order kernels declined (ties at the maximum of z, NaNs):
@@ -852,8 +904,107 @@ void rss_generic_tasks(cge_ctx *c, const Batch &B, Group *const *groups, i64 bas
     }
 }
 
-// Compute the split of every task, on the device: mean, covariance, principal eigenvector, projection, the rule's
-// 1-D cut, the children's member lists, values and means.  The host only books the results.
+// Enqueue the split of every task of a (half) batch on L.x: mean, covariance, principal eigenvector, projection, the
+// rule's 1-D cut, the children's member lists, values and means -- no host synchronisation (except the d > 512 host
+// eigen-solver).  `after_cov` (optional): recorded behind the covariance, the point the other lane's start waits for.
+void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
+    cge_ctx *c = L.x, *root = root_of(c);
+    const i64 d = c->d, T = L.T;
+    hipStream_t st = c->stream;
+    Batch &B = L.B;
+    refresh_arena_views(c);
+    bool have_means = true; // known from the parents' splits: gathered from the means arena, no pass over the rows
+    for (i64 t = 0; t < T && have_means; t++) have_means = L.groups[t]->mean_off >= 0;
+    {
+        PhaseAcc pa(root, "lm_pack");
+        build_batch(c, L.groups, T, B);
+        if (start_after) HIP_CHECK(hipStreamWaitEvent(st, start_after, 0));
+        std::vector<i64> moff;
+        if (have_means) {
+            moff.resize(T);
+            for (i64 t = 0; t < T; t++) moff[t] = L.groups[t]->mean_off;
+        }
+        upload_batch(c, B, have_means ? moff.data() : nullptr);
+    }
+    const i64 R = B.R, NC = B.NC;
+    root->stat_lm_batches++;
+    root->stat_lm_rows += R;
+    root->stat_lm_splits += T;
+    c->ls_mean.ensure((size_t)T * d); c->ls_sw.ensure(T); c->ls_cov.ensure((size_t)T * d * d);
+    c->ls_vec.ensure((size_t)T * d); c->ls_z.ensure(R);
+    {
+        PhaseAcc pa(root, "lm_pca_dev");
+        {
+            ScopedKernelTimer tm(c, "group_stats");
+            if (have_means) // the offsets went up with the batch's tables
+                k_gather_means(c, c->lm_means.p, c->ls_moff.p, T, d, c->ls_mean.p);
+            else
+                k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
+                             c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
+            k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
+                        c->ls_mean.p, c->ls_part.p, c->ls_cov.p);
+        }
+        if (after_cov) HIP_CHECK(hipEventRecord(after_cov, st));
+        if (!k_group_eig(c, c->ls_cov.p, T, d, c->ls_vec.p)) { // d > 512: host solver on a worker pool
+            std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d);
+            HIP_CHECK(hipMemcpyAsync(cov.data(), c->ls_cov.p, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            parallel_for(c, T, [&](i64 t) { host_eig_top(&cov[(size_t)t * d * d], d, &vec[(size_t)t * d]); });
+            HIP_CHECK(hipMemcpyAsync(c->ls_vec.p, vec.data(), sizeof(double) * vec.size(), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st)); // vec goes out of scope
+        }
+        {
+            ScopedKernelTimer tm(c, "group_project");
+            k_group_project(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_row_task.p, R, d, c->ls_mean.p, c->ls_vec.p,
+                            c->ls_z.p);
+        }
+    }
+    // ---- the cut: children lists into the arena, sizes / values / means to the host -----------------------------
+    L.cr.nlow.assign(T, 0);
+    L.cr.vlow.assign(T, 0.0);
+    L.cr.vhigh.assign(T, 0.0);
+    L.cr.done.assign(T, 0);
+    if (L.method == CGE_METHOD_RSS) rule_rss_sorted_enqueue(L);
+    else if (L.method == CGE_METHOD_RSS2) rule_rss2_enqueue(L);
+    else rule_cut_enqueue(L, L.method == CGE_METHOD_SIZE);
+}
+// ... and book the results when they have arrived
+void lane_collect(LaneRun &L) {
+    cge_ctx *c = L.x, *root = root_of(c);
+    const i64 T = L.T;
+    const Batch &B = L.B;
+    {
+        PhaseAcc pa(root, "lm_cut");
+        if (L.method == CGE_METHOD_RSS) {
+            rule_rss_sorted_collect(L);
+            std::vector<i64> todo;
+            for (i64 t = 0; t < T; t++)
+                if (!L.cr.done[t]) todo.push_back(t);
+            if (!todo.empty()) rss_generic_tasks(c, B, L.groups, L.base, todo, L.cr);
+        } else if (L.method == CGE_METHOD_RSS2)
+            rule_rss2_collect(L);
+        else
+            rule_cut_collect(L);
+    }
+    for (i64 t = 0; t < T; t++) {
+        Group *g = L.groups[t];
+        if (g->rc != CGE_OK) continue;
+        const i64 nl = L.cr.nlow[t], nh = g->len - nl;
+        if (nl <= 0 || nh <= 0) { g->rc = CGE_E_EMPTY_CLUSTER; continue; }
+        g->coff = L.base + B.task_row_off[t];
+        g->nlow = nl;
+        g->vlow = nl > 1 ? L.cr.vlow[t] : DBL_EPSILON;
+        g->vhigh = nh > 1 ? L.cr.vhigh[t] : DBL_EPSILON;
+    }
+}
+
+// Compute the split of every task, on the device.  The host only books the results.
+// TWO LANES: the chain of a batch is a dozen dependent kernels of very different character -- covariance (MFMA),
+// eigen-solver (126 dependent Householder steps: latency, most of the chip idle), projection / sort / scan / rounds (HBM
+// gathers).  A batch is therefore cut into two halves that run on two streams half a chain out of phase (the second
+// half starts when the first half's covariance is done), so one half's eigen-solver overlaps the other's memory-bound
+// kernels, and the host side of one half (tables, result parsing) overlaps the device side of the other.  The halves
+// are independent (disjoint groups, disjoint arena ranges); results do not depend on the split.
 void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
     const i64 d = c->d;
     std::vector<Group *> big;
@@ -880,87 +1031,36 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
 
     // Sub-batches bound the covariance buffers (T * d*d doubles) to ~1 GiB.
     const i64 max_tasks = std::max<i64>(1, (i64)(1ull << 27) / (d * d));
+    static const int lanes_env = getenv("CGE_LANES") ? atoi(getenv("CGE_LANES")) : 0; // A/B: 1 = one stream
+    const int lanes = lanes_env > 0 ? lanes_env : c->opt_lanes;
     for (size_t b0 = 0; b0 < big.size(); b0 += (size_t)max_tasks) {
         const size_t b1 = std::min(big.size(), b0 + (size_t)max_tasks);
         const i64 T = (i64)(b1 - b0);
         Group *const *groups = &big[b0];
-        hipStream_t st = c->stream;
-        Batch B;
-        i64 base;
-        bool have_means = true; // known from the parents' splits: gathered from the means arena, no pass over the rows
-        for (i64 t = 0; t < T && have_means; t++) have_means = groups[t]->mean_off >= 0;
-        {
-            PhaseAcc pa(c, "lm_pack");
-            build_batch(c, groups, T, B);
-            base = arena_alloc(c, B.R); // the children of task t: [base + task_row_off[t], + len)
-            std::vector<i64> moff;
-            if (have_means) {
-                moff.resize(T);
-                for (i64 t = 0; t < T; t++) moff[t] = groups[t]->mean_off;
-            }
-            upload_batch(c, B, have_means ? moff.data() : nullptr);
+        // (a lane is worth its fixed costs from a few dozen groups on; the N > 1 exchanges need one arena order: one lane)
+        const bool two = lanes >= 2 && T >= 64 && !c->has_coll;
+        LaneRun L[2];
+        // the first half takes every other group, so both halves see the same mix of sizes
+        std::vector<Group *> half[2];
+        if (two) {
+            for (i64 t = 0; t < T; t++) half[t & 1].push_back(groups[t]);
         }
-        const i64 R = B.R, NC = B.NC;
-        c->stat_lm_batches++;
-        c->stat_lm_rows += R;
-        c->stat_lm_splits += T;
-        c->ls_mean.ensure((size_t)T * d); c->ls_sw.ensure(T); c->ls_cov.ensure((size_t)T * d * d);
-        c->ls_vec.ensure((size_t)T * d); c->ls_z.ensure(R);
-        {
-            PhaseAcc pa(c, "lm_pca_dev");
-            {
-                ScopedKernelTimer tm(c, "group_stats");
-                if (have_means) // the offsets went up with the batch's tables
-                    k_gather_means(c, c->lm_means.p, c->ls_moff.p, T, d, c->ls_mean.p);
-                else
-                    k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
-                                 c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
-                k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
-                            c->ls_mean.p, c->ls_part.p, c->ls_cov.p);
-            }
-            if (!k_group_eig(c, c->ls_cov.p, T, d, c->ls_vec.p)) { // d > 512: host solver on a worker pool
-                std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d);
-                HIP_CHECK(hipMemcpyAsync(cov.data(), c->ls_cov.p, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipStreamSynchronize(st));
-                parallel_for(c, T, [&](i64 t) { host_eig_top(&cov[(size_t)t * d * d], d, &vec[(size_t)t * d]); });
-                HIP_CHECK(hipMemcpyAsync(c->ls_vec.p, vec.data(), sizeof(double) * vec.size(), hipMemcpyHostToDevice, st));
-                HIP_CHECK(hipStreamSynchronize(st)); // vec goes out of scope
-            }
-            {
-                ScopedKernelTimer tm(c, "group_project");
-                k_group_project(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_row_task.p, R, d, c->ls_mean.p, c->ls_vec.p,
-                                c->ls_z.p);
-            }
+        const int nl = two ? 2 : 1;
+        cge_ctx *lane = two ? cge_shadow_context(c, &c->lane, false) : nullptr;
+        // both halves' ranges are handed out before anything is in flight (growing an arena copies it)
+        for (int q = 0; q < nl; q++) {
+            L[q].x = q == 0 ? c : lane;
+            L[q].groups = two ? half[q].data() : groups;
+            L[q].T = two ? (i64)half[q].size() : T;
+            L[q].method = method;
+            i64 r = 0;
+            for (i64 t = 0; t < L[q].T; t++) r += L[q].groups[t]->len;
+            L[q].base = arena_alloc(c, r); // the children of task t: [base + task_row_off[t], + len)
+            L[q].mbase = means_alloc(c, 2 * L[q].T * d);
         }
-        // ---- the cut: children lists into the arena, sizes / values / means to the host -----------------------------
-        CutResult cr;
-        cr.nlow.assign(T, 0);
-        cr.vlow.assign(T, 0.0);
-        cr.vhigh.assign(T, 0.0);
-        cr.done.assign(T, 0);
-        {
-            PhaseAcc pa(c, "lm_cut");
-            if (method == CGE_METHOD_RSS) {
-                rule_rss_sorted(c, B, groups, base, cr);
-                std::vector<i64> todo;
-                for (i64 t = 0; t < T; t++)
-                    if (!cr.done[t]) todo.push_back(t);
-                if (!todo.empty()) rss_generic_tasks(c, B, groups, base, todo, cr);
-            } else if (method == CGE_METHOD_RSS2)
-                rule_rss2_device(c, B, groups, base, cr);
-            else
-                rule_cut_device(c, B, groups, method == CGE_METHOD_SIZE, base, cr);
-        }
-        for (i64 t = 0; t < T; t++) {
-            Group *g = groups[t];
-            if (g->rc != CGE_OK) continue;
-            const i64 nl = cr.nlow[t], nh = g->len - nl;
-            if (nl <= 0 || nh <= 0) { g->rc = CGE_E_EMPTY_CLUSTER; continue; }
-            g->coff = base + B.task_row_off[t];
-            g->nlow = nl;
-            g->vlow = nl > 1 ? cr.vlow[t] : DBL_EPSILON;
-            g->vhigh = nh > 1 ? cr.vhigh[t] : DBL_EPSILON;
-        }
+        lane_enqueue(L[0], two ? c->copy_ev : nullptr, nullptr);
+        if (two) lane_enqueue(L[1], nullptr, c->copy_ev);
+        for (int q = 0; q < nl; q++) lane_collect(L[q]);
     }
 }
 
