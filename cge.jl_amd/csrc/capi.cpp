@@ -1018,12 +1018,12 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     bool side_samples = false;
     if (landmarks) {
         // single rank: clamp, sample draws and diameter run beside runsplit on the side context (above)
-        const bool use_side = c->opt_early_diameter && !c->has_coll;
+        const bool use_side = (c->opt_early_diameter || c->opt_side_samples) && !c->has_coll;
         if (use_side) {
             cge_ctx *sd = side_context(c);
             c->smp.reset();
             job.land_f = job.land.get_future();
-            job.th = std::thread(side_job_body, c, sd, a, (i64)a->land, c->opt_diameter != 1, &job);
+            job.th = std::thread(side_job_body, c, sd, a, (i64)a->land, c->opt_early_diameter && c->opt_diameter != 1, &job);
             const std::function<i64()> late = [&]() {
                 const i64 v = job.land_f.get(); // rethrows what the clamp threw
                 c->lm_truncated = job.truncated;
@@ -1234,13 +1234,17 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;
     }
-    if (!strcmp(key, "runsplit_lanes")) { // 2 (default): the batches of runsplit run as two half-batches on two streams, out of phase; 1: one stream
+    if (!strcmp(key, "runsplit_lanes")) { // 2: the batches of runsplit run as two half-batches on two streams, out of phase; 1 (default): one stream
         if (value < 1 || value > 2) return CGE_E_ARG;
         c->opt_lanes = (int)value;
         return CGE_OK;
     }
-    if (!strcmp(key, "early_diameter")) { // 1 (default): clamp, sample draws and diameter on the side context beside runsplit (single rank); 0: in line
-        c->opt_early_diameter = value != 0;
+    if (!strcmp(key, "early_diameter")) { // 1: the diameter too on the side context beside runsplit (single rank), from the cluster-chunk partition;
+        c->opt_early_diameter = value != 0; // 0 (default): in line after landmarks(), from the landmark partition
+        return CGE_OK;
+    }
+    if (!strcmp(key, "side_samples")) { // 1 (default): the `land` clamp and the sample draws on the side context beside runsplit (single rank); 0: in line
+        c->opt_side_samples = value != 0;
         return CGE_OK;
     }
     if (!strcmp(key, "landmark_edges")) { // 1: cge_score also builds the landmark-pair matrix / edge count that landmarks() returns

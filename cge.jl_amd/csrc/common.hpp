@@ -389,9 +389,15 @@ struct cge_ctx {
     cge_ctx *lane = nullptr; // second lane of runsplit's batches (landmarks_host.cpp): normal priority, borrows the arenas too
     cge_ctx *root = nullptr; // shadow contexts: the context they belong to
     bool is_side = false;
-    int opt_lanes = 2;       // runsplit: 2 = every batch as two half-batches on two streams, half a chain out of phase; 1 = one stream
+    int opt_lanes = 1;       // runsplit: 2 = every batch as two half-batches on two streams, half a chain out of phase; 1 (default) = one
+                             // stream.  Measured (profiles/r03_lanes_ab.txt): the eigen-solver of a half batch takes as long as that of
+                             // a whole one and the halves' kernels stretch each other: no gain on any workload
     int opt_landmark_edges = 0;  // 1: cge_score builds the N x N landmark-pair matrix too (what landmarks() returns)
-    int opt_early_diameter = 1; // 0: the diameter after landmarks(), from the landmark partition, on the main stream (A/B, tests)
+    int opt_early_diameter = 0; // 1: the diameter on the side context too (cluster-chunk partition); 0: after landmarks(), from the
+                                // landmark partition, on the main stream.  Measured (profiles/r03_side_context_ab.txt): the search is
+                                // HBM- and MFMA-heavy and runsplit's big first batches are too -- run side by side they slow each
+                                // other by as much as the overlap saves, so the default keeps it in line.
+    int opt_side_samples = 1;   // the `land` clamp and the sample draws (little device work, several host round trips) on the side context
     // grow-only scratch of per-score helpers (no hipMalloc / hipFree inside a scoring call after the first: a hipFree waits
     // for every stream of the device, the side context's included)
     DevBuf<i32> epd_i, s_star;

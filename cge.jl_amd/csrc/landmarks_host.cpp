@@ -1174,10 +1174,27 @@ void throw_rc(int rc) {
     }
 }
 
+// What the splits seen so far say about the next ones: the mean ratio child value / parent value (low and high child) and
+// the mean share of the rows that goes to the low child.  Only used to GUESS which groups will be popped (advance_heaps);
+// no result depends on it.
+struct SplitModel {
+    double sum_lo = 0.0, sum_hi = 0.0, sum_share = 0.0;
+    i64 n = 0;
+    double r_lo() const { return n ? sum_lo / (double)n : 0.5; }
+    double r_hi() const { return n ? sum_hi / (double)n : 0.5; }
+    double share() const { return n ? sum_share / (double)n : 0.5; }
+};
+
 // create the child groups of every freshly split task (single-threaded: the pool is not thread-safe)
-void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool, i64 c_d) {
+void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool, i64 c_d, SplitModel *model = nullptr) {
     for (Group *g : tasks) {
         if (g->rc != CGE_OK || g->clo) continue;
+        if (model && g->value < 0.0 && g->nlow > 1 && g->len - g->nlow > 1) { // (heap keys are -total_rss: ratios are positive)
+            model->sum_lo += g->vlow / g->value;
+            model->sum_hi += g->vhigh / g->value;
+            model->sum_share += (double)g->nlow / (double)g->len;
+            model->n++;
+        }
         pool.emplace_back();
         g->clo = &pool.back();
         g->clo->off = g->coff;
@@ -1209,7 +1226,7 @@ void replay_one(Heap &h) {
 // `speculate` = false: only the current top of each heap is split per round (no wasted splits; used for the
 // many small per-community heaps of the forced phase, which need s-1 rounds anyway).
 void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64> &targets, int method,
-                   std::deque<Group> &pool, bool speculate) {
+                   std::deque<Group> &pool, bool speculate, SplitModel &model) {
     for (;;) {
         PhaseAcc *ph = new PhaseAcc(c, "lm_heap"); // replay + choice of the next batch (host)
         std::vector<Group *> batch;
@@ -1221,12 +1238,57 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
                 batch.push_back(h.top());
                 continue;
             }
+            const i64 remaining = targets[q] - (i64)h.len();
+            std::vector<Group *> frontier;
+            if (c->opt_speculation_pct == 0) {
+                // PLAY THE REST OF THE POP SEQUENCE FORWARD on what is known: cached splits contribute their real children, an
+                // unsplit group two GUESSED children (value and size scaled by the mean ratios of the splits seen so far).  The
+                // known unsplit groups this rehearsal pops are the ones to split now -- all of them at once, so a round of
+                // batches resolves one level of the relevant split tree; groups the rehearsal leaves alone are (probably) never
+                // popped and cost nothing.  A margin below the rehearsal's last popped value covers the guess.  Whatever the
+                // guesses, the replay above is the reference's own sequence: a wrong guess costs a wasted or a late split.
+                struct Sim { double value; Group *g; double len; };
+                auto later = [](const Sim &a, const Sim &b) { return a.value > b.value; }; // min-heap on value
+                std::vector<Sim> pq;
+                pq.reserve(h.len() + 2 * remaining + 8);
+                for (size_t i = 1; i <= h.len(); i++) pq.push_back(Sim{h.a[i]->value, h.a[i], (double)h.a[i]->len});
+                std::make_heap(pq.begin(), pq.end(), later);
+                const double r_lo = model.r_lo(), r_hi = model.r_hi(), share = std::min(0.95, std::max(0.05, model.share()));
+                double last = 0.0;
+                i64 pops = remaining;
+                while (pops > 0 && !pq.empty()) {
+                    std::pop_heap(pq.begin(), pq.end(), later);
+                    const Sim it = pq.back();
+                    pq.pop_back();
+                    if (!(it.value < 0.0) && !(it.g && it.g == h.top())) break; // only singletons (eps()) are left: the reference stops here too
+                    pops--;
+                    last = it.value;
+                    if (it.g && it.g->has_split) {
+                        if (it.g->rc != CGE_OK) break; // the replay will raise it
+                        for (Group *ch : {it.g->clo, it.g->chi}) {
+                            pq.push_back(Sim{ch->value, ch, (double)ch->len});
+                            std::push_heap(pq.begin(), pq.end(), later);
+                        }
+                        continue;
+                    }
+                    if (it.g) frontier.push_back(it.g);
+                    const double l1 = it.len * share, l2 = it.len - l1;
+                    if (l1 >= 2.0) { pq.push_back(Sim{it.value * r_lo, nullptr, l1}); std::push_heap(pq.begin(), pq.end(), later); }
+                    if (l2 >= 2.0) { pq.push_back(Sim{it.value * r_hi, nullptr, l2}); std::push_heap(pq.begin(), pq.end(), later); }
+                }
+                const double margin = (method == CGE_METHOD_SIZE || method == CGE_METHOD_DIAMETER) ? 0.75 : 0.9;
+                for (const Sim &it : pq) // known, unsplit, just below the rehearsal's threshold (values are negative)
+                    if (it.g && !it.g->has_split && it.g->len > 1 && it.value <= last * margin) frontier.push_back(it.g);
+                if (frontier.empty() && !h.top()->has_split) frontier.push_back(h.top());
+                batch.insert(batch.end(), frontier.begin(), frontier.end());
+                continue;
+            }
+            // (explicit speculation_pct: the rank rule of rounds 1-2, kept for A/B)
             // Exactly `remaining` more pops will happen.  A node can only be among them if its value ranks within
             // `remaining` among ALL known unpopped nodes (cached splits and unsplit ones alike): nodes still to be
             // discovered only add competitors.  So every unsplit node above that threshold is a candidate and
             // every one below it is certainly never popped.
-            const i64 remaining = targets[q] - (i64)h.len();
-            std::vector<Group *> frontier, stack;
+            std::vector<Group *> stack;
             std::vector<double> vals;
             for (size_t i = 1; i <= h.len(); i++) stack.push_back(h.a[i]);
             while (!stack.empty()) {
@@ -1256,9 +1318,7 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
             // outrank it).  Splitting only the most valuable part per round costs a round or two more and saves the
             // eigen-problems of the rest; what is left over is reconsidered, with more known, in the next round.
             // (never fewer than 256 at a time: the last pops would otherwise trickle through many tiny rounds)
-            const int spec_pct = c->opt_speculation_pct > 0 ? c->opt_speculation_pct
-                                 : (method == CGE_METHOD_SIZE || method == CGE_METHOD_DIAMETER) ? 10
-                                 : (c->d > 128 ? 25 : 40); // wide embeddings: a wasted split costs a memory-resident eigen-problem
+            const int spec_pct = c->opt_speculation_pct;
             const i64 take = std::max<i64>(std::min<i64>(remaining, 256), (i64)((double)remaining * spec_pct / 100.0));
             if ((i64)frontier.size() > take) {
                 std::nth_element(frontier.begin(), frontier.begin() + (take - 1), frontier.end(),
@@ -1276,7 +1336,7 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
         if (speculate) compute_splits_sharded(c, batch, method); // the global phase (N > 1: split over the ranks)
         else compute_splits(c, batch, method);
         PhaseAcc pm(c, "lm_materialise");
-        materialise_children(batch, pool, c->d);
+        materialise_children(batch, pool, c->d, &model);
     }
 }
 
@@ -1293,6 +1353,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         CGE_THROW(CGE_E_ARG, "runsplit: embedding / vertex weights are not resident");
     std::deque<Group> pool;
     Heap H;
+    SplitModel model;
     PhaseAcc *pinit = new PhaseAcc(c, "lm_init");
     // sort(initial_clusters): lexicographic (:281)
     std::vector<i64> order(ncl);
@@ -1370,7 +1431,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         std::vector<i64> tg;
         for (i64 b = 0; b < nbig; b++)
             if (owner[b] == me) { hs.push_back(&locals[b].h); tg.push_back(forced); }
-        if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false);
+        if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model);
         if (shard) {
             PhaseAcc px(c, "lm_exchange");
             double *X = c->xptr;
@@ -1477,7 +1538,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         if (late_nland) nland = (*late_nland)(); // the `land` clamp (src/landmarks.jl:371-376), computed beside the forced phase
         std::vector<Heap *> hs{&H};
         std::vector<i64> tg{nland};
-        advance_heaps(c, hs, tg, method, pool, true);
+        advance_heaps(c, hs, tg, method, pool, true, model);
     }
     // ---- the heap array is the numbering (:337-342): v2l and the landmark index, on the device -----------------------
     PhaseAcc pfin(c, "lm_final");

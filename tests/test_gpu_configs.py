@@ -123,21 +123,30 @@ def _run_config(ctx, name, check_host_flow=True):
     tr = ctx.last_trace
     hi, path, _, _ = ctx.last_diameter()
     assert hi == float(fx["hi"]), f"diameter {hi!r} ({path}) != exact CPU value {float(fx['hi'])!r}"
-    assert ctx.get_stat("diameter_on_side_context") == 1  # found beside runsplit, from a partition that needs no landmarks
     lm = _check_landmarks(ctx, fx)
     _check_sweep(res, tr, fx, same_samples=False)
     assert res[6] == pytest.approx(1.96 * math.sqrt(res[5] * (1 - res[5]) / wl["samples"]), rel=1e-9)
     res_again = ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=42,
                           auc_samples=wl["samples"])
     assert np.array_equal(res, res_again)  # bitwise reproducible (fixed summation orders; unit weights)
-    try:  # everything in line on the main stream, the diameter from the LANDMARK partition: the same bits
-        ctx.set_option("early_diameter", 0)
-        res_serial = ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=42,
-                               auc_samples=wl["samples"])
-        assert ctx.get_stat("diameter_on_side_context") == 0 and ctx.last_diameter()[0] == hi
-        assert np.array_equal(res, res_serial)
-    finally:
-        ctx.set_option("early_diameter", 1)
+    assert ctx.get_stat("diameter_on_side_context") == 0
+    # The diameter's branch and bound is exact for any partition: on the side context (beside runsplit) it runs from the
+    # clusters cut into chunks instead of the landmarks -- the same bits; so do two half-batches per round on two streams,
+    # the rank rule of rounds 1-2 for the speculative splits, and everything in line on one thread.
+    for opts in ({"early_diameter": 1}, {"runsplit_lanes": 2}, {"speculation_pct": 40}, {"side_samples": 0}):
+        try:
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            res_alt = ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=42,
+                                auc_samples=wl["samples"])
+            assert ctx.get_stat("diameter_on_side_context") == opts.get("early_diameter", 0) and ctx.last_diameter()[0] == hi
+            assert np.array_equal(res, res_alt), opts
+            assert crc(ctx.landmarks_fetch()[6].astype(np.int32)) == crc(lm[6].astype(np.int32)), opts
+        finally:
+            ctx.set_option("early_diameter", 0)
+            ctx.set_option("runsplit_lanes", 1)
+            ctx.set_option("speculation_pct", 0)
+            ctx.set_option("side_samples", 1)
     if check_host_flow:
         # (2) the reference's call shape with the fixture's sample draws: the whole vector and every trace
         dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
@@ -245,13 +254,13 @@ def test_d512_against_oracle_fixture(ctx, method):
     res2 = ctx.wgcl(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, None, None, None, False, auc_samples=10000,
                     samples=smp, use_resident_original=True)
     _check_sweep(res2, ctx.last_trace, fx, same_samples=True)
-    for opt, val in (("diameter_f32", 0), ("diameter", 1), ("early_diameter", 0)):  # fp64 bound pass / brute force / in line
+    for opt, val, back in (("diameter_f32", 0, 1), ("diameter", 1, 0), ("early_diameter", 1, 0)):  # fp64 bound pass / brute force / side context
         try:
             ctx.set_option(opt, val)
             assert np.array_equal(res, ctx.score(g["clusters"], 300, 4, method, seed=42, auc_samples=10000))
             assert ctx.last_diameter()[0] == hi
         finally:
-            ctx.set_option(opt, 1 if opt != "diameter" else 0)
+            ctx.set_option(opt, back)
 
 
 def test_config5_full_size_ten_million_vertices():
@@ -303,6 +312,7 @@ def test_config5_full_size_ten_million_vertices():
         finally:
             c.close()
 
+    _GRAPHS.clear()
     r1 = run(1)
     res, tr = r1["res"], r1["tr"]
     hi, path, pairs, tiles = r1["hi"]
