@@ -138,7 +138,7 @@ def main():
                          "of the timed step (an undirected score does not read it); default: the step builds it")
     ap.add_argument("--side-diameter", action="store_true",
                     help="A/B: the diameter on the side context beside runsplit (default: in line, after landmarks())")
-    ap.add_argument("--no-side", action="store_true", help="A/B: clamp and sample draws in line too (no side thread)")
+    ap.add_argument("--side-samples", action="store_true", help="A/B: clamp and sample draws on the side thread (default: in line)")
     args = ap.parse_args()
 
     import torch
@@ -211,7 +211,7 @@ def main():
     ctx.set_option("diameter", args.diameter)
     ctx.set_option("landmark_edges", 0 if args.lazy_landmark_edges else 1)
     ctx.set_option("early_diameter", 1 if args.side_diameter else 0)
-    ctx.set_option("side_samples", 0 if args.no_side else 1)
+    ctx.set_option("side_samples", 1 if args.side_samples else 0)
     if os.environ.get("CGE_SPEC_PCT"):  # tuning probe: share of the missing pops one round of runsplit may split ahead
         ctx.set_option("speculation_pct", int(os.environ["CGE_SPEC_PCT"]))
     coll, coll_backend = None, None

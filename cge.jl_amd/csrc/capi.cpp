@@ -1198,8 +1198,9 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_diameter = (int)value;
         return CGE_OK;
     }
-    if (!strcmp(key, "diameter_f32")) { // 1 (default): point-to-reference maxima of the pruned diameter by fp32 MFMA (upper bounds); 0: fp64 MFMA
-        c->opt_diameter_f32 = value != 0;
+    if (!strcmp(key, "diameter_f32")) { // point-to-reference maxima of the pruned diameter: 2 (default) bf16 matrix pipe on two-term operands
+        if (value < 0 || value > 2) return CGE_E_ARG; // (K <= 128, else as 1), 1 fp32-input MFMA (both: rigorous upper bounds); 0: fp64 MFMA
+        c->opt_diameter_f32 = (int)value;
         return CGE_OK;
     }
     if (!strcmp(key, "fit_persistent")) { // 0 auto, 1 never, 2 whenever the score graph fits the register file, 3 / 4 = 2 with grid barriers / counters
@@ -1207,8 +1208,8 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_fit_persistent = (int)value;
         return CGE_OK;
     }
-    if (!strcmp(key, "speculation_pct")) { // tuning: 1..100, 0 = by split rule (results do not depend on it)
-        if (value < 0 || value > 100) return CGE_E_ARG;
+    if (!strcmp(key, "speculation_pct")) { // tuning: 1..100, 0 = by split rule, -1 = by rehearsing the pop sequence (results do not depend on it)
+        if (value < -1 || value > 100) return CGE_E_ARG;
         c->opt_speculation_pct = (int)value;
         return CGE_OK;
     }
@@ -1243,7 +1244,7 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_early_diameter = value != 0; // 0 (default): in line after landmarks(), from the landmark partition
         return CGE_OK;
     }
-    if (!strcmp(key, "side_samples")) { // 1 (default): the `land` clamp and the sample draws on the side context beside runsplit (single rank); 0: in line
+    if (!strcmp(key, "side_samples")) { // 1: the `land` clamp and the sample draws on the side context beside runsplit (single rank); 0 (default): in line
         c->opt_side_samples = value != 0;
         return CGE_OK;
     }

@@ -333,7 +333,10 @@ struct cge_ctx {
     DevBuf<double> Xs, rns, Ms, mnorm, Pm; // landmark-sorted centred copy, centroids, P matrix
     DevBuf<double> pc_groups;              // per (16-row group, reference point) maxima of the bound pass
     DevBuf<float> Xs32, Ms32;              // fp32 copies: operands of the fp32-MFMA bound pass (upper bounds only)
-    int opt_diameter_f32 = 1;              // 1: the point-to-reference maxima by fp32 MFMA with a rigorous error margin
+    DevBuf<unsigned short> Xb16, Mb16;     // two-plane bf16 operands of the bf16-split bound pass
+    DevBuf<int> dm_flag;                   // raised by the bf16 gather when a value is unfit for the split
+    int opt_diameter_f32 = 2;              // the point-to-reference maxima: 2 = bf16 matrix pipe, operands split in two terms (K <= 128; else 1),
+                                           // 1 = fp32-input MFMA, 0 = fp64 MFMA; 1 and 2 are upper bounds with a rigorous error margin
     DevBuf<i32> pos2node, sub_land, dm_soff, dm_memoff, dm_mem;
     DevBuf<double> bound_list;             // BoundRec records (2 doubles each)
     DevBuf<i32> tile_list;
@@ -397,7 +400,8 @@ struct cge_ctx {
                                 // landmark partition, on the main stream.  Measured (profiles/r03_side_context_ab.txt): the search is
                                 // HBM- and MFMA-heavy and runsplit's big first batches are too -- run side by side they slow each
                                 // other by as much as the overlap saves, so the default keeps it in line.
-    int opt_side_samples = 1;   // the `land` clamp and the sample draws (little device work, several host round trips) on the side context
+    int opt_side_samples = 0;   // 1: the `land` clamp and the sample draws on the side context too (measured: the second host thread costs
+                                // the first more than the 0.5 ms it takes over: headline 32.6 vs 31.7 ms per step)
     // grow-only scratch of per-score helpers (no hipMalloc / hipFree inside a scoring call after the first: a hipFree waits
     // for every stream of the device, the side context's included)
     DevBuf<i32> epd_i, s_star;
@@ -574,9 +578,14 @@ void k_ref_centroids(cge_ctx *c, const double *mu, const double *lw, const i32 *
 void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i);
 void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean);
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
-                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32 = nullptr);
+                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32 = nullptr,
+                        unsigned short *planes = nullptr, i64 KP = 0, int *flag = nullptr); // planes: two bf16 terms, row-major [2][ld][KP]
 void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows, const float *Ms32, const double *mnorm,
                  i64 ldm, i64 n_land, i64 N, i64 dpad, const i32 *sub_land, double *P, int part = 0, int nparts = 1);
+// the bound pass on the bf16 matrix pipe with two-term operands (kernels_dist.hip (2c))
+bool k_pcent_bf16_applies(i64 dpad);
+void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 lds_rows, const unsigned short *Mb,
+                  const double *mnorm, i64 ldm, i64 n_land, i64 N, i64 KP, const i32 *soff, double *P, int part = 0, int nparts = 1);
 // alpha sweep
 void k_copy_segments(cge_ctx *c, const i32 *src, const i64 *seg, i64 nseg, i32 *dst);
 void k_permute_rows(cge_ctx *c, const double *src, const i32 *order, i64 n, i64 width, double *dst); // dst[q] = src[order[q]]

@@ -99,17 +99,37 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     c->Ms.ensure((size_t)ldm * dpad);
     c->mnorm.ensure(ldm);
     c->Pm.ensure((size_t)N * nref);
-    const bool f32 = c->opt_diameter_f32 != 0; // the maxima as fp32-MFMA upper bounds (kernels_dist.hip, (2b))
+    // the maxima as upper bounds from a low-precision matrix pass (kernels_dist.hip (2b), (2c)) or exactly in fp64
+    bool b16 = c->opt_diameter_f32 >= 2 && k_pcent_bf16_applies(dpad);
+    const bool f32 = c->opt_diameter_f32 != 0 && !b16;
+    const i64 KP = (dpad + 31) / 32 * 32;
     if (f32) {
         c->Xs32.ensure((size_t)lds_rows * dpad);
         c->Ms32.ensure((size_t)ldm * dpad);
     }
-    k_gather_centre_fm(c, c->Xr.p, c->pos2node.p, c->gmean.p, c->Xs.p, c->rns.p, npos, d, lds_rows, dpad, f32 ? c->Xs32.p : nullptr);
-    k_gather_centre_fm(c, mu_ref, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, nref, d, ldm, dpad, f32 ? c->Ms32.p : nullptr);
+    if (b16) {
+        c->Xb16.ensure((size_t)2 * lds_rows * KP);
+        c->Mb16.ensure((size_t)2 * ldm * KP);
+        c->dm_flag.ensure(1);
+        HIP_CHECK(hipMemsetAsync(c->dm_flag.p, 0, sizeof(int), st));
+    }
+    k_gather_centre_fm(c, c->Xr.p, c->pos2node.p, c->gmean.p, c->Xs.p, c->rns.p, npos, d, lds_rows, dpad, f32 ? c->Xs32.p : nullptr,
+                       b16 ? c->Xb16.p : nullptr, KP, c->dm_flag.p);
+    k_gather_centre_fm(c, mu_ref, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, nref, d, ldm, dpad, f32 ? c->Ms32.p : nullptr,
+                       b16 ? c->Mb16.p : nullptr, KP, c->dm_flag.p);
+    if (b16) {
+        int unfit = 0;
+        HIP_CHECK(hipMemcpyAsync(&unfit, c->dm_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (unfit) b16 = false; // values beyond 2^+-100 or not finite: the exact fp64 pass (below) instead
+    }
     // Q is a maximum over vertices: with several ranks each takes its share of the vertex tiles and the maxima are
     // combined by one all-reduce(max) (only when the exchange buffer can hold N x nref doubles)
     const bool shard_q = nparts > 1 && c->has_coll && (c->rccl_comm || (c->xptr && (size_t)(N * nref) <= c->xcap));
-    if (f32)
+    if (b16)
+        k_pcent_bf16(c, c->Xb16.p, c->rns.p, lds_rows, c->Mb16.p, c->mnorm.p, ldm, N, nref, KP, c->dm_soff.p, c->Pm.p,
+                     shard_q ? part : 0, shard_q ? nparts : 1);
+    else if (f32)
         k_pcent_f32(c, c->Xs32.p, c->rns.p, lds_rows, c->Ms32.p, c->mnorm.p, ldm, N, nref, dpad, c->dm_soff.p, c->Pm.p,
                     shard_q ? part : 0, shard_q ? nparts : 1);
     else

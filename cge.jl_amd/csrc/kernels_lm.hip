@@ -74,16 +74,35 @@ __global__ void colsum_final_kernel(const double *__restrict__ part, i64 nb, i64
     mean[k] = s / (double)n;
 }
 // dst[k*ld + p] = src[idx ? idx[p] : p][k] - mean[k]  (row-major rows -> centred feature-major, 32x32 LDS tiles)
+// `planes` (optional): the same values as two row-major bf16 planes [2][ld][KP] (v = h + l + O(2^-16 v)), the operands of
+// the bf16-split bound pass (kernels_dist.hip (2c)); *flag |= 1 when a value is unfit for that split
 __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i32 *__restrict__ idx,
                                         const double *__restrict__ mean, double *__restrict__ dst, i64 npos, i64 d,
-                                        i64 ld, float *__restrict__ dst32) {
+                                        i64 ld, float *__restrict__ dst32, unsigned short *__restrict__ planes, i64 KP,
+                                        int *__restrict__ flag) {
     __shared__ double tile[32][33];
     i64 p0 = (i64)blockIdx.x * 32, k0 = (i64)blockIdx.y * 32;
     int tx = threadIdx.x, ty = threadIdx.y;
+    bool bad = false;
     for (int r = ty; r < 32; r += 8) {
         i64 p = p0 + r, k = k0 + tx;
-        if (p < npos && k < d) tile[r][tx] = src[(idx ? (i64)idx[p] : p) * d + k] - mean[k];
+        if (p < npos && k < d) {
+            const double v = src[(idx ? (i64)idx[p] : p) * d + k] - mean[k];
+            tile[r][tx] = v;
+            if (planes) {
+                const double av = fabs(v);
+                if (!(av < 1.2676506002282294e30) || (av != 0.0 && av < 7.888609052210118e-31)) bad = true; // 2^100, 2^-100
+                unsigned u = __float_as_uint((float)v);
+                u += 0x7FFFu + ((u >> 16) & 1u); // bf16, round to nearest even
+                const unsigned short h = (unsigned short)(u >> 16);
+                unsigned w = __float_as_uint((float)(v - (double)__uint_as_float((unsigned)h << 16)));
+                w += 0x7FFFu + ((w >> 16) & 1u);
+                planes[p * KP + k] = h;
+                planes[ld * KP + p * KP + k] = (unsigned short)(w >> 16);
+            }
+        }
     }
+    if (bad) atomicOr(flag, 1);
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         i64 p = p0 + tx, k = k0 + r;
@@ -114,13 +133,15 @@ void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean) {
 }
 // Centred, zero-padded feature-major copy (dpad x ld) of npos gathered rows + squared row norms (ld entries).
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
-                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32) {
+                        double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32, unsigned short *planes, i64 KP,
+                        int *flag) {
     HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(ld * dpad), c->stream));
+    if (planes) HIP_CHECK(hipMemsetAsync(planes, 0, sizeof(unsigned short) * (size_t)(2 * ld * KP), c->stream));
     if (dst32) HIP_CHECK(hipMemsetAsync(dst32, 0, sizeof(float) * (size_t)(ld * dpad), c->stream));
     HIP_CHECK(hipMemsetAsync(rnorm, 0, sizeof(double) * (size_t)ld, c->stream));
     dim3 grid((unsigned)((npos + 31) / 32), (unsigned)((d + 31) / 32));
     hipLaunchKernelGGL(gather_centre_fm_kernel, grid, dim3(32, 8), 0, c->stream, src_rowmajor, idx, mean, dst, npos, d,
-                       ld, dst32);
+                       ld, dst32, planes, KP, flag);
     hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, c->stream, dst, npos, d, ld,
                        rnorm);
 }

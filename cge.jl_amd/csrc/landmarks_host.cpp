@@ -1240,7 +1240,8 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
             }
             const i64 remaining = targets[q] - (i64)h.len();
             std::vector<Group *> frontier;
-            if (c->opt_speculation_pct == 0) {
+            if (c->opt_speculation_pct < 0) {
+                // (option speculation_pct = -1; measured equal to the rank rule below, profiles/r03_speculation_ab.txt)
                 // PLAY THE REST OF THE POP SEQUENCE FORWARD on what is known: cached splits contribute their real children, an
                 // unsplit group two GUESSED children (value and size scaled by the mean ratios of the splits seen so far).  The
                 // known unsplit groups this rehearsal pops are the ones to split now -- all of them at once, so a round of
@@ -1283,7 +1284,7 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
                 batch.insert(batch.end(), frontier.begin(), frontier.end());
                 continue;
             }
-            // (explicit speculation_pct: the rank rule of rounds 1-2, kept for A/B)
+            // (default, speculation_pct >= 0: the rank rule)
             // Exactly `remaining` more pops will happen.  A node can only be among them if its value ranks within
             // `remaining` among ALL known unpopped nodes (cached splits and unsplit ones alike): nodes still to be
             // discovered only add competitors.  So every unsplit node above that threshold is a candidate and
@@ -1318,7 +1319,9 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
             // outrank it).  Splitting only the most valuable part per round costs a round or two more and saves the
             // eigen-problems of the rest; what is left over is reconsidered, with more known, in the next round.
             // (never fewer than 256 at a time: the last pops would otherwise trickle through many tiny rounds)
-            const int spec_pct = c->opt_speculation_pct;
+            const int spec_pct = c->opt_speculation_pct > 0 ? c->opt_speculation_pct
+                                 : (method == CGE_METHOD_SIZE || method == CGE_METHOD_DIAMETER) ? 10
+                                 : (c->d > 128 ? 25 : 40); // wide embeddings: a wasted split costs a memory-resident eigen-problem
             const i64 take = std::max<i64>(std::min<i64>(remaining, 256), (i64)((double)remaining * spec_pct / 100.0));
             if ((i64)frontier.size() > take) {
                 std::nth_element(frontier.begin(), frontier.begin() + (take - 1), frontier.end(),

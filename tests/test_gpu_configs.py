@@ -132,8 +132,8 @@ def _run_config(ctx, name, check_host_flow=True):
     assert ctx.get_stat("diameter_on_side_context") == 0
     # The diameter's branch and bound is exact for any partition: on the side context (beside runsplit) it runs from the
     # clusters cut into chunks instead of the landmarks -- the same bits; so do two half-batches per round on two streams,
-    # the rank rule of rounds 1-2 for the speculative splits, and everything in line on one thread.
-    for opts in ({"early_diameter": 1}, {"runsplit_lanes": 2}, {"speculation_pct": 40}, {"side_samples": 0}):
+    # the rehearsal rule for the speculative splits, and clamp + sample draws on the side thread.
+    for opts in ({"early_diameter": 1}, {"runsplit_lanes": 2}, {"speculation_pct": -1}, {"side_samples": 1}):
         try:
             for k, v in opts.items():
                 ctx.set_option(k, v)
@@ -146,7 +146,7 @@ def _run_config(ctx, name, check_host_flow=True):
             ctx.set_option("early_diameter", 0)
             ctx.set_option("runsplit_lanes", 1)
             ctx.set_option("speculation_pct", 0)
-            ctx.set_option("side_samples", 1)
+            ctx.set_option("side_samples", 0)
     if check_host_flow:
         # (2) the reference's call shape with the fixture's sample draws: the whole vector and every trace
         dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
@@ -254,7 +254,7 @@ def test_d512_against_oracle_fixture(ctx, method):
     res2 = ctx.wgcl(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, None, None, None, False, auc_samples=10000,
                     samples=smp, use_resident_original=True)
     _check_sweep(res2, ctx.last_trace, fx, same_samples=True)
-    for opt, val, back in (("diameter_f32", 0, 1), ("diameter", 1, 0), ("early_diameter", 1, 0)):  # fp64 bound pass / brute force / side context
+    for opt, val, back in (("diameter_f32", 0, 2), ("diameter_f32", 1, 2), ("diameter", 1, 0), ("early_diameter", 1, 0)):  # fp64 / fp32 bound pass, brute force, side context
         try:
             ctx.set_option(opt, val)
             assert np.array_equal(res, ctx.score(g["clusters"], 300, 4, method, seed=42, auc_samples=10000))
@@ -398,7 +398,7 @@ def test_config5_d512_twelve_thousand_landmarks(ctx):
         assert ctx.last_diameter()[:2] == (hi, "brute")
     finally:
         ctx.set_option("diameter", 0)
-        ctx.set_option("diameter_f32", 1)
+        ctx.set_option("diameter_f32", 2)
     # the embedding handed over as a device pointer (row-major torch tensor), as bench.py --workload cfg5 does
     X = torch.from_numpy(np.ascontiguousarray(g["embedding"])).to("cuda:0")
     torch.cuda.synchronize()

@@ -824,11 +824,11 @@ def test_diameter_pruned_equals_brute(ctx, orc, example10k, synth20k, which):
     ctx.set_option("diameter", 0)
     assert got[1][1] == "brute" and got[2][1] == "pruned"
     assert got[1][2] == got[2][2] == got[0][2]  # identical score vectors
-    # the bound pass of the pruned path: fp32 MFMA upper bounds (default) vs fp64 MFMA -- the same diameter bits and score,
-    # and never fewer candidate pairs (an upper bound of an upper bound)
+    # the bound pass of the pruned path: bf16-split (default) / fp32 MFMA upper bounds vs fp64 MFMA -- the same diameter bits
+    # and score, and never fewer candidate pairs (an upper bound of an upper bound)
     pairs = {}
     try:
-        for f32 in (0, 1):
+        for f32 in (0, 1, 2):
             ctx.set_option("diameter", 2)
             ctx.set_option("diameter_f32", f32)
             res = ctx.score(g["clusters"], land, 4, method, seed=3, auc_samples=2000)
@@ -836,8 +836,8 @@ def test_diameter_pruned_equals_brute(ctx, orc, example10k, synth20k, which):
             assert hi == exp and path == "pruned" and res.tolist() == got[2][2]
     finally:
         ctx.set_option("diameter", 0)
-        ctx.set_option("diameter_f32", 1)
-    assert pairs[0] <= pairs[1] <= 1.2 * pairs[0] + 16
+        ctx.set_option("diameter_f32", 2)
+    assert pairs[0] <= pairs[1] <= 1.2 * pairs[0] + 16 and pairs[0] <= pairs[2] <= 1.2 * pairs[0] + 16
 
 
 def test_library_drawn_samples_equal_fetched_draws(ctx, synth20k):
