@@ -509,124 +509,117 @@ __global__ __launch_bounds__(256, 2) void pcent_f32_rowres_kernel(const float *_
 // [2^-100, 2^100] or not finite (the split would over- / underflow): the caller then takes the fp64 pass.
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef short s8v __attribute__((ext_vector_type(8)));
-#define PB_KC 32          // k per staged chunk of the reference operand (two MFMA k-steps)
 #define PB_APAD 8         // bf16 elements of padding per LDS row (16 bytes: the 16-byte fragment reads of 32 rows spread over the banks)
-__global__ __launch_bounds__(256) void pcent_bf16_kernel(const unsigned short *__restrict__ Xb, const double *__restrict__ rns,
-                                                         i64 lds_rows, const unsigned short *__restrict__ Mb,
-                                                         const double *__restrict__ mnorm, i64 ldm, i64 KP,
-                                                         double *__restrict__ G, i64 I0, i64 I1, double e1) {
+#define PB_T 512 // 8 waves: 4 (row blocks of 32) x 2 (column blocks of 64); two waves per SIMD cover each other's LDS / epilogue latencies
+// Both operands of a (row tile, column tile) pair are RESIDENT in LDS with their whole K (2 planes x 128 x K bf16 each:
+// 139 KB at K = 128).  The next column tile of the reference points (or the next row tile of X and its first column tile)
+// is requested into registers before the MFMA phase of the current pair and stored behind it: one pair is ~100 MFMAs per
+// wave (1.3 us), about the latency of the loads it hides.
+template <int NKS> // k-steps of 16: KP = 16 NKS
+__global__ __launch_bounds__(PB_T) void pcent_bf16_kernel(const unsigned short *__restrict__ Xb, const double *__restrict__ rns,
+                                                          i64 lds_rows, const unsigned short *__restrict__ Mb,
+                                                          const double *__restrict__ mnorm, i64 ldm,
+                                                          double *__restrict__ G, i64 I0, i64 I1, double e1,
+                                                          int diag /* timing diagnostics only: 1 no epilogue, 2 no MFMA loop, 3 neither */) {
     extern __shared__ __attribute__((aligned(16))) unsigned short ldsb[];
-    const int LDA = (int)KP + PB_APAD, LDB = PB_KC + PB_APAD;
-    unsigned short *Ah = ldsb, *Al = Ah + (size_t)128 * LDA;   // [128][LDA] each
-    unsigned short *Bst = Al + (size_t)128 * LDA;               // [2 stages][2 planes][128][LDB]
+    constexpr i64 KP = 16 * NKS;
+    constexpr int LDA = (int)KP + PB_APAD;
+    unsigned short *Ah = ldsb, *Al = Ah + (size_t)128 * LDA, *Bh = Al + (size_t)128 * LDA, *Bl = Bh + (size_t)128 * LDA;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, l32 = lane & 31, lh = lane >> 5;
-    const i64 nTJ = ldm / 128, nchunk = KP / PB_KC, nstep = nTJ * nchunk;
-    const int apieces = (int)(KP / 8); // 16-byte pieces per row and plane
-    // staging of one chunk of the reference operand: 2 planes x 128 columns x 4 pieces of 16 bytes = 1024 pieces, 4 per thread
-    const int bpl = tid >> 7, bcol = tid & 127;
+    const i64 nTJ = ldm / 128;
+    // a 128-row tile of either operand: half a wave per row, lane = 16-byte piece of the row's two planes (2 KP / 8 <= 32
+    // pieces), 16 rows per sweep of the 512 threads, 8 sweeps; all loads of a thread are issued before the first LDS store
+    constexpr int apieces = (int)(KP / 8);
+    const int arow = tid >> 5, apc = tid & 31;
+    const bool aact = apc < 2 * apieces;
+    const int apl = aact && apc >= apieces ? 1 : 0, akk = 8 * (apc - apl * apieces);
+    auto fetch = [&](const unsigned short *base, i64 rows_ld, i64 r0, uint4 (&v)[8]) {
+#pragma unroll
+        for (int it = 0; it < 8; it++)
+            v[it] = aact ? *reinterpret_cast<const uint4 *>(base + ((size_t)apl * rows_ld + r0 + 16 * it + arow) * KP + akk)
+                         : make_uint4(0, 0, 0, 0);
+    };
+    auto stash = [&](unsigned short *hi, unsigned short *lo, const uint4 (&v)[8]) {
+        if (aact) {
+#pragma unroll
+            for (int it = 0; it < 8; it++) *reinterpret_cast<uint4 *>((apl ? lo : hi) + (size_t)(16 * it + arow) * LDA + akk) = v[it];
+        }
+    };
+    uint4 av[8], bv[8];
+    if (I0 + blockIdx.x < I1) {
+        fetch(Xb, lds_rows, (I0 + blockIdx.x) * 128, av);
+        fetch(Mb, ldm, 0, bv);
+    }
     for (i64 I = I0 + blockIdx.x; I < I1; I += gridDim.x) {
         const i64 i0 = I * 128;
         __syncthreads(); // the previous row tile's readers are done
-        for (int q = tid; q < 2 * 128 * apieces; q += 256) { // the whole row tile, both planes, all k
-            const int pl = q / (128 * apieces), rem = q - pl * 128 * apieces, r = rem / apieces, pc = rem - r * apieces;
-            const uint4 v = *reinterpret_cast<const uint4 *>(Xb + ((size_t)pl * lds_rows + i0 + r) * KP + 8 * pc);
-            *reinterpret_cast<uint4 *>((pl ? Al : Ah) + (size_t)r * LDA + 8 * pc) = v;
-        }
-        uint4 rb[4];
-        {
-            const unsigned short *pb = Mb + ((size_t)bpl * ldm + bcol) * KP; // step 0: column tile 0, chunk 0
+        stash(Ah, Al, av);
+        stash(Bh, Bl, bv);
+        double rn[2][8]; // the squared norms of this lane's 16 rows of the tile, inflated (all column tiles use them)
 #pragma unroll
-            for (int u = 0; u < 4; u++) rb[u] = *reinterpret_cast<const uint4 *>(pb + 8 * u);
-            unsigned short *bd = Bst + ((size_t)bpl * 128 + bcol) * LDB;
+        for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) *reinterpret_cast<uint4 *>(bd + 8 * u) = rb[u];
-        }
+            for (int q = 0; q < 8; q++) rn[h][q] = rns[i0 + wr * 32 + 16 * h + 8 * (q >> 2) + 4 * lh + (q & 3)] * e1;
         __syncthreads();
-        f16v acc[2][2];
-        for (i64 stp = 0; stp < nstep; stp++) {
-            const i64 J = stp / nchunk, kc = stp - J * nchunk;
-            const int sg = (int)(stp & 1);
-            if (kc == 0) {
+        for (i64 J = 0; J < nTJ; J++) {
+            const bool more_cols = J + 1 < nTJ, more_rows = I + gridDim.x < I1;
+            double mn[2];
 #pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+            for (int b = 0; b < 2; b++) mn[b] = mnorm[J * 128 + wc * 64 + b * 32 + l32];
+            if (more_cols) fetch(Mb, ldm, (J + 1) * 128, bv);
+            else if (more_rows) {
+                fetch(Xb, lds_rows, (I + gridDim.x) * 128, av);
+                fetch(Mb, ldm, 0, bv);
             }
-            const bool more = stp + 1 < nstep;
-            if (more) { // the next (column tile, chunk) of the reference operand lands while the MFMAs run
-                const i64 Jn = (stp + 1) / nchunk, kn = (stp + 1) - Jn * nchunk;
-                const unsigned short *qb = Mb + ((size_t)bpl * ldm + Jn * 128 + bcol) * KP + kn * PB_KC;
+            f16v acc[2];
 #pragma unroll
-                for (int u = 0; u < 4; u++) rb[u] = *reinterpret_cast<const uint4 *>(qb + 8 * u);
-            }
-            const unsigned short *Bh = Bst + (size_t)sg * 2 * 128 * LDB, *Bl = Bh + (size_t)128 * LDB;
-            s8v ah[2][2], al[2][2], bh[2][2], bl[2][2]; // [k-step][sub-tile]
+            for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
+                for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+            if (!(diag & 2))
 #pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const size_t o = (size_t)(wr * 64 + a * 32 + l32) * LDA + kc * PB_KC + 16 * ks + 8 * lh;
-                    ah[ks][a] = *reinterpret_cast<const s8v *>(Ah + o);
-                    al[ks][a] = *reinterpret_cast<const s8v *>(Al + o);
-                }
+            for (int ks = 0; ks < NKS; ks++) {
+                const size_t oa = (size_t)(wr * 32 + l32) * LDA + 16 * ks + 8 * lh;
+                const s8v ah = *reinterpret_cast<const s8v *>(Ah + oa), al = *reinterpret_cast<const s8v *>(Al + oa);
 #pragma unroll
                 for (int b = 0; b < 2; b++) {
-                    const size_t o = (size_t)(wc * 64 + b * 32 + l32) * LDB + 16 * ks + 8 * lh;
-                    bh[ks][b] = *reinterpret_cast<const s8v *>(Bh + o);
-                    bl[ks][b] = *reinterpret_cast<const s8v *>(Bl + o);
+                    const size_t ob = (size_t)(wc * 64 + b * 32 + l32) * LDA + 16 * ks + 8 * lh;
+                    const s8v bh = *reinterpret_cast<const s8v *>(Bh + ob), bl = *reinterpret_cast<const s8v *>(Bl + ob);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bh), acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, ah), __builtin_bit_cast(bf8v, bl), acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, al), __builtin_bit_cast(bf8v, bh), acc[b], 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, ah[ks][a]),
-                                                                            __builtin_bit_cast(bf8v, bh[ks][b]), acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, ah[ks][a]),
-                                                                            __builtin_bit_cast(bf8v, bl[ks][b]), acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, al[ks][a]),
-                                                                            __builtin_bit_cast(bf8v, bh[ks][b]), acc[a][b], 0, 0, 0);
-                    }
-            if (more) {
-                unsigned short *bd = Bst + ((size_t)(sg ^ 1) * 2 * 128 + (size_t)bpl * 128 + bcol) * LDB;
-#pragma unroll
-                for (int u = 0; u < 4; u++) *reinterpret_cast<uint4 *>(bd + 8 * u) = rb[u];
-            }
-            if (kc == nchunk - 1) { // epilogue of column tile J (see pcent_f32_kernel): a non-finite sum counts as +Inf
+            if (!(diag & 1)) { // epilogue of column tile J (see pcent_f32_kernel): a non-finite sum counts as +Inf
                 const i64 j0 = J * 128;
 #pragma unroll
                 for (int b = 0; b < 2; b++) {
                     const i64 col = j0 + wc * 64 + b * 32 + l32;
-                    const double mn = mnorm[col] * e1;
+                    const double mne = mn[b] * e1;
 #pragma unroll
-                    for (int a = 0; a < 2; a++)
+                    for (int h = 0; h < 2; h++) {
+                        const i64 r0 = i0 + wr * 32 + 16 * h;
+                        double v = -1e300;
 #pragma unroll
-                        for (int h = 0; h < 2; h++) {
-                            const i64 r0 = i0 + wr * 64 + a * 32 + 16 * h;
-                            double v = -1e300;
-#pragma unroll
-                            for (int gg = 0; gg < 2; gg++)
-#pragma unroll
-                                for (int j = 0; j < 4; j++) {
-                                    const float af = acc[a][b][4 * (2 * h + gg) + j];
-                                    const double t = rns[r0 + 8 * gg + 4 * lh + j] * e1 - 2.0 * (double)af;
-                                    v = fmax(v, (af - af == 0.f) ? t : 1e300); // NaN / Inf in the accumulator: no pruning on this entry
-                                }
-                            v = fmax(v, __shfl_xor(v, 32));
-                            if (lh == 0) G[(r0 >> 4) * ldm + col] = fmax(v + mn, 0.0);
+                        for (int q = 0; q < 8; q++) {
+                            const float af = acc[b][8 * h + q]; // row 16 h + 8 (q >> 2) + 4 lh + (q & 3)
+                            const double t = rn[h][q] - 2.0 * (double)af;
+                            v = fmax(v, (af - af == 0.f) ? t : 1e300); // NaN / Inf in the accumulator: no pruning on this entry
                         }
+                        v = fmax(v, __shfl_xor(v, 32));
+                        if (lh == 0) G[(r0 >> 4) * ldm + col] = fmax(v + mne, 0.0);
+                    }
                 }
             }
-            __syncthreads();
+            if (more_cols) {
+                __syncthreads(); // every wave is done with column tile J
+                stash(Bh, Bl, bv);
+                __syncthreads();
+            }
         }
     }
 }
-
 // P[a][r] = max over the 16-row groups of landmark a (groups goff[a] .. goff[a+1], from the landmark-sorted layout)
 __global__ void pcent_groups_kernel(const double *__restrict__ G, const i32 *__restrict__ soff, i64 ldm, i64 N,
                                     double *__restrict__ P) {
@@ -739,7 +732,7 @@ void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows,
 }
 
 // the bf16-split form (2c): Xb / Mb = the two-plane row-major operands written by k_gather_centre_fm (KP = dpad rounded up to 32)
-bool k_pcent_bf16_applies(i64 dpad) { return (dpad + 31) / 32 * 32 <= 128; } // the row tile of both planes fits LDS
+bool k_pcent_bf16_applies(i64 dpad) { return (dpad + 31) / 32 * 32 <= 128; } // a tile of either operand, both planes, whole K, fits LDS
 void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 lds_rows, const unsigned short *Mb,
                   const double *mnorm, i64 ldm, i64 n_land, i64 N, i64 KP, const i32 *soff, double *P, int part, int nparts) {
     const i64 ngroups = lds_rows / 16;
@@ -749,11 +742,21 @@ void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 l
     const i64 nTI = lds_rows / 128, I0 = nTI * part / nparts, I1 = nTI * (part + 1) / nparts;
     const double e1 = 1.0 + 1.05 * (3.0 * (double)(KP + 2) * 1.1920928955078125e-07 + 3.2 * 1.52587890625e-05); // 2^-23, 2^-16
     if (I1 > I0) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void *)pcent_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        const size_t lds = ((size_t)2 * 128 * (KP + PB_APAD) + (size_t)2 * 2 * 128 * (PB_KC + PB_APAD)) * sizeof(unsigned short);
-        hipLaunchKernelGGL(pcent_bf16_kernel, dim3((unsigned)std::min<i64>(I1 - I0, 256)), dim3(256), lds, c->stream, Xb, rns,
-                           lds_rows, Mb, mnorm, ldm, KP, c->pc_groups.p, I0, I1, e1);
+        const size_t lds = (size_t)4 * 128 * (KP + PB_APAD) * sizeof(unsigned short); // both operands, both planes, whole K
+        static const int pb_diag = getenv("CGE_PB_DIAG") ? atoi(getenv("CGE_PB_DIAG")) : 0; // timing diagnostics (wrong bounds)
+#define PB_GO(NKS)                                                                                                         \
+    do {                                                                                                                   \
+        auto kern = pcent_bf16_kernel<NKS>;                                                                                 \
+        static bool attr = false;                                                                                          \
+        if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL(kern, dim3((unsigned)std::min<i64>(I1 - I0, 256)), dim3(PB_T), lds, c->stream, Xb, rns, lds_rows, Mb, \
+                           mnorm, ldm, c->pc_groups.p, I0, I1, e1, pb_diag);                                                \
+    } while (0)
+        if (KP == 32) PB_GO(2);
+        else if (KP == 64) PB_GO(4);
+        else if (KP == 96) PB_GO(6);
+        else PB_GO(8);
+#undef PB_GO
     }
     hipLaunchKernelGGL(pcent_groups_kernel, dim3((unsigned)n_land), dim3(256), 0, c->stream, c->pc_groups.p, soff, ldm, N, P);
 }
