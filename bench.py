@@ -41,6 +41,7 @@ WORKLOADS = {
 }
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD datasheet; MI355X_MICROARCH.md lists no f64 row)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector peak (155 TF measured)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense MFMA ~2.5 PFLOP/s
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -95,7 +96,7 @@ def cpu_baseline(g, wl, budget_vertices=60000):
                       f"wGCL(v_to_l=Int[]) on the landmark graph, {A} alphas, {t:.1f} s"}
 
 
-ROOFLINE_KERNELS = ("fit_persistent", "fit_symv", "group_stats", "group_project", "sorted_prefix", "pcent", "pair_list",
+ROOFLINE_KERNELS = ("fit_persistent", "fit_symv", "group_stats", "group_project", "sorted_prefix", "pcent", "pair_list",  # (pcent: also the bf16 form)
                     "max_pair_dist", "edge_scatter", "edge_scatter_wedges", "rss2_walk", "group_eig")
 
 
@@ -136,6 +137,8 @@ def main():
     ap.add_argument("--lazy-landmark-edges", action="store_true",
                     help="leave the N x N landmark-pair matrix / landmark edge count of landmarks() (src/landmarks.jl:433-463) out "
                          "of the timed step (an undirected score does not read it); default: the step builds it")
+    ap.add_argument("--no-independent", action="store_true",
+                    help="N > 1: skip the second measurement (one embedding per GPU, no collective)")
     ap.add_argument("--side-diameter", action="store_true",
                     help="A/B: the diameter on the side context beside runsplit (default: in line, after landmarks())")
     ap.add_argument("--side-samples", action="store_true", help="A/B: clamp and sample draws on the side thread (default: in line)")
@@ -287,6 +290,38 @@ def main():
     prof = ctx.profile()
     phases = ctx.phase_ms()
     trace = ctx.last_trace
+    stats_strong = None
+    if world > 1:
+        stats_strong = (coll.n_calls if coll is not None else ctx.get_stat("collective_calls"),
+                        coll.bytes if coll is not None else ctx.get_stat("collective_bytes"))
+    # N > 1, second measurement: ONE EMBEDDING PER GPU.  The path's natural multi-GPU use (comparing the embeddings of one
+    # graph) has no exchange at all: every rank scores its own embedding of the resident graph, no collective, the job's
+    # rate is the sum.  Reported beside the strong-scaling value of the contract, never instead of it.
+    independent = None
+    if world > 1 and not dev_emb and not args.no_independent:
+        ctx.clear_collectives()
+        rng = np.random.default_rng(args.seed + 7919 * (rank + 1))
+        emb_r = np.asfortranarray(g["embedding"] + 0.05 * rng.standard_normal(g["embedding"].shape))
+        ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], emb_r)
+        del emb_r
+        ctx.profile_enable(False)
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            res_i = step()
+        fence()
+        el = torch.tensor([time.perf_counter() - t1, float(ctx.last_trace["n_alpha"])], dtype=torch.float64, device=dev)
+        tmax = el.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(el, op=dist.ReduceOp.SUM)
+        sec_i = float(tmax[0].item()) / max(1, args.steps)
+        independent = {"embeddings": world, "ms_per_step": sec_i * 1e3, "alphas_evaluated_sum": float(el[1].item()),
+                       "value": g["m"] * float(el[1].item()) / sec_i, "unit": "edge-alpha evals/s",
+                       "embeddings_per_s": world / sec_i, "scaling": "weak",
+                       "note": "every rank scores its own embedding (the bench embedding + N(0, 0.05^2) noise, seeded per rank) "
+                               "of the resident graph; no collective on the data path; value = m x (sum of the ranks' alphas) / "
+                               "max over ranks of the step time"}
     if rank != 0:
         ctx.close()
         if world > 1:
@@ -312,6 +347,13 @@ def main():
         "pcent": ("mfma", F32_MFMA_PEAK_TFLOPS, "TFLOP/s", 2.0 * d * n * max(1, ctx.get_stat("diameter_refs")),
                   "fp32 MFMA (v_mfma_f32_32x32x2_f32) upper bounds, 2d flop per (vertex, reference point) pair; reference "
                   "points = community centroids; priced against the f32-input MFMA peak"),
+        "pcent_bf16": ("mfma", BF16_MFMA_PEAK_TFLOPS, "TFLOP/s", 3 * 2.0 * ((d + 31) // 32 * 32) * n * max(1, ctx.get_stat("diameter_refs")),
+                       "upper bounds of the vertex-to-reference distances on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) with "
+                       "every operand split into two bf16 terms: three MFMAs per product (x.mu ~ xh.muh + xh.mul + xl.muh, rigorous "
+                       "margin), so the work priced here is 3 x 2 K flop per (vertex, reference point) pair against the dense bf16 "
+                       "peak; `algorithmic_f32_equivalent_tflops` = 2 d n C / t, what an f32-input pass of the same bounds would "
+                       "have to sustain (its peak: 157.3).  The kernel is bound by the latency of fetching the reference tiles from "
+                       "L2, not by the matrix pipe (profiles/r03_pcent_bf16_probe.txt)"),
         "pair_list": ("mfma", F64_MFMA_PEAK_TFLOPS, "TFLOP/s", None,
                       "fp64 MFMA, 2d flop per vertex pair of the candidate 128x128 tiles"),
         "fit_symv": ("hbm", HBM_PEAK_GBS, "GB/s", 8.0 * N * (N + 1) / 2,
@@ -347,6 +389,8 @@ def main():
                       "8 d^2 bytes per matrix; 126 dependent steps per matrix -- latency-bound, not HBM-bound"),
     }
     kernels = {}
+    if d <= 128 and "pcent" in prof and ctx.get_stat("diameter_bound_pass") == 2:  # the bf16-split bound pass ran under this timer
+        prof["pcent_bf16"] = prof.pop("pcent")
     for name in prof:
         l_, ms_ = kern(name)
         ent = {"avg_launch_ms": ms_, "launches": l_, "total_ms_per_step": prof[name]["total_ms"] / steps_prof}
@@ -378,6 +422,8 @@ def main():
                 w = 8.0 * N * (N + 1) / 2 + its * per_iter
                 ent["iterations_per_launch"] = its
                 ent["streaming_equivalent_gbs"] = 8.0 * N * (N + 1) / 2 * its / (ms_ * 1e-3) / 1e9
+            if name == "pcent_bf16":
+                ent["algorithmic_f32_equivalent_tflops"] = 2.0 * d * n * max(1, ctx.get_stat("diameter_refs")) / (ms_ * 1e-3) / 1e12
             ach = w / (ms_ * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
             ent.update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                         "algorithmic_work_per_launch": w, "work_unit": "flop" if unit == "TFLOP/s" else "B",
@@ -387,6 +433,7 @@ def main():
     pmc = {}
     pmc_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (3, 2, 1)) if os.path.exists(f)), "")
     kernel_of = {"fit_symv": ("fit_step_kernel",), "fit_persistent": ("fit_flow_kernel",), "pcent": ("pcent_f32_rowres_kernel", "pcent_f32_kernel", "pcent_groups_kernel"),
+                 "pcent_bf16": ("pcent_bf16_kernel", "pcent_groups_kernel"),
                  "pair_list": ("pair_list_kernel",), "edge_scatter": ("edge_pass_kernel", "edge_row_reduce_kernel"),
                  "edge_scatter_wedges": ("wedge_pass_kernel", "wedge_tile_kernel"),
                  "group_stats": ("group_cov_mfma_kernel", "group_cov_final_kernel", "gather_means_kernel"), "group_eig": ("group_eig_kernel",),
@@ -438,10 +485,11 @@ def main():
         "result": [float(x) for x in res],
     }
     if world > 1:
-        calls = coll.n_calls if coll is not None else ctx.get_stat("collective_calls")
-        nbytes = coll.bytes if coll is not None else ctx.get_stat("collective_bytes")
+        calls, nbytes = stats_strong
         out["collectives"] = {"backend": coll_backend, "allreduce_calls_per_step": calls / (args.steps + args.warmup),
                               "bytes_per_step": nbytes / (args.steps + args.warmup)}
+        if independent is not None:
+            out["independent_embeddings"] = independent
     if world == 1 and not args.no_cpu_baseline and not directed and not dev_emb:
         try:
             out["cpu_baseline"] = cpu_baseline(g, wl)

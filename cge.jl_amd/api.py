@@ -403,6 +403,12 @@ class Context:
         self._keep = [cb, coll]
         self._check(self.L.cge_set_collectives(self.h, C.byref(coll)))
 
+    def clear_collectives(self):
+        """Back to a single-rank context: the in-library communicator is released and the hook removed."""
+        self._check(self.L.cge_comm_finalize(self.h))
+        self._check(self.L.cge_set_collectives(self.h, None))
+        self._keep = []
+
     def init_rccl(self, unique_id: bytes, rank: int, world: int):
         """In-library collectives (include/cge_hip.h: cge_comm_init_rccl): every rank calls this with rank 0's id."""
         assert len(unique_id) == 128

@@ -1067,6 +1067,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
                 c->stat_cand_pairs = sd->stat_cand_pairs;
                 c->stat_cand_tiles = sd->stat_cand_tiles;
                 c->stat_nref = sd->stat_nref;
+                c->stat_bound_pass = sd->stat_bound_pass;
                 c->stat_hi_i = sd->stat_hi_i; c->stat_hi_j = sd->stat_hi_j;
                 c->stat_diameter_path = 2;
                 c->stat_diameter_side = 1;
@@ -1265,6 +1266,7 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "diameter_candidate_pairs")) *value = c->stat_cand_pairs;
     else if (!strcmp(key, "diameter_candidate_tiles")) *value = c->stat_cand_tiles;
     else if (!strcmp(key, "diameter_refs")) *value = c->stat_nref;
+    else if (!strcmp(key, "diameter_bound_pass")) *value = c->stat_bound_pass; // of the last pruned diameter: 2 bf16-split, 1 fp32 MFMA, 0 fp64 MFMA
     else if (!strcmp(key, "diameter_arg_i")) *value = c->stat_hi_i + 1; // the arg-max pair of the last diameter (1-based vertex ids)
     else if (!strcmp(key, "diameter_arg_j")) *value = c->stat_hi_j + 1;
     else if (!strcmp(key, "diameter_on_side_context")) *value = c->stat_diameter_side;

@@ -348,6 +348,7 @@ struct cge_ctx {
     double stat_last_hi = 0.0;
     i64 stat_hi_i = -1, stat_hi_j = -1; // its arg-max pair (0-based vertex ids)
     int stat_side_status = 0;
+    int stat_bound_pass = 0;            // bound pass of the last pruned diameter: 2 bf16-split, 1 fp32 MFMA, 0 fp64 MFMA
     int stat_diameter_side = 0;         // 1: the last score took `hi` from the side context's search
     i64 stat_nref = 0; // reference points of the last pruned diameter (communities or landmarks)
     // scratch of the batched split engine (landmarks_host.cpp)

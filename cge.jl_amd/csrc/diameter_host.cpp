@@ -126,6 +126,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     // Q is a maximum over vertices: with several ranks each takes its share of the vertex tiles and the maxima are
     // combined by one all-reduce(max) (only when the exchange buffer can hold N x nref doubles)
     const bool shard_q = nparts > 1 && c->has_coll && (c->rccl_comm || (c->xptr && (size_t)(N * nref) <= c->xcap));
+    c->stat_bound_pass = b16 ? 2 : (f32 ? 1 : 0);
     if (b16)
         k_pcent_bf16(c, c->Xb16.p, c->rns.p, lds_rows, c->Mb16.p, c->mnorm.p, ldm, N, nref, KP, c->dm_soff.p, c->Pm.p,
                      shard_q ? part : 0, shard_q ? nparts : 1);
