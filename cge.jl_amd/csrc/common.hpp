@@ -328,6 +328,8 @@ struct cge_ctx {
     DevBuf<double> mp_recs;  // MaxRec records (3 doubles each)
     DevBuf<i64> mp_count;
     DevBuf<double> mp_rd2, mp_refmu; // reference-point distances / centroids of the pruned diameter
+    DevBuf<double> mp_commax;        // per-community maxima of the bound matrix (two-level candidate selection)
+    DevBuf<i32> mp_plist;            // surviving community pairs (int2 each)
     DevBuf<i32> mp_lref, mp_refoff, mp_refmem;
     DevBuf<double> gmean;    // global feature mean (the centre used by Xc)
     DevBuf<double> Xs, rns, Ms, mnorm, Pm; // landmark-sorted centred copy, centroids, P matrix
@@ -573,7 +575,9 @@ void k_pcent(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, cons
 void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,
                  i64 ntiles, double *best_val, i64 *best_i, i64 *best_j);
 i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *mu_ref, i64 N, i64 nref, i64 d, double L,
-                   void *list, i64 cap);
+                   void *list, i64 cap, const i32 *ref_off = nullptr, const i32 *ref_mem = nullptr, const double *Ms_fm = nullptr,
+                   i64 dpad = 0, i64 ldm = 0);
+i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map); // map[argmax v] (synchronises the stream)
 void k_ref_centroids(cge_ctx *c, const double *mu, const double *lw, const i32 *ref_off, const i32 *ref_mem, i64 nref,
                      i64 d, double *out);
 void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i);
@@ -586,7 +590,7 @@ void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows,
 // the bound pass on the bf16 matrix pipe with two-term operands (kernels_dist.hip (2c))
 bool k_pcent_bf16_applies(i64 dpad);
 void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 lds_rows, const unsigned short *Mb,
-                  const double *mnorm, i64 ldm, i64 n_land, i64 N, i64 KP, const i32 *soff, double *P, int part = 0, int nparts = 1);
+                  const double *mnorm, i64 ldm, i64 n_land, i64 N, i64 KP, const i32 *sub_land, double *P, int part = 0, int nparts = 1);
 // alpha sweep
 void k_copy_segments(cge_ctx *c, const i32 *src, const i64 *seg, i64 nseg, i32 *dst);
 void k_permute_rows(cge_ctx *c, const double *src, const i32 *order, i64 n, i64 width, double *dst); // dst[q] = src[order[q]]

@@ -117,18 +117,18 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
                        b16 ? c->Xb16.p : nullptr, KP, c->dm_flag.p);
     k_gather_centre_fm(c, mu_ref, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, nref, d, ldm, dpad, f32 ? c->Ms32.p : nullptr,
                        b16 ? c->Mb16.p : nullptr, KP, c->dm_flag.p);
-    if (b16) {
-        int unfit = 0;
-        HIP_CHECK(hipMemcpyAsync(&unfit, c->dm_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (unfit) b16 = false; // values beyond 2^+-100 or not finite: the exact fp64 pass (below) instead
-    }
+    int unfit = 0;
+    if (b16) HIP_CHECK(hipMemcpyAsync(&unfit, c->dm_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    // the seed of the farthest-point sweep: the vertex farthest from the centre (largest squared norm of the centred rows, just
+    // computed by the gather); its read-back is the synchronisation the flag needs anyway
+    const i64 seed_vertex = k_argmax_mapped(c, c->rns.p, npos, c->pos2node.p);
+    if (unfit) b16 = false; // values beyond 2^+-100 or not finite: the exact fp64 pass (below) instead
     // Q is a maximum over vertices: with several ranks each takes its share of the vertex tiles and the maxima are
     // combined by one all-reduce(max) (only when the exchange buffer can hold N x nref doubles)
     const bool shard_q = nparts > 1 && c->has_coll && (c->rccl_comm || (c->xptr && (size_t)(N * nref) <= c->xcap));
     c->stat_bound_pass = b16 ? 2 : (f32 ? 1 : 0);
     if (b16)
-        k_pcent_bf16(c, c->Xb16.p, c->rns.p, lds_rows, c->Mb16.p, c->mnorm.p, ldm, N, nref, KP, c->dm_soff.p, c->Pm.p,
+        k_pcent_bf16(c, c->Xb16.p, c->rns.p, lds_rows, c->Mb16.p, c->mnorm.p, ldm, N, nref, KP, c->sub_land.p, c->Pm.p,
                      shard_q ? part : 0, shard_q ? nparts : 1);
     else if (f32)
         k_pcent_f32(c, c->Xs32.p, c->rns.p, lds_rows, c->Ms32.p, c->mnorm.p, ldm, N, nref, dpad, c->dm_soff.p, c->Pm.p,
@@ -140,12 +140,13 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     lap("dm_refs_pcent");
     // ---- lower bound from farthest-point sweeps ----------------------------------------------------------
     double L = 0.0;
-    i64 p0 = 0, far_i = 0, far_j = 0;
-    // The two sweeps (memory-bound reads of Xr, each with a host round trip) run on the side stream while the MFMA pass
-    // above occupies the main one.
+    i64 p0 = seed_vertex, far_i = 0, far_j = 0;
+    // One sweep from the vertex farthest from the centre (a memory-bound read of Xr with a host round trip) on the side
+    // stream while the MFMA pass above occupies the main one.  (Rounds 1-2 made two sweeps from vertex 0: with the bound pass
+    // on the bf16 pipe they had become the longer of the two concurrent branches.)
     std::swap(c->stream, c->copy_stream);
     try {
-        for (int it = 0; it < 2; it++) { // two sweeps seed the bound; the exact search below does the rest
+        for (int it = 0; it < 1; it++) { // the exact search below does the rest
             double v;
             i64 q;
             k_farthest(c, c->Xr.p, n, d, p0, &v, &q);
@@ -161,7 +162,8 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     // ---- candidate landmark pairs ---------------------------------------------------------------------------
     const i64 cap = std::min<i64>(N * (N + 1) / 2, (i64)4 << 20);
     c->bound_list.ensure((size_t)2 * cap);
-    const i64 cnt = k_bound_select(c, c->Pm.p, c->mp_lref.p, mu_ref, N, nref, d, L * (1.0 - 1e-9), c->bound_list.p, cap);
+    const i64 cnt = k_bound_select(c, c->Pm.p, c->mp_lref.p, mu_ref, N, nref, d, L * (1.0 - 1e-9), c->bound_list.p, cap,
+                                   by_comm ? c->mp_refoff.p : nullptr, by_comm ? c->mp_refmem.p : nullptr, c->Ms.p, dpad, ldm);
     c->stat_cand_pairs = cnt;
     if (cnt > cap) return false;
     std::vector<BoundRec> cand(cnt);

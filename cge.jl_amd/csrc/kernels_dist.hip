@@ -519,12 +519,14 @@ template <int NKS> // k-steps of 16: KP = 16 NKS
 __global__ __launch_bounds__(PB_T) void pcent_bf16_kernel(const unsigned short *__restrict__ Xb, const double *__restrict__ rns,
                                                           i64 lds_rows, const unsigned short *__restrict__ Mb,
                                                           const double *__restrict__ mnorm, i64 ldm,
-                                                          double *__restrict__ G, i64 I0, i64 I1, double e1,
+                                                          const i32 *__restrict__ sub_land, i64 nref,
+                                                          unsigned long long *__restrict__ P, i64 I0, i64 I1, double e1,
                                                           int diag /* timing diagnostics only: 1 no epilogue, 2 no MFMA loop, 3 neither */) {
     extern __shared__ __attribute__((aligned(16))) unsigned short ldsb[];
     constexpr i64 KP = 16 * NKS;
     constexpr int LDA = (int)KP + PB_APAD;
     unsigned short *Ah = ldsb, *Al = Ah + (size_t)128 * LDA, *Bh = Al + (size_t)128 * LDA, *Bl = Bh + (size_t)128 * LDA;
+    double *gmax = reinterpret_cast<double *>(Bl + (size_t)128 * LDA); // [8 groups of 16 rows][128 columns] of the pair in hand
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, l32 = lane & 31, lh = lane >> 5;
     const i64 nTJ = ldm / 128;
@@ -608,15 +610,34 @@ __global__ __launch_bounds__(PB_T) void pcent_bf16_kernel(const unsigned short *
                             v = fmax(v, (af - af == 0.f) ? t : 1e300); // NaN / Inf in the accumulator: no pruning on this entry
                         }
                         v = fmax(v, __shfl_xor(v, 32));
-                        if (lh == 0) G[(r0 >> 4) * ldm + col] = fmax(v + mne, 0.0);
+                        if (lh == 0) gmax[(wr * 2 + h) * 128 + wc * 64 + b * 32 + l32] = fmax(v + mne, 0.0);
+                        (void)r0; (void)col;
                     }
                 }
             }
-            if (more_cols) {
-                __syncthreads(); // every wave is done with column tile J
-                stash(Bh, Bl, bv);
-                __syncthreads();
+            __syncthreads(); // every wave is done with column tile J (and its group maxima are in LDS)
+            if (!(diag & 1) && tid < 128) {
+                // The rows are landmark-sorted: the 8 groups of the tile belong to one, two, rarely more landmarks.  The groups of
+                // a landmark are combined here and the result joins P[landmark][column] by one atomic max per run (bit patterns of
+                // non-negative doubles order like integers; the atomics of a wave go to consecutive addresses).
+                const i64 col = J * 128 + tid;
+                double cur = 0.0;
+                int curland = -1;
+#pragma unroll
+                for (int gq = 0; gq < 8; gq++) {
+                    const int land = sub_land[(i0 >> 4) + gq]; // uniform
+                    const double v = gmax[gq * 128 + tid];
+                    if (land != curland) {
+                        if (curland >= 0 && col < nref) atomicMax(&P[(i64)curland * nref + col], (unsigned long long)__double_as_longlong(cur));
+                        curland = land;
+                        cur = v;
+                    } else
+                        cur = fmax(cur, v);
+                }
+                if (curland >= 0 && col < nref) atomicMax(&P[(i64)curland * nref + col], (unsigned long long)__double_as_longlong(cur));
             }
+            if (more_cols) stash(Bh, Bl, bv);
+            __syncthreads(); // gmax may be overwritten, the next column tile read
         }
     }
 }
@@ -734,15 +755,13 @@ void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows,
 // the bf16-split form (2c): Xb / Mb = the two-plane row-major operands written by k_gather_centre_fm (KP = dpad rounded up to 32)
 bool k_pcent_bf16_applies(i64 dpad) { return (dpad + 31) / 32 * 32 <= 128; } // a tile of either operand, both planes, whole K, fits LDS
 void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 lds_rows, const unsigned short *Mb,
-                  const double *mnorm, i64 ldm, i64 n_land, i64 N, i64 KP, const i32 *soff, double *P, int part, int nparts) {
-    const i64 ngroups = lds_rows / 16;
-    c->pc_groups.ensure((size_t)ngroups * ldm);
-    if (nparts > 1) HIP_CHECK(hipMemsetAsync(c->pc_groups.p, 0, sizeof(double) * (size_t)ngroups * ldm, c->stream));
+                  const double *mnorm, i64 ldm, i64 n_land, i64 N, i64 KP, const i32 *sub_land, double *P, int part, int nparts) {
+    HIP_CHECK(hipMemsetAsync(P, 0, sizeof(double) * n_land * N, c->stream));
     ScopedKernelTimer t(c, "pcent");
     const i64 nTI = lds_rows / 128, I0 = nTI * part / nparts, I1 = nTI * (part + 1) / nparts;
     const double e1 = 1.0 + 1.05 * (3.0 * (double)(KP + 2) * 1.1920928955078125e-07 + 3.2 * 1.52587890625e-05); // 2^-23, 2^-16
     if (I1 > I0) {
-        const size_t lds = (size_t)4 * 128 * (KP + PB_APAD) * sizeof(unsigned short); // both operands, both planes, whole K
+        const size_t lds = (size_t)4 * 128 * (KP + PB_APAD) * sizeof(unsigned short) + (size_t)8 * 128 * sizeof(double); // both operands, both planes, whole K + the group maxima
         static const int pb_diag = getenv("CGE_PB_DIAG") ? atoi(getenv("CGE_PB_DIAG")) : 0; // timing diagnostics (wrong bounds)
 #define PB_GO(NKS)                                                                                                         \
     do {                                                                                                                   \
@@ -750,7 +769,7 @@ void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 l
         static bool attr = false;                                                                                          \
         if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
         hipLaunchKernelGGL(kern, dim3((unsigned)std::min<i64>(I1 - I0, 256)), dim3(PB_T), lds, c->stream, Xb, rns, lds_rows, Mb, \
-                           mnorm, ldm, c->pc_groups.p, I0, I1, e1, pb_diag);                                                \
+                           mnorm, ldm, sub_land, N, reinterpret_cast<unsigned long long *>(P), I0, I1, e1, pb_diag);        \
     } while (0)
         if (KP == 32) PB_GO(2);
         else if (KP == 64) PB_GO(4);
@@ -758,7 +777,6 @@ void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 l
         else PB_GO(8);
 #undef PB_GO
     }
-    hipLaunchKernelGGL(pcent_groups_kernel, dim3((unsigned)n_land), dim3(256), 0, c->stream, c->pc_groups.p, soff, ldm, N, P);
 }
 
 void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, i64 npos, i64 dpad, const void *tiles,
@@ -806,6 +824,19 @@ __global__ __launch_bounds__(256) void bound_select_kernel(const double *__restr
         }
     }
 }
+// the same from the centred feature-major copy Ms (dpad x ldm, zero padded): workgroup a, thread b, coalesced along b
+__global__ __launch_bounds__(256) void ref_dist2_fm_kernel(const double *__restrict__ Ms, i64 nref, i64 dpad, i64 ldm,
+                                                           double *__restrict__ rd2) {
+    const i64 a = blockIdx.x;
+    for (i64 b = threadIdx.x; b < nref; b += blockDim.x) {
+        double s = 0.0;
+        for (i64 k = 0; k < dpad; k++) {
+            const double df = Ms[k * ldm + a] - Ms[k * ldm + b];
+            s += df * df;
+        }
+        rd2[a * nref + b] = s;
+    }
+}
 // squared distances of the nref reference points (row-major nref x d)
 __global__ void ref_dist2_kernel(const double *__restrict__ mu, i64 nref, i64 d, double *__restrict__ rd2) {
     const i64 total = nref * nref, stride = (i64)gridDim.x * blockDim.x;
@@ -820,17 +851,88 @@ __global__ void ref_dist2_kernel(const double *__restrict__ mu, i64 nref, i64 d,
         rd2[e] = s;
     }
 }
+// ---- the same selection in two levels, when the reference points are the landmarks' communities -----------------------
+// Mx[ca][r] = max over the landmarks a of community ca of Q[a][r].  Every landmark-pair bound of the community pair
+// (ca, cb) is at most  Mx[ca][cb] + Mx[cb][ca] + 2 sqrt(Mx[ca][ca] Mx[cb][cb]) - rd2[ca][cb]  (the bound is monotone in its
+// four Q terms), so a community pair below L is dropped whole: C (C + 1) / 2 tests instead of N (N + 1) / 2, and only the
+// surviving community pairs (a fraction of a percent) are expanded to landmark pairs -- with the same arithmetic, hence the
+// same (B, a, b) records as the flat kernel.
+__global__ __launch_bounds__(256) void comm_max_kernel(const double *__restrict__ Q, const i32 *__restrict__ ref_off,
+                                                       const i32 *__restrict__ ref_mem, i64 nref, double *__restrict__ Mx) {
+    const i64 ca = blockIdx.x;
+    const i32 b = ref_off[ca], e = ref_off[ca + 1];
+    for (i64 r = threadIdx.x; r < nref; r += blockDim.x) {
+        double v = 0.0;
+        for (i32 t = b; t < e; t++) v = fmax(v, Q[(i64)ref_mem[t] * nref + r]);
+        Mx[ca * nref + r] = v;
+    }
+}
+__global__ __launch_bounds__(256) void comm_pairs_kernel(const double *__restrict__ Mx, const double *__restrict__ rd2, i64 C,
+                                                         double L, int2 *__restrict__ plist, unsigned *__restrict__ pcount) {
+    const i64 total = C * C, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const i64 ca = e / C, cb = e - ca * C;
+        if (cb < ca) continue;
+        const double pre = Mx[ca * C + cb] + Mx[cb * C + ca] + 2.0 * sqrt(Mx[ca * C + ca] * Mx[cb * C + cb]);
+        if (pre * (1.0 + 1e-9) + 1e-9 < L) continue;
+        const double Bv = pre - rd2[ca * C + cb] * (1.0 - 1e-9);
+        if (Bv * (1.0 + 1e-9) + 1e-9 >= L) plist[atomicAdd(pcount, 1u)] = make_int2((int)ca, (int)cb);
+    }
+}
+// one workgroup per surviving community pair (grid-stride over the list): its landmark pairs, the flat kernel's arithmetic
+__global__ __launch_bounds__(256) void bound_expand_kernel(const double *__restrict__ Q, const double *__restrict__ rd2,
+                                                           const i32 *__restrict__ ref_off, const i32 *__restrict__ ref_mem,
+                                                           i64 nref, double L, const int2 *__restrict__ plist,
+                                                           const unsigned *__restrict__ pcount, BoundRec *__restrict__ list,
+                                                           i64 cap, unsigned long long *__restrict__ count) {
+    const unsigned np = *pcount;
+    for (unsigned q = blockIdx.x; q < np; q += gridDim.x) {
+        const i64 ca = plist[q].x, cb = plist[q].y;
+        const i32 a0 = ref_off[ca], na = ref_off[ca + 1] - a0, b0 = ref_off[cb], nb = ref_off[cb + 1] - b0;
+        const double r2 = rd2[ca * nref + cb] * (1.0 - 1e-9);
+        for (i64 e = threadIdx.x; e < (i64)na * nb; e += blockDim.x) {
+            const i64 ia = e / nb, ib = e - ia * nb;
+            i64 a = ref_mem[a0 + ia], b = ref_mem[b0 + ib];
+            if (ca == cb && b < a) continue; // an unordered pair once
+            i64 ra = ca, rb = cb;
+            if (b < a) { const i64 t = a; a = b; b = t; ra = cb; rb = ca; } // records are (a <= b), as the flat kernel writes them
+            const double qaa = Q[a * nref + ra], qbb = Q[b * nref + rb];
+            const double pre = Q[a * nref + rb] + Q[b * nref + ra] + 2.0 * sqrt(qaa * qbb);
+            if (pre * (1.0 + 1e-9) + 1e-9 < L) continue;
+            const double Bv = pre - r2;
+            if (Bv * (1.0 + 1e-9) + 1e-9 >= L) {
+                const unsigned long long idx = atomicAdd(count, 1ULL);
+                if ((i64)idx < cap) list[idx] = BoundRec{Bv, (i32)a, (i32)b};
+            }
+        }
+    }
+}
+// `ref_off` / `ref_mem` (optional, device): the landmarks grouped by reference point (lref[a] = community of a): two-level form
 i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *mu_ref, i64 N, i64 nref, i64 d, double L,
-                   void *list, i64 cap) {
-    c->mp_count.ensure(1);
+                   void *list, i64 cap, const i32 *ref_off, const i32 *ref_mem, const double *Ms_fm, i64 dpad, i64 ldm) {
+    c->mp_count.ensure(2);
     c->mp_rd2.ensure((size_t)nref * nref);
-    HIP_CHECK(hipMemsetAsync(c->mp_count.p, 0, sizeof(i64), c->stream));
+    HIP_CHECK(hipMemsetAsync(c->mp_count.p, 0, 2 * sizeof(i64), c->stream));
     ScopedKernelTimer tm(c, "bound_select");
-    hipLaunchKernelGGL(ref_dist2_kernel, dim3(grid_for(nref * nref, 256)), dim3(256), 0, c->stream, mu_ref, nref, d,
-                       c->mp_rd2.p);
-    hipLaunchKernelGGL(bound_select_kernel, dim3(grid_for(N * N, 256)), dim3(256), 0, c->stream, Q, lref, c->mp_rd2.p, N,
-                       nref, L, reinterpret_cast<BoundRec *>(list), cap,
-                       reinterpret_cast<unsigned long long *>(c->mp_count.p));
+    if (Ms_fm) // (differences of centred values: the centre cancels; the 1e-9 margins of the bound cover the rounding)
+        hipLaunchKernelGGL(ref_dist2_fm_kernel, dim3((unsigned)nref), dim3(256), 0, c->stream, Ms_fm, nref, dpad, ldm, c->mp_rd2.p);
+    else
+        hipLaunchKernelGGL(ref_dist2_kernel, dim3(grid_for(nref * nref, 256)), dim3(256), 0, c->stream, mu_ref, nref, d,
+                           c->mp_rd2.p);
+    static const bool flat = getenv("CGE_BOUND_FLAT") != nullptr; // A/B switch
+    if (ref_off && ref_mem && !flat) {
+        c->mp_commax.ensure((size_t)nref * nref);
+        c->mp_plist.ensure((size_t)nref * (nref + 1)); // int2 per community pair
+        hipLaunchKernelGGL(comm_max_kernel, dim3((unsigned)nref), dim3(256), 0, c->stream, Q, ref_off, ref_mem, nref, c->mp_commax.p);
+        hipLaunchKernelGGL(comm_pairs_kernel, dim3(grid_for(nref * nref, 256)), dim3(256), 0, c->stream, c->mp_commax.p, c->mp_rd2.p,
+                           nref, L, reinterpret_cast<int2 *>(c->mp_plist.p), reinterpret_cast<unsigned *>(c->mp_count.p + 1));
+        hipLaunchKernelGGL(bound_expand_kernel, dim3(2048), dim3(256), 0, c->stream, Q, c->mp_rd2.p, ref_off, ref_mem, nref, L,
+                           reinterpret_cast<const int2 *>(c->mp_plist.p), reinterpret_cast<const unsigned *>(c->mp_count.p + 1),
+                           reinterpret_cast<BoundRec *>(list), cap, reinterpret_cast<unsigned long long *>(c->mp_count.p));
+    } else
+        hipLaunchKernelGGL(bound_select_kernel, dim3(grid_for(N * N, 256)), dim3(256), 0, c->stream, Q, lref, c->mp_rd2.p, N,
+                           nref, L, reinterpret_cast<BoundRec *>(list), cap,
+                           reinterpret_cast<unsigned long long *>(c->mp_count.p));
     i64 cnt = 0;
     HIP_CHECK(hipMemcpyAsync(&cnt, c->mp_count.p, sizeof(i64), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -888,6 +990,27 @@ __global__ __launch_bounds__(256) void farthest_kernel(const double *__restrict_
         if (in1 && a1 > best) { best = a1; bi = i1; }
     }
     reduce_best(best, bi, src, lds, recs);
+}
+// position of the largest of n values (ties: the smallest position), mapped through `map` (optional): the vertex farthest from
+// the centre of the point set -- the seed of the farthest-point sweep
+__global__ __launch_bounds__(256) void argmax_kernel(const double *__restrict__ v, i64 n, const i32 *__restrict__ map,
+                                                     MaxRec *__restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double best = -1.0;
+    i64 bi = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
+        if (v[i] > best) { best = v[i]; bi = i; }
+    reduce_best(best, bi, map ? (i64)map[bi] : bi, lds, recs);
+}
+i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map) {
+    c->mp_recs.ensure(MP_NWG * 3);
+    MaxRec *recs = reinterpret_cast<MaxRec *>(c->mp_recs.p);
+    const int nwg = (int)std::max<i64>(1, std::min<i64>((n + 255) / 256, 256));
+    hipLaunchKernelGGL(argmax_kernel, dim3(nwg), dim3(256), 768 * sizeof(double), c->stream, v, n, map, recs);
+    double bv;
+    i64 bi, bj;
+    best_of_recs(c, recs, nwg, &bv, &bi, &bj);
+    return bj;
 }
 void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i) {
     c->mp_recs.ensure(MP_NWG * 3);

@@ -75,52 +75,62 @@ __global__ void colsum_final_kernel(const double *__restrict__ part, i64 nb, i64
 }
 // dst[k*ld + p] = src[idx ? idx[p] : p][k] - mean[k]  (row-major rows -> centred feature-major, 32x32 LDS tiles)
 // `planes` (optional): the same values as two row-major bf16 planes [2][ld][KP] (v = h + l + O(2^-16 v)), the operands of
-// the bf16-split bound pass (kernels_dist.hip (2c)); *flag |= 1 when a value is unfit for that split
+// the bf16-split bound pass (kernels_dist.hip (2c)); *flag |= 1 when a value is unfit for that split.
+// A workgroup takes 32 rows and walks their features in tiles of 32, so the squared norms of the centred rows
+// (rnorm[p], optional) come out of the same pass (per row: the features of a tile in ascending order per thread, the
+// eight threads of a row and then the tiles combined in fixed order).
 __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i32 *__restrict__ idx,
                                         const double *__restrict__ mean, double *__restrict__ dst, i64 npos, i64 d,
                                         i64 ld, float *__restrict__ dst32, unsigned short *__restrict__ planes, i64 KP,
-                                        int *__restrict__ flag) {
+                                        int *__restrict__ flag, double *__restrict__ rnorm) {
     __shared__ double tile[32][33];
-    i64 p0 = (i64)blockIdx.x * 32, k0 = (i64)blockIdx.y * 32;
-    int tx = threadIdx.x, ty = threadIdx.y;
+    __shared__ double nrm[8][33];
+    const i64 p0 = (i64)blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
     bool bad = false;
-    for (int r = ty; r < 32; r += 8) {
-        i64 p = p0 + r, k = k0 + tx;
-        if (p < npos && k < d) {
-            const double v = src[(idx ? (i64)idx[p] : p) * d + k] - mean[k];
-            tile[r][tx] = v;
-            if (planes) {
-                const double av = fabs(v);
-                if (!(av < 1.2676506002282294e30) || (av != 0.0 && av < 7.888609052210118e-31)) bad = true; // 2^100, 2^-100
-                unsigned u = __float_as_uint((float)v);
-                u += 0x7FFFu + ((u >> 16) & 1u); // bf16, round to nearest even
-                const unsigned short h = (unsigned short)(u >> 16);
-                unsigned w = __float_as_uint((float)(v - (double)__uint_as_float((unsigned)h << 16)));
-                w += 0x7FFFu + ((w >> 16) & 1u);
-                planes[p * KP + k] = h;
-                planes[ld * KP + p * KP + k] = (unsigned short)(w >> 16);
+    double sq = 0.0; // of row p0 + tx, the features this thread visits in the second phase
+    for (i64 k0 = 0; k0 < d; k0 += 32) {
+        for (int r = ty; r < 32; r += 8) {
+            const i64 p = p0 + r, k = k0 + tx;
+            if (p < npos && k < d) {
+                const double v = src[(idx ? (i64)idx[p] : p) * d + k] - mean[k];
+                tile[r][tx] = v;
+                if (planes) {
+                    const double av = fabs(v);
+                    if (!(av < 1.2676506002282294e30) || (av != 0.0 && av < 7.888609052210118e-31)) bad = true; // 2^100, 2^-100
+                    unsigned u = __float_as_uint((float)v);
+                    u += 0x7FFFu + ((u >> 16) & 1u); // bf16, round to nearest even
+                    const unsigned short h = (unsigned short)(u >> 16);
+                    unsigned w = __float_as_uint((float)(v - (double)__uint_as_float((unsigned)h << 16)));
+                    w += 0x7FFFu + ((w >> 16) & 1u);
+                    planes[p * KP + k] = h;
+                    planes[ld * KP + p * KP + k] = (unsigned short)(w >> 16);
+                }
             }
         }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const i64 p = p0 + tx, k = k0 + r;
+            if (p < npos && k < d) {
+                const double v = tile[tx][r];
+                dst[k * ld + p] = v;
+                if (dst32) dst32[k * ld + p] = (float)v; // operand of the fp32-MFMA bound pass
+                sq += v * v;
+            }
+        }
+        __syncthreads();
     }
     if (bad) atomicOr(flag, 1);
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        i64 p = p0 + tx, k = k0 + r;
-        if (p < npos && k < d) {
-            dst[k * ld + p] = tile[tx][r];
-            if (dst32) dst32[k * ld + p] = (float)tile[tx][r]; // operand of the fp32-MFMA bound pass
+    if (rnorm) {
+        nrm[ty][tx] = sq;
+        __syncthreads();
+        if (ty == 0 && p0 + tx < npos) {
+            double s = nrm[0][tx];
+#pragma unroll
+            for (int q = 1; q < 8; q++) s += nrm[q][tx];
+            rnorm[p0 + tx] = s;
         }
     }
-}
-__global__ void rownorm_kernel(const double *__restrict__ Xc, i64 n, i64 d, i64 ldn, double *__restrict__ rnorm) {
-    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (i64 k = 0; k < d; k++) {
-        double v = Xc[k * ldn + i];
-        s += v * v;
-    }
-    rnorm[i] = s;
 }
 void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean) {
     const int NB = 512;
@@ -139,11 +149,9 @@ void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, 
     if (planes) HIP_CHECK(hipMemsetAsync(planes, 0, sizeof(unsigned short) * (size_t)(2 * ld * KP), c->stream));
     if (dst32) HIP_CHECK(hipMemsetAsync(dst32, 0, sizeof(float) * (size_t)(ld * dpad), c->stream));
     HIP_CHECK(hipMemsetAsync(rnorm, 0, sizeof(double) * (size_t)ld, c->stream));
-    dim3 grid((unsigned)((npos + 31) / 32), (unsigned)((d + 31) / 32));
+    dim3 grid((unsigned)((npos + 31) / 32));
     hipLaunchKernelGGL(gather_centre_fm_kernel, grid, dim3(32, 8), 0, c->stream, src_rowmajor, idx, mean, dst, npos, d,
-                       ld, dst32, planes, KP, flag);
-    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, c->stream, dst, npos, d, ld,
-                       rnorm);
+                       ld, dst32, planes, KP, flag, rnorm);
 }
 
 // ------------------------------------------------------------------------------------------------
