@@ -362,23 +362,14 @@ static i64 clamp_to_unique_rows(cge_ctx *c, i64 land, int *truncated) {
     *truncated = 0;
     if (land <= 1) return land;
     // `land` distinct hashes among a prefix of the rows already prove `land` distinct rows: hash 8*land rows first,
-    // the whole matrix only when that prefix does not settle it
-    std::vector<uint64_t> h;
-    std::unordered_set<uint64_t> seen;
-    seen.reserve((size_t)std::min<i64>(n, 2 * land));
+    // the whole matrix only when that prefix does not settle it.  The distinct hashes are counted on the device (a set
+    // of atomicCAS slots): one 8-byte read-back instead of the hashes themselves and a host set.
     i64 done = 0;
     c->uniq_hash.ensure(n);
     for (int pass = 0; pass < 2 && done < n; pass++) {
         const i64 upto = pass == 0 ? std::min<i64>(n, 8 * land) : n;
         k_row_hash(c, c->Xr.p + done * d, c->uniq_hash.p + done, upto - done, d);
-        h.resize(upto);
-        HIP_CHECK(hipMemcpyAsync(h.data() + done, c->uniq_hash.p + done, sizeof(uint64_t) * (upto - done), hipMemcpyDeviceToHost,
-                                 c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        for (i64 i = done; i < upto; i++) {
-            seen.insert(h[i]);
-            if ((i64)seen.size() >= land) return land;
-        }
+        if (k_count_distinct(c, c->uniq_hash.p, upto) >= land) return land;
         done = upto;
     }
     // fewer distinct hashes than `land`: count bitwise-distinct rows exactly

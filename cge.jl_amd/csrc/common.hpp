@@ -102,6 +102,9 @@ struct PinBuf {
 };
 
 // Persistent worker pool: run(n, fn) executes fn(0..n-1) on the workers + the calling thread.
+// Completion is counted in ITEMS, not in workers: the caller takes items itself and returns as soon as the last one is
+// done, so a worker that is slow to wake up (a sleeping core: milliseconds, seen as sporadic 2-6 ms stalls of a 0.1 ms
+// job) delays nobody -- it finds the job drained and goes back to sleep.
 class ThreadPool {
   public:
     explicit ThreadPool(int n_workers) {
@@ -123,52 +126,52 @@ class ThreadPool {
             for (i64 i = 0; i < n; i++) fn(i);
             return;
         }
+        auto job = std::make_shared<Job>();
+        job->fn = &fn;
+        job->n = n;
         {
             std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn;
-            n_ = n;
-            next_.store(0);
-            pending_ = (int)workers_.size();
+            cur_ = job;
             gen_++;
         }
         cv_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(m_);
-        done_cv_.wait(lk, [this]() { return pending_ == 0; });
-        fn_ = nullptr;
+        work(*job);
+        while (job->done.load(std::memory_order_acquire) < n) std::this_thread::yield(); // items other threads still hold
+        // (a late worker may still look at `job` through its own reference: it finds next >= n and never touches fn)
     }
 
   private:
-    void work() {
+    struct Job {
+        const std::function<void(i64)> *fn = nullptr;
+        i64 n = 0;
+        std::atomic<i64> next{0}, done{0};
+    };
+    static void work(Job &j) {
         for (;;) {
-            const i64 i = next_.fetch_add(1);
-            if (i >= n_) break;
-            (*fn_)(i);
+            const i64 i = j.next.fetch_add(1);
+            if (i >= j.n) break;
+            (*j.fn)(i);
+            j.done.fetch_add(1, std::memory_order_release);
         }
     }
     void loop() {
         unsigned long long seen = 0;
         for (;;) {
+            std::shared_ptr<Job> job;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&]() { return gen_ != seen; });
                 seen = gen_;
                 if (stop_) return;
+                job = cur_;
             }
-            work();
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                if (--pending_ == 0) done_cv_.notify_one();
-            }
+            if (job) work(*job);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_;
-    std::condition_variable cv_, done_cv_;
-    const std::function<void(i64)> *fn_ = nullptr;
-    i64 n_ = 0;
-    std::atomic<i64> next_{0};
-    int pending_ = 0;
+    std::condition_variable cv_;
+    std::shared_ptr<Job> cur_;
     unsigned long long gen_ = 0;
     bool stop_ = false;
 };
@@ -344,6 +347,7 @@ struct cge_ctx {
     DevBuf<i32> tile_list;
     std::vector<i32> h_mem_off, h_mem;     // landmark -> members (ascending vertex id), host copy
     DevBuf<uint64_t> uniq_hash;            // row hashes of the unique-row check
+    DevBuf<unsigned long long> uniq_table; // ... and the device set that counts the distinct ones
     int opt_diameter = 0;                  // 0 auto (pruned with brute-force fallback), 1 brute force, 2 pruned only
     i64 stat_cand_pairs = 0, stat_cand_tiles = 0; // last pruned run
     int stat_diameter_path = 0;            // 1 brute, 2 pruned
@@ -498,6 +502,7 @@ cge_ctx *cge_shadow_context(cge_ctx *c, cge_ctx **slot, bool low_priority); // c
 // layout
 void k_transpose_to_rowmajor(cge_ctx *c, const double *Xcol, double *Xrow, i64 n, i64 d);
 void k_row_hash(cge_ctx *c, const double *Xrow, uint64_t *hash, i64 n, i64 d);
+i64 k_count_distinct(cge_ctx *c, const uint64_t *hash, i64 n); // distinct values among the hashes (device set; synchronises)
 // landmark split primitives (batched over tasks; rows = concatenated 0-based vertex ids)
 void k_group_mean(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *chunk_task,
                   const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,

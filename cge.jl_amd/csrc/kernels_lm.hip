@@ -177,6 +177,39 @@ void k_row_hash(cge_ctx *c, const double *Xrow, uint64_t *hash, i64 n, i64 d) {
     hipLaunchKernelGGL(row_hash_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, Xrow, hash,
                        n, d);
 }
+// number of DISTINCT values among hash[0 .. n): an open-addressing set in `table` (tsize slots, a power of two >= 2 n, all
+// ones = empty), every first insertion counted.  (A hash equal to the empty marker is folded onto another value: the count
+// is then a lower bound of the distinct rows as well, which is all the caller needs.)
+__global__ void count_distinct_kernel(const uint64_t *__restrict__ hash, i64 n, unsigned long long *__restrict__ table, i64 mask,
+                                      unsigned long long *__restrict__ count) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned long long key = hash[i];
+        if (key == ~0ULL) key = 0x5bd1e995ULL;
+        i64 slot = (i64)(mix64(key) & (uint64_t)mask);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&table[slot], ~0ULL, key);
+            if (old == ~0ULL) { mine++; break; }
+            if (old == key) break;
+            slot = (slot + 1) & mask;
+        }
+    }
+    if (mine) atomicAdd(count, mine);
+}
+i64 k_count_distinct(cge_ctx *c, const uint64_t *hash, i64 n) {
+    i64 tsize = 1024;
+    while (tsize < 2 * n) tsize <<= 1;
+    c->uniq_table.ensure((size_t)tsize + 1);
+    HIP_CHECK(hipMemsetAsync(c->uniq_table.p, 0xFF, sizeof(unsigned long long) * tsize, c->stream));
+    HIP_CHECK(hipMemsetAsync(c->uniq_table.p + tsize, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(count_distinct_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, c->stream, hash, n, c->uniq_table.p, tsize - 1,
+                       c->uniq_table.p + tsize);
+    unsigned long long cnt = 0;
+    HIP_CHECK(hipMemcpyAsync(&cnt, c->uniq_table.p + tsize, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return (i64)cnt;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Batched group statistics.  A batch is a list of tasks (groups); `rows` holds their 0-based
