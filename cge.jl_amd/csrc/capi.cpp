@@ -438,7 +438,7 @@ static void scatter_wedges(cge_ctx *c, int directed) {
     const int rank = c->has_coll ? c->coll.rank : 0, world = c->has_coll ? c->coll.world : 1;
     // the tiled two-pass form on the blocked copy of the edge list (kernels_scatter.hip): the tiles are written whole, the
     // positive entries counted on the way (one rank) -- else the gather + atomics kernel into a zeroed matrix
-    bool tiled = (c->blocked_ready || (k_edge_scatter_blocked_applies(c, 1) && k_build_blocked_edges(c))) &&
+    bool tiled = (c->blocked_ready || (k_blocked_edges_possible(c) && k_build_blocked_edges(c))) &&
                  k_wedge_scatter_blocked(c, c->v2l.p, N, c->be_nchunks * rank / world, c->be_nchunks * (rank + 1) / world, directed,
                                          c->wedges.p, cnt.p);
     if (!tiled) {
@@ -463,9 +463,24 @@ static void scatter_wedges(cge_ctx *c, int directed) {
 static void scatter_vectC_resident(cge_ctx *c, i64 C, int directed, double *vectC) {
     const i64 vlen = directed ? C * C : packed_len(C);
     const int rank = c->has_coll ? c->coll.rank : 0, world = c->has_coll ? c->coll.world : 1;
+    bool done = false;
     if (k_edge_scatter_blocked_applies(c, C) && (c->blocked_ready || k_build_blocked_edges(c))) {
         k_edge_scatter_blocked(c, c->be_nchunks * rank / world, c->be_nchunks * (rank + 1) / world, C, directed, vectC);
-    } else {
+        done = true;
+    } else if (C > 1 && C <= 16384 && (c->blocked_ready || (k_blocked_edges_possible(c) && k_build_blocked_edges(c)))) {
+        // beyond the 2048 row counters of the row-bucketed form: the community pairs as a dense C x C matrix through the
+        // TILED two-pass form of the landmark-pair matrix (tiles of rows in LDS, written whole), then packed
+        DevBuf<i64> &cnt = c->wed_cnt;
+        cnt.ensure(1);
+        double *dense = vectC;
+        if (!directed) { c->cc_dense.ensure((size_t)C * C); dense = c->cc_dense.p; }
+        if (k_wedge_scatter_blocked(c, c->comm.p, C, c->be_nchunks * rank / world, c->be_nchunks * (rank + 1) / world, directed,
+                                    dense, cnt.p, "edge_scatter")) {
+            if (!directed) k_pack_upper(c, dense, C, vectC);
+            done = true;
+        }
+    }
+    if (!done) {
         HIP_CHECK(hipMemsetAsync(vectC, 0, sizeof(double) * vlen, c->stream));
         k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, c->m * rank / world, c->m * (rank + 1) / world,
                        nullptr, c->comm.p, 1, C, directed, nullptr, vectC);
@@ -1159,9 +1174,8 @@ int cge_edge_scatter(cge_ctx *c, const int64_t *v_to_l, int64_t N, int64_t C, in
         dc.ensure(vlen);
         HIP_CHECK(hipMemsetAsync(dc.p, 0, sizeof(double) * vlen, st));
     }
-    if (!wedges_out && vect_C_out && e0 == 0 && e1 == c->m && C == c->n_comm_max && !c->has_coll &&
-        k_edge_scatter_blocked_applies(c, C) && (c->blocked_ready || k_build_blocked_edges(c)))
-        k_edge_scatter_blocked(c, 0, c->be_nchunks, C, directed, dc.p); // the score path's form of the whole-list pass
+    if (!wedges_out && vect_C_out && e0 == 0 && e1 == c->m && C == c->n_comm_max && !c->has_coll)
+        scatter_vectC_resident(c, C, directed, dc.p); // the score path's forms of the whole-list pass
     else
         k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, v_to_l ? dv.p : nullptr,
                        c->comm.p, N, C, directed, wedges_out ? dw.p : nullptr, vect_C_out ? dc.p : nullptr);

@@ -414,6 +414,7 @@ struct cge_ctx {
     DevBuf<i32> epd_i, s_star;
     DevBuf<double> epd_d;
     DevBuf<i64> wed_cnt;
+    DevBuf<double> cc_dense; // dense C x C stage of vect_C beyond 2048 communities (tiled two-pass form)
     DevBuf<unsigned> samp_attempt;
     DevBuf<i32> samp_todo_a, samp_todo_b, samp_hit;
     DevBuf<unsigned long long> samp_table, samp_count;
@@ -548,10 +549,13 @@ void k_landmark_aggregate(cge_ctx *c, const double *Xr, const double *vw, const 
                           const i32 *mem, i64 N, i64 d, double *lemb, double *lweight, double *dii, i32 *lcomm);
 // per-edge scatter
 bool k_edge_scatter_blocked_applies(const cge_ctx *c, i64 C);
+bool k_blocked_edges_possible(const cge_ctx *c);
+void k_pack_upper(cge_ctx *c, const double *dense, i64 C, double *packed);
 bool k_build_blocked_edges(cge_ctx *c);
 void k_edge_scatter_blocked(cge_ctx *c, i64 c0, i64 c1, i64 C, int directed, double *vectC);
 // the N x N landmark-pair matrix by the tiled two-pass form (kernels_scatter.hip); false: does not apply
-bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, int directed, double *wedges, i64 *positive);
+bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, int directed, double *wedges, i64 *positive,
+                             const char *timer = "edge_scatter_wedges");
 #define CGE_COMM16_PAD 32768 // the uint16 community table is padded to a multiple of the edge pass's vertex block
 void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 e0, i64 e1, const i32 *v2l,
                     const i32 *comm, i64 N, i64 C, int directed, double *wedges, double *vectC);

@@ -570,7 +570,8 @@ static bool wedge_geometry(const cge_ctx *c, i64 N, i64 nchunks, int *rshift, in
 
 // wedges (N x N, row-major [a * N + b]) and *positive (device counter) from chunks [c0, c1) of the blocked edge list;
 // returns false when the tiled form does not apply.  v2l: 0-based landmark of every vertex (device).
-bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, int directed, double *wedges, i64 *positive) {
+bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, int directed, double *wedges, i64 *positive,
+                             const char *timer) {
     const i64 nwg = c1 - c0;
     int rshift, colbits;
     i64 ntile;
@@ -587,7 +588,7 @@ bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, 
     c->be_keys.ensure(c->m + 64);
     if (!c->unit_weights) c->be_wkeys.ensure(c->m + 64);
     c->be_runoff.ensure((size_t)nwg * (ntile + 1));
-    ScopedKernelTimer t(c, "edge_scatter_wedges");
+    ScopedKernelTimer t(c, timer);
     hipLaunchKernelGGL(wedge_table_kernel, dim3(grid_for(npad, 256)), dim3(256), 0, st, v2l, c->n, npad, c->v2l16.p);
     const int ntpad = (int)((ntile + EB_THREADS - 1) / EB_THREADS * EB_THREADS);
     const size_t lds1 = (size_t)2 * (1 << EB_VBITS) + sizeof(unsigned) * ((size_t)ntpad + 18);
@@ -614,6 +615,24 @@ bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, 
     else WG_GO(false, false);
 #undef WG_GO
     return true;
+}
+
+// can the blocked copy of the resident edge list exist at all (sort key of 32 bits: tile, source inside the tile)?
+bool k_blocked_edges_possible(const cge_ctx *c) {
+    static const bool off = getenv("CGE_SCATTER_GATHER") != nullptr; // A/B switch: force the gather + atomics kernel
+    return !off && c->m > 0 && c->m < (1LL << 31) &&
+           ((c->n + (1 << EB_UBITS) - 1) >> EB_UBITS) * ((c->n + (1 << EB_VBITS) - 1) >> EB_VBITS) <= 32768; // n <= ~1.4e7
+}
+// dense C x C (row-major, a <= b when undirected) -> the packed upper triangle of vect_C (src/auxilary.jl:57-59)
+__global__ void pack_upper_kernel(const double *__restrict__ dense, i64 C, double *__restrict__ packed) {
+    const i64 total = C * C, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const i64 a = e / C, b = e - a * C;
+        if (b >= a) packed[C * a - a * (a - 1) / 2 + (b - a)] = dense[e];
+    }
+}
+void k_pack_upper(cge_ctx *c, const double *dense, i64 C, double *packed) {
+    hipLaunchKernelGGL(pack_upper_kernel, dim3(grid_for(C * C, 256)), dim3(256), 0, c->stream, dense, C, packed);
 }
 
 bool k_edge_scatter_blocked_applies(const cge_ctx *c, i64 C) {

@@ -758,11 +758,13 @@ def test_edge_scatter_blocked_two_pass_form(ctx, directed, weighted):
     """The score path's form of the per-edge cluster-pair scatter (kernels_scatter.hip: blocked edge list, community
     slices in LDS, off-diagonal pairs bucketed by row, no global atomics) against numpy: several vertex blocks, chunks
     that split a tile, unit and dyadic weights, packed (undirected) and C x C (directed) outputs; repeated calls reuse the
-    blocked copy; 1500 communities (config 5) still take this path, 2500 fall back to the gather kernel with the same result."""
+    blocked copy; 1500 communities (config 5) still take this path, 2500 and 9000 go through the tiled form of the landmark-pair
+    matrix (a dense C x C stage, packed afterwards) with the same result."""
     from cge.jl_amd import synth
 
     rng = np.random.default_rng(11)
-    for n, m, C in ((150_000, 1_600_000, 37), (40_000, 300_000, 1500), (60_000, 400_000, 2500), (3_000, 20_000, 5)):
+    for n, m, C in ((150_000, 1_600_000, 37), (40_000, 300_000, 1500), (60_000, 400_000, 2500), (100_000, 500_000, 9000),
+                    (3_000, 20_000, 5)):
         g = synth.abcd_like(n, m, C, 4, seed=23, directed=directed)
         w = (rng.integers(1, 9, size=g["m"]) / 4.0) if weighted else g["eweights"]
         ctx.set_graph(g["edges"], w, g["n"])
