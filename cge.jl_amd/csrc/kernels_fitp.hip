@@ -927,6 +927,10 @@ __global__ __launch_bounds__(256) void fit_dataflow_dir_kernel(const double *__r
         for (int s = 0; s < TPW; s++) { // 2. tile products
             if (tI[s] < 0) continue;
             const int I = tI[s], J = tJ[s];
+            // FACTORED: Sin_i = Tin_i * sum_j g_ij Tout_j and Sout_i = Tout_i * sum_j g_ij Tin_j -- the row's own factor is
+            // applied once by the reducer, so an element costs four fused multiply-adds (two per sum it feeds) instead of four
+            // multiplications and four additions: ri / ci collect g * Tout (rows of block I / columns = rows of block J),
+            // ro / co collect g * Tin.
             double ini[8], oui[8], inj[8], ouj[8], ri[8], ro[8], ci[8], co[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -941,10 +945,10 @@ __global__ __launch_bounds__(256) void fit_dataflow_dir_kernel(const double *__r
             for (int a = 0; a < 8; a++)
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    double e1 = (ini[a] * ouj[b]) * g[s][a][b], e2 = (inj[b] * oui[a]) * g[s][a][b];
-                    if (diag_tile && rq == cq && a == b) { e1 += e1; e2 += e2; } // the j == i term counts twice
-                    ri[a] += e1; co[b] += e1;
-                    ro[a] += e2; ci[b] += e2;
+                    double gv = g[s][a][b];
+                    if (diag_tile && rq == cq && a == b) gv += gv; // the j == i term counts twice
+                    ri[a] = fma(gv, ouj[b], ri[a]); ci[b] = fma(gv, oui[a], ci[b]);
+                    ro[a] = fma(gv, inj[b], ro[a]); co[b] = fma(gv, ini[a], co[b]);
                 }
             const double s_ri = transpose_reduce8<0>(ri, lane), s_ro = transpose_reduce8<0>(ro, lane);
             st_sc1(P + ((i64)I * Nt + J) * 64 + lane, s_ri);
@@ -997,6 +1001,8 @@ __global__ __launch_bounds__(256) void fit_dataflow_dir_kernel(const double *__r
                 if (row < N) {
                     const double di = deg_in[row], dout = deg_out[row];
                     const double tin = ld_sc1(Tin + row), tout = ld_sc1(Tout + row);
+                    Si *= tin; // the row's own factor (the tiles summed g * Tout / g * Tin)
+                    So *= tout;
                     double nin = tin, nout = tout;
                     if (di > 0) { nin = tin + (eps * tin) * (di / Si - 1.0); fr = fmax(fr, fabs(di - Si)); }
                     if (dout > 0) { nout = tout + (eps * tout) * (dout / So - 1.0); fr = fmax(fr, fabs(dout - So)); }
@@ -1122,9 +1128,10 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__r
                 double(*Cc)[FLOW_RLD] = rsh[wave][1];
 #pragma unroll 1
                 for (int pass = 0; pass < 2; pass++) { // one copy of the code: the two passes share their registers
-                    // pass 0: e1 = (Tin_i*Tout_j)*g -> rows: Sin partial, columns: Sout partial
-                    // pass 1: e2 = (Tin_j*Tout_i)*g -> rows: Sout partial, columns: Sin partial
-                    const double *trow = tsh[wave][pass], *tcol = tsh[wave][3 - pass]; // Tin_i, Tout_j / Tout_i, Tin_j
+                    // FACTORED (as fit_dataflow_dir_kernel): the row's own factor Tin_i / Tout_i is applied by the reducer.
+                    // pass 0: g * Tout -> rows: Sin partial of block I, columns: Sin partial of block J
+                    // pass 1: g * Tin  -> rows: Sout partial of block I, columns: Sout partial of block J
+                    const double *trow = tsh[wave][1 - pass], *tcol = tsh[wave][3 - pass]; // Tout_I, Tout_J / Tin_I, Tin_J
                     double ta[8], tb[8], pr[8], pc[8];
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -1137,10 +1144,10 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__r
                     for (int a = 0; a < 8; a++)
 #pragma unroll
                         for (int b = 0; b < 8; b++) {
-                            double e = (ta[a] * tb[b]) * g[a][b];
-                            if (diag_tile && rq == cq && a == b) e += e; // the j == i term counts twice
-                            pr[a] += e;
-                            pc[b] += e;
+                            double gv = g[a][b];
+                            if (diag_tile && rq == cq && a == b) gv += gv; // the j == i term counts twice
+                            pr[a] = fma(gv, tb[b], pr[a]);
+                            pc[b] = fma(gv, ta[a], pc[b]);
                         }
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -1156,11 +1163,11 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__r
                     }
                     __builtin_amdgcn_wave_barrier();
                     const double rsum = ((u[0] + u[4]) + (u[2] + u[6])) + ((u[1] + u[5]) + (u[3] + u[7]));
-                    // pass 0 rows -> Sin of block I (plane 0), pass 1 rows -> Sout of block I (plane 1)
+                    // pass 0 -> the Sin plane (0), pass 1 -> the Sout plane (1): rows for block I, columns for block J
                     st_sc1(Pk + (i64)pass * Pstride + ((i64)I * Nt + J) * 64 + lane, rsum);
-                    if (!diag_tile) { // pass 0 columns -> Sout of block J (plane 1), pass 1 columns -> Sin of block J (plane 0)
+                    if (!diag_tile) {
                         const double csum = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
-                        st_sc1(Pk + (i64)(1 - pass) * Pstride + ((i64)J * Nt + I) * 64 + lane, csum);
+                        st_sc1(Pk + (i64)pass * Pstride + ((i64)J * Nt + I) * 64 + lane, csum);
                     }
                 }
             }
@@ -1232,6 +1239,8 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__r
                 double Si = red[k & 1][i][0][0][r16], So = red[k & 1][i][1][0][r16];
 #pragma unroll
                 for (int u = 1; u < 16; u++) { Si += red[k & 1][i][0][u][r16]; So += red[k & 1][i][1][u][r16]; }
+                Si *= tin_cur[i]; // the row's own factor (the tiles summed g * Tout / g * Tin)
+                So *= tout_cur[i];
                 const i64 row = (i64)64 * b + rib;
                 double fr = 0.0, nin = 0.0, nout = 0.0;
                 if (row < N) {
