@@ -187,9 +187,8 @@ __global__ __launch_bounds__(256) void fit_persistent_kernel(const double *__res
             for (int a = 0; a < 8; a++)
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    const double p = (ti[a] * tj[b]) * g[s][a][b];
-                    pr[a] += p;
-                    pc[b] += p;
+                    pr[a] = fma(g[s][a][b], tj[b], pr[a]); // factored: the row's own T_i is applied by the reducer
+                    pc[b] = fma(g[s][a][b], ti[a], pc[b]);
                 }
             const double rsum = transpose_reduce8<0>(pr, lane); // row 8*rq + cq of the tile
             st_sc1(P + ((i64)I * Nt + J) * 64 + lane, rsum);
@@ -219,6 +218,7 @@ __global__ __launch_bounds__(256) void fit_persistent_kernel(const double *__res
                 const i64 row = (i64)64 * b + rib;
                 if (row < N) {
                     const double tcur = Ts[row], wi = w[row];
+                    S *= tcur; // S_i = T_i * sum_j g_ij T_j: the tiles summed g * T
                     st_sc1(Tbuf + (i64)(par ^ 1) * Tld + row, tcur + (eps * tcur) * (wi / S - 1.0));
                     fmine = fmax(fmine, fabs(wi - S));
                 }
@@ -362,9 +362,8 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
             for (int a = 0; a < 8; a++)
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    const double p = (ti[a] * tj[b]) * g[s][a][b];
-                    pr[a] += p;
-                    pc[b] += p;
+                    pr[a] = fma(g[s][a][b], tj[b], pr[a]); // factored: the row's own T_i is applied by the reducer
+                    pc[b] = fma(g[s][a][b], ti[a], pc[b]);
                 }
             const double rsum = transpose_reduce8<0>(pr, lane);
             st_sc1(P + ((i64)I * Nt + J) * 64 + lane, rsum);
@@ -411,6 +410,7 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
                 double fr = 0.0;
                 if (row < N) {
                     const double tcur = ld_sc1(Tk + row), wi = w[row];
+                    S *= tcur; // S_i = T_i * sum_j g_ij T_j: the tiles summed g * T
                     st_sc1(Tbuf + (i64)(par ^ 1) * Tld + row, tcur + (eps * tcur) * (wi / S - 1.0));
                     fr = fabs(wi - S);
                 }
@@ -598,9 +598,8 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
             for (int a = 0; a < 8; a++)
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    const double p = (ti[a] * tj[b]) * g[s][a][b];
-                    pr[a] += p;
-                    pc[b] += p;
+                    pr[a] = fma(g[s][a][b], tj[b], pr[a]); // factored: the row's own T_i is applied by the reducer
+                    pc[b] = fma(g[s][a][b], ti[a], pc[b]);
                 }
             // The transposing reductions of transpose_reduce8 (same pairs, same bits) through LDS: the partial of lane
             // (rq, cq) for row 8*rq + a goes to R[cq][8*rq + a], lane l then adds the eight partials of row l as
@@ -693,6 +692,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
                 const i64 row = (i64)64 * b + rib;
                 double fr = 0.0, tnew = 0.0;
                 if (row < N) {
+                    S *= tcur[i]; // S_i = T_i * sum_j g_ij T_j: the tiles summed g * T
                     tnew = tcur[i] + (eps * tcur[i]) * (wrow[i] / S - 1.0);
                     fr = fabs(wrow[i] - S);
                 }
@@ -794,9 +794,8 @@ __global__ __launch_bounds__(256) void fit_symtile_kernel(const double *__restri
     for (int a = 0; a < 8; a++)
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            const double p = (ti[a] * tj[b]) * g[a][b];
-            pr[a] += p;
-            pc[b] += p;
+            pr[a] = fma(g[a][b], tj[b], pr[a]); // factored: the row's own T_i is applied by the reducer
+            pc[b] = fma(g[a][b], ti[a], pc[b]);
         }
     const double rsum = transpose_reduce8<0>(pr, lane); // row 8*rq + cq of the tile
     P[(I * Nt + J) * 64 + lane] = rsum;
@@ -836,8 +835,8 @@ __global__ __launch_bounds__(256) void fit_symreduce_kernel(const double *__rest
         const i64 row = 64 * b + r;
         double f = 0.0;
         if (row < N) {
-            const double S = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
             const double ti = T[row], wi = w[row];
+            const double S = ti * (((red[0][r] + red[1][r]) + red[2][r]) + red[3][r]); // the tiles summed g * T
             Tout[row] = ti + (eps * ti) * (wi / S - 1.0);
             f = fabs(wi - S);
         }
