@@ -386,7 +386,10 @@ __global__ __launch_bounds__(256, 2) void pcent_f32_kernel(const float *__restri
                     for (int gg = 0; gg < 2; gg++)
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            v = fmax(v, rns[r0 + 8 * gg + 4 * lh + j] * e1 - 2.0 * (double)acc[a][b][4 * (2 * h + gg) + j]);
+                        {
+                            const float af = acc[a][b][4 * (2 * h + gg) + j]; // a non-finite sum (overflow) must not prune: it counts as +Inf
+                            v = fmax(v, (af - af == 0.f) ? rns[r0 + 8 * gg + 4 * lh + j] * e1 - 2.0 * (double)af : 1e300);
+                        }
                     v = fmax(v, __shfl_xor(v, 32));
                     if (lh == 0) G[(r0 >> 4) * ldm + col] = fmax(v + mn, 0.0);
                 }
@@ -483,7 +486,10 @@ __global__ __launch_bounds__(256, 2) void pcent_f32_rowres_kernel(const float *_
                             for (int gg = 0; gg < 2; gg++)
 #pragma unroll
                                 for (int j = 0; j < 4; j++)
-                                    v = fmax(v, rns[r0 + 8 * gg + 4 * lh + j] * e1 - 2.0 * (double)acc[a][b][4 * (2 * h + gg) + j]);
+                                {
+                            const float af = acc[a][b][4 * (2 * h + gg) + j]; // a non-finite sum (overflow) must not prune: it counts as +Inf
+                            v = fmax(v, (af - af == 0.f) ? rns[r0 + 8 * gg + 4 * lh + j] * e1 - 2.0 * (double)af : 1e300);
+                        }
                             v = fmax(v, __shfl_xor(v, 32));
                             if (lh == 0) G[(r0 >> 4) * ldm + col] = fmax(v + mn, 0.0);
                         }
@@ -738,7 +744,7 @@ void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows,
     ScopedKernelTimer t(c, "pcent");
     const i64 nTI = lds_rows / 128, I0 = nTI * part / nparts, I1 = nTI * (part + 1) / nparts;
     const i64 ntiles = (I1 - I0) * (ldm / 128);
-    const double e1 = 1.0 + 1.01 * (double)(dpad + 2) * 5.9604644775390625e-08; // 1 + e, e = 1.01 (K + 2) 2^-24
+    const double e1 = 1.0 + 1.01 * (double)(dpad + 3) * 5.9604644775390625e-08; // 1 + e, e = 1.01 (K + 3) 2^-24 (covers separately rounded products too)
     static const bool no_rowres = getenv("CGE_PCENT_NO_ROWRES") != nullptr; // A/B switch
     if (ntiles > 0 && dpad <= 128 && !no_rowres) { // the row tile of X stays in LDS: X is read once
         static bool attr = false;

@@ -219,10 +219,21 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
 /* ---- options / statistics --------------------------------------------------------------------- */
 /* "diameter": 0 = auto (exact landmark-pair pruning, brute-force MFMA kernel when pruning is weak),
  *             1 = always brute force, 2 = always pruned.  All three return the same exact value.
- * "diameter_f32": 1 (default) = the point-to-reference maxima that bound the landmark pairs of the pruned diameter are
- *             computed by fp32 MFMA (v_mfma_f32_32x32x2_f32) as rigorous UPPER bounds (fp64 norms, error margin
- *             (K + 2) 2^-24 on the fp32 dot products); the surviving pairs are evaluated in fp64 as always, so the diameter
- *             keeps its bits.  0 = those maxima by fp64 MFMA.
+ * "diameter_f32": how the point-to-reference maxima that bound the landmark pairs of the pruned diameter are computed.
+ *             2 (default) = on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) with every operand split into two bf16 terms,
+ *             1 = by fp32-input MFMA (v_mfma_f32_32x32x2_f32); both as rigorous UPPER bounds (fp64 norms, an error margin
+ *             of 1.05 (3 (K + 2) 2^-23 + 3.2 2^-16) resp. 1.01 (K + 3) 2^-24 on the dot products, a non-finite accumulator
+ *             counted as +Inf; values beyond 2^+-100 send the pass to fp64; K > 128 takes 1 for 2).  0 = in fp64.  The
+ *             surviving pairs are evaluated in fp64 as always, so the diameter keeps its bits in every mode.
+ * "landmark_edges": 1 = cge_score also builds the N x N landmark-pair matrix and its positive-entry count, i.e. all that
+ *             landmarks() returns (src/landmarks.jl:433-463); 0 (default) = on the first cge_landmarks_fetch /
+ *             cge_landmarks_info (an undirected score does not read it).  bench.py sets 1.
+ * "early_diameter", "side_samples": 1 = cge_score runs the diameter (from the clusters cut into chunks instead of the
+ *             landmarks: the search is exact for any partition) resp. the `land` clamp and the sample draws on a second host
+ *             thread with its own low-priority streams, beside runsplit (single rank only).  0 (default): in line.  Same
+ *             results; measured slower or equal on every workload.
+ * "runsplit_lanes": 2 = every batch of runsplit as two half-batches on two streams, half a chain out of phase; 1 (default).
+ *             Same results.
  * "fit_persistent": how the Chung-Lu fixed point (src/divergence.jl:150-168, :434-467) is launched.
  *             0 = auto: one persistent launch per alpha (the matrix register-resident, the workgroups exchanging
  *                 partial sums and iterates by polling the data itself) for score graphs of >= 128 vertices that fit
@@ -233,7 +244,8 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             differently between the launch-per-iteration and the persistent forms (last-bit differences of the
  *             score vector).
  * "speculation_pct": 1..100, or 0 (default) = by split rule (40 for rss / rss2 -- 25 when d > 128 --, 10 for size / diameter): share of the pops
- *             still missing that one round of runsplit's global phase may split ahead of the heap; tuning only -- the
+ *             still missing that one round of runsplit's global phase may split ahead of the heap; -1 = the groups to split
+ *             are chosen by rehearsing the pop sequence on the known values with guessed children; tuning only -- the
  *             replay makes the result independent of it.
  * "shard_runsplit": with collectives set (N > 1): 1 (default) = the forced per-community phase of runsplit and the big
  *             batches of its global phase are split over the ranks and gathered by one all-reduce each (hook op 2);

@@ -29,7 +29,8 @@ if ks:
     print("| kernel | calls | total ms | avg ms | % |")
     print("|---|---|---|---|---|")
     rows = list(csv.DictReader(open(ks)))
-    ALWAYS = ("edge_pass_kernel", "edge_row_reduce_kernel", "edge_scatter_kernel", "pcent", "pair_list_kernel", "rss2_", "fit_")
+    ALWAYS = ("edge_pass_kernel", "edge_row_reduce_kernel", "edge_scatter_kernel", "pcent", "pair_list_kernel", "rss2_", "fit_",
+              "wedge_", "bound_", "comm_", "group_eig", "group_cov", "argmax")
     for i, r in enumerate(rows):
         if i < 25 or any(a in r["Name"] for a in ALWAYS):  # the top 25 + the kernels bench.py prices against a roofline
             print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
@@ -54,7 +55,7 @@ for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         corr = per * 2 if ctr == "FETCH_SIZE" else per
         traffic.setdefault(k, {"launches": n})[ctr + "_bytes_per_launch"] = corr * 1e6
     for i, (k, (n, v)) in enumerate(sorted(agg.items(), key=lambda kv: -kv[1][1])):
-        if i >= 12 and not any(a in k for a in ("edge_pass", "edge_row", "pcent", "fit_")):
+        if i >= 12 and not any(a in k for a in ("edge_pass", "edge_row", "pcent", "fit_", "wedge_", "group_eig", "group_cov")):
             continue
         per = v * 1024 / n / 1e6
         corr = per * 2 if ctr == "FETCH_SIZE" else per
