@@ -1241,6 +1241,10 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;
     }
+    if (!strcmp(key, "cov_derive")) { // 1: the larger child's covariance = its parent's minus its sibling's (only the smaller child is summed); 0 (default): every one over its rows
+        c->opt_cov_derive = value != 0;
+        return CGE_OK;
+    }
     if (!strcmp(key, "runsplit_lanes")) { // 2: the batches of runsplit run as two half-batches on two streams, out of phase; 1 (default): one stream
         if (value < 1 || value > 2) return CGE_E_ARG;
         c->opt_lanes = (int)value;
@@ -1282,6 +1286,7 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "landmark_batches")) *value = c->stat_lm_batches;
     else if (!strcmp(key, "landmark_batch_rows")) *value = c->stat_lm_rows;
     else if (!strcmp(key, "landmark_splits")) *value = c->stat_lm_splits;
+    else if (!strcmp(key, "covariances_derived")) *value = c->stat_cov_derived; // sibling pairs derived from the parent's matrix
     else if (!strcmp(key, "edge_layout_build_us")) *value = c->stat_layout_build_us;
     else if (!strcmp(key, "collective_calls")) *value = c->stat_coll_calls;
     else if (!strcmp(key, "collective_bytes")) *value = c->stat_coll_bytes;

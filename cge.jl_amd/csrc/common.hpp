@@ -316,6 +316,7 @@ struct cge_ctx {
                                    // config 3 68.4 -> 63.8 ms per step)
     int opt_fit_test_timeout = 0; // testing: the persistent fit gives up at once, so the fallback path runs
     i64 stat_lm_batches = 0, stat_lm_rows = 0, stat_lm_splits = 0; // last runsplit: device batches, their rows, groups split
+    i64 stat_cov_derived = 0; // ... sibling pairs whose covariances were derived from the parent's
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
     // A hand-off of a persistent fit timed out (e.g. another process holds CUs): the rest of THIS sweep runs one launch per
@@ -372,6 +373,13 @@ struct cge_ctx {
     i64 lm_arena_used = 0;
     DevBuf<double> lm_means; // weighted means of groups, known from their parents' splits (d doubles each)
     i64 lm_means_used = 0;
+    // covariances of the groups that have been split (d*d doubles each, about the group's own mean): a child's covariance is
+    // its parent's minus its sibling's, so only the smaller child of a pair is summed over its rows (landmarks_host.cpp)
+    DevBuf<double> lm_covs;
+    i64 lm_covs_used = 0;
+    int opt_cov_derive = 0;  // 1: the larger child of a sibling pair by subtraction (measured: no gain, profiles/r03_cov_derive_ab.txt)
+    DevBuf<i32> ls_ct2, ls_cb2, ls_ce2, ls_tco2; // chunk tables of the tasks whose covariance is summed directly
+    DevBuf<i64> ls_pairs;                        // the sibling pairs to derive
     DevBuf<i64> ls_moff;
     PinBuf<i64> pin_moff;
     // small host <-> device tables of a landmark batch travel packed: one pinned staging area, one copy, one kernel that
@@ -529,6 +537,10 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
 #define CGE_PARTIAL_BLOCKS 64 // block partials of the JS / AUC reductions (summed in block order)
 #define CGE_PREFIX_STRIDE 8 // the sorted-order WSSE prefix is stored every 8th row of a chunk (CGE_CHUNK_ROWS % 8 == 0)
 void k_gather_means(cge_ctx *c, const double *arena, const i64 *off, i64 T, i64 d, double *mean);
+// sibling pairs q: covs[ts] holds the smaller child's covariance (about its own mean); covs[tl] becomes the larger child's,
+// parent - sibling re-centred (pairs: {ts, tl, parent cov offset, mean offsets of parent, ts, tl})
+void k_cov_derive(cge_ctx *c, const i64 *pairs, i64 n_pairs, const double *means_arena, const double *covs_arena, double *covs,
+                  const i32 *rows, const i32 *task_row_off, const double *vw, i64 d);
 void k_gather_rows(cge_ctx *c, const i32 *arena, const i32 *task_off, const i32 *task_row_off, const i32 *chunk_task,
                    const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, i32 *rows, i32 *row_task);
 void k_rss_child_keys(cge_ctx *c, const i32 *perm, const i32 *row_task, const i32 *task_row_off, const i32 *meta,

@@ -531,6 +531,51 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
 }
 
 // ------------------------------------------------------------------------------------------------
+// A child's covariance from its parent's.  With C_X(mu) = sum_{i in X} w_i (x_i - mu)(x_i - mu)^T and a parent P = S u L:
+//   C_L(mu_P) = C_P(mu_P) - C_S(mu_P),    C_X(mu_X) = C_X(mu_P) - W_X (mu_X - mu_P)(mu_X - mu_P)^T,  W_X = sum_{i in X} w_i,
+// so only the SMALLER child S is summed over its rows -- about its OWN mean, as ever (re-centring it from the parent's mean
+// would cancel catastrophically for a tight child far from that mean) -- and one workgroup per sibling pair forms the larger
+// child's matrix  C_L = C_P - (C_S + W_S dS dS^T) - W_L dL dL^T,  d = mu_child - mu_P.  It carries the rounding of one
+// subtraction of matrices of its own magnitude, the level of the SYRK's own rounding; it feeds the principal eigenvector
+// only.  (Measured: no gain -- the SYRK of a batch is bound per chunk, not per row; option cov_derive, off by default.)
+__global__ __launch_bounds__(256) void cov_derive_kernel(const i64 *__restrict__ pairs, const double *__restrict__ means,
+                                                         const double *__restrict__ covs_arena, double *__restrict__ covs,
+                                                         const i32 *__restrict__ rows, const i32 *__restrict__ task_row_off,
+                                                         const double *__restrict__ vw, i64 d) {
+    extern __shared__ __attribute__((aligned(16))) double sh[]; // ds[d], dl[d], red[8]
+    double *ds = sh, *dl = sh + d, *red = sh + 2 * d;
+    const i64 *pq = pairs + 6 * (i64)blockIdx.x;
+    const i64 ts = pq[0], tl = pq[1], pc = pq[2], mp = pq[3], ms = pq[4], ml = pq[5], dd = d * d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double ws = 0.0, wl = 0.0;
+    for (i64 r = task_row_off[ts] + tid; r < task_row_off[ts + 1]; r += 256) ws += vw[rows[r]];
+    for (i64 r = task_row_off[tl] + tid; r < task_row_off[tl + 1]; r += 256) wl += vw[rows[r]];
+    ws = wave_allsum(ws);
+    wl = wave_allsum(wl);
+    if (lane == 0) { red[wave] = ws; red[4 + wave] = wl; }
+    for (i64 k = tid; k < d; k += 256) {
+        ds[k] = means[ms + k] - means[mp + k];
+        dl[k] = means[ml + k] - means[mp + k];
+    }
+    __syncthreads();
+    ws = ((red[0] + red[1]) + red[2]) + red[3];
+    wl = ((red[4] + red[5]) + red[6]) + red[7];
+    const double *cp = covs_arena + pc;
+    const double *cs = covs + ts * dd;
+    double *cl = covs + tl * dd;
+    for (i64 e = tid; e < dd; e += 256) {
+        const i64 i = e / d, j = e - i * d;
+        cl[e] = (cp[e] - (cs[e] + ws * ds[i] * ds[j])) - wl * dl[i] * dl[j];
+    }
+}
+void k_cov_derive(cge_ctx *c, const i64 *pairs, i64 n_pairs, const double *means_arena, const double *covs_arena, double *covs,
+                  const i32 *rows, const i32 *task_row_off, const double *vw, i64 d) {
+    if (n_pairs <= 0) return;
+    hipLaunchKernelGGL(cov_derive_kernel, dim3((unsigned)n_pairs), dim3(256), (size_t)(2 * d + 8) * sizeof(double), c->stream, pairs,
+                       means_arena, covs_arena, covs, rows, task_row_off, vw, d);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-task, per-side WSSE column sums (src/landmarks.jl:50-67): for the rows of a task whose side[j] is
 // 1 or 2, out[task][side-1] = { sum w x^2 [d], sum w x [d], sum w }.  Used by the rss rule's median-cut
 // rounds (:184-185, :201-202) and for the children's total_rss (:269).  Rows with side 0 are skipped.

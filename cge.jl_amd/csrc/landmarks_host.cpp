@@ -20,6 +20,7 @@
 #include <deque>
 #include <memory>
 #include <thread>
+#include <unordered_map>
 
 #include "common.hpp"
 
@@ -50,6 +51,8 @@ struct Group {
     // split (the WSSE column sums of a child are sum w x and sum w): d doubles at this offset of the means arena
     // (c->lm_means), -1 = compute it on the device.  cmean_off: the two children's means, low then high.
     i64 mean_off = -1, cmean_off = -1;
+    Group *parent = nullptr; // (children of a cached split)
+    i64 cov_off = -1;        // this group's covariance in the covariance arena (c->lm_covs), once it has been a task
 };
 
 // The arenas belong to the ROOT context; a lane (shadow context, below) sees them through borrowed views.
@@ -59,6 +62,7 @@ inline void refresh_arena_views(cge_ctx *x) {
     if (x == c) return;
     x->lm_arena.borrow(c->lm_arena);
     x->lm_means.borrow(c->lm_means);
+    x->lm_covs.borrow(c->lm_covs);
 }
 // Growth copies the arena into a larger allocation: everything that may still read or write the old one has to be done.
 template <typename T>
@@ -82,6 +86,17 @@ i64 arena_alloc(cge_ctx *x, i64 cnt) {
     if ((i64)c->lm_arena.n < need || !c->lm_arena.p) arena_grow(c, c->lm_arena, c->lm_arena_used, need);
     const i64 at = c->lm_arena_used;
     c->lm_arena_used = need;
+    return at;
+}
+// reserve `cnt` doubles of the covariance arena; -1 when it would outgrow its budget (the caller then keeps the batch's
+// covariances in scratch and sums every one of them over its rows)
+i64 covs_alloc(cge_ctx *x, i64 cnt) {
+    cge_ctx *c = root_of(x);
+    const i64 need = c->lm_covs_used + cnt;
+    if (need > ((i64)6 << 30)) return -1; // 48 GB of doubles
+    if ((i64)c->lm_covs.n < need || !c->lm_covs.p) arena_grow(c, c->lm_covs, c->lm_covs_used, need);
+    const i64 at = c->lm_covs_used;
+    c->lm_covs_used = need;
     return at;
 }
 // reserve `cnt` doubles of the means arena (same growth rule as the member arena)
@@ -691,7 +706,8 @@ struct LaneRun {
     i64 T = 0;
     int method = 0;
     Batch B;
-    i64 base = 0, mbase = -1;
+    i64 rmbase = -1; // roots only: where this batch's own means go in the means arena
+    i64 base = 0, mbase = -1, cbase = -1; // children ranges, children means, this batch's covariances (arena offsets; cbase -1: scratch)
     CutResult cr;
     std::unique_ptr<WordGatherer> wg;
     size_t i_status = 0, i_meta = 0, i_vals = 0, i_nlow = 0;
@@ -930,24 +946,73 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
     root->stat_lm_batches++;
     root->stat_lm_rows += R;
     root->stat_lm_splits += T;
-    c->ls_mean.ensure((size_t)T * d); c->ls_sw.ensure(T); c->ls_cov.ensure((size_t)T * d * d);
+    c->ls_mean.ensure((size_t)T * d); c->ls_sw.ensure(T);
+    if (L.cbase < 0) c->ls_cov.ensure((size_t)T * d * d);
     c->ls_vec.ensure((size_t)T * d); c->ls_z.ensure(R);
     {
         PhaseAcc pa(root, "lm_pca_dev");
+        double *covp = L.cbase >= 0 ? c->lm_covs.p + L.cbase : c->ls_cov.p; // this batch's covariances: kept for the children
         {
             ScopedKernelTimer tm(c, "group_stats");
             if (have_means) // the offsets went up with the batch's tables
                 k_gather_means(c, c->lm_means.p, c->ls_moff.p, T, d, c->ls_mean.p);
-            else
+            else {
                 k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                              c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
-            k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
-                        c->ls_mean.p, c->ls_part.p, c->ls_cov.p);
+                if (L.cbase >= 0 && L.rmbase >= 0) // roots: their means join the arena, their children can then be derived
+                    HIP_CHECK(hipMemcpyAsync(c->lm_means.p + L.rmbase, c->ls_mean.p, sizeof(double) * T * d, hipMemcpyDeviceToDevice, st));
+            }
+            // sibling pairs whose parent's covariance is on file: the smaller one is summed, the larger one derived
+            std::vector<i64> pairs;
+            std::vector<char> skip(T, 0);
+            if (L.cbase >= 0 && have_means) {
+                std::unordered_map<const Group *, i64> first;
+                for (i64 t = 0; t < T; t++) {
+                    const Group *g = L.groups[t], *p = g->parent;
+                    if (!p || p->cov_off < 0 || p->mean_off < 0) continue;
+                    auto it = first.find(p);
+                    if (it == first.end()) { first[p] = t; continue; }
+                    const i64 u = it->second;
+                    const i64 ts = L.groups[u]->len <= g->len ? u : t, tl = ts == u ? t : u;
+                    pairs.insert(pairs.end(), {ts, tl, p->cov_off, p->mean_off, L.groups[ts]->mean_off, L.groups[tl]->mean_off});
+                    skip[tl] = 1;
+                }
+            }
+            if (pairs.empty())
+                k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
+                            c->ls_mean.p, c->ls_part.p, covp);
+            else {
+                std::vector<i32> ct2, cb2, ce2, tco2(T + 1, 0);
+                for (i64 t = 0; t < T; t++) {
+                    tco2[t] = (i32)ct2.size();
+                    if (skip[t]) continue;
+                    for (i32 ch = B.task_chunk_off[t]; ch < B.task_chunk_off[t + 1]; ch++) {
+                        ct2.push_back(B.chunk_task[ch]); cb2.push_back(B.chunk_beg[ch]); ce2.push_back(B.chunk_end[ch]);
+                    }
+                }
+                tco2[T] = (i32)ct2.size();
+                const i64 NC2 = (i64)ct2.size(), NP = (i64)pairs.size() / 6;
+                c->ls_ct2.ensure(NC2); c->ls_cb2.ensure(NC2); c->ls_ce2.ensure(NC2); c->ls_tco2.ensure(T + 1);
+                c->ls_pairs.ensure(6 * NP);
+                WordPacker pk(c);
+                pk.add(c->ls_ct2.p, ct2.data(), NC2); pk.add(c->ls_cb2.p, cb2.data(), NC2); pk.add(c->ls_ce2.p, ce2.data(), NC2);
+                pk.add(c->ls_tco2.p, tco2.data(), T + 1); pk.add(c->ls_pairs.p, pairs.data(), 6 * NP);
+                pk.flush();
+                k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct2.p, c->ls_cb2.p, c->ls_ce2.p, NC2, c->ls_tco2.p, T, d,
+                            c->ls_mean.p, c->ls_part.p, covp);
+                k_cov_derive(c, c->ls_pairs.p, NP, c->lm_means.p, c->lm_covs.p, covp, c->ls_rows.p, c->sp_tro.p, c->vw.p, d);
+                root->stat_cov_derived += NP;
+            }
+            if (L.cbase >= 0)
+                for (i64 t = 0; t < T; t++) {
+                    L.groups[t]->cov_off = L.cbase + t * d * d;
+                    if (!have_means && L.rmbase >= 0) L.groups[t]->mean_off = L.rmbase + t * d;
+                }
         }
         if (after_cov) HIP_CHECK(hipEventRecord(after_cov, st));
-        if (!k_group_eig(c, c->ls_cov.p, T, d, c->ls_vec.p)) { // d > 512: host solver on a worker pool
+        if (!k_group_eig(c, covp, T, d, c->ls_vec.p)) { // d > 512: host solver on a worker pool
             std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d);
-            HIP_CHECK(hipMemcpyAsync(cov.data(), c->ls_cov.p, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(cov.data(), covp, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             parallel_for(c, T, [&](i64 t) { host_eig_top(&cov[(size_t)t * d * d], d, &vec[(size_t)t * d]); });
             HIP_CHECK(hipMemcpyAsync(c->ls_vec.p, vec.data(), sizeof(double) * vec.size(), hipMemcpyHostToDevice, st));
@@ -1057,6 +1122,14 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
             for (i64 t = 0; t < L[q].T; t++) r += L[q].groups[t]->len;
             L[q].base = arena_alloc(c, r); // the children of task t: [base + task_row_off[t], + len)
             L[q].mbase = means_alloc(c, 2 * L[q].T * d);
+            // option cov_derive: the batch's covariances stay on file for the children (not with several ranks: every rank must
+            // take the same path to the same bits, and a parent's matrix lives only where it was computed)
+            if (c->opt_cov_derive && !c->has_coll && d <= 512) {
+                L[q].cbase = covs_alloc(c, L[q].T * d * d);
+                bool roots = false;
+                for (i64 t = 0; t < L[q].T && !roots; t++) roots = L[q].groups[t]->mean_off < 0;
+                if (L[q].cbase >= 0 && roots) L[q].rmbase = means_alloc(c, L[q].T * d);
+            }
         }
         lane_enqueue(L[0], two ? c->copy_ev : nullptr, nullptr);
         if (two) lane_enqueue(L[1], nullptr, c->copy_ev);
@@ -1201,12 +1274,14 @@ void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool, 
         g->clo->len = g->nlow;
         g->clo->value = g->vlow;
         g->clo->mean_off = g->cmean_off;
+        g->clo->parent = g;
         pool.emplace_back();
         g->chi = &pool.back();
         g->chi->off = g->coff + g->nlow;
         g->chi->len = g->len - g->nlow;
         g->chi->value = g->vhigh;
         g->chi->mean_off = g->cmean_off >= 0 ? g->cmean_off + c_d : -1;
+        g->chi->parent = g;
     }
 }
 
@@ -1369,7 +1444,8 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     const i64 total = cl_off[ncl];
     c->lm_arena_used = 0;
     c->lm_means_used = 0;
-    c->stat_lm_batches = c->stat_lm_rows = c->stat_lm_splits = 0;
+    c->lm_covs_used = 0;
+    c->stat_lm_batches = c->stat_lm_rows = c->stat_lm_splits = c->stat_cov_derived = 0;
     {
         c->pin_rows[0].ensure(total);
         i32 *stage = c->pin_rows[0].p;

@@ -132,8 +132,9 @@ def _run_config(ctx, name, check_host_flow=True):
     assert ctx.get_stat("diameter_on_side_context") == 0
     # The diameter's branch and bound is exact for any partition: on the side context (beside runsplit) it runs from the
     # clusters cut into chunks instead of the landmarks -- the same bits; so do two half-batches per round on two streams,
-    # the rehearsal rule for the speculative splits, and clamp + sample draws on the side thread.
-    for opts in ({"early_diameter": 1}, {"runsplit_lanes": 2}, {"speculation_pct": -1}, {"side_samples": 1}):
+    # the rehearsal rule for the speculative splits, clamp + sample draws on the side thread, and the larger child's covariance
+    # derived from the parent's instead of summed over its rows.
+    for opts in ({"early_diameter": 1}, {"runsplit_lanes": 2}, {"speculation_pct": -1}, {"side_samples": 1}, {"cov_derive": 1}):
         try:
             for k, v in opts.items():
                 ctx.set_option(k, v)
@@ -147,6 +148,7 @@ def _run_config(ctx, name, check_host_flow=True):
             ctx.set_option("runsplit_lanes", 1)
             ctx.set_option("speculation_pct", 0)
             ctx.set_option("side_samples", 0)
+            ctx.set_option("cov_derive", 0)
     if check_host_flow:
         # (2) the reference's call shape with the fixture's sample draws: the whole vector and every trace
         dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
