@@ -194,52 +194,72 @@ int cge_set_exchange_buffer(cge_ctx *c, void *dev_ptr, int64_t cap) {
 }
 
 // ---- resident inputs ------------------------------------------------------------------------------
+static void allreduce(cge_ctx *c, double *dev, i64 count, int op);
+static double allreduce_scalar_max(cge_ctx *c, double v);
+// N > 1 with option "shard_ingest": which rows of the caller's edge list / embedding this rank uploads
+static bool ingest_sharded(const cge_ctx *c) { return c->opt_shard_ingest && c->has_coll && !c->is_side && c->coll.world > 1; }
+
 int cge_set_graph(cge_ctx *c, const int64_t *src, const int64_t *dst, const double *w, int64_t m, int64_t n) {
     if (!c || !src || !dst || m <= 0 || n <= 0 || n >= (1LL << 31)) return CGE_E_ARG;
     CGE_TRY(c)
     HIP_CHECK(hipSetDevice(c->device));
-    c->src.alloc_exact(m);
-    c->dst.alloc_exact(m);
+    // N > 1, option "shard_ingest": this rank uploads and keeps rows [e0, e1) of the list only (the edge passes are sums over
+    // edges: every rank scatters what it holds and the all-reduce adds; the sampler's look-ups are exchanged, kernels_fit.hip).
+    // Not for graphs small enough for the sampler to enumerate their non-edges on the host (wgcl_host.cpp).
+    const bool shard = ingest_sharded(c) && (double)n * (double)(n - 1) > 33554432.0 && m >= c->coll.world;
+    const i64 e0 = shard ? m * c->coll.rank / c->coll.world : 0, e1 = shard ? m * (c->coll.rank + 1) / c->coll.world : m;
+    const i64 ml = e1 - e0;
+    c->src.alloc_exact(ml);
+    c->dst.alloc_exact(ml);
     // ids: validated and narrowed to 0-based int32 by the host workers on their way into the staging buffers
     std::atomic<i64> bad{-1};
     for (int col = 0; col < 2; col++) {
-        const int64_t *h = col ? dst : src;
-        staged_upload<i32>(c, col ? c->dst.p : c->src.p, (size_t)m, [&](i32 *o, size_t e0, size_t e1) {
-            for (size_t e = e0; e < e1; e++) {
+        const int64_t *h = (col ? dst : src) + e0;
+        staged_upload<i32>(c, col ? c->dst.p : c->src.p, (size_t)ml, [&](i32 *o, size_t a0, size_t a1) {
+            for (size_t e = a0; e < a1; e++) {
                 const int64_t v = h[e];
                 if (v < 1 || v > n) { i64 exp = -1; bad.compare_exchange_strong(exp, (i64)e); }
-                o[e - e0] = (i32)(v - 1);
+                o[e - a0] = (i32)(v - 1);
             }
         });
     }
-    if (bad.load() >= 0) {
-        c->src.release(); c->dst.release(); c->m = 0; // (the previous resident graph is gone: cge_hip.h says so)
+    // (sharded: every rank must take the same exit -- the verdicts are exchanged before anybody throws)
+    const bool any_bad = shard ? allreduce_scalar_max(c, bad.load() >= 0 ? 1.0 : 0.0) != 0.0 : bad.load() >= 0;
+    if (any_bad) {
+        c->src.release(); c->dst.release(); c->m = c->m_total = 0; // (the previous resident graph is gone: cge_hip.h says so)
         c->blocked_ready = false; c->be_nchunks = 0; c->lm_ready = false;
-        CGE_THROW(CGE_E_ARG, "edge %lld has a vertex id outside 1..%lld", (long long)bad.load() + 1, (long long)n);
+        if (bad.load() >= 0)
+            CGE_THROW(CGE_E_ARG, "edge %lld has a vertex id outside 1..%lld", (long long)(e0 + bad.load()) + 1, (long long)n);
+        CGE_THROW(CGE_E_ARG, "an edge held by another rank has a vertex id outside 1..%lld", (long long)n);
     }
     // weights: all ones (an unweighted list, src/auxilary.jl:105) => neither a device copy nor a host mirror is kept
     bool unit = true;
     if (w) {
         const int nt = std::max(1, c->n_threads);
         std::vector<char> nonunit(nt, 0);
-        const i64 per = (m + nt - 1) / nt;
+        const i64 per = (ml + nt - 1) / nt;
         const std::function<void(i64)> job = [&](i64 t) {
-            const i64 a = std::min<i64>(m, t * per), e = std::min<i64>(m, a + per);
+            const i64 a = std::min<i64>(ml, t * per), e = std::min<i64>(ml, a + per);
             char f = 0;
-            for (i64 k = a; k < e && !f; k++) f = w[k] != 1.0;
+            for (i64 k = a; k < e && !f; k++) f = w[e0 + k] != 1.0;
             nonunit[t] = f;
         };
         c->pool->run(nt, job);
         for (char f : nonunit) unit = unit && !f;
     }
+    if (shard) unit = allreduce_scalar_max(c, unit ? 0.0 : 1.0) == 0.0;
     c->unit_weights = unit;
     c->h_w.clear();
     c->w.release();
     if (!unit) {
-        c->h_w.assign(w, w + m); // mirror: weights of host-side sample draws
-        c->w.alloc_exact(m);
-        staged_upload<double>(c, c->w.p, (size_t)m, [&](double *o, size_t e0, size_t e1) { memcpy(o, w + e0, sizeof(double) * (e1 - e0)); });
+        c->h_w.assign(w + e0, w + e1); // mirror: weights of host-side sample draws
+        c->w.alloc_exact(ml);
+        staged_upload<double>(c, c->w.p, (size_t)ml, [&](double *o, size_t a0, size_t a1) { memcpy(o, w + e0 + a0, sizeof(double) * (a1 - a0)); });
     }
+    c->m_total = m;
+    c->e_first = e0;
+    c->edges_sharded = shard;
+    m = ml;
     c->m = m;
     if (c->n && c->n != n) { // another vertex set: nothing that was sized for the old one may survive (stale or short buffers)
         c->h_Xr.clear(); c->h_vw.clear(); c->h_comm.clear();
@@ -286,6 +306,32 @@ int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
     HIP_CHECK(hipSetDevice(c->device));
     if (c->n && c->n != n) CGE_THROW(CGE_E_ASSERT, "No. rows in embedding and no. vertices in a graph differ.");
     DevBuf<double> col;
+    if (ingest_sharded(c)) {
+        // N > 1, option "shard_ingest": every rank uploads n / world ROWS (a strided piece of each column of the caller's
+        // column-major matrix) over its own PCIe link, transposes them into its place of Xr, and the pieces are all-gathered
+        // device to device (xGMI) -- instead of world full uploads side by side.  Equal pieces of `per` rows (ncclAllGather):
+        // Xr carries up to world - 1 rows of padding behind row n.
+        const i64 W = c->coll.world, r = c->coll.rank, per = (n + W - 1) / W;
+        const i64 r0 = std::min<i64>(n, per * r), r1 = std::min<i64>(n, r0 + per), nl = r1 - r0;
+        c->Xr.alloc_exact((size_t)per * W * d);
+        if (nl < per) HIP_CHECK(hipMemsetAsync(c->Xr.p + (size_t)(per * r + nl) * d, 0, sizeof(double) * (size_t)(per - nl) * d, c->stream));
+        if (nl > 0) {
+            col.alloc_exact((size_t)nl * d);
+            staged_upload<double>(c, col.p, (size_t)nl * d, [&](double *o, size_t a0, size_t a1) {
+                for (size_t e = a0; e < a1;) { // element e of the (nl x d, column-major) slice: column e / nl, row r0 + e % nl
+                    const size_t k = e / (size_t)nl, i = e % (size_t)nl, run = std::min<size_t>(a1 - e, (size_t)nl - i);
+                    memcpy(o + (e - a0), X + k * (size_t)n + (size_t)r0 + i, sizeof(double) * run);
+                    e += run;
+                }
+            });
+            k_transpose_to_rowmajor(c, col.p, c->Xr.p + (size_t)per * r * d, nl, d);
+        }
+        cge_allgather_dev(c, c->Xr.p, per * d);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        col.release();
+        embedding_resident(c, n, d);
+        return CGE_OK;
+    }
     col.alloc_exact((size_t)n * d);
     staged_upload<double>(c, col.p, (size_t)n * d, [&](double *o, size_t e0, size_t e1) { memcpy(o, X + e0, sizeof(double) * (e1 - e0)); });
     c->Xr.alloc_exact((size_t)n * d);
@@ -435,7 +481,8 @@ static void scatter_wedges(cge_ctx *c, int directed) {
     c->wedges.ensure((size_t)N * N);
     DevBuf<i64> &cnt = c->wed_cnt;
     cnt.ensure(1);
-    const int rank = c->has_coll ? c->coll.rank : 0, world = c->has_coll ? c->coll.world : 1;
+    // this rank's share of the edges: of a replicated list its slice of the chunks; of a sharded list all that it holds
+    const int rank = (c->has_coll && !c->edges_sharded) ? c->coll.rank : 0, world = (c->has_coll && !c->edges_sharded) ? c->coll.world : 1;
     // the tiled two-pass form on the blocked copy of the edge list (kernels_scatter.hip): the tiles are written whole, the
     // positive entries counted on the way (one rank) -- else the gather + atomics kernel into a zeroed matrix
     bool tiled = (c->blocked_ready || (k_blocked_edges_possible(c) && k_build_blocked_edges(c))) &&
@@ -443,11 +490,7 @@ static void scatter_wedges(cge_ctx *c, int directed) {
                                          c->wedges.p, cnt.p);
     if (!tiled) {
         HIP_CHECK(hipMemsetAsync(c->wedges.p, 0, sizeof(double) * N * N, st));
-        i64 e0 = 0, e1 = c->m;
-        if (c->has_coll) { // edge shard of this rank
-            e0 = c->m * c->coll.rank / c->coll.world;
-            e1 = c->m * (c->coll.rank + 1) / c->coll.world;
-        }
+        const i64 e0 = c->m * rank / world, e1 = c->m * (rank + 1) / world;
         k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, c->v2l.p, c->comm.p, N,
                        c->n_comm_max, directed, c->wedges.p, nullptr);
     }
@@ -462,7 +505,7 @@ static void scatter_wedges(cge_ctx *c, int directed) {
 // (kernels_scatter.hip) where it applies, else the gather + atomics kernel; this rank's share, then the all-reduce
 static void scatter_vectC_resident(cge_ctx *c, i64 C, int directed, double *vectC) {
     const i64 vlen = directed ? C * C : packed_len(C);
-    const int rank = c->has_coll ? c->coll.rank : 0, world = c->has_coll ? c->coll.world : 1;
+    const int rank = (c->has_coll && !c->edges_sharded) ? c->coll.rank : 0, world = (c->has_coll && !c->edges_sharded) ? c->coll.world : 1;
     bool done = false;
     if (k_edge_scatter_blocked_applies(c, C) && (c->blocked_ready || k_build_blocked_edges(c))) {
         k_edge_scatter_blocked(c, c->be_nchunks * rank / world, c->be_nchunks * (rank + 1) / world, C, directed, vectC);
@@ -642,6 +685,7 @@ int cge_draw_samples(cge_ctx *c, int64_t seed, int64_t stream_id, int64_t S, int
     CGE_TRY(c)
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->src.p) CGE_THROW(CGE_E_ARG, "draw_samples: no resident graph");
+    if (c->edges_sharded) CGE_THROW(CGE_E_ARG, "draw_samples: the resident edge list is sharded over the ranks (option shard_ingest); cge_score draws on the device");
     host_draw_samples(c, seed, stream_id, S, directed, pos_idx, neg_i, neg_j);
     CGE_CATCH(c)
 }
@@ -775,6 +819,9 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
     HIP_CHECK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int directed = a->directed;
+    // the score graph of this entry point (and the init_* graph it may upload) is held whole on every rank
+    struct KeepOption { int &ref; int val; ~KeepOption() { ref = val; } } keep_ingest{c->opt_shard_ingest, c->opt_shard_ingest};
+    c->opt_shard_ingest = 0;
     if (!a->edges_src || !a->edges_dst || a->m <= 0) CGE_THROW(CGE_E_ARG, "wGCL: empty edge list");
     i64 N = 0;
     for (i64 e = 0; e < a->m; e++) N = std::max(N, std::max(a->edges_src[e], a->edges_dst[e])); // maximum(edges) :41
@@ -869,6 +916,7 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
     }
     SampleSet smp;
     if (a->pos_idx && a->neg_i && a->neg_j && a->n_sample_sets > 0) {
+        if (c->edges_sharded) CGE_THROW(CGE_E_ARG, "wGCL: caller-drawn samples index the whole edge list, the resident one is sharded (option shard_ingest)");
         smp.S = a->auc_samples;
         smp.n_sets = a->n_sample_sets;
         const i64 tot = smp.S * smp.n_sets;
@@ -1092,6 +1140,8 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         c->stat_last_hi = hi;
         c->phases.ms["diameter"] = now_ms() - t0; // what the main thread still waited for
     } else {
+        if (c->edges_sharded)
+            CGE_THROW(CGE_E_ARG, "score: exact mode reads the whole edge list on every rank; the resident one is sharded (option shard_ingest)");
         const i64 N = c->n, C = c->n_comm_max;
         zeros.ensure(N);
         HIP_CHECK(hipMemsetAsync(zeros.p, 0, sizeof(double) * N, st)); // distances = zeros (CGE_CLI.jl:4)
@@ -1159,6 +1209,7 @@ int cge_edge_scatter(cge_ctx *c, const int64_t *v_to_l, int64_t N, int64_t C, in
     CGE_TRY(c)
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->src.p || !c->comm.p) CGE_THROW(CGE_E_ARG, "edge_scatter: graph and vertex data must be resident");
+    if (c->edges_sharded) CGE_THROW(CGE_E_ARG, "edge_scatter: the resident edge list is sharded over the ranks (option shard_ingest)");
     if (e1 > c->m) CGE_THROW(CGE_E_ARG, "edge_scatter: edge range beyond m");
     hipStream_t st = c->stream;
     DevBuf<i32> dv;
@@ -1192,6 +1243,7 @@ int cge_louvain(cge_ctx *c, int64_t *comm_out, int64_t *n_comm, double *modulari
     CGE_TRY(c)
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->src.p || c->m <= 0 || c->n <= 0) CGE_THROW(CGE_E_ARG, "louvain: no resident graph (cge_set_graph)");
+    if (c->edges_sharded) CGE_THROW(CGE_E_ARG, "louvain: the resident edge list is sharded over the ranks (option shard_ingest)");
     k_louvain_level1(c, comm_out, n_comm, modularity, rounds);
     CGE_CATCH(c)
 }
@@ -1241,6 +1293,11 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;
     }
+    if (!strcmp(key, "shard_ingest")) { // N > 1: 1 = cge_set_graph keeps this rank's slice of the edge list only and cge_set_embedding uploads a
+        // slice of rows per rank and all-gathers them over xGMI (set the collectives first); 0 (default): every rank uploads and keeps everything
+        c->opt_shard_ingest = value != 0;
+        return CGE_OK;
+    }
     if (!strcmp(key, "cov_derive")) { // 1: the larger child's covariance = its parent's minus its sibling's (only the smaller child is summed); 0 (default): every one over its rows
         c->opt_cov_derive = value != 0;
         return CGE_OK;
@@ -1288,6 +1345,10 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "landmark_splits")) *value = c->stat_lm_splits;
     else if (!strcmp(key, "covariances_derived")) *value = c->stat_cov_derived; // sibling pairs derived from the parent's matrix
     else if (!strcmp(key, "edge_layout_build_us")) *value = c->stat_layout_build_us;
+    else if (!strcmp(key, "edge_chunks")) *value = c->be_nchunks;
+    else if (!strcmp(key, "edges_resident")) *value = c->m;
+    else if (!strcmp(key, "edges_total")) *value = c->m_total;
+    else if (!strcmp(key, "embedding_words_resident")) *value = (i64)c->Xr.n;
     else if (!strcmp(key, "collective_calls")) *value = c->stat_coll_calls;
     else if (!strcmp(key, "collective_bytes")) *value = c->stat_coll_bytes;
     else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`
@@ -1425,6 +1486,7 @@ cge_ctx *cge_shadow_context(cge_ctx *c, cge_ctx **slot, bool low_priority) {
     cge_ctx *sd = *slot;
     // views are re-taken at every use: an upload may have replaced the buffers since the last one
     sd->n = c->n; sd->m = c->m; sd->d = c->d; sd->ldn = c->ldn; sd->dpad = c->dpad;
+    sd->m_total = c->m_total; sd->e_first = c->e_first; sd->edges_sharded = c->edges_sharded;
     sd->unit_weights = c->unit_weights; sd->n_comm_max = c->n_comm_max;
     sd->Xr.borrow(c->Xr); sd->gmean.borrow(c->gmean); sd->vw.borrow(c->vw); sd->comm.borrow(c->comm);
     sd->src.borrow(c->src); sd->dst.borrow(c->dst); sd->w.borrow(c->w);
@@ -1432,6 +1494,20 @@ cge_ctx *cge_shadow_context(cge_ctx *c, cge_ctx **slot, bool low_priority) {
     sd->profiling = c->profiling; sd->profile_only = c->profile_only;
     sd->h_Xr.clear(); // (a stale host mirror must not answer for a new embedding; it is fetched on demand)
     return sd;
+}
+
+// all-gather of 8-byte words in place (the sharded ingest of the embedding): ncclAllGather on the ctx stream with the
+// in-library communicator; through the hook (tests), or with a librccl that lacks the symbol, a zero-filled all-reduce of
+// the words as integers -- exact on the bit patterns (a sum of doubles would turn -0.0 into +0.0)
+void cge_allgather_dev(cge_ctx *c, double *buf, i64 wpr) {
+    if (!c->has_coll || wpr <= 0) return;
+    if (c->rccl_comm && cge_rccl_allgather(c, buf, wpr)) return;
+    const i64 W = c->coll.world, r = c->coll.rank, total = wpr * W;
+    if (r > 0) HIP_CHECK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)(wpr * r), c->stream));
+    if (r + 1 < W) HIP_CHECK(hipMemsetAsync(buf + wpr * (r + 1), 0, sizeof(double) * (size_t)(wpr * (W - 1 - r)), c->stream));
+    const i64 piece = c->rccl_comm ? total : (i64)c->xcap;
+    if (piece <= 0) CGE_THROW(CGE_E_COLLECTIVE, "all-gather: no exchange buffer set");
+    for (i64 off = 0; off < total; off += piece) allreduce(c, buf + off, std::min(piece, total - off), 2);
 }
 
 // for the other translation units (diameter_host.cpp)

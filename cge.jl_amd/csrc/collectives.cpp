@@ -18,6 +18,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr; // optional (the sharded ingest of the embedding)
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
@@ -42,6 +43,7 @@ RcclApi &rccl() {
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
     api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
     if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) {
@@ -67,6 +69,21 @@ void cge_rccl_allreduce(cge_ctx *c, void *dev, i64 count, int op) {
     if (r != ncclSuccess) CGE_THROW(CGE_E_COLLECTIVE, "ncclAllReduce failed: %s", rccl_str(r));
     c->stat_coll_calls++;
     c->stat_coll_bytes += 8 * count;
+}
+
+// all-gather of 8-byte words in place on the ctx stream: rank r contributes buf[r * words_per_rank, (r + 1) * words_per_rank)
+// (the in-place form of ncclAllGather: sendbuff = recvbuff + rank * sendcount).  false when librccl has no ncclAllGather
+// (the caller then falls back to a zero-filled integer all-reduce).
+bool cge_rccl_allgather(cge_ctx *c, void *dev, i64 words_per_rank) {
+    RcclApi &a = rccl();
+    if (!a.lib || !c->rccl_comm) CGE_THROW(CGE_E_COLLECTIVE, "no RCCL communicator on this context");
+    if (!a.AllGather) return false;
+    const char *mine = (const char *)dev + (size_t)8 * words_per_rank * c->coll.rank;
+    const ncclResult_t r = a.AllGather(mine, dev, (size_t)words_per_rank, ncclInt64, (ncclComm_t)c->rccl_comm, c->stream);
+    if (r != ncclSuccess) CGE_THROW(CGE_E_COLLECTIVE, "ncclAllGather failed: %s", rccl_str(r));
+    c->stat_coll_calls++;
+    c->stat_coll_bytes += 8 * words_per_rank * c->coll.world;
+    return true;
 }
 
 extern "C" {

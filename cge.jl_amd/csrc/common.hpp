@@ -236,7 +236,13 @@ struct cge_ctx {
     size_t xcap = 0;
 
     // ---- resident original graph --------------------------------------------------------
-    i64 n = 0, m = 0, d = 0;
+    i64 n = 0, m = 0, d = 0;   // m = edges RESIDENT on this rank (all of them unless the list is sharded, below)
+    // N > 1 with option "shard_ingest": a rank uploads and keeps rows [e_first, e_first + m) of the caller's edge list only
+    // (m_total = the caller's count); the embedding is uploaded as a slice of rows per rank and all-gathered over xGMI
+    i64 m_total = 0, e_first = 0;
+    bool edges_sharded = false;
+    int opt_shard_ingest = 0;
+    DevBuf<double> samp_xchg;  // sampled edges of a sharded list on their way through the all-reduce
     bool unit_weights = false;
     bool blocked_ready = false; // blocked copy of the edge list (edge pass) matches src/dst
     DevBuf<i32> src, dst;     // 0-based
@@ -588,6 +594,9 @@ void k_diameter_layout(cge_ctx *c, const i32 *mem_off, const i32 *mem, const i32
                        i64 n_sub);
 void cge_allreduce_dev(cge_ctx *c, double *dev, i64 count, int op /*0 sum, 1 max*/); // no-op without collectives
 void cge_rccl_allreduce(cge_ctx *c, void *dev, i64 count, int op); // collectives.cpp: in place, on the ctx stream
+bool cge_rccl_allgather(cge_ctx *c, void *dev, i64 words_per_rank); // in place (rank r's piece at r * words_per_rank); false: no such symbol
+// all-gather of 8-byte words in place: `buf` holds world pieces of `words_per_rank`, this rank's piece is filled in
+void cge_allgather_dev(cge_ctx *c, double *buf, i64 words_per_rank);
 // can the exchange buffer hold `need` doubles?  With the in-library communicator a library-owned buffer grows on demand
 // (contents are not preserved); a caller-provided one (cge_set_exchange_buffer, the hook path) is what it is.
 bool cge_exchange_fits(cge_ctx *c, size_t need);

@@ -851,10 +851,12 @@ __global__ void check_neg_kernel(const i32 *__restrict__ todo, i64 cnt, const i3
     }
 }
 void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i32 *d_pos, i32 *d_ni, i32 *d_nj) {
-    const i64 n = c->n, m = c->m;
+    const i64 n = c->n, m = c->m; // m: the edges resident on this rank
     hipStream_t st = c->stream;
     const unsigned nb = (unsigned)((S + 255) / 256);
-    hipLaunchKernelGGL(draw_pos_kernel, dim3(nb), dim3(256), 0, st, (uint64_t)seed, (uint64_t)stream_id, S, m, d_pos);
+    // positive draws are rows of the caller's WHOLE list (a sharded list: the owner of a row answers for it, k_prep_samples)
+    hipLaunchKernelGGL(draw_pos_kernel, dim3(nb), dim3(256), 0, st, (uint64_t)seed, (uint64_t)stream_id, S,
+                       c->edges_sharded ? c->m_total : m, d_pos);
     DevBuf<unsigned> &attempt = c->samp_attempt; // grow-only scratch of the context
     DevBuf<i32> &todo_a = c->samp_todo_a, &todo_b = c->samp_todo_b, &hit = c->samp_hit;
     DevBuf<unsigned long long> &table = c->samp_table, &count = c->samp_count;
@@ -875,6 +877,9 @@ void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed
         hipLaunchKernelGGL(draw_neg_kernel, dim3(g), dim3(256), 0, st, (uint64_t)seed, (uint64_t)stream_id, n, directed, todo, cnt,
                            attempt.p, d_ni, d_nj, table.p, tsize - 1);
         k_mark_edge_hits(c, c->src.p, c->dst.p, m, directed, reinterpret_cast<const uint64_t *>(table.p), tsize, hit.p);
+        // a sharded list: every rank has marked the candidates that are among ITS edges; the flags (0 / 1 in 32-bit words, two
+        // to an 8-byte word, at most `world` per word half: no carry) are added over the ranks
+        if (c->edges_sharded) cge_allreduce_dev(c, reinterpret_cast<double *>(hit.p), tsize / 2, 2);
         hipLaunchKernelGGL(check_neg_kernel, dim3(g), dim3(256), 0, st, todo, cnt, d_ni, d_nj, table.p, tsize - 1, hit.p, attempt.p,
                            next, count.p);
         unsigned long long hc = 0;
@@ -905,8 +910,46 @@ __global__ void prep_samples_kernel(const i32 *__restrict__ pos, const i32 *__re
     ni[k] = u;
     nj[k] = v;
 }
+// the same over a SHARDED edge list: rows held by this rank are looked up (ids + 1, weight), the others contribute zeros;
+// after the all-reduce(sum) of the 3 S doubles (exact: one non-zero term each) the second kernel orders and stores them
+__global__ void prep_lookup_sharded_kernel(const i32 *__restrict__ pos, const i32 *__restrict__ pos_pairs, const i32 *__restrict__ e_src,
+                                           const i32 *__restrict__ e_dst, const double *__restrict__ e_w, i64 e_first, i64 m_local, i64 S,
+                                           double *__restrict__ x) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S) return;
+    const i64 rp = (i64)pos_pairs[k] - e_first, rw = (i64)pos[k] - e_first;
+    const bool mine = rp >= 0 && rp < m_local, minew = rw >= 0 && rw < m_local;
+    x[k] = mine ? (double)(e_src[rp] + 1) : 0.0;
+    x[S + k] = mine ? (double)(e_dst[rp] + 1) : 0.0;
+    x[2 * S + k] = minew ? (e_w ? e_w[rw] : 1.0) : 0.0;
+}
+__global__ void prep_store_sharded_kernel(const double *__restrict__ x, const i32 *__restrict__ ni_in, const i32 *__restrict__ nj_in,
+                                          i64 S, int directed, i32 *__restrict__ pi, i32 *__restrict__ pj, i32 *__restrict__ ni,
+                                          i32 *__restrict__ nj, double *__restrict__ wts) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S) return;
+    i32 a = (i32)x[k] - 1, b = (i32)x[S + k] - 1;
+    if (!directed && a > b) { const i32 t = a; a = b; b = t; }
+    pi[k] = a;
+    pj[k] = b;
+    wts[k] = x[2 * S + k];
+    i32 u = ni_in[k], v = nj_in[k];
+    if (!directed && u > v) { const i32 t = u; u = v; v = t; }
+    ni[k] = u;
+    nj[k] = v;
+}
 void k_prep_samples(cge_ctx *c, const i32 *pos, const i32 *pos_pairs, const i32 *ni_in, const i32 *nj_in, const i32 *e_src,
                     const i32 *e_dst, const double *e_w, i64 S, int directed, i32 *pi, i32 *pj, i32 *ni, i32 *nj, double *wts) {
+    if (c->edges_sharded && e_src == c->src.p) {
+        const unsigned nb = (unsigned)((S + 255) / 256);
+        c->samp_xchg.ensure((size_t)3 * S);
+        hipLaunchKernelGGL(prep_lookup_sharded_kernel, dim3(nb), dim3(256), 0, c->stream, pos, pos_pairs, e_src, e_dst,
+                           c->unit_weights ? nullptr : e_w, c->e_first, c->m, S, c->samp_xchg.p);
+        cge_allreduce_dev(c, c->samp_xchg.p, 3 * S, 0);
+        hipLaunchKernelGGL(prep_store_sharded_kernel, dim3(nb), dim3(256), 0, c->stream, c->samp_xchg.p, ni_in, nj_in, S, directed, pi,
+                           pj, ni, nj, wts);
+        return;
+    }
     hipLaunchKernelGGL(prep_samples_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream, pos, pos_pairs, ni_in, nj_in,
                        e_src, e_dst, e_w, S, directed, pi, pj, ni, nj, wts);
 }

@@ -93,10 +93,14 @@ bool k_build_blocked_edges(cge_ctx *c) {
     for (i64 t = T - 1; t >= 0; t--)
         if (tf[t] < 0) tf[t] = tf[t + 1]; // tiles without edges
     std::vector<i32> ch;
+    static const i64 want = getenv("CGE_EB_CHUNKS") ? atoll(getenv("CGE_EB_CHUNKS")) : 0; // A/B: aim at this many chunks
+    const i64 ideal = want > 0 ? std::max<i64>(1, m / want) : 0;
     for (i64 t = 0; t < T; t++) {
         const i64 len = tf[t + 1] - tf[t];
         if (len <= 0) continue;
-        const i64 parts = (len + EB_CHUNK - 1) / EB_CHUNK, per = (len + parts - 1) / parts; // equal pieces
+        i64 parts = (len + EB_CHUNK - 1) / EB_CHUNK;
+        if (ideal > 0) parts = std::max(parts, (len + ideal / 2) / ideal);
+        const i64 per = (len + parts - 1) / parts; // equal pieces
         for (i64 s = 0; s < len; s += per) {
             ch.push_back((i32)(t / nbv)); ch.push_back((i32)(t % nbv));
             ch.push_back((i32)(tf[t] + s)); ch.push_back((i32)std::min(per, len - s));

@@ -12,6 +12,11 @@ What is sharded:
     evaluation (one all-reduce(max) of a scalar);
 and what is replicated: the heap of runsplit and its small batches, and the alpha sweep (sequentially
 dependent iterations of a register-resident persistent fit that already uses every CU).  No other collective is issued.
+
+Option "shard_ingest" (set the collectives first, then upload): `set_graph` keeps only the rows edge_shard(m, rank, world)
+of the edge list on a rank (the scatter passes then run over what a rank holds; the sampler's edge look-ups and non-edge
+checks are all-reduced), and `set_embedding` uploads n / world rows per rank and all-gathers them over xGMI
+(ncclAllGather in the library; through this hook: op 2 on zero-filled pieces).
 """
 from __future__ import annotations
 

@@ -34,7 +34,7 @@ def _graph():
     return synth.abcd_like(30000, 300000, 30, 16, seed=21)
 
 
-def _rank(rank, world, port, q, mode, method="rss", shard_samples=1, fit_persistent=1, timeout_rank=-1):
+def _rank(rank, world, port, q, mode, method="rss", shard_samples=1, fit_persistent=1, timeout_rank=-1, shard_ingest=0):
     try:
         import torch
         import torch.distributed as dist
@@ -48,8 +48,15 @@ def _rank(rank, world, port, q, mode, method="rss", shard_samples=1, fit_persist
 
         g = _graph()
         ctx = api.Context(0)
-        ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
-        coll = TorchCollectives(ctx, 600 * 600 * 2 + 1024, torch.device("cuda", 0))
+        if shard_ingest:  # collectives first: the uploads themselves are split over the ranks
+            coll = TorchCollectives(ctx, 600 * 600 * 2 + 1024, torch.device("cuda", 0))
+            ctx.set_option("shard_ingest", 1)
+            if shard_ingest == 2:  # a weighted list (dyadic weights: the sums stay exact whatever their grouping)
+                g["eweights"] = 1.0 + (np.arange(g["m"]) % 4) * 0.25
+            ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+        else:
+            ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+            coll = TorchCollectives(ctx, 600 * 600 * 2 + 1024, torch.device("cuda", 0))
         ctx.set_option("fit_persistent", fit_persistent)
         if rank == timeout_rank:  # this rank's persistent fits give up at once; the other rank's succeed
             ctx.set_option("fit_persistent_test_timeout", 1)
@@ -60,7 +67,8 @@ def _rank(rank, world, port, q, mode, method="rss", shard_samples=1, fit_persist
         batches = ctx.get_stat("landmark_batches")
         n0 = coll.n_calls
         v2l = ctx.landmarks_fetch()[6]
-        q.put((rank, res.tolist(), hi, (n0, coll.n_calls - n0, batches, ctx.get_stat("fit_persistent_alphas")),
+        q.put((rank, res.tolist(), hi, (n0, coll.n_calls - n0, batches, ctx.get_stat("fit_persistent_alphas"),
+                                        ctx.get_stat("edges_resident"), ctx.get_stat("edges_total")),
                int(zlib.crc32(v2l.tobytes()))))
         ctx.close()
     except Exception as e:  # surface the failure in the parent
@@ -104,7 +112,7 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx, mode):
         assert np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
         # vect_C (sum), the centroid bounds (max), the diameter (max); + the forced phase's groups (gather) + one gather per
         # split batch of the global phase; the fetch adds the landmark-pair matrix (sum)
-        during, fetch, batches, _ = n_calls
+        during, fetch, batches = n_calls[:3]
         assert fetch == 1 and during >= 3 + (mode > 0)
         if mode == 2:
             assert during > 4  # batches of the global phase went through the exchange
@@ -173,3 +181,44 @@ def test_two_ranks_fit_abandoned_on_one_rank_only(ctx):
     assert results[0][1] == results[1][1]
     assert results[0][3][0] == results[1][3][0]  # the same number of exchanges on both ranks
     assert results[0][3][3] == 0 and results[1][3][3] == 0  # no alpha was taken from a persistent fit: both ranks fell back together
+
+
+@pytest.mark.parametrize("weighted", [0, 1])
+def test_two_ranks_sharded_ingest(ctx, weighted):
+    """Option shard_ingest (north star: "edge list and embedding rows shard across the GPUs"): every rank uploads HALF of the
+    edge list and keeps only that (its scatter passes run over what it holds; the sampler's edge look-ups and non-edge checks
+    are exchanged), and uploads half of the embedding's rows, which are all-gathered device to device.  The score, the
+    diameter and the landmark ids are those of one rank holding everything."""
+    import torch.multiprocessing as mp
+
+    g = _graph()
+    if weighted:
+        g["eweights"] = 1.0 + (np.arange(g["m"]) % 4) * 0.25
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    try:
+        ctx.set_option("fit_persistent", 1)
+        ref = ctx.score(g["clusters"], 600, 2, "rss", seed=5, auc_samples=4000)
+        hi_ref = ctx.last_diameter()[0]
+        lm_ref = ctx.landmarks_fetch()
+        crc_ref = int(zlib.crc32(lm_ref[6].tobytes()))
+    finally:
+        ctx.set_option("fit_persistent", 0)
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank, args=(r, 2, port, q, 1, "rss", 1, 1, -1, 1 + weighted)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+    held = 0
+    for rank, res, hi, n_calls, crc in results:
+        assert hi is not None, res  # a traceback otherwise
+        assert crc == crc_ref and hi == hi_ref
+        assert res[0] == ref[0] and res[4] == ref[4]
+        assert np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
+        assert n_calls[5] == g["m"] and n_calls[4] in (g["m"] // 2, g["m"] - g["m"] // 2)
+        held += n_calls[4]
+    assert held == g["m"]  # every edge is resident on exactly one rank
+    assert results[0][1] == results[1][1]
