@@ -234,6 +234,15 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             results; measured slower or equal on every workload.
  * "runsplit_lanes": 2 = every batch of runsplit as two half-batches on two streams, half a chain out of phase; 1 (default).
  *             Same results.
+ * "cov_derive": 1 = runsplit takes the covariance of the larger child of a split as parent - sibling (the smaller child is
+ *             still summed over its rows); 0 (default).  Same landmark ids; measured no faster.
+ * "shard_ingest": N > 1, set AFTER the collectives (cge_comm_init_rccl / cge_set_collectives) and BEFORE the uploads:
+ *             1 = cge_set_graph keeps only this rank's slice [m r / W, m (r+1) / W) of the edge list resident (the scatter
+ *             passes run over what a rank holds, the sampler's look-ups are exchanged) and cge_set_embedding uploads n / W
+ *             rows per rank and all-gathers them device to device; every rank still passes the WHOLE arrays.  Entry points
+ *             that need the whole list on one rank (exact-mode cge_score, cge_louvain, cge_edge_scatter, cge_draw_samples,
+ *             caller-drawn samples of cge_wgcl) return CGE_E_ARG on a sharded list.  0 (default): every rank uploads and
+ *             keeps everything.  Same results.
  * "fit_persistent": how the Chung-Lu fixed point (src/divergence.jl:150-168, :434-467) is launched.
  *             0 = auto: one persistent launch per alpha (the matrix register-resident, the workgroups exchanging
  *                 partial sums and iterates by polling the data itself) for score graphs of >= 128 vertices that fit
