@@ -383,6 +383,13 @@ class Context:
         self._check(self.L.cge_pow_test(self.h, _p(x), C.c_int64(x.size), C.c_double(alpha), C.c_int(method), _p(out)))
         return out
 
+    def wave_tree_test(self, x):
+        """Testing hook: per row of 64 doubles the shuffle-tree sum and the lane-swap sum of the projection kernel."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 64)
+        a, b = np.empty(x.shape[0]), np.empty(x.shape[0])
+        self._check(self.L.cge_wave_tree_test(self.h, _p(x), C.c_int64(x.shape[0]), _p(a), _p(b)))
+        return a, b
+
     def js(self, vC, vB, vI=None, internal=True):
         vC, vB = _f64(vC), _f64(vB)
         vi = None if vI is None or len(vI) == 0 else np.ascontiguousarray(vI, dtype=np.uint8)

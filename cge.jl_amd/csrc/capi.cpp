@@ -1450,6 +1450,23 @@ int cge_pow_test(void *ctx, const double *x, int64_t n, double alpha, int method
     CGE_CATCH(c)
 }
 
+// testing hook (include/cge_hip_testing.h): lane 0's sum of 64 values per row by the shfl_down tree and by the VALU lane
+// swaps that replace it in the projection kernel -- the same bits are expected
+int cge_wave_tree_test(void *ctx, const double *x, int64_t n_rows, double *out_ref, double *out_new) {
+    cge_ctx *c = (cge_ctx *)ctx;
+    if (!c || !x || !out_ref || !out_new || n_rows <= 0) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    DevBuf<double> dx, da, db;
+    dx.ensure((size_t)n_rows * 64); da.ensure(n_rows); db.ensure(n_rows);
+    HIP_CHECK(hipMemcpyAsync(dx.p, x, sizeof(double) * n_rows * 64, hipMemcpyHostToDevice, c->stream));
+    k_wave_tree_test(c, dx.p, n_rows, da.p, db.p);
+    HIP_CHECK(hipMemcpyAsync(out_ref, da.p, sizeof(double) * n_rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(out_new, db.p, sizeof(double) * n_rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    CGE_CATCH(c)
+}
+
 } // extern "C"
 
 bool cge_exchange_fits(cge_ctx *c, size_t need) {

@@ -622,6 +622,7 @@ bool k_pcent_bf16_applies(i64 dpad);
 void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 lds_rows, const unsigned short *Mb,
                   const double *mnorm, i64 ldm, i64 n_land, i64 N, i64 KP, const i32 *sub_land, double *P, int part = 0, int nparts = 1);
 // alpha sweep
+void k_wave_tree_test(cge_ctx *c, const double *x, i64 n_rows, double *out_ref, double *out_new); // testing hook
 void k_copy_segments(cge_ctx *c, const i32 *src, const i64 *seg, i64 nseg, i32 *dst);
 void k_permute_rows(cge_ctx *c, const double *src, const i32 *order, i64 n, i64 width, double *dst); // dst[q] = src[order[q]]
 void k_permute_i32(cge_ctx *c, const i32 *src, const i32 *order, i64 n, i32 *dst);

@@ -34,6 +34,54 @@ __device__ __forceinline__ double wave_allsum(double v) {
     return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
 }
 
+// Lane 0's result of `for (off = 32; off > 0; off >>= 1) v += __shfl_down(v, off)` -- the same pairs added in the same order,
+// hence the same bits -- without the LDS crossbar (12 ds_bpermute per double and their waits): gfx950's lane swaps for the
+// distances 32 and 16 (v_permlane32_swap: lanes 0..31 of the second result hold lanes 32..63; v_permlane16_swap: rows 0 / 2
+// of the second result hold rows 1 / 3), DPP row shifts for 8, 4, 2, 1 inside the first row of 16.  Other lanes: garbage.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_tree_sum_lane0(double v) {
+    {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v += __longlong_as_double((long long)(((unsigned long long)r1[1] << 32) | r0[1]));
+    }
+    {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v += __longlong_as_double((long long)(((unsigned long long)r1[1] << 32) | r0[1]));
+    }
+    v += dpp_shift<0x108>(v); // row_shl:8
+    v += dpp_shift<0x104>(v); // row_shl:4
+    v += dpp_shift<0x102>(v); // row_shl:2
+    v += dpp_shift<0x101>(v); // row_shl:1
+    return v;
+}
+// testing hook: both forms on n_rows x 64 values, one wave per row
+__global__ void wave_tree_test_kernel(const double *__restrict__ x, i64 n_rows, double *__restrict__ out_ref, double *__restrict__ out_new) {
+    const i64 r = ((i64)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & 63;
+    if (r >= n_rows) return;
+    const double v = x[r * 64 + lane];
+    double s = v;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    const double t = wave_tree_sum_lane0(v);
+    if (lane == 0) { out_ref[r] = s; out_new[r] = t; }
+}
+void k_wave_tree_test(cge_ctx *c, const double *x, i64 n_rows, double *out_ref, double *out_new) {
+    hipLaunchKernelGGL(wave_tree_test_kernel, dim3((unsigned)((n_rows * WAVE + 255) / 256)), dim3(256), 0, c->stream, x, n_rows,
+                       out_ref, out_new);
+}
+
 // ------------------------------------------------------------------------------------------------
 // column-major (n x d, Julia) -> row-major (node-major).  32x32 tiles through LDS.
 __global__ void transpose_kernel(const double *__restrict__ Xcol, double *__restrict__ Xrow, i64 n, i64 d) {
@@ -697,6 +745,29 @@ __global__ void scan_write_kernel(const double *__restrict__ Xr, const double *_
         double run_ss = 0.0, run_s = 0.0, run_w = 0.0;
         i32 j = beg;
         i64 bi = 0;
+        constexpr int NB = 4; // blocks of SB rows requested together: a workgroup is two waves at d = 128 and there are only a
+                              // few hundred chunks, so the rows in flight per thread are what fills the memory pipeline
+        for (; j + NB * SB - 1 < end; j += NB * SB, bi += NB) {
+            double xv[NB * SB], wv[NB * SB];
+#pragma unroll
+            for (int q = 0; q < NB * SB; q++) {
+                const i64 v = srows[j + q];
+                wv[q] = vw[v];
+                xv[q] = Xr[v * d + c];
+            }
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+#pragma unroll
+                for (int q = 0; q < SB; q++) {
+                    run_ss += wv[b * SB + q] * (xv[b * SB + q] * xv[b * SB + q]);
+                    run_s += wv[b * SB + q] * xv[b * SB + q];
+                    run_w += wv[b * SB + q];
+                }
+                slots[(bi + b) * W + c] = run_ss;
+                slots[(bi + b) * W + d + c] = run_s;
+                if (c == 0) slots[(bi + b) * W + 2 * d] = run_w;
+            }
+        }
         for (; j + SB - 1 < end; j += SB, bi++) { // SB rows in flight
             double xv[SB], wv[SB];
 #pragma unroll
@@ -2996,36 +3067,59 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
     return true;
 }
 
-// projection z_j = sum_c ((x_jc - mu_c) * sqrt(w_j)) * v_c ; one wave per row
+// projection z_j = sum_c ((x_jc - mu_c) * sqrt(w_j)) * v_c
+// d <= 128: one wave per PR = 16 consecutive rows of the batch.  Lanes 0..15 fetch the rows' vertex ids, tasks and weights
+// (one coalesced request each instead of three per row), the ids travel to scalar registers by v_readlane, and all 32 row
+// loads of the wave (two 512-byte requests per row: columns lane and lane + 64, the per-lane split the sum has always had)
+// are in flight together; the task's mean and direction are fetched once per wave (rows are in task order: a second task
+// inside a wave's 16 rows is the exception and reloads).  Per row the same two FMAs per lane and the same tree as ever.
 __global__ __launch_bounds__(256) void group_project_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                                             const i32 *__restrict__ rows, const i32 *__restrict__ row_task,
                                                             i64 n_rows, i64 d, const double *__restrict__ mean,
                                                             const double *__restrict__ vec, double *__restrict__ z) {
-    // one wave per PR consecutive rows, their loads in flight together; per row the same lane-strided sum as ever
-    constexpr int PR = 4;
+    constexpr int PR = 16;
     const i64 j0 = (((i64)blockIdx.x * blockDim.x + threadIdx.x) / WAVE) * PR;
     const int lane = threadIdx.x & 63;
     if (j0 >= n_rows) return;
-    if (d <= 128) { // two columns per lane: everything fits registers
-        double xa[PR], xb[PR], ma[PR], mb[PR], ea[PR], eb[PR], sq[PR];
+    if (d <= 128) {
+        const i64 jl = (j0 + (lane & 15) < n_rows) ? j0 + (lane & 15) : n_rows - 1;
+        const i32 vrow = rows[jl], trow = row_task[jl];
+        const double sqv = sqrt(vw[vrow]);
         const bool hb = lane + 64 < d, ha = lane < d;
+        double xa[PR], xb[PR];
 #pragma unroll
         for (int u = 0; u < PR; u++) {
-            const i64 j = (j0 + u < n_rows) ? j0 + u : j0;
-            const i64 v = rows[j], t = row_task[j];
-            sq[u] = sqrt(vw[v]);
-            const double *x = Xr + v * d, *mu = mean + t * d, *ev = vec + t * d;
-            xa[u] = ha ? x[lane] : 0.0; ma[u] = ha ? mu[lane] : 0.0; ea[u] = ha ? ev[lane] : 0.0;
-            xb[u] = hb ? x[lane + 64] : 0.0; mb[u] = hb ? mu[lane + 64] : 0.0; eb[u] = hb ? ev[lane + 64] : 0.0;
+            const i64 v = __builtin_amdgcn_readlane(vrow, u);
+            const double *x = Xr + v * d;
+            xa[u] = ha ? x[lane] : 0.0;
+            xb[u] = hb ? x[lane + 64] : 0.0;
         }
+        int cur = __builtin_amdgcn_readlane(trow, 0);
+        double ma, mb, ea, eb;
+        {
+            const double *mu = mean + (i64)cur * d, *ev = vec + (i64)cur * d;
+            ma = ha ? mu[lane] : 0.0; ea = ha ? ev[lane] : 0.0;
+            mb = hb ? mu[lane + 64] : 0.0; eb = hb ? ev[lane + 64] : 0.0;
+        }
+        double zs = 0.0; // lane u keeps the result of row u: one coalesced store at the end
 #pragma unroll
         for (int u = 0; u < PR; u++) {
+            const int t = __builtin_amdgcn_readlane(trow, u);
+            if (t != cur) { // wave-uniform
+                cur = t;
+                const double *mu = mean + (i64)cur * d, *ev = vec + (i64)cur * d;
+                ma = ha ? mu[lane] : 0.0; ea = ha ? ev[lane] : 0.0;
+                mb = hb ? mu[lane + 64] : 0.0; eb = hb ? ev[lane + 64] : 0.0;
+            }
+            const double sq = lane_value(sqv, u);
             double s = 0.0;
-            if (ha) s = fma((xa[u] - ma[u]) * sq[u], ea[u], s);
-            if (hb) s = fma((xb[u] - mb[u]) * sq[u], eb[u], s);
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-            if (lane == 0 && j0 + u < n_rows) z[j0 + u] = s;
+            if (ha) s = fma((xa[u] - ma) * sq, ea, s);
+            if (hb) s = fma((xb[u] - mb) * sq, eb, s);
+            s = wave_tree_sum_lane0(s); // the pairs of the shfl_down tree, in VALU lane swaps
+            const double s0 = lane_value(s, 0);
+            if (lane == u) zs = s0;
         }
+        if (lane < PR && j0 + lane < n_rows) z[j0 + lane] = zs;
         return;
     }
     for (int u = 0; u < PR && j0 + u < n_rows; u++) {
@@ -3036,13 +3130,13 @@ __global__ __launch_bounds__(256) void group_project_kernel(const double *__rest
         const double *x = Xr + v * d, *mu = mean + t * d, *ev = vec + t * d;
         double s = 0.0;
         for (i64 col = lane; col < d; col += WAVE) s = fma((x[col] - mu[col]) * sq, ev[col], s);
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        s = wave_tree_sum_lane0(s);
         if (lane == 0) z[j] = s;
     }
 }
 void k_group_project(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const i32 *row_task, i64 n_rows,
                      i64 d, const double *mean, const double *vec, double *z) {
-    i64 threads = (n_rows + 3) / 4 * WAVE; // one wave per 4 rows
+    i64 threads = (n_rows + 15) / 16 * WAVE; // one wave per 16 rows
     hipLaunchKernelGGL(group_project_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, Xr, vw,
                        rows, row_task, n_rows, d, mean, vec, z);
 }

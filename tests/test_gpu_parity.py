@@ -1280,3 +1280,18 @@ def test_randomised_landmarks_sweep_mid_size(ctx, orc, case):
     args = (g["edges"], g["eweights"], g["vweights"], g["clusters"], g["comm"], g["embedding"], False, land, forced, method,
             directed)
     _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
+
+
+def test_projection_reduction_keeps_the_shuffle_tree_bits(ctx):
+    """group_project_kernel adds the 64 lane partials of a row by gfx950 lane swaps (v_permlane32_swap / v_permlane16_swap /
+    DPP row shifts) instead of six ds_bpermute rounds: the same pairs in the same order, so lane 0 must hold the same bits."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.standard_normal((4096, 64)), rng.standard_normal((512, 64)) * 10.0 ** rng.integers(-8, 8, (512, 64)),
+                        np.arange(64 * 7, dtype=np.float64).reshape(7, 64)])
+    a, b = ctx.wave_tree_test(x)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    # and the tree is the one the comment states: ((..(l, l+32) .. (l, l+16)) .. ) with lane 0 last
+    t = x.copy()
+    for off in (32, 16, 8, 4, 2, 1):
+        t = t[:, :off] + t[:, off:2 * off]
+    assert np.array_equal(t[:, 0], a)
