@@ -1665,7 +1665,49 @@ __device__ __forceinline__ double fast_rcp(double q) {
     r = fma(fma(-q, r, 1.0), r, r);
     return r;
 }
+// acc += (lane N of the reader's row of 16 lanes of `bc`) * a as ONE instruction: gfx950's fp64 FMA takes a DPP broadcast on its
+// first factor at the plain FMA's rate (profiles/microbench_dpp_fmac.hip), so a value that is the same for all lanes needs no
+// LDS broadcast read and no v_readlane.  `bc` must have been written at least two instructions earlier (dpp_fence).
+template <int N>
+__device__ __forceinline__ void fmac_bcast(double &acc, double bc, double a) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(a), "n"(N));
+}
+template <int NG>
+__device__ __forceinline__ void dpp_fence(double (&v)[NG]) { // VALU write -> DPP read of the same register: two wait states
+    if constexpr (NG == 1) asm volatile("s_nop 1" : "+v"(v[0]));
+    else asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[NG - 1]));
+}
+// the column loops of a Householder step with compile-time column numbers (the DPP lane is an immediate)
+template <int JJ, int NR, int NC>
+struct EigCols {
+    static constexpr int NG = (NC + 15) / 16;
+    static __device__ __forceinline__ void matvec(double (&s)[NR], const double (&a)[NR][NC], const double (&uc)[NG]) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) fmac_bcast<JJ % 16>(s[r], uc[JJ / 16], a[r][JJ]);
+        EigCols<JJ + 1, NR, NC>::matvec(s, a, uc);
+    }
+    static __device__ __forceinline__ void rank2(double (&a)[NR][NC], const double (&uc)[NG], const double (&wc)[NG],
+                                                 const double (&nu)[NR], const double (&nw)[NR]) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            fmac_bcast<JJ % 16>(a[r][JJ], uc[JJ / 16], nw[r]); // a - w_r u_j
+            fmac_bcast<JJ % 16>(a[r][JJ], wc[JJ / 16], nu[r]); //   - u_r w_j
+        }
+        EigCols<JJ + 1, NR, NC>::rank2(a, uc, wc, nu, nw);
+    }
+};
 template <int NR, int NC>
+struct EigCols<NC, NR, NC> {
+    static constexpr int NG = (NC + 15) / 16;
+    static __device__ __forceinline__ void matvec(double (&)[NR], const double (&)[NR][NC], const double (&)[NG]) {}
+    static __device__ __forceinline__ void rank2(double (&)[NR][NC], const double (&)[NG], const double (&)[NG], const double (&)[NR],
+                                                 const double (&)[NR]) {}
+};
+// DPPF: the two O(d^2) loops of a step take u_j / w_j as DPP broadcasts from registers that hold the wave's column values
+// (read from LDS once per step: NC / 16 reads instead of NC) -- and u's column values come from the published row itself, so
+// the matrix-vector product no longer waits for the reflector's square root and divisions (only the column next to the
+// diagonal does).  Same operations on the same values as the LDS-broadcast form: the same bits.
+template <int NR, int NC, bool DPPF>
 __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restrict__ cov, int d,
                                                            double *__restrict__ vec, int diag_stage) {
     constexpr int DP = 64 * NR; // padded dimension (rows held); 4*NC >= d columns held
@@ -1718,6 +1760,15 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             x[r] = (row > k) ? X[row] : 0.0;
             part += (row > o) ? x[r] * x[r] : 0.0;
         }
+        constexpr int NG = (NC + 15) / 16;
+        double uc[NG], wc[NG];
+        if (DPPF) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int col = NC * wv + 16 * g + (lane & 15);
+                uc[g] = (col > k && col < DP) ? X[col < DP ? col : 0] : 0.0;
+            }
+        }
         const double alpha = X[o];
         if (tid == 0) diag[k] = X[k];
         const double sigma = wave_allsum(part);
@@ -1743,7 +1794,13 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
         for (int r = 0; r < NR; r++) {
             const int row = lane + 64 * r;
             u[r] = (row == o) ? v0 : x[r];
-            U[row] = u[r]; // every wave writes the same values
+            if (!DPPF) U[row] = u[r]; // every wave writes the same values
+        }
+        if (DPPF) {
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+                if (NC * wv + 16 * g + (lane & 15) == o) uc[g] = v0;
+            dpp_fence(uc);
         }
         __builtin_amdgcn_wave_barrier();
         const bool live = NC * wv + NC > o && diag_stage != 10; // this wave still owns unfinished columns
@@ -1751,7 +1808,9 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             double s[NR];
 #pragma unroll
             for (int r = 0; r < NR; r++) s[r] = 0.0;
-            if (live) {
+            if (DPPF) {
+                if (live) EigCols<0, NR, NC>::matvec(s, a, uc);
+            } else if (live) {
 #pragma unroll
                 for (int jj = 0; jj < NC; jj++) {
                     if (jj % 8 == 0) asm volatile("" ::: "memory"); // at most 8 broadcast reads in flight (registers)
@@ -1780,7 +1839,20 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             W[row] = w[r];
         }
         __builtin_amdgcn_wave_barrier();
-        if (diag_stage != 10) { // rank-2 update; waves whose columns are all finished run it too (u = w = 0 there: nothing changes)
+        if (DPPF) {
+            if (diag_stage != 10) {
+                double nu[NR], nw[NR];
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    const int col = NC * wv + 16 * g + (lane & 15);
+                    wc[g] = W[col < DP ? col : 0];
+                }
+#pragma unroll
+                for (int r = 0; r < NR; r++) { nu[r] = -u[r]; nw[r] = -w[r]; }
+                dpp_fence(wc);
+                EigCols<0, NR, NC>::rank2(a, uc, wc, nu, nw);
+            }
+        } else if (diag_stage != 10) { // rank-2 update; waves whose columns are all finished run it too (u = w = 0 there: nothing changes)
 #pragma unroll
             for (int jj = 0; jj < NC; jj++) {
                 if (jj % 8 == 0) asm volatile("" ::: "memory");
@@ -3033,16 +3105,20 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
     }
     ScopedKernelTimer t(c, "group_eig");
     static const int diag_stage = getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0; // 0 = normal
-    // A/B: CGE_EIG_FORM=0 (default) the first form (blocked columns, reflectors in place), 4 / 8: the cyclic form on 4 / 8 waves
-    static const int form = getenv("CGE_EIG_FORM") ? atoi(getenv("CGE_EIG_FORM")) : 0;
+    // A/B: CGE_EIG_FORM=5 (default) blocked columns, reflectors in place, column values as DPP broadcasts; 0: the same with LDS
+    // broadcast reads (the form of rounds 1-2, same bits); 4 / 8: the cyclic form on 4 / 8 waves
+    static const int form = getenv("CGE_EIG_FORM") ? atoi(getenv("CGE_EIG_FORM")) : 5;
     const dim3 grid((unsigned)n_tasks), block(256);
-    if (form == 0) {
-        if (d <= 32)
-            hipLaunchKernelGGL((group_eig_kernel<1, 8>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
-        else if (d <= 64)
-            hipLaunchKernelGGL((group_eig_kernel<1, 16>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
-        else
-            hipLaunchKernelGGL((group_eig_kernel<2, 32>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
+    if (form == 0 || form == 5) { // 5: the column values as DPP broadcasts of the FMAs (same bits)
+#define CGE_EIG_GO(NR, NC)                                                                                                  \
+    do {                                                                                                                    \
+        if (form == 5) hipLaunchKernelGGL((group_eig_kernel<NR, NC, true>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage); \
+        else hipLaunchKernelGGL((group_eig_kernel<NR, NC, false>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);  \
+    } while (0)
+        if (d <= 32) CGE_EIG_GO(1, 8);
+        else if (d <= 64) CGE_EIG_GO(1, 16);
+        else CGE_EIG_GO(2, 32);
+#undef CGE_EIG_GO
         return true;
     }
     const i64 DP = d <= 64 ? 64 : 128;
