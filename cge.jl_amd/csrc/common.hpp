@@ -611,6 +611,8 @@ i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map); // map[
 void k_ref_centroids(cge_ctx *c, const double *mu, const double *lw, const i32 *ref_off, const i32 *ref_mem, i64 nref,
                      i64 d, double *out);
 void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i);
+void k_farthest_enqueue(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src); // launch only (c->stream) ...
+void k_farthest_collect(cge_ctx *c, double *best_val, i64 *best_i);            // ... and its result (synchronises c->stream)
 void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean);
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
                         double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32 = nullptr,

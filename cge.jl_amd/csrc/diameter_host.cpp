@@ -127,6 +127,18 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     // combined by one all-reduce(max) (only when the exchange buffer can hold N x nref doubles)
     const bool shard_q = nparts > 1 && c->has_coll && (c->rccl_comm || (c->xptr && (size_t)(N * nref) <= c->xcap));
     c->stat_bound_pass = b16 ? 2 : (f32 ? 1 : 0);
+    // One farthest-point sweep from the vertex farthest from the centre (a memory-bound read of Xr) on the side stream, LAUNCHED
+    // AHEAD of the bound pass: its small workgroups then fill the CUs first and the sweep runs at its own speed (~0.3 ms) while
+    // the bound pass's one-workgroup-per-CU tiles move in beside them -- launched behind it, the sweep was left the gaps
+    // (1.0 ms, the longer of the two concurrent branches).  Its result is collected after the bound pass has been enqueued.
+    std::swap(c->stream, c->copy_stream);
+    try {
+        k_farthest_enqueue(c, c->Xr.p, n, d, seed_vertex);
+    } catch (...) {
+        std::swap(c->stream, c->copy_stream);
+        throw;
+    }
+    std::swap(c->stream, c->copy_stream);
     if (b16)
         k_pcent_bf16(c, c->Xb16.p, c->rns.p, lds_rows, c->Mb16.p, c->mnorm.p, ldm, N, nref, KP, c->sub_land.p, c->Pm.p,
                      shard_q ? part : 0, shard_q ? nparts : 1);
@@ -141,18 +153,12 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     // ---- lower bound from farthest-point sweeps ----------------------------------------------------------
     double L = 0.0;
     i64 p0 = seed_vertex, far_i = 0, far_j = 0;
-    // One sweep from the vertex farthest from the centre (a memory-bound read of Xr with a host round trip) on the side
-    // stream while the MFMA pass above occupies the main one.  (Rounds 1-2 made two sweeps from vertex 0: with the bound pass
-    // on the bf16 pipe they had become the longer of the two concurrent branches.)
     std::swap(c->stream, c->copy_stream);
     try {
-        for (int it = 0; it < 1; it++) { // the exact search below does the rest
-            double v;
-            i64 q;
-            k_farthest(c, c->Xr.p, n, d, p0, &v, &q);
-            if (v > L) { L = v; far_i = p0; far_j = q; }
-            p0 = q;
-        }
+        double v;
+        i64 q;
+        k_farthest_collect(c, &v, &q);
+        if (v > L) { L = v; far_i = p0; far_j = q; }
     } catch (...) {
         std::swap(c->stream, c->copy_stream);
         throw;

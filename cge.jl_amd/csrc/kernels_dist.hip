@@ -1018,13 +1018,21 @@ i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map) {
     best_of_recs(c, recs, nwg, &bv, &bi, &bj);
     return bj;
 }
-void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i) {
+// the sweep in two halves: the launch (on c->stream), and the read-back of its result (synchronises c->stream).  Nothing else
+// may use c->mp_recs in between (the bound passes do not).
+static const int FAR_NWG = 1024 > MP_NWG ? MP_NWG : 1024;
+void k_farthest_enqueue(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src) {
     c->mp_recs.ensure(MP_NWG * 3);
     MaxRec *recs = reinterpret_cast<MaxRec *>(c->mp_recs.p);
-    const int nwg = 1024 > MP_NWG ? MP_NWG : 1024;
-    hipLaunchKernelGGL(farthest_kernel, dim3(nwg), dim3(256), 768 * sizeof(double), c->stream, Xr, n, d, src, recs);
+    hipLaunchKernelGGL(farthest_kernel, dim3(FAR_NWG), dim3(256), 768 * sizeof(double), c->stream, Xr, n, d, src, recs);
+}
+void k_farthest_collect(cge_ctx *c, double *best_val, i64 *best_i) {
     i64 bj;
-    best_of_recs(c, recs, nwg, best_val, best_i, &bj);
+    best_of_recs(c, reinterpret_cast<MaxRec *>(c->mp_recs.p), FAR_NWG, best_val, best_i, &bj);
+}
+void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i) {
+    k_farthest_enqueue(c, Xr, n, d, src);
+    k_farthest_collect(c, best_val, best_i);
 }
 
 // ------------------------------------------------------------------------------------------------
