@@ -3198,6 +3198,55 @@ __global__ __launch_bounds__(256) void group_project_kernel(const double *__rest
         if (lane < PR && j0 + lane < n_rows) z[j0 + lane] = zs;
         return;
     }
+    if (d <= 512) { // the same with up to eight columns per lane (column lane + 64 t), two rows in flight at a time
+        constexpr int NS = 8, RF = 2;
+        const i64 jl = (j0 + (lane & 15) < n_rows) ? j0 + (lane & 15) : n_rows - 1;
+        const i32 vrow = rows[jl], trow = row_task[jl];
+        const double sqv = sqrt(vw[vrow]);
+        int cur = __builtin_amdgcn_readlane(trow, 0);
+        double mu[NS], ev[NS];
+        auto load_task = [&](int t) {
+            const double *m = mean + (i64)t * d, *e = vec + (i64)t * d;
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                const i64 col = lane + 64 * q;
+                mu[q] = col < d ? m[col] : 0.0;
+                ev[q] = col < d ? e[col] : 0.0;
+            }
+        };
+        load_task(cur);
+        double zs = 0.0;
+#pragma unroll
+        for (int u0 = 0; u0 < PR; u0 += RF) {
+            double xv[RF][NS];
+#pragma unroll
+            for (int f = 0; f < RF; f++) {
+                const i64 v = __builtin_amdgcn_readlane(vrow, u0 + f);
+                const double *x = Xr + v * d;
+#pragma unroll
+                for (int q = 0; q < NS; q++) {
+                    const i64 col = lane + 64 * q;
+                    xv[f][q] = col < d ? x[col] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < RF; f++) {
+                const int u = u0 + f;
+                const int t = __builtin_amdgcn_readlane(trow, u);
+                if (t != cur) { cur = t; load_task(cur); } // wave-uniform
+                const double sq = lane_value(sqv, u);
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < NS; q++)
+                    if (lane + 64 * q < d) s = fma((xv[f][q] - mu[q]) * sq, ev[q], s);
+                s = wave_tree_sum_lane0(s);
+                const double s0 = lane_value(s, 0);
+                if (lane == u) zs = s0;
+            }
+        }
+        if (lane < PR && j0 + lane < n_rows) z[j0 + lane] = zs;
+        return;
+    }
     for (int u = 0; u < PR && j0 + u < n_rows; u++) {
         const i64 j = j0 + u;
         const i64 v = rows[j];
