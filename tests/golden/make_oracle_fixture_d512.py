@@ -10,7 +10,7 @@ The GPU test regenerates graph and draws, so only expected OUTPUTS are stored (v
 On the device this exercises what no other fixture reaches: group_eig_panel_kernel (128 < d <= 512), the tile-pair
 covariance (four 128-column tiles), the K = 512 fp32-MFMA bound pass of the diameter.
 
-usage: python tests/golden/make_oracle_fixture_d512.py [small]
+usage: python tests/golden/make_oracle_fixture_d512.py [small|quick]
 """
 import os
 import sys
@@ -29,6 +29,10 @@ from oracle import oracle as orc  # noqa: E402
 D512 = dict(n=20_000, m=200_000, C=30, d=512, land=300, forced=4, samples=10000, seed=42)
 # `small` (argv[1]): the same at 8000 vertices / 12 communities / -l 120 (a third of the Jacobi problems: ~21 s each at d = 512)
 D512_SMALL = dict(n=8_000, m=80_000, C=12, d=512, land=120, forced=4, samples=10000, seed=42)
+# `quick` (argv[1]): every group that is split keeps >= ~500 rows.  The oracle's cyclic Jacobi takes ~26 s on the covariance of
+# >= 500 rows at d = 512 and ~136 s on a rank-deficient one (150 rows), so the two fixtures above cost 4 h (small) and ~20 h
+# (large) of one core per split rule; this one, 30 splits per rule, costs ~15 minutes per rule.
+D512_QUICK = dict(n=12_000, m=120_000, C=6, d=512, land=36, forced=4, samples=10000, seed=42)
 
 
 def crc(a):
@@ -36,12 +40,13 @@ def crc(a):
 
 
 def main():
-    small = len(sys.argv) > 1 and sys.argv[1] == "small"
-    c = D512_SMALL if small else D512
+    which = sys.argv[1] if len(sys.argv) > 1 else ""
+    small = which == "small"
+    c = D512_SMALL if small else D512_QUICK if which == "quick" else D512
     g = synth.abcd_like(c["n"], int(c["m"] * 1.05), c["C"], c["d"], seed=c["seed"])
     print(f"graph n={g['n']} m={g['m']}", flush=True)
     out = dict(n=g["n"], m=g["m"], edges_crc=crc(g["edges"]), emb_crc=crc(g["embedding"]), gen_n=c["n"], gen_m=int(c["m"] * 1.05),
-               gen_C=c["C"], land=c["land"])
+               gen_C=c["C"], land=c["land"], forced=c["forced"])
     t0 = time.time()
     hi = orc.max_pair_dist(g["embedding"])
     t_hi = time.time() - t0
@@ -69,7 +74,7 @@ def main():
                     p + "lw_crc": crc(lw), p + "n_ledges": len(lw), p + "result": res, p + "iters": np.array(tr["iters"]),
                     p + "div": np.array(tr["div"]), p + "auc": np.array(tr["auc"])})
     np.savez_compressed(
-        os.path.join(ROOT, "tests", "golden", "oracle_d512_small.npz" if small else "oracle_d512.npz"),
+        os.path.join(ROOT, "tests", "golden", "oracle_d512_small.npz" if small else "oracle_d512_quick.npz" if which == "quick" else "oracle_d512.npz"),
         provenance=np.array("oracle/cge_oracle.c (CPU restatement), tests/golden/make_oracle_fixture_d512.py; diameter "
                             f"{t_hi:.0f} s; rss: landmarks {times['rss'][0]:.0f} s + wGCL {times['rss'][1]:.0f} s; diameter "
                             f"rule: landmarks {times['diameter'][0]:.0f} s + wGCL {times['diameter'][1]:.0f} s; one core"),

@@ -226,11 +226,12 @@ def test_config4_directed_million_samples_against_oracle_fixture(ctx):
     assert np.array_equal(res, res_h)
 
 
-@pytest.mark.parametrize("which", ["oracle_d512", "oracle_d512_small"])
+@pytest.mark.parametrize("which", ["oracle_d512", "oracle_d512_small", "oracle_d512_quick"])
 @pytest.mark.parametrize("method", ["rss", "diameter"])
 def test_d512_against_oracle_fixture(ctx, method, which):
     """The oracle pin of config 5's code paths (tests/golden/make_oracle_fixture_d512.py): d = 512, 20 000 vertices, 30
-    communities, -l 300 -f 4 (`_small`: 8000 vertices, 12 communities, -l 120) -- group_eig_panel_kernel (128 < d <= 512), the tile-pair covariance and the K = 512 fp32-MFMA
+    communities, -l 300 -f 4 (`_small`: 8000 vertices, 12 communities, -l 120; `_quick`: 12 000 vertices, 6 communities, -l 36:
+    the one the oracle's Jacobi finishes in half an hour, see the generator) -- group_eig_panel_kernel (128 < d <= 512), the tile-pair covariance and the K = 512 fp32-MFMA
     bound pass against the CPU oracle's Jacobi eigenvectors and O(n^2 d) diameter loop: v_to_l, d_ii, weights and
     communities bit for bit, centroid / landmark-edge checksums, the diameter's bits, iteration counts, the 7-vector and
     every trace at 1e-9, for the rss rule and for a cut rule."""
@@ -242,13 +243,13 @@ def test_d512_against_oracle_fixture(ctx, method, which):
     fx0 = np.load(path, allow_pickle=False)
     fx = _Prefixed(fx0, method + "_")
     gen = (20_000, 210_000, 30, 300) if "gen_n" not in fx0 else tuple(int(fx0[k]) for k in ("gen_n", "gen_m", "gen_C", "land"))
-    land = gen[3]
+    land, forced = gen[3], (int(fx0["forced"]) if "forced" in fx0 else 4)
     g = synth.abcd_like(gen[0], gen[1], gen[2], 512, seed=42)
     assert g["n"] == int(fx["n"]) and g["m"] == int(fx["m"])
     assert crc(g["edges"]) == int(fx["edges_crc"]) and crc(g["embedding"]) == int(fx["emb_crc"])
     ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
     ctx.set_option("diameter", 0)
-    res = ctx.score(g["clusters"], land, 4, method, seed=42, auc_samples=10000)
+    res = ctx.score(g["clusters"], land, forced, method, seed=42, auc_samples=10000)
     tr = ctx.last_trace
     hi, dpath, _, _ = ctx.last_diameter()
     assert hi == float(fx["hi"]) and dpath == "pruned", (hi, float(fx["hi"]), dpath)
@@ -262,7 +263,7 @@ def test_d512_against_oracle_fixture(ctx, method, which):
     for opt, val, back in (("diameter_f32", 0, 2), ("diameter_f32", 1, 2), ("diameter", 1, 0), ("early_diameter", 1, 0)):  # fp64 / fp32 bound pass, brute force, side context
         try:
             ctx.set_option(opt, val)
-            assert np.array_equal(res, ctx.score(g["clusters"], land, 4, method, seed=42, auc_samples=10000))
+            assert np.array_equal(res, ctx.score(g["clusters"], land, forced, method, seed=42, auc_samples=10000))
             assert ctx.last_diameter()[0] == hi
         finally:
             ctx.set_option(opt, back)
