@@ -908,21 +908,6 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
         }
         w += Cp[2 * d];
     };
-    // range sums S(a,b) = P[b-1] - P[a-1] for this lane's columns
-    auto range = [&](i64 a, i64 b, double (&ss)[NS], double (&s1)[NS], double &w) {
-#pragma unroll
-        for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
-        w = 0.0;
-        if (b <= a) return;
-        prefix_at(b - 1, ss, s1, w);
-        if (a > 0) {
-            double qs[NS], q1[NS], qw;
-            prefix_at(a - 1, qs, q1, qw);
-#pragma unroll
-            for (int s = 0; s < NS; s++) { ss[s] -= qs[s]; s1[s] -= q1[s]; }
-            w -= qw;
-        }
-    };
     // sum over the columns of wsse(base + add)
     auto fsum = [&](const double (&bss)[NS], const double (&bs1)[NS], double bw, const double (&ass)[NS],
                     const double (&as1)[NS], double aw) {
@@ -950,16 +935,42 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
     double med = median(0, k);
     double a_ss[NS], a_s[NS], b_ss[NS], b_s[NS], aw, bw;
     bool leftover = false;
+    // The prefixes at the two ends of the gray range are carried from round to round (PA = P[ga-1], PB = P[gb-1]): a round
+    // needs ONE new prefix, at its cut -- the same values subtracted in the same way as four prefix look-ups per round gave
+    // (two of them were the same look-up, two the previous round's).  PK = P[k-1] for the children's totals.
+    double PA_ss[NS], PA_s[NS], PA_w, PB_ss[NS], PB_s[NS], PB_w, PK_ss[NS], PK_s[NS], PK_w, PC_ss[NS], PC_s[NS], PC_w;
+    prefix_at(ga - 1, PA_ss, PA_s, PA_w);
+    prefix_at(gb - 1 > 0 ? gb - 1 : 0, PB_ss, PB_s, PB_w);
+    prefix_at(k - 1, PK_ss, PK_s, PK_w);
     while (ga < gb) {
-        // number of gray ranks with z < med (binary search; z ascending)
+        // number of gray ranks with z < med (z ascending): a 64-way search, the lanes probing 64 places at once -- two or
+        // three dependent loads instead of log2 of the range
         i64 lo = ga, hi = gb;
-        while (lo < hi) {
-            const i64 mid = (lo + hi) >> 1;
-            if (z[mid] < med) lo = mid + 1; else hi = mid;
+        while (hi - lo > 64) {
+            const i64 step = (hi - lo + 63) / 64, idx = lo + (i64)lane * step;
+            const bool below = idx < hi && z[idx < hi ? idx : lo] < med;
+            const int cnt = __popcll(__ballot(below)); // probes 0 .. cnt-1 are below the median, probe cnt is not (or beyond hi)
+            if (cnt == 0) { hi = lo; break; }
+            const i64 nlo = lo + (i64)(cnt - 1) * step + 1, nhi = lo + (i64)cnt * step;
+            hi = nhi < hi ? nhi : hi;
+            lo = nlo;
+        }
+        if (hi > lo) {
+            const i64 idx = lo + lane;
+            const bool below = idx < hi && z[idx < hi ? idx : lo] < med;
+            lo += __popcll(__ballot(below));
         }
         const i64 cut = lo; // t1 = [ga, cut), t2 = [cut, gb)
-        range(ga, cut, a_ss, a_s, aw);
-        range(cut, gb, b_ss, b_s, bw);
+        if (cut > ga && cut < gb) prefix_at(cut - 1, PC_ss, PC_s, PC_w);
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (cut <= ga) { a_ss[s] = 0.0; a_s[s] = 0.0; b_ss[s] = PB_ss[s] - PA_ss[s]; b_s[s] = PB_s[s] - PA_s[s]; }
+            else if (cut >= gb) { a_ss[s] = PB_ss[s] - PA_ss[s]; a_s[s] = PB_s[s] - PA_s[s]; b_ss[s] = 0.0; b_s[s] = 0.0; }
+            else { a_ss[s] = PC_ss[s] - PA_ss[s]; a_s[s] = PC_s[s] - PA_s[s]; b_ss[s] = PB_ss[s] - PC_ss[s]; b_s[s] = PB_s[s] - PC_s[s]; }
+        }
+        if (cut <= ga) { aw = 0.0; bw = PB_w - PA_w; }
+        else if (cut >= gb) { aw = PB_w - PA_w; bw = 0.0; }
+        else { aw = PC_w - PA_w; bw = PB_w - PC_w; }
         const double f1 = fsum(rl_ss, rl_s, rl_w, a_ss, a_s, aw);
         const double f2 = fsum(rh_ss, rh_s, rh_w, b_ss, b_s, bw);
         if (nr >= RR_MAXROUNDS - 1) { rc = 1; break; }
@@ -971,6 +982,15 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
             if (lane == 0) { rlog[3 * nr] = (i32)ga; rlog[3 * nr + 1] = (i32)cut; rlog[3 * nr + 2] = 1; }
             nr++;
             ga = cut;
+            if (cut < gb) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) { PA_ss[s] = PC_ss[s]; PA_s[s] = PC_s[s]; }
+                PA_w = PC_w;
+            } else { // the whole gray range went low: ga == gb, the loop ends
+#pragma unroll
+                for (int s = 0; s < NS; s++) { PA_ss[s] = PB_ss[s]; PA_s[s] = PB_s[s]; }
+                PA_w = PB_w;
+            }
         } else {
             if (cut == gb) { leftover = true; break; }
 #pragma unroll
@@ -979,21 +999,40 @@ __global__ __launch_bounds__(64) void rss_rounds_kernel(const double *__restrict
             if (lane == 0) { rlog[3 * nr] = (i32)cut; rlog[3 * nr + 1] = (i32)gb; rlog[3 * nr + 2] = 2; }
             nr++;
             gb = cut;
+            if (cut > ga) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) { PB_ss[s] = PC_ss[s]; PB_s[s] = PC_s[s]; }
+                PB_w = PC_w;
+            } else { // the whole gray range went high: gb == ga
+#pragma unroll
+                for (int s = 0; s < NS; s++) { PB_ss[s] = PA_ss[s]; PB_s[s] = PA_s[s]; }
+                PB_w = PA_w;
+            }
         }
         if (ga < gb) med = median(ga, gb);
     }
     if (leftover && rc == 0) { // :200-208
-        range(ga, gb, a_ss, a_s, aw);
+#pragma unroll
+        for (int s = 0; s < NS; s++) { a_ss[s] = PB_ss[s] - PA_ss[s]; a_s[s] = PB_s[s] - PA_s[s]; }
+        aw = PB_w - PA_w;
         const double fa1 = fsum(rl_ss, rl_s, rl_w, a_ss, a_s, aw), fa2 = fsum(rh_ss, rh_s, rh_w, zero_ss, zero_s, 0.0);
         const double fb1 = fsum(rl_ss, rl_s, rl_w, zero_ss, zero_s, 0.0), fb2 = fsum(rh_ss, rh_s, rh_w, a_ss, a_s, aw);
         const int side = (fmax(fa1, fa2) < fmax(fb1, fb2)) ? 1 : 2;
         if (lane == 0) { rlog[3 * nr] = (i32)ga; rlog[3 * nr + 1] = (i32)gb; rlog[3 * nr + 2] = side; }
         nr++;
-        if (side == 1) ga = gb; else gb = ga;
+        if (side == 1) { // ga = gb
+            ga = gb;
+#pragma unroll
+            for (int s = 0; s < NS; s++) { PA_ss[s] = PB_ss[s]; PA_s[s] = PB_s[s]; }
+            PA_w = PB_w;
+        } else
+            gb = ga;
     }
-    // children: low = ranks [0, ga), high = ranks [ga, k); total_rss from the prefix sums
-    range(0, ga, a_ss, a_s, aw);
-    range(ga, k, b_ss, b_s, bw);
+    // children: low = ranks [0, ga), high = ranks [ga, k); total_rss from the prefix sums: P[ga-1] and P[k-1] - P[ga-1]
+#pragma unroll
+    for (int s = 0; s < NS; s++) { a_ss[s] = PA_ss[s]; a_s[s] = PA_s[s]; b_ss[s] = PK_ss[s] - PA_ss[s]; b_s[s] = PK_s[s] - PA_s[s]; }
+    aw = PA_w;
+    bw = PK_w - PA_w;
     const double vlow = -fsum(zero_ss, zero_s, 0.0, a_ss, a_s, aw), vhigh = -fsum(zero_ss, zero_s, 0.0, b_ss, b_s, bw);
     // the children's weighted means (matrix_w_mean, :71-81) are the same column sums: sum w x / sum w
 #pragma unroll
