@@ -646,16 +646,20 @@ __global__ __launch_bounds__(256) void group_side_sums_partial_kernel(const doub
     for (int q = 0; q < 2; q++)
 #pragma unroll
         for (int t = 0; t < SS_SLOTS; t++) { ss[q][t] = 0.0; s1[q][t] = 0.0; }
-    constexpr int RF = NS <= 2 ? 4 : NS <= 4 ? 2 : 1; // rows in flight per wave; the additions keep the row order
+    // rows in flight per wave; the additions keep the row order (wave w takes rows beg + w, + 4, + 8, ...).  Lanes 0 .. RF-1
+    // fetch the ids, sides and weights of the wave's next RF rows in one request each, the ids travel to scalar registers
+    // (v_readlane) and all row loads are in flight together -- what the projection kernel does
+    constexpr int RF = NS <= 2 ? 16 : NS <= 4 ? 8 : 4;
     for (i32 j0 = beg + wave; j0 < end; j0 += 4 * RF) {
-        int sd[RF];
-        double w[RF], xv[RF][NS];
+        const i32 jl = j0 + 4 * (lane & (RF - 1));
+        const bool onl = jl < end;
+        const i32 vl = rows[onl ? jl : beg];
+        const int sdl = onl ? (int)side[jl] : 0;
+        const double wl = vw[vl];
+        double xv[RF][NS];
 #pragma unroll
         for (int u = 0; u < RF; u++) {
-            const i32 j = j0 + 4 * u;
-            sd[u] = j < end ? side[j] : 0; // wave-uniform
-            const i64 v = rows[j < end ? j : beg];
-            w[u] = vw[v];
+            const i64 v = __builtin_amdgcn_readlane(vl, u);
             const double *x = Xr + v * d;
 #pragma unroll
             for (int t = 0; t < NS; t++) {
@@ -665,11 +669,13 @@ __global__ __launch_bounds__(256) void group_side_sums_partial_kernel(const doub
         }
 #pragma unroll
         for (int u = 0; u < RF; u++) {
-            if (sd[u] == 0) continue;
-            const int q = sd[u] == 1 ? 0 : 1;
-            ws[q] += w[u];
+            const int sd = __builtin_amdgcn_readlane(sdl, u); // wave-uniform
+            if (sd == 0) continue;
+            const int q = sd == 1 ? 0 : 1;
+            const double w = lane_value(wl, u);
+            ws[q] += w;
 #pragma unroll
-            for (int t = 0; t < NS; t++) { ss[q][t] += w[u] * (xv[u][t] * xv[u][t]); s1[q][t] += w[u] * xv[u][t]; }
+            for (int t = 0; t < NS; t++) { ss[q][t] += w * (xv[u][t] * xv[u][t]); s1[q][t] += w * xv[u][t]; }
         }
     }
     double *out = part + ch * 2 * (2 * d + 1);
