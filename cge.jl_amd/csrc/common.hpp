@@ -399,6 +399,7 @@ struct cge_ctx {
     DevBuf<unsigned char> ls_keys;
     PinBuf<i32> pin_small;
     DevBuf<unsigned char> sort_tmp;
+    DevBuf<unsigned long long> sort_k64; // sorted 4096-row pieces of the long groups on their way to the rank merge
 
     DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;
     DevBuf<double> r2_F, r2_ck; // rss2: RSS of every prefix / suffix along sorted z, block checkpoints of the two chains
@@ -556,7 +557,7 @@ void k_sort_children(cge_ctx *c, const unsigned char *keys, const i32 *rows, con
                      int key_bits, i32 *out);
 i64 k_groups_to_index(cge_ctx *c, const i32 *arena, const i32 *goff, const i32 *glen, i64 N, i64 n, i32 *v2l, i32 *mem);
 void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 *row_task, const i32 *task_row_off,
-                        i64 R, i64 T, double *zs, i32 *perm, i32 *srows, i32 *status);
+                        i64 R, i64 T, double *zs, i32 *perm, i32 *srows, i32 *status, i64 max_len = 0 /* longest group, 0: unknown */);
 void k_rss_side(cge_ctx *c, const double *z, const i32 *row_task, i64 n_rows, const double *params,
                 unsigned char *state, unsigned char *side);
 bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec);

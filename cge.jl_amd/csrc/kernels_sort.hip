@@ -66,12 +66,115 @@ __global__ void finish_two_pass_kernel(const i32 *__restrict__ pos, const double
     zs[j] = z[p];
     perm[j] = p - task_row_off[row_task[p]];
 }
+// Per-group sort of (z, local index) pairs without a device-wide sort.  A group is cut into pieces of SEGSORT_CAP rows; one
+// workgroup sorts a piece in LDS by a bitonic network on the radix order of the doubles (sign-flipped bit patterns: -0 before
+// +0, NaNs at the two ends -- the order of rocPRIM's radix sort and of Julia's isless), ties by index, i.e. the permutation of
+// a stable sort.  A group of one piece is finished there; the pieces of a longer group are merged by RANK: every element
+// counts, by a binary search in each of the other sorted pieces of its group, how many elements precede it in the (key,
+// index) order and goes straight to its final place.  For the batches of long groups this replaces two device-wide sorts of
+// all rows (a 64-bit merge sort in ~20 launches, then a radix sort by task: 0.35 ms per batch) by two launches.
+#define SEGSORT_CAP 4096
+#define SEGSORT_MAXPIECES 8
+__device__ __forceinline__ unsigned long long z_sort_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double z_from_sort_key(unsigned long long key) {
+    return __longlong_as_double((long long)((key >> 63) ? (key & 0x7fffffffffffffffULL) : ~key));
+}
+__global__ __launch_bounds__(256) void segment_piece_sort_kernel(const double *__restrict__ z, const i32 *__restrict__ task_row_off,
+                                                                 int cap, double *__restrict__ zs, i32 *__restrict__ perm,
+                                                                 unsigned long long *__restrict__ tkey, i32 *__restrict__ tidx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skey[]; // [cap] keys, then [cap] indices
+    int *sidx = reinterpret_cast<int *>(skey + cap);
+    const i64 t = blockIdx.x, o = task_row_off[t];
+    const int len = (int)(task_row_off[t + 1] - o), piece = blockIdx.y, p0 = piece * SEGSORT_CAP, tid = threadIdx.x;
+    if (p0 >= len) return; // (uniform) the group has fewer pieces
+    const int k = min(SEGSORT_CAP, len - p0);
+    int n2 = 1;
+    while (n2 < k) n2 <<= 1;
+    for (int i = tid; i < n2; i += 256) {
+        skey[i] = i < k ? z_sort_key(z[o + p0 + i]) : ~0ULL;
+        sidx[i] = i < k ? p0 + i : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (n2 >> 1); i += 256) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long ka = skey[lo], kb = skey[hi];
+                const int ia = sidx[lo], ib = sidx[hi];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == up) {
+                    skey[lo] = kb; skey[hi] = ka;
+                    sidx[lo] = ib; sidx[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    if (len <= SEGSORT_CAP) { // the whole group: done
+        for (int i = tid; i < k; i += 256) {
+            zs[o + i] = z_from_sort_key(skey[i]);
+            perm[o + i] = sidx[i];
+        }
+    } else {
+        for (int i = tid; i < k; i += 256) {
+            tkey[o + p0 + i] = skey[i];
+            tidx[o + p0 + i] = sidx[i];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void segment_rank_merge_kernel(const unsigned long long *__restrict__ tkey, const i32 *__restrict__ tidx,
+                                                                 const i32 *__restrict__ row_task, const i32 *__restrict__ task_row_off,
+                                                                 i64 R, double *__restrict__ zs, i32 *__restrict__ perm) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= R) return;
+    const i32 t = row_task[j];
+    const i64 o = task_row_off[t];
+    const int len = (int)(task_row_off[t + 1] - o);
+    if (len <= SEGSORT_CAP) return; // finished by the piece sort
+    const int q = (int)(j - o), mine = q / SEGSORT_CAP;
+    const unsigned long long key = tkey[j];
+    const int ix = tidx[j];
+    int rank = q - mine * SEGSORT_CAP; // elements of my own piece in front of me
+    const int npieces = (len + SEGSORT_CAP - 1) / SEGSORT_CAP;
+    for (int p = 0; p < npieces; p++) {
+        if (p == mine) continue;
+        const i64 b = o + (i64)p * SEGSORT_CAP;
+        int lo = 0, hi = min(SEGSORT_CAP, len - p * SEGSORT_CAP);
+        while (lo < hi) { // first element of piece p that does not precede (key, ix)
+            const int mid = (lo + hi) >> 1;
+            const unsigned long long km = tkey[b + mid];
+            if (km < key || (km == key && tidx[b + mid] < ix)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+    }
+    zs[o + rank] = z_from_sort_key(key);
+    perm[o + rank] = ix;
+}
 void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 *row_task, const i32 *task_row_off,
-                        i64 R, i64 T, double *zs, i32 *perm, i32 *srows, i32 *status) {
+                        i64 R, i64 T, double *zs, i32 *perm, i32 *srows, i32 *status, i64 max_len) {
     ScopedKernelTimer tm(c, "segmented_sort");
     c->sort_idx.ensure(R);
     const unsigned nb = (unsigned)((R + 255) / 256);
-    if (R / std::max<i64>(T, 1) >= 768) {
+    // CGE_SEGSORT: 0 = rocPRIM only, 1 (default) = the LDS network for batches of few long groups, 2 = for every batch whose
+    // groups fit it
+    static const int segsort = getenv("CGE_SEGSORT") ? atoi(getenv("CGE_SEGSORT")) : 1;
+    const bool long_groups = R / std::max<i64>(T, 1) >= 768;
+    if (max_len > 0 && max_len <= (i64)SEGSORT_CAP * SEGSORT_MAXPIECES && ((segsort == 1 && long_groups) || segsort == 2)) {
+        int cap = 64;
+        while (cap < std::min<i64>(max_len, SEGSORT_CAP)) cap <<= 1;
+        const unsigned npieces = (unsigned)((max_len + SEGSORT_CAP - 1) / SEGSORT_CAP);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void *)segment_piece_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEGSORT_CAP * 12); attr = true; }
+        if (npieces > 1) { c->sort_k64.ensure(R); c->sort_idx2.ensure(R); }
+        hipLaunchKernelGGL(segment_piece_sort_kernel, dim3((unsigned)T, npieces), dim3(256), (size_t)cap * 12, c->stream, z, task_row_off, cap,
+                           zs, perm, c->sort_k64.p, c->sort_idx2.p);
+        if (npieces > 1)
+            hipLaunchKernelGGL(segment_rank_merge_kernel, dim3(nb), dim3(256), 0, c->stream, c->sort_k64.p, c->sort_idx2.p, row_task,
+                               task_row_off, R, zs, perm);
+    } else if (long_groups) {
         // Few long segments: the segmented sort walks each of them alone through all its radix passes.  Two device-wide
         // stable sorts do the same job at full occupancy: all rows by z, then (stably) by task.
         c->sort_keys32.ensure(R);

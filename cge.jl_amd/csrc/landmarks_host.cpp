@@ -349,7 +349,7 @@ namespace {
 // A batch = a list of groups; `rows` (device: c->ls_rows) holds their 0-based vertex ids back to back in the groups'
 // own member order; every group is cut into chunks of CH rows (one workgroup each).
 struct Batch {
-    i64 T = 0, R = 0, NC = 0;
+    i64 T = 0, R = 0, NC = 0, max_len = 0; // max_len: rows of the longest group
     i32 *rows = nullptr, *row_task = nullptr; // host-built batches only: pinned staging owned by the ctx
     std::vector<i32> chunk_task, chunk_beg, chunk_end, task_chunk_off, task_row_off, task_off;
 };
@@ -361,10 +361,12 @@ void batch_tables(Batch &B, const std::vector<i64> &lens) {
     B.task_chunk_off.assign(T + 1, 0);
     B.task_row_off.assign(T + 1, 0);
     i64 pos = 0;
+    B.max_len = 0;
     for (i64 t = 0; t < T; t++) {
         B.task_row_off[t] = (i32)pos;
         B.task_chunk_off[t] = (i32)B.chunk_task.size();
         const i64 k = lens[t];
+        B.max_len = std::max(B.max_len, k);
         for (i64 s = 0; s < k; s += CH) {
             B.chunk_task.push_back((i32)t);
             B.chunk_beg.push_back((i32)(pos + s));
@@ -728,7 +730,7 @@ void rule_rss_sorted_enqueue(LaneRun &L) {
     c->sp_meta.ensure(2 * T); c->sp_rounds.ensure((size_t)T * 3 * CGE_RR_MAXROUNDS); c->sp_vals.ensure(2 * T);
     c->ls_keys.ensure(R); c->ls_nlow.ensure(T);
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
-                       c->sp_srows.p, c->sp_status.p);
+                       c->sp_srows.p, c->sp_status.p, B.max_len);
     k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
     k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->ls_tco.p, c->sp_prefix.p, c->sp_coff.p,
@@ -770,7 +772,7 @@ void rule_rss2_enqueue(LaneRun &L) {
     c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
     c->sp_meta.ensure(2 * T); c->sp_vals.ensure(2 * T);
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
-                       c->sp_srows.p, c->sp_status.p);
+                       c->sp_srows.p, c->sp_status.p, B.max_len);
     HIP_CHECK(hipMemcpyAsync(c->lm_arena.p + L.base, c->sp_srows.p, sizeof(i32) * R, hipMemcpyDeviceToDevice, st));
     c->r2_rows = R;
     k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->lm_means.p + L.mbase);
@@ -806,7 +808,7 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
     if (use_median) { // the median needs the sorted projections
         c->sp_srows.ensure(R); c->sp_zs.ensure(R); c->sp_perm.ensure(R); c->sp_status.ensure(T);
         k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
-                           c->sp_srows.p, c->sp_status.p);
+                           c->sp_srows.p, c->sp_status.p, B.max_len);
     }
     c->ls_nlow.ensure(T);
     k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p);
