@@ -402,7 +402,8 @@ struct cge_ctx {
     DevBuf<unsigned long long> sort_k64; // sorted 4096-row pieces of the long groups on their way to the rank merge
 
     DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;
-    DevBuf<double> r2_F, r2_ck; // rss2: RSS of every prefix / suffix along sorted z, block checkpoints of the two chains
+    DevBuf<double> r2_F, r2_ck;
+    DevBuf<double> r2_PS, r2_PW; // rss2 rule: the running sums (and weights) of every row of a batch, both directions // rss2: RSS of every prefix / suffix along sorted z, block checkpoints of the two chains
     i64 r2_rows = 0;            // rows of the batch the rss2 kernels are about to see
 
     // ---- the side context of cge_score (capi.cpp) ------------------------------------------------

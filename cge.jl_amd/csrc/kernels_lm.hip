@@ -1379,6 +1379,120 @@ __global__ __launch_bounds__(256) void rss2_chain_kernel(const double *__restric
     }
 }
 
+// ---- the same chains in two steps (round 3): the additions by ONE wave per (group, direction), the divisions by everybody ----
+// In rss2_chain_kernel every one of a workgroup's four waves runs the whole chain of additions and pays the divisions and the
+// tree sum for a quarter of the rows: a group of 13 000 rows (config 2's largest community) keeps four waves busy for
+// 1.5 ms while the rest of the GPU waits.  Here a single wave per (group, direction) runs the chain -- the same additions in
+// the same order -- and STORES the running sums of every row (2 NS 64 + 1 doubles); a second launch, one wave per row over
+// all rows of the batch, evaluates sum_c (ss - s1^2 / w) with the same division and the same tree (wave_allsum).  Same bits.
+template <int NS>
+__global__ __launch_bounds__(64) void rss2_prefix_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                                         const i32 *__restrict__ srows, const i32 *__restrict__ task_row_off,
+                                                         i64 d, i64 R, double *__restrict__ PS /* [2][R][2 NS 64] */,
+                                                         double *__restrict__ PW /* [2][R] */,
+                                                         double *__restrict__ ck /* [2][slots][2 NS 64 + 64] */, i64 slots) {
+    const i64 t = blockIdx.x;
+    const int dir = blockIdx.y, lane = threadIdx.x;
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    const i32 *p = srows + o;
+    const i64 nblk = (k + R2_BR - 1) / R2_BR, slot0 = o / R2_BR + t;
+    double *PSo = PS + ((i64)dir * R + o) * (2 * NS * 64);
+    double *PWo = PW + (i64)dir * R + o;
+    double *cko = ck + ((i64)dir * slots + slot0) * (2 * NS * 64 + 64);
+    double ss[NS], s1[NS], wacc = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
+    // The wave is alone in its workgroup and may use the whole register file: NSET sets of 16 rows rotate (128 rows in flight
+    // at d <= 64), and the row ids of a set are requested one rotation ahead of its rows -- the chain is bound by the latency
+    // of its gathers (id -> weight, row), not by its additions.
+    constexpr int NSET = NS == 1 ? 8 : 4;
+    auto load_ids = [&](i64 b, int &vq) {
+        const i64 q = b * R2_BR + lane;
+        vq = (lane < R2_BR && q < k) ? p[dir ? k - 1 - q : q] : p[0]; // slots past the end: a valid row (its weight counts as 0)
+    };
+    auto load_rows = [&](i64 b, const int vq, double (&x)[R2_BR][NS], double &wl) {
+        const i64 q = b * R2_BR + lane;
+        wl = (lane < R2_BR && q < k) ? vw[vq] : 0.0;
+#pragma unroll
+        for (int u = 0; u < R2_BR; u++) {
+            const i64 v = __builtin_amdgcn_readlane(vq, u);
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const i64 c = lane + 64 * s;
+                x[u][s] = (c < d) ? Xr[v * d + c] : 0.0;
+            }
+        }
+    };
+    auto process = [&](i64 b, const double (&x)[R2_BR][NS], const double wl) {
+        // checkpoint: the triple before this block (what rss2_merge_kernel starts its boundary adjustment from)
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            cko[b * (2 * NS * 64 + 64) + (2 * s) * 64 + lane] = ss[s];
+            cko[b * (2 * NS * 64 + 64) + (2 * s + 1) * 64 + lane] = s1[s];
+        }
+        if (lane == 0) cko[b * (2 * NS * 64 + 64) + 2 * NS * 64] = wacc;
+        double wrow = 0.0; // lane q keeps the running weight after row q of the block
+#pragma unroll
+        for (int q = 0; q < R2_BR; q++) {
+            const double w = lane_value(wl, q);
+            const i64 row = b * R2_BR + q;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const double xv = x[q][s];
+                ss[s] += w * (xv * xv);
+                s1[s] += w * xv;
+                if (row < k) {
+                    PSo[row * (2 * NS * 64) + (2 * s) * 64 + lane] = ss[s];
+                    PSo[row * (2 * NS * 64) + (2 * s + 1) * 64 + lane] = s1[s];
+                }
+            }
+            wacc += w;
+            if (lane == q) wrow = wacc;
+        }
+        const i64 rowl = b * R2_BR + lane;
+        if (lane < R2_BR && rowl < k) PWo[rowl] = wrow;
+    };
+    double x[NSET][R2_BR][NS], wl[NSET];
+    int vq[NSET];
+#pragma unroll
+    for (int i = 0; i < NSET; i++) { wl[i] = 0.0; vq[i] = 0; if (i < nblk) load_ids(i, vq[i]); }
+#pragma unroll
+    for (int i = 0; i < NSET; i++)
+        if (i < nblk) {
+            load_rows(i, vq[i], x[i], wl[i]);
+            if (i + NSET < nblk) load_ids(i + NSET, vq[i]);
+        }
+    for (i64 b = 0; b < nblk; b += NSET) {
+#pragma unroll
+        for (int i = 0; i < NSET; i++)
+            if (b + i < nblk) {
+                process(b + i, x[i], wl[i]);
+                if (b + i + NSET < nblk) {
+                    load_rows(b + i + NSET, vq[i], x[i], wl[i]);
+                    if (b + i + 2 * NSET < nblk) load_ids(b + i + 2 * NSET, vq[i]);
+                }
+            }
+    }
+}
+// F[dir][row] = sum over the columns of ss - s1^2 / w from the stored running sums: one wave per row, lane = column
+template <int NS>
+__global__ __launch_bounds__(256) void rss2_eval_kernel(const double *__restrict__ PS, const double *__restrict__ PW, i64 R,
+                                                        double *__restrict__ F) {
+    const i64 r = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; // row of [2][R]
+    const int lane = threadIdx.x & 63;
+    if (r >= 2 * R) return;
+    const double *ps = PS + r * (2 * NS * 64);
+    const double wacc = PW[r];
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const double ss = ps[(2 * s) * 64 + lane], s1 = ps[(2 * s + 1) * 64 + lane];
+        acc += ss - s1 * s1 / wacc; // padded columns are 0
+    }
+    const double f = wave_allsum(acc);
+    if (lane == 0) F[r] = f;
+}
+
 template <int NS>
 __global__ __launch_bounds__(64) void rss2_merge_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                                         const i32 *__restrict__ srows,
@@ -1535,6 +1649,31 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
         c->r2_F.ensure((size_t)2 * R);
         c->r2_ck.ensure((size_t)2 * slots * stride);
         const dim3 gridA((unsigned)n_tasks, 2);
+        // CGE_RSS2_SPLIT=1: the chain by one wave per (group, direction) + a parallel evaluation of all rows (while the stored
+        // running sums stay below 2 GB); default 0 = the four-wave chain kernel of round 2.  Measured (config 2): 3.9 against
+        // 4.25 ms per step -- a single wave cannot pull its rows faster than ~12 GB/s (63 requests in flight), which is what
+        // bounds either form on the longest group; not worth 200 MB of traffic per batch
+        static const int split = getenv("CGE_RSS2_SPLIT") ? atoi(getenv("CGE_RSS2_SPLIT")) : 0;
+        const size_t ps_words = (size_t)2 * R * (2 * ns0 * 64);
+        if (split && ps_words * sizeof(double) <= ((size_t)2 << 30)) {
+            c->r2_PS.ensure(ps_words);
+            c->r2_PW.ensure((size_t)2 * R);
+            const unsigned nbe = (unsigned)((2 * R * 64 + 255) / 256);
+            if (ns0 == 1) {
+                hipLaunchKernelGGL((rss2_prefix_kernel<1>), gridA, dim3(64), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_PS.p,
+                                   c->r2_PW.p, c->r2_ck.p, slots);
+                hipLaunchKernelGGL((rss2_eval_kernel<1>), dim3(nbe), dim3(256), 0, c->stream, c->r2_PS.p, c->r2_PW.p, R, c->r2_F.p);
+                hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+                                   d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+            } else {
+                hipLaunchKernelGGL((rss2_prefix_kernel<2>), gridA, dim3(64), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_PS.p,
+                                   c->r2_PW.p, c->r2_ck.p, slots);
+                hipLaunchKernelGGL((rss2_eval_kernel<2>), dim3(nbe), dim3(256), 0, c->stream, c->r2_PS.p, c->r2_PW.p, R, c->r2_F.p);
+                hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+                                   d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+            }
+            return;
+        }
         if (ns0 == 1) {
             hipLaunchKernelGGL((rss2_chain_kernel<1>), gridA, dim3(256), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
                                c->r2_ck.p, slots);

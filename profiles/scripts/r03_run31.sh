@@ -1,0 +1,22 @@
+set -o pipefail
+export TMPDIR=/tmp
+OUT=gpurun_out/r4c; mkdir -p $OUT
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_cfg2 -- python3 bench.py --workload cfg2 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/trace_cfg2.log 2>&1; echo "rc=$?"
+python3 - <<'PY'
+import csv,glob
+f=glob.glob("gpurun_out/r4c/trace_cfg2/*/*kernel_trace.csv")[0]
+rows=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+idx=[i for i,r in enumerate(rows) if "row_hash_kernel" in r["Kernel_Name"]]
+seq=rows[idx[-1]:]
+from collections import defaultdict
+agg=defaultdict(list)
+for r in seq:
+    nm=r["Kernel_Name"]
+    nm="rocprim_"+("merge" if "merge" in nm else "onesweep" if "onesweep" in nm else "segmented" if "segmented" in nm else "other") if "rocprim" in nm else nm.split("(")[0].replace("void ","")[:40]
+    agg[nm].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
+for k,v in sorted(agg.items(), key=lambda kv:-sum(kv[1]))[:22]:
+    print(f"{k:42s} n={len(v):3d} total={sum(v):8.1f} us  each={[round(x) for x in v[:12]]}")
+span=(int(seq[-1]["End_Timestamp"])-int(seq[0]["Start_Timestamp"]))/1e3
+print("span us", span, "busy", sum(sum(v) for v in agg.values()))
+PY
