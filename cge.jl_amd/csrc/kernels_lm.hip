@@ -1379,6 +1379,124 @@ __global__ __launch_bounds__(256) void rss2_chain_kernel(const double *__restric
     }
 }
 
+// ---- the same chains with the rows SHARED through LDS (round 3) -----------------------------------------------------------
+// rss2_chain_kernel's four waves each load every row of the group themselves.  Here the waves load DIFFERENT blocks: in a round of four blocks (64 rows) wave w fetches block 4r + w into registers (two rounds ahead, two
+// register sets), parks it in LDS, and after one barrier every wave runs its chain over the 64 rows from LDS -- the same
+// additions in the same order, the divisions and tree sums of a block by the wave that owns it, as before.  Same bits.
+// Config 2: 4.24 -> 3.91 ms per step (the loads were not the bound: a wave issues an fp64 instruction per ~5.5 ns when it is
+// alone on its SIMD, and a row costs ~15 of them in the chain plus ~40 per IEEE division in its owner's quarter).
+template <int NS>
+__global__ __launch_bounds__(256) void rss2_chain_lds_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                                             const i32 *__restrict__ srows,
+                                                             const i32 *__restrict__ task_row_off, i64 d, i64 R,
+                                                             double *__restrict__ F /* [2][R] */,
+                                                             double *__restrict__ ck /* [2][slots][2 NS 64 + 64] */, i64 slots) {
+    extern __shared__ __attribute__((aligned(16))) double r2lds[];
+    constexpr int XW = NS * 64; // doubles per row
+    double(*tile)[R2_BR][65] = reinterpret_cast<double(*)[R2_BR][65]>(r2lds);          // [4][16][65]
+    double *xs = r2lds + 4 * R2_BR * 65;                                                // [2][64][XW]
+    double *wsh = xs + 2 * 64 * XW;                                                     // [2][64]
+    const i64 t = blockIdx.x;
+    const int dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    const i32 *p = srows + o;
+    const i64 nblk = (k + R2_BR - 1) / R2_BR, nround = (nblk + 3) / 4, slot0 = o / R2_BR + t;
+    double *Fo = F + (i64)dir * R + o;
+    double *cko = ck + ((i64)dir * slots + slot0) * (2 * NS * 64 + 64);
+    double ss[NS], s1[NS], wacc = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
+    // this wave's block of round r: rows 64 r + 16 wave + (0..15); lane u < 16 keeps the id / weight of row u
+    auto load_block = [&](i64 r, double (&x)[R2_BR][NS], double &wl) {
+        const i64 q = r * 64 + 16 * wave + lane;
+        const bool ok = lane < R2_BR && q < k;
+        const int vq = ok ? p[dir ? k - 1 - q : q] : p[0]; // slots past the end: a valid row with weight 0
+        wl = ok ? vw[vq] : 0.0;
+#pragma unroll
+        for (int u = 0; u < R2_BR; u++) {
+            const i64 v = __builtin_amdgcn_readlane(vq, u);
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const i64 c = lane + 64 * s;
+                x[u][s] = (c < d) ? Xr[v * d + c] : 0.0;
+            }
+        }
+    };
+    auto park = [&](int buf, const double (&x)[R2_BR][NS], const double wl) {
+        double *xb = xs + (size_t)buf * 64 * XW + (size_t)(16 * wave) * XW;
+#pragma unroll
+        for (int u = 0; u < R2_BR; u++)
+#pragma unroll
+            for (int s = 0; s < NS; s++) xb[u * XW + lane + 64 * s] = x[u][s];
+        if (lane < R2_BR) wsh[buf * 64 + 16 * wave + lane] = wl;
+    };
+    auto process = [&](i64 b, const double *xb, const double *wb) { // block b: 16 rows at xb (LDS), their weights at wb
+        const bool mine = (int)(b & 3) == wave;
+        if (mine) { // checkpoint: the triple before this block
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                cko[b * (2 * NS * 64 + 64) + (2 * s) * 64 + lane] = ss[s];
+                cko[b * (2 * NS * 64 + 64) + (2 * s + 1) * 64 + lane] = s1[s];
+            }
+            if (lane == 0) cko[b * (2 * NS * 64 + 64) + 2 * NS * 64] = wacc;
+        }
+#pragma unroll
+        for (int q = 0; q < R2_BR; q++) {
+            const double w = wb[q];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const double xv = xb[q * XW + lane + 64 * s];
+                ss[s] += w * (xv * xv);
+                s1[s] += w * xv;
+            }
+            wacc += w;
+            if (mine) {
+                double acc = 0.0;
+#pragma unroll
+                for (int s = 0; s < NS; s++) acc += ss[s] - s1[s] * s1[s] / wacc; // padded columns are 0
+                tile[wave][q][lane] = acc;
+            }
+        }
+        if (mine) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane < R2_BR) { // wave_allsum's tree: adjacent pairs inside each row of 16 lanes, then ((R0 + R1) + R2) + R3
+                const double *v = tile[wave][lane];
+                double r16[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const double *u = v + 16 * g;
+                    const double a0 = (u[0] + u[1]) + (u[2] + u[3]), a1 = (u[4] + u[5]) + (u[6] + u[7]);
+                    const double a2 = (u[8] + u[9]) + (u[10] + u[11]), a3 = (u[12] + u[13]) + (u[14] + u[15]);
+                    r16[g] = (a0 + a1) + (a2 + a3);
+                }
+                const i64 q = b * R2_BR + lane;
+                if (q < k) Fo[q] = ((r16[0] + r16[1]) + r16[2]) + r16[3];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    double xa[R2_BR][NS], xbq[R2_BR][NS], wa = 0.0, wbq = 0.0;
+    load_block(0, xa, wa);
+    if (1 < nround) load_block(1, xbq, wbq);
+    for (i64 r = 0; r < nround; r++) {
+        const int buf = (int)(r & 1);
+        if (buf == 0) {
+            park(0, xa, wa);
+            if (r + 2 < nround) load_block(r + 2, xa, wa);
+        } else {
+            park(1, xbq, wbq);
+            if (r + 2 < nround) load_block(r + 2, xbq, wbq);
+        }
+        __syncthreads(); // the round's 64 rows are in LDS (and everybody is done with the round that used this buffer before)
+#pragma unroll 1
+        for (int bb = 0; bb < 4; bb++) {
+            const i64 b = 4 * r + bb;
+            if (b >= nblk) break;
+            process(b, xs + (size_t)buf * 64 * XW + (size_t)(16 * bb) * XW, wsh + buf * 64 + 16 * bb);
+        }
+    }
+}
+
 // ---- the same chains in two steps (round 3): the additions by ONE wave per (group, direction), the divisions by everybody ----
 // In rss2_chain_kernel every one of a workgroup's four waves runs the whole chain of additions and pays the divisions and the
 // tree sum for a quarter of the rows: a group of 13 000 rows (config 2's largest community) keeps four waves busy for
@@ -1650,9 +1768,10 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
         c->r2_ck.ensure((size_t)2 * slots * stride);
         const dim3 gridA((unsigned)n_tasks, 2);
         // CGE_RSS2_SPLIT=1: the chain by one wave per (group, direction) + a parallel evaluation of all rows (while the stored
-        // running sums stay below 2 GB); default 0 = the four-wave chain kernel of round 2.  Measured (config 2): 3.9 against
-        // 4.25 ms per step -- a single wave cannot pull its rows faster than ~12 GB/s (63 requests in flight), which is what
-        // bounds either form on the longest group; not worth 200 MB of traffic per batch
+        // running sums stay below 2 GB); default 0.  Measured (config 2): 3.9 against 4.25 ms per step -- what bounds the longest
+        // group is the instruction issue of ONE wave (an fp64 instruction per ~5.5 ns with one wave on its SIMD,
+        // profiles/microbench_dpp_fmac.hip; ~15 instructions per row of the chain, ~40 more per row of IEEE division), whoever
+        // loads the rows; not worth 200 MB of traffic per batch
         static const int split = getenv("CGE_RSS2_SPLIT") ? atoi(getenv("CGE_RSS2_SPLIT")) : 0;
         const size_t ps_words = (size_t)2 * R * (2 * ns0 * 64);
         if (split && ps_words * sizeof(double) <= ((size_t)2 << 30)) {
@@ -1669,6 +1788,26 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
                 hipLaunchKernelGGL((rss2_prefix_kernel<2>), gridA, dim3(64), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_PS.p,
                                    c->r2_PW.p, c->r2_ck.p, slots);
                 hipLaunchKernelGGL((rss2_eval_kernel<2>), dim3(nbe), dim3(256), 0, c->stream, c->r2_PS.p, c->r2_PW.p, R, c->r2_F.p);
+                hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+                                   d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+            }
+            return;
+        }
+        // CGE_RSS2_LDS: 1 (default) = the waves of a chain share the rows through LDS; 0 = every wave loads every row itself
+        static const int lds_form = getenv("CGE_RSS2_LDS") ? atoi(getenv("CGE_RSS2_LDS")) : 1;
+        if (lds_form && ns0 == 1) { // (d <= 64; two 64-row buffers of 128 columns would not fit beside the tree-sum tiles)
+            const size_t lds = (size_t)(4 * R2_BR * 65 + 2 * 64 * ns0 * 64 + 2 * 64) * sizeof(double);
+            static bool attr1 = false, attr2 = false;
+            if (ns0 == 1) {
+                if (!attr1) { (void)hipFuncSetAttribute((const void *)rss2_chain_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+                hipLaunchKernelGGL((rss2_chain_lds_kernel<1>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
+                                   c->r2_ck.p, slots);
+                hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+                                   d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+            } else {
+                if (!attr2) { (void)hipFuncSetAttribute((const void *)rss2_chain_lds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
+                hipLaunchKernelGGL((rss2_chain_lds_kernel<2>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
+                                   c->r2_ck.p, slots);
                 hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
                                    d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
             }
