@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--lazy-landmark-edges", action="store_true",
                     help="leave the N x N landmark-pair matrix / landmark edge count of landmarks() (src/landmarks.jl:433-463) out "
                          "of the timed step (an undirected score does not read it); default: the step builds it")
+    ap.add_argument("--no-back-to-back", action="store_true",
+                    help="skip the 30 back-to-back passes of the per-edge scatter behind the timed region (profiles of the step alone)")
     ap.add_argument("--no-independent", action="store_true",
                     help="N > 1: skip the second measurement (one embedding per GPU, no collective)")
     ap.add_argument("--side-diameter", action="store_true",
@@ -314,7 +316,7 @@ def main():
     # each other -- inside a step the pass starts cold (40 MB of edge words and the tables come from HBM behind the landmark
     # phase's traffic) and the timer also spans the gap between its two launches
     scatter_b2b = None
-    if world == 1 and args.workload != "cfg5":
+    if world == 1 and args.workload != "cfg5" and not args.no_back_to_back:
         try:
             ctx.profile_select(("edge_scatter",))
             ctx.profile_reset()

@@ -82,7 +82,8 @@ __device__ __forceinline__ unsigned long long z_sort_key(double v) {
 __device__ __forceinline__ double z_from_sort_key(unsigned long long key) {
     return __longlong_as_double((long long)((key >> 63) ? (key & 0x7fffffffffffffffULL) : ~key));
 }
-__global__ __launch_bounds__(256) void segment_piece_sort_kernel(const double *__restrict__ z, const i32 *__restrict__ task_row_off,
+#define SEGSORT_T 512
+__global__ __launch_bounds__(SEGSORT_T) void segment_piece_sort_kernel(const double *__restrict__ z, const i32 *__restrict__ task_row_off,
                                                                  int cap, double *__restrict__ zs, i32 *__restrict__ perm,
                                                                  unsigned long long *__restrict__ tkey, i32 *__restrict__ tidx) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skey[]; // [cap] keys, then [cap] indices
@@ -93,33 +94,40 @@ __global__ __launch_bounds__(256) void segment_piece_sort_kernel(const double *_
     const int k = min(SEGSORT_CAP, len - p0);
     int n2 = 1;
     while (n2 < k) n2 <<= 1;
-    for (int i = tid; i < n2; i += 256) {
+    for (int i = tid; i < n2; i += SEGSORT_T) {
         skey[i] = i < k ? z_sort_key(z[o + p0 + i]) : ~0ULL;
         sidx[i] = i < k ? p0 + i : 0x7fffffff;
     }
     __syncthreads();
     for (int size = 2; size <= n2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (n2 >> 1); i += 256) {
-                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned long long ka = skey[lo], kb = skey[hi];
-                const int ia = sidx[lo], ib = sidx[hi];
-                const bool gt = ka > kb || (ka == kb && ia > ib);
-                if (gt == up) {
-                    skey[lo] = kb; skey[hi] = ka;
-                    sidx[lo] = ib; sidx[hi] = ia;
+            // two compare-exchanges per trip: their eight LDS reads are in flight together
+            for (int i = tid; i < (n2 >> 1); i += 2 * SEGSORT_T) {
+                const int j = i + SEGSORT_T;
+                const bool two = j < (n2 >> 1);
+                const int lo0 = 2 * i - (i & (stride - 1)), hi0 = lo0 + stride;
+                const int lo1 = two ? 2 * j - (j & (stride - 1)) : lo0, hi1 = lo1 + stride;
+                const unsigned long long ka0 = skey[lo0], kb0 = skey[hi0], ka1 = skey[lo1], kb1 = skey[hi1];
+                const int ia0 = sidx[lo0], ib0 = sidx[hi0], ia1 = sidx[lo1], ib1 = sidx[hi1];
+                const bool gt0 = ka0 > kb0 || (ka0 == kb0 && ia0 > ib0), gt1 = ka1 > kb1 || (ka1 == kb1 && ia1 > ib1);
+                if (gt0 == ((lo0 & size) == 0)) {
+                    skey[lo0] = kb0; skey[hi0] = ka0;
+                    sidx[lo0] = ib0; sidx[hi0] = ia0;
+                }
+                if (two && gt1 == ((lo1 & size) == 0)) {
+                    skey[lo1] = kb1; skey[hi1] = ka1;
+                    sidx[lo1] = ib1; sidx[hi1] = ia1;
                 }
             }
             __syncthreads();
         }
     if (len <= SEGSORT_CAP) { // the whole group: done
-        for (int i = tid; i < k; i += 256) {
+        for (int i = tid; i < k; i += SEGSORT_T) {
             zs[o + i] = z_from_sort_key(skey[i]);
             perm[o + i] = sidx[i];
         }
     } else {
-        for (int i = tid; i < k; i += 256) {
+        for (int i = tid; i < k; i += SEGSORT_T) {
             tkey[o + p0 + i] = skey[i];
             tidx[o + p0 + i] = sidx[i];
         }
@@ -169,7 +177,7 @@ void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void *)segment_piece_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEGSORT_CAP * 12); attr = true; }
         if (npieces > 1) { c->sort_k64.ensure(R); c->sort_idx2.ensure(R); }
-        hipLaunchKernelGGL(segment_piece_sort_kernel, dim3((unsigned)T, npieces), dim3(256), (size_t)cap * 12, c->stream, z, task_row_off, cap,
+        hipLaunchKernelGGL(segment_piece_sort_kernel, dim3((unsigned)T, npieces), dim3(SEGSORT_T), (size_t)cap * 12, c->stream, z, task_row_off, cap,
                            zs, perm, c->sort_k64.p, c->sort_idx2.p);
         if (npieces > 1)
             hipLaunchKernelGGL(segment_rank_merge_kernel, dim3(nb), dim3(256), 0, c->stream, c->sort_k64.p, c->sort_idx2.p, row_task,

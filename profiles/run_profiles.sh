@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p "$OUT"
 cd "$ROOT"
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-back-to-back $*"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS > "$OUT/bench_stats.json" 2> "$OUT/stats.err" || { echo "stats pass: non-zero exit"; tail -30 "$OUT/stats.err"; exit 1; }
 ls "$OUT"/stats/*/*_kernel_stats.csv > /dev/null 2>&1 || { echo "stats pass produced no output"; tail -5 "$OUT/stats.err"; exit 1; }
 timeout -k 10 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err" || { echo "fetch pass: non-zero exit"; tail -30 "$OUT/fetch.err"; exit 1; }

@@ -13,7 +13,7 @@ for w in cfg2 cfg3 cfg4; do
   timeout -k 10 300 python bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "$w rc=$?"
 done
 timeout -k 10 600 python bench.py --workload cfg5 --steps 3 --warmup 1 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; echo "cfg5 rc=$?"
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_cfg4 -- python3 bench.py --workload cfg4 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/trace_cfg4.log 2>&1; echo "cfg4 trace rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_cfg4 -- python3 bench.py --workload cfg4 --steps 1 --warmup 1 --no-cpu-baseline --no-back-to-back > $OUT/trace_cfg4.log 2>&1; echo "cfg4 trace rc=$?"
 python3 profiles/timeline_gaps.py $OUT/trace_cfg4 0.5 > $OUT/timeline_gaps_cfg4.txt 2>&1
 find gpurun_out -name "*_kernel_trace.csv" -size +6M -delete
 find gpurun_out -name "*_counter_collection.csv" -size +6M -delete
