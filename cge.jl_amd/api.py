@@ -383,6 +383,14 @@ class Context:
         self._check(self.L.cge_pow_test(self.h, _p(x), C.c_int64(x.size), C.c_double(alpha), C.c_int(method), _p(out)))
         return out
 
+    def segment_sort_test(self, z, offsets):
+        """Testing hook: the per-group stable sort of runsplit's projections; returns (sorted z, local permutation)."""
+        z = _f64(z)
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        zs, perm = np.empty_like(z), np.empty(z.size, dtype=np.int32)
+        self._check(self.L.cge_segment_sort_test(self.h, _p(z), _p(off), C.c_int64(off.size - 1), _p(zs), _p(perm)))
+        return zs, perm
+
     def wave_tree_test(self, x):
         """Testing hook: per row of 64 doubles the shuffle-tree sum and the lane-swap sum of the projection kernel."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 64)

@@ -1450,6 +1450,35 @@ int cge_pow_test(void *ctx, const double *x, int64_t n, double alpha, int method
     CGE_CATCH(c)
 }
 
+// testing hook (include/cge_hip_testing.h): the per-group stable sort of the projections as runsplit calls it
+int cge_segment_sort_test(void *ctx, const double *z, const int32_t *task_row_off, int64_t T, double *zs_out, int32_t *perm_out) {
+    cge_ctx *c = (cge_ctx *)ctx;
+    if (!c || !z || !task_row_off || !zs_out || !perm_out || T <= 0) return CGE_E_ARG;
+    CGE_TRY(c)
+    HIP_CHECK(hipSetDevice(c->device));
+    const i64 R = task_row_off[T];
+    if (R <= 0) CGE_THROW(CGE_E_ARG, "segment_sort_test: no rows");
+    std::vector<i32> rt(R), rows(R);
+    i64 max_len = 0;
+    for (i64 t = 0; t < T; t++) {
+        if (task_row_off[t + 1] <= task_row_off[t]) CGE_THROW(CGE_E_ARG, "segment_sort_test: empty group");
+        max_len = std::max<i64>(max_len, task_row_off[t + 1] - task_row_off[t]);
+        for (i64 j = task_row_off[t]; j < task_row_off[t + 1]; j++) { rt[j] = (i32)t; rows[j] = (i32)j; }
+    }
+    DevBuf<double> dz, dzs;
+    DevBuf<i32> dtro, drt, drows, dperm, dsrows, dstatus;
+    dz.ensure(R); dzs.ensure(R); dtro.ensure(T + 1); drt.ensure(R); drows.ensure(R); dperm.ensure(R); dsrows.ensure(R); dstatus.ensure(T);
+    HIP_CHECK(hipMemcpyAsync(dz.p, z, sizeof(double) * R, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(dtro.p, task_row_off, sizeof(i32) * (T + 1), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(drt.p, rt.data(), sizeof(i32) * R, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(drows.p, rows.data(), sizeof(i32) * R, hipMemcpyHostToDevice, c->stream));
+    k_segmented_sort_z(c, dz.p, drows.p, drt.p, dtro.p, R, T, dzs.p, dperm.p, dsrows.p, dstatus.p, max_len);
+    HIP_CHECK(hipMemcpyAsync(zs_out, dzs.p, sizeof(double) * R, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(perm_out, dperm.p, sizeof(i32) * R, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    CGE_CATCH(c)
+}
+
 // testing hook (include/cge_hip_testing.h): lane 0's sum of 64 values per row by the shfl_down tree and by the VALU lane
 // swaps that replace it in the projection kernel -- the same bits are expected
 int cge_wave_tree_test(void *ctx, const double *x, int64_t n_rows, double *out_ref, double *out_new) {

@@ -67,20 +67,18 @@ __global__ void finish_two_pass_kernel(const i32 *__restrict__ pos, const double
     perm[j] = p - task_row_off[row_task[p]];
 }
 // Per-group sort of (z, local index) pairs without a device-wide sort.  A group is cut into pieces of SEGSORT_CAP rows; one
-// workgroup sorts a piece in LDS by a bitonic network on the radix order of the doubles (sign-flipped bit patterns: -0 before
-// +0, NaNs at the two ends -- the order of rocPRIM's radix sort and of Julia's isless), ties by index, i.e. the permutation of
-// a stable sort.  A group of one piece is finished there; the pieces of a longer group are merged by RANK: every element
+// workgroup sorts a piece in LDS by a bitonic network on the radix order of the doubles (sign-flipped bit patterns, -0 taken
+// as +0, NaNs at the two ends -- the order of rocPRIM's radix sort, which the other batches use), ties by index, i.e. the
+// permutation of a stable sort.  A group of one piece is finished there; the pieces of a longer group are merged by RANK: every element
 // counts, by a binary search in each of the other sorted pieces of its group, how many elements precede it in the (key,
 // index) order and goes straight to its final place.  For the batches of long groups this replaces two device-wide sorts of
 // all rows (a 64-bit merge sort in ~20 launches, then a radix sort by task: 0.35 ms per batch) by two launches.
 #define SEGSORT_CAP 4096
 #define SEGSORT_MAXPIECES 8
 __device__ __forceinline__ unsigned long long z_sort_key(double v) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    if (b == 0x8000000000000000ULL) b = 0ULL; // -0.0 sorts as +0.0 (rocPRIM's radix sort and the oracle's `<` agree on that)
     return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
-}
-__device__ __forceinline__ double z_from_sort_key(unsigned long long key) {
-    return __longlong_as_double((long long)((key >> 63) ? (key & 0x7fffffffffffffffULL) : ~key));
 }
 #define SEGSORT_T 512
 __global__ __launch_bounds__(SEGSORT_T) void segment_piece_sort_kernel(const double *__restrict__ z, const i32 *__restrict__ task_row_off,
@@ -123,7 +121,7 @@ __global__ __launch_bounds__(SEGSORT_T) void segment_piece_sort_kernel(const dou
         }
     if (len <= SEGSORT_CAP) { // the whole group: done
         for (int i = tid; i < k; i += SEGSORT_T) {
-            zs[o + i] = z_from_sort_key(skey[i]);
+            zs[o + i] = z[o + sidx[i]]; // (the value itself: the key has lost the sign of a zero)
             perm[o + i] = sidx[i];
         }
     } else {
@@ -133,9 +131,10 @@ __global__ __launch_bounds__(SEGSORT_T) void segment_piece_sort_kernel(const dou
         }
     }
 }
-__global__ __launch_bounds__(256) void segment_rank_merge_kernel(const unsigned long long *__restrict__ tkey, const i32 *__restrict__ tidx,
-                                                                 const i32 *__restrict__ row_task, const i32 *__restrict__ task_row_off,
-                                                                 i64 R, double *__restrict__ zs, i32 *__restrict__ perm) {
+__global__ __launch_bounds__(256) void segment_rank_merge_kernel(const double *__restrict__ z, const unsigned long long *__restrict__ tkey,
+                                                                 const i32 *__restrict__ tidx, const i32 *__restrict__ row_task,
+                                                                 const i32 *__restrict__ task_row_off, i64 R, double *__restrict__ zs,
+                                                                 i32 *__restrict__ perm) {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= R) return;
     const i32 t = row_task[j];
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(256) void segment_rank_merge_kernel(const unsigned 
         }
         rank += lo;
     }
-    zs[o + rank] = z_from_sort_key(key);
+    zs[o + rank] = z[o + ix];
     perm[o + rank] = ix;
 }
 void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 *row_task, const i32 *task_row_off,
@@ -180,7 +179,7 @@ void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 
         hipLaunchKernelGGL(segment_piece_sort_kernel, dim3((unsigned)T, npieces), dim3(SEGSORT_T), (size_t)cap * 12, c->stream, z, task_row_off, cap,
                            zs, perm, c->sort_k64.p, c->sort_idx2.p);
         if (npieces > 1)
-            hipLaunchKernelGGL(segment_rank_merge_kernel, dim3(nb), dim3(256), 0, c->stream, c->sort_k64.p, c->sort_idx2.p, row_task,
+            hipLaunchKernelGGL(segment_rank_merge_kernel, dim3(nb), dim3(256), 0, c->stream, z, c->sort_k64.p, c->sort_idx2.p, row_task,
                                task_row_off, R, zs, perm);
     } else if (long_groups) {
         // Few long segments: the segmented sort walks each of them alone through all its radix passes.  Two device-wide

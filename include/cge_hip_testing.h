@@ -21,6 +21,11 @@ int cge_pow_test(void *ctx, const double *x, int64_t n, double alpha, int method
 /* needs the GPU and a communicator (cge_comm_init_rccl; one rank is enough): host array -> device -> the in-library
  * ncclAllReduce (op 0 sum / 1 max of doubles, 2 sum of the words as int64) -> host */
 int cge_rccl_selftest(void *ctx, double *host_inout, int64_t count, int op);
+/* kernel-level hook (needs the GPU): the per-group ascending STABLE sort of the projections as runsplit calls it (LDS pieces
+ * + rank merge for long groups, rocPRIM otherwise): group t = rows [task_row_off[t], task_row_off[t+1]) of z; zs_out = sorted
+ * values, perm_out[j] = index INSIDE its group of the element at sorted position j.  Order: ascending, -0.0 == 0.0, ties by
+ * index (a group with NaNs is routed to the host path by its status) */
+int cge_segment_sort_test(void *ctx, const double *z, const int32_t *task_row_off, int64_t T, double *zs_out, int32_t *perm_out);
 /* kernel-level hook (needs the GPU): per row of 64 doubles, lane 0's sum by the shuffle tree (out_ref) and by the gfx950
  * lane swaps the projection kernel uses instead (out_new): the same pairs in the same order, so the same bits */
 int cge_wave_tree_test(void *ctx, const double *x, int64_t n_rows, double *out_ref, double *out_new);

@@ -1295,3 +1295,31 @@ def test_projection_reduction_keeps_the_shuffle_tree_bits(ctx):
     for off in (32, 16, 8, 4, 2, 1):
         t = t[:, :off] + t[:, off:2 * off]
     assert np.array_equal(t[:, 0], a)
+
+
+@pytest.mark.parametrize("mode", ["long", "short", "huge"])
+def test_per_group_sort_is_the_stable_isless_sort(ctx, mode):
+    """k_segmented_sort_z: groups sorted where they lie -- pieces of 4096 rows by a bitonic network in LDS, longer groups merged
+    by rank (`long`), rocPRIM's segmented radix sort for batches of short groups (`short`), the device-wide pair of sorts when a
+    group exceeds eight pieces (`huge`).  All must give the permutation of a STABLE ascending sort with -0.0 == 0.0 (the
+    oracle's `<`; ties -- many: the values are drawn from a small set -- by index), and hand back the values' own bits."""
+    rng = np.random.default_rng(11)
+    lens = {"long": [4096, 4097, 1, 2, 9000, 21530, 777, 8192, 12289, 5000],
+            "short": [rng.integers(1, 700) for _ in range(400)],
+            "huge": [40000, 3000, 5000]}[mode]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    R = int(off[-1])
+    z = rng.standard_normal(R)
+    ties = rng.random(R) < 0.3
+    z[ties] = rng.choice([0.0, -0.0, 1.5, -2.25, 1e-300, -1e300], ties.sum())
+    zs, perm = ctx.segment_sort_test(z, off)
+    key = z.view(np.uint64).copy()
+    key[key == np.uint64(1) << np.uint64(63)] = 0  # -0.0 sorts as 0.0
+    neg = (key >> np.uint64(63)) == 1
+    key[neg] = ~key[neg]
+    key[~neg] |= np.uint64(1) << np.uint64(63)
+    for t in range(len(lens)):
+        a, b = int(off[t]), int(off[t + 1])
+        order = np.argsort(key[a:b], kind="stable")
+        assert np.array_equal(perm[a:b], order.astype(np.int32)), (mode, t, lens[t])
+        assert np.array_equal(zs[a:b].view(np.uint64), z[a:b][order].view(np.uint64))
