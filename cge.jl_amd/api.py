@@ -73,9 +73,11 @@ class Collectives(C.Structure):
 
 
 # Live contexts are closed from an `atexit` hook: it runs inside Py_Finalize, i.e. BEFORE the C-level exit handlers
-# of the HIP runtime and of a profiler's tool library.  A context that is still alive when those run leaves streams and
-# events behind that the runtime then destroys after the profiler has finalised its HSA hooks -- the exit-time SIGSEGV
-# recorded in round 1 (gpurun_out/prof_r01f/stats.err: exit -> a library's exit handler -> a second library).
+# of the HIP runtime and of a profiler's tool library, so no stream or event of this library is left for the runtime to
+# destroy after a profiler has finalised its HSA hooks.  DEFENCE IN DEPTH ONLY: it is NOT an established fix for the
+# exit-time SIGSEGV under rocprofv3 recorded in round 1 -- a probe that left a context alive with this hook disabled exited
+# cleanly, so the cause of that fault is still unproven (the cooperative launches that build used
+# are gone; the fault has not reappeared in any record since).
 _live = weakref.WeakSet()
 _atexit_registered = False
 
