@@ -737,11 +737,14 @@ void rule_rss_sorted_enqueue(LaneRun &L) {
                  T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p, c->lm_means.p + L.mbase); // the children's means stay on the device
     k_rss_child_keys(c, c->sp_perm.p, c->ls_row_task.p, c->sp_tro.p, c->sp_meta.p, c->sp_rounds.p, R, T, c->ls_keys.p,
                      c->ls_nlow.p);
-    k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + L.base);
+    // what the host needs for the heap (status, rounds, children values and sizes) is fetched BEFORE the children's member
+    // lists are written: the host replays the heap and builds the next batch while that sort still runs (it only feeds the
+    // device-side arena; the next batch queues behind it on the same stream)
     L.wg.reset(new WordGatherer(c));
     L.i_status = L.wg->add(c->sp_status.p, T); L.i_meta = L.wg->add(c->sp_meta.p, 2 * T);
     L.i_vals = L.wg->add(c->sp_vals.p, 2 * T); L.i_nlow = L.wg->add(c->ls_nlow.p, T);
     L.wg->fetch_async();
+    k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + L.base);
 }
 void rule_rss_sorted_collect(LaneRun &L) {
     const i64 T = L.B.T, d = L.x->d;
@@ -813,7 +816,6 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
     c->ls_nlow.ensure(T);
     k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p);
     k_side_counts(c, c->ls_side.p, c->sp_tro.p, T, c->ls_nlow.p);
-    k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + L.base);
     c->pin_res.ensure((size_t)T); // pinned: the copies do not stall the host, the event below covers them
     HIP_CHECK(hipMemcpyAsync(c->pin_res.p, c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
     k_group_side_sums(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
@@ -821,6 +823,8 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
     c->pin_sums.ensure((size_t)B.T * width);
     HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->ls_sums.p, sizeof(double) * B.T * width, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(c->copy_done, st));
+    // the children's member lists last: the host already has what its heap needs and builds the next batch meanwhile
+    k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + L.base);
 }
 void rule_cut_collect(LaneRun &L) {
     cge_ctx *c = L.x;
