@@ -1319,6 +1319,11 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_landmark_edges = value != 0; // (src/landmarks.jl:433-463; the undirected score itself does not read it); 0 (default): on first fetch
         return CGE_OK;
     }
+    if (!strcmp(key, "fit_persistent_test_delay")) { // testing: start skew of the persistent fits' tile waves, in naps of ~3 us
+        if (value < 0 || value > 100000) return CGE_E_ARG;
+        c->opt_fit_test_delay = (int)value;
+        return CGE_OK;
+    }
     if (!strcmp(key, "fit_persistent_test_timeout")) { // testing: 1 = the persistent fit abandons every launch at once
         c->opt_fit_test_timeout = value != 0;
         return CGE_OK;

@@ -321,6 +321,8 @@ struct cge_ctx {
                                    // size / diameter (their cuts are unbalanced, a speculative split is wasted more often:
                                    // config 3 68.4 -> 63.8 ms per step)
     int opt_fit_test_timeout = 0; // testing: the persistent fit gives up at once, so the fallback path runs
+    int opt_fit_test_delay = 0;   // testing: the tile waves of the data-as-signal fits nap this many times (~3 us each) before
+                                  // their first load -- start skew, as under contention; results must not change
     i64 stat_lm_batches = 0, stat_lm_rows = 0, stat_lm_splits = 0; // last runsplit: device batches, their rows, groups split
     i64 stat_cov_derived = 0; // ... sibling pairs whose covariances were derived from the parent's
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep

@@ -461,11 +461,13 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
 __device__ __forceinline__ bool armed(double v) { return (unsigned long long)__double_as_longlong(v) == FLOW_SENTINEL; }
 __device__ __forceinline__ double sentinel() { return __longlong_as_double((long long)FLOW_SENTINEL); }
 // every 64th unsuccessful poll: 1 = the fit is over, 2 = abandoned (wave-uniform)
+// (`done` / `fail` are armed with the sentinel word like everything else of these kernels' buffers: they are SET when they
+// hold 1 -- testing them against zero, as rounds 1-2 did, made every wait of more than 64 polls end the fit as "converged")
 __device__ __forceinline__ int flow_check(unsigned &spins, unsigned *fail, unsigned *done, long long deadline) {
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 63u) != 0) return 0;
-    if (__hip_atomic_load(done, RLX_AGENT) != 0u) return 1;
-    if (wall_clock64() > deadline || __hip_atomic_load(fail, RLX_AGENT) != 0u) {
+    if (__hip_atomic_load(done, RLX_AGENT) == 1u) return 1;
+    if (wall_clock64() > deadline || __hip_atomic_load(fail, RLX_AGENT) == 1u) {
         __hip_atomic_store(fail, 1u, RLX_AGENT);
         return 2;
     }
@@ -505,7 +507,7 @@ template <int TPW, int NW>
 __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restrict__ GD, i64 N, int Nt, const double *T0,
                                                             double *Tout, i64 Tld, const double *__restrict__ w, double eps,
                                                             double delta, int max_iters, double *ring, double *P, double *fq,
-                                                            unsigned *sync, int *flags, long long timeout_ticks) {
+                                                            unsigned *sync, int *flags, long long timeout_ticks, int test_naps) {
     constexpr int NSB = 2; // quarter blocks per workgroup at most (4*Nt <= 2*G, checked by the host)
     __shared__ double red[2][NSB][16][17]; // by the parity of k: no barrier is needed to recycle it
     __shared__ double fred[2][4];
@@ -521,6 +523,8 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
 
     double g[TPW][8][8];
     int tI[TPW], tJ[TPW];
+    if (test_naps > 0 && (wg * NW + wave) < NT) // testing (option fit_persistent_test_delay): the tile waves start late
+        for (int q = 0; q < test_naps; q++) __builtin_amdgcn_s_sleep(127);
 #pragma unroll
     for (int s = 0; s < TPW; s++) {
         const int t = (wg * NW + wave) + s * NW * G;
@@ -1043,7 +1047,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__r
                                                                 const double *__restrict__ deg_out, double eps0, double f0,
                                                                 double delta, int max_iters, double *ring, double *P,
                                                                 double *fq, unsigned *sync, int *flags,
-                                                                long long timeout_ticks) {
+                                                                long long timeout_ticks, int test_naps) {
     __shared__ double red[2][NSB][2][16][17]; // [parity of k][quarter block][Sin / Sout]
     __shared__ double fred[2][4];
     __shared__ __attribute__((aligned(16))) double tsh[NW][4][64];          // Tin_I, Tout_I, Tin_J, Tout_J
@@ -1058,6 +1062,8 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_dir_kernel(const double *__r
 
     double g[8][8];
     int tI = -1, tJ = -1;
+    if (test_naps > 0 && (wg * NW + wave) < NT) // testing (option fit_persistent_test_delay): the tile waves start late
+        for (int q = 0; q < test_naps; q++) __builtin_amdgcn_s_sleep(127);
     {
         const int t = wg * NW + wave;
         if (t < NT) {
@@ -1360,7 +1366,9 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
     unsigned *aSync = (unsigned *)c->fp_flow.p;
     int *aFlags = dev_flags;
     long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS; // per iteration (0: the test hook)
-    void *args[] = {&aGD, &aN, &aNt, &aT0, &aTout, &aTld, &aW, &aEps, &aDelta, &aMax, &aRing, &aP, &aFq, &aSync, &aFlags, &aTicks};
+    int aNaps = c->opt_fit_test_delay;
+    void *args[] = {&aGD, &aN, &aNt, &aT0, &aTout, &aTld, &aW, &aEps, &aDelta, &aMax, &aRing, &aP, &aFq, &aSync, &aFlags, &aTicks,
+                    &aNaps};
     hipError_t e;
     {
         ScopedKernelTimer tm(c, "fit_persistent");
@@ -1489,8 +1497,9 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
                 unsigned *aSync = (unsigned *)c->fp_flow.p;
                 int *aFlags = dev_flags ? dev_flags : c->fp_flags.p;
                 long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS;
+                int aNaps = c->opt_fit_test_delay;
                 void *args[] = {&aGD, &aN, &aNt, &aT0, &aTi, &aTo, &aTld, &aDi, &aDo, &aEps, &aF0, &aDelta, &aMax, &aRing, &aP, &aFq,
-                                &aSync, &aFlags, &aTicks};
+                                &aSync, &aFlags, &aTicks, &aNaps};
                 hipError_t e;
                 {
                     ScopedKernelTimer tm(c, "fit_persistent");

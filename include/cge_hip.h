@@ -234,6 +234,9 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             results; measured slower or equal on every workload.
  * "runsplit_lanes": 2 = every batch of runsplit as two half-batches on two streams, half a chain out of phase; 1 (default).
  *             Same results.
+ * "fit_persistent_test_delay": testing -- the tile waves of the persistent fits nap n x ~3 us before their first load (start skew,
+ *             as under contention); results must not depend on it.  "fit_persistent_test_timeout": testing -- 1 = the persistent
+ *             fit abandons every launch at once (the fallback path runs).
  * "cov_derive": 1 = runsplit takes the covariance of the larger child of a split as parent - sibling (the smaller child is
  *             still summed over its rows); 0 (default).  Same landmark ids; measured no faster.
  * "shard_ingest": N > 1, set AFTER the collectives (cge_comm_init_rccl / cge_set_collectives) and BEFORE the uploads:

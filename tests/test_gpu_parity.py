@@ -1323,3 +1323,27 @@ def test_per_group_sort_is_the_stable_isless_sort(ctx, mode):
         order = np.argsort(key[a:b], kind="stable")
         assert np.array_equal(perm[a:b], order.astype(np.int32)), (mode, t, lens[t])
         assert np.array_equal(zs[a:b].view(np.uint64), z[a:b][order].view(np.uint64))
+
+
+@pytest.mark.parametrize("directed", [False, True])
+def test_persistent_fit_survives_start_skew(ctx, directed):
+    """The data-as-signal fits must not care when their workgroups start.  Rounds 1-2 tested their `done` / `fail` words
+    against zero although the launch arms them with the sentinel pattern, so ANY hand-off wait of more than 64 polls ended the
+    fit as "converged" -- silently, with the iterate of that moment.  Healthy runs never wait that long; a late workgroup does.
+    Option fit_persistent_test_delay makes the tile waves nap ~60 us before their first load: same iteration counts, same bits."""
+    from cge.jl_amd import synth
+
+    g = synth.abcd_like(20000, 200000, 30, 16, seed=33, directed=directed)
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    try:
+        ctx.set_option("fit_persistent", 2)
+        ref = ctx.score(g["clusters"], 300, 2, "rss", directed=directed, seed=3, auc_samples=3000)
+        it_ref, n_ref = list(ctx.last_trace["iters"]), ctx.get_stat("fit_persistent_alphas")
+        ctx.set_option("fit_persistent_test_delay", 20)
+        got = ctx.score(g["clusters"], 300, 2, "rss", directed=directed, seed=3, auc_samples=3000)
+        assert n_ref > 0 and ctx.get_stat("fit_persistent_alphas") == n_ref  # the persistent form ran, and was not abandoned
+        assert list(ctx.last_trace["iters"]) == it_ref
+        assert np.array_equal(got, ref)
+    finally:
+        ctx.set_option("fit_persistent_test_delay", 0)
+        ctx.set_option("fit_persistent", 0)
