@@ -73,12 +73,16 @@ def main():
                     p + "lcomm": lcomm[:, 0], p + "lemb_crc": crc(lemb), p + "ledges_crc": crc(ledges),
                     p + "lw_crc": crc(lw), p + "n_ledges": len(lw), p + "result": res, p + "iters": np.array(tr["iters"]),
                     p + "div": np.array(tr["div"]), p + "auc": np.array(tr["auc"])})
+        save(out, times, t_hi, small, which)  # after every rule: a rule of the larger variants is hours of one core
+
+
+def save(out, times, t_hi, small, which):
+    """The fixture with the rules finished so far (the GPU test skips a rule whose keys are missing)."""
+    prov = ("oracle/cge_oracle.c (CPU restatement), tests/golden/make_oracle_fixture_d512.py; diameter "
+            f"{t_hi:.0f} s; " + "; ".join(f"{m}: landmarks {t[0]:.0f} s + wGCL {t[1]:.0f} s" for m, t in times.items()) + "; one core")
     np.savez_compressed(
         os.path.join(ROOT, "tests", "golden", "oracle_d512_small.npz" if small else "oracle_d512_quick.npz" if which == "quick" else "oracle_d512.npz"),
-        provenance=np.array("oracle/cge_oracle.c (CPU restatement), tests/golden/make_oracle_fixture_d512.py; diameter "
-                            f"{t_hi:.0f} s; rss: landmarks {times['rss'][0]:.0f} s + wGCL {times['rss'][1]:.0f} s; diameter "
-                            f"rule: landmarks {times['diameter'][0]:.0f} s + wGCL {times['diameter'][1]:.0f} s; one core"),
-        **out)
+        provenance=np.array(prov), **out)
 
 
 if __name__ == "__main__":
