@@ -117,6 +117,8 @@ int cge_create(cge_ctx **out, int device, void *stream) {
         unsigned hc = std::thread::hardware_concurrency();
         c->n_threads = (int)std::max(1u, std::min(hc ? hc : 8u, 16u));
         c->pool = new ThreadPool(c->n_threads - 1);
+        if (const char *nap = getenv("CGE_FIT_TEST_DELAY")) // stress runs: option fit_persistent_test_delay for every context
+            c->opt_fit_test_delay = std::max(0, std::min(atoi(nap), 100000));
     } catch (const CgeError &e) {
         delete c;
         return e.code;
