@@ -117,8 +117,15 @@ int cge_create(cge_ctx **out, int device, void *stream) {
         unsigned hc = std::thread::hardware_concurrency();
         c->n_threads = (int)std::max(1u, std::min(hc ? hc : 8u, 16u));
         c->pool = new ThreadPool(c->n_threads - 1);
-        if (const char *nap = getenv("CGE_FIT_TEST_DELAY")) // stress runs: option fit_persistent_test_delay for every context
-            c->opt_fit_test_delay = std::max(0, std::min(atoi(nap), 100000));
+        if (const char *nap = getenv("CGE_FIT_TEST_DELAY")) { // stress runs of whole suites: option fit_persistent_test_delay for
+            // every context.  A testing knob in a production path: clamped to 2000 naps (~6 ms, far below the 1 s hand-off
+            // deadline, so it can never force the time-out path) and announced once per process.
+            c->opt_fit_test_delay = std::max(0, std::min(atoi(nap), 2000));
+            static std::atomic<bool> told{false};
+            if (c->opt_fit_test_delay > 0 && !told.exchange(true))
+                fprintf(stderr, "cge: CGE_FIT_TEST_DELAY=%d is set: every persistent fit starts its tile waves late (testing knob)\n",
+                        c->opt_fit_test_delay);
+        }
     } catch (const CgeError &e) {
         delete c;
         return e.code;

@@ -44,6 +44,33 @@ struct CgeError {
                       hipGetErrorString(_e), __FILE__, __LINE__);                                       \
     } while (0)
 
+// Every kernel launch of the library is followed by hipGetLastError: a refused launch (dynamic LDS beyond what the device
+// grants, a bad grid) raises CGE_E_HIP instead of leaving the output at its memset zeros.
+inline void cge_launch_check(const char *what, const char *file, int line) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) CGE_THROW(CGE_E_HIP, "launch of %s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                         \
+    do {                                                            \
+        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);      \
+        cge_launch_check(#kernelName, __FILE__, __LINE__);          \
+    } while (0)
+
+// Dynamic LDS beyond 64 KB has to be granted per kernel AND per device (the attribute belongs to the function's code object on
+// the current device); the grant is checked.
+inline void cge_allow_lds(const void *fn, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> done;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(mu);
+    auto it = done.find({fn, dev});
+    if (it != done.end() && it->second >= bytes) return;
+    HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done[{fn, dev}] = bytes;
+}
+
 // RAII device buffer
 template <typename T>
 struct DevBuf {
@@ -434,7 +461,7 @@ struct cge_ctx {
     DevBuf<i64> wed_cnt;
     DevBuf<double> cc_dense; // dense C x C stage of vect_C beyond 2048 communities (tiled two-pass form)
     DevBuf<unsigned> samp_attempt;
-    DevBuf<i32> samp_todo_a, samp_todo_b, samp_hit;
+    DevBuf<i32> samp_todo_a, samp_todo_b, samp_hit, samp_flag;
     DevBuf<unsigned long long> samp_table, samp_count;
     SampleSet smp;                 // library-drawn samples of the running score
     std::vector<std::unique_ptr<DevSamples>> dsets; // their device form (wgcl_host.cpp)

@@ -101,7 +101,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     c->Pm.ensure((size_t)N * nref);
     // the maxima as upper bounds from a low-precision matrix pass (kernels_dist.hip (2b), (2c)) or exactly in fp64
     bool b16 = c->opt_diameter_f32 >= 2 && k_pcent_bf16_applies(dpad);
-    const bool f32 = c->opt_diameter_f32 != 0 && !b16;
+    bool f32 = c->opt_diameter_f32 != 0 && !b16;
     const i64 KP = (dpad + 31) / 32 * 32;
     if (f32) {
         c->Xs32.ensure((size_t)lds_rows * dpad);
@@ -110,19 +110,26 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     if (b16) {
         c->Xb16.ensure((size_t)2 * lds_rows * KP);
         c->Mb16.ensure((size_t)2 * ldm * KP);
+    }
+    const bool lowp = b16 || f32;
+    if (lowp) {
         c->dm_flag.ensure(1);
         HIP_CHECK(hipMemsetAsync(c->dm_flag.p, 0, sizeof(int), st));
     }
     k_gather_centre_fm(c, c->Xr.p, c->pos2node.p, c->gmean.p, c->Xs.p, c->rns.p, npos, d, lds_rows, dpad, f32 ? c->Xs32.p : nullptr,
-                       b16 ? c->Xb16.p : nullptr, KP, c->dm_flag.p);
+                       b16 ? c->Xb16.p : nullptr, KP, lowp ? c->dm_flag.p : nullptr);
     k_gather_centre_fm(c, mu_ref, nullptr, c->gmean.p, c->Ms.p, c->mnorm.p, nref, d, ldm, dpad, f32 ? c->Ms32.p : nullptr,
-                       b16 ? c->Mb16.p : nullptr, KP, c->dm_flag.p);
+                       b16 ? c->Mb16.p : nullptr, KP, lowp ? c->dm_flag.p : nullptr);
     int unfit = 0;
-    if (b16) HIP_CHECK(hipMemcpyAsync(&unfit, c->dm_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (lowp) HIP_CHECK(hipMemcpyAsync(&unfit, c->dm_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
     // the seed of the farthest-point sweep: the vertex farthest from the centre (largest squared norm of the centred rows, just
     // computed by the gather); its read-back is the synchronisation the flag needs anyway
     const i64 seed_vertex = k_argmax_mapped(c, c->rns.p, npos, c->pos2node.p);
-    if (unfit) b16 = false; // values beyond 2^+-100 or not finite: the exact fp64 pass (below) instead
+    // The exact fp64 pass (below) instead of a low-precision one when a centred value lies beyond 2^+-100 or is not finite
+    // (bit 0), or when NO centred value reaches 2^-40 (bit 1 clear): products below 2^-126 are flushed to zero in the fp32
+    // accumulators, an absolute error of < 3K 2^-126 per dot product that the relative margin e only covers while the
+    // distances that matter (>= L >= the largest centred norm squared >= 2^-80) dwarf it.
+    if ((unfit & 1) || (lowp && !(unfit & 2))) b16 = f32 = false;
     // Q is a maximum over vertices: with several ranks each takes its share of the vertex tiles and the maxima are
     // combined by one all-reduce(max) (only when the exchange buffer can hold N x nref doubles)
     const bool shard_q = nparts > 1 && c->has_coll && (c->rccl_comm || (c->xptr && (size_t)(N * nref) <= c->xcap));

@@ -747,8 +747,7 @@ void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows,
     const double e1 = 1.0 + 1.01 * (double)(dpad + 3) * 5.9604644775390625e-08; // 1 + e, e = 1.01 (K + 3) 2^-24 (covers separately rounded products too)
     static const bool no_rowres = getenv("CGE_PCENT_NO_ROWRES") != nullptr; // A/B switch
     if (ntiles > 0 && dpad <= 128 && !no_rowres) { // the row tile of X stays in LDS: X is read once
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void *)pcent_f32_rowres_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        cge_allow_lds((const void *)pcent_f32_rowres_kernel, 160 * 1024);
         const size_t lds = ((size_t)dpad * 128 + 2 * PF_BK * 128) * sizeof(float);
         hipLaunchKernelGGL(pcent_f32_rowres_kernel, dim3((unsigned)std::min<i64>(I1 - I0, 512)), dim3(256), lds, c->stream, Xs32, rns,
                            lds_rows, Ms32, mnorm, ldm, N, dpad, c->pc_groups.p, I0, I1, e1);
@@ -772,8 +771,7 @@ void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 l
 #define PB_GO(NKS)                                                                                                         \
     do {                                                                                                                   \
         auto kern = pcent_bf16_kernel<NKS>;                                                                                 \
-        static bool attr = false;                                                                                          \
-        if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        cge_allow_lds((const void *)kern, 160 * 1024); \
         hipLaunchKernelGGL(kern, dim3((unsigned)std::min<i64>(I1 - I0, 256)), dim3(PB_T), lds, c->stream, Xb, rns, lds_rows, Mb, \
                            mnorm, ldm, sub_land, N, reinterpret_cast<unsigned long long *>(P), I0, I1, e1, pb_diag);        \
     } while (0)

@@ -850,6 +850,31 @@ __global__ void check_neg_kernel(const i32 *__restrict__ todo, i64 cnt, const i3
         next[atomicAdd(next_cnt, 1ULL)] = (i32)k;
     }
 }
+// A sharded edge list: the verdicts are exchanged BY SAMPLE INDEX k, which is the same on every rank.  (A key's slot is not:
+// draw_neg_kernel places keys by atomicCAS with linear probing, so two keys of one probe run can sit in swapped slots on two
+// ranks, and flags added slot by slot would pin one rank's hit on another rank's key.)  flag[k] = "my edges contain the pair
+// of sample k" for the samples of this round, 0 elsewhere; the ranks add the flags; check_neg_flag_kernel reads flag[k].
+__global__ void collect_hit_kernel(const i32 *__restrict__ todo, i64 cnt, const i32 *__restrict__ ni, const i32 *__restrict__ nj,
+                                   const unsigned long long *__restrict__ table, i64 mask, const i32 *__restrict__ hit,
+                                   i32 *__restrict__ flag) {
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cnt) return;
+    const i64 k = todo ? todo[idx] : idx;
+    const unsigned long long key = ((unsigned long long)(uint32_t)ni[k] << 32) | (unsigned long long)(uint32_t)nj[k];
+    i64 slot = (i64)(mixk(key) & (uint64_t)mask);
+    while (table[slot] != key) slot = (slot + 1) & mask; // present: inserted by draw_neg_kernel
+    flag[k] = hit[slot];
+}
+__global__ void check_neg_flag_kernel(const i32 *__restrict__ todo, i64 cnt, const i32 *__restrict__ flag,
+                                      unsigned *__restrict__ attempt, i32 *__restrict__ next, unsigned long long *__restrict__ next_cnt) {
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cnt) return;
+    const i64 k = todo ? todo[idx] : idx;
+    if (flag[k]) {
+        attempt[k] += 1;
+        next[atomicAdd(next_cnt, 1ULL)] = (i32)k;
+    }
+}
 void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i32 *d_pos, i32 *d_ni, i32 *d_nj) {
     const i64 n = c->n, m = c->m; // m: the edges resident on this rank
     hipStream_t st = c->stream;
@@ -877,11 +902,20 @@ void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed
         hipLaunchKernelGGL(draw_neg_kernel, dim3(g), dim3(256), 0, st, (uint64_t)seed, (uint64_t)stream_id, n, directed, todo, cnt,
                            attempt.p, d_ni, d_nj, table.p, tsize - 1);
         k_mark_edge_hits(c, c->src.p, c->dst.p, m, directed, reinterpret_cast<const uint64_t *>(table.p), tsize, hit.p);
-        // a sharded list: every rank has marked the candidates that are among ITS edges; the flags (0 / 1 in 32-bit words, two
-        // to an 8-byte word, at most `world` per word half: no carry) are added over the ranks
-        if (c->edges_sharded) cge_allreduce_dev(c, reinterpret_cast<double *>(hit.p), tsize / 2, 2);
-        hipLaunchKernelGGL(check_neg_kernel, dim3(g), dim3(256), 0, st, todo, cnt, d_ni, d_nj, table.p, tsize - 1, hit.p, attempt.p,
-                           next, count.p);
+        if (c->edges_sharded) {
+            // every rank has marked the candidates that are among ITS edges; the verdicts travel by sample index (0 / 1 in 32-bit
+            // words, two to an 8-byte word, at most `world` per word half: no carry) and are added over the ranks
+            DevBuf<i32> &flag = c->samp_flag;
+            const i64 words = (S + 1) / 2;
+            flag.ensure(2 * words);
+            HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(i32) * 2 * words, st));
+            hipLaunchKernelGGL(collect_hit_kernel, dim3(g), dim3(256), 0, st, todo, cnt, d_ni, d_nj, table.p, tsize - 1, hit.p, flag.p);
+            cge_allreduce_dev(c, reinterpret_cast<double *>(flag.p), words, 2);
+            hipLaunchKernelGGL(check_neg_flag_kernel, dim3(g), dim3(256), 0, st, todo, cnt, flag.p, attempt.p, next, count.p);
+        } else {
+            hipLaunchKernelGGL(check_neg_kernel, dim3(g), dim3(256), 0, st, todo, cnt, d_ni, d_nj, table.p, tsize - 1, hit.p,
+                               attempt.p, next, count.p);
+        }
         unsigned long long hc = 0;
         HIP_CHECK(hipMemcpyAsync(&hc, count.p, sizeof(hc), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));

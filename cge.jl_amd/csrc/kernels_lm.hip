@@ -135,7 +135,7 @@ __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i3
     __shared__ double nrm[8][33];
     const i64 p0 = (i64)blockIdx.x * 32;
     const int tx = threadIdx.x, ty = threadIdx.y;
-    bool bad = false;
+    bool bad = false, big = false;
     double sq = 0.0; // of row p0 + tx, the features this thread visits in the second phase
     for (i64 k0 = 0; k0 < d; k0 += 32) {
         for (int r = ty; r < 32; r += 8) {
@@ -143,9 +143,12 @@ __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i3
             if (p < npos && k < d) {
                 const double v = src[(idx ? (i64)idx[p] : p) * d + k] - mean[k];
                 tile[r][tx] = v;
-                if (planes) {
+                if (flag) { // fitness for the low-precision bound passes (bit 0: unfit value; bit 1: a value of ordinary size exists)
                     const double av = fabs(v);
                     if (!(av < 1.2676506002282294e30) || (av != 0.0 && av < 7.888609052210118e-31)) bad = true; // 2^100, 2^-100
+                    if (av >= 9.094947017729282e-13) big = true; // 2^-40
+                }
+                if (planes) {
                     unsigned u = __float_as_uint((float)v);
                     u += 0x7FFFu + ((u >> 16) & 1u); // bf16, round to nearest even
                     const unsigned short h = (unsigned short)(u >> 16);
@@ -169,6 +172,7 @@ __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i3
         __syncthreads();
     }
     if (bad) atomicOr(flag, 1);
+    if (big) atomicOr(flag, 2);
     if (rnorm) {
         nrm[ty][tx] = sq;
         __syncthreads();
@@ -1797,15 +1801,14 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
         static const int lds_form = getenv("CGE_RSS2_LDS") ? atoi(getenv("CGE_RSS2_LDS")) : 1;
         if (lds_form && ns0 == 1) { // (d <= 64; two 64-row buffers of 128 columns would not fit beside the tree-sum tiles)
             const size_t lds = (size_t)(4 * R2_BR * 65 + 2 * 64 * ns0 * 64 + 2 * 64) * sizeof(double);
-            static bool attr1 = false, attr2 = false;
             if (ns0 == 1) {
-                if (!attr1) { (void)hipFuncSetAttribute((const void *)rss2_chain_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+                cge_allow_lds((const void *)rss2_chain_lds_kernel<1>, 160 * 1024);
                 hipLaunchKernelGGL((rss2_chain_lds_kernel<1>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
                                    c->r2_ck.p, slots);
                 hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
                                    d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
             } else {
-                if (!attr2) { (void)hipFuncSetAttribute((const void *)rss2_chain_lds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
+                cge_allow_lds((const void *)rss2_chain_lds_kernel<2>, 160 * 1024);
                 hipLaunchKernelGGL((rss2_chain_lds_kernel<2>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
                                    c->r2_ck.p, slots);
                 hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
@@ -3414,8 +3417,7 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
         static const bool one_step = getenv("CGE_EIG_WIDE_UNBLOCKED") && atoi(getenv("CGE_EIG_WIDE_UNBLOCKED")) != 0; // A/B
         if (!one_step) {
             const size_t plds = (size_t)(2 * EWP_NB * d + d + 8 + 8 * 2 * EWP_NB + 2 * EWP_NB + 32) * sizeof(double);
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void *)group_eig_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            cge_allow_lds((const void *)group_eig_panel_kernel, 160 * 1024);
             c->ls_eigscr.ensure((size_t)n_tasks * EWP_SCR);
             hipLaunchKernelGGL(group_eig_panel_kernel, dim3((unsigned)n_tasks), dim3(EWP_T), plds, c->stream,
                                const_cast<double *>(cov), (int)d, vec, c->ls_eigscr.p);

@@ -358,8 +358,7 @@ void k_edge_scatter_blocked(cge_ctx *c, i64 c0, i64 c1, i64 C, int directed, dou
 #define EB_GO2(P, W, D)                                                                                                    \
     do {                                                                                                                   \
         auto kern = edge_pass_kernel<P, W, D>;                                                                              \
-        static bool attr = false;                                                                                          \
-        if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        cge_allow_lds((const void *)kern, 160 * 1024); \
         hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(EB_THREADS), lds, st, c->be_edge.p, c->be_w.p, c->be_chunk.p, (int)c0, \
                            c->comm16.p, (int)C, Cpad, c->be_keys.p, c->be_wkeys.p, c->be_runoff.p, c->be_diag.p, vectC, vlen,  \
                            stop);                                                                                          \
@@ -601,12 +600,8 @@ bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, 
     do {                                                                                                                   \
         auto k1 = wedge_pass_kernel<16, W, D>;                                                                              \
         auto k2 = wedge_tile_kernel<W>;                                                                                     \
-        static bool attr = false;                                                                                          \
-        if (!attr) {                                                                                                       \
-            (void)hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
-            (void)hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
-            attr = true;                                                                                                   \
-        }                                                                                                                  \
+        cge_allow_lds((const void *)k1, 160 * 1024);                                                                        \
+        cge_allow_lds((const void *)k2, 160 * 1024);                                                                        \
         hipLaunchKernelGGL(k1, dim3((unsigned)nwg), dim3(EB_THREADS), lds1, st, c->be_edge.p, c->be_w.p, c->be_chunk.p, (int)c0, \
                            c->v2l16.p, (int)ntile, ntpad, rshift, colbits, c->be_keys.p, c->be_wkeys.p, c->be_runoff.p);    \
         hipLaunchKernelGGL(k2, dim3((unsigned)ntile), dim3(WT_THREADS), lds2, st, c->be_keys.p, c->be_wkeys.p, c->be_runoff.p, \

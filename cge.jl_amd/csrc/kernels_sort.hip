@@ -173,8 +173,7 @@ void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 
         int cap = 64;
         while (cap < std::min<i64>(max_len, SEGSORT_CAP)) cap <<= 1;
         const unsigned npieces = (unsigned)((max_len + SEGSORT_CAP - 1) / SEGSORT_CAP);
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void *)segment_piece_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SEGSORT_CAP * 12); attr = true; }
+        cge_allow_lds((const void *)segment_piece_sort_kernel, SEGSORT_CAP * 12);
         if (npieces > 1) { c->sort_k64.ensure(R); c->sort_idx2.ensure(R); }
         hipLaunchKernelGGL(segment_piece_sort_kernel, dim3((unsigned)T, npieces), dim3(SEGSORT_T), (size_t)cap * 12, c->stream, z, task_row_off, cap,
                            zs, perm, c->sort_k64.p, c->sort_idx2.p);

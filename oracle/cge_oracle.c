@@ -179,7 +179,28 @@ static double total_rss(const view_t *v) {
  * destroyed) by cyclic Jacobi.  Stands in for `eigvecs(A)[:, end]`
  * (src/landmarks.jl:99,162,225,254; LAPACK syevr, ascending eigenvalues).
  * Sign convention (the reference's is unspecified): largest-|.| component > 0. */
+/* Fixture generation only: a caller-supplied routine for the eigenvector of the largest eigenvalue
+ * (oracle.py::use_lapack_eig hands in LAPACK's syevr through scipy -- the routine Julia's `eigvecs`
+ * itself calls).  The sign rule below is applied to its result as to Jacobi's.  NULL = Jacobi.    */
+typedef int (*orc_eig_fn)(const double *A, i64 d, double *v);
+static orc_eig_fn g_eig_hook = 0;
+void orc_set_eig_hook(orc_eig_fn fn) { g_eig_hook = fn; }
+
+static void eig_sign_rule(double *vout, i64 d) {
+    i64 big = 0;
+    for (i64 k = 1; k < d; k++)
+        if (fabs(vout[k]) > fabs(vout[big])) big = k;
+    if (vout[big] < 0.0)
+        for (i64 k = 0; k < d; k++) vout[k] = -vout[k];
+}
+
 static int eig_top(double *A, i64 d, double *vout) {
+    if (g_eig_hook) {
+        int rc = g_eig_hook(A, d, vout);
+        if (rc != 0) return ORC_E_ASSERT;
+        eig_sign_rule(vout, d);
+        return ORC_OK;
+    }
     double *V = (double *)malloc(sizeof(double) * (size_t)(d * d));
     if (!V) return ORC_E_ALLOC;
     for (i64 i = 0; i < d; i++)

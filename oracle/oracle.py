@@ -123,6 +123,36 @@ def eig_top(A):
     return v
 
 
+_EIG_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double))
+_eig_cb = None  # keeps the callback object alive while the C side holds its address
+
+
+def use_lapack_eig(on: bool = True):
+    """Fixture generation: take `eigvecs(A)[:, end]` (src/landmarks.jl:99,162,225,254) from LAPACK's syevr -- the routine
+    Julia's `eigvecs` calls on a symmetric matrix -- through scipy.linalg.eigh(driver="evr", all eigenpairs as `eigvecs`
+    computes them) instead of the oracle's cyclic Jacobi, which needs 26-136 s per 512-wide matrix.  The oracle's sign rule
+    (largest-|component| positive) is applied on the C side either way.  tests/test_oracle_golden.py checks that both
+    routines give the same partitions on the committed fixtures."""
+    global _eig_cb
+    if not on:
+        lib().orc_set_eig_hook(None)
+        _eig_cb = None
+        return
+    from scipy.linalg import eigh
+
+    def cb(Ap, d, vp):
+        try:
+            A = np.ctypeslib.as_array(Ap, shape=(d, d))
+            w, V = eigh(A, driver="evr", check_finite=False)
+            np.ctypeslib.as_array(vp, shape=(d,))[:] = V[:, -1]
+            return 0
+        except Exception:  # noqa: BLE001 -- nothing may propagate through the C frame
+            return 1
+
+    _eig_cb = _EIG_FN(cb)
+    lib().orc_set_eig_hook(_eig_cb)
+
+
 def total_rss(embedding, w, idxs):
     e, ef = _f(embedding)
     w = np.ascontiguousarray(w, dtype=np.float64)

@@ -10,7 +10,16 @@ The GPU test regenerates graph and draws, so only expected OUTPUTS are stored (v
 On the device this exercises what no other fixture reaches: group_eig_panel_kernel (128 < d <= 512), the tile-pair
 covariance (four 128-column tiles), the K = 512 fp32-MFMA bound pass of the diameter.
 
-usage: python tests/golden/make_oracle_fixture_d512.py [small|quick]
+Eigenvectors: `--eig=lapack` (the default since round 4) takes `eigvecs(A)[:, end]` from LAPACK's syevr through
+scipy.linalg.eigh(driver="evr") -- the routine Julia's `eigvecs` calls (src/landmarks.jl:99,162,225,254) -- with the oracle's
+sign rule; `--eig=jacobi` keeps the oracle's cyclic Jacobi (26-136 s per 512-wide matrix: only `quick` is affordable, and
+oracle_d512_quick.npz was made that way).  tests/test_oracle_golden.py::test_lapack_eig_reproduces_the_jacobi_fixtures holds
+the two routines to the same partitions and bits on the committed Jacobi fixtures.
+
+`lowrank`: 6000 vertices in 20 communities (~300 rows each), -l 200 -f 4: EVERY covariance is rank-deficient (< 512 rows)
+and ~120 splits happen in the global phase -- what config 5's last splits of small communities produce.
+
+usage: python tests/golden/make_oracle_fixture_d512.py [large|small|quick|lowrank] [--eig=lapack|jacobi]
 """
 import os
 import sys
@@ -33,6 +42,9 @@ D512_SMALL = dict(n=8_000, m=80_000, C=12, d=512, land=120, forced=4, samples=10
 # >= 500 rows at d = 512 and ~136 s on a rank-deficient one (150 rows), so the two fixtures above cost 4 h (small) and ~20 h
 # (large) of one core per split rule; this one, 30 splits per rule, costs ~15 minutes per rule.
 D512_QUICK = dict(n=12_000, m=120_000, C=6, d=512, land=36, forced=4, samples=10000, seed=42)
+D512_LOWRANK = dict(n=6_000, m=60_000, C=20, d=512, land=200, forced=4, samples=10000, seed=42)
+VARIANTS = {"large": (D512, "oracle_d512.npz"), "": (D512, "oracle_d512.npz"), "small": (D512_SMALL, "oracle_d512_small.npz"),
+            "quick": (D512_QUICK, "oracle_d512_quick.npz"), "lowrank": (D512_LOWRANK, "oracle_d512_lowrank.npz")}
 
 
 def crc(a):
@@ -40,13 +52,16 @@ def crc(a):
 
 
 def main():
-    which = sys.argv[1] if len(sys.argv) > 1 else ""
-    small = which == "small"
-    c = D512_SMALL if small else D512_QUICK if which == "quick" else D512
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    eig = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--eig=")), "lapack")
+    which = pos[0] if pos else ""
+    c, fname = VARIANTS[which]
+    if eig == "lapack":
+        orc.use_lapack_eig(True)
     g = synth.abcd_like(c["n"], int(c["m"] * 1.05), c["C"], c["d"], seed=c["seed"])
     print(f"graph n={g['n']} m={g['m']}", flush=True)
     out = dict(n=g["n"], m=g["m"], edges_crc=crc(g["edges"]), emb_crc=crc(g["embedding"]), gen_n=c["n"], gen_m=int(c["m"] * 1.05),
-               gen_C=c["C"], land=c["land"], forced=c["forced"])
+               gen_C=c["C"], land=c["land"], forced=c["forced"], eig=np.array(eig))
     t0 = time.time()
     hi = orc.max_pair_dist(g["embedding"])
     t_hi = time.time() - t0
@@ -73,15 +88,15 @@ def main():
                     p + "lcomm": lcomm[:, 0], p + "lemb_crc": crc(lemb), p + "ledges_crc": crc(ledges),
                     p + "lw_crc": crc(lw), p + "n_ledges": len(lw), p + "result": res, p + "iters": np.array(tr["iters"]),
                     p + "div": np.array(tr["div"]), p + "auc": np.array(tr["auc"])})
-        save(out, times, t_hi, small, which)  # after every rule: a rule of the larger variants is hours of one core
+        save(out, times, t_hi, fname, eig)  # after every rule: a rule of the larger variants is hours of one core
 
 
-def save(out, times, t_hi, small, which):
+def save(out, times, t_hi, fname, eig):
     """The fixture with the rules finished so far (the GPU test skips a rule whose keys are missing)."""
-    prov = ("oracle/cge_oracle.c (CPU restatement), tests/golden/make_oracle_fixture_d512.py; diameter "
+    prov = (f"oracle/cge_oracle.c (CPU restatement; eigenvectors: {eig}), tests/golden/make_oracle_fixture_d512.py; diameter "
             f"{t_hi:.0f} s; " + "; ".join(f"{m}: landmarks {t[0]:.0f} s + wGCL {t[1]:.0f} s" for m, t in times.items()) + "; one core")
     np.savez_compressed(
-        os.path.join(ROOT, "tests", "golden", "oracle_d512_small.npz" if small else "oracle_d512_quick.npz" if which == "quick" else "oracle_d512.npz"),
+        os.path.join(ROOT, "tests", "golden", fname),
         provenance=np.array(prov), **out)
 
 

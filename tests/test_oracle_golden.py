@@ -166,3 +166,38 @@ def test_louvain_level1_restatement_against_networkx(test115):
         assert q >= nx.community.modularity(G, lv1) - 0.05
         if truth is not None:  # found communities lie inside planted ones
             assert sum(np.bincount(truth[list(p)]).max() for p in parts) / n > 0.98
+
+
+def _landmarks_with(eig_lapack, g, land, forced, method):
+    orc.use_lapack_eig(eig_lapack)
+    try:
+        return orc.landmarks(g["edges"], g["eweights"], g["vweights"], g["clusters"], g["comm"], g["embedding"], False,
+                             land, forced, method, False)
+    finally:
+        orc.use_lapack_eig(False)
+
+
+def test_lapack_eig_reproduces_the_jacobi_fixtures(test115, example10k):
+    """The fixture generators of round 4 take `eigvecs(A)[:, end]` (src/landmarks.jl:99,162,225,254) from LAPACK's syevr -- the
+    routine Julia's `eigvecs` itself calls -- instead of the oracle's cyclic Jacobi (oracle.use_lapack_eig).  The two
+    routines must give the same raw landmark ids and the same bits downstream: on the reference's own fixtures for every
+    rule, on the committed full-size Jacobi fixture of config 2 (d = 64, rss2) and on the d = 512 Jacobi fixture."""
+    from cge.jl_amd import synth
+
+    for a, lands in ((test115, (20, 40)), (example10k, (200,))):
+        for method in ("rss", "rss2", "size", "diameter"):
+            for land in lands:
+                j = _landmarks_with(False, a, land, a["forced"], method)
+                l = _landmarks_with(True, a, land, a["forced"], method)
+                for x, y in zip(j, l):
+                    assert np.array_equal(x, y), (method, land)
+    fx = np.load(os.path.join(GOLDEN, "oracle_cfg2.npz"))
+    g = synth.abcd_like(100_000, 1_050_000, 50, 64, seed=42)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = _landmarks_with(True, g, 400, 4, "rss2")
+    assert np.array_equal(v2l, fx["v_to_l"]) and np.array_equal(dii, fx["dii"]) and np.array_equal(lweight, fx["lweight"])
+    fx = np.load(os.path.join(GOLDEN, "oracle_d512_quick.npz"))
+    g = synth.abcd_like(int(fx["gen_n"]), int(fx["gen_m"]), int(fx["gen_C"]), 512, seed=42)
+    for method in ("rss", "diameter"):
+        dii, lemb, lcomm, ledges, lw, lweight, v2l = _landmarks_with(True, g, int(fx["land"]), int(fx["forced"]), method)
+        assert np.array_equal(v2l, fx[method + "_v_to_l"]), method
+        assert np.array_equal(dii, fx[method + "_dii"]) and np.array_equal(lweight, fx[method + "_lweight"])
