@@ -226,14 +226,15 @@ def test_config4_directed_million_samples_against_oracle_fixture(ctx):
     assert np.array_equal(res, res_h)
 
 
-@pytest.mark.parametrize("which", ["oracle_d512", "oracle_d512_small", "oracle_d512_quick"])
+@pytest.mark.parametrize("which", ["oracle_d512", "oracle_d512_lowrank", "oracle_d512_quick"])
 @pytest.mark.parametrize("method", ["rss", "diameter"])
 def test_d512_against_oracle_fixture(ctx, method, which):
-    """The oracle pin of config 5's code paths (tests/golden/make_oracle_fixture_d512.py): d = 512, 20 000 vertices, 30
-    communities, -l 300 -f 4 (`_small`: 8000 vertices, 12 communities, -l 120; `_quick`: 12 000 vertices, 6 communities, -l 36:
-    the one the oracle's Jacobi finishes in half an hour, see the generator) -- group_eig_panel_kernel (128 < d <= 512), the tile-pair covariance and the K = 512 fp32-MFMA
-    bound pass against the CPU oracle's Jacobi eigenvectors and O(n^2 d) diameter loop: v_to_l, d_ii, weights and
-    communities bit for bit, centroid / landmark-edge checksums, the diameter's bits, iteration counts, the 7-vector and
+    """The oracle pins of config 5's code paths (tests/golden/make_oracle_fixture_d512.py), d = 512: `oracle_d512` (20 000
+    vertices, 30 communities, -l 300 -f 4; eigenvectors from LAPACK's syevr as in the reference), `_lowrank` (6000 vertices in
+    20 communities of ~300 rows, -l 200: EVERY covariance rank-deficient, ~120 splits in the global phase; LAPACK) and `_quick`
+    (12 000 vertices, 6 communities, -l 36; the oracle's own Jacobi) -- group_eig_panel_kernel (128 < d <= 512), the tile-pair
+    covariance and the K = 512 fp32-MFMA bound pass against the CPU oracle: v_to_l, d_ii, weights and communities bit for bit,
+    centroid / landmark-edge checksums, the diameter's bits (the oracle's O(n^2 d) loop), iteration counts, the 7-vector and
     every trace at 1e-9, for the rss rule and for a cut rule."""
     from cge.jl_amd import synth
 
