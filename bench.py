@@ -359,13 +359,15 @@ def main():
 
     if world > 1:
         ctx.set_option("shard_ingest", 0 if os.environ.get("CGE_SHARD_INGEST") == "0" else 1)
+        # the embedding rows sharded by community: a rank uploads, keeps and splits the rows of its own communities only
+        ctx.set_option("shard_rows", 0 if os.environ.get("CGE_SHARD_ROWS") == "0" else 1)
         fence0 = dist.barrier
         fence0()
         t_upload = upload()
         t = torch.tensor([t_upload], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_upload = float(t.item())
-    ingest_stats = (ctx.get_stat("edges_resident"), ctx.get_stat("edges_total"))
+    ingest_stats = (ctx.get_stat("edges_resident"), ctx.get_stat("edges_total"), ctx.get_stat("rows_resident"), ctx.get_stat("rows_total"))
 
     def step():
         return ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=args.seed,
@@ -611,8 +613,10 @@ def main():
         # Both are reported: `value` = resident step, `value_incl_h2d` = m A / (step + one upload of the inputs).
         "value_incl_h2d": g["m"] * A / (sec_per_step + t_upload), "upload_s": t_upload,
         "ingest": ("every rank uploads everything" if world == 1 or ingest_stats[0] == ingest_stats[1]
-                   else f"sharded: {ingest_stats[0]} of {ingest_stats[1]} edges resident on rank 0; embedding rows uploaded as one "
-                        "slice per rank and all-gathered over xGMI"),
+                   else f"sharded: {ingest_stats[0]} of {ingest_stats[1]} edges and {ingest_stats[2]} of {ingest_stats[3]} embedding rows "
+                        "resident on rank 0 (rows sharded by community when fewer than all: a rank uploads and keeps its own "
+                        "communities' rows; else one slice per rank uploaded and all-gathered over xGMI)"),
+        "rows_resident_rank0": ingest_stats[2], "rows_total": ingest_stats[3],
         "roofline": roofline, "kernels": kernels, "phases_ms": phases,
         "diameter": {"hi": hi, "path": dpath, "candidate_landmark_pairs": cand_pairs, "candidate_tiles": cand_tiles,
                      "all_landmark_pairs": N * (N + 1) // 2, "all_tiles": ((n + 127) // 128) * ((n + 127) // 128 + 1) // 2},

@@ -242,8 +242,8 @@ class Context:
     def set_inputs(self, edges, eweights, vweights, comm, embedding):
         n = int(np.asarray(embedding).shape[0])
         self.set_graph(edges, eweights, n)
+        self.set_vertex_data(comm, vweights)  # before the embedding: option shard_rows shards the rows BY COMMUNITY
         self.set_embedding(embedding)
-        self.set_vertex_data(comm, vweights)
 
     # ---- landmarks ----------------------------------------------------------------------------------
     def landmarks_run(self, clusters, land, forced, method, directed=False):

@@ -79,7 +79,7 @@ static void staged_upload(cge_ctx *c, T *dev, size_t total, F fill) {
 // host mirror of the row-major embedding: only the generic round-based rss path (ties at the maximum of z, NaNs) and the
 // exact unique-row count read it, so it is fetched on first demand instead of at every upload (1 GB at the headline)
 void cge_ensure_host_embedding(cge_ctx *c) {
-    const size_t need = (size_t)c->n * (size_t)c->d;
+    const size_t need = (size_t)lm_rows(c) * (size_t)c->d; // (option shard_rows: this rank's rows, local ids)
     if (c->h_Xr.size() == need) return;
     if (!c->Xr.p || need == 0) CGE_THROW(CGE_E_ARG, "embedding not resident");
     c->h_Xr.resize(need);
@@ -208,6 +208,66 @@ static double allreduce_scalar_max(cge_ctx *c, double v);
 // N > 1 with option "shard_ingest": which rows of the caller's edge list / embedding this rank uploads
 static bool ingest_sharded(const cge_ctx *c) { return c->opt_shard_ingest && c->has_coll && !c->is_side && c->coll.world > 1; }
 
+// ---- option "shard_rows": the embedding rows sharded by community (common.hpp) ---------------------------------------------
+static bool rows_shard_wanted(const cge_ctx *c) { return c->opt_shard_rows && c->has_coll && !c->is_side && c->coll.world > 1; }
+static void rows_unshard(cge_ctx *c) {
+    c->rows_sharded = false;
+    c->n_loc = 0;
+    c->h_loc2glob.clear(); c->h_glob2loc.clear(); c->comm_owner.clear(); c->h_vw_loc.clear();
+    c->loc2glob.release(); c->glob2loc.release(); c->comm_loc.release(); c->vw_loc.release();
+}
+// local copies of the per-vertex tables the row passes read (weights, communities of this rank's rows)
+static void rows_refresh_local_tables(cge_ctx *c) {
+    if (!c->rows_sharded) return;
+    const i64 nl = c->n_loc;
+    if ((i64)c->h_vw.size() == c->n) {
+        c->h_vw_loc.resize(nl);
+        for (i64 i = 0; i < nl; i++) c->h_vw_loc[i] = c->h_vw[c->h_loc2glob[i]];
+        c->vw_loc.alloc_exact(nl);
+        HIP_CHECK(hipMemcpyAsync(c->vw_loc.p, c->h_vw_loc.data(), sizeof(double) * nl, hipMemcpyHostToDevice, c->stream));
+    }
+    std::vector<i32> cl(nl);
+    for (i64 i = 0; i < nl; i++) cl[i] = c->h_comm[c->h_loc2glob[i]];
+    c->comm_loc.alloc_exact(nl);
+    HIP_CHECK(hipMemcpyAsync(c->comm_loc.p, cl.data(), sizeof(i32) * nl, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+// THE OWNERSHIP RULE (the same on every rank: it reads the replicated community vector only): communities by decreasing
+// size (ties: lower id first), each to the rank with the fewest rows so far (ties: lower rank).  cge.jl_amd/dist.py
+// restates it (community_owner) and tests/test_distributed_gloo.py holds the two together.
+static void rows_assign_ownership(cge_ctx *c) {
+    const i64 n = c->n, C = c->n_comm_max, W = c->coll.world;
+    if ((i64)c->h_comm.size() != n || C <= 0)
+        CGE_THROW(CGE_E_ARG, "option shard_rows: upload the communities (cge_set_vertex_data) before the embedding -- the rows are sharded by community");
+    std::vector<i64> size(C, 0), ord(C), load(W, 0);
+    for (i64 i = 0; i < n; i++) size[c->h_comm[i]]++;
+    for (i64 q = 0; q < C; q++) ord[q] = q;
+    std::stable_sort(ord.begin(), ord.end(), [&](i64 a, i64 b) { return size[a] > size[b]; });
+    c->comm_owner.assign(C, 0);
+    for (i64 q : ord) {
+        const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        c->comm_owner[q] = r;
+        load[r] += size[q];
+    }
+    const int me = c->coll.rank;
+    c->h_glob2loc.assign(n, -1);
+    c->h_loc2glob.clear();
+    c->h_loc2glob.reserve(load[me]);
+    for (i64 i = 0; i < n; i++)
+        if (c->comm_owner[c->h_comm[i]] == me) {
+            c->h_glob2loc[i] = (i32)c->h_loc2glob.size();
+            c->h_loc2glob.push_back((i32)i);
+        }
+    c->n_loc = (i64)c->h_loc2glob.size();
+    if (c->n_loc <= 0) CGE_THROW(CGE_E_ARG, "option shard_rows: fewer communities than ranks (rank %d would own no row)", me);
+    c->loc2glob.alloc_exact(c->n_loc);
+    c->glob2loc.alloc_exact(n);
+    HIP_CHECK(hipMemcpyAsync(c->loc2glob.p, c->h_loc2glob.data(), sizeof(i32) * c->n_loc, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->glob2loc.p, c->h_glob2loc.data(), sizeof(i32) * n, hipMemcpyHostToDevice, c->stream));
+    c->rows_sharded = true;
+    rows_refresh_local_tables(c);
+}
+
 int cge_set_graph(cge_ctx *c, const int64_t *src, const int64_t *dst, const double *w, int64_t m, int64_t n) {
     if (!c || !src || !dst || m <= 0 || n <= 0 || n >= (1LL << 31)) return CGE_E_ARG;
     CGE_TRY(c)
@@ -275,6 +335,7 @@ int cge_set_graph(cge_ctx *c, const int64_t *src, const int64_t *dst, const doub
         c->Xr.release(); c->Xc.release(); c->rnorm.release(); c->vw.release(); c->comm.release(); c->comm16.release();
         c->d = 0;
         c->centred_ready = false;
+        rows_unshard(c);
     }
     c->n = n;
     c->lm_ready = false;
@@ -295,13 +356,19 @@ static void embedding_resident(cge_ctx *c, i64 n, i64 d) {
     c->Xc.release();
     c->rnorm.release();
     c->gmean.alloc_exact((size_t)d);
-    k_col_mean(c, c->Xr.p, n, d, c->gmean.p);
+    if (c->rows_sharded) { // column sums of the local rows, added over the ranks (every rank ends with the same bits), / n
+        k_col_mean(c, c->Xr.p, c->n_loc, d, c->gmean.p, 1.0);
+        allreduce(c, c->gmean.p, d, 0);
+        k_scale_vector(c, c->gmean.p, d, 1.0 / (double)n);
+    } else
+        k_col_mean(c, c->Xr.p, n, d, c->gmean.p);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     c->centred_ready = false;
     c->lm_ready = false;
 }
 static void ensure_centred(cge_ctx *c) {
     if (c->centred_ready) return;
+    if (c->rows_sharded) CGE_THROW(CGE_E_ARG, "the brute-force diameter over the whole embedding needs every row on one rank; the resident rows are sharded (option shard_rows)");
     if (!c->Xr.p || c->d <= 0) CGE_THROW(CGE_E_ARG, "diameter: embedding not resident");
     c->Xc.alloc_exact((size_t)c->ldn * c->dpad);
     c->rnorm.alloc_exact((size_t)c->ldn);
@@ -315,6 +382,27 @@ int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
     HIP_CHECK(hipSetDevice(c->device));
     if (c->n && c->n != n) CGE_THROW(CGE_E_ASSERT, "No. rows in embedding and no. vertices in a graph differ.");
     DevBuf<double> col;
+    if (rows_shard_wanted(c)) {
+        // N > 1, option "shard_rows": this rank uploads and KEEPS the rows of its own communities only (n / world rows over
+        // its own PCIe link, nothing over xGMI): the caller's column-major matrix is read as a gather of rows per column
+        rows_assign_ownership(c);
+        const i64 nl = c->n_loc;
+        const i32 *l2g = c->h_loc2glob.data();
+        col.alloc_exact((size_t)nl * d);
+        staged_upload<double>(c, col.p, (size_t)nl * d, [&](double *o, size_t a0, size_t a1) {
+            for (size_t e = a0; e < a1; e++) { // element e of the (nl x d, column-major) slice: column e / nl, local row e % nl
+                const size_t k = e / (size_t)nl, i = e % (size_t)nl;
+                o[e - a0] = X[k * (size_t)n + (size_t)l2g[i]];
+            }
+        });
+        c->Xr.alloc_exact((size_t)nl * d);
+        k_transpose_to_rowmajor(c, col.p, c->Xr.p, nl, d);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        col.release();
+        embedding_resident(c, n, d);
+        return CGE_OK;
+    }
+    rows_unshard(c);
     if (ingest_sharded(c)) {
         // N > 1, option "shard_ingest": every rank uploads n / world ROWS (a strided piece of each column of the caller's
         // column-major matrix) over its own PCIe link, transposes them into its place of Xr, and the pieces are all-gathered
@@ -361,6 +449,15 @@ int cge_set_embedding_device(cge_ctx *c, const double *X_dev, int64_t n, int64_t
         (void)hipGetLastError();
         CGE_THROW(CGE_E_ARG, "set_embedding_device: the pointer is not device memory");
     }
+    if (rows_shard_wanted(c)) { // option shard_rows: this rank's rows are gathered out of the caller's matrix
+        rows_assign_ownership(c);
+        c->Xr.alloc_exact((size_t)c->n_loc * d);
+        k_gather_rows_f64(c, X_dev, n, d, row_major, c->loc2glob.p, c->n_loc, c->Xr.p);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        embedding_resident(c, n, d);
+        return CGE_OK;
+    }
+    rows_unshard(c);
     c->Xr.alloc_exact((size_t)n * d);
     if (row_major)
         HIP_CHECK(hipMemcpyAsync(c->Xr.p, X_dev, sizeof(double) * (size_t)n * d, hipMemcpyDeviceToDevice, c->stream));
@@ -377,6 +474,17 @@ int cge_set_vertex_data(cge_ctx *c, const int64_t *comm, const double *vw, int64
     HIP_CHECK(hipSetDevice(c->device));
     if (c->n && c->n != n) CGE_THROW(CGE_E_ASSERT, "No. communities (%lld) differ from no. nodes (%lld)", (long long)n, (long long)c->n);
     c->n = n;
+    if (comm && c->rows_sharded) {
+        // the rows are sharded BY COMMUNITY: another community vector is another ownership -- the resident rows are dropped
+        // (upload the embedding again after this call)
+        bool same = (i64)c->h_comm.size() == n;
+        for (i64 i = 0; same && i < n; i++) same = c->h_comm[i] == (i32)(comm[i] - 1);
+        if (!same) {
+            c->Xr.release(); c->h_Xr.clear();
+            c->d = 0;
+            rows_unshard(c);
+        }
+    }
     if (comm) {
         c->h_comm.resize(n);
         i64 cmax = 0;
@@ -404,6 +512,7 @@ int cge_set_vertex_data(cge_ctx *c, const int64_t *comm, const double *vw, int64
         HIP_CHECK(hipMemcpyAsync(c->vw.p, c->h_vw.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     }
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    rows_refresh_local_tables(c);
     c->lm_ready = false;
     CGE_CATCH(c)
 }
@@ -421,6 +530,66 @@ static i64 clamp_to_unique_rows(cge_ctx *c, i64 land, int *truncated) {
     // of atomicCAS slots): one 8-byte read-back instead of the hashes themselves and a host set.
     i64 done = 0;
     c->uniq_hash.ensure(n);
+    if (c->rows_sharded) {
+        // option shard_rows: every rank hashes its rows, the hashes are gathered by vertex id (8 bytes per vertex) and every
+        // rank counts the distinct ones; only if that leaves the clamp open are the rows with a shared hash -- the only
+        // candidates for equal rows -- gathered and compared bit for bit
+        const i64 nl = c->n_loc;
+        DevBuf<uint64_t> hl;
+        hl.ensure(nl);
+        k_row_hash(c, c->Xr.p, hl.p, nl, d);
+        HIP_CHECK(hipMemsetAsync(c->uniq_hash.p, 0, sizeof(uint64_t) * n, c->stream));
+        k_scatter_u64(c, hl.p, c->loc2glob.p, nl, c->uniq_hash.p);
+        allreduce(c, reinterpret_cast<double *>(c->uniq_hash.p), n, 2);
+        if (k_count_distinct(c, c->uniq_hash.p, n) >= land) return land;
+        std::vector<uint64_t> hh(n);
+        HIP_CHECK(hipMemcpyAsync(hh.data(), c->uniq_hash.p, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        std::vector<i64> ix(n);
+        for (i64 i = 0; i < n; i++) ix[i] = i;
+        std::sort(ix.begin(), ix.end(), [&](i64 a, i64 b) { return hh[a] < hh[b] || (hh[a] == hh[b] && a < b); });
+        std::vector<i32> dup; // vertices whose hash is shared, grouped by hash
+        std::vector<i64> run_off(1, 0);
+        i64 uniq = 0;
+        for (i64 a = 0; a < n;) {
+            i64 b = a + 1;
+            while (b < n && hh[ix[b]] == hh[ix[a]]) b++;
+            if (b - a > 1) {
+                for (i64 q = a; q < b; q++) dup.push_back((i32)ix[q]);
+                run_off.push_back((i64)dup.size());
+            } else
+                uniq++;
+            a = b;
+        }
+        if (!dup.empty()) {
+            const i64 nd = (i64)dup.size();
+            std::vector<i32> lidx(nd);
+            for (i64 q = 0; q < nd; q++) lidx[q] = c->h_glob2loc[dup[q]];
+            DevBuf<i32> didx;
+            DevBuf<double> rows;
+            didx.ensure(nd);
+            rows.ensure((size_t)nd * d);
+            HIP_CHECK(hipMemcpyAsync(didx.p, lidx.data(), sizeof(i32) * nd, hipMemcpyHostToDevice, c->stream));
+            k_gather_rows_f64(c, c->Xr.p, nl, d, 1, didx.p, nd, rows.p);
+            allreduce(c, rows.p, nd * d, 2);
+            std::vector<double> hr((size_t)nd * d);
+            HIP_CHECK(hipMemcpyAsync(hr.data(), rows.p, sizeof(double) * nd * d, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            for (size_t r = 0; r + 1 < run_off.size(); r++) {
+                std::vector<i64> q(run_off[r + 1] - run_off[r]);
+                for (size_t t = 0; t < q.size(); t++) q[t] = run_off[r] + (i64)t;
+                std::sort(q.begin(), q.end(), [&](i64 a, i64 b) { return memcmp(&hr[a * d], &hr[b * d], sizeof(double) * d) < 0; });
+                uniq++;
+                for (size_t t = 1; t < q.size(); t++)
+                    if (memcmp(&hr[q[t - 1] * d], &hr[q[t] * d], sizeof(double) * d) != 0) uniq++;
+            }
+        }
+        if (land > uniq) {
+            *truncated = 1;
+            return uniq;
+        }
+        return land;
+    }
     for (int pass = 0; pass < 2 && done < n; pass++) {
         const i64 upto = pass == 0 ? std::min<i64>(n, 8 * land) : n;
         k_row_hash(c, c->Xr.p + done * d, c->uniq_hash.p + done, upto - done, d);
@@ -450,15 +619,21 @@ static void allreduce(cge_ctx *c, double *dev, i64 count, int op) {
         cge_rccl_allreduce(c, dev, count, op);
         return;
     }
-    // the hook works on the ctx exchange buffer (the host side wrapped that pointer once)
-    if (!c->xptr || (size_t)count > c->xcap)
+    // the hook works on the ctx exchange buffer (the host side wrapped that pointer once); a vector that lives elsewhere
+    // and is longer than the buffer goes through it in pieces (an all-reduce is element-wise)
+    if (!c->xptr || c->xcap == 0 || (dev == c->xptr && (size_t)count > c->xcap))
         CGE_THROW(CGE_E_COLLECTIVE, "exchange buffer too small: need %lld doubles, have %lld", (long long)count, (long long)c->xcap);
-    if (dev != c->xptr)
-        HIP_CHECK(hipMemcpyAsync(c->xptr, dev, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (c->coll.allreduce_f64(c->coll.user, c->xptr, count, op) != 0) CGE_THROW(CGE_E_COLLECTIVE, "allreduce hook failed");
-    if (dev != c->xptr)
-        HIP_CHECK(hipMemcpyAsync(dev, c->xptr, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
+    for (i64 off = 0; off < count; off += (i64)c->xcap) {
+        const i64 piece = std::min<i64>((i64)c->xcap, count - off);
+        if (dev != c->xptr)
+            HIP_CHECK(hipMemcpyAsync(c->xptr, dev + off, sizeof(double) * piece, hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->coll.allreduce_f64(c->coll.user, c->xptr, piece, op) != 0) CGE_THROW(CGE_E_COLLECTIVE, "allreduce hook failed");
+        c->stat_coll_calls++;
+        c->stat_coll_bytes += 8 * piece;
+        if (dev != c->xptr)
+            HIP_CHECK(hipMemcpyAsync(dev + off, c->xptr, sizeof(double) * piece, hipMemcpyDeviceToDevice, c->stream));
+    }
 }
 
 static double allreduce_scalar_max(cge_ctx *c, double v) {
@@ -478,16 +653,23 @@ static void check_resident(cge_ctx *c, const char *who) {
         CGE_THROW(CGE_E_ARG, "%s: graph, embedding and vertex data must be resident (cge_set_graph / cge_set_embedding / "
                              "cge_set_vertex_data; a cge_wgcl call in exact mode replaces the resident graph)", who);
     const size_t n = (size_t)c->n;
-    if (c->n <= 0 || c->d <= 0 || c->m <= 0 || c->Xr.n < n * (size_t)c->d || c->vw.n < n || c->comm.n < n ||
+    const size_t rows = (size_t)lm_rows(c);
+    if (c->rows_sharded && (!c->vw_loc.p || !c->comm_loc.p))
+        CGE_THROW(CGE_E_ARG, "%s: option shard_rows needs the vertex weights and communities resident (cge_set_vertex_data)", who);
+    if (c->n <= 0 || c->d <= 0 || c->m <= 0 || c->Xr.n < rows * (size_t)c->d || c->vw.n < n || c->comm.n < n ||
         c->src.n < (size_t)c->m || c->dst.n < (size_t)c->m)
         CGE_THROW(CGE_E_ARG, "%s: resident inputs are inconsistent (n = %lld, d = %lld, m = %lld): upload them again", who,
                   (long long)c->n, (long long)c->d, (long long)c->m);
 }
 // per-edge scatter of the resident graph into the landmark-pair matrix (and its positive-entry count)
+// the row block of the landmark-pair matrix this rank ends up with after the reduce-scatter: equal blocks of `per` rows
+static inline i64 wedge_rows_per_rank(const cge_ctx *c, i64 N) { return c->has_coll ? (N + c->coll.world - 1) / c->coll.world : N; }
 static void scatter_wedges(cge_ctx *c, int directed) {
     const i64 N = c->N;
     hipStream_t st = c->stream;
-    c->wedges.ensure((size_t)N * N);
+    const i64 per = wedge_rows_per_rank(c, N), Npad = c->has_coll ? per * c->coll.world : N; // (padding rows behind row N: zeros)
+    c->wedges.ensure((size_t)Npad * N);
+    c->wedges_block_only = false;
     DevBuf<i64> &cnt = c->wed_cnt;
     cnt.ensure(1);
     // this rank's share of the edges: of a replicated list its slice of the chunks; of a sharded list all that it holds
@@ -503,11 +685,30 @@ static void scatter_wedges(cge_ctx *c, int directed) {
         k_edge_scatter(c, c->src.p, c->dst.p, c->unit_weights ? nullptr : c->w.p, e0, e1, c->v2l.p, c->comm.p, N,
                        c->n_comm_max, directed, c->wedges.p, nullptr);
     }
-    if (c->has_coll) allreduce(c, c->wedges.p, N * N, 0);
-    if (!tiled || c->has_coll) k_compact_count(c, c->wedges.p, N, directed, cnt.p);
+    if (c->has_coll) {
+        // every rank has summed ITS edges into a full N x N matrix; the sums over the ranks go out BY ROW BLOCK (SURVEY 8(e):
+        // reduce-scatter, not all-reduce): rank r ends with rows [per r, per (r + 1)).  What reads the matrix afterwards works
+        // on row blocks (the count below, the directed score's degrees); landmarks_fetch all-gathers the blocks when the host
+        // asks for the edge list.  Through the hook (gloo tests) or a librccl without the symbol: an all-reduce.
+        if (Npad > N) HIP_CHECK(hipMemsetAsync(c->wedges.p + (size_t)N * N, 0, sizeof(double) * (size_t)(Npad - N) * N, st));
+        if (c->rccl_comm && cge_rccl_reduce_scatter(c, c->wedges.p, per * N))
+            c->wedges_block_only = true;
+        else
+            allreduce(c, c->wedges.p, N * N, 0);
+        const i64 r0 = std::min<i64>(N, per * c->coll.rank), r1 = std::min<i64>(N, r0 + per);
+        k_compact_count(c, c->wedges.p, N, directed, cnt.p, r0, r1);
+        allreduce(c, reinterpret_cast<double *>(cnt.p), 1, 2); // (integer sum of the ranks' counts)
+    } else if (!tiled)
+        k_compact_count(c, c->wedges.p, N, directed, cnt.p);
     HIP_CHECK(hipMemcpyAsync(&c->n_ledges, cnt.p, sizeof(i64), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     c->wedges_ready = true;
+}
+// the whole matrix on this rank (landmarks_fetch): the row blocks of a reduce-scattered matrix are all-gathered in place
+static void wedges_whole(cge_ctx *c) {
+    if (!c->wedges_block_only) return;
+    cge_allgather_dev(c, c->wedges.p, wedge_rows_per_rank(c, c->N) * c->N);
+    c->wedges_block_only = false;
 }
 
 // vect_C of the resident graph (src/divergence.jl:59-63 / :337-345 on the original edges): the blocked two-pass form
@@ -565,8 +766,18 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
     c->lcomm.ensure(N);
     {
         ScopedKernelTimer tm(c, "landmark_aggregate");
-        k_landmark_aggregate(c, c->Xr.p, c->vw.p, c->comm.p, c->lm_memoff.p, c->lm_mem.p, N, d, c->lemb.p, c->lweight.p, c->dii.p,
+        k_landmark_aggregate(c, c->Xr.p, lm_vw(c), lm_comm(c), c->lm_memoff.p, c->lm_mem.p, N, d, c->lemb.p, c->lweight.p, c->dii.p,
                              c->lcomm.p);
+    }
+    if (c->rows_sharded) {
+        // option shard_rows: a landmark's members live on one rank, which has just aggregated it (the others wrote zeros for
+        // it); centroids, weights, d_ii and communities of ALL landmarks on every rank by one gather (N (d + 3) words)
+        DevBuf<double> &X = c->samp_xchg;
+        const i64 words = N * (d + 3);
+        X.ensure(words);
+        k_pack_landmarks(c, c->lemb.p, c->lweight.p, c->dii.p, c->lcomm.p, N, d, X.p, 0);
+        allreduce(c, X.p, words, 2);
+        k_pack_landmarks(c, c->lemb.p, c->lweight.p, c->dii.p, c->lcomm.p, N, d, X.p, 1);
     }
     HIP_CHECK(hipStreamSynchronize(st));
     c->phases.ms["aggregate"] = now_ms() - t0;
@@ -627,6 +838,7 @@ int cge_landmarks_fetch(cge_ctx *c, double *dii, double *embed, int64_t *cluster
     if (!c->lm_ready) CGE_THROW(CGE_E_ARG, "landmarks_fetch: run cge_landmarks_run first");
     HIP_CHECK(hipSetDevice(c->device));
     if (!c->wedges_ready) scatter_wedges(c, c->lm_directed);
+    if (ledges || lw_e) wedges_whole(c);
     const i64 N = c->N, d = c->d, n = c->n;
     hipStream_t st = c->stream;
     if (dii) HIP_CHECK(hipMemcpyAsync(dii, c->dii.p, sizeof(double) * N, hipMemcpyDeviceToHost, st));
@@ -739,6 +951,21 @@ static double exact_pair_distance(cge_ctx *c, i64 bi, i64 bj) {
     DevBuf<double> &dd = c->epd_d;
     pij.ensure(2);
     dd.ensure(1);
+    if (c->rows_sharded) { // the two rows come from their owners (zero-filled gather, exact), then the same kernel on the pair
+        const i64 d = c->d;
+        const i32 l[2] = {c->h_glob2loc[bi], c->h_glob2loc[bj]}, two[2] = {0, bi == bj ? 0 : 1};
+        DevBuf<double> &rows = c->dm_seed;
+        rows.ensure(2 * d + 2);
+        double hi = 0.0;
+        HIP_CHECK(hipMemcpyAsync(pij.p, l, sizeof(l), hipMemcpyHostToDevice, c->stream));
+        k_gather_rows_f64(c, c->Xr.p, c->n_loc, d, 1, pij.p, 2, rows.p);
+        allreduce(c, rows.p, 2 * d, 2);
+        HIP_CHECK(hipMemcpyAsync(pij.p, two, sizeof(two), hipMemcpyHostToDevice, c->stream));
+        k_pair_dist(c, rows.p, d, pij.p, pij.p + 1, 1, 1.0, dd.p);
+        HIP_CHECK(hipMemcpyAsync(&hi, dd.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return hi;
+    }
     const i32 h[2] = {(i32)bi, (i32)bj};
     double hi = 0.0;
     HIP_CHECK(hipMemcpyAsync(pij.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
@@ -765,7 +992,7 @@ static double resident_diameter(cge_ctx *c, int part, int nparts, i64 *ai, i64 *
 // the same with landmark-pair pruning in front (diameter_host.cpp); `mu` = N reference points (device, row-major)
 static double resident_diameter_lm(cge_ctx *c, const double *mu, const double *lw, const std::vector<i32> &lcomm, i64 C,
                                    i64 N, int part, int nparts) {
-    if (c->opt_diameter != 1 && (i64)c->h_mem_off.size() == N + 1) {
+    if ((c->opt_diameter != 1 || c->rows_sharded) && (i64)c->h_mem_off.size() == N + 1) { // (sharded rows: the pruned search only)
         double d2;
         i64 bi, bj;
         if (host_diameter_pruned(c, mu, lw, lcomm, C, N, c->h_mem_off, c->h_mem, part, nparts, &d2, &bi, &bj)) {
@@ -780,6 +1007,24 @@ static double resident_diameter_lm(cge_ctx *c, const double *mu, const double *l
 // landmark -> members CSR (ascending vertex id) from a 0-based assignment
 static void build_landmark_index(cge_ctx *c, const std::vector<i32> &v2l0, i64 N) {
     const i64 n = (i64)v2l0.size();
+    if (c->rows_sharded) { // this rank's members (local row ids, ascending) + the global sizes; the index goes to the device
+        const i64 nl = c->n_loc;
+        c->h_gl_off.assign(N + 1, 0);
+        c->h_mem_off.assign(N + 1, 0);
+        c->h_mem.resize(nl);
+        for (i64 i = 0; i < n; i++) c->h_gl_off[v2l0[i] + 1]++;
+        for (i64 i = 0; i < nl; i++) c->h_mem_off[v2l0[c->h_loc2glob[i]] + 1]++;
+        for (i64 l = 0; l < N; l++) { c->h_gl_off[l + 1] += c->h_gl_off[l]; c->h_mem_off[l + 1] += c->h_mem_off[l]; }
+        std::vector<i32> cur(c->h_mem_off.begin(), c->h_mem_off.end() - 1);
+        for (i64 i = 0; i < nl; i++) c->h_mem[cur[v2l0[c->h_loc2glob[i]]]++] = (i32)i;
+        c->lm_memoff.ensure(N + 1);
+        c->lm_mem.ensure(nl);
+        HIP_CHECK(hipMemcpyAsync(c->lm_memoff.p, c->h_mem_off.data(), sizeof(i32) * (N + 1), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(c->lm_mem.p, c->h_mem.data(), sizeof(i32) * nl, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->lm_index_on_device = true;
+        return;
+    }
     c->lm_index_on_device = false;
     c->h_mem_off.assign(N + 1, 0);
     c->h_mem.resize(n);
@@ -1106,7 +1351,15 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
             c->s_degin.ensure(N);
             c->s_degout.ensure(N);
             star.ensure(N);
-            k_wedge_degrees(c, c->wedges.p, N, c->s_degout.p, c->s_degin.p, star.p);
+            if (c->wedges_block_only) { // a reduce-scattered matrix: this rank's row block, then the ranks add the three vectors
+                const i64 per = wedge_rows_per_rank(c, N), r0 = std::min<i64>(N, per * c->coll.rank), r1 = std::min<i64>(N, r0 + per);
+                DevBuf<double> &X = c->samp_xchg;
+                X.ensure(3 * N);
+                k_wedge_degrees_block(c, c->wedges.p, N, r0, r1, X.p);
+                allreduce(c, X.p, 3 * N, 0);
+                k_degrees_unpack(c, X.p, N, c->s_degout.p, c->s_degin.p, star.p);
+            } else
+                k_wedge_degrees(c, c->wedges.p, N, c->s_degout.p, c->s_degin.p, star.p);
             if (star_exit(N)) return CGE_OK;
             G.deg_in = c->s_degin.p;
             G.deg_out = c->s_degout.p;
@@ -1151,6 +1404,8 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     } else {
         if (c->edges_sharded)
             CGE_THROW(CGE_E_ARG, "score: exact mode reads the whole edge list on every rank; the resident one is sharded (option shard_ingest)");
+        if (c->rows_sharded)
+            CGE_THROW(CGE_E_ARG, "score: exact mode reads every embedding row on every rank; the resident rows are sharded (option shard_rows)");
         const i64 N = c->n, C = c->n_comm_max;
         zeros.ensure(N);
         HIP_CHECK(hipMemsetAsync(zeros.p, 0, sizeof(double) * N, st)); // distances = zeros (CGE_CLI.jl:4)
@@ -1307,6 +1562,11 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_shard_ingest = value != 0;
         return CGE_OK;
     }
+    if (!strcmp(key, "shard_rows")) { // N > 1: 1 = cge_set_embedding / cge_set_embedding_device keep the rows of this rank's communities only
+        // (sharded BY COMMUNITY; set the collectives and upload the communities first); 0 (default): every rank holds every row
+        c->opt_shard_rows = value != 0;
+        return CGE_OK;
+    }
     if (!strcmp(key, "cov_derive")) { // 1: the larger child's covariance = its parent's minus its sibling's (only the smaller child is summed); 0 (default): every one over its rows
         c->opt_cov_derive = value != 0;
         return CGE_OK;
@@ -1363,6 +1623,8 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "edges_resident")) *value = c->m;
     else if (!strcmp(key, "edges_total")) *value = c->m_total;
     else if (!strcmp(key, "embedding_words_resident")) *value = (i64)c->Xr.n;
+    else if (!strcmp(key, "rows_resident")) *value = c->Xr.p ? lm_rows(c) : 0; // embedding rows held by this rank (option shard_rows: ~ n / world)
+    else if (!strcmp(key, "rows_total")) *value = c->n;
     else if (!strcmp(key, "collective_calls")) *value = c->stat_coll_calls;
     else if (!strcmp(key, "collective_bytes")) *value = c->stat_coll_bytes;
     else if (!strcmp(key, "diameter_bits")) memcpy(value, &c->stat_last_hi, sizeof(double)); // bit pattern of the last `hi`
@@ -1572,3 +1834,4 @@ void cge_allgather_dev(cge_ctx *c, double *buf, i64 wpr) {
 
 // for the other translation units (diameter_host.cpp)
 void cge_allreduce_dev(cge_ctx *c, double *dev, i64 count, int op) { allreduce(c, dev, count, op); }
+double cge_allreduce_scalar_max(cge_ctx *c, double v) { return allreduce_scalar_max(c, v); }

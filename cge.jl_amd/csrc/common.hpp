@@ -270,6 +270,24 @@ struct cge_ctx {
     bool edges_sharded = false;
     int opt_shard_ingest = 0;
     DevBuf<double> samp_xchg;  // sampled edges of a sharded list on their way through the all-reduce
+    // N > 1 with option "shard_rows": the EMBEDDING ROWS are sharded BY COMMUNITY (north star: "edge list and embedding rows
+    // shard across the GPUs").  A community lives on one rank (largest first, each to the least loaded rank); rank r keeps
+    // the rows of its communities only: Xr is n_loc x d, local row i = the i-th owned vertex in ascending vertex id
+    // (loc2glob / glob2loc, -1 = another rank's).  Everything that walks rows (runsplit, aggregation, the bound pass and the
+    // sweeps of the diameter, row hashes) runs over LOCAL ids against Xr / vw_loc / comm_loc; the small per-vertex tables
+    // (vw, comm, v2l: 4-8 bytes per vertex) stay replicated, global ids.  What crosses ranks is listed in DESIGN.md section 6.
+    int opt_shard_rows = 0;
+    bool rows_sharded = false;
+    i64 n_loc = 0;
+    std::vector<i32> h_loc2glob, h_glob2loc;
+    std::vector<int> comm_owner;     // owner rank of community q (0-based)
+    DevBuf<i32> loc2glob, glob2loc, comm_loc;
+    DevBuf<double> vw_loc;
+    std::vector<double> h_vw_loc;
+    std::vector<i32> h_gl_off;       // landmark -> GLOBAL member counts as a prefix (N + 1); h_mem_off holds the LOCAL ones
+    std::vector<int> lm_owner;       // owner rank of every landmark of the last run
+    DevBuf<i32> v2l_loc;             // landmark of every local row
+    bool wedges_block_only = false;  // the N x N landmark-pair matrix was reduce-scattered: only this rank's row block is summed
     bool unit_weights = false;
     bool blocked_ready = false; // blocked copy of the edge list (edge pass) matches src/dst
     DevBuf<i32> src, dst;     // 0-based
@@ -376,6 +394,10 @@ struct cge_ctx {
     DevBuf<float> Xs32, Ms32;              // fp32 copies: operands of the fp32-MFMA bound pass (upper bounds only)
     DevBuf<unsigned short> Xb16, Mb16;     // two-plane bf16 operands of the bf16-split bound pass
     DevBuf<int> dm_flag;                   // raised by the bf16 gather when a value is unfit for the split
+    // exact stage of the pruned diameter: the candidate landmarks' rows gathered per round (centred, feature-major), their
+    // norms, source rows and global vertex ids; the seed row of the farthest-point sweep (option shard_rows)
+    DevBuf<double> xe, xe_rns, dm_seed;
+    DevBuf<i32> xe_pos, xe_glob, xe_sub, dm_soffE;
     int opt_diameter_f32 = 2;              // the point-to-reference maxima: 2 = bf16 matrix pipe, operands split in two terms (K <= 128; else 1),
                                            // 1 = fp32-input MFMA, 0 = fp64 MFMA; 1 and 2 are upper bounds with a rigorous error margin
     DevBuf<i32> pos2node, sub_land, dm_soff, dm_memoff, dm_mem;
@@ -525,6 +547,12 @@ static inline void fit_sweep_begin(cge_ctx *c) {
     c->fit_persistent_broken = false;
 }
 
+// the row space the landmark phase works in: all vertices, or this rank's rows (option shard_rows)
+static inline i64 lm_rows(const cge_ctx *c) { return c->rows_sharded ? c->n_loc : c->n; }
+static inline const double *lm_vw(const cge_ctx *c) { return c->rows_sharded ? c->vw_loc.p : c->vw.p; }
+static inline const i32 *lm_comm(const cge_ctx *c) { return c->rows_sharded ? c->comm_loc.p : c->comm.p; }
+static inline const double *lm_hvw(const cge_ctx *c) { return c->rows_sharded ? c->h_vw_loc.data() : c->h_vw.data(); }
+
 static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -611,7 +639,9 @@ void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w,
 void k_edge_degrees(cge_ctx *c, const i32 *src, const i32 *dst, const double *w, i64 m, double *deg_out,
                     double *deg_in, i32 *star);
 void k_wedge_degrees(cge_ctx *c, const double *wedges, i64 N, double *deg_out, double *deg_in, i32 *star);
-void k_compact_count(cge_ctx *c, const double *wedges, i64 N, int directed, i64 *count);
+void k_compact_count(cge_ctx *c, const double *wedges, i64 N, int directed, i64 *count, i64 row0 = 0, i64 row1 = -1);
+void k_wedge_degrees_block(cge_ctx *c, const double *wedges, i64 N, i64 row0, i64 row1, double *out3N);
+void k_degrees_unpack(cge_ctx *c, const double *in3N, i64 N, double *deg_out, double *deg_in, i32 *star);
 void k_louvain_level1(cge_ctx *c, i64 *comm_out_host, i64 *n_comm, double *quality, i64 *rounds); // kernels_louvain.hip
 // distances
 void k_dist_matrix(cge_ctx *c, const double *emb, const double *diag, i64 N, i64 d, double *D);
@@ -628,6 +658,8 @@ void cge_rccl_allreduce(cge_ctx *c, void *dev, i64 count, int op); // collective
 bool cge_rccl_allgather(cge_ctx *c, void *dev, i64 words_per_rank); // in place (rank r's piece at r * words_per_rank); false: no such symbol
 // all-gather of 8-byte words in place: `buf` holds world pieces of `words_per_rank`, this rank's piece is filled in
 void cge_allgather_dev(cge_ctx *c, double *buf, i64 words_per_rank);
+bool cge_rccl_reduce_scatter(cge_ctx *c, void *dev, i64 words_per_rank); // in place: rank r's sums land at r * words_per_rank; false: no such symbol
+double cge_allreduce_scalar_max(cge_ctx *c, double v); // max of one double over the ranks (synchronises); v itself without collectives
 // can the exchange buffer hold `need` doubles?  With the in-library communicator a library-owned buffer grows on demand
 // (contents are not preserved); a caller-provided one (cge_set_exchange_buffer, the hook path) is what it is.
 bool cge_exchange_fits(cge_ctx *c, size_t need);
@@ -638,13 +670,22 @@ void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, 
 i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *mu_ref, i64 N, i64 nref, i64 d, double L,
                    void *list, i64 cap, const i32 *ref_off = nullptr, const i32 *ref_mem = nullptr, const double *Ms_fm = nullptr,
                    i64 dpad = 0, i64 ldm = 0);
-i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map); // map[argmax v] (synchronises the stream)
+i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map, double *val = nullptr);
+void k_pair_local_idx(cge_ctx *c, const i32 *pi, const i32 *pj, i64 S, const i32 *glob2loc, i32 *idx);
+void k_pair_dist_rows(cge_ctx *c, const double *B, i64 d, const i32 *pi, const i32 *pj, i64 S, double den, double *out);
+void k_position_ids(cge_ctx *c, const i32 *pos2node, const i32 *loc2glob, i64 npos, i32 *ids); // map[argmax v] (synchronises the stream)
 void k_ref_centroids(cge_ctx *c, const double *mu, const double *lw, const i32 *ref_off, const i32 *ref_mem, i64 nref,
                      i64 d, double *out);
 void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i);
-void k_farthest_enqueue(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src); // launch only (c->stream) ...
+void k_farthest_enqueue(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, const double *srow = nullptr); // launch only (c->stream) ...
 void k_farthest_collect(cge_ctx *c, double *best_val, i64 *best_i);            // ... and its result (synchronises c->stream)
-void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean);
+void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean, double sums_only = 0.0);
+void k_scale_vector(cge_ctx *c, double *v, i64 n, double f);
+void k_pack_landmarks(cge_ctx *c, double *lemb, double *lweight, double *dii, i32 *lcomm, i64 N, i64 d, double *X, int unpack);
+void k_scatter_u64(cge_ctx *c, const uint64_t *src, const i32 *idx, i64 cnt, uint64_t *dst);
+void k_scatter_i32(cge_ctx *c, const i32 *src, const i32 *idx, i64 cnt, i32 add, i32 *dst); // dst[idx[i]] = src[i] + add
+void k_add_i32(cge_ctx *c, const i32 *src, i64 n, i32 add, i32 *dst);
+void k_gather_rows_f64(cge_ctx *c, const double *X, i64 n, i64 d, int row_major, const i32 *idx, i64 cnt, double *out);
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
                         double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32 = nullptr,
                         unsigned short *planes = nullptr, i64 KP = 0, int *flag = nullptr); // planes: two bf16 terms, row-major [2][ld][KP]

@@ -960,12 +960,12 @@ __device__ __forceinline__ double row16_sum(double v) {
     return v;
 }
 __global__ __launch_bounds__(256) void farthest_kernel(const double *__restrict__ Xr, i64 n, i64 d, i64 src,
-                                                       MaxRec *__restrict__ recs) {
+                                                       const double *__restrict__ srow, MaxRec *__restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63, sub = lane & 15, quarter = lane >> 4;
     const i64 wave_global = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
-    const double *s = Xr + src * d;
+    const double *s = srow ? srow : Xr + src * d; // (srow: the seed row itself -- it may live on another rank, option shard_rows)
     double best = -1.0;
     i64 bi = 0;
     for (i64 base = wave_global * 8; base < n; base += nwaves * 8) {
@@ -1006,7 +1006,8 @@ __global__ __launch_bounds__(256) void argmax_kernel(const double *__restrict__ 
         if (v[i] > best) { best = v[i]; bi = i; }
     reduce_best(best, bi, map ? (i64)map[bi] : bi, lds, recs);
 }
-i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map) {
+i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map, double *val) {
+    if (n <= 0) { if (val) *val = -1.0; return -1; }
     c->mp_recs.ensure(MP_NWG * 3);
     MaxRec *recs = reinterpret_cast<MaxRec *>(c->mp_recs.p);
     const int nwg = (int)std::max<i64>(1, std::min<i64>((n + 255) / 256, 256));
@@ -1014,22 +1015,23 @@ i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map) {
     double bv;
     i64 bi, bj;
     best_of_recs(c, recs, nwg, &bv, &bi, &bj);
+    if (val) *val = bv;
     return bj;
 }
 // the sweep in two halves: the launch (on c->stream), and the read-back of its result (synchronises c->stream).  Nothing else
 // may use c->mp_recs in between (the bound passes do not).
 static const int FAR_NWG = 1024 > MP_NWG ? MP_NWG : 1024;
-void k_farthest_enqueue(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src) {
+void k_farthest_enqueue(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, const double *srow) {
     c->mp_recs.ensure(MP_NWG * 3);
     MaxRec *recs = reinterpret_cast<MaxRec *>(c->mp_recs.p);
-    hipLaunchKernelGGL(farthest_kernel, dim3(FAR_NWG), dim3(256), 768 * sizeof(double), c->stream, Xr, n, d, src, recs);
+    hipLaunchKernelGGL(farthest_kernel, dim3(FAR_NWG), dim3(256), 768 * sizeof(double), c->stream, Xr, n, d, src, srow, recs);
 }
 void k_farthest_collect(cge_ctx *c, double *best_val, i64 *best_i) {
     i64 bj;
     best_of_recs(c, reinterpret_cast<MaxRec *>(c->mp_recs.p), FAR_NWG, best_val, best_i, &bj);
 }
 void k_farthest(cge_ctx *c, const double *Xr, i64 n, i64 d, i64 src, double *best_val, i64 *best_i) {
-    k_farthest_enqueue(c, Xr, n, d, src);
+    k_farthest_enqueue(c, Xr, n, d, src, nullptr);
     k_farthest_collect(c, best_val, best_i);
 }
 
@@ -1051,6 +1053,37 @@ __global__ void pair_dist_kernel(const double *__restrict__ Xr, i64 d, const i32
         out[k] = s / den;
     }
 }
+// option shard_rows: the rows of a chunk of sampled pairs are gathered from their owners into B (rows 2k, 2k + 1 of pair k)
+// and the same arithmetic runs on the gathered rows
+__global__ void pair_local_idx_kernel(const i32 *__restrict__ pi, const i32 *__restrict__ pj, i64 S, const i32 *__restrict__ glob2loc,
+                                      i32 *__restrict__ idx) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S) return;
+    idx[2 * k] = glob2loc[pi[k]];
+    idx[2 * k + 1] = glob2loc[pj[k]];
+}
+__global__ void pair_dist_rows_kernel(const double *__restrict__ B, i64 d, const i32 *__restrict__ pi, const i32 *__restrict__ pj,
+                                      i64 S, double den, double *__restrict__ out) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < S; k += stride) {
+        const double *a = B + (2 * k) * d, *b = a + d;
+        double s = 0.0;
+        if (pi[k] != pj[k]) {
+            for (i64 q = 0; q < d; q++) {
+                const double df = __dsub_rn(a[q], b[q]);
+                s = __dadd_rn(s, __dmul_rn(df, df));
+            }
+            s = sqrt(s);
+        }
+        out[k] = s / den;
+    }
+}
+void k_pair_local_idx(cge_ctx *c, const i32 *pi, const i32 *pj, i64 S, const i32 *glob2loc, i32 *idx) {
+    if (S > 0) hipLaunchKernelGGL(pair_local_idx_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream, pi, pj, S, glob2loc, idx);
+}
+void k_pair_dist_rows(cge_ctx *c, const double *B, i64 d, const i32 *pi, const i32 *pj, i64 S, double den, double *out) {
+    if (S > 0) hipLaunchKernelGGL(pair_dist_rows_kernel, dim3(grid_for(S, 128)), dim3(128), 0, c->stream, B, d, pi, pj, S, den, out);
+}
 void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *pj, i64 S, double den, double *out) {
     if (S <= 0) return;
     hipLaunchKernelGGL(pair_dist_kernel, dim3(grid_for(S, 128)), dim3(128), 0, c->stream, Xr, d, pi, pj, S, den, out);
@@ -1065,7 +1098,7 @@ __global__ __launch_bounds__(256) void diameter_layout_kernel(const i32 *__restr
     const i64 m0 = mem_off[a], cnt = mem_off[a + 1] - m0, p0 = soff[a], p1 = soff[a + 1];
     for (i64 p = p0 + threadIdx.x; p < p1; p += 256) {
         const i64 q = p - p0;
-        pos2node[p] = mem[m0 + (q < cnt ? q : cnt - 1)];
+        pos2node[p] = cnt > 0 ? mem[m0 + (q < cnt ? q : cnt - 1)] : -1; // (no member here: another rank's landmark, option shard_rows)
         if ((q & 15) == 0) sub_land[p >> 4] = (i32)a;
     }
 }
@@ -1074,4 +1107,14 @@ void k_diameter_layout(cge_ctx *c, const i32 *mem_off, const i32 *mem, const i32
     HIP_CHECK(hipMemsetAsync(sub_land, 0xFF, sizeof(i32) * n_sub, c->stream));
     hipLaunchKernelGGL(diameter_layout_kernel, dim3((unsigned)N), dim3(256), 0, c->stream, mem_off, mem, soff, pos2node,
                        sub_land);
+}
+// ids[p] = (global vertex id of position p) + 1, 0 for a position whose row lives on another rank (the ranks add the words)
+__global__ void position_ids_kernel(const i32 *__restrict__ pos2node, const i32 *__restrict__ loc2glob, i64 npos, i32 *__restrict__ ids) {
+    const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npos) return;
+    const i32 v = pos2node[p];
+    ids[p] = v < 0 ? 0 : (loc2glob ? loc2glob[v] : v) + 1;
+}
+void k_position_ids(cge_ctx *c, const i32 *pos2node, const i32 *loc2glob, i64 npos, i32 *ids) {
+    if (npos > 0) hipLaunchKernelGGL(position_ids_kernel, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, c->stream, pos2node, loc2glob, npos, ids);
 }

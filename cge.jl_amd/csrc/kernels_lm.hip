@@ -140,7 +140,10 @@ __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i3
     for (i64 k0 = 0; k0 < d; k0 += 32) {
         for (int r = ty; r < 32; r += 8) {
             const i64 p = p0 + r, k = k0 + tx;
-            if (p < npos && k < d) {
+            tile[r][tx] = 0.0;
+            // (a negative index: a position whose row lives on another rank -- option shard_rows; it stays zero here and the
+            // gather over the ranks fills it)
+            if (p < npos && k < d && (!idx || idx[p] >= 0)) {
                 const double v = src[(idx ? (i64)idx[p] : p) * d + k] - mean[k];
                 tile[r][tx] = v;
                 if (flag) { // fitness for the low-precision bound passes (bit 0: unfit value; bit 1: a value of ordinary size exists)
@@ -164,7 +167,7 @@ __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i3
             const i64 p = p0 + tx, k = k0 + r;
             if (p < npos && k < d) {
                 const double v = tile[tx][r];
-                dst[k * ld + p] = v;
+                if (dst) dst[k * ld + p] = v;
                 if (dst32) dst32[k * ld + p] = (float)v; // operand of the fp32-MFMA bound pass
                 sq += v * v;
             }
@@ -184,20 +187,44 @@ __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i3
         }
     }
 }
-void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean) {
+// `sums_only` != 0: the column SUMS (the sharded rows: the ranks add their sums and divide by the global n)
+void k_col_mean(cge_ctx *c, const double *Xrow, i64 n, i64 d, double *mean, double sums_only) {
     const int NB = 512;
     DevBuf<double> part;
     part.ensure((size_t)NB * d);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(NB), dim3(256), 0, c->stream, Xrow, n, d, part.p);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, c->stream, part.p,
-                       (i64)NB, n, d, mean);
+                       (i64)NB, sums_only != 0.0 ? (i64)1 : n, d, mean);
     HIP_CHECK(hipStreamSynchronize(c->stream)); // part is freed on return
+}
+__global__ void scale_vector_kernel(double *__restrict__ v, i64 n, double f) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= f;
+}
+void k_scale_vector(cge_ctx *c, double *v, i64 n, double f) {
+    hipLaunchKernelGGL(scale_vector_kernel, dim3(grid_for(n, 256, 1 << 20)), dim3(256), 0, c->stream, v, n, f);
+}
+// out[i][k] = X[idx[i]][k] for a row-major (n x d) or column-major X: this rank's rows of a device-resident embedding
+__global__ void gather_rows_f64_kernel(const double *__restrict__ X, i64 n, i64 d, int row_major, const i32 *__restrict__ idx,
+                                       i64 cnt, double *__restrict__ out) {
+    const i64 total = cnt * d, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const i64 i = e / d, k = e - i * d, g = idx[i];
+        out[e] = g < 0 ? 0.0 : (row_major ? X[g * d + k] : X[k * n + g]); // (a negative index: a zero row -- another rank fills it)
+    }
+}
+void k_gather_rows_f64(cge_ctx *c, const double *X, i64 n, i64 d, int row_major, const i32 *idx, i64 cnt, double *out) {
+    if (cnt <= 0) return;
+    hipLaunchKernelGGL(gather_rows_f64_kernel, dim3(grid_for(cnt * d, 256, 8192)), dim3(256), 0, c->stream, X, n, d, row_major,
+                       idx, cnt, out);
 }
 // Centred, zero-padded feature-major copy (dpad x ld) of npos gathered rows + squared row norms (ld entries).
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
                         double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32, unsigned short *planes, i64 KP,
                         int *flag) {
-    HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(ld * dpad), c->stream));
+    // (`dst` = nullptr: no fp64 copy -- the low-precision bound passes read the planes / the f32 copy, and the exact stage of
+    // the diameter gathers only the candidate landmarks' rows)
+    if (dst) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(ld * dpad), c->stream));
     if (planes) HIP_CHECK(hipMemsetAsync(planes, 0, sizeof(unsigned short) * (size_t)(2 * ld * KP), c->stream));
     if (dst32) HIP_CHECK(hipMemsetAsync(dst32, 0, sizeof(float) * (size_t)(ld * dpad), c->stream));
     HIP_CHECK(hipMemsetAsync(rnorm, 0, sizeof(double) * (size_t)ld, c->stream));
@@ -3606,6 +3633,11 @@ __global__ __launch_bounds__(256) void landmark_aggregate_kernel(const double *_
     double *cen = sh, *buf = sh + d;
     const i64 l = blockIdx.x;
     const i32 b = mem_off[l], e = mem_off[l + 1];
+    if (e == b) { // no member here (option shard_rows: another rank's landmark): zeros, which the gather over the ranks fills
+        for (i64 col = threadIdx.x; col < d; col += blockDim.x) lemb[l * d + col] = 0.0;
+        if (threadIdx.x == 0) { lweight[l] = 0.0; dii[l] = 0.0; lcomm[l] = -1; }
+        return;
+    }
     double lw = 0.0;
     {
         i32 t = b;
@@ -3665,6 +3697,29 @@ __global__ __launch_bounds__(256) void landmark_aggregate_kernel(const double *_
         dii[l] = lw > 0 ? sqrt(tot / lw) : tot; // :418-423
         lcomm[l] = (e > b) ? comm[mem[e - 1]] : 0; // last writer wins (:427-429)
     }
+}
+// the landmark tables to / from one exchange vector: [lemb N x d | lweight N | dii N | lcomm + 1 as a double N]
+__global__ void pack_landmarks_kernel(double *__restrict__ lemb, double *__restrict__ lweight, double *__restrict__ dii,
+                                      i32 *__restrict__ lcomm, i64 N, i64 d, double *__restrict__ X, int unpack) {
+    const i64 total = N * (d + 3), stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        if (e < N * d) { if (unpack) lemb[e] = X[e]; else X[e] = lemb[e]; continue; }
+        const i64 q = e - N * d, l = q % N, w = q / N;
+        if (w == 0) { if (unpack) lweight[l] = X[e]; else X[e] = lweight[l]; }
+        else if (w == 1) { if (unpack) dii[l] = X[e]; else X[e] = dii[l]; }
+        else { if (unpack) lcomm[l] = (i32)X[e] - 1; else X[e] = (double)(lcomm[l] + 1); }
+    }
+}
+void k_pack_landmarks(cge_ctx *c, double *lemb, double *lweight, double *dii, i32 *lcomm, i64 N, i64 d, double *X, int unpack) {
+    hipLaunchKernelGGL(pack_landmarks_kernel, dim3(grid_for(N * (d + 3), 256, 4096)), dim3(256), 0, c->stream, lemb, lweight, dii,
+                       lcomm, N, d, X, unpack);
+}
+__global__ void scatter_u64_kernel(const uint64_t *__restrict__ src, const i32 *__restrict__ idx, i64 cnt, uint64_t *__restrict__ dst) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) dst[idx[i]] = src[i];
+}
+void k_scatter_u64(cge_ctx *c, const uint64_t *src, const i32 *idx, i64 cnt, uint64_t *dst) {
+    if (cnt > 0) hipLaunchKernelGGL(scatter_u64_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, src, idx, cnt, dst);
 }
 void k_landmark_aggregate(cge_ctx *c, const double *Xr, const double *vw, const i32 *comm, const i32 *mem_off,
                           const i32 *mem, i64 N, i64 d, double *lemb, double *lweight, double *dii, i32 *lcomm) {
@@ -3806,19 +3861,67 @@ void k_ref_centroids(cge_ctx *c, const double *mu, const double *lw, const i32 *
     hipLaunchKernelGGL(ref_centroids_kernel, dim3((unsigned)nref), dim3(128), 0, c->stream, mu, lw, ref_off, ref_mem, d, out);
 }
 
-__global__ void compact_count_kernel(const double *__restrict__ wedges, i64 N, int directed,
+__global__ void compact_count_kernel(const double *__restrict__ wedges, i64 N, int directed, i64 row0, i64 row1,
                                      unsigned long long *__restrict__ count) {
-    const i64 total = N * N, stride = (i64)gridDim.x * blockDim.x;
+    const i64 total = row1 * N, stride = (i64)gridDim.x * blockDim.x;
     unsigned long long local = 0;
-    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    for (i64 e = row0 * N + (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const i64 a = e / N, b = e - a * N;
         if ((directed || b >= a) && wedges[e] > 0) local++;
     }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
 }
-void k_compact_count(cge_ctx *c, const double *wedges, i64 N, int directed, i64 *count) {
+// positive entries of the rows [row0, row1) (row1 < 0: all rows); upper triangle incl. the diagonal when undirected
+void k_compact_count(cge_ctx *c, const double *wedges, i64 N, int directed, i64 *count, i64 row0, i64 row1) {
+    if (row1 < 0) { row0 = 0; row1 = N; }
     HIP_CHECK(hipMemsetAsync(count, 0, sizeof(i64), c->stream));
-    hipLaunchKernelGGL(compact_count_kernel, dim3(grid_for(N * N, 256)), dim3(256), 0, c->stream, wedges, N, directed,
-                       reinterpret_cast<unsigned long long *>(count));
+    if (row1 > row0)
+        hipLaunchKernelGGL(compact_count_kernel, dim3(grid_for((row1 - row0) * N, 256)), dim3(256), 0, c->stream, wedges, N, directed,
+                           row0, row1, reinterpret_cast<unsigned long long *>(count));
+}
+// degrees / star counts of the landmark graph (wedge_degrees_kernel) from a ROW BLOCK [row0, row1) of the landmark-pair matrix
+// (the matrix was reduce-scattered over the ranks): out[0..N) row sums of the block's rows (0 elsewhere), out[N..2N) this
+// block's share of every column sum, out[2N..3N) its share of the star counts; the ranks add the three vectors.
+__global__ __launch_bounds__(256) void wedge_degrees_block_kernel(const double *__restrict__ wedges, i64 N, i64 row0, i64 row1,
+                                                                  double *__restrict__ out) {
+    __shared__ double sh[256];
+    __shared__ int shc[256];
+    const i64 a = blockIdx.x; // a < N: row a (if in the block); a >= N: column a - N over the block's rows
+    double acc = 0.0;
+    int cnt = 0;
+    if (a < N) {
+        if (a >= row0 && a < row1)
+            for (i64 b = threadIdx.x; b < N; b += 256) { const double w = wedges[a * N + b]; acc += w; cnt += w > 0; }
+    } else {
+        const i64 col = a - N;
+        for (i64 r = row0 + threadIdx.x; r < row1; r += 256) { const double w = wedges[r * N + col]; acc += w; cnt += w > 0; }
+    }
+    sh[threadIdx.x] = acc;
+    shc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sh[threadIdx.x] += sh[threadIdx.x + s]; shc[threadIdx.x] += shc[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[a] = sh[0];
+        // the star count of a vertex = positive entries of its row + of its column: both halves into the same slot
+        atomicAdd(&out[2 * N + (a < N ? a : a - N)], (double)shc[0]);
+    }
+}
+__global__ void degrees_unpack_kernel(const double *__restrict__ in, i64 N, double *__restrict__ deg_out, double *__restrict__ deg_in,
+                                      i32 *__restrict__ star) {
+    const i64 a = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N) return;
+    deg_out[a] = in[a];
+    deg_in[a] = in[N + a];
+    star[a] = (i32)in[2 * N + a];
+}
+void k_wedge_degrees_block(cge_ctx *c, const double *wedges, i64 N, i64 row0, i64 row1, double *out3N) {
+    HIP_CHECK(hipMemsetAsync(out3N, 0, sizeof(double) * 3 * N, c->stream));
+    hipLaunchKernelGGL(wedge_degrees_block_kernel, dim3((unsigned)(2 * N)), dim3(256), 0, c->stream, wedges, N, row0, row1, out3N);
+}
+void k_degrees_unpack(cge_ctx *c, const double *in3N, i64 N, double *deg_out, double *deg_in, i32 *star) {
+    hipLaunchKernelGGL(degrees_unpack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, in3N, N, deg_out, deg_in, star);
 }

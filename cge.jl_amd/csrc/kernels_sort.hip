@@ -373,6 +373,22 @@ i64 k_groups_to_index(cge_ctx *c, const i32 *arena, const i32 *goff, const i32 *
     return bad;
 }
 
+// dst[idx[i]] = src[i] + add  /  dst[i] = src[i] + add  (option shard_rows: per-row results into per-vertex tables)
+__global__ void scatter_i32_kernel(const i32 *__restrict__ src, const i32 *__restrict__ idx, i64 cnt, i32 add, i32 *__restrict__ dst) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) dst[idx[i]] = src[i] + add;
+}
+__global__ void add_i32_kernel(const i32 *__restrict__ src, i64 n, i32 add, i32 *__restrict__ dst) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + add;
+}
+void k_scatter_i32(cge_ctx *c, const i32 *src, const i32 *idx, i64 cnt, i32 add, i32 *dst) {
+    if (cnt > 0) hipLaunchKernelGGL(scatter_i32_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, src, idx, cnt, add, dst);
+}
+void k_add_i32(cge_ctx *c, const i32 *src, i64 n, i32 add, i32 *dst) {
+    if (n > 0) hipLaunchKernelGGL(add_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, n, add, dst);
+}
+
 // mean[t][:] <- the d doubles at off[t] of the means arena
 __global__ void gather_means_kernel(const double *__restrict__ arena, const i64 *__restrict__ off, i64 d,
                                     double *__restrict__ mean) {

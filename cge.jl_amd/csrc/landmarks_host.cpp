@@ -52,6 +52,7 @@ struct Group {
     // (c->lm_means), -1 = compute it on the device.  cmean_off: the two children's means, low then high.
     i64 mean_off = -1, cmean_off = -1;
     Group *parent = nullptr; // (children of a cached split)
+    int owner = 0;           // option shard_rows: the rank that holds this group's rows (off / coff / mean_off are -1 elsewhere)
     i64 cov_off = -1;        // this group's covariance in the covariance arena (c->lm_covs), once it has been a task
 };
 
@@ -530,7 +531,7 @@ void upload_batch_host(cge_ctx *c, const Batch &B) {
 const double *side_sums_resident(cge_ctx *c, const Batch &B) {
     const i64 d = c->d, width = 2 * (2 * d + 1);
     hipStream_t st = c->stream;
-    k_group_side_sums(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
+    k_group_side_sums(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
                       c->ls_part.p, c->ls_sums.p);
     c->pin_sums.ensure((size_t)B.T * width);
     HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->ls_sums.p, sizeof(double) * B.T * width, hipMemcpyDeviceToHost, st));
@@ -592,7 +593,7 @@ void rule_rss_batched(cge_ctx *c, const Batch &B, Group *const *groups, const do
     const i64 T = B.T, d = c->d, width = 2 * (2 * d + 1);
     cge_ctx *hr = root_of(c); // the host mirrors live in the root context
     cge_ensure_host_embedding(hr); // generic round-based path only (ties at the maximum of z, NaNs)
-    const double *hX = hr->h_Xr.data(), *hw = hr->h_vw.data();
+    const double *hX = hr->h_Xr.data(), *hw = lm_hvw(hr); // (option shard_rows: this rank's rows, local ids)
     st.assign(T, RssState());
     parallel_for(c, T, [&](i64 t) {
         RssState &S = st[t];
@@ -731,9 +732,9 @@ void rule_rss_sorted_enqueue(LaneRun &L) {
     c->ls_keys.ensure(R); c->ls_nlow.ensure(T);
     k_segmented_sort_z(c, c->ls_z.p, c->ls_rows.p, c->ls_row_task.p, c->sp_tro.p, R, T, c->sp_zs.p, c->sp_perm.p,
                        c->sp_srows.p, c->sp_status.p, B.max_len);
-    k_sorted_prefix(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
+    k_sorted_prefix(c, c->Xr.p, lm_vw(c), c->sp_srows.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, T, d, c->sp_ctot.p,
                     c->sp_coff.p, c->sp_prefix.p);
-    k_rss_rounds(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->ls_tco.p, c->sp_prefix.p, c->sp_coff.p,
+    k_rss_rounds(c, c->Xr.p, lm_vw(c), c->sp_srows.p, c->sp_zs.p, c->sp_tro.p, c->ls_tco.p, c->sp_prefix.p, c->sp_coff.p,
                  T, d, c->sp_meta.p, c->sp_rounds.p, c->sp_vals.p, c->lm_means.p + L.mbase); // the children's means stay on the device
     k_rss_child_keys(c, c->sp_perm.p, c->ls_row_task.p, c->sp_tro.p, c->sp_meta.p, c->sp_rounds.p, R, T, c->ls_keys.p,
                      c->ls_nlow.p);
@@ -778,7 +779,7 @@ void rule_rss2_enqueue(LaneRun &L) {
                        c->sp_srows.p, c->sp_status.p, B.max_len);
     HIP_CHECK(hipMemcpyAsync(c->lm_arena.p + L.base, c->sp_srows.p, sizeof(i32) * R, hipMemcpyDeviceToDevice, st));
     c->r2_rows = R;
-    k_rss2_walk(c, c->Xr.p, c->vw.p, c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->lm_means.p + L.mbase);
+    k_rss2_walk(c, c->Xr.p, lm_vw(c), c->sp_srows.p, c->sp_tro.p, T, d, c->sp_meta.p, c->sp_vals.p, c->lm_means.p + L.mbase);
     L.wg.reset(new WordGatherer(c));
     L.i_meta = L.wg->add(c->sp_meta.p, 2 * T); L.i_vals = L.wg->add(c->sp_vals.p, 2 * T);
     L.wg->fetch_async();
@@ -818,7 +819,7 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
     k_side_counts(c, c->ls_side.p, c->sp_tro.p, T, c->ls_nlow.p);
     c->pin_res.ensure((size_t)T); // pinned: the copies do not stall the host, the event below covers them
     HIP_CHECK(hipMemcpyAsync(c->pin_res.p, c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
-    k_group_side_sums(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
+    k_group_side_sums(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
                       c->ls_part.p, c->ls_sums.p);
     c->pin_sums.ensure((size_t)B.T * width);
     HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->ls_sums.p, sizeof(double) * B.T * width, hipMemcpyDeviceToHost, st));
@@ -963,7 +964,7 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
             if (have_means) // the offsets went up with the batch's tables
                 k_gather_means(c, c->lm_means.p, c->ls_moff.p, T, d, c->ls_mean.p);
             else {
-                k_group_mean(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
+                k_group_mean(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                              c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
                 if (L.cbase >= 0 && L.rmbase >= 0) // roots: their means join the arena, their children can then be derived
                     HIP_CHECK(hipMemcpyAsync(c->lm_means.p + L.rmbase, c->ls_mean.p, sizeof(double) * T * d, hipMemcpyDeviceToDevice, st));
@@ -985,7 +986,7 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
                 }
             }
             if (pairs.empty())
-                k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
+                k_group_cov(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                             c->ls_mean.p, c->ls_part.p, covp);
             else {
                 std::vector<i32> ct2, cb2, ce2, tco2(T + 1, 0);
@@ -1004,9 +1005,9 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
                 pk.add(c->ls_ct2.p, ct2.data(), NC2); pk.add(c->ls_cb2.p, cb2.data(), NC2); pk.add(c->ls_ce2.p, ce2.data(), NC2);
                 pk.add(c->ls_tco2.p, tco2.data(), T + 1); pk.add(c->ls_pairs.p, pairs.data(), 6 * NP);
                 pk.flush();
-                k_group_cov(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_ct2.p, c->ls_cb2.p, c->ls_ce2.p, NC2, c->ls_tco2.p, T, d,
+                k_group_cov(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_ct2.p, c->ls_cb2.p, c->ls_ce2.p, NC2, c->ls_tco2.p, T, d,
                             c->ls_mean.p, c->ls_part.p, covp);
-                k_cov_derive(c, c->ls_pairs.p, NP, c->lm_means.p, c->lm_covs.p, covp, c->ls_rows.p, c->sp_tro.p, c->vw.p, d);
+                k_cov_derive(c, c->ls_pairs.p, NP, c->lm_means.p, c->lm_covs.p, covp, c->ls_rows.p, c->sp_tro.p, lm_vw(c), d);
                 root->stat_cov_derived += NP;
             }
             if (L.cbase >= 0)
@@ -1026,7 +1027,7 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
         }
         {
             ScopedKernelTimer tm(c, "group_project");
-            k_group_project(c, c->Xr.p, c->vw.p, c->ls_rows.p, c->ls_row_task.p, R, d, c->ls_mean.p, c->ls_vec.p,
+            k_group_project(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_row_task.p, R, d, c->ls_mean.p, c->ls_vec.p,
                             c->ls_z.p);
         }
     }
@@ -1143,12 +1144,59 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
     }
 }
 
+// N > 1, option shard_rows: a group's rows live on ONE rank (its community's owner), which computes the split; what the
+// replicated heap needs of it -- status, size of the low child, the two children's values: four 8-byte words per group --
+// is gathered by one all-reduce into a zero-filled buffer (op 2: integer sum of the words, exact).  The member lists, the
+// means and the arena offsets never leave the owner.
+void exchange_group_words(cge_ctx *c, std::vector<double> &w) { // in: this rank's words, zeros elsewhere; out: everybody's
+    if (w.empty()) return;
+    PhaseAcc px(c, "lm_exchange");
+    DevBuf<double> &X = c->samp_xchg; // (free during the landmark phase)
+    X.ensure(w.size());
+    HIP_CHECK(hipMemcpyAsync(X.p, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, c->stream));
+    cge_allreduce_dev(c, X.p, (i64)w.size(), 2);
+    HIP_CHECK(hipMemcpyAsync(w.data(), X.p, sizeof(double) * w.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+void compute_splits_rowsharded(cge_ctx *c, std::vector<Group *> &batch, int method) {
+    const i64 T = (i64)batch.size();
+    const int me = c->coll.rank;
+    std::vector<Group *> mine;
+    for (Group *g : batch)
+        if (g->owner == me) mine.push_back(g);
+    if (!mine.empty()) compute_splits(c, mine, method);
+    std::vector<double> w((size_t)4 * T, 0.0);
+    for (i64 t = 0; t < T; t++) {
+        const Group *g = batch[t];
+        if (g->owner != me) continue;
+        w[4 * t] = (double)(g->rc - 1); // (never the all-zero word: a group nobody answered for is detected below)
+        w[4 * t + 1] = (double)g->nlow;
+        w[4 * t + 2] = g->vlow;
+        w[4 * t + 3] = g->vhigh;
+    }
+    exchange_group_words(c, w);
+    for (i64 t = 0; t < T; t++) {
+        Group *g = batch[t];
+        if (g->owner == me) continue;
+        if (w[4 * t] == 0.0) CGE_THROW(CGE_E_COLLECTIVE, "runsplit (shard_rows): no rank answered for a group of rank %d", g->owner);
+        g->has_split = true;
+        g->rc = (int)w[4 * t] + 1;
+        g->coff = -1;
+        g->cmean_off = -1;
+        if (g->rc != CGE_OK) continue;
+        g->nlow = (i64)w[4 * t + 1];
+        g->vlow = w[4 * t + 2];
+        g->vhigh = w[4 * t + 3];
+    }
+}
+
 // N > 1, global phase: the groups of a batch are independent, so every rank cuts its share (longest first, each to the
 // least loaded rank) and the results -- status, cut position, children values, children member lists and means -- are
 // gathered by one all-reduce into zero-filled buffers (hook op 2, exact).  EVERY rank, owner or not, then re-allocates the
 // children ranges and means in the batch's order and takes the gathered values: all ranks stay in identical state.
 // Worth it only for batches with enough rows to outweigh the exchange.
 void compute_splits_sharded(cge_ctx *c, std::vector<Group *> &batch, int method) {
+    if (c->rows_sharded) { compute_splits_rowsharded(c, batch, method); return; }
     const i64 W = c->has_coll ? c->coll.world : 1, d = c->d, T = (i64)batch.size();
     i64 R = 0;
     for (Group *g : batch) R += g->len;
@@ -1281,13 +1329,15 @@ void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool, 
         g->clo->value = g->vlow;
         g->clo->mean_off = g->cmean_off;
         g->clo->parent = g;
+        g->clo->owner = g->owner;
         pool.emplace_back();
         g->chi = &pool.back();
-        g->chi->off = g->coff + g->nlow;
+        g->chi->off = g->coff >= 0 ? g->coff + g->nlow : -1; // (-1: another rank's rows, option shard_rows)
         g->chi->len = g->len - g->nlow;
         g->chi->value = g->vhigh;
         g->chi->mean_off = g->cmean_off >= 0 ? g->cmean_off + c_d : -1;
         g->chi->parent = g;
+        g->chi->owner = g->owner;
     }
 }
 
@@ -1439,7 +1489,9 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                    std::vector<i64> &group_ids, bool want_index, const std::function<i64()> *late_nland) {
     const i64 n = c->n, d = c->d;
     hipStream_t st = c->stream;
-    if (!c->Xr.p || c->Xr.n < (size_t)(n * d) || (i64)c->h_vw.size() != n)
+    const bool RS = c->rows_sharded; // option shard_rows: this rank holds (and splits) the rows of its own communities only
+    const int me = RS ? c->coll.rank : 0;
+    if (!c->Xr.p || c->Xr.n < (size_t)(lm_rows(c) * d) || (i64)c->h_vw.size() != n)
         CGE_THROW(CGE_E_ARG, "runsplit: embedding / vertex weights are not resident");
     std::deque<Group> pool;
     Heap H;
@@ -1458,7 +1510,54 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     c->lm_means_used = 0;
     c->lm_covs_used = 0;
     c->stat_lm_batches = c->stat_lm_rows = c->stat_lm_splits = c->stat_cov_derived = 0;
-    {
+    // option shard_rows: cl_owner[q] = the rank that holds cluster q's rows (the owner of its first member's community; a
+    // cluster has to lie inside one rank's rows), a_off[q] = where an OWNED cluster starts in this rank's arena (local ids)
+    std::vector<int> cl_owner;
+    std::vector<i64> a_off_v;
+    if (RS) {
+        cl_owner.assign(ncl, 0);
+        a_off_v.assign(ncl + 1, 0);
+        int bad = 0;
+        for (i64 q = 0; q < ncl; q++) {
+            a_off_v[q + 1] = a_off_v[q];
+            if (cl_off[q + 1] <= cl_off[q]) continue;
+            const i64 v0 = cl_flat[cl_off[q]];
+            if (v0 < 1 || v0 > n) { bad = 1; continue; }
+            cl_owner[q] = c->comm_owner[c->h_comm[v0 - 1]];
+            if (cl_owner[q] == me) a_off_v[q + 1] += cl_off[q + 1] - cl_off[q];
+        }
+        c->pin_rows[0].ensure(std::max<i64>(a_off_v[ncl], 1));
+        i32 *stage = c->pin_rows[0].p;
+        std::atomic<int> abad{bad};
+        parallel_for(c, ncl, [&](i64 q) {
+            const bool mine = cl_owner[q] == me;
+            for (i64 t = cl_off[q]; t < cl_off[q + 1]; t++) {
+                const i64 v = cl_flat[t];
+                if (v < 1 || v > n) { abad.store(1); continue; }
+                const i32 l = c->h_glob2loc[v - 1];
+                if (mine != (l >= 0)) { abad.store(2); continue; } // a cluster that spans two ranks' rows
+                if (mine) stage[a_off_v[q] + (t - cl_off[q])] = l;
+            }
+        });
+        // every rank must leave by the same door: the verdicts are exchanged before anybody throws
+        std::vector<double> verdict(1, (double)abad.load());
+        {
+            DevBuf<double> &X = c->samp_xchg;
+            X.ensure(1);
+            HIP_CHECK(hipMemcpyAsync(X.p, verdict.data(), sizeof(double), hipMemcpyHostToDevice, st));
+            cge_allreduce_dev(c, X.p, 1, 1);
+            HIP_CHECK(hipMemcpyAsync(verdict.data(), X.p, sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        if (verdict[0] == 1.0) CGE_THROW(CGE_E_ARG, "cluster member out of range 1..%lld", (long long)n);
+        if (verdict[0] != 0.0)
+            CGE_THROW(CGE_E_ARG, "option shard_rows: a cluster spans the rows of two ranks (the rows are sharded by the community "
+                                 "vector of cge_set_vertex_data: clusters must refine it)");
+        if (a_off_v[ncl] > 0) {
+            arena_alloc(c, a_off_v[ncl]);
+            HIP_CHECK(hipMemcpyAsync(c->lm_arena.p, stage, sizeof(i32) * a_off_v[ncl], hipMemcpyHostToDevice, st));
+        }
+    } else {
         c->pin_rows[0].ensure(total);
         i32 *stage = c->pin_rows[0].p;
         std::atomic<int> bad{0};
@@ -1472,6 +1571,8 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         arena_alloc(c, total);
         HIP_CHECK(hipMemcpyAsync(c->lm_arena.p, stage, sizeof(i32) * total, hipMemcpyHostToDevice, st));
     }
+    // where cluster q starts in this rank's arena (-1: another rank's rows)
+    auto a_off = [&](i64 q) -> i64 { return !RS ? cl_off[q] : (cl_owner[q] == me ? a_off_v[q] : -1); };
 
     // ---- forced per-community phase (:282-313): every big community owns a local heap -----------
     struct Local { Heap h; i64 pos; };
@@ -1485,8 +1586,9 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             locals.push_back(Local{Heap(), q});
             pool.emplace_back();
             Group *g = &pool.back();
-            g->off = cl_off[cidx];
+            g->off = a_off(cidx);
             g->len = len;
+            g->owner = RS ? cl_owner[cidx] : 0;
             locals.back().h.put(g);
         }
     }
@@ -1495,8 +1597,10 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         if (forced <= 1) { // with forced >= 2 every root is popped from its one-element heap: its value is never compared
             PhaseAcc pa(c, "lm_roots");
             std::vector<Group *> roots;
-            for (auto &L : locals) roots.push_back(L.h.top());
+            for (auto &L : locals)
+                if (!RS || L.h.top()->owner == me) roots.push_back(L.h.top());
             device_group_values(c, roots);
+            // (option shard_rows: the other ranks' roots get their values with the forced phase's exchange below)
         }
         // N > 1: the local heaps are independent of each other, so every rank splits its share of the communities
         // (balanced by rows) and the results -- member lists in pop order, lengths, heap values, means -- are gathered by ONE
@@ -1505,8 +1609,55 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         const i64 nbig = (i64)locals.size(), W = c->has_coll ? c->coll.world : 1;
         const i64 s_words = (total + 1) / 2, m_per = 3 + d; // per group: length, value, mean flag, mean
         const i64 x_need = s_words + nbig + nbig * forced * m_per;
-        const bool shard = W > 1 && c->opt_shard_forced && forced >= 2 && cge_exchange_fits(c, (size_t)x_need);
+        const bool shard = !RS && W > 1 && c->opt_shard_forced && forced >= 2 && cge_exchange_fits(c, (size_t)x_need);
         std::vector<int> owner(nbig, 0);
+        if (RS) {
+            // option shard_rows: every rank runs the local heaps of ITS communities; the replicated global heap needs, of every
+            // group they end with, its length and value only (pop order): one gather of 1 + 2 max(forced, 1) words per community
+            const i64 per = 1 + 2 * std::max<i64>(forced, 1);
+            std::vector<Heap *> hs;
+            std::vector<i64> tg;
+            for (i64 b = 0; b < nbig; b++) {
+                owner[b] = locals[b].h.top()->owner;
+                if (owner[b] == me) { hs.push_back(&locals[b].h); tg.push_back(forced); }
+            }
+            if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model);
+            std::vector<double> w((size_t)nbig * per, 0.0);
+            std::vector<std::vector<Group *>> popped(nbig);
+            for (i64 b = 0; b < nbig; b++) {
+                if (owner[b] != me) continue;
+                Heap &L = locals[b].h;
+                if ((i64)L.len() > std::max<i64>(forced, 1)) CGE_THROW(CGE_E_ASSERT, "forced phase: a local heap grew beyond its target");
+                while (L.len() > 0) popped[b].push_back(L.pop()); // pop order = the order in which the global heap receives them (:309-312)
+                w[b * per] = (double)popped[b].size();
+                for (size_t s_ = 0; s_ < popped[b].size(); s_++) {
+                    w[b * per + 1 + 2 * s_] = (double)popped[b][s_]->len;
+                    w[b * per + 2 + 2 * s_] = popped[b][s_]->value;
+                }
+            }
+            exchange_group_words(c, w);
+            for (i64 b = 0; b < nbig; b++) {
+                Heap &L = locals[b].h;
+                L = Heap();
+                const i64 cnt = (i64)w[b * per];
+                if (cnt < 1 || cnt > std::max<i64>(forced, 1)) CGE_THROW(CGE_E_COLLECTIVE, "forced phase (shard_rows): no rank answered for a community of rank %d", owner[b]);
+                for (i64 s_ = 0; s_ < cnt; s_++) {
+                    Group *g;
+                    if (owner[b] == me)
+                        g = popped[b][s_];
+                    else {
+                        pool.emplace_back();
+                        g = &pool.back();
+                        g->off = -1;
+                        g->len = (i64)w[b * per + 1 + 2 * s_];
+                        g->value = w[b * per + 2 + 2 * s_];
+                        g->owner = owner[b];
+                    }
+                    L.a.push_back(g); // kept in pop order: the merge below reads the array front to back
+                }
+            }
+            sharded_forced = true;
+        }
         if (shard) { // longest first, each to the least loaded rank (deterministic)
             std::vector<i64> ord(nbig), load(W, 0);
             for (i64 b = 0; b < nbig; b++) ord[b] = b;
@@ -1517,13 +1668,16 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                 load[r] += locals[b].h.top()->len;
             }
         }
-        const int me = shard ? c->coll.rank : 0;
-        std::vector<Heap *> hs;
-        std::vector<i64> tg;
-        for (i64 b = 0; b < nbig; b++)
-            if (owner[b] == me) { hs.push_back(&locals[b].h); tg.push_back(forced); }
-        if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model);
+        const int me_f = shard ? c->coll.rank : 0;
+        if (!RS) {
+            std::vector<Heap *> hs;
+            std::vector<i64> tg;
+            for (i64 b = 0; b < nbig; b++)
+                if (owner[b] == me_f) { hs.push_back(&locals[b].h); tg.push_back(forced); }
+            if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model);
+        }
         if (shard) {
+            const int me = me_f;
             PhaseAcc px(c, "lm_exchange");
             double *X = c->xptr;
             i32 *S = reinterpret_cast<i32 *>(X);
@@ -1610,9 +1764,10 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             for (i64 t = cl_off[cidx]; t < cl_off[cidx + 1]; t++) {
                 pool.emplace_back();
                 Group *g = &pool.back();
-                g->off = t;
+                g->off = a_off(cidx) >= 0 ? a_off(cidx) + (t - cl_off[cidx]) : -1;
                 g->len = 1;
                 g->value = DBL_EPSILON; // eps() (:284)
+                g->owner = RS ? cl_owner[cidx] : 0;
                 H.put(g);
             }
         } else {
@@ -1634,20 +1789,43 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     // ---- the heap array is the numbering (:337-342): v2l and the landmark index, on the device -----------------------
     PhaseAcc pfin(c, "lm_final");
     const i64 NG = (i64)H.len();
+    const i64 nrows = lm_rows(c);
     c->pin_small.ensure((size_t)2 * NG + 2);
     i32 *goff = c->pin_small.p, *glen = goff + NG;
     c->h_mem_off.assign(NG + 1, 0);
+    c->h_gl_off.assign(NG + 1, 0);
+    c->lm_owner.assign(NG, 0);
     for (i64 g = 0; g < NG; g++) {
-        goff[g] = (i32)H.a[g + 1]->off;
-        glen[g] = (i32)H.a[g + 1]->len;
+        const Group *G = H.a[g + 1];
+        const bool mine = !RS || G->owner == me;
+        goff[g] = mine ? (i32)G->off : 0; // (option shard_rows: another rank's group is an empty range here)
+        glen[g] = mine ? (i32)G->len : 0;
         c->h_mem_off[g + 1] = c->h_mem_off[g] + glen[g];
+        c->h_gl_off[g + 1] = c->h_gl_off[g] + (i32)G->len;
+        c->lm_owner[g] = G->owner;
     }
-    c->lm_goff.ensure(NG); c->lm_glen.ensure(NG); c->v2l.ensure(n); c->lm_mem.ensure(n); c->lm_memoff.ensure(NG + 1);
+    DevBuf<i32> &v2l_rows = RS ? c->v2l_loc : c->v2l; // landmark of every row this rank holds
+    c->lm_goff.ensure(NG); c->lm_glen.ensure(NG); c->v2l.ensure(n); v2l_rows.ensure(nrows); c->lm_mem.ensure(nrows); c->lm_memoff.ensure(NG + 1);
     HIP_CHECK(hipMemcpyAsync(c->lm_goff.p, goff, sizeof(i32) * NG, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->lm_glen.p, glen, sizeof(i32) * NG, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(c->lm_memoff.p, c->h_mem_off.data(), sizeof(i32) * (NG + 1), hipMemcpyHostToDevice, st));
-    const i64 unassigned = k_groups_to_index(c, c->lm_arena.p, c->lm_goff.p, c->lm_glen.p, NG, n, c->v2l.p, c->lm_mem.p);
-    if (unassigned != 0 || c->h_mem_off[NG] != n)
+    const i64 unassigned = k_groups_to_index(c, c->lm_arena.p, c->lm_goff.p, c->lm_glen.p, NG, nrows, v2l_rows.p, c->lm_mem.p);
+    bool cover_bad = unassigned != 0 || c->h_mem_off[NG] != nrows || c->h_gl_off[NG] != n;
+    if (RS) {
+        // v_to_l of ALL vertices on every rank (4 bytes per vertex: the table of the per-edge passes and of the local score):
+        // every rank writes landmark + 1 of its rows at their global ids into a zero-filled vector, the ranks add the words
+        const i64 words = (n + 1) / 2;
+        DevBuf<i32> &tmp = c->sort_idx2;
+        tmp.ensure(2 * words);
+        HIP_CHECK(hipMemsetAsync(tmp.p, 0, sizeof(i32) * 2 * words, st));
+        k_scatter_i32(c, v2l_rows.p, c->loc2glob.p, nrows, 1, tmp.p);
+        cge_allreduce_dev(c, reinterpret_cast<double *>(tmp.p), words, 2);
+        k_add_i32(c, tmp.p, n, -1, c->v2l.p);
+        std::vector<double> verdict(1, cover_bad ? 1.0 : 0.0);
+        exchange_group_words(c, verdict); // (sum: any rank's failure fails all)
+        cover_bad = verdict[0] != 0.0;
+    }
+    if (cover_bad)
         CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids)"); // :343
     c->lm_index_on_device = want_index;
     c->h_mem.clear(); // the member lists stay on the device (c->lm_mem); host copies are made by whoever asks for them

@@ -75,6 +75,28 @@ bool sampler_uses_device(const cge_ctx *c) { return (double)c->n * (double)(c->n
 static void gather_rows(cge_ctx *c, const i32 *d_arr, const std::vector<i64> &rows0, std::vector<i32> &out,
                         DevBuf<i32> &d_idx, DevBuf<i32> &d_out);
 
+// full_graph_D of sampled vertex pairs (src/divergence.jl:104-114 restricted to the draws), dist()'s own arithmetic.  Option
+// shard_rows: a pair's two rows may live on two ranks -- the rows of a chunk of pairs are gathered from their owners into a
+// zero-filled buffer (all-reduce of the words: exact) and every rank evaluates the chunk from the gathered rows.
+static void sampled_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *pj, i64 S, double den, double *out) {
+    if (!c->rows_sharded) {
+        k_pair_dist(c, Xr, d, pi, pj, S, den, out);
+        return;
+    }
+    const i64 K = std::max<i64>(1024, std::min<i64>(S, ((i64)64 << 20) / (2 * d * 8))); // <= 64 MB of rows per exchange
+    DevBuf<double> &B = c->samp_xchg;
+    DevBuf<i32> &idx = c->epd_i;
+    B.ensure((size_t)2 * K * d);
+    idx.ensure(2 * K);
+    for (i64 k0 = 0; k0 < S; k0 += K) {
+        const i64 kc = std::min(K, S - k0);
+        k_pair_local_idx(c, pi + k0, pj + k0, kc, c->glob2loc.p, idx.p);
+        k_gather_rows_f64(c, c->Xr.p, c->n_loc, d, 1, idx.p, 2 * kc, B.p);
+        cge_allreduce_dev(c, B.p, 2 * kc * d, 2);
+        k_pair_dist_rows(c, B.p, d, pi + k0, pj + k0, kc, den, out + k0);
+    }
+}
+
 void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, const i32 *ex_src, const i32 *ex_dst,
                      const double *ex_hw, i64 ex_m, int directed, int split, const SampleSet &smp, double out[7],
                      int *out_len, cge_trace *trace) {
@@ -222,8 +244,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                            ds.pj.p, ds.ni.p, ds.nj.p, ds.wts.p);
             if (landmarks) { // full_graph_D of the sampled pairs, normalised by hi (lo == 0) :104-114
                 ds.dpos.ensure(S); ds.dneg.ensure(S);
-                k_pair_dist(c, orig->Xr, d, ds.pi.p, ds.pj.p, S, orig->hi, ds.dpos.p);
-                k_pair_dist(c, orig->Xr, d, ds.ni.p, ds.nj.p, S, orig->hi, ds.dneg.p);
+                sampled_pair_dist(c, orig->Xr, d, ds.pi.p, ds.pj.p, S, orig->hi, ds.dpos.p);
+                sampled_pair_dist(c, orig->Xr, d, ds.ni.p, ds.nj.p, S, orig->hi, ds.dneg.p);
             }
         }
     } else {
@@ -264,8 +286,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             HIP_CHECK(hipMemcpyAsync(ds.wts.p, wts.data(), sizeof(double) * S, hipMemcpyHostToDevice, st));
             if (landmarks) { // full_graph_D of the sampled pairs, normalised by hi (lo == 0) :104-114
                 ds.dpos.ensure(S); ds.dneg.ensure(S);
-                k_pair_dist(c, orig->Xr, d, ds.pi.p, ds.pj.p, S, orig->hi, ds.dpos.p);
-                k_pair_dist(c, orig->Xr, d, ds.ni.p, ds.nj.p, S, orig->hi, ds.dneg.p);
+                sampled_pair_dist(c, orig->Xr, d, ds.pi.p, ds.pj.p, S, orig->hi, ds.dpos.p);
+                sampled_pair_dist(c, orig->Xr, d, ds.ni.p, ds.nj.p, S, orig->hi, ds.dneg.p);
             }
             HIP_CHECK(hipStreamSynchronize(st)); // host vectors go out of scope
         }

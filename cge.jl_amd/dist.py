@@ -13,6 +13,10 @@ What is sharded:
 and what is replicated: the heap of runsplit and its small batches, and the alpha sweep (sequentially
 dependent iterations of a register-resident persistent fit that already uses every CU).  No other collective is issued.
 
+Option "shard_rows" (set the collectives first, upload the communities before the embedding): the EMBEDDING ROWS are sharded by
+community (community_owner below); a rank keeps and splits the rows of its own communities only; see include/cge_hip.h for
+what crosses ranks.
+
 Option "shard_ingest" (set the collectives first, then upload): `set_graph` keeps only the rows edge_shard(m, rank, world)
 of the edge list on a rank (the scatter passes then run over what a rank holds; the sampler's edge look-ups and non-edge
 checks are all-reduced), and `set_embedding` uploads n / world rows per rank and all-gathers them over xGMI
@@ -43,6 +47,22 @@ def centroid_tile_shard(n_vertex_tiles: int, rank: int, world: int):
 def candidate_tile_shard(n_tiles: int, rank: int, world: int):
     """Candidate tiles owned by `rank` in the pruned diameter (diameter_host.cpp: global_tile % nparts == part)."""
     return list(range(rank, n_tiles, world))
+
+
+def community_owner(comm, world: int):
+    """Option shard_rows: owner rank of every community (index = community id, 1-based ids -> entry id - 1 ... here: returns
+    an array indexed by the 0-based community) -- the same rule as capi.cpp:rows_assign_ownership: communities by decreasing
+    size (ties: lower id first), each to the rank with the fewest rows so far (ties: lower rank).  `comm`: 1-based ids."""
+    comm = np.asarray(comm).reshape(-1)
+    size = np.bincount(comm - 1)
+    order = np.argsort(-size, kind="stable")
+    load = np.zeros(world, dtype=np.int64)
+    owner = np.zeros(len(size), dtype=np.int64)
+    for q in order:
+        r = int(np.argmin(load))
+        owner[q] = r
+        load[r] += size[q]
+    return owner
 
 
 class TorchCollectives:

@@ -246,6 +246,19 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             that need the whole list on one rank (exact-mode cge_score, cge_louvain, cge_edge_scatter, cge_draw_samples,
  *             caller-drawn samples of cge_wgcl) return CGE_E_ARG on a sharded list.  0 (default): every rank uploads and
  *             keeps everything.  Same results.
+ * "shard_rows": N > 1, set AFTER the collectives and BEFORE cge_set_embedding / cge_set_embedding_device, with the communities
+ *             already resident (cge_set_vertex_data first): 1 = the EMBEDDING ROWS ARE SHARDED BY COMMUNITY -- communities by
+ *             decreasing size, each to the rank with the fewest rows so far; a rank uploads and keeps the rows of its own
+ *             communities only (stat "rows_resident" ~ n / W; every rank still passes the whole array) and runs all splits,
+ *             forced and global, of those communities.  What crosses ranks: per runsplit round four words per split group
+ *             (status, low size, two values) for the replicated heap; v_to_l once (4 B per vertex); the landmarks' centroids /
+ *             weights / d_ii once; the bound matrix of the diameter (all-reduce max), the seed row of its sweep and the rows of
+ *             the few candidate landmarks of its exact stage; the rows of the sampled pairs of the local score once per seeded
+ *             draw; row hashes for the unique-row clamp.  The clusters handed to the landmark phase must refine the community
+ *             vector (CGE_E_ARG otherwise).  Entry points that need every row on one rank (exact-mode cge_score,
+ *             cge_max_pair_dist, the brute-force diameter option) return CGE_E_ARG.  A later cge_set_vertex_data with ANOTHER
+ *             community vector drops the resident rows (upload the embedding again).  0 (default): every rank holds every
+ *             row.  Same landmark ids, diameter bits and score.
  * "fit_persistent": how the Chung-Lu fixed point (src/divergence.jl:150-168, :434-467) is launched.
  *             0 = auto: one persistent launch per alpha (the matrix register-resident, the workgroups exchanging
  *                 partial sums and iterates by polling the data itself) for score graphs of >= 128 vertices that fit

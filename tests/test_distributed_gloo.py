@@ -99,6 +99,29 @@ def _worker(rank, world, port, q):
         got = coll.buf[30:34].view(torch.int64).tolist()
         assert got[0] == -(2 ** 63) and got[1] == torch.tensor([float("nan")], dtype=torch.float64).view(torch.int64).item()
         assert got[2] == got[3] == 123456789
+        # 4. option shard_rows: the ownership rule (rows sharded BY COMMUNITY) and the exchanges built on it.  Every rank derives
+        #    the same owners from the replicated community vector; every vertex has exactly one owner; the loads are balanced;
+        #    what a rank computes for ITS rows, written at their global ids into a zero-filled vector, is completed by the
+        #    integer all-reduce (op 2) -- v_to_l, and per-landmark tables whose rows live on one rank each.
+        owner = cd.community_owner(comm, world)
+        assert np.array_equal(cd.allreduce_numpy(owner.copy(), "sum"), world * owner)  # the same on every rank
+        mine_mask = owner[comm - 1] == rank
+        assert np.array_equal(cd.allreduce_numpy(mine_mask.astype(np.int64), "sum"), np.ones(n, dtype=np.int64))
+        loads = cd.allreduce_numpy(np.eye(world, dtype=np.int64)[rank] * int(mine_mask.sum()), "sum")
+        sizes = np.bincount(comm - 1)
+        assert loads.sum() == n and loads.max() - loads.min() <= sizes.max()  # greedy longest-first: within one community
+        order = np.argsort(-sizes, kind="stable")
+        assert owner[order[0]] == 0 and (world < 2 or owner[order[1]] == 1)  # largest first, ties to the lower rank
+        part = np.zeros(n, dtype=np.int64)
+        part[mine_mask] = v2l[mine_mask] + 1  # landmark + 1 of the rows this rank holds
+        assert np.array_equal(cd.allreduce_numpy(part, "sum") - 1, v2l)
+        lm_owner = owner[(np.arange(N) // 4)]  # a landmark lives where its community lives (v2l above: 4 landmarks per community)
+        cen = np.zeros((N, 8))
+        for l in np.flatnonzero(lm_owner == rank):
+            cen[l] = X[v2l == l].sum(0) if np.any(v2l == l) else 0.0
+        cen_ref = np.stack([X[v2l == l].sum(0) if np.any(v2l == l) else np.zeros(8) for l in range(N)])
+        got = cd.allreduce_numpy(cen.view(np.int64).copy(), "sum").view(np.float64)
+        assert np.array_equal(got, cen_ref)  # a gather, bit for bit
         q.put((rank, "ok"))
     except Exception as e:  # surface the failure in the parent
         import traceback

@@ -222,3 +222,119 @@ def test_two_ranks_sharded_ingest(ctx, weighted):
         held += n_calls[4]
     assert held == g["m"]  # every edge is resident on exactly one rank
     assert results[0][1] == results[1][1]
+
+
+# ---- option shard_rows: the embedding rows sharded by community (north star: "edge list and embedding rows shard across the GPUs") ----
+def _graph_rows(case):
+    """Inputs of the sharded-rows cases: the 30 000-vertex graph; `directed`; `weighted` (dyadic weights: sums stay exact whatever
+    their grouping); `dups`: only 400 distinct embedding rows, spread over all communities (so equal rows live on BOTH ranks):
+    `land` = 600 is clamped to the unique-row count (src/landmarks.jl:371-376) through the exact cross-rank comparison."""
+    from cge.jl_amd import synth
+
+    g = synth.abcd_like(30000, 300000, 30, 16, seed=21, directed=case.get("directed", False))
+    if case.get("weighted"):
+        g["eweights"] = 1.0 + (np.arange(g["m"]) % 4) * 0.25
+        vw = np.zeros(g["n"])
+        np.add.at(vw, g["edges"][:, 0] - 1, g["eweights"])
+        np.add.at(vw, g["edges"][:, 1] - 1, g["eweights"])
+        g["vweights"] = vw
+    if case.get("dups"):
+        g["embedding"] = np.asfortranarray(g["embedding"][np.arange(g["n"]) % 400])
+    return g
+
+
+def _rank_rows(rank, world, port, q, case):
+    try:
+        import torch
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from cge.jl_amd import api
+        from cge.jl_amd.dist import TorchCollectives, community_owner
+
+        g = _graph_rows(case)
+        ctx = api.Context(0)
+        coll = TorchCollectives(ctx, 600 * 600 * 2 + 1024, torch.device("cuda", 0))  # collectives first: the uploads are split
+        ctx.set_option("shard_ingest", 1)
+        ctx.set_option("shard_rows", 1)
+        ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+        ctx.set_option("fit_persistent", 1)  # (two processes cannot both keep a persistent grid resident on one GPU)
+        ctx.set_option("shard_samples", case.get("shard_samples", 1))
+        directed = bool(case.get("directed", False))
+        res = ctx.score(g["clusters"], 600, 2, case.get("method", "rss"), directed=directed, seed=5, auc_samples=4000)
+        hi = ctx.last_diameter()[0]
+        rows = (ctx.get_stat("rows_resident"), ctx.get_stat("rows_total"), ctx.get_stat("embedding_words_resident"))
+        owner = community_owner(g["comm"][:, 0], world)
+        mine = int(np.sum(owner[g["comm"][:, 0] - 1] == rank))
+        lm = ctx.landmarks_fetch()
+        q.put((rank, res.tolist(), hi, rows + (mine, ctx.truncated, ctx.get_stat("edges_resident")),
+               [int(zlib.crc32(np.ascontiguousarray(x).tobytes())) for x in lm]))
+        ctx.close()
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(e), None, None, None))
+    finally:
+        import torch.distributed as dist
+
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+ROW_CASES = [dict(method="rss"), dict(method="rss2"), dict(method="size"), dict(method="diameter"),
+             dict(method="rss", directed=True), dict(method="rss", weighted=True), dict(method="rss", shard_samples=2),
+             dict(method="rss", dups=True), dict(method="diameter", directed=True, weighted=True)]
+
+
+@pytest.mark.parametrize("case", ROW_CASES, ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()))
+def test_two_ranks_sharded_rows(ctx, case):
+    """rank r keeps the rows of ITS communities only (stat rows_resident ~ n / 2) and runs all their
+    splits, forced and global; the heap is replicated from (status, size, value) words; v_to_l, the landmark tables, the
+    diameter's bound matrix / seed row / candidate rows, the sampled pairs' rows and the row hashes are exchanged.  All four
+    split rules, directed, weighted, the tallies split, and a unique-row clamp whose equal rows live on both ranks: the
+    one-rank v_to_l, diameter bits, landmark tables and 7-vector, the same bits on both ranks."""
+    import torch.multiprocessing as mp
+
+    g = _graph_rows(case)
+    directed = bool(case.get("directed", False))
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    try:
+        ctx.set_option("fit_persistent", 1)
+        ref = ctx.score(g["clusters"], 600, 2, case.get("method", "rss"), directed=directed, seed=5, auc_samples=4000)
+        hi_ref = ctx.last_diameter()[0]
+        lm_ref = ctx.landmarks_fetch()
+        trunc_ref = ctx.truncated
+        crc_ref = [int(zlib.crc32(np.ascontiguousarray(x).tobytes())) for x in lm_ref]
+    finally:
+        ctx.set_option("fit_persistent", 0)
+    if case.get("dups"):
+        assert trunc_ref and len(lm_ref[0]) == 400  # the clamp really applied
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank_rows, args=(r, 2, port, q, case)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+    held = 0
+    for rank, res, hi, rows, crcs in results:
+        assert hi is not None, res  # a traceback otherwise
+        resident, total, words, mine, trunc, edges_res = rows
+        assert total == g["n"] and resident == mine and words == resident * 16  # only this rank's rows are in HBM ...
+        assert 0.35 * total < resident < 0.65 * total  # ... about half of them
+        assert edges_res < g["m"]  # (and its slice of the edge list)
+        held += resident
+        assert trunc == trunc_ref
+        assert crcs[6] == crc_ref[6], "v_to_l differs from the one-rank run"
+        assert hi == hi_ref  # the exact diameter, bit for bit
+        # d_ii, centroids, communities, landmark edge list, weights, landmark weights: the one-rank bits (dyadic / unit weights)
+        assert crcs == crc_ref
+        assert res[0] == ref[0] and res[4] == ref[4]
+        assert np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
+    assert held == g["n"]  # every row is resident on exactly one rank
+    assert results[0][1] == results[1][1]  # both ranks hold the same bits
