@@ -1657,6 +1657,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                 }
             }
             sharded_forced = true;
+            model = SplitModel(); // (it has seen this rank's splits only: the global phase must start from the same state everywhere)
         }
         if (shard) { // longest first, each to the least loaded rank (deterministic)
             std::vector<i64> ord(nbig), load(W, 0);
