@@ -113,7 +113,7 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank(ctx, mode):
         # vect_C (sum), the centroid bounds (max), the diameter (max); + the forced phase's groups (gather) + one gather per
         # split batch of the global phase; the fetch adds the landmark-pair matrix (sum)
         during, fetch, batches = n_calls[:3]
-        assert fetch == 1 and during >= 3 + (mode > 0)
+        assert fetch == 2 and during >= 3 + (mode > 0)  # (fetch: the matrix + the count of its positive entries over the row blocks)
         if mode == 2:
             assert during > 4  # batches of the global phase went through the exchange
         if mode == 0:
