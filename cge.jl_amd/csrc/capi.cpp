@@ -1593,6 +1593,11 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_fit_test_delay = (int)value;
         return CGE_OK;
     }
+    if (!strcmp(key, "fit_max_iterations")) { // iterations after which a Chung-Lu fit that has not converged raises CGE_E_ASSERT (default 2 000 000)
+        if (value < 1) return CGE_E_ARG;
+        c->opt_fit_max_iters = value;
+        return CGE_OK;
+    }
     if (!strcmp(key, "fit_persistent_test_timeout")) { // testing: 1 = the persistent fit abandons every launch at once
         c->opt_fit_test_timeout = value != 0;
         return CGE_OK;

@@ -365,6 +365,8 @@ struct cge_ctx {
                                    // 0 = by split rule: 40 for rss / rss2 (25 when d > 128: config 5 1.51 -> 1.43 s), 10 for
                                    // size / diameter (their cuts are unbalanced, a speculative split is wasted more often:
                                    // config 3 68.4 -> 63.8 ms per step)
+    i64 opt_fit_max_iters = 2000000; // a Chung-Lu fit that has not met `diff <= delta` (src/divergence.jl:151,434) after this many
+                                     // iterations raises CGE_E_ASSERT -- the reference's loop has no bound and would not return
     int opt_fit_test_timeout = 0; // testing: the persistent fit gives up at once, so the fallback path runs
     int opt_fit_test_delay = 0;   // testing: the tile waves of the data-as-signal fits nap this many times (~3 us each) before
                                   // their first load -- start skew, as under contention; results must not change

@@ -1453,7 +1453,7 @@ bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld
             *final_parity = par;
             return true;
         }
-        if (total > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge");
+        if (total > c->opt_fit_max_iters) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge (%lld iterations; the reference's `while diff > delta` would not return)", (long long)total);
     }
     return false;
 }

@@ -396,7 +396,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                     double flast;
                     std::memcpy(&flast, &hr[(k - 1) % 3], sizeof(double));
                     if (!(flast > delta)) break; // the last launch of the batch was the converging iteration (iters == k)
-                    if (iters > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g", alpha);
+                    if (iters > c->opt_fit_max_iters) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g (%lld iterations; the reference's `while diff > delta` would not return)", alpha, (long long)iters);
                     batch = std::max<i64>(4, std::min<i64>(batch, 32));
                 }
                 if (iters & 1) tpar = (tpar + 1) % 3;
@@ -426,7 +426,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             HIP_CHECK(hipStreamSynchronize(st));
             iters = hf[1];
             if (hf[0]) break;
-            if (iters > 2000000) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g", alpha);
+            if (iters > c->opt_fit_max_iters) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge at alpha=%g (%lld iterations; the reference's `while diff > delta` would not return)", alpha, (long long)iters);
             batch = std::max<i64>(4, std::min<i64>(batch, 32));
         }
         sl.iters = iters;

@@ -246,6 +246,10 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             that need the whole list on one rank (exact-mode cge_score, cge_louvain, cge_edge_scatter, cge_draw_samples,
  *             caller-drawn samples of cge_wgcl) return CGE_E_ARG on a sharded list.  0 (default): every rank uploads and
  *             keeps everything.  Same results.
+ * "fit_max_iterations": a Chung-Lu fit (src/divergence.jl:150-168, :434-467) that has not met `diff <= delta` after this many
+ *             iterations returns CGE_E_ASSERT "Chung-Lu fit did not converge" (default 2 000 000).  The reference's loop is
+ *             unbounded: on a directed graph without a fixed point within delta (e.g. two landmarks, tests/test_gpu_parity.py::
+ *             test_directed_fit_without_a_fixed_point_raises) it never returns -- a documented divergence.
  * "shard_rows": N > 1, set AFTER the collectives and BEFORE cge_set_embedding / cge_set_embedding_device, with the communities
  *             already resident (cge_set_vertex_data first): 1 = the EMBEDDING ROWS ARE SHARDED BY COMMUNITY -- communities by
  *             decreasing size, each to the rank with the fewest rows so far; a rank uploads and keeps the rows of its own

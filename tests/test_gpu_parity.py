@@ -1161,6 +1161,53 @@ def test_randomised_parity_sweep(ctx, orc, case):
     _cmp_result(res, exp, tr, etr)
 
 
+def test_directed_fit_without_a_fixed_point_raises(ctx, orc):
+    """A documented divergence from the reference: offline stress case 226 of the sweep above (116 vertices,
+    2 communities, -l 2 -f 1 -m size, directed, dyadic weights) ends in a landmark graph of TWO landmarks --
+    edges [[1 1] [1 2] [2 1] [2 2]], weights [966.5 52 71.75 485.25] -- on which the directed Chung-Lu iteration has no fixed
+    point within delta: the reference's `while diff > delta` (src/divergence.jl:434-467) never returns (the oracle, which
+    restates it, loops for ever and is therefore NOT called here for the score).  The product bounds the loop (option
+    fit_max_iterations, default 2 000 000) and returns CGE_E_ASSERT with a message, for every form of the fit; the landmark
+    phase in front of it is bit-exact against the oracle as always."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    case = 226
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.integers(60, 1500))
+    d = int(rng.choice([2, 3, 5, 8, 17, 33, 64, 100]))
+    C = int(rng.integers(2, max(3, n // 25)))
+    method = ["rss", "rss2", "size", "diameter"][case % 4]
+    directed = bool(rng.integers(0, 2))
+    split = bool(rng.integers(0, 2))
+    forced = int(rng.choice([1, 2, 4]))
+    g = synth.abcd_like(n, int(rng.integers(3, 9)) * n, C, d, seed=500 + case, directed=directed)
+    land = int(min(n // 3, max(C * forced, rng.integers(C, 6 * C + 2))))
+    assert rng.integers(0, 2) == 1 and (n, d, C, method, directed, forced, land) == (116, 8, 2, "size", True, 1, 2)
+    ew = rng.integers(1, 17, size=len(g["eweights"])) / 4.0
+    vw = np.zeros(n)
+    np.add.at(vw, g["edges"][:, 0] - 1, ew)
+    np.add.at(vw, g["edges"][:, 1] - 1, ew)
+    args = (g["edges"], ew, vw, g["clusters"], g["comm"], g["embedding"], False, land, forced, method, directed)
+    got, ref = cg.landmarks(*args, ctx=ctx), orc.landmarks(*args)
+    _check_landmarks(got, ref, unit_weights=False)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = got
+    assert len(dii) == 2 and ledges.tolist() == [[1, 1], [1, 2], [2, 1], [2, 2]] and lw.tolist() == [966.5, 52.0, 71.75, 485.25]
+    S = 1500
+    p1, ni, nj = api.draw_samples(ctx, case, S, directed=True)
+    wargs = (ledges, lw, lcomm, lemb, dii, lweight, vw, v2l, g["edges"], ew, g["embedding"], split)
+    try:
+        ctx.set_option("fit_max_iterations", 20000)
+        for opt in (0, 1, 2):
+            ctx.set_option("fit_persistent", opt)
+            with pytest.raises(api.AssertionErrorCGE) as ei:  # CGE_E_ASSERT: what a reference @assert maps to
+                cg.wGCL_directed(*wargs, case, S, samples=(p1, ni, nj, p1), ctx=ctx)
+            assert ei.value.code == -1 and "did not converge" in str(ei.value)
+    finally:
+        ctx.set_option("fit_max_iterations", 2000000)
+        ctx.set_option("fit_persistent", 0)
+
+
 def test_local_score_exact_ties_case_212(ctx, orc):
     """DESIGN section 2 (iv), profiles/repro_parity_case.py 212 (an offline stress case, 170 vertices, directed): a sampled
     edge (i, j) and a sampled non-edge (j, i) whose endpoints share ONE landmark give pos == neg in exact arithmetic
@@ -1224,16 +1271,37 @@ def test_local_score_exact_ties_case_212(ctx, orc):
         assert res[5] == np.nanmin(a_got)  # (the patience counters may stop the two sweeps at different alphas after a flipped tie)
 
 
+@pytest.mark.parametrize("form,case", [(2, 4), (2, 6), (3, 4), (4, 6), (2, 5), (2, 7), (2, 12), (2, 13)])
+def test_randomised_exact_mode_sweep_under_start_skew(ctx, orc, form, case):
+    """The start-skew class of bug (`done` / `fail` words tested against zero -- a fit that waited more than 64
+    polls ended "converged" with the iterate of that moment) had ONE tripwire, and iteration-count equality with the oracle only
+    fires under a slow schedule.  Here cases of the randomised exact-mode sweep below -- against the ORACLE -- run with the tile
+    waves of the persistent fits napping before their first load (option fit_persistent_test_delay), for every persistent
+    form of the fit: data-as-signal (2), grid barriers (3), dependency counters (4) undirected (even cases), and the directed
+    persistent form (odd cases)"""
+    try:
+        ctx.set_option("fit_persistent", form)
+        ctx.set_option("fit_persistent_test_delay", 25)
+        _exact_mode_case(ctx, orc, case, min_n=200)
+    finally:
+        ctx.set_option("fit_persistent_test_delay", 0)
+        ctx.set_option("fit_persistent", 0)
+
+
 @pytest.mark.parametrize("case", range(16))
 def test_randomised_exact_mode_sweep(ctx, orc, case):
     """The same for exact mode (v_to_l = Int[], the score graph is the graph itself): random sizes across the launch
     forms of the fit (launch per iteration below 128 vertices, one tile per wave on 4 / 8 waves above), directed and
     undirected, weighted, --split-global, seeded and unseeded samples."""
+    _exact_mode_case(ctx, orc, case)
+
+
+def _exact_mode_case(ctx, orc, case, min_n=0):
     import cge.jl_amd as cg
     from cge.jl_amd import api, synth
 
     rng = np.random.default_rng(2000 + case)
-    n = int(rng.choice([40, 90, 127, 128, 200, 333, 520, 700]))
+    n = max(min_n, int(rng.choice([40, 90, 127, 128, 200, 333, 520, 700])))  # (min_n: sizes the persistent forms take)
     d = int(rng.choice([2, 4, 9, 16]))
     C = int(rng.integers(2, max(3, n // 20)))
     directed = bool(case % 2)
