@@ -671,7 +671,9 @@ void k_pair_list(cge_ctx *c, const double *Xs, const double *rns, i64 lds_rows, 
                  i64 ntiles, double *best_val, i64 *best_i, i64 *best_j);
 i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *mu_ref, i64 N, i64 nref, i64 d, double L,
                    void *list, i64 cap, const i32 *ref_off = nullptr, const i32 *ref_mem = nullptr, const double *Ms_fm = nullptr,
-                   i64 dpad = 0, i64 ldm = 0);
+                   i64 dpad = 0, i64 ldm = 0,
+                   bool rd2_ready = false);
+void k_ref_dist2_fm(cge_ctx *c, const double *Ms_fm, i64 nref, i64 dpad, i64 ldm);
 i64 k_argmax_mapped(cge_ctx *c, const double *v, i64 n, const i32 *map, double *val = nullptr);
 void k_pair_local_idx(cge_ctx *c, const i32 *pi, const i32 *pj, i64 S, const i32 *glob2loc, i32 *idx);
 void k_pair_dist_rows(cge_ctx *c, const double *B, i64 d, const i32 *pi, const i32 *pj, i64 S, double den, double *out);

@@ -183,10 +183,14 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
         HIP_CHECK(hipStreamSynchronize(st));
         seed_glob = (i64)gid - 1;
         k_farthest_enqueue(c, c->Xr.p, n_rows, d, 0, c->dm_seed.p);
+        k_ref_dist2_fm(c, c->Ms.p, nref, dpad, ldm);
     } else {
         std::swap(c->stream, c->copy_stream);
         try {
             k_farthest_enqueue(c, c->Xr.p, n, d, seed_vertex);
+            // the reference points' mutual distances (candidate selection) do not depend on the bound pass either: beside it
+            // (the gathers that wrote Ms are done: the seed's read-back above synchronised the main stream)
+            k_ref_dist2_fm(c, c->Ms.p, nref, dpad, ldm);
         } catch (...) {
             std::swap(c->stream, c->copy_stream);
             throw;
@@ -238,7 +242,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     const i64 cap = std::min<i64>(N * (N + 1) / 2, (i64)4 << 20);
     c->bound_list.ensure((size_t)2 * cap);
     const i64 cnt = k_bound_select(c, c->Pm.p, c->mp_lref.p, mu_ref, N, nref, d, L * (1.0 - 1e-9), c->bound_list.p, cap,
-                                   by_comm ? c->mp_refoff.p : nullptr, by_comm ? c->mp_refmem.p : nullptr, c->Ms.p, dpad, ldm);
+                                   by_comm ? c->mp_refoff.p : nullptr, by_comm ? c->mp_refmem.p : nullptr, nullptr, dpad, ldm, true);
     c->stat_cand_pairs = cnt;
     if (cnt > cap) {
         if (RS) CGE_THROW(CGE_E_ARG, "diameter (shard_rows): the bounds prune too little (more than %lld candidate landmark pairs) and the brute-force "

@@ -100,21 +100,34 @@ __global__ void minmax_partial_kernel(const double *__restrict__ D, i64 N, doubl
         part[2 * blockIdx.x + 1] = shi[0];
     }
 }
-__global__ void minmax_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ lo_hi) {
+__global__ void minmax_final_kernel(const double *__restrict__ part, int nb, double *__restrict__ lo_hi) { // one block of 256 (min / max: any order)
+    __shared__ double slo[256], shi[256];
     double lo = INFINITY, hi = -INFINITY;
-    for (int b = 0; b < nb; b++) {
+    for (int b = threadIdx.x; b < nb; b += 256) {
         lo = fmin(lo, part[2 * b]);
         hi = fmax(hi, part[2 * b + 1]);
     }
-    lo_hi[0] = lo;
-    lo_hi[1] = hi;
+    slo[threadIdx.x] = lo;
+    shi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + s]);
+            shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        lo_hi[0] = slo[0];
+        lo_hi[1] = shi[0];
+    }
 }
 void k_minmax_upper(cge_ctx *c, const double *D, i64 N, double *lo_hi) {
     const int nb = (int)grid_for(N * N, 256, 1024);
     DevBuf<double> &part = c->sw_mm;
     part.ensure((size_t)2 * nb);
     hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(256), 0, c->stream, D, N, part.p);
-    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(1), 0, c->stream, part.p, nb, lo_hi);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, c->stream, part.p, nb, lo_hi);
     HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 __global__ void normalise_kernel(double *__restrict__ D, i64 total, const double *__restrict__ lo_hi) {
@@ -834,7 +847,8 @@ __global__ __launch_bounds__(256) void ref_dist2_fm_kernel(const double *__restr
     const i64 a = blockIdx.x;
     for (i64 b = threadIdx.x; b < nref; b += blockDim.x) {
         double s = 0.0;
-        for (i64 k = 0; k < dpad; k++) {
+#pragma unroll 8
+        for (i64 k = 0; k < dpad; k++) { // (dpad is a multiple of 16: eight pairs of loads in flight per round)
             const double df = Ms[k * ldm + a] - Ms[k * ldm + b];
             s += df * df;
         }
@@ -912,13 +926,23 @@ __global__ __launch_bounds__(256) void bound_expand_kernel(const double *__restr
     }
 }
 // `ref_off` / `ref_mem` (optional, device): the landmarks grouped by reference point (lref[a] = community of a): two-level form
+// the squared distances of the reference points from their centred feature-major copy, into c->mp_rd2 -- on c->stream, which the
+// caller may have pointed at a side stream: they do not depend on the bound pass and run beside it (k_bound_select(..., Ms_fm =
+// nullptr, rd2_ready = true) then takes them as they are)
+void k_ref_dist2_fm(cge_ctx *c, const double *Ms_fm, i64 nref, i64 dpad, i64 ldm) {
+    c->mp_rd2.ensure((size_t)nref * nref);
+    // (differences of centred values: the centre cancels; the 1e-9 margins of the bound cover the rounding)
+    hipLaunchKernelGGL(ref_dist2_fm_kernel, dim3((unsigned)nref), dim3(256), 0, c->stream, Ms_fm, nref, dpad, ldm, c->mp_rd2.p);
+}
 i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *mu_ref, i64 N, i64 nref, i64 d, double L,
-                   void *list, i64 cap, const i32 *ref_off, const i32 *ref_mem, const double *Ms_fm, i64 dpad, i64 ldm) {
+                   void *list, i64 cap, const i32 *ref_off, const i32 *ref_mem, const double *Ms_fm, i64 dpad, i64 ldm,
+                   bool rd2_ready) {
     c->mp_count.ensure(2);
     c->mp_rd2.ensure((size_t)nref * nref);
     HIP_CHECK(hipMemsetAsync(c->mp_count.p, 0, 2 * sizeof(i64), c->stream));
     ScopedKernelTimer tm(c, "bound_select");
-    if (Ms_fm) // (differences of centred values: the centre cancels; the 1e-9 margins of the bound cover the rounding)
+    if (rd2_ready) {
+    } else if (Ms_fm)
         hipLaunchKernelGGL(ref_dist2_fm_kernel, dim3((unsigned)nref), dim3(256), 0, c->stream, Ms_fm, nref, dpad, ldm, c->mp_rd2.p);
     else
         hipLaunchKernelGGL(ref_dist2_kernel, dim3(grid_for(nref * nref, 256)), dim3(256), 0, c->stream, mu_ref, nref, d,

@@ -174,8 +174,11 @@ __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i3
         }
         __syncthreads();
     }
-    if (bad) atomicOr(flag, 1);
-    if (big) atomicOr(flag, 2);
+    if (flag) { // one atomic per workgroup (every thread of a fit embedding sees an ordinary-sized value: millions of
+        // same-address atomics cost the launch 0.8 ms)
+        const int any_bad = __syncthreads_or(bad ? 1 : 0), any_big = __syncthreads_or(big ? 1 : 0);
+        if (tx == 0 && ty == 0 && (any_bad || any_big)) atomicOr(flag, (any_bad ? 1 : 0) | (any_big ? 2 : 0));
+    }
     if (rnorm) {
         nrm[ty][tx] = sq;
         __syncthreads();
