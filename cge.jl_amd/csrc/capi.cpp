@@ -151,8 +151,10 @@ void cge_destroy(cge_ctx *c) {
     c->event_pool.clear();
     if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->fitdone_ev) (void)hipEventDestroy(c->fitdone_ev);
     for (int i = 0; i < 2; i++) {
         if (c->sweep_ev[i]) (void)hipEventDestroy(c->sweep_ev[i]);
+        if (c->pow_ev[i]) (void)hipEventDestroy(c->pow_ev[i]);
         if (c->tab_ev[i]) (void)hipEventDestroy(c->tab_ev[i]);
     }
     for (int i = 0; i < 2; i++)

@@ -350,6 +350,8 @@ struct cge_ctx {
     DevBuf<int> fp_flags;
     PinBuf<double> pin_scal;    // the scalars of an alpha (AUC sums, divergences, the fit's verdict), two alphas in flight
     hipEvent_t sweep_ev[2] = {nullptr, nullptr};
+    hipEvent_t pow_ev[2] = {nullptr, nullptr}, fitdone_ev = nullptr; // the next alpha's power matrix on the side stream (wgcl_host.cpp)
+    DevBuf<double> sw_GD2;                                            // ... and its buffer
     int opt_pow_exp2 = 1; // (1 - D)^alpha as exp2(alpha * log2(1 - D)) with the logarithm computed once per score
     i64 pow_logs_N = 0;   // log2(1 - D) of the current sweep is in sw_Lh / sw_Ll (0: not prepared)
     bool pow_logs_upper = false;

@@ -327,6 +327,23 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                   RES_LEN = RES_FIT + 2, RES_STRIDE = RES_FIT + 16;
     c->pin_scal.ensure(2 * RES_STRIDE);
     const int fit_variant = c->opt_fit_persistent == 3 ? 0 : (c->opt_fit_persistent == 4 ? 1 : 2);
+    // THE POWER MATRIX OF THE NEXT ALPHA BESIDE THIS ALPHA'S vect_B / JS / AUC (round 4).  (1 - D)^alpha does not depend on the
+    // fit, but the persistent fit holds every register of every CU, so nothing runs beside IT; the kernels behind it
+    // (row products, block sums, JS terms, tallies: ~80 us of small launches) leave most of the chip idle.  With two GD
+    // buffers the matrix of alpha i+1 is written on a side stream as soon as the fit of alpha i has finished -- beside that
+    // tail -- and the fit of alpha i+1 waits for its event instead of for a 36 us launch of its own.  Only behind an
+    // ENQUEUED fit (the forms the host waits for leave nothing to overlap), and only while two N x N matrices are small.
+    const bool pow_overlap = (double)N * (double)N * 8.0 <= 2.0e9 && !getenv("CGE_POW_INLINE");
+    double *GDb[2] = {GD.p, GD.p};
+    if (pow_overlap) {
+        c->sw_GD2.ensure((size_t)N * N);
+        GDb[1] = c->sw_GD2.p;
+        for (int q = 0; q < 2; q++)
+            if (!c->pow_ev[q]) HIP_CHECK(hipEventCreateWithFlags(&c->pow_ev[q], hipEventDisableTiming));
+        if (!c->fitdone_ev) HIP_CHECK(hipEventCreateWithFlags(&c->fitdone_ev, hipEventDisableTiming));
+    }
+    i64 pow_ready_for = -1;    // the alpha whose matrix is being written on the side stream (pow_ev[ia & 1] behind it)
+    bool pow_ready_upper = false;
     auto enqueue_alpha = [&](i64 ia, bool want_auc, bool want_div) {
         AlphaSlot &sl = slots[ia & 1];
         const int slot = (int)(ia & 1);
@@ -337,7 +354,14 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         // the undirected persistent fit and vect_B read the upper triangle only; the exact-mode AUC, the directed vect_B
         // and the launch-per-iteration fits read whole rows
         const bool gd_upper = landmarks && !directed && (use_persistent || sym_fit);
-        k_pow_matrix(c, D.p, N, alpha, GD.p, gd_upper);
+        double *const GDc = GDb[pow_overlap ? (ia & 1) : 0]; // this alpha's matrix
+        if (pow_overlap && pow_ready_for == ia && pow_ready_upper == gd_upper)
+            HIP_CHECK(hipStreamWaitEvent(st, c->pow_ev[ia & 1], 0));
+        else {
+            if (pow_ready_for >= 0) HIP_CHECK(hipStreamSynchronize(c->copy_stream)); // (a stale pre-launch must not write under us)
+            k_pow_matrix(c, D.p, N, alpha, GDc, gd_upper);
+        }
+        pow_ready_for = -1;
         if (directed || !use_persistent) HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
         if (directed) {
             const double init[2] = {0.9, 1.0}; // epsilon, diff (:434-435)
@@ -351,7 +375,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             sl.t0_par = tpar;
             if (use_persistent) { // the whole fit in one launch, GD's upper triangle in registers (kernels_fitp.hip)
                 const int tnext = (tpar + 1) % 3;
-                if (fit_variant == 2 && k_fit_flow_enqueue(c, GD.p, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld, Tld, G.vw,
+                if (fit_variant == 2 && k_fit_flow_enqueue(c, GDc, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld, Tld, G.vw,
                                                            0.25, delta, (int *)(scal.p + RES_FIT))) {
                     sl.fit_async = true; // the verdict is looked at when the alpha is collected
                     fitted = true;
@@ -364,14 +388,14 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                     }
                     HIP_CHECK(hipMemcpyAsync(c->fp_Tsave.p, TT.p + (i64)tpar * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
                     int fpar = 0;
-                    fitted = k_fit_persistent(c, GD.p, N, TT.p + (i64)tpar * Tld, Tld, 0, G.vw, 0.25, delta, &iters, &fpar,
+                    fitted = k_fit_persistent(c, GDc, N, TT.p + (i64)tpar * Tld, Tld, 0, G.vw, 0.25, delta, &iters, &fpar,
                                               fit_variant == 2 ? 1 : fit_variant);
                     if (fitted) {
                         tpar += fpar;
                         c->stat_fit_persistent++;
                     } else { // not co-resident / timed out: restore T and use one launch per iteration from here on
                         use_persistent = false;
-                        if (gd_upper && !sym_fit) k_pow_matrix(c, D.p, N, alpha, GD.p, false);
+                        if (gd_upper && !sym_fit) k_pow_matrix(c, D.p, N, alpha, GDc, false);
                         HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
                         HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
                     }
@@ -384,7 +408,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                 i64 k = 0;
                 for (;;) {
                     for (i64 b = 0; b < batch; b++, k++)
-                        (sym_fit ? k_fit_sym_step : k_fit_step)(c, GD.p, Tb2[k & 1], Tb2[(k + 1) & 1], G.vw, N, 0.25, delta, (int)k,
+                        (sym_fit ? k_fit_sym_step : k_fit_step)(c, GDc, Tb2[k & 1], Tb2[(k + 1) & 1], G.vw, N, 0.25, delta, (int)k,
                                                                 c->sw_fring.p, flags.p, flags.p + 1);
                     int hf[2];
                     unsigned long long hr[3];
@@ -403,7 +427,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             }
             Tcur = TT.p + (i64)tpar * Tld;
         } else if (use_persistent_dir &&
-                   k_fit_persistent_dir(c, GD.p, N, T1.p, T2.p, G.deg_in, G.deg_out, 0.9, 1.0, delta, &iters, fit_variant,
+                   k_fit_persistent_dir(c, GDc, N, T1.p, T2.p, G.deg_in, G.deg_out, 0.9, 1.0, delta, &iters, fit_variant,
                                         fit_variant == 2 ? (int *)(scal.p + RES_FIT) : nullptr, &dir_async)) {
             // the whole directed fit in one launch (kernels_fitp.hip).  The default form is only enqueued: the rest of the
             // alpha's chain is queued behind it and its verdict arrives with the alpha's scalars (Tin / Tout are written
@@ -417,7 +441,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                 HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
             }
             for (i64 b = 0; b < batch; b++) {
-                k_fit_symv_dir(c, GD.p, T1.p, T2.p, N, S1.p, S2.p, flags.p);
+                k_fit_symv_dir(c, GDc, T1.p, T2.p, N, S1.p, S2.p, flags.p);
                 k_fit_update_dir(c, T1.p, T2.p, S1.p, S2.p, G.deg_in, G.deg_out, N, delta, flags.p, flags.p + 1,
                                  fitstate.p);
             }
@@ -431,6 +455,21 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         }
         sl.iters = iters;
         if (!sl.fit_async) prev_iters = iters;
+        if (pow_overlap && sl.fit_async && ia < n_alpha_total) { // the next alpha's matrix: behind this fit, beside what follows it
+            HIP_CHECK(hipEventRecord(c->fitdone_ev, st));
+            HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->fitdone_ev, 0));
+            std::swap(c->stream, c->copy_stream);
+            try {
+                k_pow_matrix(c, D.p, N, AlphaStep * (double)(ia + 1), GDb[(ia + 1) & 1], gd_upper);
+            } catch (...) {
+                std::swap(c->stream, c->copy_stream);
+                throw;
+            }
+            std::swap(c->stream, c->copy_stream);
+            HIP_CHECK(hipEventRecord(c->pow_ev[(ia + 1) & 1], c->copy_stream));
+            pow_ready_for = ia + 1;
+            pow_ready_upper = gd_upper;
+        }
 
         const double *Ta = directed ? Tout : Tcur, *Tb = directed ? Tin : Tcur;
         const double *Ta_auc = Ta, *Tb_auc = Tb;
@@ -454,7 +493,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                                ds.nj.p + s0, ds.dpos.p + s0, ds.dneg.p + s0, ds.wts.p + s0, s1 - s0, alpha, nullptr,
                                scal.p + RES_AUC);
             else
-                k_auc_exact(c, GD.p, Ta, Tb, N, ds.pi.p + s0, ds.pj.p + s0, ds.ni.p + s0, ds.nj.p + s0, ds.wts.p + s0, s1 - s0,
+                k_auc_exact(c, GDc, Ta, Tb, N, ds.pi.p + s0, ds.pj.p + s0, ds.ni.p + s0, ds.nj.p + s0, ds.wts.p + s0, s1 - s0,
                             nullptr, scal.p + RES_AUC);
         }
         if (shard_samples) {
@@ -468,7 +507,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             else cge_allreduce_dev(c, scal.p + RES_VERD, 1, 0);
         }
         if (want_div) {
-            k_bvec(c, GD.p, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
+            k_bvec(c, GDc, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
             if (!split)
                 k_js(c, G.vectC, vectB.p, vlen, C, directed, 0, nullptr, scal.p + RES_JS);
             else {
@@ -507,6 +546,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             const int *hf = (const int *)(c->pin_scal.p + RES_STRIDE * (ia & 1) + RES_FIT);
             if (hf[2] || !hf[0] || peer_failed) { // a wait timed out (here or on another rank): drain what was enqueued behind
                 HIP_CHECK(hipStreamSynchronize(st)); // it and redo this alpha from its T_0 (still in place) with one launch per
+                HIP_CHECK(hipStreamSynchronize(c->copy_stream)); // (and a pre-launched power matrix: the redo writes its own)
+                pow_ready_for = -1;
                 note_fit_fallback(c);                // iteration, as every later alpha
                 if (directed) use_persistent_dir = false;
                 else {
@@ -576,6 +617,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         }
         if (skip_div && skip_auc) break; // :253
     }
+    if (pow_overlap) HIP_CHECK(hipStreamSynchronize(c->copy_stream)); // (a matrix pre-launched for an alpha the early stop never reached)
     out[0] = best_alpha; out[1] = best_div; out[2] = best_div_ext; out[3] = best_div_int;
     out[4] = best_alpha_auc; out[5] = best_auc; out[6] = best_auc_err; // :256
     *out_len = 7;
