@@ -2278,11 +2278,13 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
     }
     __syncthreads();
     if (diag_stage == 2) { if (tid < d) out[tid] = red[4]; return; } // timing diagnostic only
-    // ---- inverse iteration, REGISTER form (round 4, the default): the tridiagonal factors and the iterate live in the wave's
-    //      registers (element i in lane i & 63, slot i >> 6); the O(d) recurrences run in every lane at once on values fetched
-    //      with v_readlane (a few cycles) instead of by lane 0 from LDS (a ~130-cycle round trip inside every step of seven
-    //      dependent sweeps).  The same operations on the same values in the same order as the LDS form below: the same bits.
-    const bool lds_tail = (diag_stage & 256) != 0; // A/B: the LDS form of rounds 1-3
+    // ---- inverse iteration, REGISTER form (round 4; CGE_EIG_TAIL_REG=1, NOT the default): the tridiagonal factors and the
+    //      iterate live in the wave's registers (element i in lane i & 63, slot i >> 6); the O(d) recurrences run in every lane
+    //      at once on values fetched with v_readlane instead of by lane 0 from LDS.  The same operations on the same values in
+    //      the same order as the LDS form below: the same bits (all parity suites pass with it).  MEASURED SLOWER: 0.60 against
+    //      0.50 ms per launch of 512 matrices (profiles/r04_eig_tail_ab.txt) -- a step of a sweep needs ~16 v_readlane_b32 and
+    //      three predicated moves, ~30 wave instructions of 4 cycles each, which is the LDS round trip it was meant to avoid.
+    const bool lds_tail = (diag_stage & 256) == 0;
     diag_stage &= 255;
     if (wv == 0 && !lds_tail) {
         const double lam = red[4];
@@ -3555,7 +3557,7 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
     }
     ScopedKernelTimer t(c, "group_eig");
     static const int diag_stage = (getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0) // 0 = normal
-                                  | ((getenv("CGE_EIG_TAIL_LDS") && atoi(getenv("CGE_EIG_TAIL_LDS"))) ? 256 : 0); // A/B: inverse iteration from LDS (rounds 1-3)
+                                  | ((getenv("CGE_EIG_TAIL_REG") && atoi(getenv("CGE_EIG_TAIL_REG"))) ? 256 : 0); // A/B: inverse iteration from registers (slower)
     // A/B: CGE_EIG_FORM=5 (default) blocked columns, reflectors in place, column values as DPP broadcasts; 0: the same with LDS
     // broadcast reads (the form of rounds 1-2, same bits); 4 / 8: the cyclic form on 4 / 8 waves
     static const int form = getenv("CGE_EIG_FORM") ? atoi(getenv("CGE_EIG_FORM")) : 5;
