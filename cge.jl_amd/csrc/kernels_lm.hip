@@ -221,16 +221,105 @@ void k_gather_rows_f64(cge_ctx *c, const double *X, i64 n, i64 d, int row_major,
     hipLaunchKernelGGL(gather_rows_f64_kernel, dim3(grid_for(cnt * d, 256, 8192)), dim3(256), 0, c->stream, X, n, d, row_major,
                        idx, cnt, out);
 }
+// The planes-only form (round 4): when the bound pass reads the bf16 planes (row-major) and nobody needs the feature-major
+// fp64 copy, no transposition is needed at all -- a wave takes whole rows (two consecutive features per lane: one 16-byte
+// load per lane, a row of d = 128 in ONE request), four rows in flight, writes the two planes with 4-byte stores and reduces
+// the squared norm inside the wave.  The tile kernel above asks for every row in four 256-byte pieces between barriers and
+// ran at half of what HBM gives a gather of 1 KB rows (profiles/r04_rocprofv3_summary.md).
+__global__ __launch_bounds__(256) void gather_planes_kernel(const double *__restrict__ src, const i32 *__restrict__ idx,
+                                                            const double *__restrict__ mean, i64 npos, i64 d, i64 ld,
+                                                            unsigned short *__restrict__ planes, i64 KP, int *__restrict__ flag,
+                                                            double *__restrict__ rnorm) {
+    const int lane = threadIdx.x & 63;
+    const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+    bool bad = false, big = false;
+    constexpr int R = 4;
+    for (i64 p0 = wave * R; p0 < npos; p0 += nwaves * R) {
+        i64 node[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const i64 p = p0 + r;
+            node[r] = p < npos ? (idx ? (i64)idx[p] : p) : -1; // (negative: a row of another rank / past the end: zeros)
+        }
+        double sq[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) sq[r] = 0.0;
+        for (i64 k = 2 * lane; k < KP; k += 128) {
+            double m0 = k < d ? mean[k] : 0.0, m1 = k + 1 < d ? mean[k + 1] : 0.0;
+            double v0[R], v1[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) { // all loads of the R rows in flight before any use
+                const double *row = src + (node[r] < 0 ? 0 : node[r]) * d;
+                const bool in = node[r] >= 0;
+                if ((d & 1) == 0 && k + 1 < d) {
+                    const double2 t = *reinterpret_cast<const double2 *>(row + k);
+                    v0[r] = in ? t.x : m0;
+                    v1[r] = in ? t.y : m1;
+                } else {
+                    v0[r] = (in && k < d) ? row[k] : m0;
+                    v1[r] = (in && k + 1 < d) ? row[k + 1] : m1;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const i64 p = p0 + r;
+                if (p >= npos) continue;
+                const double a = v0[r] - m0, b = v1[r] - m1;
+                unsigned short h[2], l[2];
+                const double vv[2] = {a, b};
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const double v = vv[q], av = fabs(v);
+                    if (flag) {
+                        if (!(av < 1.2676506002282294e30) || (av != 0.0 && av < 7.888609052210118e-31)) bad = true; // 2^100, 2^-100
+                        if (av >= 9.094947017729282e-13) big = true; // 2^-40
+                    }
+                    unsigned u = __float_as_uint((float)v);
+                    u += 0x7FFFu + ((u >> 16) & 1u); // bf16, round to nearest even
+                    h[q] = (unsigned short)(u >> 16);
+                    unsigned w = __float_as_uint((float)(v - (double)__uint_as_float((unsigned)h[q] << 16)));
+                    w += 0x7FFFu + ((w >> 16) & 1u);
+                    l[q] = (unsigned short)(w >> 16);
+                }
+                // (KP is a multiple of 32 and k even: the pair is inside the row and 4-byte aligned)
+                *reinterpret_cast<unsigned *>(planes + p * KP + k) = (unsigned)h[0] | ((unsigned)h[1] << 16);
+                *reinterpret_cast<unsigned *>(planes + ld * KP + p * KP + k) = (unsigned)l[0] | ((unsigned)l[1] << 16);
+                sq[r] += a * a + b * b;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const double s = wave_allsum(sq[r]);
+            if (lane == 0 && p0 + r < npos) rnorm[p0 + r] = s;
+        }
+    }
+    if (flag) { // one atomic per wave
+        const unsigned long long mb = __ballot(bad), mg = __ballot(big);
+        if (lane == 0 && (mb || mg)) atomicOr(flag, (mb ? 1 : 0) | (mg ? 2 : 0));
+    }
+}
 // Centred, zero-padded feature-major copy (dpad x ld) of npos gathered rows + squared row norms (ld entries).
 void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, const double *mean, double *dst,
                         double *rnorm, i64 npos, i64 d, i64 ld, i64 dpad, float *dst32, unsigned short *planes, i64 KP,
                         int *flag) {
     // (`dst` = nullptr: no fp64 copy -- the low-precision bound passes read the planes / the f32 copy, and the exact stage of
     // the diameter gathers only the candidate landmarks' rows)
+    static const bool tile_form = getenv("CGE_GATHER_TILES") != nullptr; // A/B: the tile kernel for the planes-only case too
+    const bool planes_only = planes && !dst && !dst32 && npos > 0 && !tile_form;
     if (dst) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(ld * dpad), c->stream));
-    if (planes) HIP_CHECK(hipMemsetAsync(planes, 0, sizeof(unsigned short) * (size_t)(2 * ld * KP), c->stream));
+    if (planes_only) { // the kernel writes every row below npos whole (padding features included): only the tail rows are cleared
+        for (int q = 0; q < 2; q++)
+            HIP_CHECK(hipMemsetAsync(planes + (size_t)q * ld * KP + (size_t)npos * KP, 0, sizeof(unsigned short) * (size_t)((ld - npos) * KP), c->stream));
+    } else if (planes)
+        HIP_CHECK(hipMemsetAsync(planes, 0, sizeof(unsigned short) * (size_t)(2 * ld * KP), c->stream));
     if (dst32) HIP_CHECK(hipMemsetAsync(dst32, 0, sizeof(float) * (size_t)(ld * dpad), c->stream));
     HIP_CHECK(hipMemsetAsync(rnorm, 0, sizeof(double) * (size_t)ld, c->stream));
+    if (planes_only) { // the operands of the bf16 bound pass and nothing else
+        const unsigned nb = (unsigned)std::min<i64>((npos + 15) / 16, 16384); // 4 waves x 4 rows per workgroup and round
+        hipLaunchKernelGGL(gather_planes_kernel, dim3(nb), dim3(256), 0, c->stream, src_rowmajor, idx, mean, npos, d, ld, planes, KP,
+                           flag, rnorm);
+        return;
+    }
     dim3 grid((unsigned)((npos + 31) / 32));
     hipLaunchKernelGGL(gather_centre_fm_kernel, grid, dim3(32, 8), 0, c->stream, src_rowmajor, idx, mean, dst, npos, d,
                        ld, dst32, planes, KP, flag, rnorm);
