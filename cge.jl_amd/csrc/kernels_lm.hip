@@ -269,15 +269,19 @@ __global__ __launch_bounds__(256) void gather_planes_kernel(const double *__rest
                 const double vv[2] = {a, b};
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
-                    const double v = vv[q], av = fabs(v);
+                    // The split in fp32 (the fp64 conversions and subtraction of the tile kernel made the gather compute-bound):
+                    // f = fl32(v), h = bf16(f), l = bf16(f - h) with f - h exact, so v = h + l + e with
+                    // |e| <= |v - f| + |(f - h) - l| <= (2^-24 + 2^-9 2^-9) |v| < 2^-16 |v|: inside the margin of (2c).
+                    // (A double below the fp32 range becomes 0: an absolute error far below anything the margin compares.)
+                    const float f = (float)vv[q], af = fabsf(f);
                     if (flag) {
-                        if (!(av < 1.2676506002282294e30) || (av != 0.0 && av < 7.888609052210118e-31)) bad = true; // 2^100, 2^-100
-                        if (av >= 9.094947017729282e-13) big = true; // 2^-40
+                        if (!(af < 1.2676506e30f) || (af != 0.0f && af < 7.8886091e-31f)) bad = true; // 2^100, 2^-100, not finite
+                        if (af >= 9.094947e-13f) big = true; // 2^-40
                     }
-                    unsigned u = __float_as_uint((float)v);
+                    unsigned u = __float_as_uint(f);
                     u += 0x7FFFu + ((u >> 16) & 1u); // bf16, round to nearest even
                     h[q] = (unsigned short)(u >> 16);
-                    unsigned w = __float_as_uint((float)(v - (double)__uint_as_float((unsigned)h[q] << 16)));
+                    unsigned w = __float_as_uint(f - __uint_as_float((unsigned)h[q] << 16));
                     w += 0x7FFFu + ((w >> 16) & 1u);
                     l[q] = (unsigned short)(w >> 16);
                 }
