@@ -177,7 +177,9 @@ __global__ void gather_centre_fm_kernel(const double *__restrict__ src, const i3
     if (flag) { // one atomic per workgroup (every thread of a fit embedding sees an ordinary-sized value: millions of
         // same-address atomics cost the launch 0.8 ms)
         const int any_bad = __syncthreads_or(bad ? 1 : 0), any_big = __syncthreads_or(big ? 1 : 0);
-        if (tx == 0 && ty == 0 && (any_bad || any_big)) atomicOr(flag, (any_bad ? 1 : 0) | (any_big ? 2 : 0));
+        const int need = (any_bad ? 1 : 0) | (any_big ? 2 : 0);
+        if (tx == 0 && ty == 0 && need && (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & need) != need)
+            atomicOr(flag, need); // (a plain look first: same-address atomics of every workgroup serialise)
     }
     if (rnorm) {
         nrm[ty][tx] = sq;
@@ -298,8 +300,11 @@ __global__ __launch_bounds__(256) void gather_planes_kernel(const double *__rest
         }
     }
     if (flag) { // one atomic per wave
+        // (a plain look first: once the bits are up -- after the first few waves -- nobody touches the word again; 65 000
+        // same-address atomics alone took 0.5 ms)
         const unsigned long long mb = __ballot(bad), mg = __ballot(big);
-        if (lane == 0 && (mb || mg)) atomicOr(flag, (mb ? 1 : 0) | (mg ? 2 : 0));
+        const int need = (mb ? 1 : 0) | (mg ? 2 : 0);
+        if (lane == 0 && need && (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & need) != need) atomicOr(flag, need);
     }
 }
 // Centred, zero-padded feature-major copy (dpad x ld) of npos gathered rows + squared row norms (ld entries).
