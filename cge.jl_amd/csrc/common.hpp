@@ -591,6 +591,7 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
 void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows, const unsigned char *side,
                        const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks,
                        i64 d, double *part, double *out);
+void k_side_values_means(cge_ctx *c, const double *sums, i64 n_tasks, i64 d, double *vals, double *means);
 void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *chunk_beg,
                      const i32 *chunk_end, i64 n_chunks, const i32 *task_chunk_off, i64 n_tasks, i64 d, double *ctot,
                      double *coff, double *prefix);

@@ -859,6 +859,30 @@ void k_group_side_sums(cge_ctx *c, const double *Xr, const double *vw, const i32
                        task_chunk_off, 2 * (2 * d + 1), out);
 }
 
+// The cut rules' children from the side sums, on the device (round 4): vals[2t + q] = -total_rss of child q of task t (the
+// host's rss_from_sums: sum over the columns of ss - s * s / ws, sequential, unfused) and the two means s / ws -- so the host
+// reads 2 doubles per task instead of 2 (2 d + 1) and the means never make the round trip through the host.
+__global__ __launch_bounds__(256) void side_values_means_kernel(const double *__restrict__ sums, i64 d, double *__restrict__ vals,
+                                                                double *__restrict__ means /* [task][2][d] */) {
+    const i64 t = blockIdx.x, W = 2 * d + 1;
+    const double *q0 = sums + t * 2 * W;
+    for (i64 e = threadIdx.x; e < 2 * d; e += blockDim.x) {
+        const i64 q = e / d, c2 = e - q * d;
+        const double *qq = q0 + q * W;
+        means[(t * 2 + q) * d + c2] = __ddiv_rn(qq[d + c2], qq[2 * d]);
+    }
+    if (threadIdx.x < 2) {
+        const double *qq = q0 + (i64)threadIdx.x * W;
+        const double ws = qq[2 * d];
+        double tot = 0.0;
+        for (i64 c2 = 0; c2 < d; c2++) tot = __dadd_rn(tot, __dsub_rn(qq[c2], __ddiv_rn(__dmul_rn(qq[d + c2], qq[d + c2]), ws)));
+        vals[2 * t + threadIdx.x] = -tot;
+    }
+}
+void k_side_values_means(cge_ctx *c, const double *sums, i64 n_tasks, i64 d, double *vals, double *means) {
+    if (n_tasks > 0) hipLaunchKernelGGL(side_values_means_kernel, dim3((unsigned)n_tasks), dim3(256), 0, c->stream, sums, d, vals, means);
+}
+
 // ------------------------------------------------------------------------------------------------
 // rss rule on sorted order.  Along ascending z every "gray" set of split_cluster_rss
 // (src/landmarks.jl:168-199) is a contiguous rank range, and `t1 = {z < med}` is its lower part.  With

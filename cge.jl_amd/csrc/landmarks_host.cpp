@@ -842,8 +842,14 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
     HIP_CHECK(hipMemcpyAsync(c->pin_res.p, c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
     k_group_side_sums(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
                       c->ls_part.p, c->ls_sums.p);
-    c->pin_sums.ensure((size_t)B.T * width);
-    HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->ls_sums.p, sizeof(double) * B.T * width, hipMemcpyDeviceToHost, st));
+    // the children's values and means from the sums, on the device: the means go straight into the arena (the next batch reads
+    // them there), the host reads two doubles per task (round 4; it used to fetch the sums, divide and upload the means: a
+    // round trip and a stream synchronisation per batch, thirty times per score with the cut rules)
+    (void)width;
+    c->sp_vals.ensure(2 * T);
+    k_side_values_means(c, c->ls_sums.p, T, d, c->sp_vals.p, c->lm_means.p + L.mbase);
+    c->pin_sums.ensure((size_t)2 * T);
+    HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(c->copy_done, st));
     // the children's member lists last: the host already has what its heap needs and builds the next batch meanwhile
     k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + L.base);
@@ -853,26 +859,18 @@ void rule_cut_collect(LaneRun &L) {
     const i64 T = L.B.T, d = c->d, width = 2 * (2 * d + 1);
     CutResult &out = L.cr;
     HIP_CHECK(hipEventSynchronize(c->copy_done));
-    const double *sums = c->pin_sums.p;
+    const double *vals = c->pin_sums.p; // (-total_rss of the two children, computed beside the means on the device)
     std::memcpy(out.nlow.data(), c->pin_res.p, sizeof(i32) * T);
-    c->pin_cmeans.ensure((size_t)2 * T * d);
-    parallel_for(c, T, [&](i64 t) {
+    (void)width;
+    for (i64 t = 0; t < T; t++) {
         Group *g = L.groups[t];
-        const double *q1 = &sums[(size_t)t * width], *q2 = q1 + (2 * d + 1);
-        out.vlow[t] = -rss_from_sums(q1, d);
-        out.vhigh[t] = -rss_from_sums(q2, d);
-        double *ml = c->pin_cmeans.p + (size_t)2 * t * d, *mh = ml + d;
-        for (i64 c2 = 0; c2 < d; c2++) {
-            ml[c2] = q1[d + c2] / q1[2 * d];
-            mh[c2] = q2[d + c2] / q2[2 * d];
-        }
+        out.vlow[t] = vals[2 * t];
+        out.vhigh[t] = vals[2 * t + 1];
         g->cmean_off = L.mbase + 2 * t * d;
         g->rc = CGE_OK;
         out.done[t] = 1;
-    });
-    // the next batch reads these means from either lane's stream: the copy has to be over before anything more is enqueued
-    HIP_CHECK(hipMemcpyAsync(c->lm_means.p + L.mbase, c->pin_cmeans.p, sizeof(double) * 2 * T * d, hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    // (the means are in the arena already, written on this lane's stream; a second lane starts behind an event of this stream)
 }
 
 // The generic round-based rss path for the tasks the sorted-order kernels declined (ties at the maximum of z, NaNs):
