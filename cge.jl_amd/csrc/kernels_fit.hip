@@ -564,10 +564,47 @@ __global__ void bvec_fold_kernel(const double *__restrict__ Z, i64 C, int direct
         vectB[C * c1 - c1 * (c1 - 1) / 2 + (c2 - c1)] = (c1 == c2) ? Z[e] : Z[e] + Z[c2 * C + c1];
     }
 }
+// vect_B by COMMUNITY BLOCKS (round 4), for a score graph whose communities are ranges of consecutive vertices (the sweep
+// relabels it, wgcl_host.cpp): bin (ca, cb) is the sum of P over the block rows(ca) x columns(cb) -- one thread per bin walks
+// its block row by row, j ascending: `for i, for j: vect_B[..] += P[i, j]` (src/divergence.jl:229-234, :533-538) restricted to
+// the bin, i.e. the REFERENCE'S OWN ORDER of additions.  A wave's 64 threads read 64 neighbouring column ranges of the same
+// row (contiguous memory); no row bins, no second stage, no fold: one launch instead of three, and GD is read once.
+// Undirected: cb >= ca, the diagonal block takes j >= i (GD holds the upper triangle); directed: all C x C blocks, whole rows.
+__global__ __launch_bounds__(256) void bvec_blocks_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
+                                                          const double *__restrict__ Tb, const i32 *__restrict__ cm_off, i64 N,
+                                                          i64 C, int directed, double *__restrict__ vectB) {
+    const i64 ca = blockIdx.x;
+    const i64 cb = (directed ? 0 : ca) + (i64)blockIdx.y * 256 + threadIdx.x;
+    if (cb >= C) return;
+    const i32 a0 = cm_off[ca], a1 = cm_off[ca + 1], b0 = cm_off[cb], b1 = cm_off[cb + 1];
+    const bool diag = !directed && ca == cb;
+    double acc = 0.0;
+    for (i32 i = a0; i < a1; i++) {
+        const double ti = Ta[i];
+        const double *row = GD + (i64)i * N;
+        i32 j = diag ? i : b0;
+        for (; j + 3 < b1; j += 4) { // four loads in flight; the additions keep j's order
+            const double g0 = row[j], g1 = row[j + 1], g2 = row[j + 2], g3 = row[j + 3];
+            const double t0 = Tb[j], t1 = Tb[j + 1], t2 = Tb[j + 2], t3 = Tb[j + 3];
+            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, t0), g0));
+            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, t1), g1));
+            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, t2), g2));
+            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, t3), g3));
+        }
+        for (; j < b1; j++) acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, Tb[j]), row[j]));
+    }
+    vectB[directed ? ca * C + cb : C * ca - ca * (ca - 1) / 2 + (cb - ca)] = acc;
+}
 void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_pos, const i32 *cm_off,
             const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB) {
     ScopedKernelTimer t(c, "bvec");
     const int plain = c->opt_test_bvec_plain; // testing: the forms for score graphs beyond the LDS budget / 512 communities
+    if (c->bvec_blocks && !plain) {
+        const i64 ncb = directed ? C : C; // (the undirected grid is cut off by cb >= C inside the kernel)
+        hipLaunchKernelGGL(bvec_blocks_kernel, dim3((unsigned)C, (unsigned)((ncb + 255) / 256)), dim3(256), 0, c->stream, GD, Ta, Tb,
+                           cm_off, N, C, directed, vectB);
+        return;
+    }
     if (N * sizeof(double) <= 64 * 1024 && !plain)
         hipLaunchKernelGGL((bvec_rows_kernel<1>), dim3((unsigned)N), dim3(256), N * sizeof(double), c->stream, GD, Ta,
                            Tb, cm_off, cm_mem, cm_pos, N, C, directed, rowbins);

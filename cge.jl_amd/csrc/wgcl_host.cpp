@@ -144,7 +144,13 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     DevBuf<i32> d_old2new;
     // (also the landmark graph of a landmark-mode score with more than 8192 landmarks -- config 5 has 12 000; the local
     // score then reads T through the landmark ids of the original numbering, see the un-permuted copy in the sweep)
-    const bool relabel = N > 8192 && c->opt_exact_relabel;
+    // Round 4: every sweep from 256 vertices on is relabelled, and vect_B is then summed BY COMMUNITY BLOCKS in one launch
+    // (kernels_fit.hip: bvec_blocks_kernel -- the reference's own order of additions inside a bin) instead of row bins + row
+    // sums + fold: 57 -> ~20 us per alpha at the headline.  Option bvec_blocks = 0 / CGE_BVEC_BLOCKS=0: the forms of rounds 1-3.
+    static const bool blocks_env = !(getenv("CGE_BVEC_BLOCKS") && atoi(getenv("CGE_BVEC_BLOCKS")) == 0);
+    const bool blocks = blocks_env && c->opt_bvec_blocks && c->opt_exact_relabel && N >= 256 && C >= 2 && !c->opt_test_bvec_plain;
+    const bool relabel = (N > 8192 && c->opt_exact_relabel) || blocks;
+    c->bvec_blocks = blocks;
     c->bvec_contig = relabel && N >= 64 * C; // a wave per (row, community) pays off for communities of a wave's width or more
     if (relabel) {
         DevBuf<i32> &d_order = c->sw_rl_order;
