@@ -564,45 +564,85 @@ __global__ void bvec_fold_kernel(const double *__restrict__ Z, i64 C, int direct
         vectB[C * c1 - c1 * (c1 - 1) / 2 + (c2 - c1)] = (c1 == c2) ? Z[e] : Z[e] + Z[c2 * C + c1];
     }
 }
-// vect_B by COMMUNITY BLOCKS (round 4), for a score graph whose communities are ranges of consecutive vertices (the sweep
-// relabels it, wgcl_host.cpp): bin (ca, cb) is the sum of P over the block rows(ca) x columns(cb) -- one thread per bin walks
-// its block row by row, j ascending: `for i, for j: vect_B[..] += P[i, j]` (src/divergence.jl:229-234, :533-538) restricted to
-// the bin, i.e. the REFERENCE'S OWN ORDER of additions.  A wave's 64 threads read 64 neighbouring column ranges of the same
-// row (contiguous memory); no row bins, no second stage, no fold: one launch instead of three, and GD is read once.
-// Undirected: cb >= ca, the diagonal block takes j >= i (GD holds the upper triangle); directed: all C x C blocks, whole rows.
-__global__ __launch_bounds__(256) void bvec_blocks_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
-                                                          const double *__restrict__ Tb, const i32 *__restrict__ cm_off, i64 N,
-                                                          i64 C, int directed, double *__restrict__ vectB) {
-    const i64 ca = blockIdx.x;
-    const i64 cb = (directed ? 0 : ca) + (i64)blockIdx.y * 256 + threadIdx.x;
-    if (cb >= C) return;
-    const i32 a0 = cm_off[ca], a1 = cm_off[ca + 1], b0 = cm_off[cb], b1 = cm_off[cb + 1];
-    const bool diag = !directed && ca == cb;
-    double acc = 0.0;
-    for (i32 i = a0; i < a1; i++) {
-        const double ti = Ta[i];
-        const double *row = GD + (i64)i * N;
-        i32 j = diag ? i : b0;
-        for (; j + 3 < b1; j += 4) { // four loads in flight; the additions keep j's order
-            const double g0 = row[j], g1 = row[j + 1], g2 = row[j + 2], g3 = row[j + 3];
-            const double t0 = Tb[j], t1 = Tb[j + 1], t2 = Tb[j + 2], t3 = Tb[j + 3];
-            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, t0), g0));
-            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, t1), g1));
-            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, t2), g2));
-            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, t3), g3));
+// vect_B by TILES (round 4), for a score graph whose communities are ranges of consecutive vertices (the sweep relabels it,
+// wgcl_host.cpp).  One workgroup per 64 x 64 tile of GD (the upper tiles when undirected): the tile is read once, coalesced, as
+// the products (Ta_i Tb_j) GD_ij into LDS; inside the tile a community pair is a rectangle (row segment x column segment), so
+// (a) every row is summed over each column segment (ascending j), (b) every rectangle over its rows (ascending i): one
+// partial per (tile, row segment, column segment), at base[tile] + rs * ns[J] + cs.  A second small kernel adds, per bin, the
+// partials of the tiles its rectangle touches (I ascending, then J): every sum has a fixed order, nothing is atomic, GD is
+// read once, and the row bins (N x C doubles written and read back) are gone: 57 -> ~20 us per alpha at the headline.
+// fc[b] / ns[b]: first community and number of communities (empty ones included) of the 64-vertex block b.
+__global__ __launch_bounds__(256) void bvec_tile_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
+                                                        const double *__restrict__ Tb, const i32 *__restrict__ cm_off,
+                                                        const i32 *__restrict__ fc, const i32 *__restrict__ ns,
+                                                        const i32 *__restrict__ base, i64 N, int Nt, int directed,
+                                                        double *__restrict__ partial) {
+    const int I = blockIdx.y, J = blockIdx.x;
+    if (!directed && J < I) return;
+    __shared__ double prod[64][65], rp[64][65];
+    const int t = threadIdx.x;
+    { // products of the tile (zero outside the matrix and, undirected, below the diagonal)
+        const int r = t >> 2, c0 = (t & 3) * 16;
+        const i64 i = (i64)64 * I + r;
+        const double ti = i < N ? Ta[i] : 0.0;
+        double g[16], tb[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const i64 j = (i64)64 * J + c0 + u;
+            const bool live = i < N && j < N && (directed || j >= i);
+            g[u] = live ? GD[i * N + j] : 0.0;
+            tb[u] = live ? Tb[j] : 0.0;
         }
-        for (; j < b1; j++) acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(ti, Tb[j]), row[j]));
+#pragma unroll
+        for (int u = 0; u < 16; u++) prod[r][c0 + u] = __dmul_rn(__dmul_rn(ti, tb[u]), g[u]);
     }
-    vectB[directed ? ca * C + cb : C * ca - ca * (ca - 1) / 2 + (cb - ca)] = acc;
+    __syncthreads();
+    const int nsI = ns[I], nsJ = ns[J], fcI = fc[I], fcJ = fc[J];
+    for (int idx = t; idx < 64 * nsJ; idx += 256) { // (a) row r over the columns of community fcJ + s
+        const int r = idx / nsJ, s2 = idx - r * nsJ;
+        const int b0 = max(cm_off[fcJ + s2], 64 * J) - 64 * J, b1 = min(cm_off[fcJ + s2 + 1], 64 * J + 64) - 64 * J;
+        double acc = 0.0;
+        for (int c2 = b0; c2 < b1; c2++) acc = __dadd_rn(acc, prod[r][c2]);
+        rp[r][s2] = acc;
+    }
+    __syncthreads();
+    for (int idx = t; idx < nsI * nsJ; idx += 256) { // (b) the rectangle (fcI + rs) x (fcJ + s)
+        const int rs = idx / nsJ, s2 = idx - rs * nsJ;
+        const int a0 = max(cm_off[fcI + rs], 64 * I) - 64 * I, a1 = min(cm_off[fcI + rs + 1], 64 * I + 64) - 64 * I;
+        double acc = 0.0;
+        for (int r = a0; r < a1; r++) acc = __dadd_rn(acc, rp[r][s2]);
+        partial[(i64)base[I * Nt + J] + idx] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void bvec_bins_kernel(const double *__restrict__ partial, const i32 *__restrict__ cm_off,
+                                                        const i32 *__restrict__ fc, const i32 *__restrict__ ns,
+                                                        const i32 *__restrict__ base, i64 C, int Nt, int directed,
+                                                        double *__restrict__ vectB) {
+    const i64 total = C * C, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const i64 ca = e / C, cb = e - ca * C;
+        if (!directed && cb < ca) continue;
+        const i32 a0 = cm_off[ca], a1 = cm_off[ca + 1], b0 = cm_off[cb], b1 = cm_off[cb + 1];
+        double acc = 0.0;
+        if (a1 > a0 && b1 > b0)
+            for (int I = a0 >> 6; I <= (a1 - 1) >> 6; I++)
+                for (int J = b0 >> 6; J <= (b1 - 1) >> 6; J++) {
+                    if (!directed && J < I) continue; // (the mirrored part of a diagonal bin: the reference sums j >= i only)
+                    acc = __dadd_rn(acc, partial[(i64)base[I * Nt + J] + (i64)(ca - fc[I]) * ns[J] + (cb - fc[J])]);
+                }
+        vectB[directed ? e : C * ca - ca * (ca - 1) / 2 + (cb - ca)] = acc;
+    }
 }
 void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_pos, const i32 *cm_off,
             const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB) {
     ScopedKernelTimer t(c, "bvec");
     const int plain = c->opt_test_bvec_plain; // testing: the forms for score graphs beyond the LDS budget / 512 communities
     if (c->bvec_blocks && !plain) {
-        const i64 ncb = directed ? C : C; // (the undirected grid is cut off by cb >= C inside the kernel)
-        hipLaunchKernelGGL(bvec_blocks_kernel, dim3((unsigned)C, (unsigned)((ncb + 255) / 256)), dim3(256), 0, c->stream, GD, Ta, Tb,
-                           cm_off, N, C, directed, vectB);
+        const int Nt = (int)((N + 63) / 64);
+        hipLaunchKernelGGL(bvec_tile_kernel, dim3((unsigned)Nt, (unsigned)Nt), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off, c->sw_bt_fc.p,
+                           c->sw_bt_ns.p, c->sw_bt_base.p, N, Nt, directed, c->sw_bt_part.p);
+        hipLaunchKernelGGL(bvec_bins_kernel, dim3(grid_for(C * C, 256, 1024)), dim3(256), 0, c->stream, c->sw_bt_part.p, cm_off,
+                           c->sw_bt_fc.p, c->sw_bt_ns.p, c->sw_bt_base.p, C, Nt, directed, vectB);
         return;
     }
     if (N * sizeof(double) <= 64 * 1024 && !plain)

@@ -144,13 +144,41 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     DevBuf<i32> d_old2new;
     // (also the landmark graph of a landmark-mode score with more than 8192 landmarks -- config 5 has 12 000; the local
     // score then reads T through the landmark ids of the original numbering, see the un-permuted copy in the sweep)
-    // Round 4: every sweep from 256 vertices on is relabelled, and vect_B is then summed BY COMMUNITY BLOCKS in one launch
-    // (kernels_fit.hip: bvec_blocks_kernel -- the reference's own order of additions inside a bin) instead of row bins + row
-    // sums + fold: 57 -> ~20 us per alpha at the headline.  Option bvec_blocks = 0 / CGE_BVEC_BLOCKS=0: the forms of rounds 1-3.
+    // Round 4: every sweep from 256 vertices on is relabelled, and vect_B is then summed BY TILES (kernels_fit.hip:
+    // bvec_tile_kernel + bvec_bins_kernel: GD read once, no row bins) instead of row bins + row sums + fold.  Option
+    // bvec_blocks = 0 / CGE_BVEC_BLOCKS=0: the forms of rounds 1-3.
     static const bool blocks_env = !(getenv("CGE_BVEC_BLOCKS") && atoi(getenv("CGE_BVEC_BLOCKS")) == 0);
     const bool blocks = blocks_env && c->opt_bvec_blocks && c->opt_exact_relabel && N >= 256 && C >= 2 && !c->opt_test_bvec_plain;
-    const bool relabel = (N > 8192 && c->opt_exact_relabel) || blocks;
-    c->bvec_blocks = blocks;
+    bool blocks_ok = blocks;
+    std::vector<i32> bt_fc, bt_ns, bt_base;
+    if (blocks) { // per 64-vertex block of the relabelled graph: first community and number of communities; per tile: its partials
+        const i64 Nt = (N + 63) / 64;
+        std::vector<i32> comm_new(N);
+        for (i64 q2 = 0; q2 < C; q2++)
+            for (i32 t2 = cm_off[q2]; t2 < cm_off[q2 + 1]; t2++) comm_new[t2] = (i32)q2; // position t2 of the community-sorted order
+        bt_fc.resize(Nt); bt_ns.resize(Nt); bt_base.assign(Nt * Nt + 1, 0);
+        for (i64 b = 0; b < Nt; b++) {
+            bt_fc[b] = comm_new[64 * b];
+            bt_ns[b] = comm_new[std::min<i64>(N, 64 * b + 64) - 1] - bt_fc[b] + 1;
+            if (bt_ns[b] > 64) blocks_ok = false; // (empty communities in between: the row-bin form takes such a graph)
+        }
+        i64 tot = 0;
+        for (i64 I = 0; I < Nt && blocks_ok; I++)
+            for (i64 J = 0; J < Nt; J++) {
+                bt_base[I * Nt + J] = (i32)tot;
+                if (directed || J >= I) tot += (i64)bt_ns[I] * bt_ns[J];
+                if (tot > (i64)1 << 30) blocks_ok = false;
+            }
+        if (blocks_ok) {
+            c->sw_bt_fc.ensure(Nt); c->sw_bt_ns.ensure(Nt); c->sw_bt_base.ensure(Nt * Nt + 1); c->sw_bt_part.ensure(std::max<i64>(tot, 1));
+            HIP_CHECK(hipMemcpyAsync(c->sw_bt_fc.p, bt_fc.data(), sizeof(i32) * Nt, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(c->sw_bt_ns.p, bt_ns.data(), sizeof(i32) * Nt, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(c->sw_bt_base.p, bt_base.data(), sizeof(i32) * Nt * Nt, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st)); // (the tables are locals)
+        }
+    }
+    const bool relabel = (N > 8192 && c->opt_exact_relabel) || blocks_ok;
+    c->bvec_blocks = blocks_ok;
     c->bvec_contig = relabel && N >= 64 * C; // a wave per (row, community) pays off for communities of a wave's width or more
     if (relabel) {
         DevBuf<i32> &d_order = c->sw_rl_order;
