@@ -580,7 +580,11 @@ __global__ __launch_bounds__(256) void bvec_tile_kernel(const double *__restrict
     const int I = blockIdx.y, J = blockIdx.x;
     if (!directed && J < I) return;
     __shared__ double prod[64][65], rp[64][65];
+    __shared__ int segI[66], segJ[66]; // the communities' boundaries inside the tile's row / column range
     const int t = threadIdx.x;
+    const int nsI = ns[I], nsJ = ns[J], fcI = fc[I], fcJ = fc[J];
+    if (t <= nsJ) segJ[t] = min(max(cm_off[fcJ + t], 64 * J), 64 * J + 64) - 64 * J;
+    if (t >= 128 && t - 128 <= nsI) segI[t - 128] = min(max(cm_off[fcI + t - 128], 64 * I), 64 * I + 64) - 64 * I;
     { // products of the tile (zero outside the matrix and, undirected, below the diagonal)
         const int r = t >> 2, c0 = (t & 3) * 16;
         const i64 i = (i64)64 * I + r;
@@ -597,21 +601,25 @@ __global__ __launch_bounds__(256) void bvec_tile_kernel(const double *__restrict
         for (int u = 0; u < 16; u++) prod[r][c0 + u] = __dmul_rn(__dmul_rn(ti, tb[u]), g[u]);
     }
     __syncthreads();
-    const int nsI = ns[I], nsJ = ns[J], fcI = fc[I], fcJ = fc[J];
-    for (int idx = t; idx < 64 * nsJ; idx += 256) { // (a) row r over the columns of community fcJ + s
-        const int r = idx / nsJ, s2 = idx - r * nsJ;
-        const int b0 = max(cm_off[fcJ + s2], 64 * J) - 64 * J, b1 = min(cm_off[fcJ + s2 + 1], 64 * J + 64) - 64 * J;
-        double acc = 0.0;
-        for (int c2 = b0; c2 < b1; c2++) acc = __dadd_rn(acc, prod[r][c2]);
-        rp[r][s2] = acc;
+    { // (a) row r over the columns of community fcJ + s: four threads per row take every fourth segment
+        const int r = t >> 2;
+        for (int s2 = t & 3; s2 < nsJ; s2 += 4) {
+            const int b0 = segJ[s2], b1 = segJ[s2 + 1];
+            double acc = 0.0;
+            for (int c2 = b0; c2 < b1; c2++) acc = __dadd_rn(acc, prod[r][c2]);
+            rp[r][s2] = acc;
+        }
     }
     __syncthreads();
-    for (int idx = t; idx < nsI * nsJ; idx += 256) { // (b) the rectangle (fcI + rs) x (fcJ + s)
-        const int rs = idx / nsJ, s2 = idx - rs * nsJ;
-        const int a0 = max(cm_off[fcI + rs], 64 * I) - 64 * I, a1 = min(cm_off[fcI + rs + 1], 64 * I + 64) - 64 * I;
-        double acc = 0.0;
-        for (int r = a0; r < a1; r++) acc = __dadd_rn(acc, rp[r][s2]);
-        partial[(i64)base[I * Nt + J] + idx] = acc;
+    { // (b) the rectangle (fcI + rs) x (fcJ + s): a wave's lanes take neighbouring column segments
+        const int s2 = t & 63;
+        if (s2 < nsJ)
+            for (int rs = t >> 6; rs < nsI; rs += 4) {
+                const int a0 = segI[rs], a1 = segI[rs + 1];
+                double acc = 0.0;
+                for (int r = a0; r < a1; r++) acc = __dadd_rn(acc, rp[r][s2]);
+                partial[(i64)base[I * Nt + J] + rs * nsJ + s2] = acc;
+            }
     }
 }
 __global__ __launch_bounds__(256) void bvec_bins_kernel(const double *__restrict__ partial, const i32 *__restrict__ cm_off,
