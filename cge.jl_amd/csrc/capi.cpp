@@ -1555,8 +1555,8 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_exact_relabel = value != 0;
         return CGE_OK;
     }
-    if (!strcmp(key, "bvec_blocks")) { // 1 (default): sweeps from 256 vertices on relabel the score graph by community and sum vect_B by
-        c->opt_bvec_blocks = value != 0; // community blocks in one launch; 0: row bins + row sums + fold (rounds 1-3)
+    if (!strcmp(key, "bvec_blocks")) { // 1: sweeps from 256 vertices on relabel the score graph by community and sum vect_B by tiles
+        c->opt_bvec_blocks = value != 0; // (measured slower); 0 (default): row bins + row sums + fold
         return CGE_OK;
     }
     if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget

@@ -345,8 +345,9 @@ struct cge_ctx {
     DevBuf<double> ls_eigscr;            // wide eigen-solver: partial vectors of its tile sweeps (kernels_lm.hip)
     bool bvec_contig = false;            // the score graph of the running sweep has contiguous communities (relabelled)
     bool bvec_blocks = false;            // ... and vect_B is summed by tiles (kernels_fit.hip: bvec_tile_kernel + bvec_bins_kernel)
-    int opt_bvec_blocks = 1;             // 1 (default): relabel the score graph of a sweep by community (from 256 vertices on) and sum
-                                         // vect_B by tiles; 0: the row-bin form of rounds 1-3 (relabelled only beyond 8192 vertices)
+    int opt_bvec_blocks = 0;             // 1: relabel the score graph of a sweep by community (from 256 vertices on) and sum vect_B by
+                                         // tiles (measured slower: profiles/r04_bvec_tiles_ab.txt); 0 (default): the row-bin form
+                                         // (relabelled only beyond 8192 vertices)
     DevBuf<i32> sw_bt_fc, sw_bt_ns, sw_bt_base; // per 64-vertex block: first community, communities; per tile: base of its partials
     DevBuf<double> sw_bt_part;
     DevBuf<i32> sw_rl_order, sw_rl_comm; // exact mode, N > 8192: the score graph relabelled by community (wgcl_host.cpp)

@@ -144,11 +144,12 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     DevBuf<i32> d_old2new;
     // (also the landmark graph of a landmark-mode score with more than 8192 landmarks -- config 5 has 12 000; the local
     // score then reads T through the landmark ids of the original numbering, see the un-permuted copy in the sweep)
-    // Round 4: every sweep from 256 vertices on is relabelled, and vect_B is then summed BY TILES (kernels_fit.hip:
-    // bvec_tile_kernel + bvec_bins_kernel: GD read once, no row bins) instead of row bins + row sums + fold.  Option
-    // bvec_blocks = 0 / CGE_BVEC_BLOCKS=0: the forms of rounds 1-3.
-    static const bool blocks_env = !(getenv("CGE_BVEC_BLOCKS") && atoi(getenv("CGE_BVEC_BLOCKS")) == 0);
-    const bool blocks = blocks_env && c->opt_bvec_blocks && c->opt_exact_relabel && N >= 256 && C >= 2 && !c->opt_test_bvec_plain;
+    // Round 4, option bvec_blocks = 1 / CGE_BVEC_BLOCKS=1 (NOT the default): the sweep is relabelled from 256 vertices on and
+    // vect_B is summed BY TILES (kernels_fit.hip: bvec_tile_kernel + bvec_bins_kernel: GD read once, no row bins) instead of
+    // row bins + row sums + fold.  Correct (every parity suite passes with it) and measured slower: the tile kernel takes
+    // 56 us where the three launches it replaces take 57 (profiles/r04_bvec_tiles_ab.txt).
+    static const bool blocks_env = getenv("CGE_BVEC_BLOCKS") && atoi(getenv("CGE_BVEC_BLOCKS")) != 0;
+    const bool blocks = (blocks_env || c->opt_bvec_blocks) && c->opt_exact_relabel && N >= 256 && C >= 2 && !c->opt_test_bvec_plain;
     bool blocks_ok = blocks;
     std::vector<i32> bt_fc, bt_ns, bt_base;
     if (blocks) { // per 64-vertex block of the relabelled graph: first community and number of communities; per tile: its partials

@@ -451,8 +451,8 @@ def test_pow_methods_give_the_same_sweep(ctx, orc, test115):
 def test_vect_b_plain_kernels_give_the_same_bits(ctx, test115):
     """vect_B of score graphs beyond the LDS budget (N > 8192) or with more than 512 communities goes through kernels
     without staging; forced here on small inputs: same additions in the same order, so the same score bits (undirected,
-    directed, landmark mode) as the staged row-bin form -- and both against round 4's default, the tile form on the
-    relabelled graph."""
+    directed, landmark mode) as the staged row-bin form -- and both against round 4's option bvec_blocks, the tile
+    form on the relabelled graph."""
     import cge.jl_amd as cg
     from cge.jl_amd import api, synth
 
@@ -467,14 +467,15 @@ def test_vect_b_plain_kernels_give_the_same_bits(ctx, test115):
             smp, fn = api.draw_samples(ctx, 5, 500), cg.wGCL
         args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
         try:
-            dflt, tdflt = fn(*args, samples=smp, trace=True, ctx=ctx)  # round 4's default: relabelled, vect_B by tiles
+            ref, tref = fn(*args, samples=smp, trace=True, ctx=ctx)  # the default: the staged row-bin form
+            ctx.set_option("bvec_blocks", 1)
+            dflt, tdflt = fn(*args, samples=smp, trace=True, ctx=ctx)  # round 4's option: relabelled, vect_B by tiles
             ctx.set_option("bvec_blocks", 0)
-            ref, tref = fn(*args, samples=smp, trace=True, ctx=ctx)  # the staged row-bin form of rounds 1-3
             ctx.set_option("test_bvec_plain", 1)
             res, tr = fn(*args, samples=smp, trace=True, ctx=ctx)
         finally:
             ctx.set_option("test_bvec_plain", 0)
-            ctx.set_option("bvec_blocks", 1)
+            ctx.set_option("bvec_blocks", 0)
         assert np.array_equal(res, ref) and np.array_equal(tr["div"], tref["div"], equal_nan=True), (n, directed)
         # the tile form groups the same products differently (and the fit sums in the relabelled order): equal to rounding
         assert tdflt["iters"] == tref["iters"] and dflt[0] == ref[0] and dflt[4] == ref[4]
