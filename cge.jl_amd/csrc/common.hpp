@@ -604,7 +604,7 @@ void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *
 void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
                  i32 *meta, double *vals, double *cmeans);
 void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
-                 unsigned char *side);
+                 unsigned char *side, i32 *nlow_out = nullptr); // nlow_out: rows of the low side per task (replaces k_side_counts)
 void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const double *zs,
                   const i32 *task_row_off, const i32 *task_chunk_off, const double *prefix, const double *coff,
                   i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals, double *cmeans /* [task][2][d] */);

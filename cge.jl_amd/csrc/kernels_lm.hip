@@ -871,16 +871,24 @@ __global__ __launch_bounds__(256) void side_values_means_kernel(const double *__
         const double *qq = q0 + q * W;
         means[(t * 2 + q) * d + c2] = __ddiv_rn(qq[d + c2], qq[2 * d]);
     }
+    // the columns' terms ss - s * s / ws in parallel (the IEEE divisions are the expensive part), then the host's sequential sum
+    extern __shared__ double term[]; // [2][d]
+    for (i64 e = threadIdx.x; e < 2 * d; e += blockDim.x) {
+        const i64 q = e / d, c2 = e - q * d;
+        const double *qq = q0 + q * W;
+        term[e] = __dsub_rn(qq[c2], __ddiv_rn(__dmul_rn(qq[d + c2], qq[d + c2]), qq[2 * d]));
+    }
+    __syncthreads();
     if (threadIdx.x < 2) {
-        const double *qq = q0 + (i64)threadIdx.x * W;
-        const double ws = qq[2 * d];
+        const double *tq = term + (i64)threadIdx.x * d;
         double tot = 0.0;
-        for (i64 c2 = 0; c2 < d; c2++) tot = __dadd_rn(tot, __dsub_rn(qq[c2], __ddiv_rn(__dmul_rn(qq[d + c2], qq[d + c2]), ws)));
+        for (i64 c2 = 0; c2 < d; c2++) tot = __dadd_rn(tot, tq[c2]);
         vals[2 * t + threadIdx.x] = -tot;
     }
 }
 void k_side_values_means(cge_ctx *c, const double *sums, i64 n_tasks, i64 d, double *vals, double *means) {
-    if (n_tasks > 0) hipLaunchKernelGGL(side_values_means_kernel, dim3((unsigned)n_tasks), dim3(256), 0, c->stream, sums, d, vals, means);
+    if (n_tasks > 0)
+        hipLaunchKernelGGL(side_values_means_kernel, dim3((unsigned)n_tasks), dim3(256), sizeof(double) * 2 * d, c->stream, sums, d, vals, means);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1989,24 +1997,31 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
 // order.  A row with z == cut joins the side that is smaller at that moment of the reference's sequential pass
 // (:229-236, :255-261); the running sizes are carried across 64-row chunks as ballot counts, the ties of a chunk are
 // settled in lane order.
-__global__ __launch_bounds__(64) void cut_sides_kernel(const double *__restrict__ z, const double *__restrict__ zs,
-                                                       const i32 *__restrict__ task_row_off, int use_median,
-                                                       unsigned char *__restrict__ side) {
+// Round 4: a workgroup of four waves per task, and the sequential tie rule only where a tie exists.  The cut (median of the
+// sorted z, or (min + max) / 2) almost never EQUALS a projection; without such a row the sides are `z < cut` row by row and
+// the size of the low side is a count -- both fully parallel (and the count replaces the side_counts launch).  A task that
+// does hold a row with z == cut is redone by its first wave with the reference's sequential rule (the code of rounds 1-3).
+__global__ __launch_bounds__(256) void cut_sides_kernel(const double *__restrict__ z, const double *__restrict__ zs,
+                                                        const i32 *__restrict__ task_row_off, int use_median,
+                                                        unsigned char *__restrict__ side, i32 *__restrict__ nlow_out) {
+    __shared__ double slo[4], shi[4];
+    __shared__ int scnt[4];
     const i64 t = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    if (k <= 0) { if (tid == 0 && nlow_out) nlow_out[t] = 0; return; }
     double cut;
     if (use_median)
         cut = (k & 1) ? zs[o + k / 2] : zs[o + k / 2 - 1] / 2.0 + zs[o + k / 2] / 2.0;
     else {
         double lo = z[o], hi = z[o];
-        i64 j = lane;
-        for (; j + 192 < k; j += 256) { // four loads in flight: one wave walks the whole task
-            const double v0 = z[o + j], v1 = z[o + j + 64], v2 = z[o + j + 128], v3 = z[o + j + 192];
+        i64 j = tid;
+        for (; j + 768 < k; j += 1024) { // four loads in flight per thread
+            const double v0 = z[o + j], v1 = z[o + j + 256], v2 = z[o + j + 512], v3 = z[o + j + 768];
             lo = fmin(fmin(lo, v0), fmin(fmin(v1, v2), v3));
             hi = fmax(fmax(hi, v0), fmax(fmax(v1, v2), v3));
         }
-        for (; j < k; j += 64) {
+        for (; j < k; j += 256) {
             const double v = z[o + j];
             lo = fmin(lo, v);
             hi = fmax(hi, v);
@@ -2015,8 +2030,42 @@ __global__ __launch_bounds__(64) void cut_sides_kernel(const double *__restrict_
             lo = fmin(lo, __shfl_xor(lo, off));
             hi = fmax(hi, __shfl_xor(hi, off));
         }
+        if (lane == 0) { slo[wv] = lo; shi[wv] = hi; }
+        __syncthreads();
+        lo = fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3])); // (min / max: any grouping gives the same value)
+        hi = fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]));
         cut = (lo + hi) / 2.0;
     }
+    // the parallel pass: sides as if there were no tie (a tie provisionally high), the low side counted
+    int cnt = 0, tie = 0;
+    {
+        i64 j = tid;
+        for (; j + 768 < k; j += 1024) {
+            const double v0 = z[o + j], v1 = z[o + j + 256], v2 = z[o + j + 512], v3 = z[o + j + 768];
+            side[o + j] = v0 < cut ? 1 : 2; side[o + j + 256] = v1 < cut ? 1 : 2;
+            side[o + j + 512] = v2 < cut ? 1 : 2; side[o + j + 768] = v3 < cut ? 1 : 2;
+            cnt += (v0 < cut) + (v1 < cut) + (v2 < cut) + (v3 < cut);
+            tie |= (v0 == cut) | (v1 == cut) | (v2 == cut) | (v3 == cut);
+        }
+        for (; j < k; j += 256) {
+            const double v = z[o + j];
+            side[o + j] = v < cut ? 1 : 2;
+            cnt += v < cut;
+            tie |= v == cut;
+        }
+    }
+    const int any_tie = __syncthreads_or(tie); // (also orders the provisional sides before the sequential redo)
+    if (!any_tie) {
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane == 0) scnt[wv] = cnt;
+        __syncthreads();
+        if (tid == 0 && nlow_out) nlow_out[t] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+        return;
+    }
+    if (wv != 0) return;
+    // a row with z == cut joins the side that is smaller at that moment of the reference's sequential pass (:229-236,
+    // :255-261): one wave walks the task, the running sizes carried across 64-row chunks as ballot counts, the ties of a
+    // chunk settled in lane order
     i64 nlow = 0, nhigh = 0;
     double znext[4]; // the next four 64-row chunks are requested while the current ones are settled
 #pragma unroll
@@ -2052,11 +2101,12 @@ __global__ __launch_bounds__(64) void cut_sides_kernel(const double *__restrict_
         nhigh += __popcll(mh) + eh;
         }
     }
+    if (lane == 0 && nlow_out) nlow_out[t] = (i32)nlow;
 }
 void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
-                 unsigned char *side) {
+                 unsigned char *side, i32 *nlow_out) {
     ScopedKernelTimer t(c, "cut_sides");
-    hipLaunchKernelGGL(cut_sides_kernel, dim3((unsigned)n_tasks), dim3(64), 0, c->stream, z, zs, task_row_off, use_median, side);
+    hipLaunchKernelGGL(cut_sides_kernel, dim3((unsigned)n_tasks), dim3(256), 0, c->stream, z, zs, task_row_off, use_median, side, nlow_out);
 }
 
 // Side flags of one rss round, derived on the device (no per-round row-sized upload).  Per task t,

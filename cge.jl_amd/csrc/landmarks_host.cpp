@@ -836,8 +836,7 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
                            c->sp_srows.p, c->sp_status.p, B.max_len);
     }
     c->ls_nlow.ensure(T);
-    k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p);
-    k_side_counts(c, c->ls_side.p, c->sp_tro.p, T, c->ls_nlow.p);
+    k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p, c->ls_nlow.p);
     c->pin_res.ensure((size_t)T); // pinned: the copies do not stall the host, the event below covers them
     HIP_CHECK(hipMemcpyAsync(c->pin_res.p, c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
     k_group_side_sums(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
