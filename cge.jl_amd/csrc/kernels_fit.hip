@@ -585,20 +585,24 @@ __global__ __launch_bounds__(256) void bvec_tile_kernel(const double *__restrict
     const int nsI = ns[I], nsJ = ns[J], fcI = fc[I], fcJ = fc[J];
     if (t <= nsJ) segJ[t] = min(max(cm_off[fcJ + t], 64 * J), 64 * J + 64) - 64 * J;
     if (t >= 128 && t - 128 <= nsI) segI[t - 128] = min(max(cm_off[fcI + t - 128], 64 * I), 64 * I + 64) - 64 * I;
-    { // products of the tile (zero outside the matrix and, undirected, below the diagonal)
-        const int r = t >> 2, c0 = (t & 3) * 16;
-        const i64 i = (i64)64 * I + r;
-        const double ti = i < N ? Ta[i] : 0.0;
-        double g[16], tb[16];
+    { // products of the tile (zero outside the matrix and, undirected, below the diagonal): a wave takes 16 rows, one row
+        // per load instruction (64 consecutive doubles: four cache lines), all 16 loads in flight
+        const int lane = t & 63, w = t >> 6;
+        const i64 j = (i64)64 * J + lane;
+        const double tbj = j < N ? Tb[j] : 0.0;
+        double g[16];
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-            const i64 j = (i64)64 * J + c0 + u;
+            const i64 i = (i64)64 * I + 16 * w + u;
             const bool live = i < N && j < N && (directed || j >= i);
             g[u] = live ? GD[i * N + j] : 0.0;
-            tb[u] = live ? Tb[j] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 16; u++) prod[r][c0 + u] = __dmul_rn(__dmul_rn(ti, tb[u]), g[u]);
+        for (int u = 0; u < 16; u++) {
+            const i64 i = (i64)64 * I + 16 * w + u;
+            const double ti = i < N ? Ta[i] : 0.0;
+            prod[16 * w + u][lane] = __dmul_rn(__dmul_rn(ti, tbj), g[u]); // (0 where the element is not live: g is 0 there)
+        }
     }
     __syncthreads();
     { // (a) row r over the columns of community fcJ + s: four threads per row take every fourth segment
