@@ -258,7 +258,7 @@ def _rank_rows(rank, world, port, q, case):
         g = _graph_rows(case)
         ctx = api.Context(0)
         coll = TorchCollectives(ctx, 600 * 600 * 2 + 1024, torch.device("cuda", 0))  # collectives first: the uploads are split
-        ctx.set_option("shard_ingest", 1)
+        ctx.set_option("shard_ingest", 0 if case.get("wgcl") else 1)  # (caller-drawn samples index the whole edge list)
         ctx.set_option("shard_rows", 1)
         ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
         ctx.set_option("fit_persistent", 1)  # (two processes cannot both keep a persistent grid resident on one GPU)
@@ -270,7 +270,19 @@ def _rank_rows(rank, world, port, q, case):
         owner = community_owner(g["comm"][:, 0], world)
         mine = int(np.sum(owner[g["comm"][:, 0] - 1] == rank))
         lm = ctx.landmarks_fetch()
-        q.put((rank, res.tolist(), hi, rows + (mine, ctx.truncated, ctx.get_stat("edges_resident")),
+        extra = None
+        if case.get("wgcl"):  # the reference's call shape, wGCL(landmark graph, v_to_l, ...), on the sharded rows: the landmark
+            # index is rebuilt from the caller's v_to_l (this rank's members), the diameter and the sampled pairs' rows go
+            # through the same exchanges
+            dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+            rng = np.random.default_rng(9)
+            smp = (rng.integers(1, g["m"] + 1, size=(1, 3000)), rng.integers(1, g["n"] + 1, size=(1, 3000)),
+                   rng.integers(1, g["n"] + 1, size=(1, 3000)))
+            smp[2][smp[1] == smp[2]] = smp[2][smp[1] == smp[2]] % g["n"] + 1
+            r2 = ctx.wgcl(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, None, None, None, False, auc_samples=3000,
+                          samples=smp, use_resident_original=True)
+            extra = (r2.tolist(), ctx.last_diameter()[0])
+        q.put((rank, res.tolist(), hi, rows + (mine, ctx.truncated, ctx.get_stat("edges_resident"), extra),
                [int(zlib.crc32(np.ascontiguousarray(x).tobytes())) for x in lm]))
         ctx.close()
     except Exception as e:  # surface the failure in the parent
@@ -284,7 +296,7 @@ def _rank_rows(rank, world, port, q, case):
             dist.destroy_process_group()
 
 
-ROW_CASES = [dict(method="rss"), dict(method="rss2"), dict(method="size"), dict(method="diameter"),
+ROW_CASES = [dict(method="rss"), dict(method="rss", wgcl=True), dict(method="rss2"), dict(method="size"), dict(method="diameter"),
              dict(method="rss", directed=True), dict(method="rss", weighted=True), dict(method="rss", shard_samples=2),
              dict(method="rss", dups=True), dict(method="diameter", directed=True, weighted=True)]
 
@@ -308,6 +320,16 @@ def test_two_ranks_sharded_rows(ctx, case):
         lm_ref = ctx.landmarks_fetch()
         trunc_ref = ctx.truncated
         crc_ref = [int(zlib.crc32(np.ascontiguousarray(x).tobytes())) for x in lm_ref]
+        extra_ref = None
+        if case.get("wgcl"):
+            dii, lemb, lcomm, ledges, lw, lweight, v2l = lm_ref
+            rng = np.random.default_rng(9)
+            smp = (rng.integers(1, g["m"] + 1, size=(1, 3000)), rng.integers(1, g["n"] + 1, size=(1, 3000)),
+                   rng.integers(1, g["n"] + 1, size=(1, 3000)))
+            smp[2][smp[1] == smp[2]] = smp[2][smp[1] == smp[2]] % g["n"] + 1
+            r2 = ctx.wgcl(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, None, None, None, False, auc_samples=3000,
+                          samples=smp, use_resident_original=True)
+            extra_ref = (r2.tolist(), ctx.last_diameter()[0])
     finally:
         ctx.set_option("fit_persistent", 0)
     if case.get("dups"):
@@ -324,10 +346,13 @@ def test_two_ranks_sharded_rows(ctx, case):
     held = 0
     for rank, res, hi, rows, crcs in results:
         assert hi is not None, res  # a traceback otherwise
-        resident, total, words, mine, trunc, edges_res = rows
+        resident, total, words, mine, trunc, edges_res, extra = rows
         assert total == g["n"] and resident == mine and words == resident * 16  # only this rank's rows are in HBM ...
         assert 0.35 * total < resident < 0.65 * total  # ... about half of them
-        assert edges_res < g["m"]  # (and its slice of the edge list)
+        assert case.get("wgcl") or edges_res < g["m"]  # (and its slice of the edge list)
+        if case.get("wgcl"):
+            assert extra[1] == extra_ref[1] and extra[0][0] == extra_ref[0][0] and extra[0][4] == extra_ref[0][4]
+            assert np.allclose(extra[0], extra_ref[0], rtol=1e-12, atol=1e-14), (extra, extra_ref)
         held += resident
         assert trunc == trunc_ref
         assert crcs[6] == crc_ref[6], "v_to_l differs from the one-rank run"

@@ -186,3 +186,27 @@ def test_text_table_reader_edge_cases(tmp_path):
     bad.write_text("")
     with pytest.raises(api.CGEError):
         api.read_table(str(bad))
+
+
+def test_flattened_clusters_are_cached_by_identity():
+    """api._flatten_clusters: a list of clusters that was flattened before is recognised by identity (the list and every member
+    array) and reused; another list, or the same list with a member REPLACED, is flattened again; FlatClusters passes through."""
+    from cge.jl_amd import api
+
+    rng = np.random.default_rng(3)
+    cl = [np.sort(rng.choice(5000, size=int(rng.integers(3, 40)), replace=False)) + 1 for _ in range(40)]
+    f1, o1 = api._flatten_clusters(cl)
+    f2, o2 = api._flatten_clusters(cl)
+    assert f1 is f2 and o1 is o2  # the cached arrays themselves
+    assert np.array_equal(f1, np.concatenate(cl)) and np.array_equal(np.diff(o1), [len(c) for c in cl])
+    cl2 = list(cl)  # another list object: flattened again (same content)
+    f3, _ = api._flatten_clusters(cl2)
+    assert f3 is not f1 and np.array_equal(f3, f1)
+    cl[7] = cl[7][:-1].copy()  # a member replaced: the fingerprint (ids and lengths of the members) no longer matches
+    f4, o4 = api._flatten_clusters(cl)
+    assert f4 is not f1 and np.array_equal(f4, np.concatenate(cl)) and o4[-1] == len(f1) - 1
+    fc = api.flatten_clusters(cl)
+    f5, o5 = api._flatten_clusters(fc)
+    assert f5 is fc.flat and o5 is fc.off and len(fc) == 40
+    small = [np.array([1, 2]), np.array([3])]  # short lists are not cached
+    assert api._flatten_clusters(small)[0] is not api._flatten_clusters(small)[0]
