@@ -546,7 +546,6 @@ __global__ __launch_bounds__(PB_T) void pcent_bf16_kernel(const unsigned short *
     constexpr int LDA = (int)KP + PB_APAD;
     unsigned short *Ah = ldsb, *Al = Ah + (size_t)128 * LDA, *Bh = Al + (size_t)128 * LDA, *Bl = Bh + (size_t)128 * LDA;
     double *gmax = reinterpret_cast<double *>(Bl + (size_t)128 * LDA); // [8 groups of 16 rows][128 columns] of the pair in hand
-    double *rnl = gmax + 8 * 128; // the inflated squared norms of the row tile's 128 rows (registers went to the second tile in flight)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, l32 = lane & 31, lh = lane >> 5;
     const i64 nTJ = ldm / 128;
@@ -568,40 +567,32 @@ __global__ __launch_bounds__(PB_T) void pcent_bf16_kernel(const unsigned short *
             for (int it = 0; it < 8; it++) *reinterpret_cast<uint4 *>((apl ? lo : hi) + (size_t)(16 * it + arow) * LDA + akk) = v[it];
         }
     };
-    // TWO reference tiles in flight (round 4).  The reference tiles form one cyclic stream 0, 1, .., nTJ - 1, 0, 1, .. across the
-    // row tiles; tile g + 1 of the stream is stored to LDS behind the MFMA phase of tile g.  With ONE tile requested at the start
-    // of that phase the store waited for it (a 64 KB tile from L2 takes longer than the ~0.7 us of MFMAs it was meant to hide:
-    // the data-movement skeleton alone was 0.42 of the kernel's 0.8 ms); now tile g + 2 is requested there, into the register set
-    // that tile g's store freed, and the store behind phase g finds tile g + 1 long arrived.  The two sets swap roles tile by
-    // tile, statically (the walk is unrolled by two; no register copies: a copy would wait for the loads in flight).
-    uint4 av[8], bvA[8], bvB[8];
-    const bool any = I0 + blockIdx.x < I1;
-    if (any) {
+    uint4 av[8], bv[8];
+    if (I0 + blockIdx.x < I1) {
         fetch(Xb, lds_rows, (I0 + blockIdx.x) * 128, av);
-        fetch(Mb, ldm, 0, bvB);
+        fetch(Mb, ldm, 0, bv);
     }
-    const i64 nTJe = nTJ + (nTJ & 1); // tiles walked per row tile: even, so set A always holds the odd tiles' successors
-    bool first = true;
     for (i64 I = I0 + blockIdx.x; I < I1; I += gridDim.x) {
         const i64 i0 = I * 128;
         __syncthreads(); // the previous row tile's readers are done
         stash(Ah, Al, av);
-        if (first) { // the very first reference tile comes through set B; set A then takes tile 1 of the stream
-            stash(Bh, Bl, bvB);
-            fetch(Mb, ldm, (1 % nTJe % nTJ) * 128, bvA);
-            first = false;
-        }
-        if (tid < 128) rnl[tid] = rns[i0 + tid] * e1; // the squared norms of the tile's rows, inflated (all column tiles use them)
+        stash(Bh, Bl, bv);
+        double rn[2][8]; // the squared norms of this lane's 16 rows of the tile, inflated (all column tiles use them)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) rn[h][q] = rns[i0 + wr * 32 + 16 * h + 8 * (q >> 2) + 4 * lh + (q & 3)] * e1;
         __syncthreads();
-        // one reference tile: `nxt` holds tile Jx + 1 of the stream (requested two phases ago), `far` is free for tile Jx + 2
-        auto col_tile = [&](const i64 Jx, uint4 (&nxt)[8], uint4 (&far)[8]) {
-            const i64 J = Jx % nTJ; // (an odd number of tiles is walked as nTJ + 1: tile 0 twice -- P is a maximum, idempotent)
-            const bool more_cols = true, more_rows = I + gridDim.x < I1;
+        for (i64 J = 0; J < nTJ; J++) {
+            const bool more_cols = J + 1 < nTJ, more_rows = I + gridDim.x < I1;
             double mn[2];
 #pragma unroll
             for (int b = 0; b < 2; b++) mn[b] = mnorm[J * 128 + wc * 64 + b * 32 + l32];
-            fetch(Mb, ldm, ((Jx + 2) % nTJe % nTJ) * 128, far);
-            if (Jx + 1 == nTJe && more_rows) fetch(Xb, lds_rows, (I + gridDim.x) * 128, av);
+            if (more_cols) fetch(Mb, ldm, (J + 1) * 128, bv);
+            else if (more_rows) {
+                fetch(Xb, lds_rows, (I + gridDim.x) * 128, av);
+                fetch(Mb, ldm, 0, bv);
+            }
             f16v acc[2];
 #pragma unroll
             for (int b = 0; b < 2; b++)
@@ -634,7 +625,7 @@ __global__ __launch_bounds__(PB_T) void pcent_bf16_kernel(const unsigned short *
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
                             const float af = acc[b][8 * h + q]; // row 16 h + 8 (q >> 2) + 4 lh + (q & 3)
-                            const double t = rnl[wr * 32 + 16 * h + 8 * (q >> 2) + 4 * lh + (q & 3)] - 2.0 * (double)af;
+                            const double t = rn[h][q] - 2.0 * (double)af;
                             v = fmax(v, (af - af == 0.f) ? t : 1e300); // NaN / Inf in the accumulator: no pruning on this entry
                         }
                         v = fmax(v, __shfl_xor(v, 32));
@@ -664,12 +655,8 @@ __global__ __launch_bounds__(PB_T) void pcent_bf16_kernel(const unsigned short *
                 }
                 if (curland >= 0 && col < nref) atomicMax(&P[(i64)curland * nref + col], (unsigned long long)__double_as_longlong(cur));
             }
-            if (more_cols) stash(Bh, Bl, nxt); // tile Jx + 1 of the stream
+            if (more_cols) stash(Bh, Bl, bv);
             __syncthreads(); // gmax may be overwritten, the next column tile read
-        };
-        for (i64 Jx = 0; Jx < nTJe; Jx += 2) { // the two register sets swap roles tile by tile: static, no copies
-            col_tile(Jx, bvA, bvB);
-            col_tile(Jx + 1, bvB, bvA);
         }
     }
 }
@@ -792,7 +779,7 @@ void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 l
     const i64 nTI = lds_rows / 128, I0 = nTI * part / nparts, I1 = nTI * (part + 1) / nparts;
     const double e1 = 1.0 + 1.05 * (3.0 * (double)(KP + 2) * 1.1920928955078125e-07 + 3.2 * 1.52587890625e-05); // 2^-23, 2^-16
     if (I1 > I0) {
-        const size_t lds = (size_t)4 * 128 * (KP + PB_APAD) * sizeof(unsigned short) + (size_t)9 * 128 * sizeof(double); // both operands, both planes, whole K + the group maxima + the row norms
+        const size_t lds = (size_t)4 * 128 * (KP + PB_APAD) * sizeof(unsigned short) + (size_t)8 * 128 * sizeof(double); // both operands, both planes, whole K + the group maxima
         static const int pb_diag = getenv("CGE_PB_DIAG") ? atoi(getenv("CGE_PB_DIAG")) : 0; // timing diagnostics (wrong bounds)
 #define PB_GO(NKS)                                                                                                         \
     do {                                                                                                                   \
