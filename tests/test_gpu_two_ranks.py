@@ -281,7 +281,22 @@ def _rank_rows(rank, world, port, q, case):
             smp[2][smp[1] == smp[2]] = smp[2][smp[1] == smp[2]] % g["n"] + 1
             r2 = ctx.wgcl(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, None, None, None, False, auc_samples=3000,
                           samples=smp, use_resident_original=True)
-            extra = (r2.tolist(), ctx.last_diameter()[0])
+            # ... and what sharded rows refuse, with a message instead of a hang: exact mode (every row on every rank), and
+            # clusters that do not refine the community vector (here: two communities of different ranks merged) -- the
+            # verdict is exchanged, so BOTH ranks leave by the same door
+            errs = []
+            for bad in ("exact", "span"):
+                try:
+                    if bad == "exact":
+                        ctx.score(g["clusters"], -1, 2, "rss", seed=5, auc_samples=1000)
+                    else:
+                        a, b = int(np.flatnonzero(owner == 0)[0]), int(np.flatnonzero(owner == 1)[0])
+                        cl = [c for k, c in enumerate(g["clusters"]) if k not in (a, b)] + [np.sort(np.concatenate([g["clusters"][a], g["clusters"][b]]))]
+                        ctx.score(cl, 600, 2, "rss", seed=5, auc_samples=1000)
+                    errs.append("no error")
+                except api.CGEError as e:
+                    errs.append((e.code, "shard_rows" in str(e)))
+            extra = (r2.tolist(), ctx.last_diameter()[0], errs)
         q.put((rank, res.tolist(), hi, rows + (mine, ctx.truncated, ctx.get_stat("edges_resident"), extra),
                [int(zlib.crc32(np.ascontiguousarray(x).tobytes())) for x in lm]))
         ctx.close()
@@ -353,6 +368,7 @@ def test_two_ranks_sharded_rows(ctx, case):
         if case.get("wgcl"):
             assert extra[1] == extra_ref[1] and extra[0][0] == extra_ref[0][0] and extra[0][4] == extra_ref[0][4]
             assert np.allclose(extra[0], extra_ref[0], rtol=1e-12, atol=1e-14), (extra, extra_ref)
+            assert extra[2] == [(-7, True), (-7, True)], extra[2]  # CGE_E_ARG, naming the option, on both ranks
         held += resident
         assert trunc == trunc_ref
         assert crcs[6] == crc_ref[6], "v_to_l differs from the one-rank run"
