@@ -1756,6 +1756,106 @@ __global__ __launch_bounds__(64) void rss2_prefix_kernel(const double *__restric
             }
     }
 }
+// ---- the chains as STREAMS (round 4): products first, in parallel; the chain wave only adds ---------------------------------
+// What bounds the longest group is the instruction issue of the ONE wave that must add its rows in order (rounds 2-3: ~15
+// instructions per row for gather, products and additions, ~110 ns per row with the divisions).  Here (1) a parallel kernel
+// writes the products w x^2 and w x of every row of the batch in sorted order (the same two multiplications, the same bits),
+// (2) the chain wave of a (group, direction) STREAMS them -- two contiguous 512-byte loads, two additions and two stores per
+// row and 64 columns, 48 rows in flight -- and stores the running sums of every row, (3) rss2_eval_kernel evaluates
+// sum_c (ss - s1^2 / w) of all rows in parallel, as in the split form above.  The same additions in the same order: same bits.
+template <int NS>
+__global__ __launch_bounds__(256) void rss2_products_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                                            const i32 *__restrict__ srows, i64 d, i64 R,
+                                                            double *__restrict__ P /* [R][2 NS 64] */, double *__restrict__ Wt /* [R] */) {
+    const i64 r = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const i64 v = srows[r];
+    const double w = vw[v];
+    double *pr = P + r * (2 * NS * 64);
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const i64 c = lane + 64 * s;
+        const double xv = (c < d) ? Xr[v * d + c] : 0.0;
+        pr[(2 * s) * 64 + lane] = w * (xv * xv);
+        pr[(2 * s + 1) * 64 + lane] = w * xv;
+    }
+    if (lane == 0) Wt[r] = w;
+}
+template <int NS>
+__global__ __launch_bounds__(64) void rss2_stream_kernel(const double *__restrict__ P, const double *__restrict__ Wt,
+                                                         const i32 *__restrict__ task_row_off, i64 R,
+                                                         double *__restrict__ PS /* [2][R][2 NS 64] */, double *__restrict__ PW /* [2][R] */,
+                                                         double *__restrict__ ck /* [2][slots][2 NS 64 + 64] */, i64 slots) {
+    const i64 t = blockIdx.x;
+    const int dir = blockIdx.y, lane = threadIdx.x;
+    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
+    const i64 nblk = (k + R2_BR - 1) / R2_BR, slot0 = o / R2_BR + t;
+    double *PSo = PS + ((i64)dir * R + o) * (2 * NS * 64);
+    double *PWo = PW + (i64)dir * R + o;
+    double *cko = ck + ((i64)dir * slots + slot0) * (2 * NS * 64 + 64);
+    double ss[NS], s1[NS], wacc = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
+    constexpr int NSET = NS == 1 ? 3 : 1; // sets of 16 rows in flight (64 registers each at NS = 1)
+    auto load_rows = [&](i64 b, double (&x)[R2_BR][2 * NS], double &wl) {
+        const i64 ql = b * R2_BR + lane;
+        wl = (lane < R2_BR && ql < k) ? Wt[o + (dir ? k - 1 - ql : ql)] : 0.0; // slots past the end: weight 0, products 0
+#pragma unroll
+        for (int u = 0; u < R2_BR; u++) {
+            const i64 q = b * R2_BR + u; // (uniform)
+            const bool in = q < k;
+            const double *pr = P + (o + (in ? (dir ? k - 1 - q : q) : 0)) * (2 * NS * 64);
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                x[u][2 * s] = in ? pr[(2 * s) * 64 + lane] : 0.0;
+                x[u][2 * s + 1] = in ? pr[(2 * s + 1) * 64 + lane] : 0.0;
+            }
+        }
+    };
+    auto process = [&](i64 b, const double (&x)[R2_BR][2 * NS], const double wl) {
+        // checkpoint: the triple before this block (what rss2_merge_kernel starts its boundary adjustment from)
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            cko[b * (2 * NS * 64 + 64) + (2 * s) * 64 + lane] = ss[s];
+            cko[b * (2 * NS * 64 + 64) + (2 * s + 1) * 64 + lane] = s1[s];
+        }
+        if (lane == 0) cko[b * (2 * NS * 64 + 64) + 2 * NS * 64] = wacc;
+        double wrow = 0.0; // lane q keeps the running weight after row q of the block
+#pragma unroll
+        for (int q = 0; q < R2_BR; q++) {
+            const double w = lane_value(wl, q);
+            const i64 row = b * R2_BR + q;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                ss[s] += x[q][2 * s];
+                s1[s] += x[q][2 * s + 1];
+                if (row < k) {
+                    PSo[row * (2 * NS * 64) + (2 * s) * 64 + lane] = ss[s];
+                    PSo[row * (2 * NS * 64) + (2 * s + 1) * 64 + lane] = s1[s];
+                }
+            }
+            wacc += w;
+            if (lane == q) wrow = wacc;
+        }
+        const i64 rowl = b * R2_BR + lane;
+        if (lane < R2_BR && rowl < k) PWo[rowl] = wrow;
+    };
+    double x[NSET][R2_BR][2 * NS], wl[NSET];
+#pragma unroll
+    for (int i = 0; i < NSET; i++) {
+        wl[i] = 0.0;
+        if (i < nblk) load_rows(i, x[i], wl[i]);
+    }
+    for (i64 b = 0; b < nblk; b += NSET) {
+#pragma unroll
+        for (int i = 0; i < NSET; i++)
+            if (b + i < nblk) {
+                process(b + i, x[i], wl[i]);
+                if (b + i + NSET < nblk) load_rows(b + i + NSET, x[i], wl[i]);
+            }
+    }
+}
 // F[dir][row] = sum over the columns of ss - s1^2 / w from the stored running sums: one wave per row, lane = column
 template <int NS>
 __global__ __launch_bounds__(256) void rss2_eval_kernel(const double *__restrict__ PS, const double *__restrict__ PW, i64 R,
@@ -1936,9 +2036,24 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
         // group is the instruction issue of ONE wave (an fp64 instruction per ~5.5 ns with one wave on its SIMD,
         // profiles/microbench_dpp_fmac.hip; ~15 instructions per row of the chain, ~40 more per row of IEEE division), whoever
         // loads the rows; not worth 200 MB of traffic per batch
-        static const int split = getenv("CGE_RSS2_SPLIT") ? atoi(getenv("CGE_RSS2_SPLIT")) : 0;
+        static const int split = getenv("CGE_RSS2_SPLIT") ? atoi(getenv("CGE_RSS2_SPLIT")) : 2;
         const size_t ps_words = (size_t)2 * R * (2 * ns0 * 64);
-        if (split && ps_words * sizeof(double) <= ((size_t)2 << 30)) {
+        // 2 (default since round 4, d <= 64): the chains as streams of precomputed products (rss2_products_kernel +
+        // rss2_stream_kernel + rss2_eval_kernel) while the three row-sized arrays stay below 4 GB
+        if (split == 2 && ns0 == 1 && (ps_words + ps_words / 2) * sizeof(double) <= ((size_t)4 << 30)) {
+            c->r2_PS.ensure(ps_words + ps_words / 2); // running sums of both directions, then the products
+            c->r2_PW.ensure((size_t)3 * R);            // running weights of both directions, then the rows' weights
+            double *P = c->r2_PS.p + ps_words, *Wt = c->r2_PW.p + 2 * R;
+            const unsigned nbp = (unsigned)((R * 64 + 255) / 256), nbe = (unsigned)((2 * R * 64 + 255) / 256);
+            hipLaunchKernelGGL((rss2_products_kernel<1>), dim3(nbp), dim3(256), 0, c->stream, Xr, vw, srows, d, R, P, Wt);
+            hipLaunchKernelGGL((rss2_stream_kernel<1>), gridA, dim3(64), 0, c->stream, P, Wt, task_row_off, R, c->r2_PS.p, c->r2_PW.p,
+                               c->r2_ck.p, slots);
+            hipLaunchKernelGGL((rss2_eval_kernel<1>), dim3(nbe), dim3(256), 0, c->stream, c->r2_PS.p, c->r2_PW.p, R, c->r2_F.p);
+            hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+                               d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+            return;
+        }
+        if (split == 1 && ps_words * sizeof(double) <= ((size_t)2 << 30)) {
             c->r2_PS.ensure(ps_words);
             c->r2_PW.ensure((size_t)2 * R);
             const unsigned nbe = (unsigned)((2 * R * 64 + 255) / 256);
