@@ -2036,10 +2036,12 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
         // group is the instruction issue of ONE wave (an fp64 instruction per ~5.5 ns with one wave on its SIMD,
         // profiles/microbench_dpp_fmac.hip; ~15 instructions per row of the chain, ~40 more per row of IEEE division), whoever
         // loads the rows; not worth 200 MB of traffic per batch
-        static const int split = getenv("CGE_RSS2_SPLIT") ? atoi(getenv("CGE_RSS2_SPLIT")) : 2;
+        static const int split = getenv("CGE_RSS2_SPLIT") ? atoi(getenv("CGE_RSS2_SPLIT")) : 0;
         const size_t ps_words = (size_t)2 * R * (2 * ns0 * 64);
-        // 2 (default since round 4, d <= 64): the chains as streams of precomputed products (rss2_products_kernel +
-        // rss2_stream_kernel + rss2_eval_kernel) while the three row-sized arrays stay below 4 GB
+        // 2 (round 4, d <= 64; NOT the default): the chains as streams of precomputed products (rss2_products_kernel +
+        // rss2_stream_kernel + rss2_eval_kernel) while the three row-sized arrays stay below 4 GB.  Same bits; measured slower
+        // (config 2: 0.625 against 0.559 ms per launch of the walk, 12.6 against 12.1 ms per step): ONE wave cannot stream
+        // 2 KB per row faster than it could compute the products -- its outstanding loads, not its instructions, bound it.
         if (split == 2 && ns0 == 1 && (ps_words + ps_words / 2) * sizeof(double) <= ((size_t)4 << 30)) {
             c->r2_PS.ensure(ps_words + ps_words / 2); // running sums of both directions, then the products
             c->r2_PW.ensure((size_t)3 * R);            // running weights of both directions, then the rows' weights
