@@ -1108,8 +1108,64 @@ void k_pair_local_idx(cge_ctx *c, const i32 *pi, const i32 *pj, i64 S, const i32
 void k_pair_dist_rows(cge_ctx *c, const double *B, i64 d, const i32 *pi, const i32 *pj, i64 S, double den, double *out) {
     if (S > 0) hipLaunchKernelGGL(pair_dist_rows_kernel, dim3(grid_for(S, 128)), dim3(128), 0, c->stream, B, d, pi, pj, S, den, out);
 }
+// The same for MANY pairs (round 4): a thread per pair walks two 1 KB rows eight bytes at a time -- 64 different rows per load
+// instruction -- and took 2.3 - 3.5 ms per million pairs (config 4: 7 ms of a 70 ms step, found in the kernel sequence).
+// Here a workgroup takes 16 pairs at a time: its four waves read the 32 rows coalesced (a wave per row, 512 bytes per load),
+// write the squared differences (a_k - b_k)^2 -- the reference's own products -- to LDS, and 16 threads add them in
+// ascending k, unfused, one accumulator per pair: dist()'s arithmetic (src/auxilary.jl:14-20), the same bits as the kernel above.
+__global__ __launch_bounds__(256) void pair_dist_tile_kernel(const double *__restrict__ Xr, i64 d, const i32 *__restrict__ pi,
+                                                             const i32 *__restrict__ pj, i64 S, double den,
+                                                             double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sq[]; // [16][d + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const i64 ld = d + 1;
+    for (i64 p0 = (i64)blockIdx.x * 16; p0 < S; p0 += (i64)gridDim.x * 16) {
+        // wave wv takes the pairs p0 + wv, p0 + wv + 4, ...: both rows of a pair in flight together, four pairs per wave
+        i64 ra[4], rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const i64 p = p0 + wv + 4 * u;
+            ra[u] = p < S ? (i64)pi[p] : 0;
+            rb[u] = p < S ? (i64)pj[p] : 0;
+        }
+        for (i64 k0 = 0; k0 < d; k0 += 64) {
+            const i64 k = k0 + lane;
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                a[u] = k < d ? Xr[ra[u] * d + k] : 0.0;
+                b[u] = k < d ? Xr[rb[u] * d + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (k < d) {
+                    const double df = __dsub_rn(a[u], b[u]);
+                    sq[(i64)(wv + 4 * u) * ld + k] = __dmul_rn(df, df);
+                }
+        }
+        __syncthreads();
+        if (tid < 16 && p0 + tid < S) {
+            const i64 p = p0 + tid;
+            double acc = 0.0;
+            if (pi[p] != pj[p]) {
+                const double *q = sq + (i64)tid * ld;
+                for (i64 k = 0; k < d; k++) acc = __dadd_rn(acc, q[k]);
+                acc = sqrt(acc);
+            }
+            out[p] = acc / den;
+        }
+        __syncthreads();
+    }
+}
 void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *pj, i64 S, double den, double *out) {
     if (S <= 0) return;
+    static const bool thread_form = getenv("CGE_PAIR_DIST_THREADS") != nullptr; // A/B: a thread per pair for every size
+    const size_t lds = (size_t)16 * (d + 1) * sizeof(double);
+    if (S >= 4096 && lds <= 64 * 1024 && !thread_form) {
+        const unsigned nb = (unsigned)std::min<i64>((S + 15) / 16, 256 * 16);
+        hipLaunchKernelGGL(pair_dist_tile_kernel, dim3(nb), dim3(256), lds, c->stream, Xr, d, pi, pj, S, den, out);
+        return;
+    }
     hipLaunchKernelGGL(pair_dist_kernel, dim3(grid_for(S, 128)), dim3(128), 0, c->stream, Xr, d, pi, pj, S, den, out);
 }
 
