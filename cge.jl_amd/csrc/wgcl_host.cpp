@@ -149,7 +149,11 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     // row bins + row sums + fold.  Correct (every parity suite passes with it) and measured slower: the tile kernel takes
     // 56 us where the three launches it replaces take 57 (profiles/r04_bvec_tiles_ab.txt).
     static const bool blocks_env = getenv("CGE_BVEC_BLOCKS") && atoi(getenv("CGE_BVEC_BLOCKS")) != 0;
-    const bool blocks = (blocks_env || c->opt_bvec_blocks) && c->opt_exact_relabel && N >= 256 && C >= 2 && !c->opt_test_bvec_plain;
+    // (beyond 8192 vertices the sweep is relabelled anyway and the staged row-bin kernel no longer fits LDS: there the tile
+    // form replaces the plain gather -- config 5, N = 12 000: 1.1 ms per alpha for the row bins alone)
+    static const bool blocks_off = getenv("CGE_BVEC_BLOCKS") && atoi(getenv("CGE_BVEC_BLOCKS")) == 0;
+    const bool blocks = (blocks_env || c->opt_bvec_blocks || (N > 8192 && !blocks_off)) && c->opt_exact_relabel && N >= 256 && C >= 2 &&
+                        !c->opt_test_bvec_plain;
     bool blocks_ok = blocks;
     std::vector<i32> bt_fc, bt_ns, bt_base;
     if (blocks) { // per 64-vertex block of the relabelled graph: first community and number of communities; per tile: its partials
