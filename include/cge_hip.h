@@ -290,6 +290,9 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  * "exact_relabel": exact mode (v_to_l empty) beyond 8192 vertices: 1 (default) = the score graph is relabelled by community
  *             inside the sweep, so that vect_B's row sums are contiguous pieces of a row; 0 = vertices as given (A/B and
  *             tests; same iteration counts, scores equal up to the rounding of the fit's summation order).
+ * "bvec_blocks": 1 = sweeps from 256 vertices on relabel the score graph by community and sum vect_B by 64 x 64 tiles (one read of
+ *             GD); 0 (default) = row bins + row sums + fold below 8192 vertices (beyond that the sweep is relabelled and uses the
+ *             tiles anyway).  Same results up to the rounding of the summation order; measured no faster at the headline.
  * "fit_persistent_test_timeout": testing hook, 1 = every persistent launch gives up at once (the host then
  *             restores the iterate and falls back to one launch per iteration).                              */
 int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
@@ -298,7 +301,9 @@ int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
  * "diameter_bits" = the bit pattern of the last `hi` (reinterpret the int64 as a double);
  * "fit_persistent_alphas" = alphas of the last sweep fitted by a persistent launch, "fit_persistent_fallbacks" = persistent fits abandoned since the context was created, "fit_iterations" = Chung-Lu
  * iterations of the last sweep (all alphas); "landmark_batches" / "landmark_batch_rows" / "landmark_splits" =
- * device batches of the last runsplit, the rows they covered, the groups they split                     */
+ * device batches of the last runsplit, the rows they covered, the groups they split;
+ * "edges_resident" / "edges_total" (option shard_ingest), "rows_resident" / "rows_total" (option shard_rows: the embedding rows this
+ * rank holds -- about n / W -- and n), "embedding_words_resident" (doubles of the resident row matrix)   */
 int cge_get_stat(cge_ctx *ctx, const char *key, int64_t *value);
 
 /* ---- text tables (the step right before the path: `readdlm` at src/auxilary.jl:80-168) -------------------------
