@@ -1558,12 +1558,8 @@ __global__ __launch_bounds__(256) void rss2_chain_lds_kernel(const double *__res
     extern __shared__ __attribute__((aligned(16))) double r2lds[];
     constexpr int XW = NS * 64; // doubles per row
     double(*tile)[R2_BR][65] = reinterpret_cast<double(*)[R2_BR][65]>(r2lds);          // [4][16][65]
-    // Round 4: the waves park the PRODUCTS w x^2 and w x of their blocks (the same two multiplications, done once and in
-    // parallel instead of by every wave for every row), so a row of the chain is two LDS reads and two additions per column
-    // instead of a read, three multiplications and two additions: ~17 instead of ~25 wave instructions per row with the
-    // divisions' share.  One buffer of 64 rows (two barriers per round; the next two rounds' rows wait in registers).
-    double *xs = r2lds + 4 * R2_BR * 65;                                                // [64][2 XW]: (w x^2, w x) per column
-    double *wsh = xs + 64 * 2 * XW;                                                     // [64]
+    double *xs = r2lds + 4 * R2_BR * 65;                                                // [2][64][XW]
+    double *wsh = xs + 2 * 64 * XW;                                                     // [2][64]
     const i64 t = blockIdx.x;
     const int dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
@@ -1590,19 +1586,13 @@ __global__ __launch_bounds__(256) void rss2_chain_lds_kernel(const double *__res
             }
         }
     };
-    auto park = [&](const double (&x)[R2_BR][NS], const double wl) {
-        double *xb = xs + (size_t)(16 * wave) * 2 * XW;
+    auto park = [&](int buf, const double (&x)[R2_BR][NS], const double wl) {
+        double *xb = xs + (size_t)buf * 64 * XW + (size_t)(16 * wave) * XW;
 #pragma unroll
-        for (int u = 0; u < R2_BR; u++) {
-            const double w = lane_value(wl, u);
+        for (int u = 0; u < R2_BR; u++)
 #pragma unroll
-            for (int s = 0; s < NS; s++) {
-                const double xv = x[u][s];
-                xb[u * 2 * XW + lane + 64 * s] = w * (xv * xv);
-                xb[u * 2 * XW + XW + lane + 64 * s] = w * xv;
-            }
-        }
-        if (lane < R2_BR) wsh[16 * wave + lane] = wl;
+            for (int s = 0; s < NS; s++) xb[u * XW + lane + 64 * s] = x[u][s];
+        if (lane < R2_BR) wsh[buf * 64 + 16 * wave + lane] = wl;
     };
     auto process = [&](i64 b, const double *xb, const double *wb) { // block b: 16 rows at xb (LDS), their weights at wb
         const bool mine = (int)(b & 3) == wave;
@@ -1619,8 +1609,9 @@ __global__ __launch_bounds__(256) void rss2_chain_lds_kernel(const double *__res
             const double w = wb[q];
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                ss[s] += xb[q * 2 * XW + lane + 64 * s];
-                s1[s] += xb[q * 2 * XW + XW + lane + 64 * s];
+                const double xv = xb[q * XW + lane + 64 * s];
+                ss[s] += w * (xv * xv);
+                s1[s] += w * xv;
             }
             wacc += w;
             if (mine) {
@@ -1652,20 +1643,20 @@ __global__ __launch_bounds__(256) void rss2_chain_lds_kernel(const double *__res
     load_block(0, xa, wa);
     if (1 < nround) load_block(1, xbq, wbq);
     for (i64 r = 0; r < nround; r++) {
-        if (r > 0) __syncthreads(); // everybody is done with the previous round's rows
-        if ((r & 1) == 0) {
-            park(xa, wa);
+        const int buf = (int)(r & 1);
+        if (buf == 0) {
+            park(0, xa, wa);
             if (r + 2 < nround) load_block(r + 2, xa, wa);
         } else {
-            park(xbq, wbq);
+            park(1, xbq, wbq);
             if (r + 2 < nround) load_block(r + 2, xbq, wbq);
         }
-        __syncthreads(); // the round's 64 rows (their products) are in LDS
+        __syncthreads(); // the round's 64 rows are in LDS (and everybody is done with the round that used this buffer before)
 #pragma unroll 1
         for (int bb = 0; bb < 4; bb++) {
             const i64 b = 4 * r + bb;
             if (b >= nblk) break;
-            process(b, xs + (size_t)(16 * bb) * 2 * XW, wsh + 16 * bb);
+            process(b, xs + (size_t)buf * 64 * XW + (size_t)(16 * bb) * XW, wsh + buf * 64 + 16 * bb);
         }
     }
 }
