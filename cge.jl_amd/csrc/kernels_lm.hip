@@ -1549,30 +1549,32 @@ __global__ __launch_bounds__(256) void rss2_chain_kernel(const double *__restric
 // additions in the same order, the divisions and tree sums of a block by the wave that owns it, as before.  Same bits.
 // Config 2: 4.24 -> 3.91 ms per step (the loads were not the bound: a wave issues an fp64 instruction per ~5.5 ns when it is
 // alone on its SIMD, and a row costs ~15 of them in the chain plus ~40 per IEEE division in its owner's quarter).
-template <int NS>
-__global__ __launch_bounds__(256) void rss2_chain_lds_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+template <int NS, int NW>
+__global__ __launch_bounds__(64 * NW) void rss2_chain_lds_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                                              const i32 *__restrict__ srows,
                                                              const i32 *__restrict__ task_row_off, i64 d, i64 R,
                                                              double *__restrict__ F /* [2][R] */,
                                                              double *__restrict__ ck /* [2][slots][2 NS 64 + 64] */, i64 slots) {
     extern __shared__ __attribute__((aligned(16))) double r2lds[];
     constexpr int XW = NS * 64; // doubles per row
-    double(*tile)[R2_BR][65] = reinterpret_cast<double(*)[R2_BR][65]>(r2lds);          // [4][16][65]
-    double *xs = r2lds + 4 * R2_BR * 65;                                                // [2][64][XW]
-    double *wsh = xs + 2 * 64 * XW;                                                     // [2][64]
+    constexpr int RR = 16 * NW;           // rows per round
+    constexpr int NB = (NW == 4) ? 2 : 1; // LDS buffers of a round's rows (one when eight waves need the room)
+    double(*tile)[R2_BR][65] = reinterpret_cast<double(*)[R2_BR][65]>(r2lds);          // [NW][16][65]
+    double *xs = r2lds + NW * R2_BR * 65;                                               // [NB][RR][XW]
+    double *wsh = xs + NB * RR * XW;                                                    // [NB][RR]
     const i64 t = blockIdx.x;
     const int dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
     const i32 *p = srows + o;
-    const i64 nblk = (k + R2_BR - 1) / R2_BR, nround = (nblk + 3) / 4, slot0 = o / R2_BR + t;
+    const i64 nblk = (k + R2_BR - 1) / R2_BR, nround = (nblk + NW - 1) / NW, slot0 = o / R2_BR + t;
     double *Fo = F + (i64)dir * R + o;
     double *cko = ck + ((i64)dir * slots + slot0) * (2 * NS * 64 + 64);
     double ss[NS], s1[NS], wacc = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
-    // this wave's block of round r: rows 64 r + 16 wave + (0..15); lane u < 16 keeps the id / weight of row u
+    // this wave's block of round r: rows RR r + 16 wave + (0..15); lane u < 16 keeps the id / weight of row u
     auto load_block = [&](i64 r, double (&x)[R2_BR][NS], double &wl) {
-        const i64 q = r * 64 + 16 * wave + lane;
+        const i64 q = r * RR + 16 * wave + lane;
         const bool ok = lane < R2_BR && q < k;
         const int vq = ok ? p[dir ? k - 1 - q : q] : p[0]; // slots past the end: a valid row with weight 0
         wl = ok ? vw[vq] : 0.0;
@@ -1587,76 +1589,120 @@ __global__ __launch_bounds__(256) void rss2_chain_lds_kernel(const double *__res
         }
     };
     auto park = [&](int buf, const double (&x)[R2_BR][NS], const double wl) {
-        double *xb = xs + (size_t)buf * 64 * XW + (size_t)(16 * wave) * XW;
+        double *xb = xs + (size_t)buf * RR * XW + (size_t)(16 * wave) * XW;
 #pragma unroll
         for (int u = 0; u < R2_BR; u++)
 #pragma unroll
             for (int s = 0; s < NS; s++) xb[u * XW + lane + 64 * s] = x[u][s];
-        if (lane < R2_BR) wsh[buf * 64 + 16 * wave + lane] = wl;
+        if (lane < R2_BR) wsh[buf * RR + 16 * wave + lane] = wl;
     };
-    auto process = [&](i64 b, const double *xb, const double *wb) { // block b: 16 rows at xb (LDS), their weights at wb
-        const bool mine = (int)(b & 3) == wave;
-        if (mine) { // checkpoint: the triple before this block
+    // A block's 16 rows and weights come out of LDS in ONE batch, a block ahead of their use: read where they are used, every
+    // row waited for its own LDS round trip (the tile stores between the rows keep the compiler from hoisting the reads), and
+    // that latency -- not the additions, the divisions or the global loads -- was what a row of the longest group cost.
+    auto lds_fetch = [&](const double *xb, const double *wb, double (&x)[R2_BR][NS], double &wl) {
+#pragma unroll
+        for (int q = 0; q < R2_BR; q++)
+#pragma unroll
+            for (int s = 0; s < NS; s++) x[q][s] = xb[q * XW + lane + 64 * s];
+        wl = wb[lane & (R2_BR - 1)];
+    };
+    // Block b, its 16 rows and weights in registers.  The same operations as the walk, in an order that lets them overlap: the
+    // 48 products first (independent of the chain), then the chain as bare additions, and in the owner's block the running
+    // sums of all 16 rows are kept so that the 16 divisions -- independent of one another -- follow as one straight-line
+    // stretch.  Written row by row behind a branch per row, every instruction waited for the one before it.
+    auto process = [&](i64 b, const double (&x)[R2_BR][NS], const double wl) {
+        const bool mine = (int)(b % NW) == wave;
+        double p2[R2_BR][NS], p1[R2_BR][NS], wq[R2_BR];
+#pragma unroll
+        for (int q = 0; q < R2_BR; q++) {
+            const double w = lane_value(wl, q);
+            wq[q] = w;
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                cko[b * (2 * NS * 64 + 64) + (2 * s) * 64 + lane] = ss[s];
-                cko[b * (2 * NS * 64 + 64) + (2 * s + 1) * 64 + lane] = s1[s];
+                const double xv = x[q][s];
+                p2[q][s] = w * (xv * xv);
+                p1[q][s] = w * xv;
             }
-            if (lane == 0) cko[b * (2 * NS * 64 + 64) + 2 * NS * 64] = wacc;
+        }
+        if (!mine) {
+#pragma unroll
+            for (int q = 0; q < R2_BR; q++) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    ss[s] += p2[q][s];
+                    s1[s] += p1[q][s];
+                }
+                wacc += wq[q];
+            }
+            return;
+        }
+        // checkpoint: the triple before this block
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            cko[b * (2 * NS * 64 + 64) + (2 * s) * 64 + lane] = ss[s];
+            cko[b * (2 * NS * 64 + 64) + (2 * s + 1) * 64 + lane] = s1[s];
+        }
+        if (lane == 0) cko[b * (2 * NS * 64 + 64) + 2 * NS * 64] = wacc;
+#pragma unroll
+        for (int q = 0; q < R2_BR; q++) { // the running sums after every row, in place of the products
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                ss[s] += p2[q][s];
+                s1[s] += p1[q][s];
+                p2[q][s] = ss[s];
+                p1[q][s] = s1[s];
+            }
+            wacc += wq[q];
+            wq[q] = wacc;
         }
 #pragma unroll
         for (int q = 0; q < R2_BR; q++) {
-            const double w = wb[q];
+            double acc = 0.0;
 #pragma unroll
-            for (int s = 0; s < NS; s++) {
-                const double xv = xb[q * XW + lane + 64 * s];
-                ss[s] += w * (xv * xv);
-                s1[s] += w * xv;
-            }
-            wacc += w;
-            if (mine) {
-                double acc = 0.0;
-#pragma unroll
-                for (int s = 0; s < NS; s++) acc += ss[s] - s1[s] * s1[s] / wacc; // padded columns are 0
-                tile[wave][q][lane] = acc;
-            }
+            for (int s = 0; s < NS; s++) acc += p2[q][s] - p1[q][s] * p1[q][s] / wq[q]; // padded columns are 0
+            tile[wave][q][lane] = acc;
         }
-        if (mine) {
-            __builtin_amdgcn_wave_barrier();
-            if (lane < R2_BR) { // wave_allsum's tree: adjacent pairs inside each row of 16 lanes, then ((R0 + R1) + R2) + R3
-                const double *v = tile[wave][lane];
-                double r16[4];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const double *u = v + 16 * g;
-                    const double a0 = (u[0] + u[1]) + (u[2] + u[3]), a1 = (u[4] + u[5]) + (u[6] + u[7]);
-                    const double a2 = (u[8] + u[9]) + (u[10] + u[11]), a3 = (u[12] + u[13]) + (u[14] + u[15]);
-                    r16[g] = (a0 + a1) + (a2 + a3);
-                }
-                const i64 q = b * R2_BR + lane;
-                if (q < k) Fo[q] = ((r16[0] + r16[1]) + r16[2]) + r16[3];
-            }
-            __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();
+        { // wave_allsum's tree for 16 rows at once: lane (g, row) adds adjacent pairs inside group g of 16 lanes of `row`,
+          // then ((R0 + R1) + R2) + R3 on the lanes of g = 0
+            const int row = lane & (R2_BR - 1), g = lane >> 4;
+            const double *u = tile[wave][row] + 16 * g;
+            const double a0 = (u[0] + u[1]) + (u[2] + u[3]), a1 = (u[4] + u[5]) + (u[6] + u[7]);
+            const double a2 = (u[8] + u[9]) + (u[10] + u[11]), a3 = (u[12] + u[13]) + (u[14] + u[15]);
+            const double r = (a0 + a1) + (a2 + a3);
+            const double r1 = __shfl(r, row + 16), r2 = __shfl(r, row + 32), r3 = __shfl(r, row + 48);
+            const i64 q = b * R2_BR + row;
+            if (g == 0 && q < k) Fo[q] = ((r + r1) + r2) + r3;
         }
+        __builtin_amdgcn_wave_barrier();
     };
     double xa[R2_BR][NS], xbq[R2_BR][NS], wa = 0.0, wbq = 0.0;
+    double y0[R2_BR][NS], y1[R2_BR][NS], u0 = 0.0, u1 = 0.0; // the blocks being added, out of LDS
     load_block(0, xa, wa);
     if (1 < nround) load_block(1, xbq, wbq);
     for (i64 r = 0; r < nround; r++) {
-        const int buf = (int)(r & 1);
-        if (buf == 0) {
-            park(0, xa, wa);
+        const int buf = (NB == 2) ? (int)(r & 1) : 0;
+        if (NB == 1 && r > 0) __syncthreads(); // everybody is done with the round that is in the buffer
+        if ((r & 1) == 0) {
+            park(buf, xa, wa);
             if (r + 2 < nround) load_block(r + 2, xa, wa);
         } else {
-            park(1, xbq, wbq);
+            park(buf, xbq, wbq);
             if (r + 2 < nround) load_block(r + 2, xbq, wbq);
         }
-        __syncthreads(); // the round's 64 rows are in LDS (and everybody is done with the round that used this buffer before)
+        __syncthreads(); // the round's rows are in LDS (and everybody is done with the round that used this buffer before)
+        const double *xr = xs + (size_t)buf * RR * XW;
+        const double *wr = wsh + buf * RR;
+        lds_fetch(xr, wr, y0, u0);
 #pragma unroll 1
-        for (int bb = 0; bb < 4; bb++) {
-            const i64 b = 4 * r + bb;
+        for (int bb = 0; bb < NW; bb += 2) {
+            const i64 b = NW * r + bb;
             if (b >= nblk) break;
-            process(b, xs + (size_t)buf * 64 * XW + (size_t)(16 * bb) * XW, wsh + buf * 64 + 16 * bb);
+            lds_fetch(xr + (size_t)(16 * (bb + 1)) * XW, wr + 16 * (bb + 1), y1, u1);
+            process(b, y0, u0);
+            if (b + 1 >= nblk) break;
+            if (bb + 2 < NW) lds_fetch(xr + (size_t)(16 * (bb + 2)) * XW, wr + 16 * (bb + 2), y0, u0);
+            process(b + 1, y1, u1);
         }
     }
 }
@@ -2074,23 +2120,24 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
             }
             return;
         }
-        // CGE_RSS2_LDS: 1 (default) = the waves of a chain share the rows through LDS; 0 = every wave loads every row itself
+        // CGE_RSS2_LDS: 1 (default) = the four waves of a chain share the rows through LDS; 2 = eight waves, two per SIMD (each owns
+        // the divisions of one block in eight, but the chain is repeated by twice as many waves and its registers spill:
+        // 0.455 against 0.343 ms per launch on config 2); 0 = every wave loads every row itself
         static const int lds_form = getenv("CGE_RSS2_LDS") ? atoi(getenv("CGE_RSS2_LDS")) : 1;
-        if (lds_form && ns0 == 1) { // (d <= 64; two 64-row buffers of 128 columns would not fit beside the tree-sum tiles)
-            const size_t lds = (size_t)(4 * R2_BR * 65 + 2 * 64 * ns0 * 64 + 2 * 64) * sizeof(double);
-            if (ns0 == 1) {
-                cge_allow_lds((const void *)rss2_chain_lds_kernel<1>, 160 * 1024);
-                hipLaunchKernelGGL((rss2_chain_lds_kernel<1>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
-                                   c->r2_ck.p, slots);
-                hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
-                                   d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+        if (lds_form && ns0 == 1) { // (d <= 64; the rows of a round with 128 columns would not fit beside the tree-sum tiles)
+            if (lds_form == 2) {
+                const size_t lds = (size_t)(8 * R2_BR * 65 + 128 * 64 + 128) * sizeof(double);
+                cge_allow_lds((const void *)rss2_chain_lds_kernel<1, 8>, 160 * 1024);
+                hipLaunchKernelGGL((rss2_chain_lds_kernel<1, 8>), gridA, dim3(512), lds, c->stream, Xr, vw, srows, task_row_off, d, R,
+                                   c->r2_F.p, c->r2_ck.p, slots);
             } else {
-                cge_allow_lds((const void *)rss2_chain_lds_kernel<2>, 160 * 1024);
-                hipLaunchKernelGGL((rss2_chain_lds_kernel<2>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
-                                   c->r2_ck.p, slots);
-                hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
-                                   d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+                const size_t lds = (size_t)(4 * R2_BR * 65 + 2 * 64 * 64 + 2 * 64) * sizeof(double);
+                cge_allow_lds((const void *)rss2_chain_lds_kernel<1, 4>, 160 * 1024);
+                hipLaunchKernelGGL((rss2_chain_lds_kernel<1, 4>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R,
+                                   c->r2_F.p, c->r2_ck.p, slots);
             }
+            hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+                               d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
             return;
         }
         if (ns0 == 1) {
