@@ -1572,12 +1572,18 @@ __global__ __launch_bounds__(64 * NW) void rss2_chain_lds_kernel(const double *_
     double ss[NS], s1[NS], wacc = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
-    // this wave's block of round r: rows RR r + 16 wave + (0..15); lane u < 16 keeps the id / weight of row u
-    auto load_block = [&](i64 r, double (&x)[R2_BR][NS], double &wl) {
+    if (k <= 0) return;
+    // This wave's block of round r: rows RR r + 16 wave + (0..15); lane u < 16 keeps the id / weight of row u.  The row ids
+    // are requested a round BEFORE the rows themselves: asked for together, every round waited out a memory round trip
+    // between the two (the ids, then the rows), which was a third of what a row cost.
+    const int p0 = p[0];
+    auto request_ids = [&](i64 r) -> int { // -1: a slot past the end
         const i64 q = r * RR + 16 * wave + lane;
-        const bool ok = lane < R2_BR && q < k;
-        const int vq = ok ? p[dir ? k - 1 - q : q] : p[0]; // slots past the end: a valid row with weight 0
-        wl = ok ? vw[vq] : 0.0;
+        return (lane < R2_BR && q < k) ? p[dir ? k - 1 - q : q] : -1;
+    };
+    auto load_rows = [&](const int vid, double (&x)[R2_BR][NS], double &wl) {
+        const int vq = vid >= 0 ? vid : p0; // slots past the end: a valid row with weight 0
+        wl = vid >= 0 ? vw[vq] : 0.0;
 #pragma unroll
         for (int u = 0; u < R2_BR; u++) {
             const i64 v = __builtin_amdgcn_readlane(vq, u);
@@ -1678,18 +1684,27 @@ __global__ __launch_bounds__(64 * NW) void rss2_chain_lds_kernel(const double *_
     };
     double xa[R2_BR][NS], xbq[R2_BR][NS], wa = 0.0, wbq = 0.0;
     double y0[R2_BR][NS], y1[R2_BR][NS], u0 = 0.0, u1 = 0.0; // the blocks being added, out of LDS
-    load_block(0, xa, wa);
-    if (1 < nround) load_block(1, xbq, wbq);
+    int vqp; // the ids of the round whose rows are requested next
+    {
+        const int v0 = request_ids(0), v1 = request_ids(1);
+        vqp = request_ids(2);
+        load_rows(v0, xa, wa);
+        if (1 < nround) load_rows(v1, xbq, wbq);
+    }
     for (i64 r = 0; r < nround; r++) {
         const int buf = (NB == 2) ? (int)(r & 1) : 0;
         if (NB == 1 && r > 0) __syncthreads(); // everybody is done with the round that is in the buffer
+        int vqn; // (requested behind the park: the park waits for every load in flight, and those are a round old by then)
         if ((r & 1) == 0) {
             park(buf, xa, wa);
-            if (r + 2 < nround) load_block(r + 2, xa, wa);
+            vqn = request_ids(r + 3);
+            if (r + 2 < nround) load_rows(vqp, xa, wa);
         } else {
             park(buf, xbq, wbq);
-            if (r + 2 < nround) load_block(r + 2, xbq, wbq);
+            vqn = request_ids(r + 3);
+            if (r + 2 < nround) load_rows(vqp, xbq, wbq);
         }
+        vqp = vqn;
         __syncthreads(); // the round's rows are in LDS (and everybody is done with the round that used this buffer before)
         const double *xr = xs + (size_t)buf * RR * XW;
         const double *wr = wsh + buf * RR;
