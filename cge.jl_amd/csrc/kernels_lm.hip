@@ -902,80 +902,63 @@ void k_side_values_means(cge_ctx *c, const double *sums, i64 n_tasks, i64 d, dou
 // P[r] has the bits of the full running sum at 1/8 of the write traffic), and the chunk total; a tiny second
 // kernel turns the totals of a task's chunks into exclusive offsets.  P[r] = prefix-in-chunk[r] + coff[chunk of r].
 // Block slots of chunk ch start at chunk_beg[ch] / STRIDE + ch (chunks never share a slot).
-// The ids and weights of the chunk's rows go to LDS first, and the rows of the NEXT group are requested before the current
-// one is added: asked for where they are used, ids -> rows were two dependent memory round trips per 32 rows with nothing
-// else in flight (a workgroup is two waves at d = 128), 4.8 us per 32 rows of a chunk.
 __global__ void scan_write_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                   const i32 *__restrict__ srows, const i32 *__restrict__ chunk_beg,
                                   const i32 *__restrict__ chunk_end, i64 d, i64 W, double *__restrict__ ctot,
                                   double *__restrict__ prefix) {
     constexpr int SB = CGE_PREFIX_STRIDE;
-    constexpr int G = 2 * SB; // rows per group (two groups in flight per thread)
-    __shared__ i32 s_id[CGE_CHUNK_ROWS];
-    __shared__ double s_w[CGE_CHUNK_ROWS];
     const i64 ch = blockIdx.x;
-    const i32 beg = chunk_beg[ch], end = chunk_end[ch], n = end - beg; // n <= CGE_CHUNK_ROWS (build_batch)
+    const i32 beg = chunk_beg[ch], end = chunk_end[ch];
     double *slots = prefix + ((i64)(beg / SB) + ch) * W;
-    for (i32 r = threadIdx.x; r < n; r += blockDim.x) {
-        const i32 v = srows[beg + r];
-        s_id[r] = v;
-        s_w[r] = vw[v];
-    }
-    __syncthreads();
     // thread c < d owns columns c (w x^2) and d + c (w x): one load of x per row; thread 0 also owns column 2d (w)
     for (i64 c = threadIdx.x; c < d; c += blockDim.x) {
         double run_ss = 0.0, run_s = 0.0, run_w = 0.0;
-        const i32 nfull = n / G;
-        double xa[G], xb[G];
-        auto fetch = [&](i32 g, double (&x)[G]) {
+        i32 j = beg;
+        i64 bi = 0;
+        constexpr int NB = 4; // blocks of SB rows requested together: a workgroup is two waves at d = 128 and there are only a
+                              // few hundred chunks, so the rows in flight per thread are what fills the memory pipeline
+        for (; j + NB * SB - 1 < end; j += NB * SB, bi += NB) {
+            double xv[NB * SB], wv[NB * SB];
 #pragma unroll
-            for (int q = 0; q < G; q++) x[q] = Xr[(i64)s_id[g * G + q] * d + c];
-        };
-        auto eat = [&](i32 g, const double (&x)[G]) {
+            for (int q = 0; q < NB * SB; q++) {
+                const i64 v = srows[j + q];
+                wv[q] = vw[v];
+                xv[q] = Xr[v * d + c];
+            }
 #pragma unroll
-            for (int b = 0; b < G / SB; b++) {
+            for (int b = 0; b < NB; b++) {
 #pragma unroll
                 for (int q = 0; q < SB; q++) {
-                    const double w = s_w[g * G + b * SB + q], xv = x[b * SB + q];
-                    run_ss += w * (xv * xv);
-                    run_s += w * xv;
-                    run_w += w;
+                    run_ss += wv[b * SB + q] * (xv[b * SB + q] * xv[b * SB + q]);
+                    run_s += wv[b * SB + q] * xv[b * SB + q];
+                    run_w += wv[b * SB + q];
                 }
-                double *sl = slots + ((i64)g * (G / SB) + b) * W;
-                sl[c] = run_ss;
-                sl[d + c] = run_s;
-                if (c == 0) sl[2 * d] = run_w;
-            }
-        };
-        if (nfull > 0) fetch(0, xa);
-        if (nfull > 1) fetch(1, xb);
-        for (i32 g = 0; g < nfull; g += 2) {
-            eat(g, xa);
-            if (g + 2 < nfull) fetch(g + 2, xa);
-            if (g + 1 < nfull) {
-                eat(g + 1, xb);
-                if (g + 3 < nfull) fetch(g + 3, xb);
+                slots[(bi + b) * W + c] = run_ss;
+                slots[(bi + b) * W + d + c] = run_s;
+                if (c == 0) slots[(bi + b) * W + 2 * d] = run_w;
             }
         }
-        i32 j = nfull * G;
-        i64 bi = (i64)nfull * (G / SB);
-        for (; j + SB - 1 < n; j += SB, bi++) { // (at most one block)
-            double xv[SB];
-#pragma unroll
-            for (int q = 0; q < SB; q++) xv[q] = Xr[(i64)s_id[j + q] * d + c];
+        for (; j + SB - 1 < end; j += SB, bi++) { // SB rows in flight
+            double xv[SB], wv[SB];
 #pragma unroll
             for (int q = 0; q < SB; q++) {
-                const double w = s_w[j + q];
-                run_ss += w * (xv[q] * xv[q]);
-                run_s += w * xv[q];
-                run_w += w;
+                const i64 v = srows[j + q];
+                wv[q] = vw[v];
+                xv[q] = Xr[v * d + c];
+            }
+#pragma unroll
+            for (int q = 0; q < SB; q++) {
+                run_ss += wv[q] * (xv[q] * xv[q]);
+                run_s += wv[q] * xv[q];
+                run_w += wv[q];
             }
             slots[bi * W + c] = run_ss;
             slots[bi * W + d + c] = run_s;
             if (c == 0) slots[bi * W + 2 * d] = run_w;
         }
-        for (; j < n; j++) {
-            const double w = s_w[j], xv = Xr[(i64)s_id[j] * d + c];
+        for (; j < end; j++) {
+            const i64 v = srows[j];
+            const double w = vw[v], xv = Xr[v * d + c];
             run_ss += w * (xv * xv);
             run_s += w * xv;
             run_w += w;
