@@ -2742,28 +2742,53 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
         }
         __builtin_amdgcn_wave_barrier();
         unsigned long long swp0 = 0ULL, swp1 = 0ULL; // pivot flags, d <= 128 (lane 0)
+        // The three recurrences below run in lane 0 over values in LDS.  Written step by step (load, compute, store), every step
+        // waited for its own LDS round trip: the stores of step i may alias the loads of step i + 1 as far as the compiler can
+        // tell.  So the operands of EB steps are read in one batch, the steps run on registers with selects instead of branches
+        // (the same operations on the same values: the same bits), and the results are stored behind them.
+        constexpr int EB = 8;
         if (lane == 0) { // LU with partial pivoting of the shifted tridiagonal matrix
             double di = dd[0], ui = du[0];
-            for (int i = 0; i + 1 < d; i++) {
-                const double li = dl[i], dn = dd[i + 1], un = du[i + 1];
-                if (fabs(di) >= fabs(li)) {
-                    if (di == 0.0) di = tiny;
-                    const double f = li * fast_rcp(di);
-                    dd[i] = di;
-                    dl[i] = f;
-                    du[i] = ui;
-                    di = dn - f * ui;
-                    ui = un;
-                } else {
-                    const double f = di * fast_rcp(li);
-                    dd[i] = li;
-                    dl[i] = f;
-                    du[i] = dn;
-                    di = ui - f * dn;
-                    if (i + 2 < d) du2[i] = un;
-                    ui = -f * un;
-                    if (i < 64) swp0 |= 1ULL << i; else swp1 |= 1ULL << (i - 64);
+            auto lu_step = [&](int i, double li, double dn, double un, double &o_dd, double &o_dl, double &o_du, double &o_du2,
+                               bool &o_sw) {
+                const bool keep = fabs(di) >= fabs(li); // no row swap
+                const double den = keep ? (di == 0.0 ? tiny : di) : li, num = keep ? li : di;
+                const double f = num * fast_rcp(den);
+                o_dd = den;
+                o_dl = f;
+                o_du = keep ? ui : dn;
+                const double ya = keep ? dn : ui, yb = keep ? ui : dn;
+                di = ya - f * yb;
+                const double fu = f * un;
+                ui = keep ? un : -fu;
+                o_du2 = un;
+                o_sw = !keep;
+                if (!keep) { if (i < 64) swp0 |= 1ULL << i; else swp1 |= 1ULL << (i - 64); }
+            };
+            int i = 0;
+            for (; i + EB < d; i += EB) { // steps i .. i + EB - 1 (all of them have i + 1 < d)
+                double li[EB], dn[EB], un[EB], odd[EB], odl[EB], odu[EB], odu2[EB];
+                bool osw[EB];
+#pragma unroll
+                for (int q = 0; q < EB; q++) { li[q] = dl[i + q]; dn[q] = dd[i + q + 1]; un[q] = du[i + q + 1]; }
+#pragma unroll
+                for (int q = 0; q < EB; q++) lu_step(i + q, li[q], dn[q], un[q], odd[q], odl[q], odu[q], odu2[q], osw[q]);
+#pragma unroll
+                for (int q = 0; q < EB; q++) {
+                    dd[i + q] = odd[q];
+                    dl[i + q] = odl[q];
+                    du[i + q] = odu[q];
+                    if (osw[q] && i + q + 2 < d) du2[i + q] = odu2[q];
                 }
+            }
+            for (; i + 1 < d; i++) {
+                double o_dd, o_dl, o_du, o_du2;
+                bool o_sw;
+                lu_step(i, dl[i], dd[i + 1], du[i + 1], o_dd, o_dl, o_du, o_du2, o_sw);
+                dd[i] = o_dd;
+                dl[i] = o_dl;
+                du[i] = o_du;
+                if (o_sw && i + 2 < d) du2[i] = o_du2;
             }
             if (di == 0.0) di = tiny;
             dd[d - 1] = di;
@@ -2778,17 +2803,47 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
         for (int it = 0; it < 3; it++) {
             if (lane == 0) {
                 double yi = y[0];
-                for (int i = 0; i + 1 < d; i++) { // forward: L with the recorded row swaps
+                auto fw_step = [&](int i, double yn, double li, double &o_y) { // forward: L with the recorded row swaps
                     const bool sw = (i < 64) ? ((swp0 >> i) & 1ULL) : ((swp1 >> (i - 64)) & 1ULL);
-                    const double yn = y[i + 1], li = dl[i];
-                    y[i] = sw ? yn : yi;
-                    yi = sw ? yi - li * yn : yn - li * yi;
+                    o_y = sw ? yn : yi;
+                    const double ya = sw ? yi : yn, yb = sw ? yn : yi;
+                    yi = ya - li * yb;
+                };
+                int i = 0;
+                for (; i + EB < d; i += EB) {
+                    double yn[EB], li[EB], oy[EB];
+#pragma unroll
+                    for (int q = 0; q < EB; q++) { yn[q] = y[i + q + 1]; li[q] = dl[i + q]; }
+#pragma unroll
+                    for (int q = 0; q < EB; q++) fw_step(i + q, yn[q], li[q], oy[q]);
+#pragma unroll
+                    for (int q = 0; q < EB; q++) y[i + q] = oy[q];
+                }
+                for (; i + 1 < d; i++) {
+                    double oy;
+                    fw_step(i, y[i + 1], dl[i], oy);
+                    y[i] = oy;
                 }
                 double y1 = yi * dd[d - 1]; // backward: U with two super-diagonals
                 y[d - 1] = y1;
                 double y0 = (y[d - 2] - du[d - 2] * y1) * dd[d - 2];
                 y[d - 2] = y0;
-                for (int i = d - 3; i >= 0; i--) {
+                i = d - 3;
+                for (; i - (EB - 1) >= 0; i -= EB) { // steps i, i - 1, .., i - EB + 1
+                    double yy[EB], uu[EB], u2[EB], pv[EB], ot[EB];
+#pragma unroll
+                    for (int q = 0; q < EB; q++) { yy[q] = y[i - q]; uu[q] = du[i - q]; u2[q] = du2[i - q]; pv[q] = dd[i - q]; }
+#pragma unroll
+                    for (int q = 0; q < EB; q++) {
+                        const double t = (yy[q] - uu[q] * y0 - u2[q] * y1) * pv[q];
+                        ot[q] = t;
+                        y1 = y0;
+                        y0 = t;
+                    }
+#pragma unroll
+                    for (int q = 0; q < EB; q++) y[i - q] = ot[q];
+                }
+                for (; i >= 0; i--) {
                     const double t = (y[i] - du[i] * y0 - du2[i] * y1) * dd[i];
                     y[i] = t;
                     y1 = y0;
