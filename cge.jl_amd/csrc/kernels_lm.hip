@@ -6,6 +6,7 @@
 //   landmark aggregation                : src/landmarks.jl:387-430
 //   per-edge scatter                    : src/landmarks.jl:433-451, src/divergence.jl:59-63, :337-345
 #include "common.hpp"
+#include <type_traits>
 #include "mfma_tile.hpp"
 
 #define WAVE 64
@@ -2384,27 +2385,28 @@ __device__ __forceinline__ void dpp_fence(double (&v)[NG]) { // VALU write -> DP
     if constexpr (NG == 1) asm volatile("s_nop 1" : "+v"(v[0]));
     else asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[NG - 1]));
 }
-// the column loops of a Householder step with compile-time column numbers (the DPP lane is an immediate)
-template <int JJ, int NR, int NC>
+// the column loops of a Householder step with compile-time column numbers (the DPP lane is an immediate); R0 = the first
+// row block that still has live rows (the blocks above it hold finished rows only: u = w = 0 there, nothing would change)
+template <int JJ, int NR, int NC, int R0 = 0>
 struct EigCols {
     static constexpr int NG = (NC + 15) / 16;
     static __device__ __forceinline__ void matvec(double (&s)[NR], const double (&a)[NR][NC], const double (&uc)[NG]) {
 #pragma unroll
-        for (int r = 0; r < NR; r++) fmac_bcast<JJ % 16>(s[r], uc[JJ / 16], a[r][JJ]);
-        EigCols<JJ + 1, NR, NC>::matvec(s, a, uc);
+        for (int r = R0; r < NR; r++) fmac_bcast<JJ % 16>(s[r], uc[JJ / 16], a[r][JJ]);
+        EigCols<JJ + 1, NR, NC, R0>::matvec(s, a, uc);
     }
     static __device__ __forceinline__ void rank2(double (&a)[NR][NC], const double (&uc)[NG], const double (&wc)[NG],
                                                  const double (&nu)[NR], const double (&nw)[NR]) {
 #pragma unroll
-        for (int r = 0; r < NR; r++) {
+        for (int r = R0; r < NR; r++) {
             fmac_bcast<JJ % 16>(a[r][JJ], uc[JJ / 16], nw[r]); // a - w_r u_j
             fmac_bcast<JJ % 16>(a[r][JJ], wc[JJ / 16], nu[r]); //   - u_r w_j
         }
-        EigCols<JJ + 1, NR, NC>::rank2(a, uc, wc, nu, nw);
+        EigCols<JJ + 1, NR, NC, R0>::rank2(a, uc, wc, nu, nw);
     }
 };
-template <int NR, int NC>
-struct EigCols<NC, NR, NC> {
+template <int NR, int NC, int R0>
+struct EigCols<NC, NR, NC, R0> {
     static constexpr int NG = (NC + 15) / 16;
     static __device__ __forceinline__ void matvec(double (&)[NR], const double (&)[NR][NC], const double (&)[NG]) {}
     static __device__ __forceinline__ void rank2(double (&)[NR][NC], const double (&)[NG], const double (&)[NG], const double (&)[NR],
@@ -2441,22 +2443,25 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
     // symmetric up to the rounding of the two fused updates, which is the rounding level of the method itself)
     // because a row is spread over the waves' static column slots -- no dynamic register indexing.  Readers mask
     // the part left of the sub-diagonal themselves.
-    auto extract = [&](int kn) {
+    // RB (compile-time) = the row block of kn.  Chosen at run time inside one routine, the compiler turned the choice into 64
+    // selects feeding 16 stores through the same four registers: 1500 cycles per step, a third of the tridiagonalisation.
+    auto extract = [&](int kn, auto rbc) {
+        constexpr int RB = decltype(rbc)::value;
         if (lane == (kn & 63)) {
-            if (NR > 1 && kn >= 64) {
 #pragma unroll
-                for (int jj = 0; jj < NC; jj++) X[NC * wv + jj] = a[NR - 1][jj];
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < NC; jj++) X[NC * wv + jj] = a[0][jj];
-            }
+            for (int jj = 0; jj < NC; jj++) X[NC * wv + jj] = a[RB][jj];
         }
     };
+    using RBlk0 = std::integral_constant<int, 0>;
+    using RBlkL = std::integral_constant<int, NR - 1>;
     if (tid < DP) { beta[tid] = 0.0; off[tid] = 0.0; V0[tid] = 0.0; X[tid] = 0.0; }
     __syncthreads();
-    extract(0);
+    extract(0, RBlk0{});
     // ---- tridiagonalisation ------------------------------------------------------------------------
-    for (int k = 0; k + 2 < d; k++) {
+    // One Householder step; R0 (compile-time) = the first row block with live rows: once k has passed row 63 the upper block
+    // of a 128-row matrix is finished and the two O(d^2) loops skip it (exact: u = w = 0 there).
+    auto hh_step = [&](const int k, auto r0c) {
+        constexpr int R0 = decltype(r0c)::value;
         __syncthreads(); // (a) X, diag of column k are visible; U, W, Pp of the previous step are dead
         const int o = k + 1;
         double x[NR], u[NR];
@@ -2516,14 +2521,14 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
 #pragma unroll
             for (int r = 0; r < NR; r++) s[r] = 0.0;
             if (DPPF) {
-                if (live) EigCols<0, NR, NC>::matvec(s, a, uc);
+                if (live) EigCols<0, NR, NC, R0>::matvec(s, a, uc);
             } else if (live) {
 #pragma unroll
                 for (int jj = 0; jj < NC; jj++) {
                     if (jj % 8 == 0) asm volatile("" ::: "memory"); // at most 8 broadcast reads in flight (registers)
                     const double uj = U[NC * wv + jj];
 #pragma unroll
-                    for (int r = 0; r < NR; r++) s[r] = fma(a[r][jj], uj, s[r]);
+                    for (int r = R0; r < NR; r++) s[r] = fma(a[r][jj], uj, s[r]);
                 }
             }
 #pragma unroll
@@ -2557,7 +2562,7 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
 #pragma unroll
                 for (int r = 0; r < NR; r++) { nu[r] = -u[r]; nw[r] = -w[r]; }
                 dpp_fence(wc);
-                EigCols<0, NR, NC>::rank2(a, uc, wc, nu, nw);
+                EigCols<0, NR, NC, R0>::rank2(a, uc, wc, nu, nw);
             }
         } else if (diag_stage != 10) { // rank-2 update; waves whose columns are all finished run it too (u = w = 0 there: nothing changes)
 #pragma unroll
@@ -2565,15 +2570,25 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
                 if (jj % 8 == 0) asm volatile("" ::: "memory");
                 const double uj = U[NC * wv + jj], wj = W[NC * wv + jj];
 #pragma unroll
-                for (int r = 0; r < NR; r++) a[r][jj] = fma(-u[r], wj, fma(-w[r], uj, a[r][jj]));
+                for (int r = R0; r < NR; r++) a[r][jj] = fma(-u[r], wj, fma(-w[r], uj, a[r][jj]));
             }
         }
-        extract(k + 1);
+        extract(k + 1, r0c); // row k + 1 lies in block R0 (k + 1 < 64 in the first loop below, >= 64 in the second)
+    };
+    {
+        int k = 0;
+        if constexpr (NR > 1) {
+            for (; k + 2 < d && k + 1 < 64; k++) hh_step(k, RBlk0{});
+            for (; k + 2 < d; k++) hh_step(k, RBlkL{});
+        } else {
+            for (; k + 2 < d; k++) hh_step(k, RBlk0{});
+        }
     }
     __syncthreads();
     if (tid == 0) { diag[d - 2] = X[d - 2]; off[d - 2] = X[d - 1]; } // row d-2 was the last one published
     __syncthreads();
-    extract(d - 1);
+    if (NR > 1 && d - 1 >= 64) extract(d - 1, RBlkL{});
+    else extract(d - 1, RBlk0{});
     __syncthreads();
     if (tid == 0) diag[d - 1] = X[d - 1];
     __syncthreads();
