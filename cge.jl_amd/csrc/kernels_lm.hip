@@ -2412,6 +2412,26 @@ struct EigCols<NC, NR, NC, R0> {
     static __device__ __forceinline__ void rank2(double (&)[NR][NC], const double (&)[NG], const double (&)[NG], const double (&)[NR],
                                                  const double (&)[NR]) {}
 };
+// v[r] = a[r][jj] for a run-time column slot jj (uniform): a switch, so that the register block stays in registers
+template <int NR, int NC>
+__device__ __forceinline__ void eig_pick_column(const double (&a)[NR][NC], int jj, double (&v)[NR]) {
+#define EP_CASE(J)                                                                                                          \
+    case J:                                                                                                                 \
+        if constexpr (J < NC) {                                                                                             \
+            _Pragma("unroll") for (int r = 0; r < NR; r++) v[r] = a[r][J];                                                  \
+        }                                                                                                                   \
+        break;
+#pragma unroll
+    for (int r = 0; r < NR; r++) v[r] = 0.0;
+    switch (jj) {
+        EP_CASE(0) EP_CASE(1) EP_CASE(2) EP_CASE(3) EP_CASE(4) EP_CASE(5) EP_CASE(6) EP_CASE(7)
+        EP_CASE(8) EP_CASE(9) EP_CASE(10) EP_CASE(11) EP_CASE(12) EP_CASE(13) EP_CASE(14) EP_CASE(15)
+        EP_CASE(16) EP_CASE(17) EP_CASE(18) EP_CASE(19) EP_CASE(20) EP_CASE(21) EP_CASE(22) EP_CASE(23)
+        EP_CASE(24) EP_CASE(25) EP_CASE(26) EP_CASE(27) EP_CASE(28) EP_CASE(29) EP_CASE(30) EP_CASE(31)
+    default: break;
+    }
+#undef EP_CASE
+}
 // DPPF: the two O(d^2) loops of a step take u_j / w_j as DPP broadcasts from registers that hold the wave's column values
 // (read from LDS once per step: NC / 16 reads instead of NC) -- and u's column values come from the published row itself, so
 // the matrix-vector product no longer waits for the reflector's square root and divisions (only the column next to the
@@ -2439,17 +2459,18 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             a[r][jj] = (row < d && col < d) ? src[(size_t)col * d + row] : 0.0; // symmetric: coalesced along rows
         }
     }
-    // publish row kn of the matrix: X[col] = A[kn][col].  Row kn is read instead of column kn (the matrix is
-    // symmetric up to the rounding of the two fused updates, which is the rounding level of the method itself)
-    // because a row is spread over the waves' static column slots -- no dynamic register indexing.  Readers mask
-    // the part left of the sub-diagonal themselves.
-    // RB (compile-time) = the row block of kn.  Chosen at run time inside one routine, the compiler turned the choice into 64
-    // selects feeding 16 stores through the same four registers: 1500 cycles per step, a third of the tridiagonalisation.
-    auto extract = [&](int kn, auto rbc) {
-        constexpr int RB = decltype(rbc)::value;
-        if (lane == (kn & 63)) {
+    // publish COLUMN kn of the matrix: X[row] = A[row][kn], two full-wave stores by the wave that owns the column (the register
+    // is picked by a switch on the column's slot: scalar branches).  Rounds 1-4 published ROW kn instead -- a row is spread
+    // over the waves' static column slots, no switch -- but a row sits in ONE lane: 16 single-lane 16-byte stores per wave,
+    // 64 LDS instructions per step through the CU's one LDS pipeline, ~1000 cycles of every step (CGE_EIG_CLOCK).  The
+    // matrix is symmetric up to the rounding of the two fused updates (the rounding level of the method itself), so the
+    // column differs from the row in the last bits only; readers mask the part above the sub-diagonal themselves.
+    auto extract = [&](int kn, auto) {
+        if (wv == kn / NC) { // uniform
+            double v[NR];
+            eig_pick_column<NR, NC>(a, kn % NC, v);
 #pragma unroll
-            for (int jj = 0; jj < NC; jj++) X[NC * wv + jj] = a[RB][jj];
+            for (int r = 0; r < NR; r++) X[lane + 64 * r] = v[r];
         }
     };
     using RBlk0 = std::integral_constant<int, 0>;
@@ -2457,12 +2478,25 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
     if (tid < DP) { beta[tid] = 0.0; off[tid] = 0.0; V0[tid] = 0.0; X[tid] = 0.0; }
     __syncthreads();
     extract(0, RBlk0{});
+    // CGE_EIG_CLOCK (a build flag, diagnostics only): s_memtime stamps around the sections of a step, summed over the steps and
+    // printed by waves 0 and 3 of the first matrix (the stamps wait for the LDS queue: shares, not absolute times)
+#ifdef CGE_EIG_CLOCK
+    unsigned long long ck_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = __builtin_amdgcn_s_memtime();
+#define CK(j) { const unsigned long long ck_n = __builtin_amdgcn_s_memtime(); ck_acc[j] += ck_n - ck_t; ck_t = ck_n; }
+#else
+#define CK(j)
+#endif
     // ---- tridiagonalisation ------------------------------------------------------------------------
     // One Householder step; R0 (compile-time) = the first row block with live rows: once k has passed row 63 the upper block
     // of a 128-row matrix is finished and the two O(d^2) loops skip it (exact: u = w = 0 there).
     auto hh_step = [&](const int k, auto r0c) {
         constexpr int R0 = decltype(r0c)::value;
+        // The owner's store of column k has LANDED before anybody passes the barrier: spelled out, because the compiler leaves
+        // the wait out of the loop's back edge (the store sits in a conditional block in front of it) and the readers then
+        // see the previous column now and then -- found as run-to-run differences of the landmark pipeline.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads(); // (a) X, diag of column k are visible; U, W, Pp of the previous step are dead
+        CK(0)
         const int o = k + 1;
         double x[NR], u[NR];
         double part = 0.0;
@@ -2484,6 +2518,7 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
         const double alpha = X[o];
         if (tid == 0) diag[k] = X[k];
         const double sigma = wave_allsum(part);
+        CK(1)
         // sigma == 0: no reflection at this step.  It runs through the same code with u = w = 0 (the update then
         // leaves every register bit as it is) -- a branch around the update would make the compiler keep two copies
         // of the matrix block.
@@ -2501,6 +2536,7 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
         }
         const double v0 = refl ? v0r : 0.0;
         const double bp = refl ? bpr : 0.0; // H = I - bp u u^T, u = (v0, x[o+1..])
+        CK(2)
         if (tid == 0) { beta[k] = bp; off[k] = refl ? mu : alpha; V0[k] = v0; }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -2534,7 +2570,9 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
 #pragma unroll
             for (int r = 0; r < NR; r++) Pp[wv][lane + 64 * r] = s[r];
         }
+        CK(3)
         __syncthreads(); // (b)
+        CK(4)
         double w[NR];
         part = 0.0;
 #pragma unroll
@@ -2551,6 +2589,7 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             W[row] = w[r];
         }
         __builtin_amdgcn_wave_barrier();
+        CK(5)
         if (DPPF) {
             if (diag_stage != 10) {
                 double nu[NR], nw[NR];
@@ -2573,7 +2612,9 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
                 for (int r = R0; r < NR; r++) a[r][jj] = fma(-u[r], wj, fma(-w[r], uj, a[r][jj]));
             }
         }
+        CK(6)
         extract(k + 1, r0c); // row k + 1 lies in block R0 (k + 1 < 64 in the first loop below, >= 64 in the second)
+        CK(7)
     };
     {
         int k = 0;
@@ -2584,8 +2625,13 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             for (; k + 2 < d; k++) hh_step(k, RBlk0{});
         }
     }
+#ifdef CGE_EIG_CLOCK
+    if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 3))
+        printf("eig clock wave %d: barrier_a %llu  reads+sigma %llu  sqrt/div %llu  matvec+Pp %llu  barrier_b %llu  w %llu  rank2 %llu  extract %llu (s_memtime ticks over %d steps)\n",
+               wv, ck_acc[0], ck_acc[1], ck_acc[2], ck_acc[3], ck_acc[4], ck_acc[5], ck_acc[6], ck_acc[7], d - 2);
+#endif
     __syncthreads();
-    if (tid == 0) { diag[d - 2] = X[d - 2]; off[d - 2] = X[d - 1]; } // row d-2 was the last one published
+    if (tid == 0) { diag[d - 2] = X[d - 2]; off[d - 2] = X[d - 1]; } // column d-2 was the last one published
     __syncthreads();
     if (NR > 1 && d - 1 >= 64) extract(d - 1, RBlkL{});
     else extract(d - 1, RBlk0{});
