@@ -55,7 +55,8 @@ def scan(path):
     flush()
     return out
 
-for f in sys.argv[1:]:
-    for kern, ln in scan(f):
-        if 'rocprim' in kern: continue
-        print(f.split('/')[-1], kern[:80], 'line', ln)
+if __name__ == "__main__":
+    for f in sys.argv[1:]:
+        for kern, ln in scan(f):
+            if 'rocprim' in kern: continue
+            print(f.split('/')[-1], kern[:80], 'line', ln)
