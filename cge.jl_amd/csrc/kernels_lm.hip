@@ -1564,7 +1564,7 @@ __global__ __launch_bounds__(64 * NW) void rss2_chain_lds_kernel(const double *_
     double *xs = r2lds + NW * R2_BR * 65;                                               // [NB][RR][XW]
     double *wsh = xs + NB * RR * XW;                                                    // [NB][RR]
     const i64 t = blockIdx.x;
-    const int dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
     const i32 *p = srows + o;
     const i64 nblk = (k + R2_BR - 1) / R2_BR, nround = (nblk + NW - 1) / NW, slot0 = o / R2_BR + t;
@@ -2442,7 +2442,7 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
     constexpr int DP = 64 * NR; // padded dimension (rows held); 4*NC >= d columns held
     __shared__ __attribute__((aligned(16))) double X[DP], U[DP], W[DP], Pp[4][DP], V[DP];
     __shared__ __attribute__((aligned(16))) double diag[DP], off[DP], beta[DP], V0[DP], tri[4 * DP], red[32];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (the wave's number as a scalar)
     const double *src = cov + (size_t)blockIdx.x * d * d;
     double *out = vec + (size_t)blockIdx.x * d;
     if (d == 1) {
