@@ -1628,6 +1628,13 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "landmark_batches")) *value = c->stat_lm_batches;
     else if (!strcmp(key, "landmark_batch_rows")) *value = c->stat_lm_rows;
     else if (!strcmp(key, "landmark_splits")) *value = c->stat_lm_splits;
+    else if (!strcmp(key, "cut_tie_tasks")) { // (read from the device on request: a synchronising copy)
+        int v = 0;
+        if (c->cut_ties.p && (hipStreamSynchronize(c->stream) != hipSuccess ||
+                              hipMemcpy(&v, c->cut_ties.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess))
+            return CGE_E_HIP;
+        *value = v;
+    }
     else if (!strcmp(key, "covariances_derived")) *value = c->stat_cov_derived; // sibling pairs derived from the parent's matrix
     else if (!strcmp(key, "edge_layout_build_us")) *value = c->stat_layout_build_us;
     else if (!strcmp(key, "edge_chunks")) *value = c->be_nchunks;

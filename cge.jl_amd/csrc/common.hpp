@@ -379,6 +379,7 @@ struct cge_ctx {
     int opt_fit_test_delay = 0;   // testing: the tile waves of the data-as-signal fits nap this many times (~3 us each) before
                                   // their first load -- start skew, as under contention; results must not change
     i64 stat_lm_batches = 0, stat_lm_rows = 0, stat_lm_splits = 0; // last runsplit: device batches, their rows, groups split
+    DevBuf<int> cut_ties;                                          // last runsplit: tasks of the cut rules with a row ON the cut (device counter)
     i64 stat_cov_derived = 0; // ... sibling pairs whose covariances were derived from the parent's
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
@@ -604,7 +605,8 @@ void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *
 void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
                  i32 *meta, double *vals, double *cmeans);
 void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
-                 unsigned char *side, i32 *nlow_out = nullptr); // nlow_out: rows of the low side per task (replaces k_side_counts)
+                 unsigned char *side, i32 *nlow_out = nullptr, // nlow_out: rows of the low side per task (replaces k_side_counts)
+                 int *tie_tasks = nullptr);                     // tie_tasks: counts the tasks that held a row with z == cut
 void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const double *zs,
                   const i32 *task_row_off, const i32 *task_chunk_off, const double *prefix, const double *coff,
                   i64 n_tasks, i64 d, i32 *meta, i32 *rounds, double *vals, double *cmeans /* [task][2][d] */);

@@ -2183,7 +2183,8 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
 // does hold a row with z == cut is redone by its first wave with the reference's sequential rule (the code of rounds 1-3).
 __global__ __launch_bounds__(256) void cut_sides_kernel(const double *__restrict__ z, const double *__restrict__ zs,
                                                         const i32 *__restrict__ task_row_off, int use_median,
-                                                        unsigned char *__restrict__ side, i32 *__restrict__ nlow_out) {
+                                                        unsigned char *__restrict__ side, i32 *__restrict__ nlow_out,
+                                                        int *__restrict__ tie_tasks) {
     __shared__ double slo[4], shi[4];
     __shared__ int scnt[4];
     const i64 t = blockIdx.x;
@@ -2234,7 +2235,11 @@ __global__ __launch_bounds__(256) void cut_sides_kernel(const double *__restrict
             tie |= v == cut;
         }
     }
-    const int any_tie = __syncthreads_or(tie); // (also orders the provisional sides before the sequential redo)
+    // The provisional sides have been ACKNOWLEDGED by memory before the vote: the redo below rewrites rows that other waves
+    // stored, and a barrier alone orders the instructions of the waves, not the arrival of their stores (a provisional side
+    // landing behind the final one would leave `side` and the counted sizes in disagreement).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int any_tie = __syncthreads_or(tie);
     if (!any_tie) {
         for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
         if (lane == 0) scnt[wv] = cnt;
@@ -2243,6 +2248,7 @@ __global__ __launch_bounds__(256) void cut_sides_kernel(const double *__restrict
         return;
     }
     if (wv != 0) return;
+    if (lane == 0 && tie_tasks) atomicAdd(tie_tasks, 1); // (statistics: how often the sequential rule is needed)
     // a row with z == cut joins the side that is smaller at that moment of the reference's sequential pass (:229-236,
     // :255-261): one wave walks the task, the running sizes carried across 64-row chunks as ballot counts, the ties of a
     // chunk settled in lane order
@@ -2284,9 +2290,10 @@ __global__ __launch_bounds__(256) void cut_sides_kernel(const double *__restrict
     if (lane == 0 && nlow_out) nlow_out[t] = (i32)nlow;
 }
 void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
-                 unsigned char *side, i32 *nlow_out) {
+                 unsigned char *side, i32 *nlow_out, int *tie_tasks) {
     ScopedKernelTimer t(c, "cut_sides");
-    hipLaunchKernelGGL(cut_sides_kernel, dim3((unsigned)n_tasks), dim3(256), 0, c->stream, z, zs, task_row_off, use_median, side, nlow_out);
+    hipLaunchKernelGGL(cut_sides_kernel, dim3((unsigned)n_tasks), dim3(256), 0, c->stream, z, zs, task_row_off, use_median, side, nlow_out,
+                       tie_tasks);
 }
 
 // Side flags of one rss round, derived on the device (no per-round row-sized upload).  Per task t,

@@ -836,7 +836,8 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
                            c->sp_srows.p, c->sp_status.p, B.max_len);
     }
     c->ls_nlow.ensure(T);
-    k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p, c->ls_nlow.p);
+    k_cut_sides(c, c->ls_z.p, use_median ? c->sp_zs.p : nullptr, c->sp_tro.p, T, use_median ? 1 : 0, c->ls_side.p, c->ls_nlow.p,
+                root_of(c)->cut_ties.p);
     c->pin_res.ensure((size_t)T); // pinned: the copies do not stall the host, the event below covers them
     HIP_CHECK(hipMemcpyAsync(c->pin_res.p, c->ls_nlow.p, sizeof(i32) * T, hipMemcpyDeviceToHost, st));
     k_group_side_sums(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_side.p, c->ls_cb.p, c->ls_ce.p, B.NC, c->ls_tco.p, B.T, d,
@@ -1528,6 +1529,8 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     c->lm_means_used = 0;
     c->lm_covs_used = 0;
     c->stat_lm_batches = c->stat_lm_rows = c->stat_lm_splits = c->stat_cov_derived = 0;
+    c->cut_ties.ensure(1);
+    HIP_CHECK(hipMemsetAsync(c->cut_ties.p, 0, sizeof(int), c->stream));
     // option shard_rows: cl_owner[q] = the rank that holds cluster q's rows (the owner of its first member's community; a
     // cluster has to lie inside one rank's rows), a_off[q] = where an OWNED cluster starts in this rank's arena (local ids)
     std::vector<int> cl_owner;

@@ -301,7 +301,8 @@ int cge_set_option(cge_ctx *ctx, const char *key, int64_t value);
  * "diameter_bits" = the bit pattern of the last `hi` (reinterpret the int64 as a double);
  * "fit_persistent_alphas" = alphas of the last sweep fitted by a persistent launch, "fit_persistent_fallbacks" = persistent fits abandoned since the context was created, "fit_iterations" = Chung-Lu
  * iterations of the last sweep (all alphas); "landmark_batches" / "landmark_batch_rows" / "landmark_splits" =
- * device batches of the last runsplit, the rows they covered, the groups they split;
+ * device batches of the last runsplit, the rows they covered, the groups they split; "cut_tie_tasks" = groups of the size / diameter rules
+ * of the last runsplit that held a row exactly ON the cut (settled by the reference's sequential rule; read from the device: synchronises);
  * "edges_resident" / "edges_total" (option shard_ingest), "rows_resident" / "rows_total" (option shard_rows: the embedding rows this
  * rank holds -- about n / W -- and n), "embedding_words_resident" (doubles of the resident row matrix)   */
 int cge_get_stat(cge_ctx *ctx, const char *key, int64_t *value);
