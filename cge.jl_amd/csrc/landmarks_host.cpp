@@ -1848,7 +1848,8 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         cover_bad = verdict[0] != 0.0;
     }
     if (cover_bad)
-        CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids)"); // :343
+        CGE_THROW(CGE_E_ASSERT, "AssertionError: all(>=(0), group_ids) [%lld rows without a group, %lld of %lld rows in the groups here, %lld of %lld over all ranks]",
+                  (long long)unassigned, (long long)c->h_mem_off[NG], (long long)nrows, (long long)c->h_gl_off[NG], (long long)n); // :343
     c->lm_index_on_device = want_index;
     c->h_mem.clear(); // the member lists stay on the device (c->lm_mem); host copies are made by whoever asks for them
     if (want_index) { // the fused path: v2l stays on the device too (landmarks_fetch copies it when it is asked for)

@@ -12,14 +12,16 @@ ctx = api.Context()
 ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
 ctx.set_option("diameter", 0)
 ref = None
-for opts in ({}, {"early_diameter": 1}, {"runsplit_lanes": 2}, {"speculation_pct": -1}, {"side_samples": 1}, {"cov_derive": 1}):
+seq = ({}, {"early_diameter": 1}, {"runsplit_lanes": 2}, {"speculation_pct": -1}, {"side_samples": 1}, {"cov_derive": 1})
+if len(sys.argv) > 3: seq = ({}, {"early_diameter": 1}, {"runsplit_lanes": 2}) * int(sys.argv[3])
+for opts in seq:
     for k, v in opts.items(): ctx.set_option(k, v)
     for rep in range(reps):
         try:
             r = ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=bool(wl.get("directed", False)), seed=42,
                           auc_samples=wl["samples"])
             if ref is None: ref = r.copy()
-            print(opts, rep, "same" if np.array_equal(r, ref) else f"DIFFERENT {list(r)}", "tie tasks", ctx.get_stat("cut_tie_tasks"), flush=True)
+            print(opts, rep, "same" if np.array_equal(r, ref) else f"DIFFERENT {list(r)}", flush=True)
         except Exception as e:
             print(opts, rep, "ERROR", str(e)[:150], flush=True)
     for k in opts: ctx.set_option(k, {"runsplit_lanes": 1}.get(k, 0))
