@@ -151,6 +151,7 @@ void cge_destroy(cge_ctx *c) {
     c->event_pool.clear();
     if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->members_ev) (void)hipEventDestroy(c->members_ev);
     if (c->fitdone_ev) (void)hipEventDestroy(c->fitdone_ev);
     for (int i = 0; i < 2; i++) {
         if (c->sweep_ev[i]) (void)hipEventDestroy(c->sweep_ev[i]);

@@ -476,6 +476,8 @@ struct cge_ctx {
     cge_ctx *side = nullptr;
     cge_ctx *lane = nullptr; // second lane of runsplit's batches (landmarks_host.cpp): normal priority, borrows the arenas too
     cge_ctx *root = nullptr; // shadow contexts: the context they belong to
+    hipEvent_t members_ev = nullptr; // runsplit, two lanes: behind the last children's member lists this context's stream wrote
+    bool members_ev_set = false;     // (the other lane's next batch reads them from the arena: it waits for this event)
     bool is_side = false;
     int opt_lanes = 1;       // runsplit: 2 = every batch as two half-batches on two streams, half a chain out of phase; 1 (default) = one
                              // stream.  Measured (profiles/r03_lanes_ab.txt): the eigen-solver of a half batch takes as long as that of

@@ -86,6 +86,20 @@ inline void refresh_arena_views(cge_ctx *x) {
     x->lm_means.borrow(c->lm_means);
     x->lm_covs.borrow(c->lm_covs);
 }
+// Two lanes: the children's member lists (and means) of a half batch are written to the arena by ITS lane's stream, behind the
+// event the host waits for -- and the next round deals the groups afresh, so a lane may read what the other lane wrote.  Each
+// lane records an event behind its writes and every reader's stream waits for the other lane's event first.  (Without it the
+// other lane's gather could overtake the list it reads: rows covered twice and rows covered by no group, now and then.)
+inline void members_written(cge_ctx *x) {
+    if (!x->members_ev) HIP_CHECK(hipEventCreateWithFlags(&x->members_ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(x->members_ev, x->stream));
+    x->members_ev_set = true;
+}
+inline void wait_for_other_lanes(cge_ctx *x) { // x's stream: behind the member lists the other lane (or the root) has in flight
+    cge_ctx *c = root_of(x);
+    for (cge_ctx *o : {c, c->lane})
+        if (o && o != x && o->members_ev_set) HIP_CHECK(hipStreamWaitEvent(x->stream, o->members_ev, 0));
+}
 // Growth copies the arena into a larger allocation: everything that may still read or write the old one has to be done.
 template <typename T>
 void arena_grow(cge_ctx *c, DevBuf<T> &buf, i64 used, i64 need) {
@@ -955,6 +969,7 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
     hipStream_t st = c->stream;
     Batch &B = L.B;
     refresh_arena_views(c);
+    wait_for_other_lanes(c);
     bool have_means = true; // known from the parents' splits: gathered from the means arena, no pass over the rows
     for (i64 t = 0; t < T && have_means; t++) have_means = L.groups[t]->mean_off >= 0;
     {
@@ -1058,6 +1073,7 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
     if (L.method == CGE_METHOD_RSS) rule_rss_sorted_enqueue(L);
     else if (L.method == CGE_METHOD_RSS2) rule_rss2_enqueue(L);
     else rule_cut_enqueue(L, L.method == CGE_METHOD_SIZE);
+    if (root->lane) members_written(c); // (a second lane exists: it may read these lists next round)
 }
 // ... and book the results when they have arrived
 void lane_collect(LaneRun &L) {
@@ -1160,6 +1176,7 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
         lane_enqueue(L[0], two ? c->copy_ev : nullptr, nullptr);
         if (two) lane_enqueue(L[1], nullptr, c->copy_ev);
         for (int q = 0; q < nl; q++) lane_collect(L[q]);
+        if (two) wait_for_other_lanes(c); // whatever runs on the root's stream next (a one-lane batch, the final index) reads the lane's lists
     }
 }
 
