@@ -1578,6 +1578,11 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_cov_derive = value != 0;
         return CGE_OK;
     }
+    if (!strcmp(key, "runsplit_lanes_test_delay")) { // testing: the second lane writes its children's member lists ~4 us x value late
+        if (value < 0 || value > 100000) return CGE_E_ARG;
+        c->opt_lanes_test_delay = (int)value;
+        return CGE_OK;
+    }
     if (!strcmp(key, "runsplit_lanes")) { // 2: the batches of runsplit run as two half-batches on two streams, out of phase; 1 (default): one stream
         if (value < 1 || value > 2) return CGE_E_ARG;
         c->opt_lanes = (int)value;

@@ -479,6 +479,7 @@ struct cge_ctx {
     hipEvent_t members_ev = nullptr; // runsplit, two lanes: behind the last children's member lists this context's stream wrote
     bool members_ev_set = false;     // (the other lane's next batch reads them from the arena: it waits for this event)
     bool is_side = false;
+    int opt_lanes_test_delay = 0; // testing: the second lane's member lists land this many naps (~4 us each) late
     int opt_lanes = 1;       // runsplit: 2 = every batch as two half-batches on two streams, half a chain out of phase; 1 (default) = one
                              // stream.  Measured (profiles/r03_lanes_ab.txt): the eigen-solver of a half batch takes as long as that of
                              // a whole one and the halves' kernels stretch each other: no gain on any workload
@@ -606,6 +607,7 @@ void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *
                      double *coff, double *prefix);
 void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
                  i32 *meta, double *vals, double *cmeans);
+void k_nap(cge_ctx *c, int naps); // testing: one wave that sleeps ~4 us per nap on c->stream
 void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
                  unsigned char *side, i32 *nlow_out = nullptr, // nlow_out: rows of the low side per task (replaces k_side_counts)
                  int *tie_tasks = nullptr);                     // tie_tasks: counts the tasks that held a row with z == cut

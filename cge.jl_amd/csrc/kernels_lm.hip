@@ -2289,6 +2289,13 @@ __global__ __launch_bounds__(256) void cut_sides_kernel(const double *__restrict
     }
     if (lane == 0 && nlow_out) nlow_out[t] = (i32)nlow;
 }
+// testing: a wave that does nothing for ~4 us per nap (option runsplit_lanes_test_delay: whatever is queued behind it lands late)
+__global__ void nap_kernel(int naps) {
+    for (int q = 0; q < naps; q++) __builtin_amdgcn_s_sleep(127);
+}
+void k_nap(cge_ctx *c, int naps) {
+    if (naps > 0) hipLaunchKernelGGL(nap_kernel, dim3(1), dim3(64), 0, c->stream, naps);
+}
 void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
                  unsigned char *side, i32 *nlow_out, int *tie_tasks) {
     ScopedKernelTimer t(c, "cut_sides");

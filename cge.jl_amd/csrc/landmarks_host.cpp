@@ -780,6 +780,7 @@ void rule_rss_sorted_enqueue(LaneRun &L) {
     L.i_status = L.wg->add(c->sp_status.p, T); L.i_meta = L.wg->add(c->sp_meta.p, 2 * T);
     L.i_vals = L.wg->add(c->sp_vals.p, 2 * T); L.i_nlow = L.wg->add(c->ls_nlow.p, T);
     L.wg->fetch_async();
+    if (c->root) k_nap(c, c->root->opt_lanes_test_delay); // (testing: the second lane's lists land late)
     k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + L.base);
 }
 void rule_rss_sorted_collect(LaneRun &L) {
@@ -866,6 +867,7 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
     HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(c->copy_done, st));
     // the children's member lists last: the host already has what its heap needs and builds the next batch meanwhile
+    if (c->root) k_nap(c, c->root->opt_lanes_test_delay); // (testing: the second lane's lists land late)
     k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + L.base);
 }
 void rule_cut_collect(LaneRun &L) {
@@ -1545,6 +1547,10 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     c->lm_arena_used = 0;
     c->lm_means_used = 0;
     c->lm_covs_used = 0;
+    // testing (option runsplit_lanes_test_delay): what an earlier run left in the arena is wiped -- a list that is read before
+    // it is written would otherwise often find the very ids it is about to receive (the runs of a test are identical)
+    if (c->opt_lanes_test_delay > 0 && c->lm_arena.p)
+        HIP_CHECK(hipMemsetAsync(c->lm_arena.p, 0, sizeof(i32) * c->lm_arena.n, c->stream));
     c->stat_lm_batches = c->stat_lm_rows = c->stat_lm_splits = c->stat_cov_derived = 0;
     c->cut_ties.ensure(1);
     HIP_CHECK(hipMemsetAsync(c->cut_ties.p, 0, sizeof(int), c->stream));

@@ -233,7 +233,8 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             thread with its own low-priority streams, beside runsplit (single rank only).  0 (default): in line.  Same
  *             results; measured slower or equal on every workload.
  * "runsplit_lanes": 2 = every batch of runsplit as two half-batches on two streams, half a chain out of phase; 1 (default).
- *             Same results.
+ *             Same results.  "runsplit_lanes_test_delay": testing -- the second lane's children lists land n x ~4 us late and the
+ *             member arena is wiped before the run (a list read before it is written then shows); results must not depend on it.
  * "fit_persistent_test_delay": testing -- the tile waves of the persistent fits nap n x ~3 us before their first load (start skew,
  *             as under contention); results must not depend on it.  "fit_persistent_test_timeout": testing -- 1 = the persistent
  *             fit abandons every launch at once (the fallback path runs).

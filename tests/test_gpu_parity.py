@@ -1423,3 +1423,26 @@ def test_persistent_fit_survives_start_skew(ctx, directed):
     finally:
         ctx.set_option("fit_persistent_test_delay", 0)
         ctx.set_option("fit_persistent", 0)
+
+
+@pytest.mark.parametrize("method", ["rss", "diameter", "rss2", "size"])
+def test_two_lanes_with_late_member_lists(ctx, method):
+    """runsplit_lanes = 2: the half batches of a round run on two streams and the next round deals the groups afresh, so a
+    lane reads member lists the OTHER lane wrote -- behind the event the host waits for.  With the second lane's lists held
+    back (option runsplit_lanes_test_delay: ~2 / 8 ms, and the arena wiped first) the result is still the one-lane result."""
+    from cge.jl_amd import synth
+
+    g = synth.abcd_like(60000, 600000, 40, 16, seed=5)
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    try:
+        ref = ctx.score(g["clusters"], 3000, 4, method, seed=3, auc_samples=2000).copy()
+        lm_ref = ctx.landmarks_fetch()[6].copy()
+        ctx.set_option("runsplit_lanes", 2)
+        for delay in (500, 0, 2000):  # (> 0 also wipes what the previous run left in the member arena)
+            ctx.set_option("runsplit_lanes_test_delay", delay)
+            got = ctx.score(g["clusters"], 3000, 4, method, seed=3, auc_samples=2000)
+            assert np.array_equal(got, ref), (method, delay)
+            assert np.array_equal(ctx.landmarks_fetch()[6], lm_ref), (method, delay)
+    finally:
+        ctx.set_option("runsplit_lanes_test_delay", 0)
+        ctx.set_option("runsplit_lanes", 1)
