@@ -440,7 +440,13 @@ __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict
         }
         // one pass, eight elements per thread in flight: the skipped j < i store the 0.0 that leaves a sum's bits alone
         const i64 jlo = j0 & ~(i64)255;
-        for (i64 j = threadIdx.x; j < jlo; j += 256) prod[cm_pos[j]] = 0.0;
+        // the skipped j < jlo hold 0.0: the whole row of products is cleared first (LDS stores only -- clearing just the
+        // positions cm_pos[j] of the skipped j was a serial loop of dependent global loads, longest for the rows that
+        // have the least to add)
+        if (jlo > 0) {
+            for (i64 j = threadIdx.x; j < N; j += 256) prod[j] = 0.0;
+            __syncthreads();
+        }
         for (i64 base = jlo; base < N; base += 8 * 256) {
             double r[8], t[8];
             i32 pos[8];
