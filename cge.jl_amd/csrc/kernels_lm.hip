@@ -2644,6 +2644,7 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
         printf("eig clock wave %d: barrier_a %llu  reads+sigma %llu  sqrt/div %llu  matvec+Pp %llu  barrier_b %llu  w %llu  rank2 %llu  extract %llu (s_memtime ticks over %d steps)\n",
                wv, ck_acc[0], ck_acc[1], ck_acc[2], ck_acc[3], ck_acc[4], ck_acc[5], ck_acc[6], ck_acc[7], d - 2);
 #endif
+#undef CK
     __syncthreads();
     if (tid == 0) { diag[d - 2] = X[d - 2]; off[d - 2] = X[d - 1]; } // column d-2 was the last one published
     __syncthreads();
