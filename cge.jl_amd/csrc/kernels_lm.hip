@@ -4281,6 +4281,121 @@ __global__ __launch_bounds__(256) void landmark_aggregate_kernel(const double *_
         lcomm[l] = (e > b) ? comm[mem[e - 1]] : 0; // last writer wins (:427-429)
     }
 }
+// The same aggregation without dependent loads on the chains (round 4).  Above, every sum walks the member list with an
+// index -> weight / row look-up per step (two memory round trips per eight members, for the weight sum, again for the
+// centroid).  Here the ids and weights of 256 members at a time are staged in
+// LDS by one coalesced pass and the centroid columns have 16 rows in flight behind a single look-up.  The same additions in
+// the same order with the same unfused arithmetic: the same bits.  d <= 1024 (four columns per thread).
+#define AG_MC 256 // members staged at a time (= the workgroup)
+__global__ __launch_bounds__(256) void landmark_aggregate2_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
+                                                                  const i32 *__restrict__ comm,
+                                                                  const i32 *__restrict__ mem_off,
+                                                                  const i32 *__restrict__ mem, i64 d,
+                                                                  double *__restrict__ lemb, double *__restrict__ lweight,
+                                                                  double *__restrict__ dii, i32 *__restrict__ lcomm) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    // cen[d] | bufd[256] | s_w[AG_MC] | s_id[AG_MC]
+    double *cen = sh, *bufd = sh + d, *s_w = bufd + 256;
+    i32 *s_id = reinterpret_cast<i32 *>(s_w + AG_MC);
+    __shared__ double s_lw;
+    const int tid = threadIdx.x;
+    const i64 l = blockIdx.x;
+    const i32 b = mem_off[l], e = mem_off[l + 1];
+    if (e == b) { // no member here (option shard_rows: another rank's landmark): zeros, which the gather over the ranks fills
+        for (i64 col = tid; col < d; col += 256) lemb[l * d + col] = 0.0;
+        if (tid == 0) { lweight[l] = 0.0; dii[l] = 0.0; lcomm[l] = -1; }
+        return;
+    }
+    // ---- weight sum and centroid (:391-402): one pass over the members, 256 at a time -----------------------------------
+    double lw = 0.0, acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (i32 base = b; base < e; base += AG_MC) {
+        const int cnt = min(AG_MC, e - base);
+        if (tid < cnt) {
+            const i32 v = mem[base + tid];
+            s_id[tid] = v;
+            s_w[tid] = vw[v];
+        }
+        __syncthreads();
+        if (tid == 0) { // (the additions keep the member order; the weights come out of LDS eight at a time)
+            int t = 0;
+            for (; t + 7 < cnt; t += 8) {
+                double w8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) w8[u] = s_w[t + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) lw = __dadd_rn(lw, w8[u]);
+            }
+            for (; t < cnt; t++) lw = __dadd_rn(lw, s_w[t]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const i64 col = tid + 256 * q;
+            if (col >= d) break;
+            double a = acc[q];
+            int t = 0;
+            for (; t + 15 < cnt; t += 16) { // 16 member rows in flight behind one look-up in LDS
+                double xv[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) xv[u] = Xr[(i64)s_id[t + u] * d + col];
+#pragma unroll
+                for (int u = 0; u < 16; u++) a = __dadd_rn(a, __dmul_rn(s_w[t + u], xv[u]));
+            }
+            for (; t < cnt; t++) a = __dadd_rn(a, __dmul_rn(s_w[t], Xr[(i64)s_id[t] * d + col]));
+            acc[q] = a;
+        }
+        __syncthreads(); // the staging area is rewritten by the next chunk
+    }
+    if (tid == 0) s_lw = lw;
+    __syncthreads();
+    lw = s_lw;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const i64 col = tid + 256 * q;
+        if (col >= d) break;
+        const double cv = acc[q] / lw; // :402
+        cen[col] = cv;
+        lemb[l * d + col] = cv;
+    }
+    __syncthreads();
+    // ---- dii (:408-423): the squared distances of the members to the centroid, summed in member order: a thread per member
+    //      walks its row (the rows were read a moment ago: L2).  (A tile of rows staged coalesced in LDS with a thread per row
+    //      walking it there was measured slower: 32 rows at a time against 256.)
+    double tot = 0.0; // meaningful in thread 0
+    for (i32 base = b; base < e; base += 256) {
+        const i32 t = base + (i32)tid;
+        if (t < e) {
+            const double *x = Xr + (i64)mem[t] * d;
+            double dist = 0.0;
+            i64 col = 0;
+            for (; col + 15 < d; col += 16) { // 16 values of the row in flight, then the 16 dependent steps
+                double xv[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) xv[u] = x[col + u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const double df = __dsub_rn(cen[col + u], xv[u]);
+                    dist = __dadd_rn(dist, __dmul_rn(df, df));
+                }
+            }
+            for (; col < d; col++) {
+                const double df = __dsub_rn(cen[col], x[col]);
+                dist = __dadd_rn(dist, __dmul_rn(df, df));
+            }
+            bufd[tid] = dist;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int cnt = min(256, e - base);
+            for (int q = 0; q < cnt; q++) tot = __dadd_rn(tot, bufd[q]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        lweight[l] = lw;
+        dii[l] = lw > 0 ? sqrt(tot / lw) : tot; // :418-423
+        lcomm[l] = comm[mem[e - 1]];             // last writer wins (:427-429)
+    }
+}
 // the landmark tables to / from one exchange vector: [lemb N x d | lweight N | dii N | lcomm + 1 as a double N]
 __global__ void pack_landmarks_kernel(double *__restrict__ lemb, double *__restrict__ lweight, double *__restrict__ dii,
                                       i32 *__restrict__ lcomm, i64 N, i64 d, double *__restrict__ X, int unpack) {
@@ -4306,6 +4421,14 @@ void k_scatter_u64(cge_ctx *c, const uint64_t *src, const i32 *idx, i64 cnt, uin
 }
 void k_landmark_aggregate(cge_ctx *c, const double *Xr, const double *vw, const i32 *comm, const i32 *mem_off,
                           const i32 *mem, i64 N, i64 d, double *lemb, double *lweight, double *dii, i32 *lcomm) {
+    // CGE_AGG_OLD=1: the form of rounds 1-3 (A/B); it also serves d > 1024
+    static const bool old_form = getenv("CGE_AGG_OLD") && atoi(getenv("CGE_AGG_OLD")) != 0;
+    if (!old_form && d <= 1024) {
+        const size_t lds2 = (size_t)(d + 256 + AG_MC) * sizeof(double) + (size_t)AG_MC * sizeof(i32);
+        hipLaunchKernelGGL(landmark_aggregate2_kernel, dim3((unsigned)N), dim3(256), lds2, c->stream, Xr, vw, comm, mem_off, mem, d,
+                           lemb, lweight, dii, lcomm);
+        return;
+    }
     size_t lds = (size_t)(d + 256) * sizeof(double);
     hipLaunchKernelGGL(landmark_aggregate_kernel, dim3((unsigned)N), dim3(256), lds, c->stream, Xr, vw, comm, mem_off,
                        mem, d, lemb, lweight, dii, lcomm);
