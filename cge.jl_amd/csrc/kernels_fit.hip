@@ -468,7 +468,15 @@ __global__ __launch_bounds__(256) void bvec_rows_kernel(const double *__restrict
         for (i64 cc = threadIdx.x, it = 0; cc < C; cc += 256, it++) {
             double s = 0.0;
             const i32 b = it < 2 ? ob[it] : cm_off[cc], e = it < 2 ? oe[it] : cm_off[cc + 1];
-            for (i32 t = b; t < e; t++) s += prod[t];
+            i32 t = b;
+            for (; t + 7 < e; t += 8) { // eight products out of LDS, then the eight additions in member order
+                double p8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) p8[u] = prod[t + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s += p8[u];
+            }
+            for (; t < e; t++) s += prod[t];
             rowbins[i * C + cc] = s;
         }
         return;
