@@ -157,7 +157,17 @@ __global__ __launch_bounds__(256) void exp2_matrix_upper_kernel(const double *__
     if (J < I) return;
     const i64 c0 = J * 64 + (threadIdx.x & 63);
     if (c0 >= N) return;
-    for (i64 r = I * 64 + (threadIdx.x >> 6); r < std::min<i64>(N, I * 64 + 64); r += 4) {
+    const i64 r0 = I * 64 + (threadIdx.x >> 6), rend = std::min<i64>(N, I * 64 + 64);
+    i64 r = r0;
+    for (; r + 12 < rend; r += 16) { // four entries of the column requested together (the power is ~40 dependent instructions)
+        double lh[4];
+        float ll[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { lh[u] = Lh[(r + 4 * u) * N + c0]; ll[u] = Ll[(r + 4 * u) * N + c0]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) GD[(r + 4 * u) * N + c0] = exp2_parts(alpha, lh[u], ll[u]);
+    }
+    for (; r < rend; r += 4) {
         const i64 e = r * N + c0;
         GD[e] = exp2_parts(alpha, Lh[e], Ll[e]);
     }
