@@ -1559,7 +1559,7 @@ __global__ __launch_bounds__(64 * NW) void rss2_chain_lds_kernel(const double *_
     extern __shared__ __attribute__((aligned(16))) double r2lds[];
     constexpr int XW = NS * 64; // doubles per row
     constexpr int RR = 16 * NW;           // rows per round
-    constexpr int NB = (NW == 4) ? 2 : 1; // LDS buffers of a round's rows (one when eight waves need the room)
+    constexpr int NB = (NW == 4 && NS == 1) ? 2 : 1; // LDS buffers of a round's rows (one when eight waves / 128 columns need the room)
     double(*tile)[R2_BR][65] = reinterpret_cast<double(*)[R2_BR][65]>(r2lds);          // [NW][16][65]
     double *xs = r2lds + NW * R2_BR * 65;                                               // [NB][RR][XW]
     double *wsh = xs + NB * RR * XW;                                                    // [NB][RR]
@@ -2140,7 +2140,18 @@ void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srow
         // the divisions of one block in eight, but the chain is repeated by twice as many waves and its registers spill:
         // 0.455 against 0.343 ms per launch on config 2); 0 = every wave loads every row itself
         static const int lds_form = getenv("CGE_RSS2_LDS") ? atoi(getenv("CGE_RSS2_LDS")) : 1;
-        if (lds_form && ns0 == 1) { // (d <= 64; the rows of a round with 128 columns would not fit beside the tree-sum tiles)
+        // CGE_RSS2_LDS2: 1 (default) = the same kernel for 64 < d <= 128 (one LDS buffer of rows, an extra barrier per round)
+        static const int lds_form2 = getenv("CGE_RSS2_LDS2") ? atoi(getenv("CGE_RSS2_LDS2")) : 1;
+        if (lds_form && lds_form2 && ns0 == 2) {
+            const size_t lds = (size_t)(4 * R2_BR * 65 + 64 * 128 + 64) * sizeof(double);
+            cge_allow_lds((const void *)rss2_chain_lds_kernel<2, 4>, 160 * 1024);
+            hipLaunchKernelGGL((rss2_chain_lds_kernel<2, 4>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R,
+                               c->r2_F.p, c->r2_ck.p, slots);
+            hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+                               d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
+            return;
+        }
+        if (lds_form && ns0 == 1) { // (d <= 64)
             if (lds_form == 2) {
                 const size_t lds = (size_t)(8 * R2_BR * 65 + 128 * 64 + 128) * sizeof(double);
                 cge_allow_lds((const void *)rss2_chain_lds_kernel<1, 8>, 160 * 1024);

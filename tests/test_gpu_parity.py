@@ -190,7 +190,7 @@ def test_group_eig_kernel(ctx, d):
             assert np.max(np.abs(ref - v[t])) < 1e-10 / gap, (d, t)
 
 
-@pytest.mark.parametrize("d,method", [(200, "rss"), (256, "size"), (96, "diameter"), (65, "rss2"), (129, "rss")])
+@pytest.mark.parametrize("d,method", [(200, "rss"), (256, "size"), (96, "diameter"), (65, "rss2"), (128, "rss2"), (129, "rss")])
 def test_landmarks_parity_wide_embeddings(ctx, orc, d, method):
     """Embedding dimensions beyond one MFMA tile / one register-resident covariance: the global-memory eigen-solver
     (128 < d <= 512), multi-tile MFMA SYRK, dimensions that are not multiples of 8/16/128.  (The oracle's Jacobi solver
