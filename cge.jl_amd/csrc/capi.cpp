@@ -1560,6 +1560,10 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_bvec_blocks = value != 0; // (measured slower); 0 (default): row bins + row sums + fold
         return CGE_OK;
     }
+    if (!strcmp(key, "fit_fused")) { // 1 (default): in landmark mode the power matrix, vect_B's tile sums and the local score's tallies ride
+        c->opt_fit_fused = value != 0; // on the launch of the undirected persistent fit; 0: separate launches (A/B, cross-check)
+        return CGE_OK;
+    }
     if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;
@@ -1630,6 +1634,7 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "side_diameter_status")) *value = c->stat_side_status; // 1 found, 2 declined (candidate list / pruning too weak), 3 failed
     else if (!strcmp(key, "fit_persistent_alphas")) *value = c->stat_fit_persistent;
     else if (!strcmp(key, "fit_iterations")) *value = c->stat_fit_iters;
+    else if (!strcmp(key, "fit_fused_alphas")) *value = c->stat_fit_fused; // alphas of the last sweep whose chain rode on the fit's launch
     else if (!strcmp(key, "fit_persistent_fallbacks")) *value = c->stat_fit_fallbacks;
     else if (!strcmp(key, "landmark_batches")) *value = c->stat_lm_batches;
     else if (!strcmp(key, "landmark_batch_rows")) *value = c->stat_lm_rows;

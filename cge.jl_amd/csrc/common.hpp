@@ -240,6 +240,8 @@ struct SampleSet {
 struct DevSamples { // one sample set as the AUC kernels read it (device, 0-based)
     DevBuf<i32> pi, pj, ni, nj;
     DevBuf<double> wts, dpos, dneg;
+    DevBuf<i32> aidx;     // the fused fit's prepared tally operands (k_auc_prepare)
+    DevBuf<double> afac;
 };
 
 struct cge_ctx {
@@ -336,6 +338,8 @@ struct cge_ctx {
     DevBuf<double> s_emb, s_dist, s_vw, s_vectC, s_degin, s_degout;
     DevBuf<i32> s_comm;
     DevBuf<double> auc_part, js_part;
+    DevBuf<unsigned> js_counter; // bins_js_kernel's arrival counter (monotonic: js_launches x CGE_PARTIAL_BLOCKS arrivals so far)
+    unsigned js_launches = 0;
     // alpha-sweep scratch (grow-only: no hipMalloc/hipFree inside a scoring call after the first)
     DevBuf<double> sw_D, sw_GD, sw_T1, sw_T2, sw_S1, sw_S2, sw_rowbins, sw_vectB, sw_scal, sw_lohi, sw_fitstate, sw_mm;
     DevBuf<int> sw_flags;
@@ -350,6 +354,10 @@ struct cge_ctx {
                                          // (relabelled only beyond 8192 vertices)
     DevBuf<i32> sw_bt_fc, sw_bt_ns, sw_bt_base; // per 64-vertex block: first community, communities; per tile: base of its partials
     DevBuf<double> sw_bt_part;
+    DevBuf<double> sw_fused_pw;          // ... and the two powers per sample its prologue writes for its epilogue
+    DevBuf<char> sw_fused_epi;           // the fused chain's tables, one cge_fit_fused per sample set (wgcl_host.cpp)
+    int opt_fit_fused = 1;               // 1 (default): landmark-mode sweeps let the rest of an alpha's chain ride on the fit's launch
+    i64 stat_fit_fused = 0;              // alphas of the last sweep that did
     DevBuf<i32> sw_rl_order, sw_rl_comm; // exact mode, N > 8192: the score graph relabelled by community (wgcl_host.cpp)
     DevBuf<double> sw_rl_emb, sw_rl_vec, sw_rl_T;
     DevBuf<unsigned> fp_sync;
@@ -729,8 +737,29 @@ void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD, 
 void k_pow_test(cge_ctx *c, const double *x, i64 n, double alpha, int method, double *out);
 bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
                       double delta, i64 *iters, int *final_parity, int variant);
+// What rides on the launch of the undirected persistent fit in a landmark-mode sweep relabelled by community (round 5): the
+// power matrix computed in the prologue from the stored logarithm, vect_B's tile partials and the local score's tallies in the
+// epilogue (kernels_fitp.hip: fit_flow_kernel<.., true>).  partial / auc_part == nullptr in the host copy: that part is not
+// wanted this alpha (the device copy, written once per sweep and sample set, always holds both).
+#define CGE_FLOW_NP 32 // runs of one community inside an 8-column chunk ("pieces") per 64-vertex block at most
+struct cge_fit_fused {
+    const double *Lh; const float *Ll; double alpha;   // host copy only: log2(1 - D) in two parts, this alpha
+    const i32 *comm, *fc, *ns, *base; double *partial; // vect_B by tiles (relabelled sweep: communities are ranges of vertices)
+    // the local score's samples, prepared once per sweep and sample set (k_auc_prepare): everything that depends neither on
+    // alpha nor on T -- T's indices in the sweep's numbering [4][S], the factors vw_i, lw_li, vw_j, lw_lj, ... [8][S], the
+    // weight sums of the CGE_PARTIAL_BLOCKS blocks -- and per alpha the two powers [2][S], which the fit's prologue writes
+    i64 S; const double *dpos, *dneg, *wts; const i32 *aidx; const double *afac, *aden; double *apw; double *auc_part;
+};
 bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,
-                        double eps, double delta, int *dev_flags);
+                        double eps, double delta, int *dev_flags, const cge_fit_fused *ff = nullptr,
+                        const cge_fit_fused *ff_dev = nullptr); // ff_dev: the device copy of *ff the epilogue reads (alpha, partial and
+                                                                // auc_part are taken from *ff: they change per alpha)
+bool k_fit_flow_fused_applies(cge_ctx *c, i64 N); // the geometry the fused instances exist for (one tile per wave, one quarter block per workgroup)
+void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, double *vectB, int n_modes, double *fpart);
+void k_bvec_tiles(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_off, i64 N, int directed); // the tile partials only
+void k_auc_prepare(cge_ctx *c, const i32 *v2l, const i32 *old2new, const double *vw_orig, const double *lweight, const i32 *pi,
+                   const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, i32 *aidx, double *afac, double *aden);
+void k_bvec_bins(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, int directed, double *vectB); // folds the tile partials into vect_B
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
                           const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant, int *dev_flags = nullptr,
                           bool *enqueued_only = nullptr);

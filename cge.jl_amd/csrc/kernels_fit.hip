@@ -25,96 +25,7 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh) {
     return r;
 }
 
-// ------------------------------------------------------------------------------------------------
-// GD = (1 - D)^alpha, forty times per score on the same D.  x^alpha = 2^(alpha * log2 x), and log2(1 - D) does not depend
-// on alpha: it is computed ONCE per score to ~70 bits (a double plus a float correction), and an alpha then costs one
-// exp2 of a double-double exponent per element instead of a full pow (which spends most of its time on that logarithm).
-// Accuracy: below one ulp (log2 to 2^-70, the product alpha*L exact through an fma residual, 2^f as 1 + f*ln2 + f^2*P(f)
-// with the leading term carried as hi + lo) -- the same class as the library pow this replaces (option "pow_exp2" = 0).
-struct dd_t { double h, l; };
-__device__ __forceinline__ dd_t two_sum(double a, double b) {
-    const double s = a + b, bb = s - a;
-    return {s, (a - (s - bb)) + (b - bb)};
-}
-__device__ __forceinline__ dd_t quick_two_sum(double a, double b) { // |a| >= |b|
-    const double s = a + b;
-    return {s, b - (s - a)};
-}
-__device__ __forceinline__ dd_t dd_add(dd_t x, dd_t y) {
-    const dd_t s = two_sum(x.h, y.h);
-    return quick_two_sum(s.h, s.l + (x.l + y.l));
-}
-__device__ __forceinline__ dd_t dd_mul(dd_t x, dd_t y) {
-    const double p = x.h * y.h;
-    const double e = fma(x.h, y.h, -p) + (x.h * y.l + x.l * y.h);
-    return quick_two_sum(p, e);
-}
-__device__ __forceinline__ dd_t dd_div(dd_t x, dd_t y) { // three quotient digits
-    const double q1 = x.h / y.h;
-    dd_t r = dd_add(x, dd_mul(y, {-q1, 0.0}));
-    const double q2 = r.h / y.h;
-    r = dd_add(r, dd_mul(y, {-q2, 0.0}));
-    const double q3 = r.h / y.h;
-    const dd_t q = quick_two_sum(q1, q2);
-    return dd_add(q, {q3, 0.0});
-}
-// log2(x), x > 0 finite and normal, as hi + lo (|lo| <= ulp(hi)/2): x = m*2^e with m in [sqrt(1/2), sqrt(2)),
-// log2 m = (2/ln 2) * atanh(s), s = (m-1)/(m+1), atanh(s) = s*(1 + z*(1/3 + z*(1/5 + z*R(z)))), z = s^2 <= 0.0295;
-// R in double (it enters below 2^-13 of the result), the rest in double-double.
-__device__ __forceinline__ dd_t log2_dd(double x) {
-    int e;
-    double m = frexp(x, &e);
-    if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
-    const dd_t s = dd_div({m - 1.0, 0.0}, two_sum(m, 1.0));
-    const dd_t z = dd_mul(s, s);
-    double R = 1.0 / 33.0;
-#pragma unroll
-    for (int k = 31; k >= 7; k -= 2) R = fma(R, z.h, 1.0 / (double)k);
-    const dd_t A = dd_add({0.20000000000000001, -1.1102230246251566e-17}, dd_mul(z, {R, 0.0}));
-    const dd_t B = dd_add({0.33333333333333331, 1.8503717077085941e-17}, dd_mul(z, A));
-    const dd_t C = dd_add({1.0, 0.0}, dd_mul(z, B));
-    const dd_t T = dd_mul(s, C);
-    const dd_t L = dd_mul(T, {2.8853900817779268, 4.0710547481862066e-17});
-    return dd_add({(double)e, 0.0}, L);
-}
-// the two stored parts of log2(1 - D): 1 - D == 0 -> -inf (the power is 0), NaN stays NaN
-__device__ __forceinline__ void log_parts(double d, double &Lh, float &Ll) {
-    const double x = 1.0 - d;
-    if (x > 0.0 && x < 1.7976931348623157e308) {
-        const dd_t L = log2_dd(x);
-        Lh = L.h;
-        Ll = (float)L.l;
-    } else {
-        Lh = (x == 0.0) ? -__builtin_huge_val() : ((x != x) ? x : log2(x)); // 0, NaN, (never: negative / inf)
-        Ll = 0.0f;
-    }
-}
-// 2^(alpha * (Lh + Ll))
-__device__ __forceinline__ double exp2_parts(double alpha, double Lh, float Ll) {
-    const double p = alpha * Lh;
-    if (!(p > -1100.0)) return (p != p) ? p : 0.0; // NaN stays NaN; -inf and anything below the subnormals is 0
-    const double yl = fma(alpha, Lh, -p) + alpha * (double)Ll;
-    const double k = rint(p);
-    const double f = (p - k) + yl; // |f| <= 1/2 (+ a rounding)
-    const double LN2H = 0.69314718055994529, LN2L = 2.3190468138462996e-17;
-    const double t1 = f * LN2H;
-    const double t1e = fma(f, LN2H, -t1) + f * LN2L;
-    double P = 6.7787263548225451e-14; // ln2^i / i!, i = 14 .. 2
-    P = fma(P, f, 1.3691488853904128e-12);
-    P = fma(P, f, 2.5678435993488206e-11);
-    P = fma(P, f, 4.4455382718708116e-10);
-    P = fma(P, f, 7.0549116208011234e-09);
-    P = fma(P, f, 1.01780860092397e-07);
-    P = fma(P, f, 1.321548679014431e-06);
-    P = fma(P, f, 1.5252733804059841e-05);
-    P = fma(P, f, 0.00015403530393381609);
-    P = fma(P, f, 0.0013333558146428443);
-    P = fma(P, f, 0.0096181291076284769);
-    P = fma(P, f, 0.055504108664821583);
-    P = fma(P, f, 0.24022650695910072);
-    const double q = t1 + fma(f * f, P, t1e);
-    return ldexp(1.0 + q, (int)k);
-}
+#include "pow_parts.hpp"
 __global__ void pow_matrix_kernel(const double *__restrict__ D, i64 total, double alpha, double *__restrict__ GD) {
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) GD[e] = pow(1.0 - D[e], alpha);
@@ -630,11 +541,19 @@ __global__ __launch_bounds__(256) void bvec_tile_kernel(const double *__restrict
     }
     __syncthreads();
     { // (a) row r over the columns of community fcJ + s: four threads per row take every fourth segment
+        // (by 8-column chunks: the columns of a chunk in ascending order, then the chunks in ascending order -- the order in
+        // which the fused epilogue of the persistent fit, whose lanes hold 8-column chunks, adds the same products)
         const int r = t >> 2;
         for (int s2 = t & 3; s2 < nsJ; s2 += 4) {
             const int b0 = segJ[s2], b1 = segJ[s2 + 1];
             double acc = 0.0;
-            for (int c2 = b0; c2 < b1; c2++) acc = __dadd_rn(acc, prod[r][c2]);
+            for (int c2 = b0; c2 < b1;) {
+                const int ce = min(b1, (c2 & ~7) + 8);
+                double ch = prod[r][c2];
+                for (int c3 = c2 + 1; c3 < ce; c3++) ch = __dadd_rn(ch, prod[r][c3]);
+                acc = (c2 == b0) ? ch : __dadd_rn(acc, ch);
+                c2 = ce;
+            }
             rp[r][s2] = acc;
         }
     }
@@ -668,6 +587,18 @@ __global__ __launch_bounds__(256) void bvec_bins_kernel(const double *__restrict
                 }
         vectB[directed ? e : C * ca - ca * (ca - 1) / 2 + (cb - ca)] = acc;
     }
+}
+void k_bvec_tiles(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_off, i64 N, int directed) {
+    ScopedKernelTimer t(c, "bvec");
+    const int Nt = (int)((N + 63) / 64);
+    hipLaunchKernelGGL(bvec_tile_kernel, dim3((unsigned)Nt, (unsigned)Nt), dim3(256), 0, c->stream, GD, Ta, Tb, cm_off, c->sw_bt_fc.p,
+                       c->sw_bt_ns.p, c->sw_bt_base.p, N, Nt, directed, c->sw_bt_part.p);
+}
+void k_bvec_bins(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, int directed, double *vectB) {
+    ScopedKernelTimer t(c, "bvec");
+    const int Nt = (int)((N + 63) / 64);
+    hipLaunchKernelGGL(bvec_bins_kernel, dim3(grid_for(C * C, 256, 1024)), dim3(256), 0, c->stream, c->sw_bt_part.p, cm_off,
+                       c->sw_bt_fc.p, c->sw_bt_ns.p, c->sw_bt_base.p, C, Nt, directed, vectB);
 }
 void k_bvec(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_pos, const i32 *cm_off,
             const i32 *cm_mem, i64 N, i64 C, int directed, double *rowbins, double *vectB) {
@@ -757,6 +688,109 @@ __global__ void js_final_kernel(const double *__restrict__ fpart, double *__rest
     for (int b = 0; b < JS_BLOCKS; b++) f += __shfl(v, b);
     if (threadIdx.x == 0) *out = f / 2.0;
 }
+// vect_B from the tile partials AND its divergence from vect_C in ONE launch (round 5; undirected, behind the fused fit or
+// bvec_tile_kernel): bvec_bins_kernel + js_sums_kernel + js_terms_kernel with their additions in their order, so the bits are
+// those of the three launches.  JS_BLOCKS workgroups (co-resident: a quarter of the chip, and the stream's previous kernel has
+// finished); block b owns the bins k = 256 b + t + 256 JS_BLOCKS i.  Phase 1: vect_B[k] = the partials of the tiles its
+// rectangle touches (I ascending, then J), and the block sums of vect_C / vect_B / count per mode.  One arrival counter
+// (monotonic over the launches of a context: `target` = JS_BLOCKS x launches so far) separates the phases; a block that waits
+// too long gives up and publishes NaN (the sweep then fails its checks loudly instead of hanging).  Phase 2: js_terms_kernel.
+// n_modes = 1: all bins; 2: internal then external bins (--split-global).
+__global__ __launch_bounds__(256) void bins_js_kernel(const double *__restrict__ partial, const i32 *__restrict__ cm_off,
+                                                      const i32 *__restrict__ fc, const i32 *__restrict__ ns,
+                                                      const i32 *__restrict__ base, i64 C, int Nt, const double *__restrict__ vC,
+                                                      double *__restrict__ vectB, int n_modes, double *__restrict__ part,
+                                                      unsigned *counter, unsigned target, double *__restrict__ fpart) {
+    __shared__ double sh[256];
+    __shared__ int ok_sh;
+    const i64 len = C * (C + 1) / 2;
+    const int first_mode = n_modes == 1 ? 0 : 1;
+    double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0}, cnt[2] = {0.0, 0.0};
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < len; k += (i64)JS_BLOCKS * 256) {
+        // packed index -> (ca, cb), ca <= cb: row ca starts at off(ca) = C ca - ca (ca - 1) / 2
+        const double bq = 2.0 * (double)C + 1.0;
+        i64 ca = (i64)((bq - sqrt(bq * bq - 8.0 * (double)k)) * 0.5);
+        if (ca < 0) ca = 0;
+        if (ca > C - 1) ca = C - 1;
+        while (ca > 0 && C * ca - ca * (ca - 1) / 2 > k) ca--;
+        while (ca + 1 < C && C * (ca + 1) - (ca + 1) * ca / 2 <= k) ca++;
+        const i64 cb = ca + (k - (C * ca - ca * (ca - 1) / 2));
+        const i32 a0 = cm_off[ca], a1 = cm_off[ca + 1], b0 = cm_off[cb], b1 = cm_off[cb + 1];
+        double acc = 0.0;
+        if (a1 > a0 && b1 > b0)
+            for (int I = a0 >> 6; I <= (a1 - 1) >> 6; I++)
+                for (int J = b0 >> 6; J <= (b1 - 1) >> 6; J++) {
+                    if (J < I) continue; // (the mirrored part of a diagonal bin: the reference sums j >= i only)
+                    acc = __dadd_rn(acc, partial[(i64)base[I * Nt + J] + (i64)(ca - fc[I]) * ns[J] + (cb - fc[J])]);
+                }
+        vectB[k] = acc;
+        const double c_k = vC[k];
+        for (int m = 0; m < n_modes; m++) {
+            const int mode = first_mode + m;
+            if (mode == 0 || (mode == 1) == (ca == cb)) { s1[m] += c_k; s2[m] += acc; cnt[m] += 1.0; }
+        }
+    }
+    for (int m = 0; m < n_modes; m++) {
+        const double a = block_sum_256(s1[m], sh), b = block_sum_256(s2[m], sh), c3 = block_sum_256(cnt[m], sh);
+        if (threadIdx.x == 0) {
+            double *pp = part + (i64)m * 3 * JS_BLOCKS + 3 * blockIdx.x;
+            __hip_atomic_store(pp, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 2, c3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- every block's sums are in memory before anybody reads them ----
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        const long long deadline = wall_clock64() + CGE_FIT_TIMEOUT_TICKS;
+        for (;;) {
+            // (the counter only grows; a difference that has not wrapped means "at least `target` arrivals")
+            if ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { ok = 1; break; }
+            if (wall_clock64() > deadline) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        ok_sh = ok;
+    }
+    __syncthreads();
+    const bool ok = ok_sh != 0;
+    for (int m = 0; m < n_modes; m++) {
+        const int mode = first_mode + m;
+        double t1 = 0.0, t2 = 0.0, tc = 0.0;
+        const double *pm = part + (i64)m * 3 * JS_BLOCKS;
+        for (int b = 0; b < JS_BLOCKS; b++) {
+            t1 += __hip_atomic_load(pm + 3 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t2 += __hip_atomic_load(pm + 3 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tc += __hip_atomic_load(pm + 3 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const double sp1 = t1 + tc, sp2 = t2 + tc;
+        double f = 0.0;
+        for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < len; k += (i64)JS_BLOCKS * 256)
+            if (js_selected(k, C, 0, mode)) {
+                const double p = (vC[k] + 1.0) / sp1, q = (vectB[k] + 1.0) / sp2; // (vectB[k]: this thread's own store)
+                const double mm = (p + q) / 2.0;
+                f += p * log(p / mm) + q * log(q / mm);
+            }
+        f = block_sum_256(f, sh);
+        if (threadIdx.x == 0) fpart[(i64)m * JS_BLOCKS + blockIdx.x] = ok ? f : __builtin_nan("");
+    }
+}
+// fpart: n_modes x CGE_PARTIAL_BLOCKS block sums of the divergence terms (the caller adds them in block order, then / 2)
+void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, double *vectB, int n_modes, double *fpart) {
+    ScopedKernelTimer t(c, "bvec_js");
+    const int Nt = (int)((N + 63) / 64);
+    c->js_part.ensure(8 * JS_BLOCKS);
+    if (!c->js_counter.p) {
+        c->js_counter.ensure(32);
+        HIP_CHECK(hipMemsetAsync(c->js_counter.p, 0, 32 * sizeof(unsigned), c->stream));
+        c->js_launches = 0;
+    }
+    c->js_launches++;
+    hipLaunchKernelGGL(bins_js_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, c->sw_bt_part.p, cm_off, c->sw_bt_fc.p,
+                       c->sw_bt_ns.p, c->sw_bt_base.p, C, Nt, vC, vectB, n_modes, c->js_part.p, c->js_counter.p,
+                       (unsigned)(c->js_launches * JS_BLOCKS), fpart);
+}
 // `partials` != nullptr: the CGE_PARTIAL_BLOCKS block sums of the divergence terms go there and the caller adds them (in
 // block order, then / 2: what js_final_kernel does) -- the sweep does that on the host, behind the copy it makes anyway
 void k_js(cge_ctx *c, const double *vC, const double *vB, i64 len, i64 C, int directed, int mode, double *out,
@@ -800,6 +834,37 @@ __global__ __launch_bounds__(256) void auc_landmark_kernel(const double *__restr
     num = block_sum_256(num, sh);
     den = block_sum_256(den, sh);
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = num; part[2 * blockIdx.x + 1] = den; }
+}
+// The parts of auc_landmark_kernel's tally that depend neither on alpha nor on T, once per sweep and sample set, for the
+// epilogue of the fused persistent fit (kernels_fitp.hip): idx[4][S] = T's indices of i, j, u, v (through old2new when the sweep
+// is relabelled), fac[8][S] = vw_i, lw_li, vw_j, lw_lj, vw_u, lw_lu, vw_v, lw_lv, den[b] = block b's weight sum (the additions of
+// auc_landmark_kernel's own `den`).  gridDim.x == AUC_BLOCKS.
+__global__ __launch_bounds__(256) void auc_prepare_kernel(const i32 *__restrict__ v2l, const i32 *__restrict__ old2new,
+                                                          const double *__restrict__ vw_orig, const double *__restrict__ lweight,
+                                                          const i32 *__restrict__ pi, const i32 *__restrict__ pj,
+                                                          const i32 *__restrict__ ni, const i32 *__restrict__ nj,
+                                                          const double *__restrict__ wts, i64 S, i32 *__restrict__ idx,
+                                                          double *__restrict__ fac, double *__restrict__ den_part) {
+    __shared__ double sh[256];
+    double den = 0.0;
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < S; k += (i64)gridDim.x * 256) {
+        const i64 v[4] = {pi[k], pj[k], ni[k], nj[k]};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const i64 l = v2l[v[q]];
+            idx[q * S + k] = old2new ? old2new[l] : (i32)l;
+            fac[(2 * q) * S + k] = vw_orig[v[q]];
+            fac[(2 * q + 1) * S + k] = lweight[l];
+        }
+        den += wts[k];
+    }
+    den = block_sum_256(den, sh);
+    if (threadIdx.x == 0) den_part[blockIdx.x] = den;
+}
+void k_auc_prepare(cge_ctx *c, const i32 *v2l, const i32 *old2new, const double *vw_orig, const double *lweight, const i32 *pi,
+                   const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, i32 *aidx, double *afac, double *aden) {
+    hipLaunchKernelGGL(auc_prepare_kernel, dim3(AUC_BLOCKS), dim3(256), 0, c->stream, v2l, old2new, vw_orig, lweight, pi, pj, ni, nj,
+                       wts, S, aidx, afac, aden);
 }
 __global__ __launch_bounds__(256) void auc_exact_kernel(const double *__restrict__ GD, const double *__restrict__ Ta,
                                                         const double *__restrict__ Tb, i64 N,

@@ -27,6 +27,7 @@
 // back to one launch per iteration.  All sums have a fixed order: a run is bitwise reproducible, and the forms give
 // identical bits.
 #include "common.hpp"
+#include "pow_parts.hpp"
 
 namespace {
 
@@ -35,6 +36,15 @@ namespace {
 __device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, RLX_AGENT); }
 typedef double dbl2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, RLX_AGENT); }
+// the same with a wave-uniform base and a 32-bit element index (the buffers of these kernels are far below 4 GB): the
+// address is base (scalar registers) + one 32-bit vector offset, so an index that is invariant over the iterations costs
+// one vector register to keep instead of two -- fit_flow_kernel runs at the 256-register limit
+__device__ __forceinline__ double ld_sc1_at(const double *base, unsigned idx) {
+    return ld_sc1(reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (idx << 3)));
+}
+__device__ __forceinline__ void st_sc1_at(double *base, unsigned idx, double v) {
+    st_sc1(reinterpret_cast<double *>(reinterpret_cast<char *>(base) + (idx << 3)), v);
+}
 
 // combine v[0..8) across the 8 lanes that differ in lane bits SH, SH+1, SH+2: afterwards the lane whose three bits
 // spell q holds sum_lanes v[q].  Additions are pairwise in a fixed tree.
@@ -459,6 +469,10 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
 #define FLOW_SENTINEL_WORD 0x7FF8DEADu
 #define FLOW_SENTINEL 0x7FF8DEAD7FF8DEADull
 __device__ __forceinline__ bool armed(double v) { return (unsigned long long)__double_as_longlong(v) == FLOW_SENTINEL; }
+// fit_flow_kernel: a converged reducer stores this where T_{k+1} would go, so the tile waves of workgroups WITHOUT a quarter
+// block (G > 4 Nt), which poll that slot, leave at once instead of at their next look at `done` (every 64 polls)
+#define FLOW_FINISHED 0x7FF8D0D07FF8D0D0ull
+__device__ __forceinline__ bool finished_mark(double v) { return (unsigned long long)__double_as_longlong(v) == FLOW_FINISHED; }
 __device__ __forceinline__ double sentinel() { return __longlong_as_double((long long)FLOW_SENTINEL); }
 // every 64th unsuccessful poll: 1 = the fit is over, 2 = abandoned (wave-uniform)
 // (`done` / `fail` are armed with the sentinel word like everything else of these kernels' buffers: they are SET when they
@@ -503,16 +517,53 @@ __device__ __forceinline__ double wave_max(double v) {
 // matrix lives in accumulation registers and is copied back before use.  The quarter blocks are always reduced by the
 // first 256 threads, with the additions of fit_dataflow_kernel in the same order.
 #define FLOW_RLD 66 // row stride (doubles) of the transposing-reduction scratch: 16-byte accesses of 8 lanes hit 8 banks groups
-template <int TPW, int NW>
+// ---- what rides on the fit's launch (round 5): the rest of the alpha's chain, src/divergence.jl:146, :170-176, :178-213, :226-234 ----
+// FUSED = true (landmark mode, sweep relabelled by community; wgcl_host.cpp decides):
+//   prologue  g = 2^(alpha * log2(1 - D)) from the stored logarithm (pow_parts.hpp: exp2_matrix_upper_kernel's own function and
+//             bits) -- the power matrix is never written;
+//   epilogue  when the fit has converged the tile and (from the ring) the final T are at hand: the products
+//             P_ij = (T_i T_j) g_ij are summed per (row community, column community) rectangle of the tile in the fixed order
+//             of bvec_tile_kernel (kernels_fit.hip) -> `partial`, which bvec_bins_kernel folds into vect_B; and the first
+//             CGE_PARTIAL_BLOCKS workgroups tally the local score's sampled pairs exactly as auc_landmark_kernel's blocks do.
+// Neither launch re-reads the matrix: bvec_rows / bvec_zsum / bvec_fold / exp2_matrix_upper / auc_landmark and one read +
+// one write of GD per alpha are gone from the chain.
+#define FLOW_NP 32 // pieces (runs of one community inside an 8-column chunk) per 64-column block at most: LDS per wave FLOW_NP x 66 doubles
+struct FlowFused { // by value: what the prologue needs, and where the epilogue finds the rest (device memory: loaded after the loop,
+                   // so that none of it is held in registers across it -- the loop runs at the register limit)
+    const double *Lh; const float *Ll; double alpha; // log2(1 - D) in two parts (k_pow_prepare)
+    const cge_fit_fused *epi;                        // device copy of the sweep's table for this sample set
+    int want;                                        // bit 0: vect_B's tile partials, bit 1: the local score's tallies
+};
+// the sum of the first 256 threads' values, block_sum_256's additions (kernels_fit.hip); every thread of the workgroup calls it
+__device__ __forceinline__ double flow_sum_256(double v, double *sh, int tid) {
+    if (tid < 256) sh[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+template <int TPW, int NW, bool FUSED, int NSB> // NSB: quarter blocks a workgroup may have to reduce (1 when 4*Nt <= G)
 __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restrict__ GD, i64 N, int Nt, const double *T0,
                                                             double *Tout, i64 Tld, const double *__restrict__ w, double eps,
                                                             double delta, int max_iters, double *ring, double *P, double *fq,
-                                                            unsigned *sync, int *flags, long long timeout_ticks, int test_naps) {
-    constexpr int NSB = 2; // quarter blocks per workgroup at most (4*Nt <= 2*G, checked by the host)
+                                                            unsigned *sync, int *flags, long long timeout_ticks, int test_naps,
+                                                            const FlowFused fz) {
+    // (4*Nt <= NSB*G, checked by the host)
     __shared__ double red[2][NSB][16][17]; // by the parity of k: no barrier is needed to recycle it
     __shared__ double fred[2][4];
     __shared__ __attribute__((aligned(16))) double tsh[NW][2][64];     // per wave: T of the tile's row block / column block
-    __shared__ __attribute__((aligned(16))) double rsh[NW][2][8][FLOW_RLD]; // per wave: the two transposing reductions
+    // per wave: the two transposing reductions of an iteration ([2][8][FLOW_RLD]); the fused epilogue stages its pieces there
+    constexpr int RSH_W = FUSED ? (FLOW_NP * FLOW_RLD > 2 * 8 * FLOW_RLD ? FLOW_NP * FLOW_RLD : 2 * 8 * FLOW_RLD) : 2 * 8 * FLOW_RLD;
+    __shared__ __attribute__((aligned(16))) double rsh_all[NW][RSH_W];
+    // fused epilogue, filled by the prologue (so the epilogue waits for no global load): per wave the communities of its tile's
+    // row / column runs, and {segI, segJ (the rows / columns that start a run, 64-bit masks), fc[I], fc[J], ns[J], base[I][J]}
+    static_assert(!FUSED || TPW == 1, "the fused form keeps one tile per wave");
+    __shared__ i32 segtab[FUSED ? NW : 1][2][64];
+    __shared__ i32 ehdr[FUSED ? NW : 1][8];
     __shared__ int lds_exit;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
     const int rq = lane >> 3, cq = lane & 7;
@@ -523,6 +574,42 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
 
     double g[TPW][8][8];
     int tI[TPW], tJ[TPW];
+#ifdef CGE_FLOW_CLOCK
+    const long long ck0 = wall_clock64();
+#endif
+    if (FUSED && (fz.want & 2) && tid < 256) { // the local score's two powers per sample, ahead of everything (nothing is live yet): the
+        const cge_fit_fused *ep0 = fz.epi; // epilogue's tally then waits for loads only.  Block vb = this workgroup's, as below
+        const i64 S0 = ep0->S;
+        const int GR0 = G < 4 * Nt ? G : 4 * Nt;
+        if (wg < GR0)
+            for (int vb = wg; vb < CGE_PARTIAL_BLOCKS; vb += GR0)
+                for (i64 q = (i64)vb * 256 + tid; q < S0; q += (i64)CGE_PARTIAL_BLOCKS * 256) {
+                    ep0->apw[q] = pow(1.0 - ep0->dpos[q], fz.alpha);
+                    ep0->apw[S0 + q] = pow(1.0 - ep0->dneg[q], fz.alpha);
+                }
+    }
+    if (FUSED && (fz.want & 1)) { // vect_B's tile geometry into LDS (this wave's tile: slot 0)
+        const cge_fit_fused *ep0 = fz.epi;
+        const int t = wg * NW + wave;
+        if (t < NT) { // uniform per wave
+            int I = 0, rem = t;
+            while (rem >= Nt - I) { rem -= Nt - I; I++; }
+            const int J = I + rem;
+            const i64 vI = (i64)64 * I + lane, vJ = (i64)64 * J + lane;
+            // communities of the block's rows / columns (-1 beyond the matrix): a set bit of segI / segJ starts a run
+            const i32 cI = vI < N ? ep0->comm[vI] : -1, cJ = vJ < N ? ep0->comm[vJ] : -1;
+            const i32 cIp = __shfl_up(cI, 1), cJp = __shfl_up(cJ, 1);
+            const unsigned long long segI = __ballot(lane == 0 || cI != cIp), segJ = __ballot(lane == 0 || cJ != cJp);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if ((segI >> lane) & 1ull) segtab[wave][0][__popcll(segI & below)] = cI;
+            if ((segJ >> lane) & 1ull) segtab[wave][1][__popcll(segJ & below)] = cJ;
+            if (lane == 0) {
+                ehdr[wave][0] = (i32)(unsigned)segI; ehdr[wave][1] = (i32)(unsigned)(segI >> 32);
+                ehdr[wave][2] = (i32)(unsigned)segJ; ehdr[wave][3] = (i32)(unsigned)(segJ >> 32);
+                ehdr[wave][4] = ep0->fc[I]; ehdr[wave][5] = ep0->fc[J]; ehdr[wave][6] = ep0->ns[J]; ehdr[wave][7] = ep0->base[I * Nt + J];
+            }
+        }
+    }
     if (test_naps > 0 && (wg * NW + wave) < NT) // testing (option fit_persistent_test_delay): the tile waves start late
         for (int q = 0; q < test_naps; q++) __builtin_amdgcn_s_sleep(127);
 #pragma unroll
@@ -536,6 +623,38 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
             tI[s] = I;
             tJ[s] = I + rem;
         }
+        if (FUSED) { // the stored logarithm -> this alpha's power, in place (the element stays 0.0 outside the matrix).  Every
+            // load is unconditional (indices clamped into the matrix, the result selected afterwards): no divergent branches
+            const int Ic = tI[s] < 0 ? 0 : tI[s], Jc = tJ[s] < 0 ? 0 : tJ[s];
+            const unsigned Nu = (unsigned)N;
+            unsigned rowc[8], colc[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                rowc[q] = min(64u * Ic + 8u * rq + q, Nu - 1u);
+                colc[q] = min(64u * Jc + 8u * cq + q, Nu - 1u);
+            }
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) g[s][a][b] = fz.Lh[(i64)rowc[a] * N + colc[b]];
+#pragma unroll
+            for (int h = 0; h < 2; h++) { // the float parts by half tiles: 32 registers beside the 128 of the tile
+                float ll[4][8];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 8; b++) ll[a][b] = fz.Ll[(i64)rowc[4 * h + a] * N + colc[b]];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const bool in = tI[s] >= 0 && 64u * Ic + 8u * rq + 4 * h + a < Nu && 64u * Jc + 8u * cq + b < Nu;
+                        const double e = exp2_parts(fz.alpha, g[s][4 * h + a][b], ll[a][b]);
+                        g[s][4 * h + a][b] = in ? e : 0.0;
+                    }
+            }
+            continue;
+        }
 #pragma unroll
         for (int a = 0; a < 8; a++) {
             const i64 row = (i64)64 * tI[s] + 8 * rq + a;
@@ -546,6 +665,10 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
             }
         }
     }
+#ifdef CGE_FLOW_CLOCK // (a build flag, diagnostics only: wall-clock stamps of the launch's sections, printed by two waves)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long ck1 = wall_clock64();
+#endif
     // the rows this thread updates (threads 0..15 only): the current iterate and the target stay in registers
     const int r16 = tid & 15, qg = (tid >> 4) & 15;
     const bool reducer = tid < 256;
@@ -561,7 +684,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
     if (tid == 0) lds_exit = 0;
     __syncthreads();
 
-    int k = 0, converged = 0, failed = 0;
+    int k = 0, converged = 0, failed = 0, left_on = 0;
     if (timeout_ticks <= 0) max_iters = 0; // test hook: abandon at once
     for (;;) {
         deadline = wall_clock64() + timeout_ticks;
@@ -580,8 +703,9 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
             double vi, vj;
             unsigned spins = 0;
             for (;;) {
-                vi = ld_sc1(Tk + 64 * I + lane);
-                vj = ld_sc1(Tk + 64 * J + lane);
+                vi = ld_sc1_at(Tk, 64u * (unsigned)I + (unsigned)lane);
+                vj = ld_sc1_at(Tk, 64u * (unsigned)J + (unsigned)lane);
+                if (__any(finished_mark(vi) || finished_mark(vj))) { bad = 1; break; } // the fit ended with iteration k - 1
                 if (__all(!armed(vi) && !armed(vj))) break;
                 bad = flow_check(spins, fail, done, deadline);
                 if (bad) break;
@@ -608,8 +732,8 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
             // The transposing reductions of transpose_reduce8 (same pairs, same bits) through LDS: the partial of lane
             // (rq, cq) for row 8*rq + a goes to R[cq][8*rq + a], lane l then adds the eight partials of row l as
             // ((u0+u4)+(u2+u6)) + ((u1+u5)+(u3+u7)); the same for the columns with the roles of rq and cq exchanged.
-            double(*R)[FLOW_RLD] = rsh[wave][0];
-            double(*Cc)[FLOW_RLD] = rsh[wave][1];
+            double(*R)[FLOW_RLD] = reinterpret_cast<double(*)[FLOW_RLD]>(rsh_all[wave]);
+            double(*Cc)[FLOW_RLD] = reinterpret_cast<double(*)[FLOW_RLD]>(rsh_all[wave] + 8 * FLOW_RLD);
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 R[cq][8 * rq + q] = pr[q];
@@ -624,10 +748,10 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
             }
             __builtin_amdgcn_wave_barrier();
             const double rsum = ((u[0] + u[4]) + (u[2] + u[6])) + ((u[1] + u[5]) + (u[3] + u[7]));
-            st_sc1(Pk + ((i64)I * Nt + J) * 64 + lane, rsum);
+            st_sc1_at(Pk, ((unsigned)I * (unsigned)Nt + (unsigned)J) * 64u + (unsigned)lane, rsum);
             if (I != J) {
                 const double csum = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
-                st_sc1(Pk + ((i64)J * Nt + I) * 64 + lane, csum);
+                st_sc1_at(Pk, ((unsigned)J * (unsigned)Nt + (unsigned)I) * 64u + (unsigned)lane, csum);
             }
         }
         // ---- 2. the quarter blocks this workgroup reduces -----------------------------------------------------------------
@@ -643,7 +767,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
             if (!bad && fcheck && reducer) { // stored an iteration ago: asked for ahead of the partial vectors
 #pragma unroll
                 for (int u = 0; u < 2; u++)
-                    if (tid + 256 * u < 4 * Nt) fx[u] = ld_sc1(fp + tid + 256 * u);
+                    if (tid + 256 * u < 4 * Nt) fx[u] = ld_sc1_at(fp, (unsigned)(tid + 256 * u));
             }
             if (!bad && reducer) {
                 unsigned spins = 0;
@@ -653,7 +777,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
                     for (int u = 0; u < 4; u++) {
                         const int q = qg + 16 * u;
                         if (q < Nt) {
-                            pv[u] = ld_sc1(Pk + ((i64)b * Nt + q) * 64 + rib);
+                            pv[u] = ld_sc1_at(Pk, ((unsigned)b * (unsigned)Nt + (unsigned)q) * 64u + (unsigned)rib);
                             ok = ok && !armed(pv[u]);
                         }
                     }
@@ -670,7 +794,7 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
                     if (bad) break;
 #pragma unroll
                     for (int u = 0; u < 2; u++)
-                        if (tid + 256 * u < 4 * Nt) fx[u] = ld_sc1(fp + tid + 256 * u);
+                        if (tid + 256 * u < 4 * Nt) fx[u] = ld_sc1_at(fp, (unsigned)(tid + 256 * u));
                 }
                 fv = fmax(fx[0], fx[1]);
             }
@@ -687,7 +811,20 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
             if (ex) { failed = (ex & 2) != 0; converged = !failed; stop = true; break; } // uniform
             if (fcheck) {
                 const double f = fmax(fmax(fred[k & 1][0], fred[k & 1][1]), fmax(fred[k & 1][2], fred[k & 1][3]));
-                if (!(f > delta)) { converged = 1; stop = true; break; } // uniform; nothing of iteration k is published
+                if (!(f > delta)) { // uniform; nothing of iteration k is published -- only the mark that ends the waiting
+                    if (tid < 16) {
+#pragma unroll
+                        for (int i2 = 0; i2 < NSB; i2++) {
+                            const int sb2 = wg + i2 * G;
+                            if (sb2 < 4 * Nt)
+                                st_sc1(ring + (i64)((k + 1) & 3) * Tld + (i64)64 * (sb2 >> 2) + 16 * (sb2 & 3) + r16,
+                                       __longlong_as_double((long long)FLOW_FINISHED));
+                        }
+                    }
+                    converged = 1;
+                    stop = true;
+                    break;
+                }
             }
             if (tid < 16) { // the update first: it is what the other workgroups wait for
                 double S = red[k & 1][i][0][r16];
@@ -700,22 +837,22 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
                     tnew = tcur[i] + (eps * tcur[i]) * (wrow[i] / S - 1.0);
                     fr = fabs(wrow[i] - S);
                 }
-                st_sc1(ring + (i64)((k + 1) & 3) * Tld + row, tnew);
+                st_sc1_at(ring + (i64)((k + 1) & 3) * Tld, (unsigned)row, tnew);
                 tcur[i] = tnew;
                 fr = row16_max(fr);
-                if (r16 == 0) st_sc1(fq + (i64)(k % 3) * 4 * Nt + sb, fr);
-                st_sc1(ring + (i64)((k + 3) & 3) * Tld + row, sentinel());
-                if (r16 == 0) st_sc1(fq + (i64)((k + 1) % 3) * 4 * Nt + sb, sentinel());
+                if (r16 == 0) st_sc1_at(fq + (i64)(k % 3) * 4 * Nt, (unsigned)sb, fr);
+                st_sc1_at(ring + (i64)((k + 3) & 3) * Tld, (unsigned)row, sentinel());
+                if (r16 == 0) st_sc1_at(fq + (i64)((k + 1) % 3) * 4 * Nt, (unsigned)sb, sentinel());
             }
             if (reducer) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) { // arm the entries just read (their next writer is two iterations away)
                     const int q = qg + 16 * u;
-                    if (q < Nt) st_sc1(Pk + ((i64)b * Nt + q) * 64 + rib, sentinel());
+                    if (q < Nt) st_sc1_at(Pk, ((unsigned)b * (unsigned)Nt + (unsigned)q) * 64u + (unsigned)rib, sentinel());
                 }
             }
         }
-        if (wg >= 4 * Nt && bad) break; // no quarter block, no barrier in the loop: each wave leaves on its own
+        if (wg >= 4 * Nt && bad) { left_on = bad; break; } // no quarter block, no barrier in the loop: each wave leaves on its own
         if (stop) {
             if (converged && tid == 0) __hip_atomic_store(done, 1u, RLX_AGENT);
             break;
@@ -736,6 +873,165 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
         flags[2] = failed || !converged;
         flags[3] = 0;
     }
+#ifdef CGE_FLOW_CLOCK
+    const long long ck2 = wall_clock64();
+#endif
+    if (!FUSED) return;
+    // ---- the rest of the alpha's chain, from the tile and the final iterate --------------------------------------------------
+    // A workgroup with a quarter block left the loop as a whole, at iteration k (T_k is final).  A wave of a workgroup without
+    // one left on its own when it met the end mark / `done` while polling T_k: for it T_{k-1} is final.  T_final sits in its
+    // ring slot, complete and not re-armed: every tile consumed it, and the converging iteration published nothing.
+    // (lane ids the compiler cannot see through: nothing of the epilogue is computed ahead of the loop and kept in registers
+    // across it -- the loop runs at the 256-register limit)
+    int lane_e = lane, tid_e = tid;
+    asm volatile("" : "+v"(lane_e), "+v"(tid_e));
+    const cge_fit_fused *ep = fz.epi;
+    const int want = fz.want;
+    const int rq_e = lane_e >> 3, cq_e = lane_e & 7, wave_e = tid_e >> 6;
+    const bool wg_reduces = wg < 4 * Nt;
+    const bool ok = wg_reduces ? (converged != 0) : (left_on == 1 && k >= 1); // (wave-uniform; an abandoned fit computes nothing)
+    const int kfin = wg_reduces ? k : k - 1;
+    const double *Tf = (kfin == 0) ? T0 : ring + (i64)(kfin & 3) * Tld;
+    if ((want & 1) && ok) {
+        double(*R)[FLOW_RLD] = reinterpret_cast<double(*)[FLOW_RLD]>(rsh_all[wave_e]);
+        double *const partial = ep->partial; // (the one global load of this part, asked for ahead of the arithmetic)
+        {
+            constexpr int s = 0;
+            if (tI[s] >= 0) { // uniform per wave
+            const int I = tI[s], J = tJ[s];
+            const unsigned long long segI = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ehdr[wave_e][1]) << 32) |
+                                            (unsigned)__builtin_amdgcn_readfirstlane(ehdr[wave_e][0]);
+            const unsigned long long segJ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ehdr[wave_e][3]) << 32) |
+                                            (unsigned)__builtin_amdgcn_readfirstlane(ehdr[wave_e][2]);
+            // T_final of the tile's row and column block: what this wave staged for its last products (tsh is written once per
+            // iteration, after the poll that a finished fit never passes)
+            double ti[8], tj[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                ti[q] = tsh[wave_e][0][8 * rq_e + q];
+                tj[q] = tsh[wave_e][1][8 * cq_e + q];
+            }
+            // (a) pieces: a piece is a run of columns of one community inside this lane_e's 8-column chunk; its eight row sums
+            // (ascending column) go to R[piece][row].  pm: the columns that start a piece.
+            const unsigned long long pm = segJ | 0x0101010101010101ull;
+            const unsigned startb = (unsigned)(pm >> (8 * cq_e)) & 0xFFu, endb = (startb >> 1) | 0x80u;
+            int pc = __popcll(pm & ((1ull << (8 * cq_e)) - 1ull));
+            double cs[8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const bool st = (startb >> b) & 1u;
+#pragma unroll
+                for (int a = 0; a < 8; a++) {
+                    const bool dead = (I == J) && (8 * rq_e + a > 8 * cq_e + b); // the reference sums j >= i only (:229)
+                    const double pv = dead ? 0.0 : __dmul_rn(__dmul_rn(ti[a], tj[b]), g[s][a][b]);
+                    cs[a] = st ? pv : __dadd_rn(cs[a], pv);
+                }
+                if ((endb >> b) & 1u) {
+#pragma unroll
+                    for (int a = 0; a < 8; a++) R[pc][8 * rq_e + a] = cs[a];
+                    pc++;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // (b) lane = row: the pieces of a community's run, ascending, into the run's sum -> R[run][row].  All pieces are
+            // requested first (the tile's registers are free by now), so the adds do not each wait for an LDS round trip; a lane
+            // touches its own column of R only.
+            int nrunJ = 0;
+            {
+                const int npieces = __popcll(pm);
+                double xp[FLOW_NP];
+#pragma unroll
+                for (int q = 0; q < FLOW_NP; q++) xp[q] = q < npieces ? R[q][lane_e] : 0.0;
+                unsigned long long m = pm;
+                int run = -1;
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < FLOW_NP; q++) {
+                    if (q < npieces) { // uniform
+                        const int cpos = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        if ((segJ >> cpos) & 1ull) {
+                            if (run >= 0) R[run][lane_e] = acc;
+                            run++;
+                            acc = xp[q];
+                        } else
+                            acc = __dadd_rn(acc, xp[q]);
+                    }
+                }
+                R[run][lane_e] = acc;
+                nrunJ = run + 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // (c) lane = column run: the rows of a row run, ascending -> one partial per (row community, column community);
+            // again every operand is requested before the first add
+            {
+                const int run = lane_e < nrunJ ? lane_e : nrunJ - 1;
+                const i32 ccol = segtab[wave_e][1][run];
+                const bool live = lane_e < nrunJ && ccol >= 0;
+                const i32 fcI = __builtin_amdgcn_readfirstlane(ehdr[wave_e][4]), fcJ = __builtin_amdgcn_readfirstlane(ehdr[wave_e][5]),
+                          nsJ = __builtin_amdgcn_readfirstlane(ehdr[wave_e][6]);
+                double *out = partial + (i64)__builtin_amdgcn_readfirstlane(ehdr[wave_e][7]) + (ccol - fcJ);
+                double xr[64];
+#pragma unroll
+                for (int r = 0; r < 64; r += 2) {
+                    const dbl2f v2 = *reinterpret_cast<const dbl2f *>(&R[run][r]);
+                    xr[r] = v2.x;
+                    xr[r + 1] = v2.y;
+                }
+                double acc = 0.0;
+                int rrun = -1;
+                i32 crow = -1;
+#pragma unroll
+                for (int r = 0; r < 64; r++) { // uniform
+                    if ((segI >> r) & 1ull) {
+                        if (rrun >= 0 && crow >= 0 && live) out[(i64)(crow - fcI) * nsJ] = acc;
+                        rrun++;
+                        crow = segtab[wave_e][0][rrun];
+                        acc = xr[r];
+                    } else
+                        acc = __dadd_rn(acc, xr[r]);
+                }
+                if (crow >= 0 && live) out[(i64)(crow - fcI) * nsJ] = acc;
+            }
+            }
+        }
+    }
+#ifdef CGE_FLOW_CLOCK
+    const long long ck3 = wall_clock64();
+#endif
+    if ((want & 2) && wg_reduces) { // (`converged` is uniform over such a workgroup: the barriers below are safe)
+        double *sh = &rsh_all[0][0]; // >= 256 doubles; every wave_e is past its own use of it once the barrier below is passed
+        const int GR = G < 4 * Nt ? G : 4 * Nt;
+        __syncthreads();
+        for (int vb = wg; vb < CGE_PARTIAL_BLOCKS; vb += GR) { // uniform
+            double num = 0.0;
+            const i64 S = ep->S;
+            if (converged && tid_e < 256)
+                for (i64 q = (i64)vb * 256 + tid_e; q < S; q += (i64)CGE_PARTIAL_BLOCKS * 256) {
+                    // auc_landmark_kernel's arithmetic on the prepared operands (k_auc_prepare) and this launch's own powers
+                    i32 ix[4];
+                    double f[8];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) ix[u] = ep->aidx[u * S + q];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) f[u] = ep->afac[u * S + q];
+                    const double pp = ep->apw[q], pn = ep->apw[S + q], wq = ep->wts[q];
+                    const double t_i = ld_sc1(Tf + ix[0]), t_j = ld_sc1(Tf + ix[1]), t_u = ld_sc1(Tf + ix[2]), t_v = ld_sc1(Tf + ix[3]);
+                    const double ai = (t_i * f[0]) / f[1], aj = (t_j * f[2]) / f[3];
+                    const double au = (t_u * f[4]) / f[5], av = (t_v * f[6]) / f[7];
+                    const double pos = (ai * aj) * pp;
+                    const double neg = (au * av) * pn;
+                    num += (pos > neg ? 1.0 : 0.0) * wq;
+                }
+            num = flow_sum_256(num, sh, tid_e);
+            if (tid_e == 0 && converged) { ep->auc_part[2 * vb] = num; ep->auc_part[2 * vb + 1] = ep->aden[vb]; }
+        }
+    }
+#ifdef CGE_FLOW_CLOCK
+    if (lane_e == 0 && ((wg == 0 && wave_e == 0) || (wg == 130 && wave_e == 5)))
+        printf("flow clock wg %d wave %d: prologue %lld  loop %lld (%d iterations)  vect_B epilogue %lld  tallies %lld  (10 ns ticks)\n", wg, wave_e,
+               ck1 - ck0, ck2 - ck1, k, ck3 - ck2, wall_clock64() - ck3);
+#endif
 }
 
 // ---- one Chung-Lu iteration per launch pair, over the UPPER tiles only --------------------------------------------
@@ -1326,8 +1622,8 @@ static hipError_t launch_plain(const void *fn, int G, void **args, size_t lds, h
 // The default form of the undirected fit (fit_flow_kernel), enqueue only: T_0 is left alone, the result goes to `Tout`
 // (both Tld doubles, zero beyond N), the kernel's verdict {converged, iterations, failed, -} to `dev_flags`.  Nothing is
 // waited for.  false = this form does not apply (nothing was enqueued).
-bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,
-                        double eps, double delta, int *dev_flags) {
+// geometry of fit_flow_kernel for N vertices on this device; false: the form does not apply
+static bool flow_geometry(i64 N, i64 Tld, int *G_out, int *NW_out, int *tpw_out) {
     const int Nt = (int)((N + 63) / 64);
     const i64 NT = (i64)Nt * (Nt + 1) / 2;
     int dev = 0, cus = 0;
@@ -1345,11 +1641,37 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
     }
     // three tiles per wave: the counter form keeps the matrix without spills; a workgroup reduces at most two quarter blocks
     if (tpw > 2 || Nt > 64 || 4 * Nt > 2 * G) return false; // (a reducer adds up to 64 partial vectors)
+    *G_out = G; *NW_out = NW; *tpw_out = tpw;
+    return true;
+}
+bool k_fit_flow_fused_applies(cge_ctx *c, i64 N) {
+    int G = 0, NW = 0, tpw = 0;
+    return flow_geometry(N, (N + 63) / 64 * 64, &G, &NW, &tpw) && tpw == 1 && 4 * (int)((N + 63) / 64) <= G;
+}
+bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,
+                        double eps, double delta, int *dev_flags, const cge_fit_fused *ff, const cge_fit_fused *ff_dev) {
+    const bool fused = ff != nullptr;
+    FlowFused fz{};
+    if (fused) {
+        static_assert(CGE_FLOW_NP == FLOW_NP, "piece limit");
+        fz.Lh = ff->Lh; fz.Ll = ff->Ll; fz.alpha = ff->alpha;
+        fz.epi = ff_dev;
+        fz.want = (ff->partial ? 1 : 0) | (ff->auc_part ? 2 : 0);
+    }
+    const int Nt = (int)((N + 63) / 64);
+    int G = 0, NW = 0, tpw = 0;
+    if (!flow_geometry(N, Tld, &G, &NW, &tpw)) return false;
+    if (fused && (tpw != 1 || 4 * Nt > G)) return false; // (callers ask k_fit_flow_fused_applies first)
     const size_t psz = (size_t)Nt * Nt * 64, n_ring = (size_t)4 * Tld, n_fq = (size_t)3 * 4 * Nt;
     const size_t n_sync = 32; // fail / done words, armed with everything else
     c->fp_flow.ensure(n_sync + n_ring + n_fq + 2 * psz);
-    const void *fn = NW == 8 ? (const void *)fit_flow_kernel<1, 8>
-                             : (tpw == 1 ? (const void *)fit_flow_kernel<1, 4> : (const void *)fit_flow_kernel<2, 4>);
+    const bool one = 4 * Nt <= G; // every workgroup reduces at most one quarter block
+    const void *fn;
+#define FLOW_PICK(F, B) (NW == 8 ? (const void *)fit_flow_kernel<1, 8, F, B> \
+                                 : (tpw == 1 ? (const void *)fit_flow_kernel<1, 4, F, B> : (const void *)fit_flow_kernel<2, 4, F, B>))
+    if (fused) fn = NW == 8 ? (const void *)fit_flow_kernel<1, 8, true, 1> : (const void *)fit_flow_kernel<1, 4, true, 1>;
+    else fn = one ? FLOW_PICK(false, 1) : FLOW_PICK(false, 2);
+#undef FLOW_PICK
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * NW, 0) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
@@ -1368,7 +1690,7 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
     long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS; // per iteration (0: the test hook)
     int aNaps = c->opt_fit_test_delay;
     void *args[] = {&aGD, &aN, &aNt, &aT0, &aTout, &aTld, &aW, &aEps, &aDelta, &aMax, &aRing, &aP, &aFq, &aSync, &aFlags, &aTicks,
-                    &aNaps};
+                    &aNaps, &fz};
     hipError_t e;
     {
         ScopedKernelTimer tm(c, "fit_persistent");

@@ -152,9 +152,22 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     // (beyond 8192 vertices the sweep is relabelled anyway and the staged row-bin kernel no longer fits LDS: there the tile
     // form replaces the plain gather -- config 5, N = 12 000: 1.1 ms per alpha for the row bins alone)
     static const bool blocks_off = getenv("CGE_BVEC_BLOCKS") && atoi(getenv("CGE_BVEC_BLOCKS")) == 0;
-    const bool blocks = (blocks_env || c->opt_bvec_blocks || (N > 8192 && !blocks_off)) && c->opt_exact_relabel && N >= 256 && C >= 2 &&
-                        !c->opt_test_bvec_plain;
-    bool blocks_ok = blocks;
+    const bool blocks_req = (blocks_env || c->opt_bvec_blocks || (N > 8192 && !blocks_off)) && c->opt_exact_relabel && N >= 256 && C >= 2 &&
+                            !c->opt_test_bvec_plain;
+    // Round 5, the default in landmark mode wherever the undirected persistent fit runs with one tile per wave: the rest of
+    // an alpha's chain RIDES ON THE FIT'S LAUNCH (kernels_fitp.hip, fit_flow_kernel<.., true>: the power matrix in its
+    // prologue, vect_B's tile partials and the local score's tallies in its epilogue).  It needs the relabelled sweep and the
+    // tile tables below; option "fit_fused" = 0 / CGE_FIT_FUSED=0 keeps the separate launches (A/B, cross-check in the tests).
+    // Every undirected landmark-mode sweep of >= 256 landmarks is relabelled and sums vect_B by tiles then, whichever form of the
+    // fit runs (so that all forms add in the same order and give the same bits); the fused launch itself needs the default
+    // persistent form with one tile per wave.
+    static const bool fused_off_env = getenv("CGE_FIT_FUSED") && atoi(getenv("CGE_FIT_FUSED")) == 0;
+    const bool tiles_req = orig != nullptr && !directed && c->opt_fit_fused && !fused_off_env && c->opt_exact_relabel && N >= 256 &&
+                           C >= 2 && !c->opt_test_bvec_plain;
+    const bool fuse_req = tiles_req && !c->fit_persistent_broken && (c->opt_fit_persistent == 0 || c->opt_fit_persistent == 2) &&
+                          c->opt_pow_exp2 && k_fit_flow_fused_applies(c, N);
+    const bool blocks = blocks_req || tiles_req;
+    bool blocks_ok = blocks, pieces_ok = true;
     std::vector<i32> bt_fc, bt_ns, bt_base;
     if (blocks) { // per 64-vertex block of the relabelled graph: first community and number of communities; per tile: its partials
         const i64 Nt = (N + 63) / 64;
@@ -166,6 +179,14 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             bt_fc[b] = comm_new[64 * b];
             bt_ns[b] = comm_new[std::min<i64>(N, 64 * b + 64) - 1] - bt_fc[b] + 1;
             if (bt_ns[b] > 64) blocks_ok = false; // (empty communities in between: the row-bin form takes such a graph)
+            // the fused epilogue stages one "piece" per run of a community inside an 8-column chunk (the tail beyond N is a run)
+            int pieces = 0;
+            for (i64 q = 0; q < 64; q++) {
+                const i64 v = 64 * b + q, u = v - 1;
+                const i32 cv = v < N ? comm_new[v] : -1, cu = (q > 0) ? (u < N ? comm_new[u] : -1) : -2;
+                if ((q & 7) == 0 || cv != cu) pieces++;
+            }
+            if (pieces > CGE_FLOW_NP) pieces_ok = false;
         }
         i64 tot = 0;
         for (i64 I = 0; I < Nt && blocks_ok; I++)
@@ -182,6 +203,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             HIP_CHECK(hipStreamSynchronize(st)); // (the tables are locals)
         }
     }
+    bool fuse = fuse_req && blocks_ok && pieces_ok;
+    if (!blocks_req && !tiles_req) blocks_ok = false;
     const bool relabel = (N > 8192 && c->opt_exact_relabel) || blocks_ok;
     c->bvec_blocks = blocks_ok;
     c->bvec_contig = relabel && N >= 64 * C; // a wave per (row, community) pays off for communities of a wave's width or more
@@ -341,6 +364,37 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             k_remap_i32(c, ds.nj.p, d_old2new.p, S);
         }
 
+    // ---- the fused chain's table, one per sample set (device copies: the fit's epilogue loads them after its loop) ----------
+    constexpr i64 RES_AUC_EARLY = 0; // == RES_AUC below
+    const i64 fz_s0 = shard_samples ? S * c->coll.rank / c->coll.world : 0;
+    const i64 fz_s1 = shard_samples ? S * (c->coll.rank + 1) / c->coll.world : S;
+    const bool fuse_auc = landmarks && fz_s1 - fz_s0 < 65536 && fz_s1 > fz_s0; // (beyond: auc_landmark_kernel's wide form, as its own launch)
+    std::vector<cge_fit_fused> h_epi;
+    if (fuse) {
+        h_epi.resize(smp.n_sets);
+        for (i64 t = 0; t < smp.n_sets; t++) {
+            const DevSamples &ds = *dsets[t];
+            cge_fit_fused &e = h_epi[t];
+            e = cge_fit_fused{};
+            e.comm = G.comm; e.fc = c->sw_bt_fc.p; e.ns = c->sw_bt_ns.p; e.base = c->sw_bt_base.p; e.partial = c->sw_bt_part.p;
+            e.S = fz_s1 - fz_s0;
+            e.dpos = ds.dpos.p + fz_s0; e.dneg = ds.dneg.p + fz_s0; e.wts = ds.wts.p + fz_s0;
+            if (fuse_auc && e.S > 0) { // everything of the tally that depends neither on alpha nor on T, once
+                DevSamples &dsw = *dsets[t];
+                dsw.aidx.ensure((size_t)4 * e.S); dsw.afac.ensure((size_t)8 * e.S + CGE_PARTIAL_BLOCKS);
+                c->sw_fused_pw.ensure((size_t)2 * e.S);
+                k_auc_prepare(c, orig->v2l, d_old2new.p, orig->vw, orig->lweight, ds.pi.p + fz_s0, ds.pj.p + fz_s0, ds.ni.p + fz_s0,
+                              ds.nj.p + fz_s0, e.wts, e.S, dsw.aidx.p, dsw.afac.p, dsw.afac.p + 8 * e.S);
+                e.aidx = dsw.aidx.p; e.afac = dsw.afac.p; e.aden = dsw.afac.p + 8 * e.S; e.apw = c->sw_fused_pw.p;
+            }
+            e.auc_part = scal.p + RES_AUC_EARLY;
+        }
+        c->sw_fused_epi.ensure(h_epi.size() * sizeof(cge_fit_fused));
+        HIP_CHECK(hipMemcpyAsync(c->sw_fused_epi.p, h_epi.data(), h_epi.size() * sizeof(cge_fit_fused), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    c->stat_fit_fused = 0;
+
     // ---- alpha sweep ---------------------------------------------------------------------------
     int alpha_div_counter = 5, alpha_auc_counter = 5; // :38
     bool skip_div = false, skip_auc = false;
@@ -357,11 +411,13 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     // fit's verdict of an alpha land in slot (alpha index mod 2).
     struct AlphaSlot {
         bool fit_async = false, did_auc = false, did_div = false;
+        bool fused = false; // the rest of the chain rode on the fit's launch
         bool shared_verdict = false; // N > 1, tallies split: the verdict of the fit travelled with the all-reduced tallies
         int t0_par = 0;  // the half of TT that held T_0 of this alpha
         i64 iters = 0;
     } slots[2];
     // RES_VERD sits right behind the tallies: one all-reduce(sum) covers both (the slot after it only keeps RES_JS 16-byte aligned)
+    static_assert(RES_AUC_EARLY == 0, "");
     constexpr i64 RES_AUC = 0, RES_VERD = 2 * CGE_PARTIAL_BLOCKS, RES_JS = RES_VERD + 2, RES_FIT = RES_JS + 2 * CGE_PARTIAL_BLOCKS,
                   RES_LEN = RES_FIT + 2, RES_STRIDE = RES_FIT + 16;
     c->pin_scal.ensure(2 * RES_STRIDE);
@@ -376,7 +432,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     // dependencies per alpha (fit -> side stream, side stream -> next fit) cost more than the 36 us they hide.  Kept behind
     // CGE_POW_OVERLAP=1 for A/B; off by default.
     static const bool pow_overlap_env = getenv("CGE_POW_OVERLAP") && atoi(getenv("CGE_POW_OVERLAP")) != 0;
-    const bool pow_overlap = pow_overlap_env && (double)N * (double)N * 8.0 <= 2.0e9;
+    const bool pow_overlap = pow_overlap_env && !fuse && (double)N * (double)N * 8.0 <= 2.0e9;
     double *GDb[2] = {GD.p, GD.p};
     if (pow_overlap) {
         c->sw_GD2.ensure((size_t)N * N);
@@ -398,7 +454,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         // and the launch-per-iteration fits read whole rows
         const bool gd_upper = landmarks && !directed && (use_persistent || sym_fit);
         double *const GDc = GDb[pow_overlap ? (ia & 1) : 0]; // this alpha's matrix
-        if (pow_overlap && pow_ready_for == ia && pow_ready_upper == gd_upper)
+        const bool fused_now = fuse && use_persistent && c->pow_logs_N == N; // (a fallback in mid-sweep ends it: the matrix is needed then)
+        bool auc_done = false, bvec_partials = false;
+        if (fused_now) {
+        } else if (pow_overlap && pow_ready_for == ia && pow_ready_upper == gd_upper)
             HIP_CHECK(hipStreamWaitEvent(st, c->pow_ev[ia & 1], 0));
         else {
             if (pow_ready_for >= 0) HIP_CHECK(hipStreamSynchronize(c->copy_stream)); // (a stale pre-launch must not write under us)
@@ -418,8 +477,25 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             sl.t0_par = tpar;
             if (use_persistent) { // the whole fit in one launch, GD's upper triangle in registers (kernels_fitp.hip)
                 const int tnext = (tpar + 1) % 3;
-                if (fit_variant == 2 && k_fit_flow_enqueue(c, GDc, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld, Tld, G.vw,
-                                                           0.25, delta, (int *)(scal.p + RES_FIT))) {
+                cge_fit_fused ff{};
+                const cge_fit_fused *ffp = nullptr, *ffd = nullptr;
+                if (fused_now) {
+                    const i64 set = smp.n_sets == 1 ? 0 : ia - 1;
+                    ff = h_epi[set];
+                    ff.Lh = c->sw_Lh.p; ff.Ll = c->sw_Ll.p; ff.alpha = alpha;
+                    static const int parts_env = getenv("CGE_FUSE_PARTS") ? atoi(getenv("CGE_FUSE_PARTS")) : 3; // A/B: bit 0 vect_B, bit 1 local score
+                    if (!want_div || !(parts_env & 1)) ff.partial = nullptr;
+                    if (!(want_auc && fuse_auc) || !(parts_env & 2)) ff.auc_part = nullptr;
+                    ffp = &ff;
+                    ffd = reinterpret_cast<const cge_fit_fused *>(c->sw_fused_epi.p) + set;
+                }
+                if (fit_variant == 2 && k_fit_flow_enqueue(c, fused_now ? nullptr : GDc, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld,
+                                                           Tld, G.vw, 0.25, delta, (int *)(scal.p + RES_FIT), ffp, ffd)) {
+                    if (fused_now) {
+                        auc_done = ff.auc_part != nullptr;
+                        bvec_partials = ff.partial != nullptr;
+                        sl.fused = true;
+                    }
                     sl.fit_async = true; // the verdict is looked at when the alpha is collected
                     fitted = true;
                     tpar = tnext;
@@ -516,7 +592,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
 
         const double *Ta = directed ? Tout : Tcur, *Tb = directed ? Tin : Tcur;
         const double *Ta_auc = Ta, *Tb_auc = Tb;
-        if (want_auc && relabel && landmarks) { // v_to_l holds the landmark ids of the original numbering
+        if (want_auc && !auc_done && relabel && landmarks) { // v_to_l holds the landmark ids of the original numbering
             c->sw_rl_T.ensure((size_t)2 * N);
             k_permute_rows(c, Ta, d_old2new.p, N, 1, c->sw_rl_T.p);
             Ta_auc = Tb_auc = c->sw_rl_T.p;
@@ -525,7 +601,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                 Tb_auc = c->sw_rl_T.p + N;
             }
         }
-        if (want_auc) {
+        if (want_auc && !auc_done) {
             const DevSamples &ds = *dsets[smp.n_sets == 1 ? 0 : ia - 1];
             // N > 1 with many samples: rank r tallies the samples [S r / W, S (r + 1) / W) and the block tallies
             // are summed over the ranks -- the same array on every rank afterwards, so all ranks take the same early stops
@@ -550,12 +626,20 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             else cge_allreduce_dev(c, scal.p + RES_VERD, 1, 0);
         }
         if (want_div) {
-            k_bvec(c, GDc, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
-            if (!split)
-                k_js(c, G.vectC, vectB.p, vlen, C, directed, 0, nullptr, scal.p + RES_JS);
-            else {
-                k_js(c, G.vectC, vectB.p, vlen, C, directed, 1, nullptr, scal.p + RES_JS);
-                k_js(c, G.vectC, vectB.p, vlen, C, directed, 2, nullptr, scal.p + RES_JS + CGE_PARTIAL_BLOCKS);
+            static const bool one_js_off = getenv("CGE_BINS_JS") && atoi(getenv("CGE_BINS_JS")) == 0; // A/B: the separate launches
+            if ((bvec_partials || c->bvec_blocks) && !directed && !c->opt_test_bvec_plain && !one_js_off) {
+                // tile partials (from the fit's epilogue, or one pass over GD) -> vect_B and its divergence(s) in one launch
+                if (!bvec_partials) k_bvec_tiles(c, GDc, Ta, Tb, d_cm_off.p, N, directed);
+                k_bins_js(c, d_cm_off.p, N, C, G.vectC, vectB.p, split ? 2 : 1, scal.p + RES_JS);
+            } else {
+                if (bvec_partials) k_bvec_bins(c, d_cm_off.p, N, C, directed, vectB.p); // the tile partials came with the fit
+                else k_bvec(c, GDc, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
+                if (!split)
+                    k_js(c, G.vectC, vectB.p, vlen, C, directed, 0, nullptr, scal.p + RES_JS);
+                else {
+                    k_js(c, G.vectC, vectB.p, vlen, C, directed, 1, nullptr, scal.p + RES_JS);
+                    k_js(c, G.vectC, vectB.p, vlen, C, directed, 2, nullptr, scal.p + RES_JS + CGE_PARTIAL_BLOCKS);
+                }
             }
         }
         // the block partials of the alpha's reductions and (behind them) the verdict of an enqueued fit, one copy; the host
@@ -604,6 +688,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             sl.iters = hf[1];
             prev_iters = sl.iters;
             c->stat_fit_persistent++;
+            if (sl.fused) c->stat_fit_fused++;
         }
         const i64 iters = sl.iters;
         c->stat_fit_iters += iters;

@@ -12,7 +12,7 @@ The graphs are bench.py's workloads (`cge.jl_amd.synth.abcd_like(n, 1.05 m, C, d
 `conftest.random_samples(default_rng(42), m, n, S)`; the GPU test regenerates both, so only expected OUTPUTS are stored
 (checksums for the big arrays).
 
-usage: python tests/golden/make_oracle_fixture_fullsize.py headline|cfg3|cfg4|cfg3_size|small
+usage: python tests/golden/make_oracle_fixture_fullsize.py headline|cfg3|cfg4|cfg3_size|small|cfg5_200k|cfg2_d128
 """
 import os
 import sys
@@ -39,6 +39,12 @@ WORKLOADS = {  # == bench.py WORKLOADS
     # fixtures do not reach; its diameter is config 3's (same embedding), taken from oracle_cfg3.npz when that exists
     "cfg3_size": dict(n=1_000_000, m=20_000_000, C=500, d=128, land=4000, forced=4, method="size", samples=10000,
                       same_graph_as="cfg3"),
+    # config 5's own shape at the size the GPU test budget allows (tests/test_gpu_configs.py::
+    # test_config5_d512_twelve_thousand_landmarks): 12 000 landmarks at d = 512, eigenvectors from LAPACK's syevr
+    "cfg5_200k": dict(n=200_000, m_exact=4_200_000, C=1500, d=512, land=12000, forced=4, method="rss", samples=10000,
+                      lapack=True),
+    # config 2's graph with a 128-wide embedding under rss2: groups of >= 5000 rows through the d > 64 chain kernel
+    "cfg2_d128": dict(n=100_000, m=1_000_000, C=50, d=128, land=400, forced=4, method="rss2", samples=10000),
 }
 
 
@@ -50,7 +56,9 @@ def main(name):
     c = WORKLOADS[name]
     directed = bool(c.get("directed", False))
     t0 = time.time()
-    g = synth.abcd_like(c["n"], int(c["m"] * 1.05), c["C"], c["d"], seed=42, directed=directed)
+    if c.get("lapack"):
+        orc.use_lapack_eig(True)  # the routine Julia's eigvecs calls; Jacobi at d = 512 is minutes per matrix
+    g = synth.abcd_like(c["n"], c.get("m_exact") or int(c["m"] * 1.05), c["C"], c["d"], seed=42, directed=directed)
     print(f"[{name}] graph n={g['n']} m={g['m']} ({time.time() - t0:.0f} s)", flush=True)
     t0 = time.time()
     twin = os.path.join(ROOT, "tests", "golden", f"oracle_{c.get('same_graph_as', '')}.npz")
@@ -79,7 +87,8 @@ def main(name):
         os.path.join(ROOT, "tests", "golden", f"oracle_{name}.npz"),
         provenance=np.array(f"oracle/cge_oracle.c (CPU restatement) via tests/golden/make_oracle_fixture_fullsize.py {name}; "
                             f"diameter from tests/diameter_ref.py ({t_hi:.0f} s), landmarks {t_lm:.0f} s, score {t_sc:.0f} s, "
-                            "one core"),
+                            "one core" + ("; eigenvectors: LAPACK syevr (oracle.use_lapack_eig), the routine Julia's eigvecs calls"
+                                          if c.get("lapack") else "")),
         n=g["n"], m=g["m"], N=len(dii), v_to_l_crc=crc(v2l.astype(np.int32)), landmark_sizes=np.bincount(v2l)[1:],
         v_to_l_sample=v2l[::997].astype(np.int32), dii=dii, lweight=lweight, lcomm=lcomm[:, 0], lemb_crc=crc(lemb),
         ledges_crc=crc(ledges), lw_crc=crc(lw), n_ledges=len(lw), edges_crc=crc(g["edges"]), emb_crc=crc(g["embedding"]),

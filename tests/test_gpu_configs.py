@@ -167,6 +167,30 @@ def test_config2_rss2_full_size_against_oracle_fixture(ctx):
     assert float(fx["hi"]) == ctx.last_diameter()[0]  # here the fixture's diameter is the oracle's own O(n^2 d) loop
 
 
+def test_config2_graph_d128_rss2_long_groups_against_oracle_fixture(ctx):
+    """config 2's graph with a 128-wide embedding under rss2 (oracle_cfg2_d128.npz): groups of >= 5000 rows through the
+    64 < d <= 128 form of the chain kernel (rss2_chain_lds_kernel<2,4>: one row buffer, many rounds) -- src/landmarks.jl:92-147."""
+    from cge.jl_amd import synth
+
+    fx = _fixture("cfg2_d128")
+    g = synth.abcd_like(100_000, 1_050_000, 50, 128, seed=42)
+    assert g["n"] == int(fx["n"]) and g["m"] == int(fx["m"]) and crc(g["edges"]) == int(fx["edges_crc"]) and \
+        crc(g["embedding"]) == int(fx["emb_crc"]), "the synthetic generator no longer reproduces the fixture's graph"
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    ctx.set_option("diameter", 0)
+    res = ctx.score(g["clusters"], 400, 4, "rss2", seed=42, auc_samples=10000)
+    tr = ctx.last_trace
+    assert ctx.last_diameter()[0] == float(fx["hi"])
+    lm = _check_landmarks(ctx, fx)
+    assert max(len(c) for c in g["clusters"]) >= 5000  # the first splits of such a community are chains over thousands of rows
+    _check_sweep(res, tr, fx, same_samples=False)
+    assert np.array_equal(res, ctx.score(g["clusters"], 400, 4, "rss2", seed=42, auc_samples=10000))
+    smp = random_samples(np.random.default_rng(42), g["m"], g["n"], 10000)
+    res_h = ctx.wgcl(lm[3], lm[4], lm[2], lm[1], lm[0], lm[5], g["vweights"], lm[6], None, None, None, False, auc_samples=10000,
+                     directed=False, samples=smp, use_resident_original=True)
+    _check_sweep(res_h, ctx.last_trace, fx, same_samples=True)
+
+
 def test_headline_full_size_against_oracle_fixture(ctx):
     """BASELINE.json metric workload: 10^6 vertices, ~10^7 edges, d = 128, -l 4000 -m rss."""
     _run_config(ctx, "headline")
@@ -360,11 +384,13 @@ def test_config5_full_size_ten_million_vertices():
 
 
 def test_config5_d512_twelve_thousand_landmarks(ctx):
-    """configs[4] (ABCD 10M / 200M, d = 512, -l 12000) at the shape the test budget allows: n = 200 000 vertices, 4.2M edges,
-    1500 communities, d = 512, 12 000 landmarks, i.e. the code paths of that configuration (the batched eigen-solver for
-    128 < d <= 512, the fp32-MFMA bound pass at K = 512, 12 000-landmark sweep on the launch-per-iteration fit) -- the
-    full-size run is `bench.py --workload cfg5` (the 41 GB embedding is generated in HBM).  No oracle can do 12 000 splits
-    at d = 512 in test time, so: the reference's invariants, the exact diameter against the CPU branch and bound,
+    """configs[4] (ABCD 10M / 200M, d = 512, -l 12000) at the shape the test budget allows: n = 200 000 vertices, 4.2M edges
+    asked for, 1500 communities, d = 512, 12 000 landmarks, i.e. the code paths of that configuration (the batched eigen-solver
+    for 128 < d <= 512, the fp32-MFMA bound pass at K = 512, the 12 000-landmark sweep on the launch-per-iteration fit, vect_B
+    by tiles) -- the full-size run is `bench.py --workload cfg5` (the 41 GB embedding is generated in HBM).  Round 5: PINNED
+    against the oracle's run of exactly this graph (tests/golden/oracle_cfg5_200k.npz, make_oracle_fixture_fullsize.py
+    cfg5_200k: 12 000 splits with LAPACK's syevr eigenvectors, 16 CPU-minutes) -- raw landmark ids, d_ii, weights, communities,
+    checksums, iteration counts, the 7-vector and its traces -- plus: the exact diameter against the CPU branch and bound,
     pruned == brute force, fp32 bound pass == fp64 bound pass, host upload == device-pointer upload, reproducible bits."""
     import torch
 
@@ -398,6 +424,17 @@ def test_config5_d512_twelve_thousand_landmarks(ctx):
     best = int(np.nanargmin(tr["div"]))
     assert res[1] == tr["div"][best] and res[0] == 0.25 * (best + 1) and all(it >= 1 for it in tr["iters"])
     assert np.array_equal(res, ctx.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000))
+    # the oracle's run of this graph (src/landmarks.jl:160-209, :279-345; src/divergence.jl:139-256)
+    fx = _fixture("cfg5_200k")
+    assert g["n"] == int(fx["n"]) and g["m"] == int(fx["m"]) and crc(g["edges"]) == int(fx["edges_crc"]) and \
+        crc(g["embedding"]) == int(fx["emb_crc"]), "the synthetic generator no longer reproduces the fixture's graph"
+    assert hi == float(fx["hi"])
+    lm = _check_landmarks(ctx, fx)
+    _check_sweep(res, tr, fx, same_samples=False)
+    smp = random_samples(np.random.default_rng(42), g["m"], g["n"], 10000)
+    res_h = ctx.wgcl(lm[3], lm[4], lm[2], lm[1], lm[0], lm[5], g["vweights"], lm[6], None, None, None, False, auc_samples=10000,
+                     directed=False, samples=smp, use_resident_original=True)
+    _check_sweep(res_h, ctx.last_trace, fx, same_samples=True)
     try:  # bound pass in fp64, then brute force: the same diameter bits, the same score
         ctx.set_option("diameter_f32", 0)
         assert np.array_equal(res, ctx.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000))

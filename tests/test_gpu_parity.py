@@ -1446,3 +1446,95 @@ def test_two_lanes_with_late_member_lists(ctx, method):
     finally:
         ctx.set_option("runsplit_lanes_test_delay", 0)
         ctx.set_option("runsplit_lanes", 1)
+
+
+def _fused_case(seed=21, n=30000, C=24, d=24):
+    from cge.jl_amd import synth
+
+    g = synth.abcd_like(n, 10 * n, C, d, seed=seed)
+    rng = np.random.default_rng(seed)
+    ew = rng.integers(1, 17, size=len(g["eweights"])) / 4.0  # dyadic weights: order-free scatter sums
+    vw = np.zeros(n)
+    np.add.at(vw, g["edges"][:, 0] - 1, ew)
+    np.add.at(vw, g["edges"][:, 1] - 1, ew)
+    return g, ew, vw
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_fused_alpha_chain_equals_separate_launches_and_oracle(ctx, orc, split):
+    """Round 5: in landmark mode the power matrix, vect_B's tile sums and the local score's tallies ride on the launch of the
+    persistent fit (kernels_fitp.hip, fit_flow_kernel<.., true>; src/divergence.jl:146, :170-213, :226-241).  The same sweep with
+    the separate launches on the same relabelled graph (`fit_fused` = 0, `bvec_blocks` = 1: exp2 matrix, fit, auc_landmark,
+    bvec_tile + bins, js) must give the SAME BITS -- vector, both traces, iteration counts -- and both agree with the oracle."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api
+
+    g, ew, vw = _fused_case()
+    args_lm = (g["edges"], ew, vw, g["clusters"], g["comm"], g["embedding"], False, 1000, 4, "rss", False)
+    lm = cg.landmarks(*args_lm, ctx=ctx)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+    smp = api.draw_samples(ctx, 9, 6000)
+    wargs = (ledges, lw, lcomm, lemb, dii, lweight, vw, v2l, g["edges"], ew, g["embedding"], split)
+    try:
+        res, tr = cg.wGCL(*wargs, 9, 6000, samples=smp, trace=True, ctx=ctx)
+        n_fused = ctx.get_stat("fit_fused_alphas")
+        assert n_fused == tr["n_alpha"] and ctx.get_stat("fit_persistent_alphas") == n_fused  # every alpha rode on its fit
+        ctx.set_option("fit_fused", 0)
+        ctx.set_option("bvec_blocks", 1)
+        res2, tr2 = cg.wGCL(*wargs, 9, 6000, samples=smp, trace=True, ctx=ctx)
+        assert ctx.get_stat("fit_fused_alphas") == 0 and ctx.get_stat("fit_persistent_alphas") == tr2["n_alpha"]
+        assert np.array_equal(res, res2) and tr["iters"] == tr2["iters"]
+        assert np.array_equal(tr["div"], tr2["div"], equal_nan=True) and np.array_equal(tr["auc"], tr2["auc"], equal_nan=True)
+        ctx.set_option("bvec_blocks", 0)  # the graph as given, vect_B by row bins: another order of the same sums
+        res3, tr3 = cg.wGCL(*wargs, 9, 6000, samples=smp, trace=True, ctx=ctx)
+        assert tr3["iters"] == tr["iters"] and np.allclose(res3, res, rtol=1e-12, atol=1e-15)
+    finally:
+        ctx.set_option("fit_fused", 1)
+        ctx.set_option("bvec_blocks", 0)
+    exp, etr = orc.wGCL(*wargs, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
+    if split:
+        assert res[2] > 0.0 and res[3] > 0.0
+
+
+def test_fused_alpha_chain_abandoned_and_late_launches(ctx):
+    """The fused launch under the two testing knobs of the persistent fits: tile waves that start late (same bits), and a
+    launch that gives up at once (nothing of its epilogue may be used: the alpha is redone with one launch per iteration,
+    which needs the power matrix the fused form never wrote)."""
+    g, ew, vw = _fused_case(seed=22, n=20000, C=16, d=16)
+    ctx.set_inputs(g["edges"], ew, vw, g["comm"], g["embedding"])
+    try:
+        ref = ctx.score(g["clusters"], 700, 4, "size", seed=5, auc_samples=4000)
+        it_ref = list(ctx.last_trace["iters"])
+        assert ctx.get_stat("fit_fused_alphas") == len(it_ref)
+        ctx.set_option("fit_persistent_test_delay", 20)
+        got = ctx.score(g["clusters"], 700, 4, "size", seed=5, auc_samples=4000)
+        assert ctx.get_stat("fit_fused_alphas") == len(it_ref) and list(ctx.last_trace["iters"]) == it_ref
+        assert np.array_equal(got, ref)
+        ctx.set_option("fit_persistent_test_delay", 0)
+        ctx.set_option("fit_persistent_test_timeout", 1)
+        got = ctx.score(g["clusters"], 700, 4, "size", seed=5, auc_samples=4000)
+        assert ctx.get_stat("fit_fused_alphas") == 0 and ctx.get_stat("fit_persistent_alphas") == 0  # (nothing of the fused tries counts)
+        assert list(ctx.last_trace["iters"]) == it_ref and np.allclose(got, ref, rtol=1e-11, atol=1e-14)
+    finally:
+        ctx.set_option("fit_persistent_test_delay", 0)
+        ctx.set_option("fit_persistent_test_timeout", 0)
+
+
+def test_fused_alpha_chain_declined_for_many_tiny_communities(ctx, orc):
+    """More runs of communities in a 64-landmark block than the fused epilogue stages (CGE_FLOW_NP pieces): the sweep keeps the
+    separate launches -- and still matches the oracle."""
+    import cge.jl_amd as cg
+    from cge.jl_amd import api, synth
+
+    g = synth.abcd_like(12000, 90000, 400, 12, seed=8)  # 400 communities of ~30 vertices: -f 1 gives one or two landmarks each
+    args_lm = (g["edges"], g["eweights"], g["vweights"], g["clusters"], g["comm"], g["embedding"], False, 500, 1, "rss", False)
+    lm, ref = cg.landmarks(*args_lm, ctx=ctx), orc.landmarks(*args_lm)
+    _check_landmarks(lm, ref)
+    dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
+    smp = api.draw_samples(ctx, 4, 3000)
+    wargs = (ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, g["edges"], g["eweights"], g["embedding"], False)
+    res, tr = cg.wGCL(*wargs, 4, 3000, samples=smp, trace=True, ctx=ctx)
+    assert ctx.get_stat("fit_fused_alphas") == 0 and ctx.get_stat("fit_persistent_alphas") == tr["n_alpha"]
+    exp, etr = orc.wGCL(*wargs, smp, trace=True)
+    _cmp_result(res, exp, tr, etr)
