@@ -54,11 +54,10 @@ static void flush_timers(cge_ctx *c) {
 // buffer while chunk k-1 is on the wire from the other (a plain hipMemcpy from pageable memory is a single-threaded
 // bounce copy).  fill(dst, e0, e1) writes elements [e0, e1) of the output into `dst` (e1 - e0 <= chunk) and may be
 // called from several threads on disjoint sub-ranges.
-template <typename T, typename F>
-static void staged_upload(cge_ctx *c, T *dev, size_t total, F fill) {
-    const size_t chunk = CGE_STAGE_BYTES / sizeof(T);
+template <typename T, typename F, typename A>
+static void staged_upload_chunks(cge_ctx *c, T *dev, size_t total, size_t chunk, size_t dev_ring, F fill, A after) {
     for (int b = 0; b < 2; b++) c->stage[b].ensure(CGE_STAGE_BYTES);
-    const int nt = std::max(1, c->n_threads);
+    const int nt = std::max(1, std::min(c->n_threads, 8)); // (more fill threads than that slow the link down: profiles/r05_microbench_upload.txt)
     for (size_t off = 0, k = 0; off < total; off += chunk, k++) {
         const int b = (int)(k & 1);
         if (k >= 2) HIP_CHECK(hipEventSynchronize(c->stage_ev[b])); // the copy that last read this buffer is done
@@ -70,10 +69,20 @@ static void staged_upload(cge_ctx *c, T *dev, size_t total, F fill) {
             if (e > a) fill(dst + a, off + a, off + e);
         };
         c->pool->run(nt, job);
-        HIP_CHECK(hipMemcpyAsync(dev + off, dst, sizeof(T) * len, hipMemcpyHostToDevice, c->stream));
+        T *where = dev_ring ? dev + (k % dev_ring) * chunk : dev + off; // (a ring on the device: `after` consumes the chunk in stream order)
+        HIP_CHECK(hipMemcpyAsync(where, dst, sizeof(T) * len, hipMemcpyHostToDevice, c->stream));
         HIP_CHECK(hipEventRecord(c->stage_ev[b], c->stream));
+        after(where, off, len);
     }
     HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+template <typename T, typename F>
+static void staged_upload(cge_ctx *c, T *dev, size_t total, F fill) {
+    // at least ~8 chunks, so that the fill of one overlaps the copy of the one before it (a 40 MB column of edge ids in one
+    // 64 MiB chunk would be filled, then copied), of at least 2 MiB, at most a staging buffer
+    const size_t cap = CGE_STAGE_BYTES / sizeof(T), lo = ((size_t)2 << 20) / sizeof(T);
+    const size_t chunk = std::min(cap, std::max(lo, (total + 7) / 8));
+    staged_upload_chunks<T>(c, dev, total, chunk, 0, fill, [](T *, size_t, size_t) {});
 }
 
 // host mirror of the row-major embedding: only the generic round-based rss path (ties at the maximum of z, NaNs) and the
@@ -117,6 +126,18 @@ int cge_create(cge_ctx **out, int device, void *stream) {
         unsigned hc = std::thread::hardware_concurrency();
         c->n_threads = (int)std::max(1u, std::min(hc ? hc : 8u, 16u));
         c->pool = new ThreadPool(c->n_threads - 1);
+        // the pinned staging buffers of the uploads: made here, once per context, not inside the first cge_set_graph (pinning
+        // 128 MiB is ~10 ms of page work that has nothing to do with any graph)
+        for (int b = 0; b < 2; b++) c->stage[b].ensure(CGE_STAGE_BYTES);
+        { // ... and the copy path itself walked once (the first host-to-device copy of a process sets up the DMA queues)
+            DevBuf<unsigned char> warm;
+            warm.ensure((size_t)1 << 20);
+            for (int b = 0; b < 2; b++) {
+                memset(c->stage[b].p, 0, (size_t)1 << 20);
+                HIP_CHECK(hipMemcpyAsync(warm.p, c->stage[b].p, (size_t)1 << 20, hipMemcpyHostToDevice, c->stream));
+            }
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
         if (const char *nap = getenv("CGE_FIT_TEST_DELAY")) { // stress runs of whole suites: option fit_persistent_test_delay for
             // every context.  A testing knob in a production path: clamped to 2000 naps (~6 ms, far below the 1 s hand-off
             // deadline, so it can never force the time-out path) and announced once per process.
@@ -432,10 +453,26 @@ int cge_set_embedding(cge_ctx *c, const double *X, int64_t n, int64_t d) {
         embedding_resident(c, n, d);
         return CGE_OK;
     }
-    col.alloc_exact((size_t)n * d);
-    staged_upload<double>(c, col.p, (size_t)n * d, [&](double *o, size_t e0, size_t e1) { memcpy(o, X + e0, sizeof(double) * (e1 - e0)); });
+    // The caller's column-major matrix goes up in chunks of whole columns (of row pieces of one column, when a column is
+    // longer than a staging buffer); every chunk is transposed into its place of the row-major Xr right behind its copy, on the
+    // stream, while the next chunk is on the wire: no n x d column-major device buffer, no separate transpose pass.
     c->Xr.alloc_exact((size_t)n * d);
-    k_transpose_to_rowmajor(c, col.p, c->Xr.p, n, d);
+    const size_t cap = CGE_STAGE_BYTES / sizeof(double);
+    if ((size_t)n <= cap) {
+        const size_t kc = std::min<size_t>((size_t)d, cap / (size_t)n), chunk = kc * (size_t)n; // whole columns per chunk
+        col.alloc_exact(2 * chunk);
+        staged_upload_chunks<double>(c, col.p, (size_t)n * d, chunk, 2,
+                                     [&](double *o, size_t e0, size_t e1) { memcpy(o, X + e0, sizeof(double) * (e1 - e0)); },
+                                     [&](double *piece, size_t off, size_t len) {
+                                         k_transpose_piece(c, piece, c->Xr.p, n, (i64)(len / (size_t)n), 0, (i64)(off / (size_t)n), d);
+                                     });
+    } else { // one column in row pieces
+        col.alloc_exact(2 * cap);
+        for (i64 k = 0; k < d; k++)
+            staged_upload_chunks<double>(c, col.p, (size_t)n, cap, 2,
+                                         [&](double *o, size_t e0, size_t e1) { memcpy(o, X + (size_t)k * n + e0, sizeof(double) * (e1 - e0)); },
+                                         [&](double *piece, size_t off, size_t len) { k_transpose_piece(c, piece, c->Xr.p, (i64)len, 1, (i64)off, k, d); });
+    }
     HIP_CHECK(hipStreamSynchronize(c->stream));
     col.release();
     embedding_resident(c, n, d);

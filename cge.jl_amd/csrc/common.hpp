@@ -590,13 +590,14 @@ static inline unsigned grid_for(i64 work, int block, i64 cap = 256 * 8) {
     return (unsigned)g;
 }
 
-#define CGE_STAGE_BYTES ((size_t)16 << 20) // one staging buffer of the uploads
+#define CGE_STAGE_BYTES ((size_t)64 << 20) // one staging buffer of the uploads (profiles/r05_microbench_upload.txt: 64 MiB chunks reach the link's 54-57 GB/s)
 void cge_ensure_host_embedding(cge_ctx *c); // capi.cpp: fetch the host mirror of Xr on first demand
 cge_ctx *cge_shadow_context(cge_ctx *c, cge_ctx **slot, bool low_priority); // capi.cpp: create / refresh c->side or c->lane
 
 // ---- kernels_*.hip entry points (host launchers) ---------------------------------------------
 // layout
 void k_transpose_to_rowmajor(cge_ctx *c, const double *Xcol, double *Xrow, i64 n, i64 d);
+void k_transpose_piece(cge_ctx *c, const double *piece, double *Xrow, i64 rows, i64 cols, i64 i0, i64 k0, i64 d); // rows [i0, i0 + rows) x columns [k0, k0 + cols), column-major piece -> its place in the row-major matrix
 void k_row_hash(cge_ctx *c, const double *Xrow, uint64_t *hash, i64 n, i64 d);
 i64 k_count_distinct(cge_ctx *c, const uint64_t *hash, i64 n); // distinct values among the hashes (device set; synchronises)
 // landmark split primitives (batched over tasks; rows = concatenated 0-based vertex ids)

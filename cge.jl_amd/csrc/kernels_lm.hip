@@ -84,24 +84,31 @@ void k_wave_tree_test(cge_ctx *c, const double *x, i64 n_rows, double *out_ref, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// column-major (n x d, Julia) -> row-major (node-major).  32x32 tiles through LDS.
-__global__ void transpose_kernel(const double *__restrict__ Xcol, double *__restrict__ Xrow, i64 n, i64 d) {
+// column-major (n x d, Julia) -> row-major (node-major).  32x32 tiles through LDS.  The source may be a PIECE of the matrix --
+// rows [i0, i0 + rows) of the columns [k0, k0 + cols), column-major with leading dimension `rows` -- as the chunks of the
+// embedding's upload arrive (cge_set_embedding transposes every chunk behind its copy: no n x d column-major device buffer
+// and no separate pass over it).
+__global__ void transpose_kernel(const double *__restrict__ Xcol, double *__restrict__ Xrow, i64 rows, i64 cols, i64 i0, i64 k0, i64 d) {
     __shared__ double tile[32][33];
-    i64 i0 = (i64)blockIdx.x * 32, k0 = (i64)blockIdx.y * 32;
+    i64 ib = (i64)blockIdx.x * 32, kb = (i64)blockIdx.y * 32;
     int tx = threadIdx.x, ty = threadIdx.y; // 32 x 8
     for (int r = ty; r < 32; r += 8) {
-        i64 i = i0 + tx, k = k0 + r;
-        if (i < n && k < d) tile[r][tx] = Xcol[i + k * n];
+        i64 i = ib + tx, k = kb + r;
+        if (i < rows && k < cols) tile[r][tx] = Xcol[i + k * rows];
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
-        i64 i = i0 + r, k = k0 + tx;
-        if (i < n && k < d) Xrow[i * d + k] = tile[tx][r];
+        i64 i = ib + r, k = kb + tx;
+        if (i < rows && k < cols) Xrow[(i0 + i) * d + k0 + k] = tile[tx][r];
     }
 }
 void k_transpose_to_rowmajor(cge_ctx *c, const double *Xcol, double *Xrow, i64 n, i64 d) {
     dim3 grid((unsigned)((n + 31) / 32), (unsigned)((d + 31) / 32));
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, c->stream, Xcol, Xrow, n, d);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, c->stream, Xcol, Xrow, n, d, (i64)0, (i64)0, d);
+}
+void k_transpose_piece(cge_ctx *c, const double *piece, double *Xrow, i64 rows, i64 cols, i64 i0, i64 k0, i64 d) {
+    dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, c->stream, piece, Xrow, rows, cols, i0, k0, d);
 }
 
 // ------------------------------------------------------------------------------------------------
