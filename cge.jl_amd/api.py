@@ -72,6 +72,13 @@ class Collectives(C.Structure):
     _fields_ = [("allreduce_f64", ALLREDUCE_FN), ("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int)]
 
 
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)  # (user, buf, words per rank): all-gather / reduce-scatter
+
+
+class CollectivesExt(C.Structure):
+    _fields_ = [("allgather", GATHER_FN), ("reduce_scatter_f64", GATHER_FN)]
+
+
 # Live contexts are closed from an `atexit` hook: it runs inside Py_Finalize, i.e. BEFORE the C-level exit handlers
 # of the HIP runtime and of a profiler's tool library, so no stream or event of this library is left for the runtime to
 # destroy after a profiler has finalised its HSA hooks.  DEFENCE IN DEPTH ONLY: it is NOT an established fix for the
@@ -458,6 +465,14 @@ class Context:
         coll = Collectives(cb, None, rank, world)
         self._keep = [cb, coll]
         self._check(self.L.cge_set_collectives(self.h, C.byref(coll)))
+
+    def set_collectives_ext(self, allgather=None, reduce_scatter=None):
+        """Optional further ops of the hook (include/cge_hip.h: cge_collectives_ext); call after set_collectives."""
+        ag = GATHER_FN(allgather) if allgather else GATHER_FN()
+        rs = GATHER_FN(reduce_scatter) if reduce_scatter else GATHER_FN()
+        ext = CollectivesExt(ag, rs)
+        self._keep = list(getattr(self, "_keep", [])) + [ag, rs, ext]
+        self._check(self.L.cge_set_collectives_ext(self.h, C.byref(ext)))
 
     def clear_collectives(self):
         """Back to a single-rank context: the in-library communicator is released and the hook removed."""

@@ -200,10 +200,17 @@ int cge_set_collectives(cge_ctx *c, const cge_collectives *coll) {
     if (!c) return CGE_E_ARG;
     if (!coll || !coll->allreduce_f64 || coll->world <= 1) {
         c->has_coll = false;
+        c->coll_ext = cge_collectives_ext{};
         return CGE_OK;
     }
     c->coll = *coll;
+    c->coll_ext = cge_collectives_ext{};
     c->has_coll = true;
+    return CGE_OK;
+}
+int cge_set_collectives_ext(cge_ctx *c, const cge_collectives_ext *ext) {
+    if (!c) return CGE_E_ARG;
+    c->coll_ext = ext ? *ext : cge_collectives_ext{};
     return CGE_OK;
 }
 
@@ -731,10 +738,25 @@ static void scatter_wedges(cge_ctx *c, int directed) {
         // on row blocks (the count below, the directed score's degrees); landmarks_fetch all-gathers the blocks when the host
         // asks for the edge list.  Through the hook (gloo tests) or a librccl without the symbol: an all-reduce.
         if (Npad > N) HIP_CHECK(hipMemsetAsync(c->wedges.p + (size_t)N * N, 0, sizeof(double) * (size_t)(Npad - N) * N, st));
-        if (c->rccl_comm && cge_rccl_reduce_scatter(c, c->wedges.p, per * N))
-            c->wedges_block_only = true;
-        else
-            allreduce(c, c->wedges.p, N * N, 0);
+        // Option "wedges_reduce_scatter" (default 0: the all-reduce, after which every consumer -- cge_landmarks_fetch on ONE
+        // rank included -- is local).  With it the matrix goes out by row blocks; the consumers then work on blocks, and a
+        // fetch of the edge list is COLLECTIVE (every rank must call it: the blocks are all-gathered).
+        bool by_blocks = false;
+        if (c->opt_wedges_rs) {
+            if (c->rccl_comm) by_blocks = cge_rccl_reduce_scatter(c, c->wedges.p, per * N);
+            else if (c->coll_ext.reduce_scatter_f64 && c->xptr && (size_t)(per * N * c->coll.world) <= c->xcap) {
+                const i64 tot = per * N * c->coll.world;
+                HIP_CHECK(hipMemcpyAsync(c->xptr, c->wedges.p, sizeof(double) * tot, hipMemcpyDeviceToDevice, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (c->coll_ext.reduce_scatter_f64(c->coll.user, c->xptr, per * N) != 0) CGE_THROW(CGE_E_COLLECTIVE, "reduce-scatter hook failed");
+                c->stat_coll_calls++;
+                c->stat_coll_bytes += 8 * tot;
+                HIP_CHECK(hipMemcpyAsync(c->wedges.p, c->xptr, sizeof(double) * tot, hipMemcpyDeviceToDevice, st));
+                by_blocks = true;
+            }
+        }
+        if (by_blocks) c->wedges_block_only = true;
+        else allreduce(c, c->wedges.p, N * N, 0);
         const i64 r0 = std::min<i64>(N, per * c->coll.rank), r1 = std::min<i64>(N, r0 + per);
         k_compact_count(c, c->wedges.p, N, directed, cnt.p, r0, r1);
         allreduce(c, reinterpret_cast<double *>(cnt.p), 1, 2); // (integer sum of the ranks' counts)
@@ -1597,6 +1619,10 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_bvec_blocks = value != 0; // (measured slower); 0 (default): row bins + row sums + fold
         return CGE_OK;
     }
+    if (!strcmp(key, "wedges_reduce_scatter")) { // N > 1: 1 = the N x N landmark-pair matrix is reduce-scattered by row blocks (a fetch of
+        c->opt_wedges_rs = value != 0;            // the landmark edge list is then collective); 0 (default): all-reduced, every consumer local
+        return CGE_OK;
+    }
     if (!strcmp(key, "fit_fused")) { // 1 (default): in landmark mode the power matrix, vect_B's tile sums and the local score's tallies ride
         c->opt_fit_fused = value != 0; // on the launch of the undirected persistent fit; 0: separate launches (A/B, cross-check)
         return CGE_OK;
@@ -1891,6 +1917,16 @@ void cge_allgather_dev(cge_ctx *c, double *buf, i64 wpr) {
     if (!c->has_coll || wpr <= 0) return;
     if (c->rccl_comm && cge_rccl_allgather(c, buf, wpr)) return;
     const i64 W = c->coll.world, r = c->coll.rank, total = wpr * W;
+    if (!c->rccl_comm && c->coll_ext.allgather && c->xptr && (size_t)total <= c->xcap) { // the hook's own all-gather, through the exchange buffer
+        if (buf != c->xptr)
+            HIP_CHECK(hipMemcpyAsync(c->xptr + wpr * r, buf + wpr * r, sizeof(double) * (size_t)wpr, hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->coll_ext.allgather(c->coll.user, c->xptr, wpr) != 0) CGE_THROW(CGE_E_COLLECTIVE, "all-gather hook failed");
+        c->stat_coll_calls++;
+        c->stat_coll_bytes += 8 * total;
+        if (buf != c->xptr) HIP_CHECK(hipMemcpyAsync(buf, c->xptr, sizeof(double) * (size_t)total, hipMemcpyDeviceToDevice, c->stream));
+        return;
+    }
     if (r > 0) HIP_CHECK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)(wpr * r), c->stream));
     if (r + 1 < W) HIP_CHECK(hipMemsetAsync(buf + wpr * (r + 1), 0, sizeof(double) * (size_t)(wpr * (W - 1 - r)), c->stream));
     const i64 piece = c->rccl_comm ? total : (i64)c->xcap;

@@ -257,7 +257,9 @@ struct cge_ctx {
     int n_threads = 8;
     ThreadPool *pool = nullptr; // persistent host workers (n_threads - 1 + caller)
     cge_collectives coll{};
+    cge_collectives_ext coll_ext{}; // optional further ops of the hook (all-gather, reduce-scatter)
     bool has_coll = false;
+    int opt_wedges_rs = 0; // 1: the N x N landmark-pair matrix goes out by row blocks (reduce-scatter); 0 (default): all-reduce
     void *rccl_comm = nullptr;           // in-library communicator (collectives.cpp); takes precedence over the hook
     i64 stat_coll_calls = 0, stat_coll_bytes = 0; // all-reduces issued since the context was created
     DevBuf<double> xown;  // library-owned exchange buffer (cge_exchange_buffer)

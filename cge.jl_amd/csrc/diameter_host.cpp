@@ -149,7 +149,15 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     // (bit 0), or when NO centred value reaches 2^-40 (bit 1 clear): products below 2^-126 are flushed to zero in the fp32
     // accumulators, an absolute error of < 3K 2^-126 per dot product that the relative margin e only covers while the
     // distances that matter (>= L >= the largest centred norm squared >= 2^-80) dwarf it.
-    if (lowp && ((unfit & 1) || !(unfit & 2)) && !(RS && npos == 0)) {
+    if (RS && lowp) {
+        // option shard_rows: the verdict is taken TOGETHER -- "some rank holds an unfit value" (max of bit 0) and "some
+        // rank holds a value of normal size" (max of bit 1) -- so every rank runs the same bound pass whatever rows it happens
+        // to hold (a rank without rows of its own simply agrees): the candidate set, the statistics and the timing no longer
+        // depend on the sharding
+        const double bad = cge_allreduce_scalar_max(c, (unfit & 1) ? 1.0 : 0.0), big = cge_allreduce_scalar_max(c, (unfit & 2) ? 1.0 : 0.0);
+        unfit = (bad != 0.0 ? 1 : 0) | (big != 0.0 ? 2 : 0);
+    }
+    if (lowp && ((unfit & 1) || !(unfit & 2))) {
         b16 = f32 = false;
         c->Xs.ensure((size_t)lds_rows * dpad);
         k_gather_centre_fm(c, c->Xr.p, c->pos2node.p, c->gmean.p, c->Xs.p, c->rns.p, npos, d, lds_rows, dpad, nullptr, nullptr, KP, nullptr);

@@ -1186,6 +1186,32 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
 // replicated heap needs of it -- status, size of the low child, the two children's values: four 8-byte words per group --
 // is gathered by one all-reduce into a zero-filled buffer (op 2: integer sum of the words, exact).  The member lists, the
 // means and the arena offsets never leave the owner.
+// Owner-only work between two collectives must not leave the other ranks waiting in the next one: an error raised by it is
+// caught (guarded_work), travels with the words of that exchange -- one slot per rank behind them -- and AFTER the exchange
+// every rank throws: the failing rank its own error, the others the same code ("every rank leaves by the same door").
+struct RankError { int code = 0; std::string msg; };
+template <class F> static RankError guarded_work(F &&work) {
+    try { work(); } catch (const CgeError &e) { return RankError{e.code ? e.code : CGE_E_ASSERT, e.msg}; }
+    return RankError{};
+}
+static void throw_if_a_rank_failed(cge_ctx *c, const RankError &mine, const double *slots, const char *where) {
+    if (mine.code) throw CgeError{mine.code, mine.msg};
+    for (int r = 0; r < c->coll.world; r++)
+        if (slots[r] != 0.0)
+            CGE_THROW((int)slots[r], "%s: rank %d failed with code %d (its message is on that rank); every rank stops here", where, r, (int)slots[r]);
+}
+void exchange_group_words(cge_ctx *c, std::vector<double> &w);
+// the exchange of exchange_group_words with the ranks' verdicts behind the words
+static void exchange_group_words_checked(cge_ctx *c, std::vector<double> &w, const RankError &mine, const char *where) {
+    const size_t n0 = w.size();
+    const int W = c->has_coll ? c->coll.world : 1;
+    w.resize(n0 + (size_t)W, 0.0);
+    if (mine.code) w[n0 + (size_t)c->coll.rank] = (double)mine.code;
+    exchange_group_words(c, w);
+    std::vector<double> slots(w.begin() + (std::ptrdiff_t)n0, w.end());
+    w.resize(n0);
+    throw_if_a_rank_failed(c, mine, slots.data(), where);
+}
 void exchange_group_words(cge_ctx *c, std::vector<double> &w) { // in: this rank's words, zeros elsewhere; out: everybody's
     if (w.empty()) return;
     PhaseAcc px(c, "lm_exchange");
@@ -1202,9 +1228,9 @@ void compute_splits_rowsharded(cge_ctx *c, std::vector<Group *> &batch, int meth
     std::vector<Group *> mine;
     for (Group *g : batch)
         if (g->owner == me) mine.push_back(g);
-    if (!mine.empty()) compute_splits(c, mine, method);
+    const RankError err = guarded_work([&] { if (!mine.empty()) compute_splits(c, mine, method); });
     std::vector<double> w((size_t)4 * T, 0.0);
-    for (i64 t = 0; t < T; t++) {
+    for (i64 t = 0; t < T && !err.code; t++) {
         const Group *g = batch[t];
         if (g->owner != me) continue;
         w[4 * t] = (double)(g->rc - 1); // (never the all-zero word: a group nobody answered for is detected below)
@@ -1212,7 +1238,7 @@ void compute_splits_rowsharded(cge_ctx *c, std::vector<Group *> &batch, int meth
         w[4 * t + 2] = g->vlow;
         w[4 * t + 3] = g->vhigh;
     }
-    exchange_group_words(c, w);
+    exchange_group_words_checked(c, w, err, "runsplit (shard_rows)");
     for (i64 t = 0; t < T; t++) {
         Group *g = batch[t];
         if (g->owner == me) continue;
@@ -1242,7 +1268,7 @@ void compute_splits_sharded(cge_ctx *c, std::vector<Group *> &batch, int method)
     const i64 x_need = s_words + T * m_per;
     // (option value 2: every batch, whatever its size -- the tests)
     if (W <= 1 || !c->opt_shard_forced || (c->opt_shard_forced == 1 && (T < 2 * W || R * d < ((i64)1 << 23))) ||
-        !cge_exchange_fits(c, (size_t)x_need)) {
+        !cge_exchange_fits(c, (size_t)(x_need + W))) {
         compute_splits(c, batch, method);
         return;
     }
@@ -1261,15 +1287,17 @@ void compute_splits_sharded(cge_ctx *c, std::vector<Group *> &batch, int method)
     std::vector<Group *> mine;
     for (i64 t = 0; t < T; t++)
         if (owner[t] == me) mine.push_back(batch[t]);
-    if (!mine.empty()) compute_splits(c, mine, method);
+    const RankError err = guarded_work([&] { if (!mine.empty()) compute_splits(c, mine, method); });
     PhaseAcc px(c, "lm_exchange");
     double *X = c->xptr;
     i32 *S = reinterpret_cast<i32 *>(X);
     double *Mg = X + s_words;
-    HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * x_need, st));
+    HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * (x_need + W), st)); // (W verdict slots behind the words)
+    const double my_verdict = (double)err.code;
+    if (err.code) HIP_CHECK(hipMemcpyAsync(X + x_need + me, &my_verdict, sizeof(double), hipMemcpyHostToDevice, st));
     std::vector<i64> seg, moff, mslot;
     std::vector<double> hg((size_t)T * 5, 0.0);
-    for (i64 t = 0; t < T; t++) {
+    for (i64 t = 0; t < T && !err.code; t++) {
         if (owner[t] != me) continue;
         Group *g = batch[t];
         hg[5 * t] = (double)g->rc;
@@ -1306,7 +1334,13 @@ void compute_splits_sharded(cge_ctx *c, std::vector<Group *> &batch, int method)
         k_gather_means_slots(c, c->lm_means.p, d_moff.p + nq, d_moff.p + 2 * nq, (i64)nq, d, m_per, 5 + d, Mg);
         HIP_CHECK(hipStreamSynchronize(st)); // off_lo / off_hi / slot_t go out of scope
     }
-    cge_allreduce_dev(c, X, x_need, 2);
+    cge_allreduce_dev(c, X, x_need + W, 2);
+    {
+        std::vector<double> slots((size_t)W);
+        HIP_CHECK(hipMemcpyAsync(slots.data(), X + x_need, sizeof(double) * W, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        throw_if_a_rank_failed(c, err, slots.data(), "runsplit (sharded batch)");
+    }
     // every rank: the same ranges and means in the batch's order, the gathered values
     c->lm_arena_used = A0;
     c->lm_means_used = M0;
@@ -1653,7 +1687,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         const i64 nbig = (i64)locals.size(), W = c->has_coll ? c->coll.world : 1;
         const i64 s_words = (total + 1) / 2, m_per = 3 + d; // per group: length, value, mean flag, mean
         const i64 x_need = s_words + nbig + nbig * forced * m_per;
-        const bool shard = !RS && W > 1 && c->opt_shard_forced && forced >= 2 && cge_exchange_fits(c, (size_t)x_need);
+        const bool shard = !RS && W > 1 && c->opt_shard_forced && forced >= 2 && cge_exchange_fits(c, (size_t)(x_need + W));
         std::vector<int> owner(nbig, 0);
         if (RS) {
             // option shard_rows: every rank runs the local heaps of ITS communities; the replicated global heap needs, of every
@@ -1665,21 +1699,25 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                 owner[b] = locals[b].h.top()->owner;
                 if (owner[b] == me) { hs.push_back(&locals[b].h); tg.push_back(forced); }
             }
-            if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model);
             std::vector<double> w((size_t)nbig * per, 0.0);
             std::vector<std::vector<Group *>> popped(nbig);
-            for (i64 b = 0; b < nbig; b++) {
-                if (owner[b] != me) continue;
-                Heap &L = locals[b].h;
-                if ((i64)L.len() > std::max<i64>(forced, 1)) CGE_THROW(CGE_E_ASSERT, "forced phase: a local heap grew beyond its target");
-                while (L.len() > 0) popped[b].push_back(L.pop()); // pop order = the order in which the global heap receives them (:309-312)
-                w[b * per] = (double)popped[b].size();
-                for (size_t s_ = 0; s_ < popped[b].size(); s_++) {
-                    w[b * per + 1 + 2 * s_] = (double)popped[b][s_]->len;
-                    w[b * per + 2 + 2 * s_] = popped[b][s_]->value;
+            // (a reference error -- "Trying to split homogenous cluster", an empty child -- is raised by the owner of the
+            // community alone: it must reach the other ranks, who would otherwise wait in the exchange for ever)
+            const RankError err = guarded_work([&] {
+                if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model);
+                for (i64 b = 0; b < nbig; b++) {
+                    if (owner[b] != me) continue;
+                    Heap &L = locals[b].h;
+                    if ((i64)L.len() > std::max<i64>(forced, 1)) CGE_THROW(CGE_E_ASSERT, "forced phase: a local heap grew beyond its target");
+                    while (L.len() > 0) popped[b].push_back(L.pop()); // pop order = the order in which the global heap receives them (:309-312)
+                    w[b * per] = (double)popped[b].size();
+                    for (size_t s_ = 0; s_ < popped[b].size(); s_++) {
+                        w[b * per + 1 + 2 * s_] = (double)popped[b][s_]->len;
+                        w[b * per + 2 + 2 * s_] = popped[b][s_]->value;
+                    }
                 }
-            }
-            exchange_group_words(c, w);
+            });
+            exchange_group_words_checked(c, w, err, "forced phase (shard_rows)");
             for (i64 b = 0; b < nbig; b++) {
                 Heap &L = locals[b].h;
                 L = Heap();
@@ -1714,12 +1752,16 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             }
         }
         const int me_f = shard ? c->coll.rank : 0;
+        RankError ferr;
         if (!RS) {
             std::vector<Heap *> hs;
             std::vector<i64> tg;
             for (i64 b = 0; b < nbig; b++)
                 if (owner[b] == me_f) { hs.push_back(&locals[b].h); tg.push_back(forced); }
-            if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model);
+            // (sharded: an error of this rank's heaps -- the reference's own "Trying to split homogenous cluster" included --
+            // travels with the exchange below, so that every rank stops instead of waiting for this one)
+            ferr = guarded_work([&] { if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model); });
+            if (!shard && ferr.code) throw CgeError{ferr.code, ferr.msg};
         }
         if (shard) {
             const int me = me_f;
@@ -1727,10 +1769,11 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             double *X = c->xptr;
             i32 *S = reinterpret_cast<i32 *>(X);
             double *Mc = X + s_words, *Mg = Mc + nbig; // counts per community; per group {len, value, flag, mean[d]}
-            HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * x_need, st));
+            HIP_CHECK(hipMemsetAsync(X, 0, sizeof(double) * (x_need + W), st)); // (W verdict slots behind the words)
             std::vector<i64> seg, moff;
             std::vector<double> hc(nbig, 0.0), hg((size_t)nbig * forced * 3, 0.0);
             std::vector<i64> gslot; // slot (b * forced + s) of every owned group, in the order of `moff`
+            if (!ferr.code) ferr = guarded_work([&] {
             for (i64 b = 0; b < nbig; b++) {
                 if (owner[b] != me) continue;
                 Heap &L = locals[b].h;
@@ -1751,6 +1794,13 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                 }
                 if (at != cl_off[cidx + 1]) CGE_THROW(CGE_E_ASSERT, "forced phase: groups do not cover their community");
             }
+            });
+            const double my_verdict = (double)ferr.code;
+            if (ferr.code) {
+                HIP_CHECK(hipMemcpyAsync(X + x_need + me, &my_verdict, sizeof(double), hipMemcpyHostToDevice, st));
+                seg.clear(); moff.clear(); gslot.clear();
+                std::fill(hc.begin(), hc.end(), 0.0);
+            }
             // member lists -> their community's range of S; {len, value, flag} and the means -> Mg
             DevBuf<i64> d_seg, d_moff;
             if (!seg.empty()) {
@@ -1768,7 +1818,13 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                 HIP_CHECK(hipMemcpyAsync(d_moff.p + moff.size(), gslot.data(), sizeof(i64) * gslot.size(), hipMemcpyHostToDevice, st));
                 k_gather_means_slots(c, c->lm_means.p, d_moff.p, d_moff.p + moff.size(), (i64)moff.size(), d, m_per, 3, Mg);
             }
-            cge_allreduce_dev(c, X, x_need, 2);
+            cge_allreduce_dev(c, X, x_need + W, 2);
+            {
+                std::vector<double> slots((size_t)W);
+                HIP_CHECK(hipMemcpyAsync(slots.data(), X + x_need, sizeof(double) * W, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                throw_if_a_rank_failed(c, ferr, slots.data(), "forced phase (sharded)");
+            }
             // every rank: communities back into the start of the arena, one means block, fresh groups
             HIP_CHECK(hipMemcpyAsync(c->lm_arena.p, S, sizeof(i32) * total, hipMemcpyDeviceToDevice, st));
             c->lm_arena_used = total;

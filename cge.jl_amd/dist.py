@@ -69,7 +69,7 @@ class TorchCollectives:
     """Implements cge_collectives.allreduce_f64 on a torch tensor that doubles as the library's
     exchange buffer (cge_set_exchange_buffer)."""
 
-    def __init__(self, ctx, capacity_doubles: int, device):
+    def __init__(self, ctx, capacity_doubles: int, device, ext: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -79,9 +79,13 @@ class TorchCollectives:
         self.base = self.buf.data_ptr()
         self.n_calls = 0
         self.bytes = 0
+        self.n_gather = 0
+        self.n_reduce_scatter = 0
         if ctx is not None:  # (None: the hook alone, as the CPU tests drive it)
             ctx._check(ctx.L.cge_set_exchange_buffer(ctx.h, _vp(self.base), _i64(self.buf.numel())))
             ctx.set_collectives(self._hook, self.rank, self.world)
+            if ext:  # the optional all-gather / reduce-scatter of the hook (include/cge_hip.h: cge_collectives_ext)
+                ctx.set_collectives_ext(self._hook_allgather, self._hook_reduce_scatter)
 
     def _hook(self, user, ptr, count, op):
         try:
@@ -103,6 +107,57 @@ class TorchCollectives:
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             print(f"[cge.dist] allreduce hook failed: {e!r}", flush=True)
+            return 1
+
+
+    def _view(self, ptr, count):
+        off = (int(ptr) - self.base) // 8
+        return self.buf[off: off + int(count)]
+
+    def _hook_allgather(self, user, ptr, words):
+        """In place: rank r's block [r * words, (r + 1) * words) to every rank (8-byte words, moved as int64)."""
+        try:
+            t = self._view(ptr, int(words) * self.world).view(self.torch.int64)
+            mine = t[self.rank * int(words): (self.rank + 1) * int(words)].clone()
+            stage = t.is_cuda and self.dist.get_backend() == "gloo"  # rehearsal on one GPU: through the host
+            if stage:
+                mine = mine.cpu()
+            parts = [self.torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine)
+            t.copy_(self.torch.cat(parts).to(t.device))
+            if t.is_cuda:
+                self.torch.cuda.synchronize(t.device)
+            self.n_gather += 1
+            self.bytes += int(words) * 8 * self.world
+            return 0
+        except Exception as e:
+            print(f"[cge.dist] all-gather hook failed: {e!r}", flush=True)
+            return 1
+
+    def _hook_reduce_scatter(self, user, ptr, words):
+        """In place: afterwards block `rank` holds the sums of that block over the ranks.  The other blocks are UNSPECIFIED by the
+        contract: they are filled with NaN here, so that a consumer that reads beyond its own block cannot pass a test."""
+        try:
+            w = int(words)
+            t = self._view(ptr, w * self.world)
+            stage = t.is_cuda and self.dist.get_backend() == "gloo"
+            h = t.cpu() if stage else t
+            blocks = [h[r * w: (r + 1) * w].clone() for r in range(self.world)]
+            out = self.torch.empty_like(blocks[0])
+            try:
+                self.dist.reduce_scatter(out, blocks)
+            except Exception:  # gloo has no reduce-scatter: all-reduce, keep the own block
+                self.dist.all_reduce(h)
+                out = h[self.rank * w: (self.rank + 1) * w].clone()
+            t.fill_(float("nan"))
+            t[self.rank * w: (self.rank + 1) * w].copy_(out.to(t.device))
+            if t.is_cuda:
+                self.torch.cuda.synchronize(t.device)
+            self.n_reduce_scatter += 1
+            self.bytes += w * 8 * self.world
+            return 0
+        except Exception as e:
+            print(f"[cge.dist] reduce-scatter hook failed: {e!r}", flush=True)
             return 1
 
 

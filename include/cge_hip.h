@@ -76,6 +76,18 @@ typedef struct {
     int rank, world;
 } cge_collectives;
 int cge_set_collectives(cge_ctx *ctx, const cge_collectives *coll);
+/* Further operations of the hook (optional; set AFTER cge_set_collectives, cleared by it): where they are present the library
+ * moves gathers as gathers and the N x N landmark-pair matrix by row blocks instead of all-reducing whole buffers (what
+ * ncclAllGather / ncclReduceScatter do on the in-library communicator).  Both work in place on `buf` (a device pointer into
+ * the exchange buffer), `words` 8-byte words PER RANK, world * words in all:
+ *   allgather(user, buf, words):          rank r contributes block [r * words, (r + 1) * words); afterwards every rank holds all;
+ *   reduce_scatter_f64(user, buf, words): afterwards block r of rank r holds the sums (doubles) of that block over the ranks;
+ *                                         the other blocks are unspecified.                                                  */
+typedef struct {
+    int (*allgather)(void *user, void *buf, int64_t words_per_rank);
+    int (*reduce_scatter_f64)(void *user, void *buf, int64_t words_per_rank);
+} cge_collectives_ext;
+int cge_set_collectives_ext(cge_ctx *ctx, const cge_collectives_ext *ext);
 int cge_exchange_buffer(cge_ctx *ctx, int64_t min_doubles, void **dev_ptr, int64_t *capacity_doubles);
 /* or hand the library a caller-owned device buffer (e.g. a torch tensor) to use as exchange buffer */
 int cge_set_exchange_buffer(cge_ctx *ctx, void *dev_ptr, int64_t capacity_doubles);

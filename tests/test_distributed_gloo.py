@@ -82,23 +82,40 @@ def _worker(rank, world, port, q):
         glob = cd.allreduce_numpy(np.array([local]), "max")[0]
         assert glob >= local and glob == max(dist_gather(local, world))
         # 3. the hook itself (what the C library calls): offset arithmetic + op mapping on the exchange buffer
-        coll = cd.TorchCollectives(None, 64, "cpu")
+        coll = cd.TorchCollectives(None, 256, "cpu")
+        tri = world * (world + 1) // 2
         coll.buf[:] = 0
         coll.buf[8:12] = torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64) * (rank + 1)
         assert coll._hook(None, coll.base + 8 * 8, 4, 0) == 0
-        assert coll.buf[8:12].tolist() == [3.0, 6.0, 9.0, 12.0] and coll.buf[12].item() == 0.0
+        assert coll.buf[8:12].tolist() == [1.0 * tri, 2.0 * tri, 3.0 * tri, 4.0 * tri] and coll.buf[12].item() == 0.0
         coll.buf[20] = float(10 + rank)
         assert coll._hook(None, coll.base + 20 * 8, 1, 1) == 0
-        assert coll.buf[20].item() == 11.0 and coll.n_calls == 2 and coll.bytes == 40
+        assert coll.buf[20].item() == 10.0 + world - 1 and coll.n_calls == 2 and coll.bytes == 40
         # op 2: the words as int64 -- disjoint shards in zero-filled buffers are gathered bit for bit (-0.0, NaN payloads, packed ints)
-        coll.buf[30:34] = 0
+        coll.buf[30:30 + 2 * world] = 0
         mine = torch.tensor([-0.0, float("nan")], dtype=torch.float64) if rank == 0 else \
-            torch.tensor([123456789], dtype=torch.int64).view(torch.float64).repeat(2)
+            torch.tensor([123456789 + rank], dtype=torch.int64).view(torch.float64).repeat(2)
         coll.buf[30 + 2 * rank: 32 + 2 * rank] = mine
-        assert coll._hook(None, coll.base + 30 * 8, 4, 2) == 0
-        got = coll.buf[30:34].view(torch.int64).tolist()
+        assert coll._hook(None, coll.base + 30 * 8, 2 * world, 2) == 0
+        got = coll.buf[30:30 + 2 * world].view(torch.int64).tolist()
         assert got[0] == -(2 ** 63) and got[1] == torch.tensor([float("nan")], dtype=torch.float64).view(torch.int64).item()
-        assert got[2] == got[3] == 123456789
+        assert all(got[2 * r] == got[2 * r + 1] == 123456789 + r for r in range(1, world))
+        # 3b. the optional ops of the hook (include/cge_hip.h: cge_collectives_ext), in place on the exchange buffer: the
+        #     all-gather moves every rank's block bit for bit; after the reduce-scatter a rank may rely on ITS block only (the
+        #     hook poisons the others, as the contract leaves them unspecified)
+        w = 3
+        blk = coll.buf[64:64 + w * world]
+        blk[:] = -1.0
+        blk[w * rank: w * (rank + 1)] = torch.tensor([rank + 0.5, -0.0, float(rank)], dtype=torch.float64)
+        assert coll._hook_allgather(None, coll.base + 64 * 8, w) == 0
+        for r in range(world):
+            assert blk[w * r].item() == r + 0.5 and blk[w * r + 2].item() == float(r)
+            assert blk[w * r + 1: w * r + 2].view(torch.int64).item() == -(2 ** 63)  # -0.0 kept its sign: words, not sums
+        blk[:] = torch.arange(w * world, dtype=torch.float64) * (rank + 1)
+        assert coll._hook_reduce_scatter(None, coll.base + 64 * 8, w) == 0
+        assert blk[w * rank: w * (rank + 1)].tolist() == [float(tri * (w * rank + k)) for k in range(w)]
+        others = torch.cat([blk[: w * rank], blk[w * (rank + 1):]])
+        assert bool(torch.isnan(others).all()) and coll.n_gather == 1 and coll.n_reduce_scatter == 1
         # 4. option shard_rows: the ownership rule (rows sharded BY COMMUNITY) and the exchanges built on it.  Every rank derives
         #    the same owners from the replicated community vector; every vertex has exactly one owner; the loads are balanced;
         #    what a rank computes for ITS rows, written at their global ids into a zero-filled vector, is completed by the
@@ -138,14 +155,17 @@ def dist_gather(value, world):
     return [float(x.item()) for x in t]
 
 
-def test_sharding_and_collective_hook_world2():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharding_and_collective_hook(world):
+    """The sharding rules and the hook at the world sizes a node offers (2, 4, 8 ranks): edge / tile / community ownership
+    partitions, every all-reduce op, the all-gather and reduce-scatter ops of the hook."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=180) for _ in procs]
+    results = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(60)
-    assert sorted(results) == [(0, "ok"), (1, "ok")], results
+    assert sorted(results) == [(r, "ok") for r in range(world)], results

@@ -379,3 +379,194 @@ def test_two_ranks_sharded_rows(ctx, case):
         assert np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
     assert held == g["n"]  # every row is resident on exactly one rank
     assert results[0][1] == results[1][1]  # both ranks hold the same bits
+
+
+# ---- round 5: the branches that only a reduce-scatter / all-gather reaches, the owner-only error, four ranks ----------------
+def _rank_ext(rank, world, port, q, directed):
+    """Sharded ingest + `wedges_reduce_scatter` through the hook's OWN all-gather / reduce-scatter (dist.TorchCollectives(ext=True):
+    the reduce-scatter leaves NaN in every block a rank does not own)."""
+    try:
+        import torch
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from cge.jl_amd import api, synth
+        from cge.jl_amd.dist import TorchCollectives
+
+        g = synth.abcd_like(30000, 300000, 30, 16, seed=21, directed=directed)
+        ctx = api.Context(0)
+        coll = TorchCollectives(ctx, 30000 * 16 + 1024, torch.device("cuda", 0), ext=True)  # (room for the embedding's all-gather)
+        ctx.set_option("shard_ingest", 1)
+        ctx.set_option("wedges_reduce_scatter", 1)
+        ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+        ag_ingest = coll.n_gather
+        ctx.set_option("fit_persistent", 1)
+        res = ctx.score(g["clusters"], 600, 2, "rss", directed=directed, seed=5, auc_samples=4000)
+        hi = ctx.last_diameter()[0]
+        rs_score, ag_score = coll.n_reduce_scatter, coll.n_gather
+        lm = ctx.landmarks_fetch()  # collective with the matrix in row blocks: the blocks are all-gathered
+        q.put((rank, res.tolist(), hi, (ag_ingest, rs_score, ag_score, coll.n_reduce_scatter, coll.n_gather),
+               [int(zlib.crc32(np.ascontiguousarray(x).tobytes())) for x in lm]))
+        ctx.close()
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(e), None, None, None))
+    finally:
+        import torch.distributed as dist
+
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("directed", [False, True])
+def test_two_ranks_reduce_scatter_and_allgather_through_the_hook(ctx, directed):
+    """VERDICT r4 item 4(a) / ADVICE r4: what runs only behind a reduce-scatter of the N x N landmark-pair matrix -- the count of
+    its positive entries over row blocks, the directed score's degrees from row blocks (k_wedge_degrees_block), the all-gather
+    of the blocks in cge_landmarks_fetch -- and the all-gather of the sharded ingest, executed through the hook's own
+    reduce-scatter (which poisons every foreign block with NaN) and all-gather: the one-rank result, tables and edge list."""
+    import torch.multiprocessing as mp
+    from cge.jl_amd import synth
+
+    g = synth.abcd_like(30000, 300000, 30, 16, seed=21, directed=directed)
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    try:
+        ctx.set_option("fit_persistent", 1)
+        ref = ctx.score(g["clusters"], 600, 2, "rss", directed=directed, seed=5, auc_samples=4000)
+        hi_ref = ctx.last_diameter()[0]
+        crc_ref = [int(zlib.crc32(np.ascontiguousarray(x).tobytes())) for x in ctx.landmarks_fetch()]
+    finally:
+        ctx.set_option("fit_persistent", 0)
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank_ext, args=(r, 2, port, q, directed)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+    for rank, res, hi, calls, crcs in results:
+        assert hi is not None, res  # a traceback otherwise
+        ag_ingest, rs_score, ag_score, rs_all, ag_all = calls
+        assert ag_ingest == 1  # the embedding's rows: one all-gather
+        assert rs_all >= 1 and ag_all == ag_score + 1  # the matrix went out by row blocks; the fetch gathered them
+        assert (rs_score >= 1) == directed or not directed  # (the directed score needs the matrix itself: degrees from row blocks)
+        assert hi == hi_ref and crcs == crc_ref
+        assert res[0] == ref[0] and res[4] == ref[4] and np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
+    assert results[0][1] == results[1][1]
+
+
+def _rank_homogeneous(rank, world, port, q):
+    try:
+        import torch
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from cge.jl_amd import api
+        from cge.jl_amd.dist import TorchCollectives, community_owner
+
+        g = _graph_homogeneous()
+        ctx = api.Context(0)
+        TorchCollectives(ctx, 600 * 600 * 2 + 1024, torch.device("cuda", 0))
+        ctx.set_option("shard_ingest", 1)
+        ctx.set_option("shard_rows", 1)
+        ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+        ctx.set_option("fit_persistent", 1)
+        owner = int(community_owner(g["comm"][:, 0], world)[g["hom"] - 1])
+        try:
+            ctx.score(g["clusters"], 600, 2, "rss", seed=5, auc_samples=1000)
+            q.put((rank, "no error", owner))
+        except api.CGEError as e:
+            q.put((rank, (e.code, str(e)), owner))
+        ctx.close()
+    except Exception as e:
+        import traceback
+
+        q.put((rank, traceback.format_exc() + repr(e), None))
+    finally:
+        import torch.distributed as dist
+
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _graph_homogeneous():
+    """The 30 000-vertex graph with ONE community whose rows are all equal (small integers: with integer degrees as weights the
+    weighted mean is exact): the rss rule must refuse to split it (src/landmarks.jl:165-167, "Trying to split homogenous cluster")."""
+    g = _graph()
+    comm = g["comm"][:, 0]
+    hom = int(np.argmin(np.bincount(comm)[1:]) + 1)  # the smallest community
+    emb = np.array(g["embedding"], order="F")
+    emb[comm == hom] = np.arange(1.0, emb.shape[1] + 1.0)  # integer coordinates: the weighted mean is exact, every z is 0 whatever the order
+    g["embedding"] = np.asfortranarray(emb)
+    g["hom"] = hom
+    return g
+
+
+def test_two_ranks_owner_only_error_reaches_both_ranks(ctx):
+    """with the rows sharded by community the reference's own errors are raised by the OWNER of the community
+    alone, between two collectives -- the other rank used to wait in the next exchange for ever.  The verdict now travels with
+    the exchange: both ranks stop with the owner's code (CGE_E_HOMOGENEOUS), the owner with the reference's message."""
+    import torch.multiprocessing as mp
+    from cge.jl_amd import api
+
+    g = _graph_homogeneous()
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    with pytest.raises(api.CGEError) as ei:  # one rank: the reference's error
+        ctx.score(g["clusters"], 600, 2, "rss", seed=5, auc_samples=1000)
+    assert ei.value.code == -2 and "homogenous" in str(ei.value)
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank_homogeneous, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in procs)  # (a hang would end here)
+    for p in procs:
+        p.join(120)
+    for rank, err, owner in results:
+        assert owner is not None and err != "no error", err
+        assert err[0] == -2, err
+        assert "homogenous" in err[1] and (f"rank {owner} failed" in err[1]) == (rank != owner), err  # (the code maps to the reference's message)
+
+
+def test_four_ranks_sharded_rows(ctx):
+    """The sharded-rows score on FOUR ranks (four processes on the test box's one GPU, gloo between them): the ownership of 30
+    communities over four owners, row blocks of 150 landmarks, four-way edge and tile shards -- the one-rank bits."""
+    import torch.multiprocessing as mp
+
+    case = dict(method="rss")
+    g = _graph_rows(case)
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    try:
+        ctx.set_option("fit_persistent", 1)
+        ref = ctx.score(g["clusters"], 600, 2, "rss", seed=5, auc_samples=4000)
+        hi_ref = ctx.last_diameter()[0]
+        crc_ref = [int(zlib.crc32(np.ascontiguousarray(x).tobytes())) for x in ctx.landmarks_fetch()]
+    finally:
+        ctx.set_option("fit_persistent", 0)
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank_rows, args=(r, 4, port, q, case)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(120)
+    held = 0
+    for rank, res, hi, rows, crcs in results:
+        assert hi is not None, res
+        resident, total, words, mine = rows[:4]
+        assert total == g["n"] and resident == mine and 0.15 * total < resident < 0.35 * total  # about a quarter each
+        held += resident
+        assert hi == hi_ref and crcs == crc_ref
+        assert res[0] == ref[0] and res[4] == ref[4] and np.allclose(res, ref, rtol=1e-12, atol=1e-14), (rank, res, ref)
+    assert held == g["n"] and all(r[1] == results[0][1] for r in results)
