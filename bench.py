@@ -228,9 +228,6 @@ def main():
                     help="skip the 30 back-to-back passes of the per-edge scatter behind the timed region (profiles of the step alone)")
     ap.add_argument("--no-independent", action="store_true",
                     help="N > 1: skip the second measurement (one embedding per GPU, no collective)")
-    ap.add_argument("--side-diameter", action="store_true",
-                    help="A/B: the diameter on the side context beside runsplit (default: in line, after landmarks())")
-    ap.add_argument("--side-samples", action="store_true", help="A/B: clamp and sample draws on the side thread (default: in line)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1 headline run: do not follow it with the other BASELINE configurations (cfg2, cfg3, cfg4; cfg5 when "
                          ">= 200 GB of HBM are free and the run is still inside --other-budget-s), reported as `other_configs`")
@@ -318,10 +315,6 @@ def main():
         t_upload = upload()
     ctx.set_option("diameter", args.diameter)
     ctx.set_option("landmark_edges", 0 if args.lazy_landmark_edges else 1)
-    ctx.set_option("early_diameter", 1 if args.side_diameter else 0)
-    ctx.set_option("side_samples", 1 if args.side_samples else 0)
-    if os.environ.get("CGE_SPEC_PCT"):  # tuning probe: share of the missing pops one round of runsplit may split ahead
-        ctx.set_option("speculation_pct", int(os.environ["CGE_SPEC_PCT"]))
     coll, coll_backend = None, None
     if world > 1:
         # default: the library's own RCCL communicator (ncclAllReduce on its stream, no host synchronisation per exchange);

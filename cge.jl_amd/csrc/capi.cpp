@@ -28,16 +28,6 @@ void k_gather_i32(cge_ctx *c, const i32 *arr, const i32 *idx, i64 S, i32 *out);
     return CGE_OK;
 
 static void flush_timers(cge_ctx *c) {
-    for (cge_ctx *sh : {c->side, c->lane}) { // the shadow contexts' kernels are reported with the main context's
-        if (!sh) continue;
-        flush_timers(sh);
-        for (auto &kv : sh->timers) {
-            KernelTimer &t = c->timers[kv.first];
-            t.launches += kv.second.launches;
-            t.total_ms += kv.second.total_ms;
-        }
-        sh->timers.clear();
-    }
     for (auto &kv : c->timers) {
         for (auto &pr : kv.second.pending) {
             float ms = 0.f;
@@ -160,23 +150,15 @@ void cge_destroy(cge_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     flush_timers(c);
-    for (cge_ctx **slot : {&c->side, &c->lane}) { // shadow contexts: own streams and scratch, borrowed views of the resident inputs
-        cge_ctx *sd = *slot;
-        *slot = nullptr;
-        if (sd) cge_destroy(sd);
-    }
-    if (!c->is_side) (void)cge_comm_finalize(c);
+    (void)cge_comm_finalize(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->event_pool.clear();
     if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
-    if (c->members_ev) (void)hipEventDestroy(c->members_ev);
-    if (c->fitdone_ev) (void)hipEventDestroy(c->fitdone_ev);
     for (int i = 0; i < 2; i++) {
         if (c->sweep_ev[i]) (void)hipEventDestroy(c->sweep_ev[i]);
-        if (c->pow_ev[i]) (void)hipEventDestroy(c->pow_ev[i]);
         if (c->tab_ev[i]) (void)hipEventDestroy(c->tab_ev[i]);
     }
     for (int i = 0; i < 2; i++)
@@ -237,10 +219,10 @@ int cge_set_exchange_buffer(cge_ctx *c, void *dev_ptr, int64_t cap) {
 static void allreduce(cge_ctx *c, double *dev, i64 count, int op);
 static double allreduce_scalar_max(cge_ctx *c, double v);
 // N > 1 with option "shard_ingest": which rows of the caller's edge list / embedding this rank uploads
-static bool ingest_sharded(const cge_ctx *c) { return c->opt_shard_ingest && c->has_coll && !c->is_side && c->coll.world > 1; }
+static bool ingest_sharded(const cge_ctx *c) { return c->opt_shard_ingest && c->has_coll && c->coll.world > 1; }
 
 // ---- option "shard_rows": the embedding rows sharded by community (common.hpp) ---------------------------------------------
-static bool rows_shard_wanted(const cge_ctx *c) { return c->opt_shard_rows && c->has_coll && !c->is_side && c->coll.world > 1; }
+static bool rows_shard_wanted(const cge_ctx *c) { return c->opt_shard_rows && c->has_coll && c->coll.world > 1; }
 static void rows_unshard(cge_ctx *c) {
     c->rows_sharded = false;
     c->n_loc = 0;
@@ -803,19 +785,17 @@ static void scatter_vectC_resident(cge_ctx *c, i64 C, int directed, double *vect
     if (c->has_coll) allreduce(c, vectC, vlen, 0);
 }
 
-// `late_land` (optional): the `land` clamp of src/landmarks.jl:371-376 is being computed elsewhere (the side context of
-// cge_score); it is asked for when the forced per-community phase, which does not depend on it, is over
 static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 land, i64 forced,
-                               int method, int directed, bool need_wedges, const std::function<i64()> *late_land = nullptr) {
+                               int method, int directed, bool need_wedges) {
     check_resident(c, "landmarks");
     if (method < 0 || method > 3) CGE_THROW(CGE_E_ARG, "unknown split method %d", method);
     const i64 d = c->d;
     hipStream_t st = c->stream;
     double t0 = now_ms();
-    if (!late_land) land = clamp_to_unique_rows(c, land, &c->lm_truncated);
+    land = clamp_to_unique_rows(c, land, &c->lm_truncated);
     c->phases.ms["lm_unique"] = now_ms() - t0;
     std::vector<i64> gid;
-    host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, true, late_land); // leaves v2l and the landmark index on the device
+    host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, true); // leaves v2l and the landmark index on the device
     HIP_CHECK(hipStreamSynchronize(st));
     c->phases.ms["landmarks"] = now_ms() - t0;
     t0 = now_ms();
@@ -1249,115 +1229,7 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
 }
 
 
-// ---- the side context of cge_score ------------------------------------------------------------------------------
-// In landmark mode three things of a score depend on the RESIDENT INPUTS only, not on the landmarks: the `land` clamp to the
-// number of unique embedding rows (src/landmarks.jl:371-376), the sample draws of the local score
-// (src/divergence.jl:184-194) and `hi` = maximum(full_graph_D) (:104-113), the diameter of the original point set.  The
-// reference computes them in line; here a second host thread drives them on a shadow context (own low-priority streams, own
-// scratch, borrowed views of the resident arrays) while the first runs runsplit -- a chain of short dependent kernels that
-// leaves most of the GPU idle.  The diameter's branch and bound is exact for ANY partition of the vertices (diameter_host.cpp:
-// only the amount of pruning depends on it), so it uses one that needs no landmarks: every cluster cut into runs of about
-// n / (4 sqrt n) members (as many groups as the automatic landmark count), reference points = the clusters' centroids.  `hi` itself is re-evaluated from the arg-max pair with dist()'s own
-// arithmetic, as before: the same bits as the landmark-based search (tests: all full-size fixtures).
-static cge_ctx *side_context(cge_ctx *c) { return cge_shadow_context(c, &c->side, true); }
-
 static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_directed, SampleSet &smp);
-
-namespace {
-struct SideJob {
-    std::thread th;
-    std::promise<i64> land; // the clamped landmark count (lm_truncated rides in `truncated`)
-    std::future<i64> land_f;
-    int truncated = 0;
-    bool samples_ok = false;
-    int dm_status = 0; // 1 = hi known, 2 = the pruned search declined (the caller takes the serial path), 3 = failed
-    double hi = 0.0, t_total = 0.0;
-    std::string err;
-    ~SideJob() { if (th.joinable()) th.join(); } // (an exception on the main path must not leave the thread running)
-};
-} // namespace
-
-static void side_job_body(cge_ctx *c, cge_ctx *sd, const cge_score_args *a, i64 land, bool want_diameter, SideJob *job) {
-    const double t0 = now_ms();
-    bool land_set = false;
-    try {
-        HIP_CHECK(hipSetDevice(sd->device));
-        sd->phases.ms.clear();
-        // (1) the clamp of `land` (a hash pass over a prefix of the rows, rarely more)
-        {
-            const i64 v = clamp_to_unique_rows(sd, land, &job->truncated);
-            sd->phases.ms["lm_unique"] = now_ms() - t0;
-            job->land.set_value(v);
-            land_set = true;
-        }
-        // (2) the sample draws (rejection against the resident edge list on the device, src/divergence.jl:184-194)
-        try {
-            const double ts = now_ms();
-            make_samples(sd, a->seed, a->auc_samples, a->directed, false, c->smp);
-            HIP_CHECK(hipStreamSynchronize(sd->stream));
-            sd->phases.ms["samples"] = now_ms() - ts;
-            job->samples_ok = true;
-        } catch (const CgeError &) { job->samples_ok = false; } // the main thread repeats the draw and reports the error
-        // (3) the diameter, from the clusters cut into runs of <= G members
-        if (want_diameter) {
-            const i64 n = sd->n, d = sd->d, ncl = a->n_clusters;
-            // as many groups as the automatic landmark count, 4 sqrt(n) (src/auxilary.jl:194-195): the candidate list of the
-            // bound pass grows with the square of the group count
-            const i64 G = std::max<i64>(64, (i64)std::ceil((double)n / std::max(1.0, 4.0 * std::sqrt((double)n))));
-            const i64 *off = a->clusters_off, *flat = a->clusters_flat;
-            const i64 total = ncl > 0 ? off[ncl] : 0;
-            job->dm_status = 2;
-            bool ok = total == n && ncl >= 1; // an exact cover of the vertices (runsplit asserts it, src/landmarks.jl:343)
-            std::vector<i32> lcomm;
-            if (ok) {
-                sd->h_mem.resize(n);
-                sd->h_mem_off.clear();
-                sd->h_mem_off.push_back(0);
-                for (i64 q = 0; q < ncl && ok; q++) {
-                    const i64 b = off[q], e = off[q + 1];
-                    if (e < b) { ok = false; break; }
-                    for (i64 k = b; k < e; k++) {
-                        if (flat[k] < 1 || flat[k] > n) { ok = false; break; }
-                        sd->h_mem[k] = (i32)(flat[k] - 1);
-                    }
-                    for (i64 g0 = b; g0 < e; g0 += G) {
-                        sd->h_mem_off.push_back((i32)std::min(e, g0 + G));
-                        lcomm.push_back((i32)q);
-                    }
-                }
-            }
-            if (ok) {
-                const i64 Ng = (i64)lcomm.size();
-                hipStream_t st = sd->stream;
-                sd->lm_memoff.ensure(Ng + 1); sd->lm_mem.ensure(n);
-                sd->lemb.ensure((size_t)Ng * d); sd->lweight.ensure(Ng); sd->dii.ensure(Ng); sd->lcomm.ensure(Ng);
-                HIP_CHECK(hipMemcpyAsync(sd->lm_memoff.p, sd->h_mem_off.data(), sizeof(i32) * (Ng + 1), hipMemcpyHostToDevice, st));
-                HIP_CHECK(hipMemcpyAsync(sd->lm_mem.p, sd->h_mem.data(), sizeof(i32) * n, hipMemcpyHostToDevice, st));
-                sd->lm_index_on_device = true;
-                k_landmark_aggregate(sd, sd->Xr.p, sd->vw.p, sd->comm.p, sd->lm_memoff.p, sd->lm_mem.p, Ng, d, sd->lemb.p,
-                                     sd->lweight.p, sd->dii.p, sd->lcomm.p);
-                double d2;
-                i64 bi, bj;
-                if (host_diameter_pruned(sd, sd->lemb.p, sd->lweight.p, lcomm, ncl, Ng, sd->h_mem_off, sd->h_mem, 0, 1, &d2, &bi, &bj)) {
-                    job->hi = exact_pair_distance(sd, bi, bj);
-                    sd->stat_hi_i = bi; sd->stat_hi_j = bj;
-                    job->dm_status = 1;
-                }
-            }
-            sd->phases.ms["diameter_side"] = now_ms() - t0;
-        }
-    } catch (const CgeError &e) {
-        job->dm_status = 3;
-        job->err = e.msg;
-        if (!land_set) job->land.set_exception(std::current_exception());
-    } catch (const std::exception &e) {
-        job->dm_status = 3;
-        job->err = e.what();
-        if (!land_set) job->land.set_exception(std::current_exception());
-    }
-    (void)hipStreamSynchronize(sd->stream);
-    job->t_total = now_ms() - t0;
-}
 
 int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, cge_trace *trace) {
     if (!c || !a || !out || !out_len) return CGE_E_ARG;
@@ -1384,26 +1256,9 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         *out_len = 6;
         return true;
     };
-    SideJob job;
-    bool side_samples = false;
     if (landmarks) {
-        // single rank: clamp, sample draws and diameter run beside runsplit on the side context (above)
-        const bool use_side = (c->opt_early_diameter || c->opt_side_samples) && !c->has_coll;
-        if (use_side) {
-            cge_ctx *sd = side_context(c);
-            c->smp.reset();
-            job.land_f = job.land.get_future();
-            job.th = std::thread(side_job_body, c, sd, a, (i64)a->land, c->opt_early_diameter && c->opt_diameter != 1, &job);
-            const std::function<i64()> late = [&]() {
-                const i64 v = job.land_f.get(); // rethrows what the clamp threw
-                c->lm_truncated = job.truncated;
-                return v;
-            };
-            landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed,
-                               directed != 0 || c->opt_landmark_edges != 0, &late);
-        } else
-            landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed,
-                               directed != 0 || c->opt_landmark_edges != 0);
+        landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed,
+                           directed != 0 || c->opt_landmark_edges != 0);
         const i64 N = c->N, C = c->n_comm_max;
         // wGCL's own `maximum(edges)` / size asserts (src/divergence.jl:41,50): the highest-numbered
         // landmark must carry an edge -- always true when every vertex has positive weight
@@ -1430,29 +1285,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
         ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.empty() ? nullptr : c->h_w.data();
         double hi = 0.0;
-        bool have_hi = false;
-        if (use_side) {
-            job.th.join();
-            cge_ctx *sd = c->side;
-            for (auto &kv : sd->phases.ms) c->phases.ms[kv.first] = kv.second; // dm_*, samples, lm_unique: concurrent with `landmarks`
-            c->phases.ms["side_total"] = job.t_total;
-            c->stat_side_status = job.dm_status;
-            if (job.dm_status == 3) c->err = "side context: " + job.err; // (the in-line path below reports what it finds itself)
-            side_samples = job.samples_ok;
-            if (job.dm_status == 1) {
-                hi = job.hi;
-                have_hi = true;
-                c->stat_cand_pairs = sd->stat_cand_pairs;
-                c->stat_cand_tiles = sd->stat_cand_tiles;
-                c->stat_nref = sd->stat_nref;
-                c->stat_bound_pass = sd->stat_bound_pass;
-                c->stat_hi_i = sd->stat_hi_i; c->stat_hi_j = sd->stat_hi_j;
-                c->stat_diameter_path = 2;
-                c->stat_diameter_side = 1;
-            }
-        }
-        if (!have_hi) { // N > 1, the brute-force option, or the side search declined: from the landmark partition, here
-            c->stat_diameter_side = 0;
+        {
             std::vector<i32> lcomm0(N); // community of a landmark = community of any member (landmarks never span two): :427
             HIP_CHECK(hipMemcpyAsync(lcomm0.data(), c->lcomm.p, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
@@ -1492,11 +1325,9 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     }
     t0 = now_ms();
     SampleSet &smp = c->smp;
-    if (!side_samples) {
-        smp.reset();
-        make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
-        c->phases.ms["samples"] = now_ms() - t0;
-    }
+    smp.reset();
+    make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
+    c->phases.ms["samples"] = now_ms() - t0;
     t0 = now_ms();
     host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.empty() ? nullptr : c->h_w.data(), c->m, directed, a->split, smp,
                     out, out_len, trace);
@@ -1587,14 +1418,9 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_diameter_f32 = (int)value;
         return CGE_OK;
     }
-    if (!strcmp(key, "fit_persistent")) { // 0 auto, 1 never, 2 whenever the score graph fits the register file, 3 / 4 = 2 with grid barriers / counters
-        if (value < 0 || value > 4) return CGE_E_ARG;
+    if (!strcmp(key, "fit_persistent")) { // 0 auto, 1 never, 2 whenever the score graph fits the register file
+        if (value < 0 || value > 2) return CGE_E_ARG;
         c->opt_fit_persistent = (int)value;
-        return CGE_OK;
-    }
-    if (!strcmp(key, "speculation_pct")) { // tuning: 1..100, 0 = by split rule, -1 = by rehearsing the pop sequence (results do not depend on it)
-        if (value < -1 || value > 100) return CGE_E_ARG;
-        c->opt_speculation_pct = (int)value;
         return CGE_OK;
     }
     if (!strcmp(key, "pow_exp2")) { // 1 (default): (1 - D)^alpha from log2(1 - D) kept per score; 0: the library pow per alpha
@@ -1627,10 +1453,6 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_fit_fused = value != 0; // on the launch of the undirected persistent fit; 0: separate launches (A/B, cross-check)
         return CGE_OK;
     }
-    if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget
-        c->opt_test_bvec_plain = value != 0;
-        return CGE_OK;
-    }
     if (!strcmp(key, "shard_ingest")) { // N > 1: 1 = cge_set_graph keeps this rank's slice of the edge list only and cge_set_embedding uploads a
         // slice of rows per rank and all-gathers them over xGMI (set the collectives first); 0 (default): every rank uploads and keeps everything
         c->opt_shard_ingest = value != 0;
@@ -1641,40 +1463,28 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
         c->opt_shard_rows = value != 0;
         return CGE_OK;
     }
-    if (!strcmp(key, "cov_derive")) { // 1: the larger child's covariance = its parent's minus its sibling's (only the smaller child is summed); 0 (default): every one over its rows
-        c->opt_cov_derive = value != 0;
-        return CGE_OK;
-    }
-    if (!strcmp(key, "runsplit_lanes_test_delay")) { // testing: the second lane writes its children's member lists ~4 us x value late
-        if (value < 0 || value > 100000) return CGE_E_ARG;
-        c->opt_lanes_test_delay = (int)value;
-        return CGE_OK;
-    }
-    if (!strcmp(key, "runsplit_lanes")) { // 2: the batches of runsplit run as two half-batches on two streams, out of phase; 1 (default): one stream
-        if (value < 1 || value > 2) return CGE_E_ARG;
-        c->opt_lanes = (int)value;
-        return CGE_OK;
-    }
-    if (!strcmp(key, "early_diameter")) { // 1: the diameter too on the side context beside runsplit (single rank), from the cluster-chunk partition;
-        c->opt_early_diameter = value != 0; // 0 (default): in line after landmarks(), from the landmark partition
-        return CGE_OK;
-    }
-    if (!strcmp(key, "side_samples")) { // 1: the `land` clamp and the sample draws on the side context beside runsplit (single rank); 0 (default): in line
-        c->opt_side_samples = value != 0;
-        return CGE_OK;
-    }
     if (!strcmp(key, "landmark_edges")) { // 1: cge_score also builds the landmark-pair matrix / edge count that landmarks() returns
         c->opt_landmark_edges = value != 0; // (src/landmarks.jl:433-463; the undirected score itself does not read it); 0 (default): on first fetch
-        return CGE_OK;
-    }
-    if (!strcmp(key, "fit_persistent_test_delay")) { // testing: start skew of the persistent fits' tile waves, in naps of ~3 us
-        if (value < 0 || value > 100000) return CGE_E_ARG;
-        c->opt_fit_test_delay = (int)value;
         return CGE_OK;
     }
     if (!strcmp(key, "fit_max_iterations")) { // iterations after which a Chung-Lu fit that has not converged raises CGE_E_ASSERT (default 2 000 000)
         if (value < 1) return CGE_E_ARG;
         c->opt_fit_max_iters = value;
+        return CGE_OK;
+    }
+    return CGE_E_ARG;
+}
+// the testing knobs (include/cge_hip_testing.h): not part of the boundary
+int cge_set_test_option(void *ctx, const char *key, int64_t value) {
+    cge_ctx *c = (cge_ctx *)ctx;
+    if (!c || !key) return CGE_E_ARG;
+    if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget
+        c->opt_test_bvec_plain = value != 0;
+        return CGE_OK;
+    }
+    if (!strcmp(key, "fit_persistent_test_delay")) { // testing: start skew of the persistent fits' tile waves, in naps of ~3 us
+        if (value < 0 || value > 100000) return CGE_E_ARG;
+        c->opt_fit_test_delay = (int)value;
         return CGE_OK;
     }
     if (!strcmp(key, "fit_persistent_test_timeout")) { // testing: 1 = the persistent fit abandons every launch at once
@@ -1693,8 +1503,6 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "diameter_bound_pass")) *value = c->stat_bound_pass; // of the last pruned diameter: 2 bf16-split, 1 fp32 MFMA, 0 fp64 MFMA
     else if (!strcmp(key, "diameter_arg_i")) *value = c->stat_hi_i + 1; // the arg-max pair of the last diameter (1-based vertex ids)
     else if (!strcmp(key, "diameter_arg_j")) *value = c->stat_hi_j + 1;
-    else if (!strcmp(key, "diameter_on_side_context")) *value = c->stat_diameter_side;
-    else if (!strcmp(key, "side_diameter_status")) *value = c->stat_side_status; // 1 found, 2 declined (candidate list / pruning too weak), 3 failed
     else if (!strcmp(key, "fit_persistent_alphas")) *value = c->stat_fit_persistent;
     else if (!strcmp(key, "fit_iterations")) *value = c->stat_fit_iters;
     else if (!strcmp(key, "fit_fused_alphas")) *value = c->stat_fit_fused; // alphas of the last sweep whose chain rode on the fit's launch
@@ -1709,7 +1517,6 @@ int cge_get_stat(cge_ctx *c, const char *key, int64_t *value) {
             return CGE_E_HIP;
         *value = v;
     }
-    else if (!strcmp(key, "covariances_derived")) *value = c->stat_cov_derived; // sibling pairs derived from the parent's matrix
     else if (!strcmp(key, "edge_layout_build_us")) *value = c->stat_layout_build_us;
     else if (!strcmp(key, "edge_chunks")) *value = c->be_nchunks;
     else if (!strcmp(key, "edges_resident")) *value = c->m;
@@ -1873,41 +1680,6 @@ bool cge_exchange_fits(cge_ctx *c, size_t need) {
     c->xptr = c->xown.p;
     c->xcap = c->xown.n;
     return true;
-}
-
-// A shadow context: own streams, events and scratch on the same device, borrowed views of the resident arrays.  `slot`
-// = &c->side (low-priority streams: the side job of cge_score) or &c->lane (the second lane of runsplit's batches).
-cge_ctx *cge_shadow_context(cge_ctx *c, cge_ctx **slot, bool low_priority) {
-    if (!*slot) {
-        cge_ctx *sd = new cge_ctx();
-        *slot = sd; // owned from here on (cge_destroy)
-        sd->is_side = true;
-        sd->root = c;
-        sd->device = c->device;
-        sd->n_threads = 1;
-        int least = 0, greatest = 0;
-        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const int prio = low_priority ? least : 0;
-        HIP_CHECK(hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, prio));
-        sd->own_stream = true;
-        HIP_CHECK(hipStreamCreateWithPriority(&sd->copy_stream, hipStreamNonBlocking, prio));
-        HIP_CHECK(hipEventCreateWithFlags(&sd->copy_ev, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&sd->copy_done, hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->sweep_ev[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->tab_ev[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&sd->stage_ev[i], hipEventDisableTiming));
-    }
-    cge_ctx *sd = *slot;
-    // views are re-taken at every use: an upload may have replaced the buffers since the last one
-    sd->n = c->n; sd->m = c->m; sd->d = c->d; sd->ldn = c->ldn; sd->dpad = c->dpad;
-    sd->m_total = c->m_total; sd->e_first = c->e_first; sd->edges_sharded = c->edges_sharded;
-    sd->unit_weights = c->unit_weights; sd->n_comm_max = c->n_comm_max;
-    sd->Xr.borrow(c->Xr); sd->gmean.borrow(c->gmean); sd->vw.borrow(c->vw); sd->comm.borrow(c->comm);
-    sd->src.borrow(c->src); sd->dst.borrow(c->dst); sd->w.borrow(c->w);
-    sd->opt_diameter = c->opt_diameter; sd->opt_diameter_f32 = c->opt_diameter_f32;
-    sd->profiling = c->profiling; sd->profile_only = c->profile_only;
-    sd->h_Xr.clear(); // (a stale host mirror must not answer for a new embedding; it is fetched on demand)
-    return sd;
 }
 
 // all-gather of 8-byte words in place (the sharded ingest of the embedding): ncclAllGather on the ctx stream with the

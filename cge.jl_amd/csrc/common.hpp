@@ -366,8 +366,6 @@ struct cge_ctx {
     DevBuf<int> fp_flags;
     PinBuf<double> pin_scal;    // the scalars of an alpha (AUC sums, divergences, the fit's verdict), two alphas in flight
     hipEvent_t sweep_ev[2] = {nullptr, nullptr};
-    hipEvent_t pow_ev[2] = {nullptr, nullptr}, fitdone_ev = nullptr; // the next alpha's power matrix on the side stream (wgcl_host.cpp)
-    DevBuf<double> sw_GD2;                                            // ... and its buffer
     int opt_pow_exp2 = 1; // (1 - D)^alpha as exp2(alpha * log2(1 - D)) with the logarithm computed once per score
     i64 pow_logs_N = 0;   // log2(1 - D) of the current sweep is in sw_Lh / sw_Ll (0: not prepared)
     bool pow_logs_upper = false;
@@ -377,12 +375,7 @@ struct cge_ctx {
     int opt_shard_samples = 1; // N > 1: 1 = local-score tallies split over the ranks from 10^5 samples on (in-library RCCL), 2 = always, 0 = never
     int opt_shard_forced = 1; // N > 1: the forced per-community phase of runsplit is split over the ranks
     int opt_test_bvec_plain = 0; // testing: vect_B without LDS staging / rows in flight (the forms of very large score graphs)
-    int opt_fit_persistent = 0; // 0 auto (score graphs of >= 128 vertices that fit the register file), 1 never, 2 whenever it
-                                // fits, 3 whenever it fits with grid barriers instead of per-block dependency counters
-    int opt_speculation_pct = 0;   // global phase: share (%) of the still missing pops that one round may split speculatively;
-                                   // 0 = by split rule: 40 for rss / rss2 (25 when d > 128: config 5 1.51 -> 1.43 s), 10 for
-                                   // size / diameter (their cuts are unbalanced, a speculative split is wasted more often:
-                                   // config 3 68.4 -> 63.8 ms per step)
+    int opt_fit_persistent = 0; // 0 auto (score graphs of >= 128 vertices that fit the register file), 1 never, 2 whenever it fits
     i64 opt_fit_max_iters = 2000000; // a Chung-Lu fit that has not met `diff <= delta` (src/divergence.jl:151,434) after this many
                                      // iterations raises CGE_E_ASSERT -- the reference's loop has no bound and would not return
     int opt_fit_test_timeout = 0; // testing: the persistent fit gives up at once, so the fallback path runs
@@ -390,7 +383,6 @@ struct cge_ctx {
                                   // their first load -- start skew, as under contention; results must not change
     i64 stat_lm_batches = 0, stat_lm_rows = 0, stat_lm_splits = 0; // last runsplit: device batches, their rows, groups split
     DevBuf<int> cut_ties;                                          // last runsplit: tasks of the cut rules with a row ON the cut (device counter)
-    i64 stat_cov_derived = 0; // ... sibling pairs whose covariances were derived from the parent's
     i64 stat_fit_persistent = 0; // alphas fitted by the persistent kernel in the last sweep
     i64 stat_fit_iters = 0;      // Chung-Lu iterations of the last sweep (all alphas)
     // A hand-off of a persistent fit timed out (e.g. another process holds CUs): the rest of THIS sweep runs one launch per
@@ -432,9 +424,7 @@ struct cge_ctx {
     int stat_diameter_path = 0;            // 1 brute, 2 pruned
     double stat_last_hi = 0.0;
     i64 stat_hi_i = -1, stat_hi_j = -1; // its arg-max pair (0-based vertex ids)
-    int stat_side_status = 0;
     int stat_bound_pass = 0;            // bound pass of the last pruned diameter: 2 bf16-split, 1 fp32 MFMA, 0 fp64 MFMA
-    int stat_diameter_side = 0;         // 1: the last score took `hi` from the side context's search
     i64 stat_nref = 0; // reference points of the last pruned diameter (communities or landmarks)
     // scratch of the batched split engine (landmarks_host.cpp)
     DevBuf<i32> ls_rows, ls_row_task, ls_ct, ls_cb, ls_ce, ls_tco;
@@ -453,11 +443,6 @@ struct cge_ctx {
     i64 lm_means_used = 0;
     // covariances of the groups that have been split (d*d doubles each, about the group's own mean): a child's covariance is
     // its parent's minus its sibling's, so only the smaller child of a pair is summed over its rows (landmarks_host.cpp)
-    DevBuf<double> lm_covs;
-    i64 lm_covs_used = 0;
-    int opt_cov_derive = 0;  // 1: the larger child of a sibling pair by subtraction (measured: no gain, profiles/r03_cov_derive_ab.txt)
-    DevBuf<i32> ls_ct2, ls_cb2, ls_ce2, ls_tco2; // chunk tables of the tasks whose covariance is summed directly
-    DevBuf<i64> ls_pairs;                        // the sibling pairs to derive
     DevBuf<i64> ls_moff;
     PinBuf<i64> pin_moff;
     // small host <-> device tables of a landmark batch travel packed: one pinned staging area, one copy, one kernel that
@@ -475,33 +460,11 @@ struct cge_ctx {
 
     DevBuf<double> sp_zs, sp_ctot, sp_coff, sp_prefix, sp_vals;
     DevBuf<double> r2_F, r2_ck;
-    DevBuf<double> r2_PS, r2_PW; // rss2 rule: the running sums (and weights) of every row of a batch, both directions // rss2: RSS of every prefix / suffix along sorted z, block checkpoints of the two chains
     i64 r2_rows = 0;            // rows of the batch the rss2 kernels are about to see
 
-    // ---- the side context of cge_score (capi.cpp) ------------------------------------------------
-    // What a landmark-mode score needs besides the landmarks -- the point-set diameter of the ORIGINAL embedding and the
-    // local-score sample draws -- depends on the resident inputs only.  It runs on a second host thread that drives a shadow
-    // context: own (low-priority) streams, own scratch, borrowed views of the resident inputs.  Single rank only (the
-    // exchanges of an N > 1 score must be issued in one order).
-    cge_ctx *side = nullptr;
-    cge_ctx *lane = nullptr; // second lane of runsplit's batches (landmarks_host.cpp): normal priority, borrows the arenas too
-    cge_ctx *root = nullptr; // shadow contexts: the context they belong to
-    hipEvent_t members_ev = nullptr; // runsplit, two lanes: behind the last children's member lists this context's stream wrote
-    bool members_ev_set = false;     // (the other lane's next batch reads them from the arena: it waits for this event)
-    bool is_side = false;
-    int opt_lanes_test_delay = 0; // testing: the second lane's member lists land this many naps (~4 us each) late
-    int opt_lanes = 1;       // runsplit: 2 = every batch as two half-batches on two streams, half a chain out of phase; 1 (default) = one
-                             // stream.  Measured (profiles/r03_lanes_ab.txt): the eigen-solver of a half batch takes as long as that of
-                             // a whole one and the halves' kernels stretch each other: no gain on any workload
     int opt_landmark_edges = 0;  // 1: cge_score builds the N x N landmark-pair matrix too (what landmarks() returns)
-    int opt_early_diameter = 0; // 1: the diameter on the side context too (cluster-chunk partition); 0: after landmarks(), from the
-                                // landmark partition, on the main stream.  Measured (profiles/r03_side_context_ab.txt): the search is
-                                // HBM- and MFMA-heavy and runsplit's big first batches are too -- run side by side they slow each
-                                // other by as much as the overlap saves, so the default keeps it in line.
-    int opt_side_samples = 0;   // 1: the `land` clamp and the sample draws on the side context too (measured: the second host thread costs
-                                // the first more than the 0.5 ms it takes over: headline 32.6 vs 31.7 ms per step)
     // grow-only scratch of per-score helpers (no hipMalloc / hipFree inside a scoring call after the first: a hipFree waits
-    // for every stream of the device, the side context's included)
+    // for every stream of the device)
     DevBuf<i32> epd_i, s_star;
     DevBuf<double> epd_d;
     DevBuf<i64> wed_cnt;
@@ -594,7 +557,6 @@ static inline unsigned grid_for(i64 work, int block, i64 cap = 256 * 8) {
 
 #define CGE_STAGE_BYTES ((size_t)64 << 20) // one staging buffer of the uploads (profiles/r05_microbench_upload.txt: 64 MiB chunks reach the link's 54-57 GB/s)
 void cge_ensure_host_embedding(cge_ctx *c); // capi.cpp: fetch the host mirror of Xr on first demand
-cge_ctx *cge_shadow_context(cge_ctx *c, cge_ctx **slot, bool low_priority); // capi.cpp: create / refresh c->side or c->lane
 
 // ---- kernels_*.hip entry points (host launchers) ---------------------------------------------
 // layout
@@ -618,7 +580,6 @@ void k_sorted_prefix(cge_ctx *c, const double *Xr, const double *vw, const i32 *
                      double *coff, double *prefix);
 void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
                  i32 *meta, double *vals, double *cmeans);
-void k_nap(cge_ctx *c, int naps); // testing: one wave that sleeps ~4 us per nap on c->stream
 void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
                  unsigned char *side, i32 *nlow_out = nullptr, // nlow_out: rows of the low side per task (replaces k_side_counts)
                  int *tie_tasks = nullptr);                     // tie_tasks: counts the tasks that held a row with z == cut
@@ -630,10 +591,6 @@ void k_rss_rounds(cge_ctx *c, const double *Xr, const double *vw, const i32 *sro
 #define CGE_PARTIAL_BLOCKS 64 // block partials of the JS / AUC reductions (summed in block order)
 #define CGE_PREFIX_STRIDE 8 // the sorted-order WSSE prefix is stored every 8th row of a chunk (CGE_CHUNK_ROWS % 8 == 0)
 void k_gather_means(cge_ctx *c, const double *arena, const i64 *off, i64 T, i64 d, double *mean);
-// sibling pairs q: covs[ts] holds the smaller child's covariance (about its own mean); covs[tl] becomes the larger child's,
-// parent - sibling re-centred (pairs: {ts, tl, parent cov offset, mean offsets of parent, ts, tl})
-void k_cov_derive(cge_ctx *c, const i64 *pairs, i64 n_pairs, const double *means_arena, const double *covs_arena, double *covs,
-                  const i32 *rows, const i32 *task_row_off, const double *vw, i64 d);
 void k_gather_rows(cge_ctx *c, const i32 *arena, const i32 *task_off, const i32 *task_row_off, const i32 *chunk_task,
                    const i32 *chunk_beg, const i32 *chunk_end, i64 n_chunks, i32 *rows, i32 *row_task);
 void k_rss_child_keys(cge_ctx *c, const i32 *perm, const i32 *row_task, const i32 *task_row_off, const i32 *meta,
@@ -738,8 +695,6 @@ void k_gather_means_slots(cge_ctx *c, const double *arena, const i64 *off, const
 void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only);
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD, bool upper_only = false);
 void k_pow_test(cge_ctx *c, const double *x, i64 n, double alpha, int method, double *out);
-bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
-                      double delta, i64 *iters, int *final_parity, int variant);
 // What rides on the launch of the undirected persistent fit in a landmark-mode sweep relabelled by community (round 5): the
 // power matrix computed in the prologue from the stored logarithm, vect_B's tile partials and the local score's tallies in the
 // epilogue (kernels_fitp.hip: fit_flow_kernel<.., true>).  partial / auc_part == nullptr in the host copy: that part is not
@@ -764,11 +719,9 @@ void k_auc_prepare(cge_ctx *c, const i32 *v2l, const i32 *old2new, const double 
                    const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, i32 *aidx, double *afac, double *aden);
 void k_bvec_bins(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, int directed, double *vectB); // folds the tile partials into vect_B
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
-                          const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant, int *dev_flags = nullptr,
+                          const double *deg_out, double eps0, double f0, double delta, i64 *iters, int *dev_flags = nullptr,
                           bool *enqueued_only = nullptr);
 void k_fit_verdict(cge_ctx *c, const int *flags, int async, double *out); // 1.0 when an enqueued fit was abandoned
-void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
-                double delta, int k, unsigned long long *fring, int *done, int *iters);
 // the same iteration over the upper 64 x 64 tiles only (kernels_fitp.hip): half the matrix traffic
 void k_fit_sym_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
                 double delta, int k, unsigned long long *fring, int *done, int *iters);
@@ -792,8 +745,7 @@ void k_mark_edge_hits(cge_ctx *c, const i32 *src, const i32 *dst, i64 m, int dir
 // ---- host modules -----------------------------------------------------------------------------
 // landmarks_host.cpp
 void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
-                   std::vector<i64> &group_ids /*0-based*/, bool want_index = false, // also fills c->v2l / lm_mem / lm_memoff (device)
-                   const std::function<i64()> *late_nland = nullptr); // nland is asked for when the forced phase is over
+                   std::vector<i64> &group_ids /*0-based*/, bool want_index = false); // also fills c->v2l / lm_mem / lm_memoff (device)
 void host_eig_top(const double *A, i64 d, double *v); // largest-eigenvalue eigenvector, sign: max |.| component > 0
 // diameter_host.cpp
 bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const std::vector<i32> &lcomm, i64 C, i64 N,

@@ -758,8 +758,7 @@ void k_pcent_f32(cge_ctx *c, const float *Xs32, const double *rns, i64 lds_rows,
     const i64 nTI = lds_rows / 128, I0 = nTI * part / nparts, I1 = nTI * (part + 1) / nparts;
     const i64 ntiles = (I1 - I0) * (ldm / 128);
     const double e1 = 1.0 + 1.01 * (double)(dpad + 3) * 5.9604644775390625e-08; // 1 + e, e = 1.01 (K + 3) 2^-24 (covers separately rounded products too)
-    static const bool no_rowres = getenv("CGE_PCENT_NO_ROWRES") != nullptr; // A/B switch
-    if (ntiles > 0 && dpad <= 128 && !no_rowres) { // the row tile of X stays in LDS: X is read once
+    if (ntiles > 0 && dpad <= 128) { // the row tile of X stays in LDS: X is read once
         cge_allow_lds((const void *)pcent_f32_rowres_kernel, 160 * 1024);
         const size_t lds = ((size_t)dpad * 128 + 2 * PF_BK * 128) * sizeof(float);
         hipLaunchKernelGGL(pcent_f32_rowres_kernel, dim3((unsigned)std::min<i64>(I1 - I0, 512)), dim3(256), lds, c->stream, Xs32, rns,
@@ -780,7 +779,7 @@ void k_pcent_bf16(cge_ctx *c, const unsigned short *Xb, const double *rns, i64 l
     const double e1 = 1.0 + 1.05 * (3.0 * (double)(KP + 2) * 1.1920928955078125e-07 + 3.2 * 1.52587890625e-05); // 2^-23, 2^-16
     if (I1 > I0) {
         const size_t lds = (size_t)4 * 128 * (KP + PB_APAD) * sizeof(unsigned short) + (size_t)8 * 128 * sizeof(double); // both operands, both planes, whole K + the group maxima
-        static const int pb_diag = getenv("CGE_PB_DIAG") ? atoi(getenv("CGE_PB_DIAG")) : 0; // timing diagnostics (wrong bounds)
+        const int pb_diag = 0; // (the kernel's timing diagnostics: 1 no epilogue, 2 no MFMA loop)
 #define PB_GO(NKS)                                                                                                         \
     do {                                                                                                                   \
         auto kern = pcent_bf16_kernel<NKS>;                                                                                 \
@@ -947,8 +946,7 @@ i64 k_bound_select(cge_ctx *c, const double *Q, const i32 *lref, const double *m
     else
         hipLaunchKernelGGL(ref_dist2_kernel, dim3(grid_for(nref * nref, 256)), dim3(256), 0, c->stream, mu_ref, nref, d,
                            c->mp_rd2.p);
-    static const bool flat = getenv("CGE_BOUND_FLAT") != nullptr; // A/B switch
-    if (ref_off && ref_mem && !flat) {
+    if (ref_off && ref_mem) {
         c->mp_commax.ensure((size_t)nref * nref);
         c->mp_plist.ensure((size_t)nref * (nref + 1)); // int2 per community pair
         hipLaunchKernelGGL(comm_max_kernel, dim3((unsigned)nref), dim3(256), 0, c->stream, Q, ref_off, ref_mem, nref, c->mp_commax.p);
@@ -1159,9 +1157,8 @@ __global__ __launch_bounds__(256) void pair_dist_tile_kernel(const double *__res
 }
 void k_pair_dist(cge_ctx *c, const double *Xr, i64 d, const i32 *pi, const i32 *pj, i64 S, double den, double *out) {
     if (S <= 0) return;
-    static const bool thread_form = getenv("CGE_PAIR_DIST_THREADS") != nullptr; // A/B: a thread per pair for every size
     const size_t lds = (size_t)16 * (d + 1) * sizeof(double);
-    if (S >= 4096 && lds <= 64 * 1024 && !thread_form) {
+    if (S >= 4096 && lds <= 64 * 1024) {
         const unsigned nb = (unsigned)std::min<i64>((S + 15) / 16, 256 * 16);
         hipLaunchKernelGGL(pair_dist_tile_kernel, dim3(nb), dim3(256), lds, c->stream, Xr, d, pi, pj, S, den, out);
         return;

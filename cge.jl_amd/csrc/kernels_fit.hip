@@ -1,7 +1,5 @@
 // kernels_fit.hip -- the alpha sweep on the device.
 //   k_pow_matrix     GD = (1 - D)^alpha                               src/divergence.jl:142-148 (:426-432)
-//   k_fit_step               one Chung-Lu iteration, undirected       src/divergence.jl:150-168
-//                            (the launch-per-iteration fallback of the persistent fit, kernels_fitp.hip)
 //   k_fit_symv_dir/_update_dir  directed (Tin/Tout, adaptive eps)     src/divergence.jl:434-467
 //   k_bvec           vect_B = community-pair sums of P                src/divergence.jl:226-234 (:530-538)
 //   k_js             JS(vect_C, vect_B[, vI])                         src/auxilary.jl:34-52
@@ -148,83 +146,9 @@ void k_pow_test(cge_ctx *c, const double *x, i64 n, double alpha, int method, do
 }
 
 // ------------------------------------------------------------------------------------------------
-// S_i = sum_j (T_i*T_j)*GD_ij  (full symmetric GD: the diagonal is counted once, as :153-159).  One wave per row,
-// 16-byte loads, shuffle reduction (fixed lane pattern => reproducible); 4 rows per workgroup.  Every launch of a fit
-// returns at once when *done is set, so the host can enqueue iterations in batches and still stop exactly at the
-// reference's iteration.
 typedef double dbl2 __attribute__((ext_vector_type(2)));
-// One whole Chung-Lu iteration per launch (undirected): S_i as above from T = Tin, then the update
-// Tout_i = T_i + eps*T_i*(w_i/S_i - 1) and f = max_i |w_i - S_i| (:160-166) in the epilogue -- no separate update
-// launch.  T is double-buffered by the caller (iteration k reads buf[k&1], writes buf[(k+1)&1]); f is an atomic
-// max on the bit pattern of a non-negative double (exact, order-free) in fring[k % 3].  The launch of iteration
-// k + 1 starts by reading f_k: when it is <= delta the fit is over (iters = k + 1, the final T is the one
-// iteration k wrote, exactly the reference's `while diff > delta`); every later launch of the batch returns at
-// `*done`.  fring[(k+1) % 3] is cleared by iteration k for iteration k + 1.
-__global__ __launch_bounds__(256) void fit_step_kernel(const double *__restrict__ GD, const double *__restrict__ T,
-                                                       double *__restrict__ Tout, const double *__restrict__ w, i64 N,
-                                                       double eps, double delta, int k,
-                                                       unsigned long long *__restrict__ fring, int *__restrict__ done,
-                                                       int *__restrict__ iters) {
-    __shared__ double fw[4];
-    if (*done) return;
-    if (k > 0) {
-        const double fprev = __longlong_as_double((long long)fring[(k - 1) % 3]);
-        if (!(fprev > delta)) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) { *iters = k; *done = 1; }
-            return;
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { fring[(k + 1) % 3] = 0ULL; *iters = k + 1; }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const i64 i = (i64)blockIdx.x * 4 + wave;
-    double f = 0.0;
-    if (i < N) {
-        const double ti = T[i];
-        const double wi = w[i]; // needed by lane 0 only, after the reduction: loaded here so that it is not waited for there
-        const double *row = GD + i * N;
-        double s0 = 0.0, s1 = 0.0;
-        if ((N & 1) == 0) { // rows are 16-B aligned
-            const i64 n2 = N >> 1;
-            const dbl2 *row2 = reinterpret_cast<const dbl2 *>(row);
-            const dbl2 *T2 = reinterpret_cast<const dbl2 *>(T);
-            i64 q = lane;
-            for (; q + 192 < n2; q += 256) { // 4 independent 16-B loads in flight per operand
-                const dbl2 g0 = row2[q], g1 = row2[q + 64], g2 = row2[q + 128], g3 = row2[q + 192];
-                const dbl2 t0 = T2[q], t1 = T2[q + 64], t2 = T2[q + 128], t3 = T2[q + 192];
-                s0 += (ti * t0.x) * g0.x; s1 += (ti * t0.y) * g0.y;
-                s0 += (ti * t1.x) * g1.x; s1 += (ti * t1.y) * g1.y;
-                s0 += (ti * t2.x) * g2.x; s1 += (ti * t2.y) * g2.y;
-                s0 += (ti * t3.x) * g3.x; s1 += (ti * t3.y) * g3.y;
-            }
-            for (; q < n2; q += 64) {
-                const dbl2 g0 = row2[q], t0 = T2[q];
-                s0 += (ti * t0.x) * g0.x; s1 += (ti * t0.y) * g0.y;
-            }
-        } else {
-            for (i64 j = lane; j < N; j += 64) s0 += (ti * T[j]) * row[j];
-        }
-        double si = s0 + s1;
-        for (int off = 32; off > 0; off >>= 1) si += __shfl_xor(si, off);
-        if (lane == 0) {
-            Tout[i] = ti + (eps * ti) * (wi / si - 1.0);
-            f = fabs(wi - si);
-        }
-    }
-    if (lane == 0) fw[wave] = f;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double fm = fmax(fmax(fw[0], fw[1]), fmax(fw[2], fw[3]));
-        // most workgroups lose against the running maximum: look before the (same-address, serialising) atomic
-        const unsigned long long fb = (unsigned long long)__double_as_longlong(fm);
-        if (fb > __hip_atomic_load(&fring[k % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&fring[k % 3], fb);
-    }
-}
-void k_fit_step(cge_ctx *c, const double *GD, const double *Tin, double *Tout, const double *w, i64 N, double eps,
-                double delta, int k, unsigned long long *fring, int *done, int *iters) {
-    ScopedKernelTimer t(c, "fit_symv");
-    hipLaunchKernelGGL(fit_step_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, GD, Tin, Tout, w, N, eps,
-                       delta, k, fring, done, iters);
-}
+// (The undirected launch-per-iteration fit lives in kernels_fitp.hip -- fit_symtile_kernel + fit_symreduce_kernel, over the
+// upper tiles only; the whole-row kernel of rounds 1-3 was removed in round 5.)
 // directed: Sin_i = sum_j (Tin_i*Tout_j)*g_ij + diagonal once more; Sout_i = sum_j (Tin_j*Tout_i)*g_ij + diagonal
 // once more (the reference's i..N inner loop visits j == i and adds both tmp1 and tmp2, :439-449)
 __global__ __launch_bounds__(256) void fit_symv_dir_kernel(const double *__restrict__ GD,

@@ -16,16 +16,14 @@
 //                B) workgroup sb (one 16-row quarter of a block): S_i = sum of the block's Nt partial vectors in a
 //                   fixed order, T_i += eps*T_i*(w_i/S_i - 1), f = max|w_i - S_i| (:160-166);
 //                C) `while f > delta`, decided by every workgroup from the same maxima.
-// Four kernels share this scheme.  fit_flow_kernel (the default, undirected) uses the data as its own signal: a slot that
-// has not been delivered holds a sentinel and consumers poll the values they need (its header has the re-arming argument).
-// fit_dataflow_kernel (option 4) and fit_dataflow_dir_kernel (directed) order A, B and C by per-block dependency counters;
-// fit_persistent_kernel (option 3) separates them by two XCD-hierarchical grid barriers per iteration.  In all of them
-// every value that crosses workgroups is stored and loaded with agent-scope relaxed atomics (sc1: write-through stores,
-// L1-bypassing loads); in the counter / barrier forms every storing wave drains its stores before one lane of its
-// workgroup signals, and a consumer puts a workgroup barrier between its poll and its loads (cdna_hip_programming.md,
-// Guideline 16).  Every spin is bounded: on a timeout the launch sets `fail`, every workgroup leaves, and the host falls
-// back to one launch per iteration.  All sums have a fixed order: a run is bitwise reproducible, and the forms give
-// identical bits.
+// Two kernels share this scheme, fit_flow_kernel (undirected) and fit_flow_dir_kernel (directed): THE DATA IS ITS OWN SIGNAL --
+// a slot that has not been delivered holds a sentinel and consumers poll the values they need (the header of fit_flow_kernel
+// has the re-arming argument).  Every value that crosses workgroups is stored and loaded with agent-scope relaxed atomics
+// (sc1: write-through stores, L1-bypassing loads).  Every spin is bounded: on a timeout the launch sets `fail`, every
+// workgroup leaves, and the host falls back to one launch per iteration (fit_symtile_kernel + fit_symreduce_kernel below,
+// which is also what score graphs beyond the register file use).  All sums have a fixed order: a run is bitwise
+// reproducible.  (Rounds 1-4 carried two more forms -- two XCD-hierarchical grid barriers per iteration, 15 us, and per-block
+// dependency counters, 10.7 us against 6.1 -- as options 3 / 4 of "fit_persistent"; removed in round 5.)
 #include "common.hpp"
 #include "pow_parts.hpp"
 
@@ -66,392 +64,8 @@ __device__ __forceinline__ double transpose_reduce8(const double (&v)[8], int la
     return keep + __shfl_xor(send, 1 << SH);
 }
 
-// ---- grid barrier ------------------------------------------------------------------------------------------------
-// Two levels, so that the 256 arrivals do not serialise on one address: workgroups are grouped by the XCD they run
-// on (read from the hardware register; any grouping would be correct, this one keeps the arrivals and the release
-// of a group inside one L2).  The last arriver of a group adds to the top counter, waits for all groups, then bumps
-// its group's generation word, which the rest of the group polls.  Counters are monotonic (epoch e = 1, 2, ...),
-// each on its own 128-byte line, zeroed by the host before the launch.  Group sizes are counted in the kernel's
-// first barrier, which is a flat one.  Every spin is bounded by `deadline`; a timeout sets `fail` for everybody.
-#define SYNC_WORDS 1024 // unsigned words zeroed per launch
-struct GridSync {
-    unsigned *flat, *fail, *top, *garr, *ggen, *gcount; // garr/ggen/gcount: 8 entries, 32 words apart
-    unsigned gsize, ngroups, epoch;
-    int xcc;
-    long long deadline;
-    int *lds_ok;
-
-    __device__ __forceinline__ bool spin_until(unsigned *word, unsigned target) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(word, RLX_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 255u) == 0 && (wall_clock64() > deadline || __hip_atomic_load(fail, RLX_AGENT) != 0u)) {
-                __hip_atomic_store(fail, 1u, RLX_AGENT);
-                return false;
-            }
-        }
-        return true;
-    }
-    // the launch's first barrier: flat, and it counts the groups
-    __device__ __forceinline__ bool init(unsigned *sync, long long dl, int *ok_word) {
-        flat = sync; fail = sync + 1; top = sync + 32; garr = sync + 64; ggen = sync + 64 + 256; gcount = sync + 64 + 512;
-        deadline = dl; lds_ok = ok_word; epoch = 0;
-        unsigned id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(id));
-        xcc = (int)(id & 7u);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(gcount + 32 * xcc, 1u, RLX_AGENT);
-            __hip_atomic_fetch_add(flat, 1u, RLX_AGENT);
-            *lds_ok = spin_until(flat, gridDim.x) ? 1 : 0;
-        }
-        __syncthreads();
-        if (!*lds_ok) return false;
-        gsize = __hip_atomic_load(gcount + 32 * xcc, RLX_AGENT);
-        ngroups = 0;
-        for (int x = 0; x < 8; x++) ngroups += __hip_atomic_load(gcount + 32 * x, RLX_AGENT) != 0u;
-        return true;
-    }
-    // all workgroups arrive; false = timed out (the launch is abandoned)
-    __device__ __forceinline__ bool sync() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its write-through stores have left
-        __syncthreads();
-        epoch++;
-        if (threadIdx.x == 0) {
-            int good = 1;
-            const unsigned before = __hip_atomic_fetch_add(garr + 32 * xcc, 1u, RLX_AGENT);
-            if (before + 1 == gsize * epoch) { // last of the group
-                __hip_atomic_fetch_add(top, 1u, RLX_AGENT);
-                good = spin_until(top, ngroups * epoch) ? 1 : 0;
-                __hip_atomic_store(ggen + 32 * xcc, epoch, RLX_AGENT);
-            } else
-                good = spin_until(ggen + 32 * xcc, epoch) ? 1 : 0;
-            *lds_ok = good;
-        }
-        __syncthreads();
-        return *lds_ok != 0;
-    }
-};
-
-template <int TPW>
-__global__ __launch_bounds__(256) void fit_persistent_kernel(const double *__restrict__ GD, i64 N, int Nt, double *Tbuf,
-                                                             i64 Tld, int parity, const double *__restrict__ w,
-                                                             double eps, double delta, int max_iters, double *P,
-                                                             double *fpart, unsigned *sync, int *flags,
-                                                             long long timeout_ticks) {
-    extern __shared__ __attribute__((aligned(16))) double Ts[]; // Nt*64 doubles: the current T, zero beyond N
-    __shared__ double red[16][17];
-    __shared__ double fred[4];
-    __shared__ int lds_ok;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
-    const int rq = lane >> 3, cq = lane & 7;
-    const int NT = Nt * (Nt + 1) / 2;
-    GridSync gs;
-
-    // ---- the wave's tiles into registers ---------------------------------------------------------------------
-    double g[TPW][8][8];
-    int tI[TPW], tJ[TPW];
-#pragma unroll
-    for (int s = 0; s < TPW; s++) {
-        const int t = (wg * 4 + wave) + s * 4 * G;
-        tI[s] = -1;
-        tJ[s] = -1;
-        if (t < NT) { // row-major upper triangle: row I holds Nt - I tiles
-            int I = 0, rem = t;
-            while (rem >= Nt - I) { rem -= Nt - I; I++; }
-            tI[s] = I;
-            tJ[s] = I + rem;
-        }
-#pragma unroll
-        for (int a = 0; a < 8; a++) {
-            const i64 row = (i64)64 * tI[s] + 8 * rq + a;
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const i64 col = (i64)64 * tJ[s] + 8 * cq + b;
-                g[s][a][b] = (tI[s] >= 0 && row < N && col < N) ? GD[row * N + col] : 0.0;
-            }
-        }
-    }
-    const int Np = Nt * 64;
-    for (int i = tid; i < Np; i += 256) Ts[i] = Tbuf[(i64)parity * Tld + i]; // written before the launch
-    __syncthreads();
-
-    int par = parity, k = 0, converged = 0, failed = 0;
-    if (timeout_ticks <= 0 || !gs.init(sync, wall_clock64() + timeout_ticks, &lds_ok)) { failed = 1; max_iters = 0; }
-    while (k < max_iters) {
-        gs.deadline = wall_clock64() + timeout_ticks; // per iteration, as in the other forms
-        // ---- A: tile products ----------------------------------------------------------------------------------
-#pragma unroll
-        for (int s = 0; s < TPW; s++) {
-            if (tI[s] < 0) continue; // uniform per wave
-            const int I = tI[s], J = tJ[s];
-            double ti[8], tj[8], pr[8], pc[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                ti[q] = Ts[64 * I + 8 * rq + q];
-                tj[q] = Ts[64 * J + 8 * cq + q];
-                pr[q] = 0.0;
-                pc[q] = 0.0;
-            }
-#pragma unroll
-            for (int a = 0; a < 8; a++)
-#pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    pr[a] = fma(g[s][a][b], tj[b], pr[a]); // factored: the row's own T_i is applied by the reducer
-                    pc[b] = fma(g[s][a][b], ti[a], pc[b]);
-                }
-            const double rsum = transpose_reduce8<0>(pr, lane); // row 8*rq + cq of the tile
-            st_sc1(P + ((i64)I * Nt + J) * 64 + lane, rsum);
-            if (I != J) {
-                const double csum = transpose_reduce8<3>(pc, lane); // column 8*cq + rq of the tile
-                st_sc1(P + ((i64)J * Nt + I) * 64 + 8 * cq + rq, csum);
-            }
-        }
-        if (!gs.sync()) { failed = 1; break; }
-        // ---- B: S, the update and f for this workgroup's quarter blocks -------------------------------------------
-        double fmine = 0.0;
-        for (int sb = wg; sb < 4 * Nt; sb += G) {
-            const int b = sb >> 2, r = tid & 15, qg = tid >> 4, rib = 16 * (sb & 3) + r;
-            double pv[5]; // up to 80 partial vectors (three tiles per wave on 256 CUs: Nt <= 77)
-#pragma unroll
-            for (int u = 0; u < 5; u++) {
-                const int q = qg + 16 * u;
-                pv[u] = (q < Nt) ? ld_sc1(P + ((i64)b * Nt + q) * 64 + rib) : 0.0;
-            }
-            __syncthreads(); // red is free again
-            red[qg][r] = (((pv[0] + pv[1]) + pv[2]) + pv[3]) + pv[4]; // pv[4] = 0.0 up to 64 blocks: the bits of the shorter sum
-            __syncthreads();
-            if (qg == 0) {
-                double S = red[0][r];
-#pragma unroll
-                for (int u = 1; u < 16; u++) S += red[u][r];
-                const i64 row = (i64)64 * b + rib;
-                if (row < N) {
-                    const double tcur = Ts[row], wi = w[row];
-                    S *= tcur; // S_i = T_i * sum_j g_ij T_j: the tiles summed g * T
-                    st_sc1(Tbuf + (i64)(par ^ 1) * Tld + row, tcur + (eps * tcur) * (wi / S - 1.0));
-                    fmine = fmax(fmine, fabs(wi - S));
-                }
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) fmine = fmax(fmine, __shfl_xor(fmine, off));
-        if (lane == 0) fred[wave] = fmine;
-        __syncthreads();
-        if (tid == 0) st_sc1(fpart + wg, fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3])));
-        if (!gs.sync()) { failed = 1; break; }
-        // ---- C: the new T and the convergence test, identical in every workgroup -----------------------------------
-        par ^= 1;
-        k++;
-        for (int i = tid; i < Np; i += 256) Ts[i] = (i < N) ? ld_sc1(Tbuf + (i64)par * Tld + i) : 0.0;
-        double f = (tid < G) ? ld_sc1(fpart + tid) : 0.0;
-        for (int q = tid + 256; q < G; q += 256) f = fmax(f, ld_sc1(fpart + q));
-        for (int off = 32; off > 0; off >>= 1) f = fmax(f, __shfl_xor(f, off));
-        if (lane == 0) fred[wave] = f;
-        __syncthreads();
-        f = fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3]));
-        __syncthreads(); // fred, Ts
-        if (!(f > delta)) { converged = 1; break; } // `while diff > delta`
-    }
-    if (wg == 0 && tid == 0) {
-        flags[0] = converged;
-        flags[1] = k;       // iterations done by this launch
-        flags[2] = failed;
-        flags[3] = par;     // the buffer that holds the current T
-    }
-}
-
-// ---- the same fit without grid barriers ---------------------------------------------------------------------------
-// Dependencies are tracked per 64-row block instead: cntP[b] counts the partial vectors published for block b (Nt per
-// iteration), cntT[b] the 16-row quarters of T published for it (4 per iteration).  A workgroup starts the tile
-// products of iteration k as soon as the T blocks of ITS tiles are there, and the reduction of its quarter block as
-// soon as that block's Nt partial vectors are there; nobody waits for the whole grid.  Buffer reuse is safe without
-// further flags: P[b][q] of iteration k+1 is written only after T_{k+1} of blocks b and q was published, i.e. after
-// their reducers have read P of iteration k; T_{k+1} overwrites T_{k-1} only after every tile that reads block b has
-// delivered its iteration-k partial, i.e. finished reading T_{k-1}; f of iteration k-1 (one maximum per quarter
-// block, two buffers) is complete when any block's iteration-k partials are.  Convergence (`while diff > delta`) is
-// decided by every reducing workgroup from the same values at the same iteration; workgroups without a quarter block
-// leave through the `done` word.  Signals follow cdna_hip_programming.md Guideline 16: write-through stores, every
-// wave drains, a workgroup barrier, then ONE lane adds to the counter; the consumer polls with one wave, a workgroup
-// barrier, then L1-bypassing loads.  Every spin is bounded (timeout -> `fail` -> host fallback).
-#define DF_WORDS 8192 // unsigned words zeroed per launch: [1] fail, [2] done, cntP at 64+32b, cntT at 4096+32b
-__device__ __forceinline__ int poll_ge(unsigned *word, unsigned target, unsigned *fail, unsigned *done, long long deadline) {
-    unsigned spins = 0; // 0 = reached, 1 = the fit is over, 2 = abandoned
-    while (__hip_atomic_load(word, RLX_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 63u) == 0) {
-            if (__hip_atomic_load(done, RLX_AGENT) != 0u) return 1;
-            if (wall_clock64() > deadline || __hip_atomic_load(fail, RLX_AGENT) != 0u) {
-                __hip_atomic_store(fail, 1u, RLX_AGENT);
-                return 2;
-            }
-        }
-    }
-    return 0;
-}
-template <int TPW>
-__global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restrict__ GD, i64 N, int Nt, double *Tbuf,
-                                                           i64 Tld, int parity, const double *__restrict__ w, double eps,
-                                                           double delta, int max_iters, double *P, double *fq,
-                                                           unsigned *sync, int *flags, long long timeout_ticks) {
-    __shared__ double red[16][17];
-    __shared__ double fred[4];
-    __shared__ int lds_flag;
-    __shared__ int blkI[4 * TPW], blkJ[4 * TPW]; // the workgroup's tiles, by wave and slot (-1 = none)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
-    const int rq = lane >> 3, cq = lane & 7;
-    const int NT = Nt * (Nt + 1) / 2;
-    unsigned *fail = sync + 1, *done = sync + 2, *cntP = sync + 64, *cntT = sync + 4096;
-    long long deadline = wall_clock64() + timeout_ticks; // re-armed at every iteration: it bounds one hand-off, not the whole fit
-
-    double g[TPW][8][8];
-    int tI[TPW], tJ[TPW];
-#pragma unroll
-    for (int s = 0; s < TPW; s++) {
-        const int t = (wg * 4 + wave) + s * 4 * G;
-        tI[s] = -1;
-        tJ[s] = -1;
-        if (t < NT) {
-            int I = 0, rem = t;
-            while (rem >= Nt - I) { rem -= Nt - I; I++; }
-            tI[s] = I;
-            tJ[s] = I + rem;
-        }
-        if (lane == 0) { blkI[wave * TPW + s] = tI[s]; blkJ[wave * TPW + s] = tJ[s]; }
-#pragma unroll
-        for (int a = 0; a < 8; a++) {
-            const i64 row = (i64)64 * tI[s] + 8 * rq + a;
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const i64 col = (i64)64 * tJ[s] + 8 * cq + b;
-                g[s][a][b] = (tI[s] >= 0 && row < N && col < N) ? GD[row * N + col] : 0.0;
-            }
-        }
-    }
-    __syncthreads();
-    // this thread's share of the workgroup's signalling / waiting: entry tid -> block of tile tid/2, side tid%2
-    int my_blk = -1;
-    if (tid < 8 * TPW) {
-        const int e = tid >> 1;
-        my_blk = (tid & 1) ? ((blkJ[e] != blkI[e]) ? blkJ[e] : -1) : blkI[e];
-    }
-
-    int par = parity, k = 0, converged = 0, failed = 0;
-    if (timeout_ticks <= 0) max_iters = 0; // test hook: abandon at once (exercises the host's restore-and-fall-back path)
-    for (;;) {
-        deadline = wall_clock64() + timeout_ticks;
-        if (k >= max_iters) { failed = 1; break; }
-        // ---- 1. wait for T_k of the blocks this workgroup's tiles read (published by iteration k-1) --------------
-        if (k > 0) {
-            if (wave == 0) {
-                int r = 0;
-                if (my_blk >= 0) r = poll_ge(cntT + 32 * my_blk, 4u * (unsigned)k, fail, done, deadline);
-                r = __any(r == 2) ? 2 : (__any(r == 1) ? 1 : 0);
-                if (lane == 0) lds_flag = r;
-            }
-            __syncthreads();
-            const int r = lds_flag;
-            __syncthreads();
-            if (r == 2) { failed = 1; break; }
-            if (r == 1) { converged = 1; break; } // see below
-        }
-        // ---- 2. tile products with T_k ------------------------------------------------------------------------------
-        const double *Tk = Tbuf + (i64)par * Tld;
-#pragma unroll
-        for (int s = 0; s < TPW; s++) {
-            if (tI[s] < 0) continue; // uniform per wave
-            const int I = tI[s], J = tJ[s];
-            double ti[8], tj[8], pr[8], pc[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                ti[q] = ld_sc1(Tk + 64 * I + 8 * rq + q);
-                tj[q] = ld_sc1(Tk + 64 * J + 8 * cq + q);
-                pr[q] = 0.0;
-                pc[q] = 0.0;
-            }
-#pragma unroll
-            for (int a = 0; a < 8; a++)
-#pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    pr[a] = fma(g[s][a][b], tj[b], pr[a]); // factored: the row's own T_i is applied by the reducer
-                    pc[b] = fma(g[s][a][b], ti[a], pc[b]);
-                }
-            const double rsum = transpose_reduce8<0>(pr, lane);
-            st_sc1(P + ((i64)I * Nt + J) * 64 + lane, rsum);
-            if (I != J) {
-                const double csum = transpose_reduce8<3>(pc, lane);
-                st_sc1(P + ((i64)J * Nt + I) * 64 + 8 * cq + rq, csum);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its partial vectors have left
-        __syncthreads();
-        if (my_blk >= 0) __hip_atomic_fetch_add(cntP + 32 * my_blk, 1u, RLX_AGENT);
-        // ---- 3. the quarter blocks this workgroup reduces ---------------------------------------------------------
-        bool stop = false;
-        for (int sb = wg; sb < 4 * Nt; sb += G) {
-            const int b = sb >> 2, r = tid & 15, qg = tid >> 4, rib = 16 * (sb & 3) + r;
-            if (tid == 0) lds_flag = poll_ge(cntP + 32 * b, (unsigned)Nt * (unsigned)(k + 1), fail, done, deadline);
-            __syncthreads();
-            const int pr_ = lds_flag;
-            if (pr_ != 0) { failed = (pr_ == 2); converged = (pr_ == 1); stop = true; break; } // uniform
-            double pv[5]; // up to 80 partial vectors (three tiles per wave on 256 CUs: Nt <= 77)
-#pragma unroll
-            for (int u = 0; u < 5; u++) {
-                const int q = qg + 16 * u;
-                pv[u] = (q < Nt) ? ld_sc1(P + ((i64)b * Nt + q) * 64 + rib) : 0.0;
-            }
-            if (k > 0 && sb == wg) { // f of iteration k-1 is complete now: `while diff > delta`
-                double f = 0.0;
-                const double *fp = fq + (i64)((k - 1) & 1) * 4 * Nt;
-                for (int q = tid; q < 4 * Nt; q += 256) f = fmax(f, ld_sc1(fp + q));
-                for (int off = 32; off > 0; off >>= 1) f = fmax(f, __shfl_xor(f, off));
-                if (lane == 0) fred[wave] = f;
-                __syncthreads();
-                f = fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3]));
-                if (!(f > delta)) { converged = 1; stop = true; break; } // uniform
-            }
-            __syncthreads(); // red and lds_flag are free again
-            red[qg][r] = (((pv[0] + pv[1]) + pv[2]) + pv[3]) + pv[4]; // pv[4] = 0.0 up to 64 blocks: the bits of the shorter sum
-            __syncthreads();
-            if (qg == 0) { // lanes 0..15 of wave 0
-                double S = red[0][r];
-#pragma unroll
-                for (int u = 1; u < 16; u++) S += red[u][r];
-                const i64 row = (i64)64 * b + rib;
-                double fr = 0.0;
-                if (row < N) {
-                    const double tcur = ld_sc1(Tk + row), wi = w[row];
-                    S *= tcur; // S_i = T_i * sum_j g_ij T_j: the tiles summed g * T
-                    st_sc1(Tbuf + (i64)(par ^ 1) * Tld + row, tcur + (eps * tcur) * (wi / S - 1.0));
-                    fr = fabs(wi - S);
-                }
-                for (int off = 8; off > 0; off >>= 1) fr = fmax(fr, __shfl_xor(fr, off));
-                if (r == 0) st_sc1(fq + (i64)(k & 1) * 4 * Nt + sb, fr);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(cntT + 32 * b, 1u, RLX_AGENT);
-        }
-        if (stop) {
-            // Whoever finds f_{k-1} <= delta says so.  `done` may be honoured at any poll: it is set only after some block's
-            // iteration-k partials were complete, i.e. after every workgroup finished its iteration-(k-1) reduction and
-            // its iteration-k products -- so every workgroup that sees it holds the same k and the same parity, T_k is
-            // complete, and nobody who has not decided yet will write T_{k+1} (the decision precedes the update).
-            if (converged && tid == 0) __hip_atomic_store(done, 1u, RLX_AGENT);
-            break;
-        }
-        par ^= 1;
-        k++;
-    }
-    if (wg == 0 && tid == 0) {
-        flags[0] = converged;
-        flags[1] = k;   // iterations done: T_k is final
-        flags[2] = failed || !converged;
-        flags[3] = par; // the buffer that holds T_k
-    }
-}
-
 // ---- the fit with the data as its own signal ------------------------------------------------------------------------
-// Same tiles, same sums and the same order of additions as fit_dataflow_kernel, but no counters: a slot that has not
+// No counters, no grid barrier: a slot that has not
 // been delivered yet holds SENTINEL (a NaN payload that arithmetic never produces), and a consumer polls the values it
 // needs until none of them is the sentinel.  A hand-off is then one write-through store and one L1-bypassing load --
 // the producer neither drains its stores nor signals, the consumer needs no barrier between a poll and its loads.
@@ -464,8 +78,8 @@ __global__ __launch_bounds__(256) void fit_dataflow_kernel(const double *__restr
 //          them two iterations later has by then consumed a T_{k+2} stored after the arming stores were drained.
 //   f      three buffers (k mod 3): f_k is stored with T_{k+1}, read by every reducer in iteration k+1, armed again by
 //          its writer in iteration k+2 -- one iteration before the next value lands there.
-// Everything is armed by a fill before the launch.  `done` / `fail` work as in fit_dataflow_kernel (looked at every 64
-// polls); a poll never sees a stale value, only the sentinel or the value it waits for.
+// Everything is armed by a fill before the launch.  `done` / `fail` are looked at every 64 polls; a poll never sees a stale
+// value, only the sentinel or the value it waits for.
 #define FLOW_SENTINEL_WORD 0x7FF8DEADu
 #define FLOW_SENTINEL 0x7FF8DEAD7FF8DEADull
 __device__ __forceinline__ bool armed(double v) { return (unsigned long long)__double_as_longlong(v) == FLOW_SENTINEL; }
@@ -1041,8 +655,10 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
 // products of the symmetric pair, exactly as the persistent kernels do with their register-resident tiles: same lane
 // layout (lane 8*rq + cq holds the 8 x 8 block), same transposing reductions, partial vectors P[block][other block][64].
 // The second kernel adds a block's Nt partial vectors (four interleaved sequential sums, then ((s0+s1)+s2)+s3 -- a fixed
-// order for any Nt), updates T and publishes f with the protocol of fit_step_kernel (fring / done / iters), so the host
-// loop is the same.  Traffic per iteration: 4 N^2 (+ N^2 / 4 for the partial vectors) instead of 8 N^2 bytes.
+// order for any Nt), updates T and publishes f: an atomic max on the bit pattern of a non-negative double (exact,
+// order-free) in fring[k % 3]; the launch of iteration k + 1 starts by reading f_k -- when it is <= delta the fit is over
+// (iters = k + 1, the final T is the one iteration k wrote, exactly the reference's `while diff > delta`) and every later
+// launch of the batch returns at `*done`; fring[(k+1) % 3] is cleared by iteration k for iteration k + 1.  Traffic per iteration: 4 N^2 (+ N^2 / 4 for the partial vectors) instead of 8 N^2 bytes.
 __global__ __launch_bounds__(256) void fit_symtile_kernel(const double *__restrict__ GD, const double *__restrict__ T, i64 N,
                                                           int Nt, i64 NT, double delta, int k,
                                                           const unsigned long long *__restrict__ fring,
@@ -1147,189 +763,6 @@ __global__ __launch_bounds__(256) void fit_symreduce_kernel(const double *__rest
         }
     }
 }
-// ---- the directed fit (src/divergence.jl:434-467) in the same dataflow form ----------------------------------------
-// Sin_i = sum_j (Tin_i*Tout_j)*g_ij, Sout_i = sum_j (Tin_j*Tout_i)*g_ij, the diagonal term counted twice (:439-449).
-// A tile element feeds four sums: e1 = (Tin_i*Tout_j)*g goes to Sin_i and Sout_j, e2 = (Tin_j*Tout_i)*g to Sout_i and
-// Sin_j.  T holds four vectors per parity (Tbuf[(2*par + 0/1)*Tld] = Tin / Tout), P two partial vectors per
-// (block, other block) (P[0] for Sin, P[1] for Sout).  The step size decays (`epsilon *= 0.99` whenever f grew, :462-464):
-// every reducing workgroup replays that rule from the same f history, which it reads anyway for the convergence test.
-template <int TPW>
-__global__ __launch_bounds__(256) void fit_dataflow_dir_kernel(const double *__restrict__ GD, i64 N, int Nt, double *Tbuf,
-                                                               i64 Tld, int parity, const double *__restrict__ deg_in,
-                                                               const double *__restrict__ deg_out, double eps0,
-                                                               double f0, double delta, int max_iters, double *P,
-                                                               double *fq, unsigned *sync, int *flags,
-                                                               long long timeout_ticks) {
-    __shared__ double red[2][16][17];
-    __shared__ double fred[4];
-    __shared__ int lds_flag;
-    __shared__ int blkI[4 * TPW], blkJ[4 * TPW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, G = gridDim.x;
-    const int rq = lane >> 3, cq = lane & 7;
-    const int NT = Nt * (Nt + 1) / 2;
-    unsigned *fail = sync + 1, *done = sync + 2, *cntP = sync + 64, *cntT = sync + 4096;
-    long long deadline = wall_clock64() + timeout_ticks; // re-armed at every iteration: it bounds one hand-off, not the whole fit
-    const i64 Pstride = (i64)Nt * Nt * 64;
-
-    double g[TPW][8][8];
-    int tI[TPW], tJ[TPW];
-#pragma unroll
-    for (int s = 0; s < TPW; s++) {
-        const int t = (wg * 4 + wave) + s * 4 * G;
-        tI[s] = -1;
-        tJ[s] = -1;
-        if (t < NT) {
-            int I = 0, rem = t;
-            while (rem >= Nt - I) { rem -= Nt - I; I++; }
-            tI[s] = I;
-            tJ[s] = I + rem;
-        }
-        if (lane == 0) { blkI[wave * TPW + s] = tI[s]; blkJ[wave * TPW + s] = tJ[s]; }
-#pragma unroll
-        for (int a = 0; a < 8; a++) {
-            const i64 row = (i64)64 * tI[s] + 8 * rq + a;
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const i64 col = (i64)64 * tJ[s] + 8 * cq + b;
-                g[s][a][b] = (tI[s] >= 0 && row < N && col < N) ? GD[row * N + col] : 0.0;
-            }
-        }
-    }
-    __syncthreads();
-    int my_blk = -1;
-    if (tid < 8 * TPW) {
-        const int e = tid >> 1;
-        my_blk = (tid & 1) ? ((blkJ[e] != blkI[e]) ? blkJ[e] : -1) : blkI[e];
-    }
-
-    int par = parity, k = 0, converged = 0, failed = 0;
-    double eps = eps0, fprev = f0;
-    if (timeout_ticks <= 0) max_iters = 0; // test hook
-    for (;;) {
-        deadline = wall_clock64() + timeout_ticks;
-        if (k >= max_iters) { failed = 1; break; }
-        if (k > 0) { // 1. T_k of the blocks this workgroup's tiles read
-            if (wave == 0) {
-                int r = 0;
-                if (my_blk >= 0) r = poll_ge(cntT + 32 * my_blk, 4u * (unsigned)k, fail, done, deadline);
-                r = __any(r == 2) ? 2 : (__any(r == 1) ? 1 : 0);
-                if (lane == 0) lds_flag = r;
-            }
-            __syncthreads();
-            const int r = lds_flag;
-            __syncthreads();
-            if (r == 2) { failed = 1; break; }
-            if (r == 1) { converged = 1; break; }
-        }
-        const double *Tin = Tbuf + (i64)(2 * par) * Tld, *Tout = Tin + Tld;
-#pragma unroll
-        for (int s = 0; s < TPW; s++) { // 2. tile products
-            if (tI[s] < 0) continue;
-            const int I = tI[s], J = tJ[s];
-            // FACTORED: Sin_i = Tin_i * sum_j g_ij Tout_j and Sout_i = Tout_i * sum_j g_ij Tin_j -- the row's own factor is
-            // applied once by the reducer, so an element costs four fused multiply-adds (two per sum it feeds) instead of four
-            // multiplications and four additions: ri / ci collect g * Tout (rows of block I / columns = rows of block J),
-            // ro / co collect g * Tin.
-            double ini[8], oui[8], inj[8], ouj[8], ri[8], ro[8], ci[8], co[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                ini[q] = ld_sc1(Tin + 64 * I + 8 * rq + q);
-                oui[q] = ld_sc1(Tout + 64 * I + 8 * rq + q);
-                inj[q] = ld_sc1(Tin + 64 * J + 8 * cq + q);
-                ouj[q] = ld_sc1(Tout + 64 * J + 8 * cq + q);
-                ri[q] = ro[q] = ci[q] = co[q] = 0.0;
-            }
-            const bool diag_tile = I == J;
-#pragma unroll
-            for (int a = 0; a < 8; a++)
-#pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    double gv = g[s][a][b];
-                    if (diag_tile && rq == cq && a == b) gv += gv; // the j == i term counts twice
-                    ri[a] = fma(gv, ouj[b], ri[a]); ci[b] = fma(gv, oui[a], ci[b]);
-                    ro[a] = fma(gv, inj[b], ro[a]); co[b] = fma(gv, ini[a], co[b]);
-                }
-            const double s_ri = transpose_reduce8<0>(ri, lane), s_ro = transpose_reduce8<0>(ro, lane);
-            st_sc1(P + ((i64)I * Nt + J) * 64 + lane, s_ri);
-            st_sc1(P + Pstride + ((i64)I * Nt + J) * 64 + lane, s_ro);
-            if (!diag_tile) {
-                const double s_ci = transpose_reduce8<3>(ci, lane), s_co = transpose_reduce8<3>(co, lane);
-                st_sc1(P + ((i64)J * Nt + I) * 64 + 8 * cq + rq, s_ci);
-                st_sc1(P + Pstride + ((i64)J * Nt + I) * 64 + 8 * cq + rq, s_co);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (my_blk >= 0) __hip_atomic_fetch_add(cntP + 32 * my_blk, 1u, RLX_AGENT);
-        bool stop = false;
-        for (int sb = wg; sb < 4 * Nt; sb += G) { // 3. the quarter blocks this workgroup reduces
-            const int b = sb >> 2, r = tid & 15, qg = tid >> 4, rib = 16 * (sb & 3) + r;
-            if (tid == 0) lds_flag = poll_ge(cntP + 32 * b, (unsigned)Nt * (unsigned)(k + 1), fail, done, deadline);
-            __syncthreads();
-            const int pr_ = lds_flag;
-            if (pr_ != 0) { failed = (pr_ == 2); converged = (pr_ == 1); stop = true; break; }
-            double pi[4], po[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int q = qg + 16 * u;
-                pi[u] = (q < Nt) ? ld_sc1(P + ((i64)b * Nt + q) * 64 + rib) : 0.0;
-                po[u] = (q < Nt) ? ld_sc1(P + Pstride + ((i64)b * Nt + q) * 64 + rib) : 0.0;
-            }
-            if (k > 0 && sb == wg) { // f of iteration k-1: the step-size rule, then `while diff > delta`
-                double f = 0.0;
-                const double *fp = fq + (i64)((k - 1) & 1) * 4 * Nt;
-                for (int q = tid; q < 4 * Nt; q += 256) f = fmax(f, ld_sc1(fp + q));
-                for (int off = 32; off > 0; off >>= 1) f = fmax(f, __shfl_xor(f, off));
-                if (lane == 0) fred[wave] = f;
-                __syncthreads();
-                f = fmax(fmax(fred[0], fred[1]), fmax(fred[2], fred[3]));
-                if (f > fprev) eps *= 0.99;
-                fprev = f;
-                if (!(f > delta)) { converged = 1; stop = true; break; }
-            }
-            __syncthreads();
-            red[0][qg][r] = ((pi[0] + pi[1]) + pi[2]) + pi[3];
-            red[1][qg][r] = ((po[0] + po[1]) + po[2]) + po[3];
-            __syncthreads();
-            if (qg == 0) {
-                double Si = red[0][0][r], So = red[1][0][r];
-#pragma unroll
-                for (int u = 1; u < 16; u++) { Si += red[0][u][r]; So += red[1][u][r]; }
-                const i64 row = (i64)64 * b + rib;
-                double fr = 0.0;
-                if (row < N) {
-                    const double di = deg_in[row], dout = deg_out[row];
-                    const double tin = ld_sc1(Tin + row), tout = ld_sc1(Tout + row);
-                    Si *= tin; // the row's own factor (the tiles summed g * Tout / g * Tin)
-                    So *= tout;
-                    double nin = tin, nout = tout;
-                    if (di > 0) { nin = tin + (eps * tin) * (di / Si - 1.0); fr = fmax(fr, fabs(di - Si)); }
-                    if (dout > 0) { nout = tout + (eps * tout) * (dout / So - 1.0); fr = fmax(fr, fabs(dout - So)); }
-                    st_sc1(Tbuf + (i64)(2 * (par ^ 1)) * Tld + row, nin);
-                    st_sc1(Tbuf + (i64)(2 * (par ^ 1) + 1) * Tld + row, nout);
-                }
-                for (int off = 8; off > 0; off >>= 1) fr = fmax(fr, __shfl_xor(fr, off));
-                if (r == 0) st_sc1(fq + (i64)(k & 1) * 4 * Nt + sb, fr);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(cntT + 32 * b, 1u, RLX_AGENT);
-        }
-        if (stop) {
-            if (converged && tid == 0) __hip_atomic_store(done, 1u, RLX_AGENT);
-            break;
-        }
-        par ^= 1;
-        k++;
-    }
-    if (wg == 0 && tid == 0) {
-        flags[0] = converged;
-        flags[1] = k;
-        flags[2] = failed || !converged;
-        flags[3] = par;
-    }
-}
-
 // ---- the directed fit with the data as its own signal (the scheme of fit_flow_kernel) -------------------------------------
 // Per tile four partial vectors (e1 = (Tin_i*Tout_j)*g feeds Sin_i and Sout_j, e2 = (Tin_j*Tout_i)*g feeds Sout_i and
 // Sin_j, the diagonal term twice), computed in two passes over the register block so that a wave of 256 registers holds
@@ -1612,16 +1045,6 @@ void k_fit_sym_step(cge_ctx *c, const double *GD, const double *Tin, double *Tou
                        delta, k, fring, done, iters);
 }
 
-static hipError_t launch_plain(const void *fn, int G, void **args, size_t lds, hipStream_t st) {
-    return hipLaunchKernel(fn, dim3((unsigned)G), dim3(256), args, lds, st);
-}
-
-// Runs the fit of one alpha from T = Tbuf[parity] (two buffers of `Tld` doubles, zero beyond N).  Returns false when the
-// persistent path does not apply or was abandoned (nothing usable was written: the caller restarts the fit with the
-// launch-per-iteration path from its own copy of T); otherwise *iters / *final_parity describe the converged state.
-// The default form of the undirected fit (fit_flow_kernel), enqueue only: T_0 is left alone, the result goes to `Tout`
-// (both Tld doubles, zero beyond N), the kernel's verdict {converged, iterations, failed, -} to `dev_flags`.  Nothing is
-// waited for.  false = this form does not apply (nothing was enqueued).
 // geometry of fit_flow_kernel for N vertices on this device; false: the form does not apply
 static bool flow_geometry(i64 N, i64 Tld, int *G_out, int *NW_out, int *tpw_out) {
     const int Nt = (int)((N + 63) / 64);
@@ -1700,90 +1123,10 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
     return true;
 }
 
-// variant: 0 = grid barriers, 1 = dependency counters (the default form is k_fit_flow_enqueue)
-bool k_fit_persistent(cge_ctx *c, const double *GD, i64 N, double *Tbuf, i64 Tld, int parity, const double *w, double eps,
-                      double delta, i64 *iters, int *final_parity, int variant) {
-    const int Nt = (int)((N + 63) / 64);
-    const i64 NT = (i64)Nt * (Nt + 1) / 2;
-    int dev = 0, cus = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus <= 0 || Tld < (i64)Nt * 64) return false;
-    const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
-    const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
-    if (tpw > 3 || Nt > 80) return false; // beyond the register file: N > ~4900 on 256 CUs (a reducer adds up to 80 partial vectors)
-    bool dataflow = variant >= 1;
-    const size_t lds = (size_t)Nt * 64 * sizeof(double);
-    if (lds > 48 * 1024) return false;
-    c->fp_P.ensure((size_t)Nt * Nt * 64);
-    c->fp_fpart.ensure(cus);
-    c->fp_sync.ensure(DF_WORDS);
-    c->fp_fq.ensure((size_t)2 * 4 * Nt);
-    if (dataflow && 4096 + 32 * Nt > DF_WORDS) dataflow = false;
-    c->fp_flags.ensure(4);
-    hipStream_t st = c->stream;
-    i64 total = 0;
-    int par = parity;
-    for (int round = 0; round < 64; round++) {
-        HIP_CHECK(hipMemsetAsync(c->fp_sync.p, 0, sizeof(unsigned) * (dataflow ? DF_WORDS : SYNC_WORDS), st));
-        const double *aGD = GD;
-        i64 aN = N, aTld = Tld;
-        int aNt = Nt, aPar = par, aMax = 100000;
-        double *aT = Tbuf, *aP = c->fp_P.p, *aF = dataflow ? c->fp_fq.p : c->fp_fpart.p;
-        if (dataflow) aMax = 2000000;
-        const double *aW = w;
-        double aEps = eps, aDelta = delta;
-        unsigned *aSync = c->fp_sync.p;
-        int *aFlags = c->fp_flags.p;
-        long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS; // per iteration (0: the test hook)
-        void *args[] = {&aGD, &aN, &aNt, &aT, &aTld, &aPar, &aW, &aEps, &aDelta, &aMax, &aP, &aF, &aSync, &aFlags, &aTicks};
-        const void *fn = dataflow ? (tpw == 1   ? (const void *)fit_dataflow_kernel<1>
-                                     : tpw == 2 ? (const void *)fit_dataflow_kernel<2>
-                                                : (const void *)fit_dataflow_kernel<3>)
-                                  : (tpw == 1   ? (const void *)fit_persistent_kernel<1>
-                                     : tpw == 2 ? (const void *)fit_persistent_kernel<2>
-                                                : (const void *)fit_persistent_kernel<3>);
-        // A plain launch: the grid is at most one workgroup per CU and nothing else runs on this stream's device queue, so
-        // it is resident as a whole (checked once against the occupancy query below); the cooperative-launch entry point
-        // would add only its launch-time size check (and rocprofv3 crashes at exit after it).  Every spin in the kernels is
-        // bounded, so a grid that is not co-resident after all ends in `fail` and the fallback, not in a hang.
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, dataflow ? 0 : lds) != hipSuccess || per_cu < 1) {
-            (void)hipGetLastError();
-            return false;
-        }
-        hipError_t e;
-        {
-            ScopedKernelTimer tm(c, "fit_persistent"); // the launch alone: comparable with the profiler's kernel duration
-            e = launch_plain(fn, G, args, dataflow ? 0 : lds, st);
-        }
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        int hf[4];
-        HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (hf[2]) { // a wait timed out
-            note_fit_fallback(c);
-            return false;
-        }
-        total += hf[1];
-        par = hf[3];
-        if (hf[0]) {
-            *iters = total;
-            *final_parity = par;
-            return true;
-        }
-        if (total > c->opt_fit_max_iters) CGE_THROW(CGE_E_ASSERT, "Chung-Lu fit did not converge (%lld iterations; the reference's `while diff > delta` would not return)", (long long)total);
-    }
-    return false;
-}
-
 // Directed fit of one alpha from Tin / Tout (N doubles each, updated in place on success).  Returns false when the
 // persistent path does not apply or was abandoned; Tin / Tout are then untouched.
 bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, double *Tout, const double *deg_in,
-                          const double *deg_out, double eps0, double f0, double delta, i64 *iters, int variant, int *dev_flags, bool *enqueued_only) {
+                          const double *deg_out, double eps0, double f0, double delta, i64 *iters, int *dev_flags, bool *enqueued_only) {
     if (enqueued_only) *enqueued_only = false;
     const int Nt = (int)((N + 63) / 64);
     const i64 NT = (i64)Nt * (Nt + 1) / 2, Tld = (i64)Nt * 64;
@@ -1793,7 +1136,7 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
     if (cus <= 0) return false;
     hipStream_t st = c->stream;
     c->fp_Td.ensure((size_t)4 * Tld);
-    if (variant == 2 && Nt <= 64) { // the data as its own signal: one tile per wave on 4 or 8 waves per CU
+    if (Nt <= 64) { // the data as its own signal: one tile per wave on 4 or 8 waves per CU
         const int NW = (NT <= (i64)4 * cus) ? 4 : 8;
         const int Gf = (int)std::min<i64>(cus, std::max<i64>((NT + NW - 1) / NW, (i64)4 * Nt));
         if (NT <= (i64)NW * Gf && 4 * Nt <= 2 * Gf) {
@@ -1846,52 +1189,5 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
             (void)hipGetLastError();
         }
     }
-    const int G = (int)std::min<i64>(cus, std::max<i64>((NT + 3) / 4, (i64)4 * Nt));
-    const int tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
-    if (tpw > 2 || Nt > 64 || 4096 + 32 * Nt > DF_WORDS) return false; // the directed tile role needs more registers: N <= ~4000
-    c->fp_P.ensure((size_t)2 * Nt * Nt * 64);
-    c->fp_sync.ensure(DF_WORDS);
-    c->fp_fq.ensure((size_t)2 * 4 * Nt);
-    c->fp_flags.ensure(4);
-    HIP_CHECK(hipMemsetAsync(c->fp_Td.p, 0, sizeof(double) * 4 * Tld, st));
-    HIP_CHECK(hipMemcpyAsync(c->fp_Td.p, Tin, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(c->fp_Td.p + Tld, Tout, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
-    HIP_CHECK(hipMemsetAsync(c->fp_sync.p, 0, sizeof(unsigned) * DF_WORDS, st));
-    const double *aGD = GD;
-    i64 aN = N, aTld = Tld;
-    int aNt = Nt, aPar = 0, aMax = 2000000;
-    double *aT = c->fp_Td.p, *aP = c->fp_P.p, *aF = c->fp_fq.p;
-    const double *aDi = deg_in, *aDo = deg_out;
-    double aEps = eps0, aF0 = f0, aDelta = delta;
-    unsigned *aSync = c->fp_sync.p;
-    int *aFlags = c->fp_flags.p;
-    long long aTicks = c->opt_fit_test_timeout ? 0LL : CGE_FIT_TIMEOUT_TICKS;
-    void *args[] = {&aGD, &aN, &aNt, &aT, &aTld, &aPar, &aDi, &aDo, &aEps, &aF0, &aDelta, &aMax, &aP, &aF, &aSync, &aFlags, &aTicks};
-    const void *fn = tpw == 1 ? (const void *)fit_dataflow_dir_kernel<1> : (const void *)fit_dataflow_dir_kernel<2>;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        return false;
-    }
-    hipError_t e;
-    {
-        ScopedKernelTimer tm(c, "fit_persistent");
-        e = launch_plain(fn, G, args, 0, st);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    int hf[4];
-    HIP_CHECK(hipMemcpyAsync(hf, c->fp_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (hf[2] || !hf[0]) {
-        note_fit_fallback(c);
-        return false;
-    }
-    const int par = hf[3];
-    HIP_CHECK(hipMemcpyAsync(Tin, c->fp_Td.p + (i64)(2 * par) * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(Tout, c->fp_Td.p + (i64)(2 * par + 1) * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
-    *iters = hf[1];
-    return true;
+    return false; // (the form does not apply to this size: the caller iterates with one launch pair per iteration)
 }

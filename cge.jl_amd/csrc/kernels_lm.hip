@@ -321,8 +321,7 @@ void k_gather_centre_fm(cge_ctx *c, const double *src_rowmajor, const i32 *idx, 
                         int *flag) {
     // (`dst` = nullptr: no fp64 copy -- the low-precision bound passes read the planes / the f32 copy, and the exact stage of
     // the diameter gathers only the candidate landmarks' rows)
-    static const bool tile_form = getenv("CGE_GATHER_TILES") != nullptr; // A/B: the tile kernel for the planes-only case too
-    const bool planes_only = planes && !dst && !dst32 && npos > 0 && !tile_form;
+    const bool planes_only = planes && !dst && !dst32 && npos > 0;
     if (dst) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)(ld * dpad), c->stream));
     if (planes_only) { // the kernel writes every row below npos whole (padding features included): only the tail rows are cleared
         for (int q = 0; q < 2; q++)
@@ -716,51 +715,6 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
     dim3 g2((unsigned)std::min<i64>((dd + 255) / 256, 64), (unsigned)n_tasks);
     hipLaunchKernelGGL(group_cov_final_kernel, g2, dim3(256), 0, c->stream, part, task_chunk_off, d, (int)(d > 128),
                        cov);
-}
-
-// ------------------------------------------------------------------------------------------------
-// A child's covariance from its parent's.  With C_X(mu) = sum_{i in X} w_i (x_i - mu)(x_i - mu)^T and a parent P = S u L:
-//   C_L(mu_P) = C_P(mu_P) - C_S(mu_P),    C_X(mu_X) = C_X(mu_P) - W_X (mu_X - mu_P)(mu_X - mu_P)^T,  W_X = sum_{i in X} w_i,
-// so only the SMALLER child S is summed over its rows -- about its OWN mean, as ever (re-centring it from the parent's mean
-// would cancel catastrophically for a tight child far from that mean) -- and one workgroup per sibling pair forms the larger
-// child's matrix  C_L = C_P - (C_S + W_S dS dS^T) - W_L dL dL^T,  d = mu_child - mu_P.  It carries the rounding of one
-// subtraction of matrices of its own magnitude, the level of the SYRK's own rounding; it feeds the principal eigenvector
-// only.  (Measured: no gain -- the SYRK of a batch is bound per chunk, not per row; option cov_derive, off by default.)
-__global__ __launch_bounds__(256) void cov_derive_kernel(const i64 *__restrict__ pairs, const double *__restrict__ means,
-                                                         const double *__restrict__ covs_arena, double *__restrict__ covs,
-                                                         const i32 *__restrict__ rows, const i32 *__restrict__ task_row_off,
-                                                         const double *__restrict__ vw, i64 d) {
-    extern __shared__ __attribute__((aligned(16))) double sh[]; // ds[d], dl[d], red[8]
-    double *ds = sh, *dl = sh + d, *red = sh + 2 * d;
-    const i64 *pq = pairs + 6 * (i64)blockIdx.x;
-    const i64 ts = pq[0], tl = pq[1], pc = pq[2], mp = pq[3], ms = pq[4], ml = pq[5], dd = d * d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double ws = 0.0, wl = 0.0;
-    for (i64 r = task_row_off[ts] + tid; r < task_row_off[ts + 1]; r += 256) ws += vw[rows[r]];
-    for (i64 r = task_row_off[tl] + tid; r < task_row_off[tl + 1]; r += 256) wl += vw[rows[r]];
-    ws = wave_allsum(ws);
-    wl = wave_allsum(wl);
-    if (lane == 0) { red[wave] = ws; red[4 + wave] = wl; }
-    for (i64 k = tid; k < d; k += 256) {
-        ds[k] = means[ms + k] - means[mp + k];
-        dl[k] = means[ml + k] - means[mp + k];
-    }
-    __syncthreads();
-    ws = ((red[0] + red[1]) + red[2]) + red[3];
-    wl = ((red[4] + red[5]) + red[6]) + red[7];
-    const double *cp = covs_arena + pc;
-    const double *cs = covs + ts * dd;
-    double *cl = covs + tl * dd;
-    for (i64 e = tid; e < dd; e += 256) {
-        const i64 i = e / d, j = e - i * d;
-        cl[e] = (cp[e] - (cs[e] + ws * ds[i] * ds[j])) - wl * dl[i] * dl[j];
-    }
-}
-void k_cov_derive(cge_ctx *c, const i64 *pairs, i64 n_pairs, const double *means_arena, const double *covs_arena, double *covs,
-                  const i32 *rows, const i32 *task_row_off, const double *vw, i64 d) {
-    if (n_pairs <= 0) return;
-    hipLaunchKernelGGL(cov_derive_kernel, dim3((unsigned)n_pairs), dim3(256), (size_t)(2 * d + 8) * sizeof(double), c->stream, pairs,
-                       means_arena, covs_arena, covs, rows, task_row_off, vw, d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1444,115 +1398,15 @@ void k_rss2_walk_one_kernel(cge_ctx *c, const double *Xr, const double *vw, cons
 // The walk of :105-117 compares sum(wsse, rss_low) with sum(wsse, rss_high); the first depends only on how many rows
 // the low side has absorbed (its additions run in rank order whatever the high side does), the second only on the high
 // side.  So  FL[i] = RSS of ranks 0..i  and  FH[j] = RSS of ranks k-1-j..k-1  can be produced for ALL i, j by two
-// independent chains with the reference's own additions in the reference's order (rss2_chain_kernel: one workgroup per
+// independent chains with the reference's own additions in the reference's order (rss2_chain_lds_kernel: one workgroup per
 // task and direction; every wave runs the cheap chain of additions over all rows, but pays the divisions and the
 // 64-lane reduction only for every fourth block of 16 rows), and the walk becomes a scalar merge of two arrays
 // (rss2_merge_kernel).  Same bits as rss2_walk_kernel: the same additions in the same order, the same reduction tree.
 #define R2_BR 16 // rows per block of the chain
-template <int NS>
-__global__ __launch_bounds__(256) void rss2_chain_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
-                                                         const i32 *__restrict__ srows,
-                                                         const i32 *__restrict__ task_row_off, i64 d, i64 R,
-                                                         double *__restrict__ F /* [2][R] */,
-                                                         double *__restrict__ ck /* [2][slots][2 NS 64 + 64] */, i64 slots) {
-    __shared__ double tile[4][R2_BR][65]; // per wave: part[q] of every lane, transposed for the row-wise tree sums
-    const i64 t = blockIdx.x;
-    const int dir = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
-    const i32 *p = srows + o;
-    const i64 nblk = (k + R2_BR - 1) / R2_BR, slot0 = o / R2_BR + t;
-    double *Fo = F + (i64)dir * R + o;
-    double *cko = ck + ((i64)dir * slots + slot0) * (2 * NS * 64 + 64);
-    double ss[NS], s1[NS], wacc = 0.0;
-#pragma unroll
-    for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
-    // Four register sets of 16 rows each rotate through the loop: 64 rows are in flight while 16 are absorbed (one set in
-    // flight leaves the chain waiting on memory for most of every block).  A lane keeps the weight of row `lane` of a set.
-    auto load_block = [&](i64 b, double (&x)[R2_BR][NS], double &wl) {
-        const i64 q = b * R2_BR + lane;
-        const bool ok = lane < R2_BR && q < k;
-        const int vq = ok ? p[dir ? k - 1 - q : q] : p[0]; // slots past the end: a valid row with weight 0
-        wl = ok ? vw[vq] : 0.0;
-#pragma unroll
-        for (int u = 0; u < R2_BR; u++) {
-            const i64 v = __builtin_amdgcn_readlane(vq, u);
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                const i64 c = lane + 64 * s;
-                x[u][s] = (c < d) ? Xr[v * d + c] : 0.0;
-            }
-        }
-    };
-    auto process = [&](i64 b, const double (&x)[R2_BR][NS], const double wl) {
-        const bool mine = (int)(b & 3) == wave;
-        if (mine) { // checkpoint: the triple before this block
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                cko[b * (2 * NS * 64 + 64) + (2 * s) * 64 + lane] = ss[s];
-                cko[b * (2 * NS * 64 + 64) + (2 * s + 1) * 64 + lane] = s1[s];
-            }
-            if (lane == 0) cko[b * (2 * NS * 64 + 64) + 2 * NS * 64] = wacc;
-        }
-#pragma unroll
-        for (int q = 0; q < R2_BR; q++) {
-            const double w = lane_value(wl, q);
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                const double xv = x[q][s];
-                ss[s] += w * (xv * xv);
-                s1[s] += w * xv;
-            }
-            wacc += w;
-            if (mine) {
-                double acc = 0.0;
-#pragma unroll
-                for (int s = 0; s < NS; s++) acc += ss[s] - s1[s] * s1[s] / wacc; // padded columns are 0
-                tile[wave][q][lane] = acc;
-            }
-        }
-        if (mine) {
-            __builtin_amdgcn_wave_barrier();
-            if (lane < R2_BR) { // wave_allsum's tree: adjacent pairs inside each row of 16 lanes, then ((R0 + R1) + R2) + R3
-                const double *v = tile[wave][lane];
-                double r16[4];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const double *u = v + 16 * g;
-                    const double a0 = (u[0] + u[1]) + (u[2] + u[3]), a1 = (u[4] + u[5]) + (u[6] + u[7]);
-                    const double a2 = (u[8] + u[9]) + (u[10] + u[11]), a3 = (u[12] + u[13]) + (u[14] + u[15]);
-                    r16[g] = (a0 + a1) + (a2 + a3);
-                }
-                const i64 q = b * R2_BR + lane;
-                if (q < k) Fo[q] = ((r16[0] + r16[1]) + r16[2]) + r16[3];
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    };
-    double x0[R2_BR][NS], x1[R2_BR][NS], x2[R2_BR][NS], x3[R2_BR][NS], w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
-    load_block(0, x0, w0);
-    if (1 < nblk) load_block(1, x1, w1);
-    if (2 < nblk) load_block(2, x2, w2);
-    if (3 < nblk) load_block(3, x3, w3);
-    for (i64 b = 0; b < nblk; b += 4) {
-        process(b, x0, w0);
-        if (b + 4 < nblk) load_block(b + 4, x0, w0);
-        if (b + 1 < nblk) {
-            process(b + 1, x1, w1);
-            if (b + 5 < nblk) load_block(b + 5, x1, w1);
-        }
-        if (b + 2 < nblk) {
-            process(b + 2, x2, w2);
-            if (b + 6 < nblk) load_block(b + 6, x2, w2);
-        }
-        if (b + 3 < nblk) {
-            process(b + 3, x3, w3);
-            if (b + 7 < nblk) load_block(b + 7, x3, w3);
-        }
-    }
-}
 
-// ---- the same chains with the rows SHARED through LDS (round 3) -----------------------------------------------------------
-// rss2_chain_kernel's four waves each load every row of the group themselves.  Here the waves load DIFFERENT blocks: in a round of four blocks (64 rows) wave w fetches block 4r + w into registers (two rounds ahead, two
+// ---- the chains with the rows SHARED through LDS (round 3) ------------------------------------------------------------------
+// (Rounds 2-3 let each of the four waves load every row of the group itself; removed in round 5.)  The waves load DIFFERENT
+// blocks: in a round of four blocks (64 rows) wave w fetches block 4r + w into registers (two rounds ahead, two
 // register sets), parks it in LDS, and after one barrier every wave runs its chain over the 64 rows from LDS -- the same
 // additions in the same order, the divisions and tree sums of a block by the wave that owns it, as before.  Same bits.
 // Config 2: 4.24 -> 3.91 ms per step (the loads were not the bound: a wave issues an fp64 instruction per ~5.5 ns when it is
@@ -1730,220 +1584,9 @@ __global__ __launch_bounds__(64 * NW) void rss2_chain_lds_kernel(const double *_
     }
 }
 
-// ---- the same chains in two steps (round 3): the additions by ONE wave per (group, direction), the divisions by everybody ----
-// In rss2_chain_kernel every one of a workgroup's four waves runs the whole chain of additions and pays the divisions and the
-// tree sum for a quarter of the rows: a group of 13 000 rows (config 2's largest community) keeps four waves busy for
-// 1.5 ms while the rest of the GPU waits.  Here a single wave per (group, direction) runs the chain -- the same additions in
-// the same order -- and STORES the running sums of every row (2 NS 64 + 1 doubles); a second launch, one wave per row over
-// all rows of the batch, evaluates sum_c (ss - s1^2 / w) with the same division and the same tree (wave_allsum).  Same bits.
-template <int NS>
-__global__ __launch_bounds__(64) void rss2_prefix_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
-                                                         const i32 *__restrict__ srows, const i32 *__restrict__ task_row_off,
-                                                         i64 d, i64 R, double *__restrict__ PS /* [2][R][2 NS 64] */,
-                                                         double *__restrict__ PW /* [2][R] */,
-                                                         double *__restrict__ ck /* [2][slots][2 NS 64 + 64] */, i64 slots) {
-    const i64 t = blockIdx.x;
-    const int dir = blockIdx.y, lane = threadIdx.x;
-    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
-    const i32 *p = srows + o;
-    const i64 nblk = (k + R2_BR - 1) / R2_BR, slot0 = o / R2_BR + t;
-    double *PSo = PS + ((i64)dir * R + o) * (2 * NS * 64);
-    double *PWo = PW + (i64)dir * R + o;
-    double *cko = ck + ((i64)dir * slots + slot0) * (2 * NS * 64 + 64);
-    double ss[NS], s1[NS], wacc = 0.0;
-#pragma unroll
-    for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
-    // The wave is alone in its workgroup and may use the whole register file: NSET sets of 16 rows rotate (128 rows in flight
-    // at d <= 64), and the row ids of a set are requested one rotation ahead of its rows -- the chain is bound by the latency
-    // of its gathers (id -> weight, row), not by its additions.
-    constexpr int NSET = NS == 1 ? 8 : 4;
-    auto load_ids = [&](i64 b, int &vq) {
-        const i64 q = b * R2_BR + lane;
-        vq = (lane < R2_BR && q < k) ? p[dir ? k - 1 - q : q] : p[0]; // slots past the end: a valid row (its weight counts as 0)
-    };
-    auto load_rows = [&](i64 b, const int vq, double (&x)[R2_BR][NS], double &wl) {
-        const i64 q = b * R2_BR + lane;
-        wl = (lane < R2_BR && q < k) ? vw[vq] : 0.0;
-#pragma unroll
-        for (int u = 0; u < R2_BR; u++) {
-            const i64 v = __builtin_amdgcn_readlane(vq, u);
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                const i64 c = lane + 64 * s;
-                x[u][s] = (c < d) ? Xr[v * d + c] : 0.0;
-            }
-        }
-    };
-    auto process = [&](i64 b, const double (&x)[R2_BR][NS], const double wl) {
-        // checkpoint: the triple before this block (what rss2_merge_kernel starts its boundary adjustment from)
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            cko[b * (2 * NS * 64 + 64) + (2 * s) * 64 + lane] = ss[s];
-            cko[b * (2 * NS * 64 + 64) + (2 * s + 1) * 64 + lane] = s1[s];
-        }
-        if (lane == 0) cko[b * (2 * NS * 64 + 64) + 2 * NS * 64] = wacc;
-        double wrow = 0.0; // lane q keeps the running weight after row q of the block
-#pragma unroll
-        for (int q = 0; q < R2_BR; q++) {
-            const double w = lane_value(wl, q);
-            const i64 row = b * R2_BR + q;
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                const double xv = x[q][s];
-                ss[s] += w * (xv * xv);
-                s1[s] += w * xv;
-                if (row < k) {
-                    PSo[row * (2 * NS * 64) + (2 * s) * 64 + lane] = ss[s];
-                    PSo[row * (2 * NS * 64) + (2 * s + 1) * 64 + lane] = s1[s];
-                }
-            }
-            wacc += w;
-            if (lane == q) wrow = wacc;
-        }
-        const i64 rowl = b * R2_BR + lane;
-        if (lane < R2_BR && rowl < k) PWo[rowl] = wrow;
-    };
-    double x[NSET][R2_BR][NS], wl[NSET];
-    int vq[NSET];
-#pragma unroll
-    for (int i = 0; i < NSET; i++) { wl[i] = 0.0; vq[i] = 0; if (i < nblk) load_ids(i, vq[i]); }
-#pragma unroll
-    for (int i = 0; i < NSET; i++)
-        if (i < nblk) {
-            load_rows(i, vq[i], x[i], wl[i]);
-            if (i + NSET < nblk) load_ids(i + NSET, vq[i]);
-        }
-    for (i64 b = 0; b < nblk; b += NSET) {
-#pragma unroll
-        for (int i = 0; i < NSET; i++)
-            if (b + i < nblk) {
-                process(b + i, x[i], wl[i]);
-                if (b + i + NSET < nblk) {
-                    load_rows(b + i + NSET, vq[i], x[i], wl[i]);
-                    if (b + i + 2 * NSET < nblk) load_ids(b + i + 2 * NSET, vq[i]);
-                }
-            }
-    }
-}
-// ---- the chains as STREAMS (round 4): products first, in parallel; the chain wave only adds ---------------------------------
-// What bounds the longest group is the instruction issue of the ONE wave that must add its rows in order (rounds 2-3: ~15
-// instructions per row for gather, products and additions, ~110 ns per row with the divisions).  Here (1) a parallel kernel
-// writes the products w x^2 and w x of every row of the batch in sorted order (the same two multiplications, the same bits),
-// (2) the chain wave of a (group, direction) STREAMS them -- two contiguous 512-byte loads, two additions and two stores per
-// row and 64 columns, 48 rows in flight -- and stores the running sums of every row, (3) rss2_eval_kernel evaluates
-// sum_c (ss - s1^2 / w) of all rows in parallel, as in the split form above.  The same additions in the same order: same bits.
-template <int NS>
-__global__ __launch_bounds__(256) void rss2_products_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
-                                                            const i32 *__restrict__ srows, i64 d, i64 R,
-                                                            double *__restrict__ P /* [R][2 NS 64] */, double *__restrict__ Wt /* [R] */) {
-    const i64 r = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (r >= R) return;
-    const i64 v = srows[r];
-    const double w = vw[v];
-    double *pr = P + r * (2 * NS * 64);
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        const i64 c = lane + 64 * s;
-        const double xv = (c < d) ? Xr[v * d + c] : 0.0;
-        pr[(2 * s) * 64 + lane] = w * (xv * xv);
-        pr[(2 * s + 1) * 64 + lane] = w * xv;
-    }
-    if (lane == 0) Wt[r] = w;
-}
-template <int NS>
-__global__ __launch_bounds__(64) void rss2_stream_kernel(const double *__restrict__ P, const double *__restrict__ Wt,
-                                                         const i32 *__restrict__ task_row_off, i64 R,
-                                                         double *__restrict__ PS /* [2][R][2 NS 64] */, double *__restrict__ PW /* [2][R] */,
-                                                         double *__restrict__ ck /* [2][slots][2 NS 64 + 64] */, i64 slots) {
-    const i64 t = blockIdx.x;
-    const int dir = blockIdx.y, lane = threadIdx.x;
-    const i64 o = task_row_off[t], k = task_row_off[t + 1] - o;
-    const i64 nblk = (k + R2_BR - 1) / R2_BR, slot0 = o / R2_BR + t;
-    double *PSo = PS + ((i64)dir * R + o) * (2 * NS * 64);
-    double *PWo = PW + (i64)dir * R + o;
-    double *cko = ck + ((i64)dir * slots + slot0) * (2 * NS * 64 + 64);
-    double ss[NS], s1[NS], wacc = 0.0;
-#pragma unroll
-    for (int s = 0; s < NS; s++) ss[s] = s1[s] = 0.0;
-    constexpr int NSET = NS == 1 ? 3 : 1; // sets of 16 rows in flight (64 registers each at NS = 1)
-    auto load_rows = [&](i64 b, double (&x)[R2_BR][2 * NS], double &wl) {
-        const i64 ql = b * R2_BR + lane;
-        wl = (lane < R2_BR && ql < k) ? Wt[o + (dir ? k - 1 - ql : ql)] : 0.0; // slots past the end: weight 0, products 0
-#pragma unroll
-        for (int u = 0; u < R2_BR; u++) {
-            const i64 q = b * R2_BR + u; // (uniform)
-            const bool in = q < k;
-            const double *pr = P + (o + (in ? (dir ? k - 1 - q : q) : 0)) * (2 * NS * 64);
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                x[u][2 * s] = in ? pr[(2 * s) * 64 + lane] : 0.0;
-                x[u][2 * s + 1] = in ? pr[(2 * s + 1) * 64 + lane] : 0.0;
-            }
-        }
-    };
-    auto process = [&](i64 b, const double (&x)[R2_BR][2 * NS], const double wl) {
-        // checkpoint: the triple before this block (what rss2_merge_kernel starts its boundary adjustment from)
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            cko[b * (2 * NS * 64 + 64) + (2 * s) * 64 + lane] = ss[s];
-            cko[b * (2 * NS * 64 + 64) + (2 * s + 1) * 64 + lane] = s1[s];
-        }
-        if (lane == 0) cko[b * (2 * NS * 64 + 64) + 2 * NS * 64] = wacc;
-        double wrow = 0.0; // lane q keeps the running weight after row q of the block
-#pragma unroll
-        for (int q = 0; q < R2_BR; q++) {
-            const double w = lane_value(wl, q);
-            const i64 row = b * R2_BR + q;
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                ss[s] += x[q][2 * s];
-                s1[s] += x[q][2 * s + 1];
-                if (row < k) {
-                    PSo[row * (2 * NS * 64) + (2 * s) * 64 + lane] = ss[s];
-                    PSo[row * (2 * NS * 64) + (2 * s + 1) * 64 + lane] = s1[s];
-                }
-            }
-            wacc += w;
-            if (lane == q) wrow = wacc;
-        }
-        const i64 rowl = b * R2_BR + lane;
-        if (lane < R2_BR && rowl < k) PWo[rowl] = wrow;
-    };
-    double x[NSET][R2_BR][2 * NS], wl[NSET];
-#pragma unroll
-    for (int i = 0; i < NSET; i++) {
-        wl[i] = 0.0;
-        if (i < nblk) load_rows(i, x[i], wl[i]);
-    }
-    for (i64 b = 0; b < nblk; b += NSET) {
-#pragma unroll
-        for (int i = 0; i < NSET; i++)
-            if (b + i < nblk) {
-                process(b + i, x[i], wl[i]);
-                if (b + i + NSET < nblk) load_rows(b + i + NSET, x[i], wl[i]);
-            }
-    }
-}
-// F[dir][row] = sum over the columns of ss - s1^2 / w from the stored running sums: one wave per row, lane = column
-template <int NS>
-__global__ __launch_bounds__(256) void rss2_eval_kernel(const double *__restrict__ PS, const double *__restrict__ PW, i64 R,
-                                                        double *__restrict__ F) {
-    const i64 r = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; // row of [2][R]
-    const int lane = threadIdx.x & 63;
-    if (r >= 2 * R) return;
-    const double *ps = PS + r * (2 * NS * 64);
-    const double wacc = PW[r];
-    double acc = 0.0;
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        const double ss = ps[(2 * s) * 64 + lane], s1 = ps[(2 * s + 1) * 64 + lane];
-        acc += ss - s1 * s1 / wacc; // padded columns are 0
-    }
-    const double f = wave_allsum(acc);
-    if (lane == 0) F[r] = f;
-}
-
+// (Rounds 3-4 also had the chains in two steps -- the additions by one wave per (group, direction), the divisions by everybody --
+// and as streams of precomputed products; both gave the same bits and were measured slower (profiles/
+// r03 / r04 notes): removed in round 5.)
 template <int NS>
 __global__ __launch_bounds__(64) void rss2_merge_kernel(const double *__restrict__ Xr, const double *__restrict__ vw,
                                                         const i32 *__restrict__ srows,
@@ -2092,97 +1735,27 @@ __global__ __launch_bounds__(64) void rss2_merge_kernel(const double *__restrict
 void k_rss2_walk(cge_ctx *c, const double *Xr, const double *vw, const i32 *srows, const i32 *task_row_off, i64 n_tasks, i64 d,
                  i32 *meta, double *vals, double *cmeans) {
     if (d > 64 * RR_SLOTS) CGE_THROW(CGE_E_ARG, "embedding dimension %lld > %d not supported", (long long)d, 64 * RR_SLOTS);
-    static const bool old_form = getenv("CGE_RSS2_ONE_KERNEL") != nullptr; // A/B switch: the one-wave-per-task walk
     const int ns0 = d <= 64 ? 1 : d <= 128 ? 2 : d <= 256 ? 4 : 8;
-    if (!old_form && ns0 <= 2 && c->r2_rows > 0) { // chain + merge (the register blocks of the chain allow d <= 128)
+    if (ns0 <= 2 && c->r2_rows > 0) { // chain + merge (the register blocks of the chain allow d <= 128)
         ScopedKernelTimer t(c, "rss2_walk");
         const i64 R = c->r2_rows, slots = R / R2_BR + n_tasks + 2, stride = 2 * ns0 * 64 + 64;
         c->r2_F.ensure((size_t)2 * R);
         c->r2_ck.ensure((size_t)2 * slots * stride);
         const dim3 gridA((unsigned)n_tasks, 2);
-        // CGE_RSS2_SPLIT=1: the chain by one wave per (group, direction) + a parallel evaluation of all rows (while the stored
-        // running sums stay below 2 GB); default 0.  Measured (config 2): 3.9 against 4.25 ms per step -- what bounds the longest
-        // group is the instruction issue of ONE wave (an fp64 instruction per ~5.5 ns with one wave on its SIMD,
-        // profiles/microbench_dpp_fmac.hip; ~15 instructions per row of the chain, ~40 more per row of IEEE division), whoever
-        // loads the rows; not worth 200 MB of traffic per batch
-        static const int split = getenv("CGE_RSS2_SPLIT") ? atoi(getenv("CGE_RSS2_SPLIT")) : 0;
-        const size_t ps_words = (size_t)2 * R * (2 * ns0 * 64);
-        // 2 (round 4, d <= 64; NOT the default): the chains as streams of precomputed products (rss2_products_kernel +
-        // rss2_stream_kernel + rss2_eval_kernel) while the three row-sized arrays stay below 4 GB.  Same bits; measured slower
-        // (config 2: 0.625 against 0.559 ms per launch of the walk, 12.6 against 12.1 ms per step): ONE wave cannot stream
-        // 2 KB per row faster than it could compute the products -- its outstanding loads, not its instructions, bound it.
-        if (split == 2 && ns0 == 1 && (ps_words + ps_words / 2) * sizeof(double) <= ((size_t)4 << 30)) {
-            c->r2_PS.ensure(ps_words + ps_words / 2); // running sums of both directions, then the products
-            c->r2_PW.ensure((size_t)3 * R);            // running weights of both directions, then the rows' weights
-            double *P = c->r2_PS.p + ps_words, *Wt = c->r2_PW.p + 2 * R;
-            const unsigned nbp = (unsigned)((R * 64 + 255) / 256), nbe = (unsigned)((2 * R * 64 + 255) / 256);
-            hipLaunchKernelGGL((rss2_products_kernel<1>), dim3(nbp), dim3(256), 0, c->stream, Xr, vw, srows, d, R, P, Wt);
-            hipLaunchKernelGGL((rss2_stream_kernel<1>), gridA, dim3(64), 0, c->stream, P, Wt, task_row_off, R, c->r2_PS.p, c->r2_PW.p,
-                               c->r2_ck.p, slots);
-            hipLaunchKernelGGL((rss2_eval_kernel<1>), dim3(nbe), dim3(256), 0, c->stream, c->r2_PS.p, c->r2_PW.p, R, c->r2_F.p);
-            hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
-                               d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
-            return;
-        }
-        if (split == 1 && ps_words * sizeof(double) <= ((size_t)2 << 30)) {
-            c->r2_PS.ensure(ps_words);
-            c->r2_PW.ensure((size_t)2 * R);
-            const unsigned nbe = (unsigned)((2 * R * 64 + 255) / 256);
-            if (ns0 == 1) {
-                hipLaunchKernelGGL((rss2_prefix_kernel<1>), gridA, dim3(64), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_PS.p,
-                                   c->r2_PW.p, c->r2_ck.p, slots);
-                hipLaunchKernelGGL((rss2_eval_kernel<1>), dim3(nbe), dim3(256), 0, c->stream, c->r2_PS.p, c->r2_PW.p, R, c->r2_F.p);
-                hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
-                                   d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
-            } else {
-                hipLaunchKernelGGL((rss2_prefix_kernel<2>), gridA, dim3(64), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_PS.p,
-                                   c->r2_PW.p, c->r2_ck.p, slots);
-                hipLaunchKernelGGL((rss2_eval_kernel<2>), dim3(nbe), dim3(256), 0, c->stream, c->r2_PS.p, c->r2_PW.p, R, c->r2_F.p);
-                hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
-                                   d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
-            }
-            return;
-        }
-        // CGE_RSS2_LDS: 1 (default) = the four waves of a chain share the rows through LDS; 2 = eight waves, two per SIMD (each owns
-        // the divisions of one block in eight, but the chain is repeated by twice as many waves and its registers spill:
-        // 0.455 against 0.343 ms per launch on config 2); 0 = every wave loads every row itself
-        static const int lds_form = getenv("CGE_RSS2_LDS") ? atoi(getenv("CGE_RSS2_LDS")) : 1;
-        // CGE_RSS2_LDS2: 1 (default) = the same kernel for 64 < d <= 128 (one LDS buffer of rows, an extra barrier per round)
-        static const int lds_form2 = getenv("CGE_RSS2_LDS2") ? atoi(getenv("CGE_RSS2_LDS2")) : 1;
-        if (lds_form && lds_form2 && ns0 == 2) {
+        // the four waves of a chain share the rows through LDS; 64 < d <= 128: one LDS buffer of rows, an extra barrier per round
+        if (ns0 == 2) {
             const size_t lds = (size_t)(4 * R2_BR * 65 + 64 * 128 + 64) * sizeof(double);
             cge_allow_lds((const void *)rss2_chain_lds_kernel<2, 4>, 160 * 1024);
             hipLaunchKernelGGL((rss2_chain_lds_kernel<2, 4>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R,
                                c->r2_F.p, c->r2_ck.p, slots);
             hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
                                d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
-            return;
-        }
-        if (lds_form && ns0 == 1) { // (d <= 64)
-            if (lds_form == 2) {
-                const size_t lds = (size_t)(8 * R2_BR * 65 + 128 * 64 + 128) * sizeof(double);
-                cge_allow_lds((const void *)rss2_chain_lds_kernel<1, 8>, 160 * 1024);
-                hipLaunchKernelGGL((rss2_chain_lds_kernel<1, 8>), gridA, dim3(512), lds, c->stream, Xr, vw, srows, task_row_off, d, R,
-                                   c->r2_F.p, c->r2_ck.p, slots);
-            } else {
-                const size_t lds = (size_t)(4 * R2_BR * 65 + 2 * 64 * 64 + 2 * 64) * sizeof(double);
-                cge_allow_lds((const void *)rss2_chain_lds_kernel<1, 4>, 160 * 1024);
-                hipLaunchKernelGGL((rss2_chain_lds_kernel<1, 4>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R,
-                                   c->r2_F.p, c->r2_ck.p, slots);
-            }
-            hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
-                               d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
-            return;
-        }
-        if (ns0 == 1) {
-            hipLaunchKernelGGL((rss2_chain_kernel<1>), gridA, dim3(256), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
-                               c->r2_ck.p, slots);
-            hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
-                               d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
         } else {
-            hipLaunchKernelGGL((rss2_chain_kernel<2>), gridA, dim3(256), 0, c->stream, Xr, vw, srows, task_row_off, d, R, c->r2_F.p,
-                               c->r2_ck.p, slots);
-            hipLaunchKernelGGL((rss2_merge_kernel<2>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
+            const size_t lds = (size_t)(4 * R2_BR * 65 + 2 * 64 * 64 + 2 * 64) * sizeof(double);
+            cge_allow_lds((const void *)rss2_chain_lds_kernel<1, 4>, 160 * 1024);
+            hipLaunchKernelGGL((rss2_chain_lds_kernel<1, 4>), gridA, dim3(256), lds, c->stream, Xr, vw, srows, task_row_off, d, R,
+                               c->r2_F.p, c->r2_ck.p, slots);
+            hipLaunchKernelGGL((rss2_merge_kernel<1>), dim3((unsigned)n_tasks), dim3(64), 0, c->stream, Xr, vw, srows, task_row_off,
                                d, R, c->r2_F.p, c->r2_ck.p, slots, meta, vals, cmeans);
         }
         return;
@@ -2306,13 +1879,6 @@ __global__ __launch_bounds__(256) void cut_sides_kernel(const double *__restrict
         }
     }
     if (lane == 0 && nlow_out) nlow_out[t] = (i32)nlow;
-}
-// testing: a wave that does nothing for ~4 us per nap (option runsplit_lanes_test_delay: whatever is queued behind it lands late)
-__global__ void nap_kernel(int naps) {
-    for (int q = 0; q < naps; q++) __builtin_amdgcn_s_sleep(127);
-}
-void k_nap(cge_ctx *c, int naps) {
-    if (naps > 0) hipLaunchKernelGGL(nap_kernel, dim3(1), dim3(64), 0, c->stream, naps);
 }
 void k_cut_sides(cge_ctx *c, const double *z, const double *zs, const i32 *task_row_off, i64 n_tasks, int use_median,
                  unsigned char *side, i32 *nlow_out, int *tie_tasks) {
@@ -2723,106 +2289,11 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
     }
     __syncthreads();
     if (diag_stage == 2) { if (tid < d) out[tid] = red[4]; return; } // timing diagnostic only
-    // ---- inverse iteration, REGISTER form (round 4; CGE_EIG_TAIL_REG=1, NOT the default): the tridiagonal factors and the
-    //      iterate live in the wave's registers (element i in lane i & 63, slot i >> 6); the O(d) recurrences run in every lane
-    //      at once on values fetched with v_readlane instead of by lane 0 from LDS.  The same operations on the same values in
-    //      the same order as the LDS form below: the same bits (all parity suites pass with it).  MEASURED SLOWER: 0.60 against
-    //      0.50 ms per launch of 512 matrices (profiles/r04_eig_tail_ab.txt) -- a step of a sweep needs ~16 v_readlane_b32 and
-    //      three predicated moves, ~30 wave instructions of 4 cycles each, which is the LDS round trip it was meant to avoid.
-    const bool lds_tail = (diag_stage & 256) == 0;
-    diag_stage &= 255;
-    if (wv == 0 && !lds_tail) {
-        const double lam = red[4];
-        double ddv[NR], dlv[NR], duv[NR], du2v[NR], yv[NR];
-        auto rl = [&](const double (&arr)[NR], int i) -> double { // element i (i is uniform)
-            if (NR > 1 && i >= 64) return lane_value(arr[NR - 1], i - 64);
-            return lane_value(arr[0], i);
-        };
-        auto put = [&](double (&arr)[NR], int i, double v) {
-            if (NR > 1 && i >= 64) { if (lane == i - 64) arr[NR - 1] = v; }
-            else if (lane == i) arr[0] = v;
-        };
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int i = lane + 64 * r;
-            ddv[r] = (i < d) ? diag[i] - lam : 1.0;
-            dlv[r] = duv[r] = (i + 1 < d) ? off[i] : 0.0;
-            du2v[r] = 0.0;
-            yv[r] = (i < d) ? 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0 : 0.0;
-        }
-        unsigned long long swp0 = 0ULL, swp1 = 0ULL; // pivot flags, d <= 128 (the same in every lane)
-        { // LU with partial pivoting of the shifted tridiagonal matrix
-            double di = rl(ddv, 0), ui = rl(duv, 0);
-            for (int i = 0; i + 1 < d; i++) {
-                const double li = rl(dlv, i), dn = rl(ddv, i + 1), un = rl(duv, i + 1);
-                if (fabs(di) >= fabs(li)) {
-                    if (di == 0.0) di = tiny;
-                    const double f = li * fast_rcp(di);
-                    put(ddv, i, di);
-                    put(dlv, i, f);
-                    put(duv, i, ui);
-                    di = dn - f * ui;
-                    ui = un;
-                } else {
-                    const double f = di * fast_rcp(li);
-                    put(ddv, i, li);
-                    put(dlv, i, f);
-                    put(duv, i, dn);
-                    di = ui - f * dn;
-                    if (i + 2 < d) put(du2v, i, un);
-                    ui = -f * un;
-                    if (i < 64) swp0 |= 1ULL << i; else swp1 |= 1ULL << (i - 64);
-                }
-            }
-            if (di == 0.0) di = tiny;
-            put(ddv, d - 1, di);
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++) // the solves multiply by the reciprocal pivots
-            if (lane + 64 * r < d) ddv[r] = fast_rcp(ddv[r]);
-        for (int it = 0; it < 3; it++) {
-            {
-                double yi = rl(yv, 0);
-                for (int i = 0; i + 1 < d; i++) { // forward: L with the recorded row swaps
-                    const bool sw = (i < 64) ? ((swp0 >> i) & 1ULL) : ((swp1 >> (i - 64)) & 1ULL);
-                    const double yn = rl(yv, i + 1), li = rl(dlv, i);
-                    put(yv, i, sw ? yn : yi);
-                    yi = sw ? yi - li * yn : yn - li * yi;
-                }
-                double y1 = yi * rl(ddv, d - 1); // backward: U with two super-diagonals
-                put(yv, d - 1, y1);
-                double y0 = (rl(yv, d - 2) - rl(duv, d - 2) * y1) * rl(ddv, d - 2);
-                put(yv, d - 2, y0);
-                for (int i = d - 3; i >= 0; i--) {
-                    const double t = (rl(yv, i) - rl(duv, i) * y0 - rl(du2v, i) * y1) * rl(ddv, i);
-                    put(yv, i, t);
-                    y1 = y0;
-                    y0 = t;
-                }
-            }
-            double amax = 0.0;
-#pragma unroll
-            for (int r = 0; r < NR; r++) amax = fmax(amax, fabs(yv[r]));
-            for (int o2 = 32; o2 > 0; o2 >>= 1) amax = fmax(amax, __shfl_xor(amax, o2));
-            if (!(amax > 0.0) || !(amax < 1e300)) { // uniform over the wave
-#pragma unroll
-                for (int r = 0; r < NR; r++) yv[r] = (lane + 64 * r == 0) ? 1.0 : 0.0;
-                break;
-            }
-            const double ra = 1.0 / amax;
-            double part = 0.0;
-#pragma unroll
-            for (int r = 0; r < NR; r++) { yv[r] *= ra; part += yv[r] * yv[r]; }
-            const double rn = 1.0 / sqrt(wave_allsum(part));
-#pragma unroll
-            for (int r = 0; r < NR; r++) yv[r] = yv[r] * rn;
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++) V[lane + 64 * r] = yv[r];
-    }
+    // (Round 4 also had a REGISTER form of the inverse iteration -- factors and iterate in the wave's registers, v_readlane instead
+    // of LDS reads by lane 0: same bits, 0.60 against 0.50 ms per launch, profiles/r04_eig_tail_ab.txt; removed in round 5.)
     // ---- inverse iteration, LDS form (wave 0: lane 0 runs the O(d) recurrences with the carried values in registers, the
     //      wave does the element-wise parts) ---------------------------------------------------------------------
-    if (wv == 0 && lds_tail) {
+    if (wv == 0) {
         const double lam = red[4];
         double *dl = tri, *dd = tri + DP, *du = tri + 2 * DP, *du2 = tri + 3 * DP;
         double *y = V;
@@ -3032,624 +2503,12 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
             if (lane + 64 * r < d) out[lane + 64 * r] = yv[r] * sg;
     }
 }
-// ---- the same solver, second form (default): columns dealt CYCLICALLY to the waves and dead work skipped -------------
-// Wave w owns the columns {w, w + NW, w + 2 NW, ...} (NC of them), lane l the rows l + 64 r.  At step k only the trailing
-// block (rows and columns > k) is live, and with the cyclic deal every wave's share of it shrinks in step: the two O(d^2)
-// loops of a step (B u and the rank-2 update) run over the wave's LIVE column groups of four only (a dead column inside a
-// live group multiplies u = w = 0: exact), and over the upper row block only once k has passed row 63.  On average a step
-// touches 28 % of the register block instead of all of it.  A finished column no longer needs to keep its reflector in
-// place (its owner is no longer one wave per 32 consecutive steps): wave 0 writes the reflector of every step to a scratch
-// row (d doubles, fire and forget) and runs the back-transformation from there with the loads of the next steps in flight.
-// The two divisions of a step are hardware reciprocals with one Newton step (the reflector is then orthogonal to ~1 ulp,
-// the level of the method's own rounding); same conventions and results to rounding as the first form
-// (tests: eigen-solver against LAPACK, landmark parity against the oracle).
-template <int NR, int NC, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void group_eigc_kernel(const double *__restrict__ cov, int d,
-                                                                double *__restrict__ vec, double *__restrict__ refl,
-                                                                int diag_stage) {
-    constexpr int DP = 64 * NR, G = 4; // padded dimension (rows held); NW * NC >= d columns held; column group
-    static_assert(NC % G == 0, "column groups of four");
-    __shared__ __attribute__((aligned(16))) double X[DP], U[DP], W[DP], Pp[NW][DP], V[DP];
-    __shared__ __attribute__((aligned(16))) double diag[DP], off[DP], beta[DP], tri[4 * DP], red[8 + 3 * NW];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: the skips below are scalar branches
-    const double *src = cov + (size_t)blockIdx.x * d * d;
-    double *out = vec + (size_t)blockIdx.x * d;
-    double *rf = refl + (size_t)blockIdx.x * DP * DP; // row k: the reflector of step k (DP doubles)
-    if (d == 1) {
-        if (tid == 0) out[0] = 1.0;
-        return;
-    }
-    double a[NR][NC];
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-        const int row = lane + 64 * r;
-#pragma unroll
-        for (int jj = 0; jj < NC; jj++) {
-            const int col = NW * jj + wv;
-            a[r][jj] = (row < d && col < d) ? src[(size_t)col * d + row] : 0.0; // symmetric: coalesced along rows
-        }
-    }
-    // publish row kn of the matrix: X[col] = A[kn][col] (row instead of column: see the first form)
-    auto extract = [&](int kn) {
-        if (lane == (kn & 63)) {
-            if (NR > 1 && kn >= 64) {
-#pragma unroll
-                for (int jj = 0; jj < NC; jj++) X[NW * jj + wv] = a[NR - 1][jj];
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < NC; jj++) X[NW * jj + wv] = a[0][jj];
-            }
-        }
-    };
-    if (tid < DP) { beta[tid] = 0.0; off[tid] = 0.0; X[tid] = 0.0; }
-    __syncthreads();
-    extract(0);
-    // ---- tridiagonalisation ------------------------------------------------------------------------
-    // The barriers of a step order LDS traffic only: a plain __syncthreads() would also wait for the reflector stores of
-    // wave 0 to reach memory (a release fence), i.e. put a global-memory round trip into every step.
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    for (int k = 0; k + 2 < d; k++) {
-        lds_barrier(); // (a) X of column k is visible; U, W, Pp of the previous step are dead
-        const int o = k + 1;
-        double x[NR], u[NR];
-        double part = 0.0;
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int row = lane + 64 * r;
-            x[r] = (row > k) ? X[row] : 0.0;
-            part += (row > o) ? x[r] * x[r] : 0.0;
-        }
-        const double alpha = X[o];
-        if (tid == 0) diag[k] = X[k];
-        const double sigma = wave_allsum(part);
-        const bool refl_on = sigma != 0.0; // sigma == 0: no reflection; the step runs with u = w = 0
-        const double mu = sqrt(alpha * alpha + sigma);
-        const double v0r = (alpha <= 0.0) ? alpha - mu : -sigma * fast_rcp(alpha + mu);
-        const double v0 = refl_on ? v0r : 0.0;
-        const double bp = refl_on ? 2.0 * fast_rcp(sigma + v0r * v0r) : 0.0; // H = I - bp u u^T, u = (v0, x[o+1..])
-        if (tid == 0) { beta[k] = bp; off[k] = refl_on ? mu : alpha; }
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int row = lane + 64 * r;
-            u[r] = (row == o) ? v0 : x[r];
-            U[row] = u[r]; // every wave writes the same values
-            if (wv == 0 && diag_stage != 12) rf[(size_t)k * DP + row] = u[r];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const bool low_live = NR == 1 || o < 64; // the rows of block 0 are all <= k once o >= 64
-        { // partial p = B u over the wave's live column groups
-            double s[NR];
-#pragma unroll
-            for (int r = 0; r < NR; r++) s[r] = 0.0;
-#pragma unroll
-            for (int g0 = 0; g0 < NC; g0 += G) {
-                if (NW * (g0 + G - 1) + wv >= o && diag_stage != 10) { // the group's last column is live
-                    double uj[G];
-#pragma unroll
-                    for (int q = 0; q < G; q++) uj[q] = U[NW * (g0 + q) + wv];
-                    if (low_live) {
-#pragma unroll
-                        for (int q = 0; q < G; q++)
-#pragma unroll
-                            for (int r = 0; r < NR; r++) s[r] = fma(a[r][g0 + q], uj[q], s[r]);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < G; q++) s[NR - 1] = fma(a[NR - 1][g0 + q], uj[q], s[NR - 1]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < NR; r++) Pp[wv][lane + 64 * r] = s[r];
-        }
-        lds_barrier(); // (b)
-        double w[NR];
-        part = 0.0;
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int row = lane + 64 * r;
-            double t = Pp[0][row];
-#pragma unroll
-            for (int q = 1; q < NW; q++) t += Pp[q][row]; // fixed order
-            w[r] = bp * t;
-            w[r] = (row >= o) ? w[r] : 0.0; // (a skipped row block left nothing meaningful behind)
-            part += w[r] * u[r];
-        }
-        const double K = 0.5 * bp * wave_allsum(part);
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int row = lane + 64 * r;
-            w[r] = (row >= o) ? w[r] - K * u[r] : 0.0; // finished rows / columns stay as they are
-            W[row] = w[r];
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int g0 = 0; g0 < NC; g0 += G) { // rank-2 update of the live column groups
-            if (NW * (g0 + G - 1) + wv >= o && diag_stage != 10) {
-                double uj[G], wj[G];
-#pragma unroll
-                for (int q = 0; q < G; q++) { uj[q] = U[NW * (g0 + q) + wv]; wj[q] = W[NW * (g0 + q) + wv]; }
-                if (low_live) {
-#pragma unroll
-                    for (int q = 0; q < G; q++)
-#pragma unroll
-                        for (int r = 0; r < NR; r++) a[r][g0 + q] = fma(-u[r], wj[q], fma(-w[r], uj[q], a[r][g0 + q]));
-                } else {
-#pragma unroll
-                    for (int q = 0; q < G; q++)
-                        a[NR - 1][g0 + q] = fma(-u[NR - 1], wj[q], fma(-w[NR - 1], uj[q], a[NR - 1][g0 + q]));
-                }
-            }
-        }
-        extract(k + 1);
-    }
-    __syncthreads();
-    if (tid == 0) { diag[d - 2] = X[d - 2]; off[d - 2] = X[d - 1]; } // row d-2 was the last one published
-    __syncthreads();
-    extract(d - 1);
-    __syncthreads();
-    if (tid == 0) diag[d - 1] = X[d - 1];
-    __syncthreads();
-    if (diag_stage == 1) { if (tid < d) out[tid] = diag[tid]; return; } // timing diagnostic only
-    // ---- Gershgorin bounds ---------------------------------------------------------------------------
-    double glo = 1e300, ghi = -1e300, gn = 0.0;
-    if (tid < d) {
-        const double rad = (tid > 0 ? fabs(off[tid - 1]) : 0.0) + (tid + 1 < d ? fabs(off[tid]) : 0.0);
-        glo = diag[tid] - rad;
-        ghi = diag[tid] + rad;
-        gn = fabs(diag[tid]) + rad;
-    }
-    for (int o2 = 32; o2 > 0; o2 >>= 1) {
-        glo = fmin(glo, __shfl_xor(glo, o2));
-        ghi = fmax(ghi, __shfl_xor(ghi, o2));
-        gn = fmax(gn, __shfl_xor(gn, o2));
-    }
-    double *gs = red + 8;
-    if (lane == 0) { gs[wv * 3] = glo; gs[wv * 3 + 1] = ghi; gs[wv * 3 + 2] = gn; }
-    __syncthreads();
-    glo = gs[0]; ghi = gs[1]; gn = gs[2];
-#pragma unroll
-    for (int q = 1; q < NW; q++) { glo = fmin(glo, gs[3 * q]); ghi = fmax(ghi, gs[3 * q + 1]); gn = fmax(gn, gs[3 * q + 2]); }
-    const double tiny = fmax(gn, 2.2250738585072014e-308) * 2.220446049250313e-16;
-    // ---- largest eigenvalue: 64-way multisection on the Sturm count (wave 0) ------------------------------
-    if (tid < 64) {
-        double lo = glo, hi = ghi + tiny;
-        for (int it = 0; it < 64; it++) {
-            const double xq = lo + (hi - lo) * ((double)(tid + 1) / 65.0);
-            int cnt = 0;
-            double q = diag[0] - xq;
-            if (q < 0) cnt++;
-            for (int i = 1; i < d; i++) {
-                if (q == 0.0) q = tiny;
-                q = diag[i] - xq - (off[i - 1] * off[i - 1]) * fast_rcp(q);
-                if (q < 0) cnt++;
-            }
-            const unsigned long long mask = __ballot(cnt >= d);
-            double nlo, nhi;
-            if (mask == 0ULL) {
-                nlo = __shfl(xq, 63);
-                nhi = hi;
-            } else {
-                const int f = __ffsll((long long)mask) - 1;
-                nhi = __shfl(xq, f);
-                nlo = (f > 0) ? __shfl(xq, f - 1) : lo;
-            }
-            if (!(nhi > nlo) || (nlo == lo && nhi == hi)) break;
-            lo = fmax(lo, nlo);
-            hi = fmin(hi, nhi);
-        }
-        if (tid == 0) red[4] = 0.5 * (lo + hi);
-    }
-    __syncthreads();
-    if (diag_stage == 2) { if (tid < d) out[tid] = red[4]; return; } // timing diagnostic only
-    // ---- inverse iteration, back-transformation, normalisation: wave 0 ----------------------------------------
-    if (wv == 0) {
-        const double lam = red[4];
-        double *dl = tri, *dd = tri + DP, *du = tri + 2 * DP, *du2 = tri + 3 * DP;
-        double *y = V;
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int i = lane + 64 * r;
-            dd[i] = (i < d) ? diag[i] - lam : 1.0;
-            dl[i] = du[i] = (i + 1 < d) ? off[i] : 0.0;
-            du2[i] = 0.0;
-            y[i] = (i < d) ? 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0 : 0.0;
-        }
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long swp0 = 0ULL, swp1 = 0ULL; // pivot flags, d <= 128 (lane 0)
-        if (lane == 0) { // LU with partial pivoting of the shifted tridiagonal matrix
-            double di = dd[0], ui = du[0];
-            for (int i = 0; i + 1 < d; i++) {
-                const double li = dl[i], dn = dd[i + 1], un = du[i + 1];
-                if (fabs(di) >= fabs(li)) {
-                    if (di == 0.0) di = tiny;
-                    const double f = li * fast_rcp(di);
-                    dd[i] = di;
-                    dl[i] = f;
-                    du[i] = ui;
-                    di = dn - f * ui;
-                    ui = un;
-                } else {
-                    const double f = di * fast_rcp(li);
-                    dd[i] = li;
-                    dl[i] = f;
-                    du[i] = dn;
-                    di = ui - f * dn;
-                    if (i + 2 < d) du2[i] = un;
-                    ui = -f * un;
-                    if (i < 64) swp0 |= 1ULL << i; else swp1 |= 1ULL << (i - 64);
-                }
-            }
-            if (di == 0.0) di = tiny;
-            dd[d - 1] = di;
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < NR; r++) { // the solves multiply by the reciprocal pivots
-            const int i = lane + 64 * r;
-            if (i < d) dd[i] = fast_rcp(dd[i]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int it = 0; it < 3; it++) {
-            if (lane == 0) {
-                double yi = y[0];
-                for (int i = 0; i + 1 < d; i++) { // forward: L with the recorded row swaps
-                    const bool sw = (i < 64) ? ((swp0 >> i) & 1ULL) : ((swp1 >> (i - 64)) & 1ULL);
-                    const double yn = y[i + 1], li = dl[i];
-                    y[i] = sw ? yn : yi;
-                    yi = sw ? yi - li * yn : yn - li * yi;
-                }
-                double y1 = yi * dd[d - 1]; // backward: U with two super-diagonals
-                y[d - 1] = y1;
-                double y0 = (y[d - 2] - du[d - 2] * y1) * dd[d - 2];
-                y[d - 2] = y0;
-                for (int i = d - 3; i >= 0; i--) {
-                    const double t = (y[i] - du[i] * y0 - du2[i] * y1) * dd[i];
-                    y[i] = t;
-                    y1 = y0;
-                    y0 = t;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            double yv[NR], amax = 0.0;
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                yv[r] = y[lane + 64 * r];
-                amax = fmax(amax, fabs(yv[r]));
-            }
-            for (int o2 = 32; o2 > 0; o2 >>= 1) amax = fmax(amax, __shfl_xor(amax, o2));
-            if (!(amax > 0.0) || !(amax < 1e300)) { // uniform over the wave
-#pragma unroll
-                for (int r = 0; r < NR; r++) y[lane + 64 * r] = (lane + 64 * r == 0) ? 1.0 : 0.0;
-                __builtin_amdgcn_wave_barrier();
-                break;
-            }
-            const double ra = 1.0 / amax;
-            double part = 0.0;
-#pragma unroll
-            for (int r = 0; r < NR; r++) { yv[r] *= ra; part += yv[r] * yv[r]; }
-            const double rn = 1.0 / sqrt(wave_allsum(part));
-#pragma unroll
-            for (int r = 0; r < NR; r++) y[lane + 64 * r] = yv[r] * rn;
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (diag_stage == 3) { if (lane < 64) for (int r = 0; r < NR; r++) if (lane + 64 * r < d) out[lane + 64 * r] = V[lane + 64 * r]; return; }
-        // back-transformation x = H_0 H_1 ... H_{d-3} y from the scratch rows this wave wrote (two steps of loads in flight)
-        double yv[NR];
-#pragma unroll
-        for (int r = 0; r < NR; r++) yv[r] = V[lane + 64 * r];
-        double un[NR], un2[NR];
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            un[r] = rf[(size_t)(d - 3) * DP + lane + 64 * r];
-            un2[r] = d >= 4 ? rf[(size_t)(d - 4) * DP + lane + 64 * r] : 0.0;
-        }
-        for (int k = d - 3; k >= 0; k--) {
-            double uu[NR], part = 0.0;
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                uu[r] = un[r];
-                un[r] = un2[r];
-                un2[r] = k >= 2 ? rf[(size_t)(k - 2) * DP + lane + 64 * r] : 0.0;
-                part += uu[r] * yv[r];
-            }
-            const double sdot = beta[k] * wave_allsum(part); // beta == 0: no reflection at this step (u = 0 as well)
-#pragma unroll
-            for (int r = 0; r < NR; r++) yv[r] -= sdot * uu[r];
-        }
-        // normalise; sign: the component of largest magnitude (the first one on ties) is positive
-        double part = 0.0, best = -1.0;
-        int bi = 0;
-#pragma unroll
-        for (int r = 0; r < NR; r++) { // rows >= d are zero
-            part += yv[r] * yv[r];
-            if (fabs(yv[r]) > best) { best = fabs(yv[r]); bi = lane + 64 * r; }
-        }
-        double nrm = sqrt(wave_allsum(part));
-        const bool degenerate = !(nrm > 0.0) || !(nrm < 1e300); // zero matrix: any unit vector is an eigenvector
-        if (degenerate) {
-#pragma unroll
-            for (int r = 0; r < NR; r++) { yv[r] = (lane + 64 * r == 0) ? 1.0 : 0.0; }
-            nrm = 1.0;
-            best = (lane == 0) ? 1.0 : 0.0;
-            bi = lane;
-        }
-        double bv = best;
-        for (int o2 = 32; o2 > 0; o2 >>= 1) {
-            const double ob = __shfl_xor(bv, o2);
-            const int oi = __shfl_xor(bi, o2);
-            if (ob > bv || (ob == bv && oi < bi)) { bv = ob; bi = oi; }
-        }
-        const double lead = (bi >= 64 && NR > 1) ? lane_value(yv[NR - 1], bi & 63) : lane_value(yv[0], bi & 63);
-        const double sg = ((lead < 0.0) ? -1.0 : 1.0) / nrm;
-#pragma unroll
-        for (int r = 0; r < NR; r++)
-            if (lane + 64 * r < d) out[lane + 64 * r] = yv[r] * sg;
-    }
-}
-// ---- the same solver for wider matrices (128 < d <= 512): the matrix stays in global memory (it is read and
-// written by one workgroup only, so it lives in that CU's L1/L2 path), the O(d) vectors in LDS.  Same algorithm and
-// conventions as above; thread j owns column j (and j + 256): for a fixed row the threads read consecutive addresses.
-// The covariance buffer is overwritten (row k keeps the reflector of step k right of the sub-diagonal).
-__device__ __forceinline__ double block_sum_256w(double v, double *red4) {
-    v = wave_allsum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return ((red4[0] + red4[1]) + red4[2]) + red4[3];
-}
-__global__ __launch_bounds__(256) void group_eig_wide_kernel(double *__restrict__ cov, int d, double *__restrict__ vec) {
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *V = sh, *W = V + d, *P = W + d, *beta = P + d, *diag = beta + d, *off = diag + d, *tri = off + d; // tri: 4*d
-    double *red = tri + 4 * d;                                                                                 // 32
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double *A = cov + (size_t)blockIdx.x * d * d;
-    double *out = vec + (size_t)blockIdx.x * d;
-    for (int i = tid; i < d; i += 256) { beta[i] = 0.0; off[i] = 0.0; }
-    __syncthreads();
-    // ---- tridiagonalisation ------------------------------------------------------------------------
-    for (int k = 0; k + 2 < d; k++) {
-        const int r = d - k - 1, o = k + 1;
-        const double *xrow = A + (size_t)k * d + o; // x = A[k][o..]
-        double part = 0.0;
-        for (int i = tid; i < r; i += 256) {
-            const double xi = xrow[i];
-            if (i >= 1) part += xi * xi;
-        }
-        const double sigma = block_sum_256w(part, red);
-        const double alpha = xrow[0];
-        if (sigma == 0.0) { // uniform: no reflection needed
-            if (tid == 0) { beta[k] = 0.0; off[k] = alpha; }
-            __syncthreads();
-            continue;
-        }
-        const double mu = sqrt(alpha * alpha + sigma);
-        const double v0 = (alpha <= 0.0) ? alpha - mu : -sigma / (alpha + mu);
-        const double bk = 2.0 * v0 * v0 / (sigma + v0 * v0);
-        for (int i = tid; i < r; i += 256) V[i] = (i == 0) ? 1.0 : xrow[i] / v0;
-        if (tid == 0) { beta[k] = bk; off[k] = mu; }
-        __syncthreads();
-        const double *B = A + (size_t)o * d + o; // B[i][j] = B[i*d + j], i, j < r
-        for (int j = tid; j < r; j += 256) { // p = bk * B v (B symmetric: column sums, coalesced along rows)
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int i = 0;
-            for (; i + 7 < r; i += 8) {
-                const double a0 = B[(size_t)(i + 0) * d + j], a1 = B[(size_t)(i + 1) * d + j], a2 = B[(size_t)(i + 2) * d + j],
-                             a3 = B[(size_t)(i + 3) * d + j], a4 = B[(size_t)(i + 4) * d + j], a5 = B[(size_t)(i + 5) * d + j],
-                             a6 = B[(size_t)(i + 6) * d + j], a7 = B[(size_t)(i + 7) * d + j];
-                s0 += a0 * V[i + 0]; s1 += a1 * V[i + 1]; s2 += a2 * V[i + 2]; s3 += a3 * V[i + 3];
-                s0 += a4 * V[i + 4]; s1 += a5 * V[i + 5]; s2 += a6 * V[i + 6]; s3 += a7 * V[i + 7];
-            }
-            for (; i < r; i++) s0 += B[(size_t)i * d + j] * V[i];
-            P[j] = bk * ((s0 + s1) + (s2 + s3));
-        }
-        __syncthreads();
-        part = 0.0;
-        for (int i = tid; i < r; i += 256) part += P[i] * V[i];
-        const double K = 0.5 * bk * block_sum_256w(part, red);
-        for (int i = tid; i < r; i += 256) W[i] = P[i] - K * V[i];
-        __syncthreads();
-        for (int j = tid; j < r; j += 256) { // B -= v w^T + w v^T
-            const double vj = V[j], wj = W[j];
-            double *col = const_cast<double *>(B) + j;
-            int i = 0;
-            for (; i + 7 < r; i += 8) {
-                double a[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) a[q] = col[(size_t)(i + q) * d];
-#pragma unroll
-                for (int q = 0; q < 8; q++) col[(size_t)(i + q) * d] = a[q] - (V[i + q] * wj + W[i + q] * vj);
-            }
-            for (; i < r; i++) col[(size_t)i * d] -= V[i] * wj + W[i] * vj;
-        }
-        for (int i = tid + 1; i < r; i += 256) A[(size_t)k * d + o + i] = V[i]; // keep the reflector in row k (v[0] = 1 implicit)
-        __syncthreads();
-    }
-    for (int i = tid; i < d; i += 256) diag[i] = A[(size_t)i * d + i];
-    if (tid == 0) off[d - 2] = A[(size_t)(d - 2) * d + (d - 1)];
-    __syncthreads();
-    // ---- Gershgorin bounds ---------------------------------------------------------------------------
-    double glo = 1e300, ghi = -1e300, gn = 0.0;
-    for (int i = tid; i < d; i += 256) {
-        const double rad = (i > 0 ? fabs(off[i - 1]) : 0.0) + (i + 1 < d ? fabs(off[i]) : 0.0);
-        glo = fmin(glo, diag[i] - rad);
-        ghi = fmax(ghi, diag[i] + rad);
-        gn = fmax(gn, fabs(diag[i]) + rad);
-    }
-    for (int o2 = 32; o2 > 0; o2 >>= 1) {
-        glo = fmin(glo, __shfl_xor(glo, o2));
-        ghi = fmax(ghi, __shfl_xor(ghi, o2));
-        gn = fmax(gn, __shfl_xor(gn, o2));
-    }
-    double *gs = red + 8;
-    if (lane == 0) { gs[wv * 3] = glo; gs[wv * 3 + 1] = ghi; gs[wv * 3 + 2] = gn; }
-    __syncthreads();
-    glo = fmin(fmin(gs[0], gs[3]), fmin(gs[6], gs[9]));
-    ghi = fmax(fmax(gs[1], gs[4]), fmax(gs[7], gs[10]));
-    gn = fmax(fmax(gs[2], gs[5]), fmax(gs[8], gs[11]));
-    const double tiny = fmax(gn, 2.2250738585072014e-308) * 2.220446049250313e-16;
-    // ---- largest eigenvalue: 64-way multisection on the Sturm count (wave 0) ------------------------------
-    if (tid < 64) {
-        double lo = glo, hi = ghi + tiny;
-        for (int it = 0; it < 64; it++) {
-            const double x = lo + (hi - lo) * ((double)(tid + 1) / 65.0);
-            int cnt = 0;
-            double q = diag[0] - x;
-            if (q < 0) cnt++;
-            for (int i = 1; i < d; i++) {
-                if (q == 0.0) q = tiny;
-                q = diag[i] - x - (off[i - 1] * off[i - 1]) * fast_rcp(q);
-                if (q < 0) cnt++;
-            }
-            const unsigned long long mask = __ballot(cnt >= d);
-            double nlo, nhi;
-            if (mask == 0ULL) {
-                nlo = __shfl(x, 63);
-                nhi = hi;
-            } else {
-                const int f = __ffsll((long long)mask) - 1;
-                nhi = __shfl(x, f);
-                nlo = (f > 0) ? __shfl(x, f - 1) : lo;
-            }
-            if (!(nhi > nlo) || (nlo == lo && nhi == hi)) break;
-            lo = fmax(lo, nlo);
-            hi = fmin(hi, nhi);
-        }
-        if (tid == 0) red[4] = 0.5 * (lo + hi);
-    }
-    __syncthreads();
-    // ---- inverse iteration (lane 0 of wave 0 runs the recurrences, the wave the element-wise parts) -----------------
-    if (wv == 0) {
-        const double lam = red[4];
-        double *dl = tri, *dd = tri + d, *du = tri + 2 * d, *du2 = tri + 3 * d;
-        double *y = V;
-        unsigned char *swp = reinterpret_cast<unsigned char *>(W); // pivot flags
-        for (int i = lane; i < d; i += 64) {
-            dd[i] = diag[i] - lam;
-            dl[i] = du[i] = (i + 1 < d) ? off[i] : 0.0;
-            du2[i] = 0.0;
-            swp[i] = 0;
-            y[i] = 1.0 + 0.01 * (double)(((unsigned)i * 2654435761u) % 97u) / 97.0;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) { // LU with partial pivoting of the shifted tridiagonal matrix
-            double di = dd[0], ui = du[0];
-            for (int i = 0; i + 1 < d; i++) {
-                const double li = dl[i], dn = dd[i + 1], un = du[i + 1];
-                if (fabs(di) >= fabs(li)) {
-                    if (di == 0.0) di = tiny;
-                    const double f = li * fast_rcp(di);
-                    dd[i] = di;
-                    dl[i] = f;
-                    du[i] = ui;
-                    di = dn - f * ui;
-                    ui = un;
-                } else {
-                    const double f = di * fast_rcp(li);
-                    dd[i] = li;
-                    dl[i] = f;
-                    du[i] = dn;
-                    di = ui - f * dn;
-                    if (i + 2 < d) du2[i] = un;
-                    ui = -f * un;
-                    swp[i] = 1;
-                }
-            }
-            if (di == 0.0) di = tiny;
-            dd[d - 1] = di;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < d; i += 64) dd[i] = fast_rcp(dd[i]);
-        __builtin_amdgcn_wave_barrier();
-        for (int it = 0; it < 3; it++) {
-            if (lane == 0) {
-                double yi = y[0];
-                for (int i = 0; i + 1 < d; i++) {
-                    const bool sw = swp[i] != 0;
-                    const double yn = y[i + 1], li = dl[i];
-                    y[i] = sw ? yn : yi;
-                    yi = sw ? yi - li * yn : yn - li * yi;
-                }
-                double y1 = yi * dd[d - 1];
-                y[d - 1] = y1;
-                double y0 = (y[d - 2] - du[d - 2] * y1) * dd[d - 2];
-                y[d - 2] = y0;
-                for (int i = d - 3; i >= 0; i--) {
-                    const double t = (y[i] - du[i] * y0 - du2[i] * y1) * dd[i];
-                    y[i] = t;
-                    y1 = y0;
-                    y0 = t;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            double amax = 0.0;
-            for (int i = lane; i < d; i += 64) amax = fmax(amax, fabs(y[i]));
-            for (int o2 = 32; o2 > 0; o2 >>= 1) amax = fmax(amax, __shfl_xor(amax, o2));
-            if (!(amax > 0.0) || !(amax < 1e300)) {
-                for (int i = lane; i < d; i += 64) y[i] = (i == 0) ? 1.0 : 0.0;
-                __builtin_amdgcn_wave_barrier();
-                break;
-            }
-            const double ra = 1.0 / amax;
-            double part = 0.0;
-            for (int i = lane; i < d; i += 64) { const double t = y[i] * ra; part += t * t; }
-            const double rn = ra / sqrt(wave_allsum(part));
-            for (int i = lane; i < d; i += 64) y[i] *= rn;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    // ---- back-transformation x = H_0 H_1 ... H_{d-3} y ------------------------------------------------------------
-    for (int k = d - 3; k >= 0; k--) {
-        const double bk = beta[k];
-        if (bk == 0.0) continue; // uniform
-        const int r = d - k - 1, o = k + 1;
-        double part = 0.0;
-        for (int i = tid; i < r; i += 256) {
-            const double vk = (i == 0) ? 1.0 : A[(size_t)k * d + o + i];
-            part += vk * V[o + i];
-        }
-        const double sc = bk * block_sum_256w(part, red);
-        for (int i = tid; i < r; i += 256) {
-            const double vk = (i == 0) ? 1.0 : A[(size_t)k * d + o + i];
-            V[o + i] -= sc * vk;
-        }
-        __syncthreads();
-    }
-    // normalise; sign: the component of largest magnitude (the first one on ties) is positive
-    double part = 0.0, best = -1.0;
-    int bi = 0;
-    for (int i = tid; i < d; i += 256) {
-        const double t = V[i];
-        part += t * t;
-        if (fabs(t) > best) { best = fabs(t); bi = i; }
-    }
-    double nrm = sqrt(block_sum_256w(part, red));
-    const bool degenerate = !(nrm > 0.0) || !(nrm < 1e300);
-    for (int o2 = 32; o2 > 0; o2 >>= 1) {
-        const double ob = __shfl_xor(best, o2);
-        const int oi = __shfl_xor(bi, o2);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    __syncthreads();
-    if (lane == 0) { red[16 + 2 * wv] = best; red[16 + 2 * wv + 1] = (double)bi; }
-    __syncthreads();
-    best = red[16];
-    bi = (int)red[17];
-    for (int q = 1; q < 4; q++) {
-        const double ob = red[16 + 2 * q];
-        const int oi = (int)red[16 + 2 * q + 1];
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    if (degenerate) {
-        for (int i = tid; i < d; i += 256) out[i] = (i == 0) ? 1.0 : 0.0;
-        return;
-    }
-    const double sg = ((V[bi] < 0.0) ? -1.0 : 1.0) / nrm;
-    for (int i = tid; i < d; i += 256) out[i] = V[i] * sg;
-}
-// ---- 128 < d <= 512, panel form.  The kernel above sweeps the trailing matrix three times per Householder step (one
-// read for B v, a read and a write for the rank-2 update): 8 d^3 bytes per matrix, 1.07 GB at d = 512, and a batch of a few
+// (Rounds 3-4 carried two more forms of this solver -- the columns dealt cyclically to 4 or 8 waves with dead work skipped,
+// and for 128 < d <= 512 an unblocked form that swept the trailing matrix three times per step: 8 d^3 bytes per matrix, 1.07 GB
+// at d = 512.  Both gave the same bits and were measured slower (profiles/r03_eig_variants.txt): removed in round 5.)
+// ---- 128 < d <= 512, panel form.  The matrix stays in global memory (read and written by one workgroup only) and is
+// overwritten: row k keeps the reflector of step k right of the sub-diagonal.  A plain Householder step sweeps the trailing
+// matrix three times (one read for B v, a read and a write for the rank-2 update): 8 d^3 bytes per matrix, 1.07 GB at d = 512, and a batch of a few
 // thousand 2 MB matrices is far beyond any cache -- the solver is bound by HBM.  Here the rank-2 updates of EWP_NB
 // consecutive steps are deferred (LAPACK's dlatrd idea): the panel's reflectors v_s and vectors w_s stay in LDS, column k
 // and B v of the *current* matrix are formed as "stored matrix minus the panel's corrections"
@@ -3676,6 +2535,9 @@ __device__ __forceinline__ double transpose_reduce4(const double (&v)[4], int la
     const double w1 = keep + __shfl_xor(send, 1 << SH);
     return w1 + __shfl_xor(w1, 4 << SH);
 }
+#ifndef EWP_OCC
+#define EWP_OCC 4
+#endif
 constexpr int EWP_NB = 8, EWP_T = 512;
 constexpr int EWP_SCR = 16 * 16 * 32; // partial vectors of the 32 x 32 tile sweep: [row block][other block][32]
 __device__ __forceinline__ double block_sum_512(double v, double *red8) {
@@ -3685,7 +2547,7 @@ __device__ __forceinline__ double block_sum_512(double v, double *red8) {
     __syncthreads();
     return ((red8[0] + red8[1]) + (red8[2] + red8[3])) + ((red8[4] + red8[5]) + (red8[6] + red8[7]));
 }
-__global__ __launch_bounds__(EWP_T, 4) void group_eig_panel_kernel(double *__restrict__ cov, int d, double *__restrict__ vec,
+__global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double *__restrict__ cov, int d, double *__restrict__ vec,
                                                                    double *__restrict__ scratch /* [task][EWP_SCR] */) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *Vp = sh;                // [NB][d] reflectors of the open panel (zero above their sub-diagonal)
@@ -4041,58 +2903,20 @@ bool k_group_eig(cge_ctx *c, const double *cov, i64 n_tasks, i64 d, double *vec)
     if (d > 512) return false; // beyond the LDS budget of the wide solver: the caller uses the host solver
     if (d > 128) { // the matrix stays in global memory and is overwritten
         ScopedKernelTimer t(c, "group_eig");
-        static const bool one_step = getenv("CGE_EIG_WIDE_UNBLOCKED") && atoi(getenv("CGE_EIG_WIDE_UNBLOCKED")) != 0; // A/B
-        if (!one_step) {
-            const size_t plds = (size_t)(2 * EWP_NB * d + d + 8 + 8 * 2 * EWP_NB + 2 * EWP_NB + 32) * sizeof(double);
-            cge_allow_lds((const void *)group_eig_panel_kernel, 160 * 1024);
-            c->ls_eigscr.ensure((size_t)n_tasks * EWP_SCR);
-            hipLaunchKernelGGL(group_eig_panel_kernel, dim3((unsigned)n_tasks), dim3(EWP_T), plds, c->stream,
-                               const_cast<double *>(cov), (int)d, vec, c->ls_eigscr.p);
-            return true;
-        }
-        const size_t lds = (size_t)(10 * d + 32) * sizeof(double);
-        hipLaunchKernelGGL(group_eig_wide_kernel, dim3((unsigned)n_tasks), dim3(256), lds, c->stream, const_cast<double *>(cov),
-                           (int)d, vec);
+        const size_t plds = (size_t)(2 * EWP_NB * d + d + 8 + 8 * 2 * EWP_NB + 2 * EWP_NB + 32) * sizeof(double);
+        cge_allow_lds((const void *)group_eig_panel_kernel, 160 * 1024);
+        c->ls_eigscr.ensure((size_t)n_tasks * EWP_SCR);
+        hipLaunchKernelGGL(group_eig_panel_kernel, dim3((unsigned)n_tasks), dim3(EWP_T), plds, c->stream,
+                           const_cast<double *>(cov), (int)d, vec, c->ls_eigscr.p);
         return true;
     }
     ScopedKernelTimer t(c, "group_eig");
-    static const int diag_stage = (getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0) // 0 = normal
-                                  | ((getenv("CGE_EIG_TAIL_REG") && atoi(getenv("CGE_EIG_TAIL_REG"))) ? 256 : 0); // A/B: inverse iteration from registers (slower)
-    // A/B: CGE_EIG_FORM=5 (default) blocked columns, reflectors in place, column values as DPP broadcasts; 0: the same with LDS
-    // broadcast reads (the form of rounds 1-2, same bits); 4 / 8: the cyclic form on 4 / 8 waves
-    static const int form = getenv("CGE_EIG_FORM") ? atoi(getenv("CGE_EIG_FORM")) : 5;
+    static const int diag_stage = getenv("CGE_EIG_DIAG") ? atoi(getenv("CGE_EIG_DIAG")) : 0; // timing diagnostics: 0 = normal
     const dim3 grid((unsigned)n_tasks), block(256);
-    if (form == 0 || form == 5) { // 5: the column values as DPP broadcasts of the FMAs (same bits)
-#define CGE_EIG_GO(NR, NC)                                                                                                  \
-    do {                                                                                                                    \
-        if (form == 5) hipLaunchKernelGGL((group_eig_kernel<NR, NC, true>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage); \
-        else hipLaunchKernelGGL((group_eig_kernel<NR, NC, false>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);  \
-    } while (0)
-        if (d <= 32) CGE_EIG_GO(1, 8);
-        else if (d <= 64) CGE_EIG_GO(1, 16);
-        else CGE_EIG_GO(2, 32);
-#undef CGE_EIG_GO
-        return true;
-    }
-    const i64 DP = d <= 64 ? 64 : 128;
-    c->ls_eigscr.ensure((size_t)n_tasks * DP * DP); // the reflectors of every step (read back by the back-transformation)
-    double *rf = c->ls_eigscr.p;
-    if (form == 8) {
-        const dim3 block8(512);
-        if (d <= 32)
-            hipLaunchKernelGGL((group_eigc_kernel<1, 4, 8>), grid, block8, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
-        else if (d <= 64)
-            hipLaunchKernelGGL((group_eigc_kernel<1, 8, 8>), grid, block8, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
-        else
-            hipLaunchKernelGGL((group_eigc_kernel<2, 16, 8>), grid, block8, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
-    } else {
-        if (d <= 32)
-            hipLaunchKernelGGL((group_eigc_kernel<1, 8, 4>), grid, block, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
-        else if (d <= 64)
-            hipLaunchKernelGGL((group_eigc_kernel<1, 16, 4>), grid, block, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
-        else
-            hipLaunchKernelGGL((group_eigc_kernel<2, 32, 4>), grid, block, 0, c->stream, cov, (int)d, vec, rf, diag_stage);
-    }
+    // blocked columns, reflectors in place, the column values of the two O(d^2) loops as DPP broadcasts of the FMAs
+    if (d <= 32) hipLaunchKernelGGL((group_eig_kernel<1, 8, true>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
+    else if (d <= 64) hipLaunchKernelGGL((group_eig_kernel<1, 16, true>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
+    else hipLaunchKernelGGL((group_eig_kernel<2, 32, true>), grid, block, 0, c->stream, cov, (int)d, vec, diag_stage);
     return true;
 }
 
@@ -4439,9 +3263,7 @@ void k_scatter_u64(cge_ctx *c, const uint64_t *src, const i32 *idx, i64 cnt, uin
 }
 void k_landmark_aggregate(cge_ctx *c, const double *Xr, const double *vw, const i32 *comm, const i32 *mem_off,
                           const i32 *mem, i64 N, i64 d, double *lemb, double *lweight, double *dii, i32 *lcomm) {
-    // CGE_AGG_OLD=1: the form of rounds 1-3 (A/B); it also serves d > 1024
-    static const bool old_form = getenv("CGE_AGG_OLD") && atoi(getenv("CGE_AGG_OLD")) != 0;
-    if (!old_form && d <= 1024) {
+    if (d <= 1024) { // (beyond: the form of rounds 1-3)
         const size_t lds2 = (size_t)(d + 256 + AG_MC) * sizeof(double) + (size_t)AG_MC * sizeof(i32);
         hipLaunchKernelGGL(landmark_aggregate2_kernel, dim3((unsigned)N), dim3(256), lds2, c->stream, Xr, vw, comm, mem_off, mem, d,
                            lemb, lweight, dii, lcomm);
@@ -4497,9 +3319,8 @@ void k_edge_scatter(cge_ctx *c, const i32 *src, const i32 *dst, const double *w,
     if (wedges && !v2l) CGE_THROW(CGE_E_ARG, "edge_scatter: the landmark-pair matrix needs v_to_l");
     // two timers: the C x C cluster-pair scatter (the score path) and the N x N landmark-pair scatter
     ScopedKernelTimer t(c, wedges ? (vectC ? "edge_scatter_both" : "edge_scatter_wedges") : "edge_scatter");
-    static const int env_grid = getenv("CGE_SCATTER_GRID") ? atoi(getenv("CGE_SCATTER_GRID")) : 0;
-    const unsigned grid = grid_for(e1 - e0, 256, env_grid > 0 ? env_grid : 512); // measured: 512 > 256, 1024, 2048
-    const bool use16 = comm == c->comm.p && c->comm16.p && C < 65536 && !getenv("CGE_SCATTER_NO16");
+    const unsigned grid = grid_for(e1 - e0, 256, 512); // measured: 512 > 256, 1024, 2048
+    const bool use16 = comm == c->comm.p && c->comm16.p && C < 65536;
     if (use16)
         hipLaunchKernelGGL(edge_scatter_kernel<unsigned short>, dim3(grid), dim3(256), (size_t)C * sizeof(double), c->stream,
                            src, dst, w, e0, e1, v2l, c->comm16.p, N, C, directed, wedges, vectC);

@@ -93,8 +93,7 @@ bool k_build_blocked_edges(cge_ctx *c) {
     for (i64 t = T - 1; t >= 0; t--)
         if (tf[t] < 0) tf[t] = tf[t + 1]; // tiles without edges
     std::vector<i32> ch;
-    static const i64 want = getenv("CGE_EB_CHUNKS") ? atoll(getenv("CGE_EB_CHUNKS")) : 0; // A/B: aim at this many chunks
-    const i64 ideal = want > 0 ? std::max<i64>(1, m / want) : 0;
+    const i64 ideal = 0; // (a target chunk count was an A/B knob of round 2)
     for (i64 t = 0; t < T; t++) {
         const i64 len = tf[t + 1] - tf[t];
         if (len <= 0) continue;
@@ -350,7 +349,7 @@ void k_edge_scatter_blocked(cge_ctx *c, i64 c0, i64 c1, i64 C, int directed, dou
     const bool wt = !c->unit_weights;
     const size_t lds = (size_t)2 * (1 << EB_VBITS) + (wt ? (size_t)8 * Cpad : 0) + (size_t)8 * Cpad + sizeof(unsigned) * 18;
     const dim3 gridB((unsigned)C, (unsigned)((nwg + EB_RBATCH - 1) / EB_RBATCH));
-    static const int stop = getenv("CGE_EB_STOP") ? atoi(getenv("CGE_EB_STOP")) : 0; // timing diagnostics (wrong results)
+    const int stop = 0; // (the kernel's timing diagnostics)
 #define EB_GO(W, D)                                                                                                        \
     do {                                                                                                                   \
         EB_GO2(16, W, D);                                                                                             \
@@ -556,8 +555,7 @@ __global__ __launch_bounds__(WT_THREADS) void wedge_tile_kernel(const unsigned s
 
 // geometry of the tiled form for N landmarks; false: it does not apply (the caller uses the gather + atomics kernel)
 static bool wedge_geometry(const cge_ctx *c, i64 N, i64 nchunks, int *rshift, int *colbits, i64 *ntile, size_t *lds2) {
-    static const bool off = getenv("CGE_SCATTER_GATHER") != nullptr;
-    if (off || N < 1 || N > 65535 || nchunks <= 0) return false;
+    if (N < 1 || N > 65535 || nchunks <= 0) return false;
     const size_t elt = c->unit_weights ? 4 : 8, fixed = sizeof(unsigned) * (2 * WT_THREADS + 32);
     int cb = 1;
     while (((i64)1 << cb) < N) cb++;
@@ -618,8 +616,7 @@ bool k_wedge_scatter_blocked(cge_ctx *c, const i32 *v2l, i64 N, i64 c0, i64 c1, 
 
 // can the blocked copy of the resident edge list exist at all (sort key of 32 bits: tile, source inside the tile)?
 bool k_blocked_edges_possible(const cge_ctx *c) {
-    static const bool off = getenv("CGE_SCATTER_GATHER") != nullptr; // A/B switch: force the gather + atomics kernel
-    return !off && c->m > 0 && c->m < (1LL << 31) &&
+    return c->m > 0 && c->m < (1LL << 31) &&
            ((c->n + (1 << EB_UBITS) - 1) >> EB_UBITS) * ((c->n + (1 << EB_VBITS) - 1) >> EB_VBITS) <= 32768; // n <= ~1.4e7
 }
 // dense C x C (row-major, a <= b when undirected) -> the packed upper triangle of vect_C (src/auxilary.jl:57-59)
@@ -635,7 +632,6 @@ void k_pack_upper(cge_ctx *c, const double *dense, i64 C, double *packed) {
 }
 
 bool k_edge_scatter_blocked_applies(const cge_ctx *c, i64 C) {
-    static const bool off = getenv("CGE_SCATTER_GATHER") != nullptr; // A/B switch: force the gather + atomics kernel
-    return !off && c->comm16.p && C >= 1 && C <= EB_MAXC && c->m < (1LL << 31) &&
+    return c->comm16.p && C >= 1 && C <= EB_MAXC && c->m < (1LL << 31) &&
            ((c->n + (1 << EB_UBITS) - 1) >> EB_UBITS) * ((c->n + (1 << EB_VBITS) - 1) >> EB_VBITS) <= 32768; // n <= ~1.4e7
 }

@@ -10,12 +10,9 @@
 // rocPRIM hands any sort of <= 1 Mi items to its merge sort, which compares whole keys (begin/end bit ignored) in ~log2(n/1024)
 // small launches.  For the 64-bit z keys that is the faster choice (8 onesweep passes otherwise); the few-bit key sorts of
 // this path (task ids, tile keys, community ids) are one or two onesweep passes instead: headline landmarks phase 17.4 ->
-// 16.4 ms.  CGE_SORT_RADIX (bit 0: the few-bit sorts, bit 1: the z sort; default 1) is the A/B switch.
+// 16.4 ms.
 using RadixOnly = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
-static int sort_radix_mask() {
-    static const int v = getenv("CGE_SORT_RADIX") ? atoi(getenv("CGE_SORT_RADIX")) : 1;
-    return v;
-}
+static int sort_radix_mask() { return 1; } // bit 0: the few-bit sorts by onesweep, bit 1: the z sort too
 template <class K, class V>
 static hipError_t radix_pairs(void *tmp, size_t &bytes, const K *ki, K *ko, const V *vi, V *vo, size_t n, int b0, int b1,
                               hipStream_t st) {
@@ -167,7 +164,7 @@ void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 
     const unsigned nb = (unsigned)((R + 255) / 256);
     // CGE_SEGSORT: 0 = rocPRIM only, 1 (default) = the LDS network for batches of few long groups, 2 = for every batch whose
     // groups fit it
-    static const int segsort = getenv("CGE_SEGSORT") ? atoi(getenv("CGE_SEGSORT")) : 1;
+    const int segsort = 1;
     const bool long_groups = R / std::max<i64>(T, 1) >= 768;
     if (max_len > 0 && max_len <= (i64)SEGSORT_CAP * SEGSORT_MAXPIECES && ((segsort == 1 && long_groups) || segsort == 2)) {
         int cap = 64;

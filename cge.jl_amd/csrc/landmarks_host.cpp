@@ -53,7 +53,6 @@ struct Group {
     i64 mean_off = -1, cmean_off = -1;
     Group *parent = nullptr; // (children of a cached split)
     int owner = 0;           // option shard_rows: the rank that holds this group's rows (off / coff / mean_off are -1 elsewhere)
-    i64 cov_off = -1;        // this group's covariance in the covariance arena (c->lm_covs), once it has been a task
 };
 
 // The groups of one runsplit call: stable addresses, handed out from chunks of 4096 (a std::deque<Group> takes one 512-byte
@@ -77,43 +76,19 @@ struct GroupPool {
     Group &back() { return chunks[(used - 1) / CH][(used - 1) % CH]; }
 };
 
-// The arenas belong to the ROOT context; a lane (shadow context, below) sees them through borrowed views.
-inline cge_ctx *root_of(cge_ctx *x) { return x->root ? x->root : x; }
-inline void refresh_arena_views(cge_ctx *x) {
-    cge_ctx *c = root_of(x);
-    if (x == c) return;
-    x->lm_arena.borrow(c->lm_arena);
-    x->lm_means.borrow(c->lm_means);
-    x->lm_covs.borrow(c->lm_covs);
-}
-// Two lanes: the children's member lists (and means) of a half batch are written to the arena by ITS lane's stream, behind the
-// event the host waits for -- and the next round deals the groups afresh, so a lane may read what the other lane wrote.  Each
-// lane records an event behind its writes and every reader's stream waits for the other lane's event first.  (Without it the
-// other lane's gather could overtake the list it reads: rows covered twice and rows covered by no group, now and then.)
-inline void members_written(cge_ctx *x) {
-    if (!x->members_ev) HIP_CHECK(hipEventCreateWithFlags(&x->members_ev, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(x->members_ev, x->stream));
-    x->members_ev_set = true;
-}
-inline void wait_for_other_lanes(cge_ctx *x) { // x's stream: behind the member lists the other lane (or the root) has in flight
-    cge_ctx *c = root_of(x);
-    for (cge_ctx *o : {c, c->lane})
-        if (o && o != x && o->members_ev_set) HIP_CHECK(hipStreamWaitEvent(x->stream, o->members_ev, 0));
-}
+inline cge_ctx *root_of(cge_ctx *x) { return x; } // (rounds 3-4 ran half batches on shadow contexts of a root; removed in round 5)
 // Growth copies the arena into a larger allocation: everything that may still read or write the old one has to be done.
 template <typename T>
 void arena_grow(cge_ctx *c, DevBuf<T> &buf, i64 used, i64 need) {
     const i64 cap = std::max<i64>(need + need / 2, 1024);
     T *fresh = nullptr;
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (c->lane) HIP_CHECK(hipStreamSynchronize(c->lane->stream));
     HIP_CHECK(hipMalloc((void **)&fresh, (size_t)cap * sizeof(T)));
     if (buf.p && used > 0) HIP_CHECK(hipMemcpyAsync(fresh, buf.p, sizeof(T) * used, hipMemcpyDeviceToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (buf.p) (void)hipFree(buf.p);
     buf.p = fresh;
     buf.n = (size_t)cap;
-    if (c->lane) refresh_arena_views(c->lane);
 }
 // reserve `cnt` entries of the member arena (ranges handed out earlier stay valid as offsets)
 i64 arena_alloc(cge_ctx *x, i64 cnt) {
@@ -122,17 +97,6 @@ i64 arena_alloc(cge_ctx *x, i64 cnt) {
     if ((i64)c->lm_arena.n < need || !c->lm_arena.p) arena_grow(c, c->lm_arena, c->lm_arena_used, need);
     const i64 at = c->lm_arena_used;
     c->lm_arena_used = need;
-    return at;
-}
-// reserve `cnt` doubles of the covariance arena; -1 when it would outgrow its budget (the caller then keeps the batch's
-// covariances in scratch and sums every one of them over its rows)
-i64 covs_alloc(cge_ctx *x, i64 cnt) {
-    cge_ctx *c = root_of(x);
-    const i64 need = c->lm_covs_used + cnt;
-    if (need > ((i64)6 << 30)) return -1; // 48 GB of doubles
-    if ((i64)c->lm_covs.n < need || !c->lm_covs.p) arena_grow(c, c->lm_covs, c->lm_covs_used, need);
-    const i64 at = c->lm_covs_used;
-    c->lm_covs_used = need;
     return at;
 }
 // reserve `cnt` doubles of the means arena (same growth rule as the member arena)
@@ -744,8 +708,7 @@ struct LaneRun {
     i64 T = 0;
     int method = 0;
     Batch B;
-    i64 rmbase = -1; // roots only: where this batch's own means go in the means arena
-    i64 base = 0, mbase = -1, cbase = -1; // children ranges, children means, this batch's covariances (arena offsets; cbase -1: scratch)
+    i64 base = 0, mbase = -1; // children ranges, children means (arena offsets)
     CutResult cr;
     std::unique_ptr<WordGatherer> wg;
     size_t i_status = 0, i_meta = 0, i_vals = 0, i_nlow = 0;
@@ -780,7 +743,6 @@ void rule_rss_sorted_enqueue(LaneRun &L) {
     L.i_status = L.wg->add(c->sp_status.p, T); L.i_meta = L.wg->add(c->sp_meta.p, 2 * T);
     L.i_vals = L.wg->add(c->sp_vals.p, 2 * T); L.i_nlow = L.wg->add(c->ls_nlow.p, T);
     L.wg->fetch_async();
-    if (c->root) k_nap(c, c->root->opt_lanes_test_delay); // (testing: the second lane's lists land late)
     k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + L.base);
 }
 void rule_rss_sorted_collect(LaneRun &L) {
@@ -867,7 +829,6 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
     HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(c->copy_done, st));
     // the children's member lists last: the host already has what its heap needs and builds the next batch meanwhile
-    if (c->root) k_nap(c, c->root->opt_lanes_test_delay); // (testing: the second lane's lists land late)
     k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + L.base);
 }
 void rule_cut_collect(LaneRun &L) {
@@ -965,19 +926,16 @@ void rss_generic_tasks(cge_ctx *c, const Batch &B, Group *const *groups, i64 bas
 // Enqueue the split of every task of a (half) batch on L.x: mean, covariance, principal eigenvector, projection, the
 // rule's 1-D cut, the children's member lists, values and means -- no host synchronisation (except the d > 512 host
 // eigen-solver).  `after_cov` (optional): recorded behind the covariance, the point the other lane's start waits for.
-void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
+void lane_enqueue(LaneRun &L) {
     cge_ctx *c = L.x, *root = root_of(c);
     const i64 d = c->d, T = L.T;
     hipStream_t st = c->stream;
     Batch &B = L.B;
-    refresh_arena_views(c);
-    wait_for_other_lanes(c);
     bool have_means = true; // known from the parents' splits: gathered from the means arena, no pass over the rows
     for (i64 t = 0; t < T && have_means; t++) have_means = L.groups[t]->mean_off >= 0;
     {
         PhaseAcc pa(root, "lm_pack");
         build_batch(c, L.groups, T, B);
-        if (start_after) HIP_CHECK(hipStreamWaitEvent(st, start_after, 0));
         std::vector<i64> moff;
         if (have_means) {
             moff.resize(T);
@@ -990,11 +948,11 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
     root->stat_lm_rows += R;
     root->stat_lm_splits += T;
     c->ls_mean.ensure((size_t)T * d); c->ls_sw.ensure(T);
-    if (L.cbase < 0) c->ls_cov.ensure((size_t)T * d * d);
+    c->ls_cov.ensure((size_t)T * d * d);
     c->ls_vec.ensure((size_t)T * d); c->ls_z.ensure(R);
     {
         PhaseAcc pa(root, "lm_pca_dev");
-        double *covp = L.cbase >= 0 ? c->lm_covs.p + L.cbase : c->ls_cov.p; // this batch's covariances: kept for the children
+        double *covp = c->ls_cov.p;
         {
             ScopedKernelTimer tm(c, "group_stats");
             if (have_means) // the offsets went up with the batch's tables
@@ -1002,57 +960,10 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
             else {
                 k_group_mean(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
                              c->ls_part.p, c->ls_mean.p, c->ls_sw.p);
-                if (L.cbase >= 0 && L.rmbase >= 0) // roots: their means join the arena, their children can then be derived
-                    HIP_CHECK(hipMemcpyAsync(c->lm_means.p + L.rmbase, c->ls_mean.p, sizeof(double) * T * d, hipMemcpyDeviceToDevice, st));
             }
-            // sibling pairs whose parent's covariance is on file: the smaller one is summed, the larger one derived
-            std::vector<i64> pairs;
-            std::vector<char> skip(T, 0);
-            if (L.cbase >= 0 && have_means) {
-                std::unordered_map<const Group *, i64> first;
-                for (i64 t = 0; t < T; t++) {
-                    const Group *g = L.groups[t], *p = g->parent;
-                    if (!p || p->cov_off < 0 || p->mean_off < 0) continue;
-                    auto it = first.find(p);
-                    if (it == first.end()) { first[p] = t; continue; }
-                    const i64 u = it->second;
-                    const i64 ts = L.groups[u]->len <= g->len ? u : t, tl = ts == u ? t : u;
-                    pairs.insert(pairs.end(), {ts, tl, p->cov_off, p->mean_off, L.groups[ts]->mean_off, L.groups[tl]->mean_off});
-                    skip[tl] = 1;
-                }
-            }
-            if (pairs.empty())
-                k_group_cov(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
-                            c->ls_mean.p, c->ls_part.p, covp);
-            else {
-                std::vector<i32> ct2, cb2, ce2, tco2(T + 1, 0);
-                for (i64 t = 0; t < T; t++) {
-                    tco2[t] = (i32)ct2.size();
-                    if (skip[t]) continue;
-                    for (i32 ch = B.task_chunk_off[t]; ch < B.task_chunk_off[t + 1]; ch++) {
-                        ct2.push_back(B.chunk_task[ch]); cb2.push_back(B.chunk_beg[ch]); ce2.push_back(B.chunk_end[ch]);
-                    }
-                }
-                tco2[T] = (i32)ct2.size();
-                const i64 NC2 = (i64)ct2.size(), NP = (i64)pairs.size() / 6;
-                c->ls_ct2.ensure(NC2); c->ls_cb2.ensure(NC2); c->ls_ce2.ensure(NC2); c->ls_tco2.ensure(T + 1);
-                c->ls_pairs.ensure(6 * NP);
-                WordPacker pk(c);
-                pk.add(c->ls_ct2.p, ct2.data(), NC2); pk.add(c->ls_cb2.p, cb2.data(), NC2); pk.add(c->ls_ce2.p, ce2.data(), NC2);
-                pk.add(c->ls_tco2.p, tco2.data(), T + 1); pk.add(c->ls_pairs.p, pairs.data(), 6 * NP);
-                pk.flush();
-                k_group_cov(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_ct2.p, c->ls_cb2.p, c->ls_ce2.p, NC2, c->ls_tco2.p, T, d,
-                            c->ls_mean.p, c->ls_part.p, covp);
-                k_cov_derive(c, c->ls_pairs.p, NP, c->lm_means.p, c->lm_covs.p, covp, c->ls_rows.p, c->sp_tro.p, lm_vw(c), d);
-                root->stat_cov_derived += NP;
-            }
-            if (L.cbase >= 0)
-                for (i64 t = 0; t < T; t++) {
-                    L.groups[t]->cov_off = L.cbase + t * d * d;
-                    if (!have_means && L.rmbase >= 0) L.groups[t]->mean_off = L.rmbase + t * d;
-                }
+            k_group_cov(c, c->Xr.p, lm_vw(c), c->ls_rows.p, c->ls_ct.p, c->ls_cb.p, c->ls_ce.p, NC, c->ls_tco.p, T, d,
+                        c->ls_mean.p, c->ls_part.p, covp);
         }
-        if (after_cov) HIP_CHECK(hipEventRecord(after_cov, st));
         if (!k_group_eig(c, covp, T, d, c->ls_vec.p)) { // d > 512: host solver on a worker pool
             std::vector<double> cov((size_t)T * d * d), vec((size_t)T * d);
             HIP_CHECK(hipMemcpyAsync(cov.data(), covp, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
@@ -1075,7 +986,6 @@ void lane_enqueue(LaneRun &L, hipEvent_t after_cov, hipEvent_t start_after) {
     if (L.method == CGE_METHOD_RSS) rule_rss_sorted_enqueue(L);
     else if (L.method == CGE_METHOD_RSS2) rule_rss2_enqueue(L);
     else rule_cut_enqueue(L, L.method == CGE_METHOD_SIZE);
-    if (root->lane) members_written(c); // (a second lane exists: it may read these lists next round)
 }
 // ... and book the results when they have arrived
 void lane_collect(LaneRun &L) {
@@ -1140,45 +1050,19 @@ void compute_splits(cge_ctx *c, std::vector<Group *> &tasks, int method) {
 
     // Sub-batches bound the covariance buffers (T * d*d doubles) to ~1 GiB.
     const i64 max_tasks = std::max<i64>(1, (i64)(1ull << 27) / (d * d));
-    static const int lanes_env = getenv("CGE_LANES") ? atoi(getenv("CGE_LANES")) : 0; // A/B: 1 = one stream
-    const int lanes = lanes_env > 0 ? lanes_env : c->opt_lanes;
     for (size_t b0 = 0; b0 < big.size(); b0 += (size_t)max_tasks) {
         const size_t b1 = std::min(big.size(), b0 + (size_t)max_tasks);
-        const i64 T = (i64)(b1 - b0);
-        Group *const *groups = &big[b0];
-        // (a lane is worth its fixed costs from a few dozen groups on; the N > 1 exchanges need one arena order: one lane)
-        const bool two = lanes >= 2 && T >= 64 && !c->has_coll;
-        LaneRun L[2];
-        // the first half takes every other group, so both halves see the same mix of sizes
-        std::vector<Group *> half[2];
-        if (two) {
-            for (i64 t = 0; t < T; t++) half[t & 1].push_back(groups[t]);
-        }
-        const int nl = two ? 2 : 1;
-        cge_ctx *lane = two ? cge_shadow_context(c, &c->lane, false) : nullptr;
-        // both halves' ranges are handed out before anything is in flight (growing an arena copies it)
-        for (int q = 0; q < nl; q++) {
-            L[q].x = q == 0 ? c : lane;
-            L[q].groups = two ? half[q].data() : groups;
-            L[q].T = two ? (i64)half[q].size() : T;
-            L[q].method = method;
-            i64 r = 0;
-            for (i64 t = 0; t < L[q].T; t++) r += L[q].groups[t]->len;
-            L[q].base = arena_alloc(c, r); // the children of task t: [base + task_row_off[t], + len)
-            L[q].mbase = means_alloc(c, 2 * L[q].T * d);
-            // option cov_derive: the batch's covariances stay on file for the children (not with several ranks: every rank must
-            // take the same path to the same bits, and a parent's matrix lives only where it was computed)
-            if (c->opt_cov_derive && !c->has_coll && d <= 512) {
-                L[q].cbase = covs_alloc(c, L[q].T * d * d);
-                bool roots = false;
-                for (i64 t = 0; t < L[q].T && !roots; t++) roots = L[q].groups[t]->mean_off < 0;
-                if (L[q].cbase >= 0 && roots) L[q].rmbase = means_alloc(c, L[q].T * d);
-            }
-        }
-        lane_enqueue(L[0], two ? c->copy_ev : nullptr, nullptr);
-        if (two) lane_enqueue(L[1], nullptr, c->copy_ev);
-        for (int q = 0; q < nl; q++) lane_collect(L[q]);
-        if (two) wait_for_other_lanes(c); // whatever runs on the root's stream next (a one-lane batch, the final index) reads the lane's lists
+        LaneRun L;
+        L.x = c;
+        L.groups = &big[b0];
+        L.T = (i64)(b1 - b0);
+        L.method = method;
+        i64 r = 0;
+        for (i64 t = 0; t < L.T; t++) r += L.groups[t]->len;
+        L.base = arena_alloc(c, r); // the children of task t: [base + task_row_off[t], + len)
+        L.mbase = means_alloc(c, 2 * L.T * d);
+        lane_enqueue(L);
+        lane_collect(L);
     }
 }
 
@@ -1373,27 +1257,10 @@ void throw_rc(int rc) {
     }
 }
 
-// What the splits seen so far say about the next ones: the mean ratio child value / parent value (low and high child) and
-// the mean share of the rows that goes to the low child.  Only used to GUESS which groups will be popped (advance_heaps);
-// no result depends on it.
-struct SplitModel {
-    double sum_lo = 0.0, sum_hi = 0.0, sum_share = 0.0;
-    i64 n = 0;
-    double r_lo() const { return n ? sum_lo / (double)n : 0.5; }
-    double r_hi() const { return n ? sum_hi / (double)n : 0.5; }
-    double share() const { return n ? sum_share / (double)n : 0.5; }
-};
-
 // create the child groups of every freshly split task (single-threaded: the pool is not thread-safe)
-void materialise_children(std::vector<Group *> &tasks, GroupPool &pool, i64 c_d, SplitModel *model = nullptr) {
+void materialise_children(std::vector<Group *> &tasks, GroupPool &pool, i64 c_d) {
     for (Group *g : tasks) {
         if (g->rc != CGE_OK || g->clo) continue;
-        if (model && g->value < 0.0 && g->nlow > 1 && g->len - g->nlow > 1) { // (heap keys are -total_rss: ratios are positive)
-            model->sum_lo += g->vlow / g->value;
-            model->sum_hi += g->vhigh / g->value;
-            model->sum_share += (double)g->nlow / (double)g->len;
-            model->n++;
-        }
         pool.emplace_back();
         g->clo = &pool.back();
         g->clo->off = g->coff;
@@ -1429,7 +1296,7 @@ void replay_one(Heap &h) {
 // `speculate` = false: only the current top of each heap is split per round (no wasted splits; used for the
 // many small per-community heaps of the forced phase, which need s-1 rounds anyway).
 void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64> &targets, int method,
-                   GroupPool &pool, bool speculate, SplitModel &model) {
+                   GroupPool &pool, bool speculate) {
     for (;;) {
         PhaseAcc *ph = new PhaseAcc(c, "lm_heap"); // replay + choice of the next batch (host)
         std::vector<Group *> batch;
@@ -1443,51 +1310,6 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
             }
             const i64 remaining = targets[q] - (i64)h.len();
             std::vector<Group *> frontier;
-            if (c->opt_speculation_pct < 0) {
-                // (option speculation_pct = -1; measured equal to the rank rule below, profiles/r03_speculation_ab.txt)
-                // PLAY THE REST OF THE POP SEQUENCE FORWARD on what is known: cached splits contribute their real children, an
-                // unsplit group two GUESSED children (value and size scaled by the mean ratios of the splits seen so far).  The
-                // known unsplit groups this rehearsal pops are the ones to split now -- all of them at once, so a round of
-                // batches resolves one level of the relevant split tree; groups the rehearsal leaves alone are (probably) never
-                // popped and cost nothing.  A margin below the rehearsal's last popped value covers the guess.  Whatever the
-                // guesses, the replay above is the reference's own sequence: a wrong guess costs a wasted or a late split.
-                struct Sim { double value; Group *g; double len; };
-                auto later = [](const Sim &a, const Sim &b) { return a.value > b.value; }; // min-heap on value
-                std::vector<Sim> pq;
-                pq.reserve(h.len() + 2 * remaining + 8);
-                for (size_t i = 1; i <= h.len(); i++) pq.push_back(Sim{h.a[i]->value, h.a[i], (double)h.a[i]->len});
-                std::make_heap(pq.begin(), pq.end(), later);
-                const double r_lo = model.r_lo(), r_hi = model.r_hi(), share = std::min(0.95, std::max(0.05, model.share()));
-                double last = 0.0;
-                i64 pops = remaining;
-                while (pops > 0 && !pq.empty()) {
-                    std::pop_heap(pq.begin(), pq.end(), later);
-                    const Sim it = pq.back();
-                    pq.pop_back();
-                    if (!(it.value < 0.0) && !(it.g && it.g == h.top())) break; // only singletons (eps()) are left: the reference stops here too
-                    pops--;
-                    last = it.value;
-                    if (it.g && it.g->has_split) {
-                        if (it.g->rc != CGE_OK) break; // the replay will raise it
-                        for (Group *ch : {it.g->clo, it.g->chi}) {
-                            pq.push_back(Sim{ch->value, ch, (double)ch->len});
-                            std::push_heap(pq.begin(), pq.end(), later);
-                        }
-                        continue;
-                    }
-                    if (it.g) frontier.push_back(it.g);
-                    const double l1 = it.len * share, l2 = it.len - l1;
-                    if (l1 >= 2.0) { pq.push_back(Sim{it.value * r_lo, nullptr, l1}); std::push_heap(pq.begin(), pq.end(), later); }
-                    if (l2 >= 2.0) { pq.push_back(Sim{it.value * r_hi, nullptr, l2}); std::push_heap(pq.begin(), pq.end(), later); }
-                }
-                const double margin = (method == CGE_METHOD_SIZE || method == CGE_METHOD_DIAMETER) ? 0.75 : 0.9;
-                for (const Sim &it : pq) // known, unsplit, just below the rehearsal's threshold (values are negative)
-                    if (it.g && !it.g->has_split && it.g->len > 1 && it.value <= last * margin) frontier.push_back(it.g);
-                if (frontier.empty() && !h.top()->has_split) frontier.push_back(h.top());
-                batch.insert(batch.end(), frontier.begin(), frontier.end());
-                continue;
-            }
-            // (default, speculation_pct >= 0: the rank rule)
             // Exactly `remaining` more pops will happen.  A node can only be among them if its value ranks within
             // `remaining` among ALL known unpopped nodes (cached splits and unsplit ones alike): nodes still to be
             // discovered only add competitors.  So every unsplit node above that threshold is a candidate and
@@ -1522,16 +1344,13 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
             // outrank it).  Splitting only the most valuable part per round costs a round or two more and saves the
             // eigen-problems of the rest; what is left over is reconsidered, with more known, in the next round.
             // (never fewer than 256 at a time: the last pops would otherwise trickle through many tiny rounds)
-            const int spec_pct = c->opt_speculation_pct > 0 ? c->opt_speculation_pct
-                                 : (method == CGE_METHOD_SIZE || method == CGE_METHOD_DIAMETER) ? 10
+            const int spec_pct = (method == CGE_METHOD_SIZE || method == CGE_METHOD_DIAMETER) ? 10
                                  : (c->d > 128 ? 25 : 40); // wide embeddings: a wasted split costs a memory-resident eigen-problem
             i64 take = std::max<i64>(std::min<i64>(remaining, 256), (i64)((double)remaining * spec_pct / 100.0));
             // The register-resident eigen-solver of 64 < d <= 128 holds two matrices per CU: 512 at a time, and a batch of 800
             // costs two rounds (0.98 ms) where 512 cost one (0.51).  The batch is cut DOWN to a multiple of 512: one round more
             // at the headline (8 batches), eigen-solver 4.7 -> 4.0 ms, landmarks 13.1 -> 12.3 ms (rounding up: 13.6).
-            // CGE_SPEC_QUANT=0 switches it off, 1 rounds up (A/B).
-            static const int quant = getenv("CGE_SPEC_QUANT") ? atoi(getenv("CGE_SPEC_QUANT")) : 2;
-            if (quant && c->d > 64 && c->d <= 128 && take > 512) take = quant == 1 ? (take + 511) / 512 * 512 : take / 512 * 512;
+            if (c->d > 64 && c->d <= 128 && take > 512) take = take / 512 * 512;
             if ((i64)frontier.size() > take) {
                 std::nth_element(frontier.begin(), frontier.begin() + (take - 1), frontier.end(),
                                  [](const Group *a, const Group *b) { return a->value < b->value; });
@@ -1548,7 +1367,7 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
         if (speculate) compute_splits_sharded(c, batch, method); // the global phase (N > 1: split over the ranks)
         else compute_splits(c, batch, method);
         PhaseAcc pm(c, "lm_materialise");
-        materialise_children(batch, pool, c->d, &model);
+        materialise_children(batch, pool, c->d);
     }
 }
 
@@ -1558,7 +1377,7 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
 // and the landmark -> members index c->lm_memoff / c->lm_mem (ascending inside a landmark), mirrored in
 // c->h_mem_off / c->h_mem when `want_index`.
 void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i64 nland, i64 forced, int method,
-                   std::vector<i64> &group_ids, bool want_index, const std::function<i64()> *late_nland) {
+                   std::vector<i64> &group_ids, bool want_index) {
     const i64 n = c->n, d = c->d;
     hipStream_t st = c->stream;
     const bool RS = c->rows_sharded; // option shard_rows: this rank holds (and splits) the rows of its own communities only
@@ -1567,7 +1386,6 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         CGE_THROW(CGE_E_ARG, "runsplit: embedding / vertex weights are not resident");
     GroupPool pool;
     Heap H;
-    SplitModel model;
     PhaseAcc *pinit = new PhaseAcc(c, "lm_init");
     // sort(initial_clusters): lexicographic (:281)
     std::vector<i64> order(ncl);
@@ -1580,12 +1398,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     const i64 total = cl_off[ncl];
     c->lm_arena_used = 0;
     c->lm_means_used = 0;
-    c->lm_covs_used = 0;
-    // testing (option runsplit_lanes_test_delay): what an earlier run left in the arena is wiped -- a list that is read before
-    // it is written would otherwise often find the very ids it is about to receive (the runs of a test are identical)
-    if (c->opt_lanes_test_delay > 0 && c->lm_arena.p)
-        HIP_CHECK(hipMemsetAsync(c->lm_arena.p, 0, sizeof(i32) * c->lm_arena.n, c->stream));
-    c->stat_lm_batches = c->stat_lm_rows = c->stat_lm_splits = c->stat_cov_derived = 0;
+    c->stat_lm_batches = c->stat_lm_rows = c->stat_lm_splits = 0;
     c->cut_ties.ensure(1);
     HIP_CHECK(hipMemsetAsync(c->cut_ties.p, 0, sizeof(int), c->stream));
     // option shard_rows: cl_owner[q] = the rank that holds cluster q's rows (the owner of its first member's community; a
@@ -1704,7 +1517,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
             // (a reference error -- "Trying to split homogenous cluster", an empty child -- is raised by the owner of the
             // community alone: it must reach the other ranks, who would otherwise wait in the exchange for ever)
             const RankError err = guarded_work([&] {
-                if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model);
+                if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false);
                 for (i64 b = 0; b < nbig; b++) {
                     if (owner[b] != me) continue;
                     Heap &L = locals[b].h;
@@ -1739,7 +1552,6 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                 }
             }
             sharded_forced = true;
-            model = SplitModel(); // (it has seen this rank's splits only: the global phase must start from the same state everywhere)
         }
         if (shard) { // longest first, each to the least loaded rank (deterministic)
             std::vector<i64> ord(nbig), load(W, 0);
@@ -1760,7 +1572,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                 if (owner[b] == me_f) { hs.push_back(&locals[b].h); tg.push_back(forced); }
             // (sharded: an error of this rank's heaps -- the reference's own "Trying to split homogenous cluster" included --
             // travels with the exchange below, so that every rank stops instead of waiting for this one)
-            ferr = guarded_work([&] { if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false, model); });
+            ferr = guarded_work([&] { if (!hs.empty()) advance_heaps(c, hs, tg, method, pool, false); });
             if (!shard && ferr.code) throw CgeError{ferr.code, ferr.msg};
         }
         if (shard) {
@@ -1882,10 +1694,9 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     delete pmerge;
     // ---- global phase (:316-335) ----------------------------------------------------------------------------
     {
-        if (late_nland) nland = (*late_nland)(); // the `land` clamp (src/landmarks.jl:371-376), computed beside the forced phase
         std::vector<Heap *> hs{&H};
         std::vector<i64> tg{nland};
-        advance_heaps(c, hs, tg, method, pool, true, model);
+        advance_heaps(c, hs, tg, method, pool, true);
     }
     // ---- the heap array is the numbering (:337-342): v2l and the landmark index, on the device -----------------------
     PhaseAcc pfin(c, "lm_final");

@@ -144,27 +144,23 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     DevBuf<i32> d_old2new;
     // (also the landmark graph of a landmark-mode score with more than 8192 landmarks -- config 5 has 12 000; the local
     // score then reads T through the landmark ids of the original numbering, see the un-permuted copy in the sweep)
-    // Round 4, option bvec_blocks = 1 / CGE_BVEC_BLOCKS=1 (NOT the default): the sweep is relabelled from 256 vertices on and
-    // vect_B is summed BY TILES (kernels_fit.hip: bvec_tile_kernel + bvec_bins_kernel: GD read once, no row bins) instead of
-    // row bins + row sums + fold.  Correct (every parity suite passes with it) and measured slower: the tile kernel takes
-    // 56 us where the three launches it replaces take 57 (profiles/r04_bvec_tiles_ab.txt).
-    static const bool blocks_env = getenv("CGE_BVEC_BLOCKS") && atoi(getenv("CGE_BVEC_BLOCKS")) != 0;
+    // Option bvec_blocks = 1: an exact-mode sweep is relabelled from 256 vertices on and vect_B is summed BY TILES (kernels_fit.hip:
+    // bvec_tile_kernel + bins: GD read once, no row bins) instead of row bins + row sums + fold (the same speed there,
+    // profiles/r04_bvec_tiles_ab.txt); landmark-mode sweeps always do (below).
     // (beyond 8192 vertices the sweep is relabelled anyway and the staged row-bin kernel no longer fits LDS: there the tile
     // form replaces the plain gather -- config 5, N = 12 000: 1.1 ms per alpha for the row bins alone)
-    static const bool blocks_off = getenv("CGE_BVEC_BLOCKS") && atoi(getenv("CGE_BVEC_BLOCKS")) == 0;
-    const bool blocks_req = (blocks_env || c->opt_bvec_blocks || (N > 8192 && !blocks_off)) && c->opt_exact_relabel && N >= 256 && C >= 2 &&
+    const bool blocks_req = (c->opt_bvec_blocks || N > 8192) && c->opt_exact_relabel && N >= 256 && C >= 2 &&
                             !c->opt_test_bvec_plain;
     // Round 5, the default in landmark mode wherever the undirected persistent fit runs with one tile per wave: the rest of
     // an alpha's chain RIDES ON THE FIT'S LAUNCH (kernels_fitp.hip, fit_flow_kernel<.., true>: the power matrix in its
     // prologue, vect_B's tile partials and the local score's tallies in its epilogue).  It needs the relabelled sweep and the
-    // tile tables below; option "fit_fused" = 0 / CGE_FIT_FUSED=0 keeps the separate launches (A/B, cross-check in the tests).
+    // tile tables below; option "fit_fused" = 0 keeps the separate launches (the cross-check of the parity tests).
     // Every undirected landmark-mode sweep of >= 256 landmarks is relabelled and sums vect_B by tiles then, whichever form of the
     // fit runs (so that all forms add in the same order and give the same bits); the fused launch itself needs the default
     // persistent form with one tile per wave.
-    static const bool fused_off_env = getenv("CGE_FIT_FUSED") && atoi(getenv("CGE_FIT_FUSED")) == 0;
-    const bool tiles_req = orig != nullptr && !directed && c->opt_fit_fused && !fused_off_env && c->opt_exact_relabel && N >= 256 &&
+    const bool tiles_req = orig != nullptr && !directed && c->opt_fit_fused && c->opt_exact_relabel && N >= 256 &&
                            C >= 2 && !c->opt_test_bvec_plain;
-    const bool fuse_req = tiles_req && !c->fit_persistent_broken && (c->opt_fit_persistent == 0 || c->opt_fit_persistent == 2) &&
+    const bool fuse_req = tiles_req && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
                           c->opt_pow_exp2 && k_fit_flow_fused_applies(c, N);
     const bool blocks = blocks_req || tiles_req;
     bool blocks_ok = blocks, pieces_ok = true;
@@ -282,9 +278,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     bool use_persistent_dir = directed && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
                               (c->opt_fit_persistent >= 2 || N >= 128);
     // one launch (pair) per iteration, when the register-resident form does not apply: over the upper tiles only
-    // (kernels_fitp.hip: k_fit_sym_step); CGE_FIT_ROWS=1 keeps the whole-row kernel for A/B
-    static const bool fit_rows_env = getenv("CGE_FIT_ROWS") && atoi(getenv("CGE_FIT_ROWS")) != 0;
-    const bool sym_fit = !directed && !fit_rows_env;
+    // (kernels_fitp.hip: k_fit_sym_step)
     c->stat_fit_persistent = 0;
     c->stat_fit_iters = 0;
 
@@ -421,28 +415,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     constexpr i64 RES_AUC = 0, RES_VERD = 2 * CGE_PARTIAL_BLOCKS, RES_JS = RES_VERD + 2, RES_FIT = RES_JS + 2 * CGE_PARTIAL_BLOCKS,
                   RES_LEN = RES_FIT + 2, RES_STRIDE = RES_FIT + 16;
     c->pin_scal.ensure(2 * RES_STRIDE);
-    const int fit_variant = c->opt_fit_persistent == 3 ? 0 : (c->opt_fit_persistent == 4 ? 1 : 2);
-    // THE POWER MATRIX OF THE NEXT ALPHA BESIDE THIS ALPHA'S vect_B / JS / AUC (round 4).  (1 - D)^alpha does not depend on the
-    // fit, but the persistent fit holds every register of every CU, so nothing runs beside IT; the kernels behind it
-    // (row products, block sums, JS terms, tallies: ~80 us of small launches) leave most of the chip idle.  With two GD
-    // buffers the matrix of alpha i+1 is written on a side stream as soon as the fit of alpha i has finished -- beside that
-    // tail -- and the fit of alpha i+1 waits for its event instead of for a 36 us launch of its own.  Only behind an
-    // ENQUEUED fit (the forms the host waits for leave nothing to overlap), and only while two N x N matrices are small.
-    // MEASURED (profiles/r04_pow_overlap_ab.txt): it does NOT pay -- headline sweep 10.1 -> 10.8 ms.  The two cross-queue
-    // dependencies per alpha (fit -> side stream, side stream -> next fit) cost more than the 36 us they hide.  Kept behind
-    // CGE_POW_OVERLAP=1 for A/B; off by default.
-    static const bool pow_overlap_env = getenv("CGE_POW_OVERLAP") && atoi(getenv("CGE_POW_OVERLAP")) != 0;
-    const bool pow_overlap = pow_overlap_env && !fuse && (double)N * (double)N * 8.0 <= 2.0e9;
-    double *GDb[2] = {GD.p, GD.p};
-    if (pow_overlap) {
-        c->sw_GD2.ensure((size_t)N * N);
-        GDb[1] = c->sw_GD2.p;
-        for (int q = 0; q < 2; q++)
-            if (!c->pow_ev[q]) HIP_CHECK(hipEventCreateWithFlags(&c->pow_ev[q], hipEventDisableTiming));
-        if (!c->fitdone_ev) HIP_CHECK(hipEventCreateWithFlags(&c->fitdone_ev, hipEventDisableTiming));
-    }
-    i64 pow_ready_for = -1;    // the alpha whose matrix is being written on the side stream (pow_ev[ia & 1] behind it)
-    bool pow_ready_upper = false;
+    // (Round 4 tried the next alpha's power matrix on a side stream beside this alpha's vect_B / JS / AUC: +0.65 ms, the two
+    // cross-queue dependencies per alpha cost more than they hid -- profiles/r04_pow_overlap_ab.txt; removed in round 5, when
+    // the power matrix moved into the fit's prologue anyway.)
     auto enqueue_alpha = [&](i64 ia, bool want_auc, bool want_div) {
         AlphaSlot &sl = slots[ia & 1];
         const int slot = (int)(ia & 1);
@@ -452,18 +427,11 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         sl.did_div = want_div;
         // the undirected persistent fit and vect_B read the upper triangle only; the exact-mode AUC, the directed vect_B
         // and the launch-per-iteration fits read whole rows
-        const bool gd_upper = landmarks && !directed && (use_persistent || sym_fit);
-        double *const GDc = GDb[pow_overlap ? (ia & 1) : 0]; // this alpha's matrix
+        const bool gd_upper = landmarks && !directed;
+        double *const GDc = GD.p; // this alpha's matrix
         const bool fused_now = fuse && use_persistent && c->pow_logs_N == N; // (a fallback in mid-sweep ends it: the matrix is needed then)
         bool auc_done = false, bvec_partials = false;
-        if (fused_now) {
-        } else if (pow_overlap && pow_ready_for == ia && pow_ready_upper == gd_upper)
-            HIP_CHECK(hipStreamWaitEvent(st, c->pow_ev[ia & 1], 0));
-        else {
-            if (pow_ready_for >= 0) HIP_CHECK(hipStreamSynchronize(c->copy_stream)); // (a stale pre-launch must not write under us)
-            k_pow_matrix(c, D.p, N, alpha, GDc, gd_upper);
-        }
-        pow_ready_for = -1;
+        if (!fused_now) k_pow_matrix(c, D.p, N, alpha, GDc, gd_upper);
         if (directed || !use_persistent) HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
         if (directed) {
             const double init[2] = {0.9, 1.0}; // epsilon, diff (:434-435)
@@ -483,13 +451,12 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                     const i64 set = smp.n_sets == 1 ? 0 : ia - 1;
                     ff = h_epi[set];
                     ff.Lh = c->sw_Lh.p; ff.Ll = c->sw_Ll.p; ff.alpha = alpha;
-                    static const int parts_env = getenv("CGE_FUSE_PARTS") ? atoi(getenv("CGE_FUSE_PARTS")) : 3; // A/B: bit 0 vect_B, bit 1 local score
-                    if (!want_div || !(parts_env & 1)) ff.partial = nullptr;
-                    if (!(want_auc && fuse_auc) || !(parts_env & 2)) ff.auc_part = nullptr;
+                    if (!want_div) ff.partial = nullptr;
+                    if (!(want_auc && fuse_auc)) ff.auc_part = nullptr;
                     ffp = &ff;
                     ffd = reinterpret_cast<const cge_fit_fused *>(c->sw_fused_epi.p) + set;
                 }
-                if (fit_variant == 2 && k_fit_flow_enqueue(c, fused_now ? nullptr : GDc, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld,
+                if (k_fit_flow_enqueue(c, fused_now ? nullptr : GDc, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld,
                                                            Tld, G.vw, 0.25, delta, (int *)(scal.p + RES_FIT), ffp, ffd)) {
                     if (fused_now) {
                         auc_done = ff.auc_part != nullptr;
@@ -499,25 +466,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                     sl.fit_async = true; // the verdict is looked at when the alpha is collected
                     fitted = true;
                     tpar = tnext;
-                } else { // the counter / barrier forms work on two adjacent buffers and are waited for
-                    if (tpar == 2) {
-                        HIP_CHECK(hipMemcpyAsync(TT.p, TT.p + 2 * Tld, sizeof(double) * Tld, hipMemcpyDeviceToDevice, st));
-                        tpar = 0;
-                        sl.t0_par = 0;
-                    }
-                    HIP_CHECK(hipMemcpyAsync(c->fp_Tsave.p, TT.p + (i64)tpar * Tld, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
-                    int fpar = 0;
-                    fitted = k_fit_persistent(c, GDc, N, TT.p + (i64)tpar * Tld, Tld, 0, G.vw, 0.25, delta, &iters, &fpar,
-                                              fit_variant == 2 ? 1 : fit_variant);
-                    if (fitted) {
-                        tpar += fpar;
-                        c->stat_fit_persistent++;
-                    } else { // not co-resident / timed out: restore T and use one launch per iteration from here on
-                        use_persistent = false;
-                        if (gd_upper && !sym_fit) k_pow_matrix(c, D.p, N, alpha, GDc, false);
-                        HIP_CHECK(hipMemcpyAsync(TT.p + (i64)tpar * Tld, c->fp_Tsave.p, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
-                        HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
-                    }
+                } else { // the register-resident form does not apply to this size: one launch per iteration from here on
+                    use_persistent = false;
+                    if (fused_now) k_pow_matrix(c, D.p, N, alpha, GDc, gd_upper); // (the fused launch was to supply the matrix)
+                    HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
                 }
             }
             if (!fitted) {
@@ -527,8 +479,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                 i64 k = 0;
                 for (;;) {
                     for (i64 b = 0; b < batch; b++, k++)
-                        (sym_fit ? k_fit_sym_step : k_fit_step)(c, GDc, Tb2[k & 1], Tb2[(k + 1) & 1], G.vw, N, 0.25, delta, (int)k,
-                                                                c->sw_fring.p, flags.p, flags.p + 1);
+                        k_fit_sym_step(c, GDc, Tb2[k & 1], Tb2[(k + 1) & 1], G.vw, N, 0.25, delta, (int)k, c->sw_fring.p, flags.p,
+                                       flags.p + 1);
                     int hf[2];
                     unsigned long long hr[3];
                     HIP_CHECK(hipMemcpyAsync(hf, flags.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
@@ -546,8 +498,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             }
             Tcur = TT.p + (i64)tpar * Tld;
         } else if (use_persistent_dir &&
-                   k_fit_persistent_dir(c, GDc, N, T1.p, T2.p, G.deg_in, G.deg_out, 0.9, 1.0, delta, &iters, fit_variant,
-                                        fit_variant == 2 ? (int *)(scal.p + RES_FIT) : nullptr, &dir_async)) {
+                   k_fit_persistent_dir(c, GDc, N, T1.p, T2.p, G.deg_in, G.deg_out, 0.9, 1.0, delta, &iters, (int *)(scal.p + RES_FIT),
+                                        &dir_async)) {
             // the whole directed fit in one launch (kernels_fitp.hip).  The default form is only enqueued: the rest of the
             // alpha's chain is queued behind it and its verdict arrives with the alpha's scalars (Tin / Tout are written
             // on success only, so a failed launch is redone from the same iterates with one launch pair per iteration).
@@ -574,22 +526,6 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         }
         sl.iters = iters;
         if (!sl.fit_async) prev_iters = iters;
-        if (pow_overlap && sl.fit_async && ia < n_alpha_total) { // the next alpha's matrix: behind this fit, beside what follows it
-            HIP_CHECK(hipEventRecord(c->fitdone_ev, st));
-            HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->fitdone_ev, 0));
-            std::swap(c->stream, c->copy_stream);
-            try {
-                k_pow_matrix(c, D.p, N, AlphaStep * (double)(ia + 1), GDb[(ia + 1) & 1], gd_upper);
-            } catch (...) {
-                std::swap(c->stream, c->copy_stream);
-                throw;
-            }
-            std::swap(c->stream, c->copy_stream);
-            HIP_CHECK(hipEventRecord(c->pow_ev[(ia + 1) & 1], c->copy_stream));
-            pow_ready_for = ia + 1;
-            pow_ready_upper = gd_upper;
-        }
-
         const double *Ta = directed ? Tout : Tcur, *Tb = directed ? Tin : Tcur;
         const double *Ta_auc = Ta, *Tb_auc = Tb;
         if (want_auc && !auc_done && relabel && landmarks) { // v_to_l holds the landmark ids of the original numbering
@@ -626,8 +562,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             else cge_allreduce_dev(c, scal.p + RES_VERD, 1, 0);
         }
         if (want_div) {
-            static const bool one_js_off = getenv("CGE_BINS_JS") && atoi(getenv("CGE_BINS_JS")) == 0; // A/B: the separate launches
-            if ((bvec_partials || c->bvec_blocks) && !directed && !c->opt_test_bvec_plain && !one_js_off) {
+            if ((bvec_partials || c->bvec_blocks) && !directed && !c->opt_test_bvec_plain) {
                 // tile partials (from the fit's epilogue, or one pass over GD) -> vect_B and its divergence(s) in one launch
                 if (!bvec_partials) k_bvec_tiles(c, GDc, Ta, Tb, d_cm_off.p, N, directed);
                 k_bins_js(c, d_cm_off.p, N, C, G.vectC, vectB.p, split ? 2 : 1, scal.p + RES_JS);
@@ -650,7 +585,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
 
     // log2(1 - D) once for the whole sweep (the upper tiles only when every alpha reads only those); a fallback of the
     // persistent fit in mid-sweep makes k_pow_matrix use the library pow for the whole rows it then needs
-    k_pow_prepare(c, D.p, N, landmarks && !directed && (use_persistent || sym_fit));
+    k_pow_prepare(c, D.p, N, landmarks && !directed);
     i64 next_enqueue = 1;
     for (i64 ia = 1; ia <= n_alpha_total; ia++) {
         const double alpha = AlphaStep * (double)ia;
@@ -673,8 +608,6 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             const int *hf = (const int *)(c->pin_scal.p + RES_STRIDE * (ia & 1) + RES_FIT);
             if (hf[2] || !hf[0] || peer_failed) { // a wait timed out (here or on another rank): drain what was enqueued behind
                 HIP_CHECK(hipStreamSynchronize(st)); // it and redo this alpha from its T_0 (still in place) with one launch per
-                HIP_CHECK(hipStreamSynchronize(c->copy_stream)); // (and a pre-launched power matrix: the redo writes its own)
-                pow_ready_for = -1;
                 note_fit_fallback(c);                // iteration, as every later alpha
                 if (directed) use_persistent_dir = false;
                 else {
@@ -745,7 +678,6 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         }
         if (skip_div && skip_auc) break; // :253
     }
-    if (pow_overlap) HIP_CHECK(hipStreamSynchronize(c->copy_stream)); // (a matrix pre-launched for an alpha the early stop never reached)
     out[0] = best_alpha; out[1] = best_div; out[2] = best_div_ext; out[3] = best_div_int;
     out[4] = best_alpha_auc; out[5] = best_auc; out[6] = best_auc_err; // :256
     *out_len = 7;

@@ -240,18 +240,6 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  * "landmark_edges": 1 = cge_score also builds the N x N landmark-pair matrix and its positive-entry count, i.e. all that
  *             landmarks() returns (src/landmarks.jl:433-463); 0 (default) = on the first cge_landmarks_fetch /
  *             cge_landmarks_info (an undirected score does not read it).  bench.py sets 1.
- * "early_diameter", "side_samples": 1 = cge_score runs the diameter (from the clusters cut into chunks instead of the
- *             landmarks: the search is exact for any partition) resp. the `land` clamp and the sample draws on a second host
- *             thread with its own low-priority streams, beside runsplit (single rank only).  0 (default): in line.  Same
- *             results; measured slower or equal on every workload.
- * "runsplit_lanes": 2 = every batch of runsplit as two half-batches on two streams, half a chain out of phase; 1 (default).
- *             Same results.  "runsplit_lanes_test_delay": testing -- the second lane's children lists land n x ~4 us late and the
- *             member arena is wiped before the run (a list read before it is written then shows); results must not depend on it.
- * "fit_persistent_test_delay": testing -- the tile waves of the persistent fits nap n x ~3 us before their first load (start skew,
- *             as under contention); results must not depend on it.  "fit_persistent_test_timeout": testing -- 1 = the persistent
- *             fit abandons every launch at once (the fallback path runs).
- * "cov_derive": 1 = runsplit takes the covariance of the larger child of a split as parent - sibling (the smaller child is
- *             still summed over its rows); 0 (default).  Same landmark ids; measured no faster.
  * "shard_ingest": N > 1, set AFTER the collectives (cge_comm_init_rccl / cge_set_collectives) and BEFORE the uploads:
  *             1 = cge_set_graph keeps only this rank's slice [m r / W, m (r+1) / W) of the edge list resident (the scatter
  *             passes run over what a rank holds, the sampler's look-ups are exchanged) and cge_set_embedding uploads n / W
@@ -280,15 +268,19 @@ int cge_max_pair_dist(cge_ctx *ctx, int part, int nparts, double *hi, int64_t *a
  *             0 = auto: one persistent launch per alpha (the matrix register-resident, the workgroups exchanging
  *                 partial sums and iterates by polling the data itself) for score graphs of >= 128 vertices that fit
  *                 the register file (N <= ~4900 undirected, ~4000 directed on 256 CUs), else one launch per iteration;
- *             1 = always one launch per iteration; 2 = persistent whenever it fits; 3 / 4 = 2 with grid barriers /
- *             with per-block dependency counters instead (undirected only; the directed fit always uses counters).
- *             Same iterates and iteration counts in all modes, identical bits among 2, 3 and 4; sums are grouped
- *             differently between the launch-per-iteration and the persistent forms (last-bit differences of the
- *             score vector).
- * "speculation_pct": 1..100, or 0 (default) = by split rule (40 for rss / rss2 -- 25 when d > 128 --, 10 for size / diameter): share of the pops
- *             still missing that one round of runsplit's global phase may split ahead of the heap; -1 = the groups to split
- *             are chosen by rehearsing the pop sequence on the known values with guessed children; tuning only -- the
- *             replay makes the result independent of it.
+ *             1 = always one launch per iteration; 2 = persistent whenever it fits.  Same iterates and iteration counts in
+ *             all modes; sums are grouped differently between the launch-per-iteration and the persistent form (last-bit
+ *             differences of the score vector).
+ * "fit_fused": 1 (default) = in landmark mode (undirected, >= 256 landmarks) the sweep is relabelled by community and the rest
+ *             of an alpha's chain rides on the launch of the persistent fit: (1 - D)^alpha in its prologue from the stored
+ *             logarithm (no power matrix is written), the community-pair sums of P = T_i T_j (1 - D_ij)^alpha (vect_B,
+ *             src/divergence.jl:226-234) per 64 x 64 tile and the tallies of the sampled pairs (:178-213) in its epilogue.
+ *             0 = separate launches on the graph as given.  Same iteration counts; the sums of vect_B are grouped differently
+ *             (last-bit differences).
+ * "wedges_reduce_scatter": N > 1: 1 = the N x N landmark-pair matrix of landmarks() is reduce-scattered by row blocks
+ *             (ncclReduceScatter / the hook's reduce_scatter_f64) instead of all-reduced; its consumers then work on row
+ *             blocks and cge_landmarks_fetch of the edge list becomes COLLECTIVE (every rank must call it: the blocks are
+ *             all-gathered).  0 (default): all-reduce, every fetch is local.
  * "shard_runsplit": with collectives set (N > 1): 1 (default) = the forced per-community phase of runsplit and the big
  *             batches of its global phase are split over the ranks and gathered by one all-reduce each (hook op 2);
  *             0 = runsplit replicated on every rank; 2 = every batch is split (tests).  Same landmark ids in all modes.

@@ -29,6 +29,12 @@ int cge_segment_sort_test(void *ctx, const double *z, const int32_t *task_row_of
 /* kernel-level hook (needs the GPU): per row of 64 doubles, lane 0's sum by the shuffle tree (out_ref) and by the gfx950
  * lane swaps the projection kernel uses instead (out_new): the same pairs in the same order, so the same bits */
 int cge_wave_tree_test(void *ctx, const double *x, int64_t n_rows, double *out_ref, double *out_new);
+/* testing knobs of a context (needs the GPU; results must not depend on them):
+ *   "fit_persistent_test_delay"   n: the tile waves of the persistent fits nap n x ~3 us before their first load (start skew, as
+ *                                 under contention);
+ *   "fit_persistent_test_timeout" 1: the persistent fit abandons every launch at once (the fallback path runs);
+ *   "test_bvec_plain"             1: vect_B by the kernels of score graphs beyond the LDS budget / 512 communities.              */
+int cge_set_test_option(void *ctx, const char *key, int64_t value);
 #ifdef __cplusplus
 }
 #endif

@@ -1,8 +1,6 @@
 """Stage split of the batched eigen-solver (kernels_lm.hip: group_eig_kernel) on T covariance matrices of width d.
 Run once per stage: CGE_EIG_DIAG=1 (stop after the tridiagonalisation), 2 (+ multisection), 3 (+ inverse iteration),
-0/unset (everything); timing-only variants with WRONG results: 10 = the two O(d^2) loops of a step skipped, 11 = (first
-form) hardware reciprocals instead of IEEE divisions, 12 = (cyclic form) no reflector stores, 13 = (first form) no square
-root / divisions.  CGE_EIG_FORM = 0 (first form), 4 / 8 (cyclic columns on 4 / 8 waves).  Prints the HIP-event time."""
+0/unset (everything).  Prints the HIP-event time.  (The forms CGE_EIG_FORM selected in rounds 3-4 were removed in round 5.)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,5 +20,5 @@ for _ in range(5):
     ctx.group_eig(A)
 pr = ctx.profile()["group_eig"]
 n, ms = pr["launches"], pr["total_ms"]
-print(f"CGE_EIG_FORM={os.environ.get('CGE_EIG_FORM', 'default')} CGE_EIG_DIAG={os.environ.get('CGE_EIG_DIAG', '0')} T={T} d={d}: "
+print(f"CGE_EIG_DIAG={os.environ.get('CGE_EIG_DIAG', '0')} T={T} d={d}: "
       f"{ms / n:.3f} ms per launch")

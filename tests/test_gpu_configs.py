@@ -129,26 +129,6 @@ def _run_config(ctx, name, check_host_flow=True):
     res_again = ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=42,
                           auc_samples=wl["samples"])
     assert np.array_equal(res, res_again)  # bitwise reproducible (fixed summation orders; unit weights)
-    assert ctx.get_stat("diameter_on_side_context") == 0
-    # The diameter's branch and bound is exact for any partition: on the side context (beside runsplit) it runs from the
-    # clusters cut into chunks instead of the landmarks -- the same bits; so do two half-batches per round on two streams,
-    # the rehearsal rule for the speculative splits, clamp + sample draws on the side thread, and the larger child's covariance
-    # derived from the parent's instead of summed over its rows.
-    for opts in ({"early_diameter": 1}, {"runsplit_lanes": 2}, {"speculation_pct": -1}, {"side_samples": 1}, {"cov_derive": 1}):
-        try:
-            for k, v in opts.items():
-                ctx.set_option(k, v)
-            res_alt = ctx.score(g["clusters"], wl["land"], wl["forced"], wl["method"], directed=directed, seed=42,
-                                auc_samples=wl["samples"])
-            assert ctx.get_stat("diameter_on_side_context") == opts.get("early_diameter", 0) and ctx.last_diameter()[0] == hi
-            assert np.array_equal(res, res_alt), opts
-            assert crc(ctx.landmarks_fetch()[6].astype(np.int32)) == crc(lm[6].astype(np.int32)), opts
-        finally:
-            ctx.set_option("early_diameter", 0)
-            ctx.set_option("runsplit_lanes", 1)
-            ctx.set_option("speculation_pct", 0)
-            ctx.set_option("side_samples", 0)
-            ctx.set_option("cov_derive", 0)
     if check_host_flow:
         # (2) the reference's call shape with the fixture's sample draws: the whole vector and every trace
         dii, lemb, lcomm, ledges, lw, lweight, v2l = lm
@@ -287,7 +267,7 @@ def test_d512_against_oracle_fixture(ctx, method, which):
     res2 = ctx.wgcl(ledges, lw, lcomm, lemb, dii, lweight, g["vweights"], v2l, None, None, None, False, auc_samples=10000,
                     samples=smp, use_resident_original=True)
     _check_sweep(res2, ctx.last_trace, fx, same_samples=True)
-    for opt, val, back in (("diameter_f32", 0, 2), ("diameter_f32", 1, 2), ("diameter", 1, 0), ("early_diameter", 1, 0)):  # fp64 / fp32 bound pass, brute force, side context
+    for opt, val, back in (("diameter_f32", 0, 2), ("diameter_f32", 1, 2), ("diameter", 1, 0)):  # fp64 / fp32 bound pass, brute force
         try:
             ctx.set_option(opt, val)
             assert np.array_equal(res, ctx.score(g["clusters"], land, forced, method, seed=42, auc_samples=10000))
@@ -301,9 +281,8 @@ def test_config5_full_size_ten_million_vertices():
     41 GB embedding generated in HBM and handed over as a device pointer (bench.py --workload cfg5).  No CPU oracle can run
     this (12 000 Jacobi problems at d = 512; 10^14 pair distances); its code paths are pinned by
     test_d512_against_oracle_fixture.  Here: the reference's invariants at full size, the landmark statistics of sampled
-    landmarks against numpy, and the diameter three ways -- found on the side context from the cluster-chunk partition,
-    found in line from the landmark partition (another context), and the CPU branch and bound on a 10^5-row sample that
-    contains the arg-max pair: the same bits."""
+    landmarks against numpy, and the diameter two ways -- from the landmark partition on the device, and by the CPU branch and
+    bound on a 10^5-row sample that contains the arg-max pair: the same bits; a second score in a fresh context: the same bits."""
     import torch
 
     import bench
@@ -328,17 +307,16 @@ def test_config5_full_size_ten_million_vertices():
         X[a:b] = centres[comm_dev[a:b]] + torch.randn(b - a, d, generator=gen, device=dev, dtype=torch.float64) * 0.5
     torch.cuda.synchronize()
 
-    def run(early):
+    def run(full):
         c = api.Context(0)
         try:
             c.set_graph(g["edges"], g["eweights"], n)
             c.set_embedding_device(X.data_ptr(), n, d, row_major=True)
             c.set_vertex_data(g["comm"], g["vweights"])
-            c.set_option("early_diameter", early)
             res = c.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000)
-            out = dict(res=res, tr=c.last_trace, hi=c.last_diameter(), side=c.get_stat("diameter_on_side_context"),
+            out = dict(res=res, tr=c.last_trace, hi=c.last_diameter(),
                        pair=(c.get_stat("diameter_arg_i"), c.get_stat("diameter_arg_j")))
-            if early:
+            if full:
                 out["again"] = c.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000)
                 out["lm"] = c.landmarks_fetch()
             return out
@@ -349,7 +327,7 @@ def test_config5_full_size_ten_million_vertices():
     r1 = run(1)
     res, tr = r1["res"], r1["tr"]
     hi, path, pairs, tiles = r1["hi"]
-    assert r1["side"] == 1 and path == "pruned" and np.array_equal(res, r1["again"])
+    assert path == "pruned" and np.array_equal(res, r1["again"])
     dii, lemb, lcomm, ledges, lw, lweight, v2l = r1["lm"]
     N = len(dii)
     assert N == land and v2l.min() == 1 and v2l.max() == N
@@ -378,9 +356,9 @@ def test_config5_full_size_ten_million_vertices():
     ref_hi, _, _, _ = exact_diameter(Xs, comm[rows])
     assert ref_hi == hi, (ref_hi, hi)
     del dii, lemb, lcomm, ledges, lw, lweight, r1
-    # in line, from the landmark partition, in a fresh context: the same diameter, the same score, bit for bit
+    # a fresh context: the same diameter, the same score, bit for bit
     r0 = run(0)
-    assert r0["side"] == 0 and r0["hi"][0] == hi and np.array_equal(r0["res"], res)
+    assert r0["hi"][0] == hi and np.array_equal(r0["res"], res)
 
 
 def test_config5_d512_twelve_thousand_landmarks(ctx):

@@ -137,26 +137,6 @@ def test_landmarks_duplicate_rows_ties(ctx, orc, method):
     _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
 
 
-@pytest.mark.parametrize("method", ["rss", "size"])
-def test_landmarks_independent_of_speculation(ctx, synth20k, method):
-    """How much of the split tree is expanded ahead of the heap is a tuning knob: the replay pops in the reference's
-    order whatever was precomputed, so landmark ids and everything derived from them must not move."""
-    import cge.jl_amd as cg
-
-    a = synth20k
-    args = (a["edges"], a["eweights"], a["vweights"], a["clusters"], a["comm"], a["embedding"], False, 300, 2, method, False)
-    out = {}
-    try:
-        for pct in (100, 40, 3):
-            ctx.set_option("speculation_pct", pct)
-            out[pct] = cg.landmarks(*args, ctx=ctx)
-    finally:
-        ctx.set_option("speculation_pct", 0)  # back to the default: by split rule
-    for pct in (40, 3):
-        for x, y in zip(out[100], out[pct]):
-            assert np.array_equal(x, y), pct
-
-
 @pytest.mark.parametrize("d", [2, 3, 5, 17, 32, 33, 64, 65, 100, 127, 128, 129, 200, 256, 333, 512])
 def test_group_eig_kernel(ctx, d):
     """The batched device eigen-solver (register-resident Householder tridiagonalisation, Sturm multisection,
@@ -301,16 +281,16 @@ def test_fit_persistent_kernel_matches_stepwise_and_oracle(ctx, orc, n):
     args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
     out = {}
     try:
-        # one launch per iteration / persistent: the data as its own signal / grid barriers / dependency counters
-        for mode in (1, 2, 3, 4):
-            ctx.set_option("fit_persistent", mode)
+        # one launch per iteration / persistent (the data as its own signal), twice
+        for mode in (1, 2, 3):
+            ctx.set_option("fit_persistent", min(mode, 2))
             out[mode] = cg.wGCL(*args, samples=smp, trace=True, ctx=ctx)
             assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode >= 2)
     finally:
         ctx.set_option("fit_persistent", 0)
-    (r1, t1), (r2, t2), (r3, t3), (r4, t4) = out[1], out[2], out[3], out[4]
-    assert t1["iters"] == t2["iters"] == t3["iters"] == t4["iters"]
-    assert np.array_equal(r2, r3) and np.array_equal(r2, r4)  # the persistent variants add in the same order
+    (r1, t1), (r2, t2), (r3, t3) = out[1], out[2], out[3]
+    assert t1["iters"] == t2["iters"] == t3["iters"]
+    assert np.array_equal(r2, r3)  # the persistent form is bitwise reproducible
     assert np.allclose(r1, r2, rtol=1e-11, atol=1e-13)
     assert np.allclose(t1["div"], t2["div"], rtol=1e-11, equal_nan=True)
     if n <= 700:
@@ -334,11 +314,11 @@ def test_fit_persistent_directed_matches_stepwise_and_oracle(ctx, orc, n):
     args = (g["edges"], g["eweights"], g["comm"], g["embedding"], np.zeros(n), g["vweights"], *empty, False)
     out = {}
     try:
-        for mode in (1, 2, 4):  # launch pair per iteration / persistent: the data as its own signal / dependency counters
-            ctx.set_option("fit_persistent", mode)
+        for mode in (1, 2, 4):  # launch pair per iteration / persistent (the data as its own signal), twice
+            ctx.set_option("fit_persistent", min(mode, 2))
             out[mode] = cg.wGCL_directed(*args, samples=smp, trace=True, ctx=ctx)
             assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode >= 2)
-        assert np.array_equal(out[2][0], out[4][0]) and out[2][1]["iters"] == out[4][1]["iters"]  # same additions, same order
+        assert np.array_equal(out[2][0], out[4][0]) and out[2][1]["iters"] == out[4][1]["iters"]  # bitwise reproducible
         ctx.set_option("fit_persistent", 2)
         ctx.set_option("fit_persistent_test_timeout", 1)  # abandoned launches: the iterates must be untouched
         out[3] = cg.wGCL_directed(*args, samples=smp, trace=True, ctx=ctx)
@@ -389,10 +369,6 @@ def test_fit_persistent_handoffs_under_varied_geometry(ctx):
             ctx.set_option("fit_persistent", 2)
             runs = [fn(*args, samples=smp, trace=True, ctx=ctx) for _ in range(3)]
             assert ctx.get_stat("fit_persistent_alphas") > 0
-            if True:  # the counter form of the same fit
-                ctx.set_option("fit_persistent", 4)
-                runs.append(fn(*args, samples=smp, trace=True, ctx=ctx))
-                assert ctx.get_stat("fit_persistent_alphas") > 0
         finally:
             ctx.set_option("fit_persistent", 0)
         for res, tr in runs:
@@ -519,15 +495,18 @@ def test_fit_persistent_kernel_headline_landmark_count(ctx):
     ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
     res = {}
     try:
-        for mode in (1, 2, 3, 4):
-            ctx.set_option("fit_persistent", mode)
+        for mode in (1, 2, 3):
+            ctx.set_option("fit_persistent", min(mode, 2))
+            ctx.set_option("fit_fused", 0 if mode == 3 else 1)  # 3: the persistent fit with the separate launches around it
             res[mode] = ctx.score(g["clusters"], 4000, 4, "rss", seed=3, auc_samples=5000)
             assert (ctx.get_stat("fit_persistent_alphas") > 0) == (mode >= 2)
+            assert (ctx.get_stat("fit_fused_alphas") > 0) == (mode == 2)
     finally:
         ctx.set_option("fit_persistent", 0)
+        ctx.set_option("fit_fused", 1)
     assert res[1][0] == res[2][0] and res[1][4] == res[2][4]
     assert np.allclose(res[1], res[2], rtol=1e-10, atol=1e-13)
-    assert np.array_equal(res[2], res[3]) and np.array_equal(res[2], res[4])
+    assert res[2][0] == res[3][0] and np.allclose(res[2], res[3], rtol=1e-10, atol=1e-13)
 
 
 @pytest.mark.parametrize("directed", [False, True])
@@ -1279,14 +1258,13 @@ def test_local_score_exact_ties_case_212(ctx, orc):
         assert res[5] == np.nanmin(a_got)  # (the patience counters may stop the two sweeps at different alphas after a flipped tie)
 
 
-@pytest.mark.parametrize("form,case", [(2, 4), (2, 6), (3, 4), (4, 6), (2, 5), (2, 7), (2, 12), (2, 13)])
+@pytest.mark.parametrize("form,case", [(2, 4), (2, 6), (2, 8), (2, 10), (2, 5), (2, 7), (2, 12), (2, 13)])
 def test_randomised_exact_mode_sweep_under_start_skew(ctx, orc, form, case):
     """The start-skew class of bug (`done` / `fail` words tested against zero -- a fit that waited more than 64
     polls ended "converged" with the iterate of that moment) had ONE tripwire, and iteration-count equality with the oracle only
     fires under a slow schedule.  Here cases of the randomised exact-mode sweep below -- against the ORACLE -- run with the tile
     waves of the persistent fits napping before their first load (option fit_persistent_test_delay), for every persistent
-    form of the fit: data-as-signal (2), grid barriers (3), dependency counters (4) undirected (even cases), and the directed
-    persistent form (odd cases)"""
+    fit: undirected (even cases) and directed (odd cases)"""
     try:
         ctx.set_option("fit_persistent", form)
         ctx.set_option("fit_persistent_test_delay", 25)
@@ -1423,29 +1401,6 @@ def test_persistent_fit_survives_start_skew(ctx, directed):
     finally:
         ctx.set_option("fit_persistent_test_delay", 0)
         ctx.set_option("fit_persistent", 0)
-
-
-@pytest.mark.parametrize("method", ["rss", "diameter", "rss2", "size"])
-def test_two_lanes_with_late_member_lists(ctx, method):
-    """runsplit_lanes = 2: the half batches of a round run on two streams and the next round deals the groups afresh, so a
-    lane reads member lists the OTHER lane wrote -- behind the event the host waits for.  With the second lane's lists held
-    back (option runsplit_lanes_test_delay: ~2 / 8 ms, and the arena wiped first) the result is still the one-lane result."""
-    from cge.jl_amd import synth
-
-    g = synth.abcd_like(60000, 600000, 40, 16, seed=5)
-    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
-    try:
-        ref = ctx.score(g["clusters"], 3000, 4, method, seed=3, auc_samples=2000).copy()
-        lm_ref = ctx.landmarks_fetch()[6].copy()
-        ctx.set_option("runsplit_lanes", 2)
-        for delay in (500, 0, 2000):  # (> 0 also wipes what the previous run left in the member arena)
-            ctx.set_option("runsplit_lanes_test_delay", delay)
-            got = ctx.score(g["clusters"], 3000, 4, method, seed=3, auc_samples=2000)
-            assert np.array_equal(got, ref), (method, delay)
-            assert np.array_equal(ctx.landmarks_fetch()[6], lm_ref), (method, delay)
-    finally:
-        ctx.set_option("runsplit_lanes_test_delay", 0)
-        ctx.set_option("runsplit_lanes", 1)
 
 
 def _fused_case(seed=21, n=30000, C=24, d=24):
