@@ -1053,17 +1053,12 @@ static bool flow_geometry(i64 N, i64 Tld, int *G_out, int *NW_out, int *tpw_out)
     HIP_CHECK(hipGetDevice(&dev));
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (cus <= 0 || Tld < (i64)Nt * 64) return false;
-    // one tile per wave when 4 or 8 waves per CU cover the triangle, else two tiles on each of 4 waves
-    const int nw = (NT <= (i64)4 * cus) ? 4 : 8;
-    const int G = (int)std::min<i64>(cus, std::max<i64>((NT + nw - 1) / nw, (i64)4 * Nt));
-    int tpw = (int)((NT + (i64)nw * G - 1) / ((i64)nw * G));
-    int NW = nw;
-    if (tpw > 1) { // 8 waves cannot hold two tiles each
-        NW = 4;
-        tpw = (int)((NT + (i64)4 * G - 1) / ((i64)4 * G));
-    }
-    // three tiles per wave: the counter form keeps the matrix without spills; a workgroup reduces at most two quarter blocks
-    if (tpw > 2 || Nt > 64 || 4 * Nt > 2 * G) return false; // (a reducer adds up to 64 partial vectors)
+    // one tile per wave: 4 waves per CU while they cover the triangle, else 8 (two per SIMD, 256 registers apiece).  Eight
+    // tiles per CU is what the register file holds: N <= 4032 on 256 CUs (two tiles on each of four waves hold no more).
+    const int NW = (NT <= (i64)4 * cus) ? 4 : 8;
+    const int G = (int)std::min<i64>(cus, std::max<i64>((NT + NW - 1) / NW, (i64)4 * Nt));
+    const int tpw = (int)((NT + (i64)NW * G - 1) / ((i64)NW * G));
+    if (tpw > 1 || Nt > 64 || 4 * Nt > 2 * G) return false; // (a reducer adds up to 64 partial vectors, a workgroup reduces at most two quarter blocks)
     *G_out = G; *NW_out = NW; *tpw_out = tpw;
     return true;
 }
@@ -1090,8 +1085,7 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
     c->fp_flow.ensure(n_sync + n_ring + n_fq + 2 * psz);
     const bool one = 4 * Nt <= G; // every workgroup reduces at most one quarter block
     const void *fn;
-#define FLOW_PICK(F, B) (NW == 8 ? (const void *)fit_flow_kernel<1, 8, F, B> \
-                                 : (tpw == 1 ? (const void *)fit_flow_kernel<1, 4, F, B> : (const void *)fit_flow_kernel<2, 4, F, B>))
+#define FLOW_PICK(F, B) (NW == 8 ? (const void *)fit_flow_kernel<1, 8, F, B> : (const void *)fit_flow_kernel<1, 4, F, B>)
     if (fused) fn = NW == 8 ? (const void *)fit_flow_kernel<1, 8, true, 1> : (const void *)fit_flow_kernel<1, 4, true, 1>;
     else fn = one ? FLOW_PICK(false, 1) : FLOW_PICK(false, 2);
 #undef FLOW_PICK

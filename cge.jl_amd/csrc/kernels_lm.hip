@@ -2540,6 +2540,14 @@ __device__ __forceinline__ double transpose_reduce4(const double (&v)[4], int la
 #endif
 constexpr int EWP_NB = 8, EWP_T = 512;
 constexpr int EWP_SCR = 16 * 16 * 32; // partial vectors of the 32 x 32 tile sweep: [row block][other block][32]
+// The workgroup's barrier of the panel solver: its waves hand each other data through GLOBAL memory (the matrix, the partial
+// vectors of the tile sweep), and the compiler's barrier waits for LDS traffic only -- it relies on the CU's memory pipeline
+// keeping one wave's store ahead of another wave's later load.  Round 4 saw exactly that assumption fail for LDS
+// (group_eig_kernel); here the store queue is drained explicitly (tests/test_device_asm.py scans for it).
+__device__ __forceinline__ void panel_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 __device__ __forceinline__ double block_sum_512(double v, double *red8) {
     v = wave_allsum(v);
     __syncthreads();
@@ -2563,7 +2571,7 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
     double *Pt = scratch + (size_t)blockIdx.x * EWP_SCR;
     const int rq = lane >> 3, cq = lane & 7;
     for (int i = tid; i < 2 * EWP_NB * d; i += EWP_T) Vp[i] = 0.0;
-    __syncthreads();
+    panel_sync();
     int q = 0;
     for (int k = 0; k + 2 < d; k++) {
         const int o = k + 1;
@@ -2603,7 +2611,7 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
                     if (lane == 0) { wpart[wv * 2 * EWP_NB + 2 * s] = g; wpart[wv * 2 * EWP_NB + 2 * s + 1] = h; }
                 }
             }
-            __syncthreads();
+            panel_sync();
             if (tid < 2 * q) {
                 double t = wpart[tid];
                 for (int w2 = 1; w2 < 8; w2++) t += wpart[w2 * 2 * EWP_NB + tid];
@@ -2659,7 +2667,7 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
                     if (rq < 4) Pt[(J * Gb + I) * 32 + 4 * cq + rq] = csum;
                 }
             }
-            __syncthreads();
+            panel_sync();
             double pi = 0.0;
             if (tid >= o && tid < d) {
                 const int bi = (tid - jb) >> 5, li = (tid - jb) & 31;
@@ -2675,7 +2683,7 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
             if (tid < d) Wp[q * d + tid] = (tid >= o) ? pi - K * vi : 0.0;
         }
         q++;
-        __syncthreads();
+        panel_sync();
         if (q == EWP_NB || k + 3 >= d) { // close the panel: the stored trailing block catches up
             if (active) {
                 double vj[EWP_NB], wj[EWP_NB];
@@ -2703,13 +2711,13 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
                     col[i * d] = a;
                 }
             }
-            __syncthreads();
+            panel_sync();
             for (int i = tid; i < 2 * EWP_NB * d; i += EWP_T) Vp[i] = 0.0;
             q = 0;
-            __syncthreads();
+            panel_sync();
         }
     }
-    __syncthreads();
+    panel_sync();
     // the tridiagonal matrix -> LDS (the panel storage is free now)
     double *diag = sh, *off = diag + d, *beta = off + d, *tri = beta + d; // tri: 4 d
     unsigned char *swp = reinterpret_cast<unsigned char *>(tri + 4 * d);
@@ -2718,7 +2726,7 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
         off[i] = (i + 2 < d) ? A[(i + 2) * d + i] : ((i == d - 2) ? A[(i + 1) * d + i] : 0.0); // the element below the diagonal
         beta[i] = (i + 2 < d) ? A[(i + 1) * d + i] : 0.0;
     }
-    __syncthreads();
+    panel_sync();
     // ---- Gershgorin bounds ---------------------------------------------------------------------------
     double glo = 1e300, ghi = -1e300, gn = 0.0;
     for (int i = tid; i < d; i += EWP_T) {
@@ -2733,7 +2741,7 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
         gn = fmax(gn, __shfl_xor(gn, o2));
     }
     if (lane == 0) { misc[wv * 3] = glo; misc[wv * 3 + 1] = ghi; misc[wv * 3 + 2] = gn; }
-    __syncthreads();
+    panel_sync();
     for (int w2 = 0; w2 < 8; w2++) {
         glo = fmin(glo, misc[w2 * 3]);
         ghi = fmax(ghi, misc[w2 * 3 + 1]);
@@ -2769,7 +2777,7 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
         }
         if (tid == 0) red[4] = 0.5 * (lo + hi);
     }
-    __syncthreads();
+    panel_sync();
     // ---- inverse iteration (lane 0 of wave 0 runs the recurrences, the wave the element-wise parts) -----------------
     if (wv == 0) {
         const double lam = red[4];
@@ -2849,7 +2857,7 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
             __builtin_amdgcn_wave_barrier();
         }
     }
-    __syncthreads();
+    panel_sync();
     // ---- back-transformation x = H_0 H_1 ... H_{d-3} y (thread t owns component t) ---------------------------------
     {
         double yt = (tid < d) ? v[tid] : 0.0;
@@ -2863,9 +2871,9 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
             const double sc = bk * block_sum_512(vk * yt, red);
             yt -= sc * vk;
         }
-        __syncthreads();
+        panel_sync();
         if (tid < d) v[tid] = yt;
-        __syncthreads();
+        panel_sync();
     }
     // normalise; sign: the component of largest magnitude (the first one on ties) is positive
     double part = 0.0, best = -1.0;
@@ -2882,9 +2890,9 @@ __global__ __launch_bounds__(EWP_T, EWP_OCC) void group_eig_panel_kernel(double 
         const int oi = __shfl_xor(bi, o2);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    __syncthreads();
+    panel_sync();
     if (lane == 0) { misc[2 * wv] = best; misc[2 * wv + 1] = (double)bi; }
-    __syncthreads();
+    panel_sync();
     best = misc[0];
     bi = (int)misc[1];
     for (int w2 = 1; w2 < 8; w2++) {

@@ -2,13 +2,24 @@
 STORE still in flight (no `s_waitcnt lgkmcnt(0)` between the ds_write and the barrier on some path).  The compiler leaves the
 wait out in places (it treats the LDS as in-order for a workgroup); on gfx950 a store issued right in front of the barrier by
 one wave was seen to lose against the loads the other waves issue right behind it (group_eig_kernel, round 4).
+Round 5: the same walk for GLOBAL stores (kind="vmem": global_store / buffer_store / scratch_store / global_atomic reaching an
+s_barrier without `s_waitcnt vmcnt(0)`) -- the same hazard where a workgroup shares global scratch across a barrier (the
+panel eigen-solver keeps its matrix in global memory).  Most kernels store results and then meet a barrier for unrelated
+reasons, so this mode is meant for a list of kernels (`only`: substrings of the mangled names).
 Usage: python3 profiles/scan_barrier_waits.py file.s [...]   -- prints kernel, line number of each such barrier."""
 import re, sys
 
-def scan(path):
+def scan(path, kind="lds", only=None):
     kern, body, out = None, [], []
+    if kind == "lds":
+        is_store = lambda ins: ins.startswith(('ds_write', 'ds_add', 'ds_max', 'ds_min', 'ds_or'))
+        drained = lambda t: 'lgkmcnt(0)' in t
+    else:
+        is_store = lambda ins: ins.startswith(('global_store', 'buffer_store', 'scratch_store', 'global_atomic', 'buffer_atomic', 'flat_store', 'flat_atomic'))
+        drained = lambda t: 'vmcnt(0)' in t
     def flush():
         if kern is None or not body: return
+        if only is not None and not any(o in kern for o in only): return
         labels = {t[:-1]: i for i, (t, _) in enumerate(body) if re.match(r'^\.LBB\d+_\d+:$', t)}
         state_in = {}  # label index -> pending flag on entry (OR over predecessors)
         changed = True
@@ -23,9 +34,9 @@ def scan(path):
                     fall = True
                     continue
                 ins = t.split()[0]
-                if ins.startswith('ds_write') or ins.startswith('ds_add') or ins.startswith('ds_max') or ins.startswith('ds_min') or ins.startswith('ds_or'):
+                if is_store(ins):
                     pend = True
-                elif ins == 's_waitcnt' and 'lgkmcnt(0)' in t:
+                elif ins == 's_waitcnt' and drained(t):
                     pend = False
                 elif ins == 's_barrier':
                     if pend: hits.add(ln)

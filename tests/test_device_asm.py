@@ -19,6 +19,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx9
          "--cuda-device-only", "-S"]  # the Makefile's flags
 
 
+# kernels in which the waves of ONE workgroup hand data to each other through global memory, separated by s_barrier (the
+# panel eigen-solver keeps its 2 MB matrix and the partial vectors of its tile sweep there)
+GLOBAL_SHARING = ("group_eig_panel_kernel",)
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_no_barrier_with_an_lds_store_in_flight(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "profiles"))
@@ -37,14 +42,21 @@ def test_no_barrier_with_an_lds_store_in_flight(tmp_path):
 
     with ThreadPoolExecutor(max_workers=min(8, len(sources))) as ex:
         outs = list(ex.map(compile_one, sources))
-    hits = []
+    hits, vhits = [], []
     n_barriers = 0
+    seen_shared = set()
     for path in outs:
-        n_barriers += open(path).read().count("s_barrier")
+        text = open(path).read()
+        n_barriers += text.count("s_barrier")
         hits += [(os.path.basename(path), kern, line) for kern, line in sbw.scan(path) if "rocprim" not in kern]
+        # kernels whose workgroup shares GLOBAL memory across its barriers: a store must have left (vmcnt(0)) before the barrier
+        vhits += [(os.path.basename(path), kern, line) for kern, line in sbw.scan(path, kind="vmem", only=GLOBAL_SHARING)]
+        seen_shared |= {k for k in GLOBAL_SHARING if k in text}
     shutil.rmtree(tmp_path, ignore_errors=True)
     assert n_barriers > 100  # the scan saw the kernels
     assert not hits, f"barriers reachable with an LDS store in flight: {hits}"
+    assert seen_shared == set(GLOBAL_SHARING), "a kernel of the list was renamed: update GLOBAL_SHARING"
+    assert not vhits, f"barriers reachable with a global store in flight, in kernels that share global scratch inside a workgroup: {vhits}"
 
 
 def test_the_scan_flags_a_missing_wait(tmp_path):
@@ -71,3 +83,10 @@ _Z3badv:
     open(good, "w").write(open(bad).read().replace(".LBB0_3:\n", ".LBB0_3:\n\ts_waitcnt lgkmcnt(0)\n"))
     assert [k for k, _ in sbw.scan(bad)] == ["_Z3badv"]
     assert sbw.scan(good) == []
+    # the global-store mode: the same shape with a global store and vmcnt(0); kernels outside the list are not looked at
+    vbad = os.path.join(tmp_path, "vbad.s")
+    open(vbad, "w").write(open(bad).read().replace("ds_write_b64 v1, v[2:3]", "global_store_dwordx2 v[4:5], v[2:3], off"))
+    vgood = os.path.join(tmp_path, "vgood.s")
+    open(vgood, "w").write(open(vbad).read().replace(".LBB0_3:\n", ".LBB0_3:\n\ts_waitcnt vmcnt(0)\n"))
+    assert sbw.scan(vbad) == [] and [k for k, _ in sbw.scan(vbad, kind="vmem")] == ["_Z3badv"]
+    assert sbw.scan(vbad, kind="vmem", only=("other_kernel",)) == [] and sbw.scan(vgood, kind="vmem") == []
