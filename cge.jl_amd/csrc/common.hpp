@@ -356,6 +356,7 @@ struct cge_ctx {
                                          // (relabelled only beyond 8192 vertices)
     DevBuf<i32> sw_bt_fc, sw_bt_ns, sw_bt_base; // per 64-vertex block: first community, communities; per tile: base of its partials
     DevBuf<double> sw_bt_part;
+    DevBuf<i32> sw_bt_desc;             // per community-pair bin: the positions of (up to four of) its tile partials (k_bins_prepare)
     DevBuf<double> sw_fused_pw;          // ... and the two powers per sample its prologue writes for its epilogue
     DevBuf<char> sw_fused_epi;           // the fused chain's tables, one cge_fit_fused per sample set (wgcl_host.cpp)
     int opt_fit_fused = 1;               // 1 (default): landmark-mode sweeps let the rest of an alpha's chain ride on the fit's launch
@@ -713,6 +714,7 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
                         const cge_fit_fused *ff_dev = nullptr); // ff_dev: the device copy of *ff the epilogue reads (alpha, partial and
                                                                 // auc_part are taken from *ff: they change per alpha)
 bool k_fit_flow_fused_applies(cge_ctx *c, i64 N); // the geometry the fused instances exist for (one tile per wave, one quarter block per workgroup)
+void k_bins_prepare(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, i64 n_partials); // once per sweep, behind the tile tables
 void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, double *vectB, int n_modes, double *fpart);
 void k_bvec_tiles(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_off, i64 N, int directed); // the tile partials only
 void k_auc_prepare(cge_ctx *c, const i32 *v2l, const i32 *old2new, const double *vw_orig, const double *lweight, const i32 *pi,

@@ -620,38 +620,94 @@ __global__ void js_final_kernel(const double *__restrict__ fpart, double *__rest
 // (monotonic over the launches of a context: `target` = JS_BLOCKS x launches so far) separates the phases; a block that waits
 // too long gives up and publishes NaN (the sweep then fails its checks loudly instead of hanging).  Phase 2: js_terms_kernel.
 // n_modes = 1: all bins; 2: internal then external bins (--split-global).
+// (ca, cb), ca <= cb, of the packed index k: row ca of the packed triangle starts at off(ca) = C ca - ca (ca - 1) / 2
+__device__ __forceinline__ void packed_pair(i64 k, i64 C, i64 &ca, i64 &cb) {
+    const double bq = 2.0 * (double)C + 1.0;
+    ca = (i64)((bq - sqrt(bq * bq - 8.0 * (double)k)) * 0.5);
+    if (ca < 0) ca = 0;
+    if (ca > C - 1) ca = C - 1;
+    while (ca > 0 && C * ca - ca * (ca - 1) / 2 > k) ca--;
+    while (ca + 1 < C && C * (ca + 1) - (ca + 1) * ca / 2 <= k) ca++;
+    cb = ca + (k - (C * ca - ca * (ca - 1) / 2));
+}
+// Once per sweep: where the partials of bin k sit.  A community pair's rectangle touches one tile, two or four (a community of
+// more than 64 landmarks: more) -- desc[k] = the positions in `partial` of up to four of them, in the order bvec_bins_kernel adds
+// them (I ascending, then J), unused slots = `zero_slot` (a position that holds +0.0: adding it leaves the sum's bits alone);
+// .w = -2: more than four tiles, the per-alpha kernel walks them as bvec_bins_kernel does.  The per-alpha kernel then needs two
+// loads in a row per bin instead of a chain of five.
+__global__ __launch_bounds__(256) void bins_desc_kernel(const i32 *__restrict__ cm_off, const i32 *__restrict__ fc,
+                                                        const i32 *__restrict__ ns, const i32 *__restrict__ base, i64 C, int Nt,
+                                                        i32 zero_slot, int4 *__restrict__ desc) {
+    const i64 len = C * (C + 1) / 2;
+    const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (k >= len) return;
+    i64 ca, cb;
+    packed_pair(k, C, ca, cb);
+    const i32 a0 = cm_off[ca], a1 = cm_off[ca + 1], b0 = cm_off[cb], b1 = cm_off[cb + 1];
+    i32 slot[4] = {zero_slot, zero_slot, zero_slot, zero_slot};
+    int cnt = 0;
+    if (a1 > a0 && b1 > b0)
+        for (int I = a0 >> 6; I <= (a1 - 1) >> 6; I++)
+            for (int J = b0 >> 6; J <= (b1 - 1) >> 6; J++) {
+                if (J < I) continue; // (the mirrored part of a diagonal bin: the reference sums j >= i only)
+                if (cnt < 4) slot[cnt] = base[I * Nt + J] + (i32)(ca - fc[I]) * ns[J] + (i32)(cb - fc[J]);
+                cnt++;
+            }
+    desc[k] = make_int4(slot[0], slot[1], slot[2], cnt > 4 ? -2 : slot[3]);
+}
 __global__ __launch_bounds__(256) void bins_js_kernel(const double *__restrict__ partial, const i32 *__restrict__ cm_off,
                                                       const i32 *__restrict__ fc, const i32 *__restrict__ ns,
                                                       const i32 *__restrict__ base, i64 C, int Nt, const double *__restrict__ vC,
                                                       double *__restrict__ vectB, int n_modes, double *__restrict__ part,
-                                                      unsigned *counter, unsigned target, double *__restrict__ fpart) {
+                                                      unsigned *counter, unsigned target, double *__restrict__ fpart,
+                                                      const int4 *__restrict__ desc) {
     __shared__ double sh[256];
     __shared__ int ok_sh;
     const i64 len = C * (C + 1) / 2;
     const int first_mode = n_modes == 1 ? 0 : 1;
     double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0}, cnt[2] = {0.0, 0.0};
-    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < len; k += (i64)JS_BLOCKS * 256) {
-        // packed index -> (ca, cb), ca <= cb: row ca starts at off(ca) = C ca - ca (ca - 1) / 2
-        const double bq = 2.0 * (double)C + 1.0;
-        i64 ca = (i64)((bq - sqrt(bq * bq - 8.0 * (double)k)) * 0.5);
-        if (ca < 0) ca = 0;
-        if (ca > C - 1) ca = C - 1;
-        while (ca > 0 && C * ca - ca * (ca - 1) / 2 > k) ca--;
-        while (ca + 1 < C && C * (ca + 1) - (ca + 1) * ca / 2 <= k) ca++;
-        const i64 cb = ca + (k - (C * ca - ca * (ca - 1) / 2));
-        const i32 a0 = cm_off[ca], a1 = cm_off[ca + 1], b0 = cm_off[cb], b1 = cm_off[cb + 1];
-        double acc = 0.0;
-        if (a1 > a0 && b1 > b0)
-            for (int I = a0 >> 6; I <= (a1 - 1) >> 6; I++)
-                for (int J = b0 >> 6; J <= (b1 - 1) >> 6; J++) {
-                    if (J < I) continue; // (the mirrored part of a diagonal bin: the reference sums j >= i only)
-                    acc = __dadd_rn(acc, partial[(i64)base[I * Nt + J] + (i64)(ca - fc[I]) * ns[J] + (cb - fc[J])]);
-                }
-        vectB[k] = acc;
-        const double c_k = vC[k];
-        for (int m = 0; m < n_modes; m++) {
-            const int mode = first_mode + m;
-            if (mode == 0 || (mode == 1) == (ca == cb)) { s1[m] += c_k; s2[m] += acc; cnt[m] += 1.0; }
+    // phase 1, eight bins at a time: all descriptors first, then all partials (a bin is two loads in a row, and the eight are
+    // independent), then the sums in the order of the one-bin-at-a-time loop
+    for (i64 k0 = (i64)blockIdx.x * 256 + threadIdx.x; k0 < len; k0 += (i64)8 * JS_BLOCKS * 256) {
+        int4 dsc[8];
+        double c_k[8], pv[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const i64 k = k0 + (i64)u * JS_BLOCKS * 256;
+            dsc[u] = k < len ? desc[k] : make_int4(0, 0, 0, 0);
+            c_k[u] = k < len ? vC[k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool far = dsc[u].w == -2;
+            pv[u][0] = partial[dsc[u].x]; pv[u][1] = partial[dsc[u].y]; pv[u][2] = partial[dsc[u].z];
+            pv[u][3] = far ? 0.0 : partial[dsc[u].w];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const i64 k = k0 + (i64)u * JS_BLOCKS * 256;
+            if (k >= len) break;
+            double acc;
+            i64 ca = 0, cb = 1;
+            if (dsc[u].w != -2)
+                acc = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(0.0, pv[u][0]), pv[u][1]), pv[u][2]), pv[u][3]);
+            else { // a rectangle over more than four tiles (communities of more than 64 landmarks): bvec_bins_kernel's walk
+                packed_pair(k, C, ca, cb);
+                const i32 a0 = cm_off[ca], a1 = cm_off[ca + 1], b0 = cm_off[cb], b1 = cm_off[cb + 1];
+                acc = 0.0;
+                for (int I = a0 >> 6; I <= (a1 - 1) >> 6; I++)
+                    for (int J = b0 >> 6; J <= (b1 - 1) >> 6; J++) {
+                        if (J < I) continue;
+                        acc = __dadd_rn(acc, partial[(i64)base[I * Nt + J] + (i64)(ca - fc[I]) * ns[J] + (cb - fc[J])]);
+                    }
+            }
+            vectB[k] = acc;
+            if (n_modes == 1) { s1[0] += c_k[u]; s2[0] += acc; cnt[0] += 1.0; }
+            else {
+                const bool diag = js_selected(k, C, 0, 1);
+                const int m = diag ? 0 : 1; // modes 1 (internal) and 2 (external) partition the bins
+                s1[m] += c_k[u]; s2[m] += acc; cnt[m] += 1.0;
+            }
         }
     }
     for (int m = 0; m < n_modes; m++) {
@@ -679,14 +735,20 @@ __global__ __launch_bounds__(256) void bins_js_kernel(const double *__restrict__
     }
     __syncthreads();
     const bool ok = ok_sh != 0;
+    // the blocks' sums: fetched ONCE per workgroup (one L2-bypassing load per value; every thread fetching all of them was
+    // 3 million requests to a dozen cache lines), then added by every thread in block order from LDS
+    __shared__ double tot_sh[2 * 3 * JS_BLOCKS];
+    for (int i = threadIdx.x; i < n_modes * 3 * JS_BLOCKS; i += 256)
+        tot_sh[i] = __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     for (int m = 0; m < n_modes; m++) {
         const int mode = first_mode + m;
         double t1 = 0.0, t2 = 0.0, tc = 0.0;
-        const double *pm = part + (i64)m * 3 * JS_BLOCKS;
+        const double *pm = tot_sh + m * 3 * JS_BLOCKS;
         for (int b = 0; b < JS_BLOCKS; b++) {
-            t1 += __hip_atomic_load(pm + 3 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t2 += __hip_atomic_load(pm + 3 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tc += __hip_atomic_load(pm + 3 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t1 += pm[3 * b];
+            t2 += pm[3 * b + 1];
+            tc += pm[3 * b + 2];
         }
         const double sp1 = t1 + tc, sp2 = t2 + tc;
         double f = 0.0;
@@ -713,7 +775,17 @@ void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, do
     c->js_launches++;
     hipLaunchKernelGGL(bins_js_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, c->sw_bt_part.p, cm_off, c->sw_bt_fc.p,
                        c->sw_bt_ns.p, c->sw_bt_base.p, C, Nt, vC, vectB, n_modes, c->js_part.p, c->js_counter.p,
-                       (unsigned)(c->js_launches * JS_BLOCKS), fpart);
+                       (unsigned)(c->js_launches * JS_BLOCKS), fpart, reinterpret_cast<const int4 *>(c->sw_bt_desc.p));
+}
+// once per sweep, after the tile tables are up: the bins' descriptors (positions of their partials) and the +0.0 slot behind
+// the partials that unused descriptor entries point to
+void k_bins_prepare(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, i64 n_partials) {
+    const int Nt = (int)((N + 63) / 64);
+    const i64 len = C * (C + 1) / 2;
+    c->sw_bt_desc.ensure((size_t)4 * len);
+    HIP_CHECK(hipMemsetAsync(c->sw_bt_part.p + n_partials, 0, sizeof(double), c->stream));
+    hipLaunchKernelGGL(bins_desc_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, cm_off, c->sw_bt_fc.p, c->sw_bt_ns.p,
+                       c->sw_bt_base.p, C, Nt, (i32)n_partials, reinterpret_cast<int4 *>(c->sw_bt_desc.p));
 }
 // `partials` != nullptr: the CGE_PARTIAL_BLOCKS block sums of the divergence terms go there and the caller adds them (in
 // block order, then / 2: what js_final_kernel does) -- the sweep does that on the host, behind the copy it makes anyway

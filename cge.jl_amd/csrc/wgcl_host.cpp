@@ -165,6 +165,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     const bool blocks = blocks_req || tiles_req;
     bool blocks_ok = blocks, pieces_ok = true;
     std::vector<i32> bt_fc, bt_ns, bt_base;
+    i64 bt_total = 0; // tile partials in all
     if (blocks) { // per 64-vertex block of the relabelled graph: first community and number of communities; per tile: its partials
         const i64 Nt = (N + 63) / 64;
         std::vector<i32> comm_new(N);
@@ -191,8 +192,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                 if (directed || J >= I) tot += (i64)bt_ns[I] * bt_ns[J];
                 if (tot > (i64)1 << 30) blocks_ok = false;
             }
+        bt_total = tot;
         if (blocks_ok) {
-            c->sw_bt_fc.ensure(Nt); c->sw_bt_ns.ensure(Nt); c->sw_bt_base.ensure(Nt * Nt + 1); c->sw_bt_part.ensure(std::max<i64>(tot, 1));
+            c->sw_bt_fc.ensure(Nt); c->sw_bt_ns.ensure(Nt); c->sw_bt_base.ensure(Nt * Nt + 1); c->sw_bt_part.ensure(std::max<i64>(tot, 1) + 1); // (+ the +0.0 slot of k_bins_prepare)
             HIP_CHECK(hipMemcpyAsync(c->sw_bt_fc.p, bt_fc.data(), sizeof(i32) * Nt, hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(c->sw_bt_ns.p, bt_ns.data(), sizeof(i32) * Nt, hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(c->sw_bt_base.p, bt_base.data(), sizeof(i32) * Nt * Nt, hipMemcpyHostToDevice, st));
@@ -241,6 +243,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     for (i64 q = 0; q < N; q++) cm_pos[cm_mem[q]] = (i32)q;
     c->sw_cm_pos.ensure(N);
     HIP_CHECK(hipMemcpyAsync(c->sw_cm_pos.p, cm_pos.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+    if (c->bvec_blocks && !directed) k_bins_prepare(c, d_cm_off.p, N, C, bt_total); // where every bin's tile partials sit
 
     // T (:118) / Tin,Tout (:399-402)
     std::vector<double> hT1(N, 1.0), hT2(N, 1.0);
