@@ -498,9 +498,11 @@ def main():
         "fit_symv": ("hbm", HBM_PEAK_GBS, "GB/s", 8.0 * N * (N + 1) / 2,
                      "8 B per unordered landmark pair per Chung-Lu iteration"),
         "fit_persistent": ("hbm", HBM_PEAK_GBS, "GB/s", None,
-                           "one launch = the whole Chung-Lu fit of one alpha with the matrix REGISTER-RESIDENT; algorithmic bytes "
-                           "= what that algorithm has to move through memory: one read of the upper triangle of GD (8 B per "
-                           "unordered landmark pair) + per iteration the partial vectors written and read once (2 x Nt^2 x 64 "
+                           "one launch = the whole Chung-Lu fit of one alpha with the matrix REGISTER-RESIDENT -- and, round 5, the "
+                           "rest of the alpha's chain (power matrix in the prologue, vect_B tile sums and local-score tallies in "
+                           "the epilogue: fit_flow_kernel<.., true>); algorithmic bytes = what that algorithm has to move through "
+                           "memory: one read of the upper triangle of log2(1 - D) (a double and a float: 12 B per unordered "
+                           "landmark pair; 8 B of GD where the chain is not fused) + per iteration the partial vectors written and read once (2 x Nt^2 x 64 "
                            "doubles), the iterate read by every tile (Nt(Nt+1)/2 x 128 doubles) and written once. The kernel "
                            "is latency-bound (two cross-workgroup hand-offs per iteration, DESIGN.md section 4), hence the low "
                            "fraction; `streaming_equivalent_gbs` = what a launch-per-iteration SYMV (SURVEY 8d(5): 8 B per "
@@ -559,7 +561,8 @@ def main():
                 its = ctx.get_stat("fit_iterations") / max(1, l_ / steps_prof)
                 Nt = (N + 63) // 64
                 per_iter = 8.0 * (2 * Nt * Nt * 64 + Nt * (Nt + 1) // 2 * 128 + N) * (2 if directed else 1)
-                w = 8.0 * N * (N + 1) / 2 + its * per_iter
+                # (the fused launch reads the stored logarithm, a double and a float per pair, instead of the power matrix)
+                w = (12.0 if ctx.get_stat("fit_fused_alphas") > 0 else 8.0) * N * (N + 1) / 2 + its * per_iter
                 ent["iterations_per_launch"] = its
                 ent["streaming_equivalent_gbs"] = 8.0 * N * (N + 1) / 2 * its / (ms_ * 1e-3) / 1e9
             if name == "pcent_bf16":
@@ -648,12 +651,6 @@ def main():
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "edge-alpha evals/s", "cores": 1, "kind": "port",
                                    "sample": f"failed: {e!r}"}
-    if world == 1 and not dev_emb:
-        # `upload_s` above is the FIRST upload of the process (it also pays the one-off device allocations); a second graph of
-        # the same size on the warm context pays the copies alone -- reported beside it, never instead of it
-        t_upload_warm = upload()
-        out["upload_warm_s"] = t_upload_warm
-        out["value_incl_h2d_warm"] = g["m"] * A / (sec_per_step + t_upload_warm)
     ctx.close()  # tear the context down before interpreter exit (profilers finalise their HIP hooks at exit)
     # The other single-GPU configurations of BASELINE.json on the same clock.  LAST key of the line: the driver keeps the
     # line's tail.  Headline `value` / `config` / `roofline` above are untouched by it.
@@ -661,8 +658,7 @@ def main():
         del g
         torch.cuda.empty_cache()
         other = {"headline": {"ms_per_step": round(sec_per_step * 1e3, 4), "steps": args.steps, "value": value,
-                              "value_incl_h2d": out["value_incl_h2d"], "upload_s": round(t_upload, 4),
-                              "value_incl_h2d_warm": out.get("value_incl_h2d_warm"), "upload_warm_s": out.get("upload_warm_s")}}
+                              "value_incl_h2d": out["value_incl_h2d"], "upload_s": round(t_upload, 4)}}
         for name, st, wu in (("cfg2", 10, 2), ("cfg3", 10, 2), ("cfg4", 10, 2), ("cfg5_200k", 3, 1), ("cfg5", 3, 1)):
             used = time.perf_counter() - t_start
             if used > args.other_budget_s:

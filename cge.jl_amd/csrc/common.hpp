@@ -355,6 +355,7 @@ struct cge_ctx {
                                          // tiles (measured slower: profiles/r04_bvec_tiles_ab.txt); 0 (default): the row-bin form
                                          // (relabelled only beyond 8192 vertices)
     DevBuf<i32> sw_bt_fc, sw_bt_ns, sw_bt_base; // per 64-vertex block: first community, communities; per tile: base of its partials
+    i64 flow_armed_words = 0;            // > 0: the persistent fit's hand-off slots (that many 4-byte words) are armed by the previous alpha's last launch
     DevBuf<double> sw_bt_part;
     DevBuf<i32> sw_bt_desc;             // per community-pair bin: the positions of (up to four of) its tile partials (k_bins_prepare)
     DevBuf<double> sw_fused_pw;          // ... and the two powers per sample its prologue writes for its epilogue
@@ -715,7 +716,16 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
                                                                 // auc_part are taken from *ff: they change per alpha)
 bool k_fit_flow_fused_applies(cge_ctx *c, i64 N); // the geometry the fused instances exist for (one tile per wave, one quarter block per workgroup)
 void k_bins_prepare(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, i64 n_partials); // once per sweep, behind the tile tables
-void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, double *vectB, int n_modes, double *fpart);
+// what bins_js_kernel, the last launch of an alpha's chain, does on the way out: the alpha's scalars straight into the host's
+// pinned slot (host_out; scal = their device copy, [res_js, res_js + 2 x CGE_PARTIAL_BLOCKS) = the JS partials this launch
+// computes), and the sentinel fill of the next alpha's persistent fit (arm: 16-byte units)
+struct cge_chain_tail {
+    double *host_out; const double *scal; int res_js, res_len;
+    uint4 *arm; i64 arm_n16; unsigned arm_word;
+};
+void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, double *vectB, int n_modes, double *fpart,
+               const cge_chain_tail *tail = nullptr);
+bool k_fit_flow_arm_region(cge_ctx *c, i64 N, i64 Tld, uint4 **ptr, i64 *n16, unsigned *word); // the fit's hand-off slots (for the tail above)
 void k_bvec_tiles(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_off, i64 N, int directed); // the tile partials only
 void k_auc_prepare(cge_ctx *c, const i32 *v2l, const i32 *old2new, const double *vw_orig, const double *lweight, const i32 *pi,
                    const i32 *pj, const i32 *ni, const i32 *nj, const double *wts, i64 S, i32 *aidx, double *afac, double *aden);

@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void bins_js_kernel(const double *__restrict__
                                                       const i32 *__restrict__ base, i64 C, int Nt, const double *__restrict__ vC,
                                                       double *__restrict__ vectB, int n_modes, double *__restrict__ part,
                                                       unsigned *counter, unsigned target, double *__restrict__ fpart,
-                                                      const int4 *__restrict__ desc) {
+                                                      const int4 *__restrict__ desc, const cge_chain_tail tail) {
     __shared__ double sh[256];
     __shared__ int ok_sh;
     const i64 len = C * (C + 1) / 2;
@@ -759,11 +759,27 @@ __global__ __launch_bounds__(256) void bins_js_kernel(const double *__restrict__
                 f += p * log(p / mm) + q * log(q / mm);
             }
         f = block_sum_256(f, sh);
-        if (threadIdx.x == 0) fpart[(i64)m * JS_BLOCKS + blockIdx.x] = ok ? f : __builtin_nan("");
+        if (threadIdx.x == 0) {
+            const double fv = ok ? f : __builtin_nan("");
+            fpart[(i64)m * JS_BLOCKS + blockIdx.x] = fv;
+            if (tail.host_out) tail.host_out[tail.res_js + m * JS_BLOCKS + blockIdx.x] = fv; // straight to the host's pinned slot
+        }
+    }
+    // ---- the tail of the alpha's chain, folded into this launch (two launches and two boundaries less per alpha) ----
+    // the alpha's other scalars (tallies, the shared verdict, the fit's flags: complete before this launch began) to the host ...
+    if (tail.host_out && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < tail.res_len; i += 256)
+            if (i < tail.res_js || i >= tail.res_js + 2 * JS_BLOCKS) tail.host_out[i] = tail.scal[i];
+    // ... and the hand-off slots of the NEXT alpha's persistent fit armed (what a memset did in front of every fit)
+    if (tail.arm) {
+        const uint4 v = make_uint4(tail.arm_word, tail.arm_word, tail.arm_word, tail.arm_word);
+        for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < tail.arm_n16; i += (i64)JS_BLOCKS * 256) tail.arm[i] = v;
     }
 }
 // fpart: n_modes x CGE_PARTIAL_BLOCKS block sums of the divergence terms (the caller adds them in block order, then / 2)
-void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, double *vectB, int n_modes, double *fpart) {
+void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, double *vectB, int n_modes, double *fpart,
+               const cge_chain_tail *tail) {
+    const cge_chain_tail tl = tail ? *tail : cge_chain_tail{};
     ScopedKernelTimer t(c, "bvec_js");
     const int Nt = (int)((N + 63) / 64);
     c->js_part.ensure(8 * JS_BLOCKS);
@@ -775,7 +791,7 @@ void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, do
     c->js_launches++;
     hipLaunchKernelGGL(bins_js_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, c->sw_bt_part.p, cm_off, c->sw_bt_fc.p,
                        c->sw_bt_ns.p, c->sw_bt_base.p, C, Nt, vC, vectB, n_modes, c->js_part.p, c->js_counter.p,
-                       (unsigned)(c->js_launches * JS_BLOCKS), fpart, reinterpret_cast<const int4 *>(c->sw_bt_desc.p));
+                       (unsigned)(c->js_launches * JS_BLOCKS), fpart, reinterpret_cast<const int4 *>(c->sw_bt_desc.p), tl);
 }
 // once per sweep, after the tile tables are up: the bins' descriptors (positions of their partials) and the +0.0 slot behind
 // the partials that unused descriptor entries point to

@@ -1066,6 +1066,20 @@ bool k_fit_flow_fused_applies(cge_ctx *c, i64 N) {
     int G = 0, NW = 0, tpw = 0;
     return flow_geometry(N, (N + 63) / 64 * 64, &G, &NW, &tpw) && tpw == 1 && 4 * (int)((N + 63) / 64) <= G;
 }
+// where the hand-off slots of fit_flow_kernel for N vertices live and how they are armed (the buffer is made if need be)
+bool k_fit_flow_arm_region(cge_ctx *c, i64 N, i64 Tld, uint4 **ptr, i64 *n16, unsigned *word) {
+    int G = 0, NW = 0, tpw = 0;
+    if (!flow_geometry(N, Tld, &G, &NW, &tpw)) return false;
+    const int Nt = (int)((N + 63) / 64);
+    const size_t psz = (size_t)Nt * Nt * 64, n_ring = (size_t)4 * Tld, n_fq = (size_t)3 * 4 * Nt, n_sync = 32;
+    const size_t doubles = n_sync + n_ring + n_fq + 2 * psz;
+    if (doubles % 2) return false; // (16-byte units)
+    c->fp_flow.ensure(doubles);
+    *ptr = reinterpret_cast<uint4 *>(c->fp_flow.p);
+    *n16 = (i64)(doubles / 2);
+    *word = FLOW_SENTINEL_WORD;
+    return true;
+}
 bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,
                         double eps, double delta, int *dev_flags, const cge_fit_fused *ff, const cge_fit_fused *ff_dev) {
     const bool fused = ff != nullptr;
@@ -1095,8 +1109,10 @@ bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, d
         return false;
     }
     hipStream_t st = c->stream;
-    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->fp_flow.p, (int)FLOW_SENTINEL_WORD,
-                                2 * (n_sync + n_ring + n_fq + 2 * psz), st));
+    const i64 arm_words = (i64)(2 * (n_sync + n_ring + n_fq + 2 * psz));
+    if (c->flow_armed_words != arm_words) // (else: armed by the last launch of the previous alpha's chain, bins_js_kernel)
+        HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)c->fp_flow.p, (int)FLOW_SENTINEL_WORD, (size_t)arm_words, st));
+    c->flow_armed_words = 0;
     const double *aGD = GD, *aT0 = T0, *aW = w;
     double *aTout = Tout, *aRing = c->fp_flow.p + n_sync, *aFq = aRing + n_ring, *aP = aFq + n_fq;
     i64 aN = N, aTld = Tld;
@@ -1142,6 +1158,7 @@ bool k_fit_persistent_dir(cge_ctx *c, const double *GD, i64 N, double *Tin, doub
                 const size_t pstride = (size_t)Nt * Nt * 64, n_sync = 32, n_ring = (size_t)8 * Tld, n_fq = (size_t)3 * 4 * Nt,
                              n_p = 4 * pstride;
                 c->fp_flow.ensure(n_sync + n_ring + n_fq + n_p);
+                c->flow_armed_words = 0; // (the undirected fit's slots live in the same buffer)
                 c->fp_flags.ensure(4);
                 HIP_CHECK(hipMemsetAsync(c->fp_Td.p, 0, sizeof(double) * 2 * Tld, st));
                 HIP_CHECK(hipMemcpyAsync(c->fp_Td.p, Tin, sizeof(double) * N, hipMemcpyDeviceToDevice, st));

@@ -433,7 +433,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         const bool gd_upper = landmarks && !directed;
         double *const GDc = GD.p; // this alpha's matrix
         const bool fused_now = fuse && use_persistent && c->pow_logs_N == N; // (a fallback in mid-sweep ends it: the matrix is needed then)
-        bool auc_done = false, bvec_partials = false;
+        bool auc_done = false, bvec_partials = false, copied_out = false;
         if (!fused_now) k_pow_matrix(c, D.p, N, alpha, GDc, gd_upper);
         if (directed || !use_persistent) HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
         if (directed) {
@@ -568,7 +568,19 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             if ((bvec_partials || c->bvec_blocks) && !directed && !c->opt_test_bvec_plain) {
                 // tile partials (from the fit's epilogue, or one pass over GD) -> vect_B and its divergence(s) in one launch
                 if (!bvec_partials) k_bvec_tiles(c, GDc, Ta, Tb, d_cm_off.p, N, directed);
-                k_bins_js(c, d_cm_off.p, N, C, G.vectC, vectB.p, split ? 2 : 1, scal.p + RES_JS);
+                // the last launch of the alpha: it also hands the alpha's scalars to the host's pinned slot and arms the hand-off
+                // slots of the next alpha's persistent fit (instead of a copy and a fill of their own)
+                cge_chain_tail tail{};
+                tail.host_out = c->pin_scal.p + RES_STRIDE * slot;
+                tail.scal = scal.p;
+                tail.res_js = (int)RES_JS;
+                tail.res_len = (int)RES_LEN;
+                bool arms = false;
+                if (use_persistent && ia < n_alpha_total) arms = k_fit_flow_arm_region(c, N, Tld, &tail.arm, &tail.arm_n16, &tail.arm_word);
+                if (!arms) { tail.arm = nullptr; tail.arm_n16 = 0; }
+                k_bins_js(c, d_cm_off.p, N, C, G.vectC, vectB.p, split ? 2 : 1, scal.p + RES_JS, &tail);
+                if (arms) c->flow_armed_words = 4 * tail.arm_n16;
+                copied_out = true;
             } else {
                 if (bvec_partials) k_bvec_bins(c, d_cm_off.p, N, C, directed, vectB.p); // the tile partials came with the fit
                 else k_bvec(c, GDc, Ta, Tb, c->sw_cm_pos.p, d_cm_off.p, d_cm_mem.p, N, C, directed, rowbins.p, vectB.p);
@@ -582,7 +594,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         }
         // the block partials of the alpha's reductions and (behind them) the verdict of an enqueued fit, one copy; the host
         // adds the partials in block order -- what the one-thread "final" kernels did, without their launches
-        HIP_CHECK(hipMemcpyAsync(c->pin_scal.p + RES_STRIDE * slot, scal.p, sizeof(double) * RES_LEN, hipMemcpyDeviceToHost, st));
+        if (!copied_out)
+            HIP_CHECK(hipMemcpyAsync(c->pin_scal.p + RES_STRIDE * slot, scal.p, sizeof(double) * RES_LEN, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipEventRecord(c->sweep_ev[slot], st));
     };
 
