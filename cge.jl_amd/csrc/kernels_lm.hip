@@ -1978,6 +1978,11 @@ template <int N>
 __device__ __forceinline__ void fmac_bcast(double &acc, double bc, double a) {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(a), "n"(N));
 }
+// acc -= (that lane's value) * a: the same FMA with the sign flipped on the second factor (a source modifier: exact)
+template <int N>
+__device__ __forceinline__ void fnmac_bcast(double &acc, double bc, double a) {
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(a), "n"(N));
+}
 template <int NG>
 __device__ __forceinline__ void dpp_fence(double (&v)[NG]) { // VALU write -> DPP read of the same register: two wait states
     if constexpr (NG == 1) asm volatile("s_nop 1" : "+v"(v[0]));
@@ -1994,13 +1999,13 @@ struct EigCols {
         EigCols<JJ + 1, NR, NC, R0>::matvec(s, a, uc);
     }
     static __device__ __forceinline__ void rank2(double (&a)[NR][NC], const double (&uc)[NG], const double (&wc)[NG],
-                                                 const double (&nu)[NR], const double (&nw)[NR]) {
+                                                 const double (&u)[NR], const double (&w)[NR]) {
 #pragma unroll
         for (int r = R0; r < NR; r++) {
-            fmac_bcast<JJ % 16>(a[r][JJ], uc[JJ / 16], nw[r]); // a - w_r u_j
-            fmac_bcast<JJ % 16>(a[r][JJ], wc[JJ / 16], nu[r]); //   - u_r w_j
+            fnmac_bcast<JJ % 16>(a[r][JJ], uc[JJ / 16], w[r]); // a - w_r u_j
+            fnmac_bcast<JJ % 16>(a[r][JJ], wc[JJ / 16], u[r]); //   - u_r w_j
         }
-        EigCols<JJ + 1, NR, NC, R0>::rank2(a, uc, wc, nu, nw);
+        EigCols<JJ + 1, NR, NC, R0>::rank2(a, uc, wc, u, w);
     }
 };
 template <int NR, int NC, int R0>
@@ -2190,16 +2195,13 @@ __global__ __launch_bounds__(256, 2) void group_eig_kernel(const double *__restr
         CK(5)
         if (DPPF) {
             if (diag_stage != 10) {
-                double nu[NR], nw[NR];
 #pragma unroll
                 for (int g = 0; g < NG; g++) {
                     const int col = NC * wv + 16 * g + (lane & 15);
                     wc[g] = W[col < DP ? col : 0];
                 }
-#pragma unroll
-                for (int r = 0; r < NR; r++) { nu[r] = -u[r]; nw[r] = -w[r]; }
                 dpp_fence(wc);
-                EigCols<0, NR, NC, R0>::rank2(a, uc, wc, nu, nw);
+                EigCols<0, NR, NC, R0>::rank2(a, uc, wc, u, w);
             }
         } else if (diag_stage != 10) { // rank-2 update; waves whose columns are all finished run it too (u = w = 0 there: nothing changes)
 #pragma unroll

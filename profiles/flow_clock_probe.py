@@ -7,8 +7,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cge.jl_amd import api, synth  # noqa: E402
 
-api._LIB_PATH = os.path.join(os.path.dirname(api._LIB_PATH), "libcge_hip_clock.so")
 name = sys.argv[1] if len(sys.argv) > 1 else "headline"
+api._LIB_PATH = os.path.join(os.path.dirname(api._LIB_PATH), sys.argv[2] if len(sys.argv) > 2 else "libcge_hip_clock.so")
 W = {"small": (50_000, 525_000, 25, 128, 400), "headline": (1_000_000, 10_500_000, 500, 128, 4000)}
 n, m, C, d, land = W[name]
 g = synth.abcd_like(n, m, C, d, seed=42)
