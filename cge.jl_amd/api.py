@@ -504,7 +504,7 @@ class Context:
         self._check(self.L.cge_louvain(self.h, _p(out), C.byref(nc), C.byref(q), C.byref(rounds)))
         return out, nc.value, q.value, rounds.value
 
-    _TEST_OPTIONS = ("fit_persistent_test_delay", "fit_persistent_test_timeout", "test_bvec_plain", "fit_strip")
+    _TEST_OPTIONS = ("fit_persistent_test_delay", "fit_persistent_test_timeout", "test_bvec_plain")
 
     def set_option(self, key, value):
         if key in self._TEST_OPTIONS:  # the testing knobs are not part of the boundary (include/cge_hip_testing.h)

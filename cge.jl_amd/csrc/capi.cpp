@@ -1478,10 +1478,6 @@ int cge_set_option(cge_ctx *c, const char *key, int64_t value) {
 int cge_set_test_option(void *ctx, const char *key, int64_t value) {
     cge_ctx *c = (cge_ctx *)ctx;
     if (!c || !key) return CGE_E_ARG;
-    if (!strcmp(key, "fit_strip")) { // A/B: 1 = the strip form of the undirected persistent fit (experimental) instead of the tile form
-        c->opt_fit_strip = value != 0;
-        return CGE_OK;
-    }
     if (!strcmp(key, "test_bvec_plain")) { // testing: 1 = vect_B by the kernels of score graphs beyond the LDS budget
         c->opt_test_bvec_plain = value != 0;
         return CGE_OK;

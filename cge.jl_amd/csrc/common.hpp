@@ -358,12 +358,6 @@ struct cge_ctx {
     i64 flow_armed_words = 0;            // > 0: the persistent fit's hand-off slots (that many 4-byte words) are armed by the previous alpha's last launch
     DevBuf<double> sw_bt_part;
     DevBuf<i32> sw_bt_desc;             // per community-pair bin: the positions of (up to four of) its tile partials (k_bins_prepare)
-    // the strip form of the undirected fit (kernels_fits.hip): its tables (cge_fit_fused::st_*), per community the first / last row
-    // run and column segment [4][C], the partials [runs][segments] (+ a +0.0 slot) and the bins' descriptors over them
-    DevBuf<i32> sw_st_rmask, sw_st_rr0, sw_st_cseg, sw_st_c4, sw_st_desc;
-    DevBuf<double> sw_st_part;
-    i64 sw_st_ncs = 0;
-    int opt_fit_strip = 0; // experimental (A/B): 1 = the strip form of the undirected persistent fit (kernels_fits.hip), unfused
     DevBuf<double> sw_fused_pw;          // ... and the two powers per sample its prologue writes for its epilogue
     DevBuf<char> sw_fused_epi;           // the fused chain's tables, one cge_fit_fused per sample set (wgcl_host.cpp)
     int opt_fit_fused = 1;               // 1 (default): landmark-mode sweeps let the rest of an alpha's chain ride on the fit's launch
@@ -715,18 +709,7 @@ struct cge_fit_fused {
     // alpha nor on T -- T's indices in the sweep's numbering [4][S], the factors vw_i, lw_li, vw_j, lw_lj, ... [8][S], the
     // weight sums of the CGE_PARTIAL_BLOCKS blocks -- and per alpha the two powers [2][S], which the fit's prologue writes
     i64 S; const double *dpos, *dneg, *wts; const i32 *aidx; const double *afac, *aden; double *apw; double *auc_part;
-    // the strip form of the undirected fit (kernels_fits.hip): vect_B's partials per (row run, column segment) -- a row run is a
-    // maximal run of one community inside a strip of 16 landmarks, a column segment one inside a slot of 512 -- as
-    // partial[run * st_ncs + segment].  st_rmask[strip]: the rows of the strip that start a run (bit r), st_rr0[strip]: its first
-    // run, st_cseg[segment]: the column a segment starts at (st_ncs + 1 entries), st_csslot[slot]: a slot's first segment
-    const i32 *st_rmask, *st_rr0, *st_cseg; i32 st_csslot[9]; i32 st_ncs;
 };
-// the strip form: N <= 4096 vertices on ceil(N / 16) compute units, the whole matrix on the chip (kernels_fits.hip)
-bool k_fit_strip_applies(cge_ctx *c, i64 N);
-bool k_fit_strip_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,
-                         double eps, double delta, int *dev_flags, const cge_fit_fused *ff = nullptr,
-                         const cge_fit_fused *ff_dev = nullptr); // GD: the FULL matrix (ff == nullptr), else from ff->Lh / Ll (full)
-bool k_fit_strip_arm_region(cge_ctx *c, i64 N, i64 Tld, uint4 **ptr, i64 *n16, unsigned *word);
 bool k_fit_flow_enqueue(cge_ctx *c, const double *GD, i64 N, const double *T0, double *Tout, i64 Tld, const double *w,
                         double eps, double delta, int *dev_flags, const cge_fit_fused *ff = nullptr,
                         const cge_fit_fused *ff_dev = nullptr); // ff_dev: the device copy of *ff the epilogue reads (alpha, partial and
@@ -741,8 +724,7 @@ struct cge_chain_tail {
     uint4 *arm; i64 arm_n16; unsigned arm_word;
 };
 void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, double *vectB, int n_modes, double *fpart,
-               const cge_chain_tail *tail = nullptr, bool strip = false); // strip: the partials of the strip fit (sw_st_*)
-void k_bins_prepare_strip(cge_ctx *c, const i32 *cm_off, i64 C, i64 n_runs, i64 n_segs); // once per sweep, behind the strip tables
+               const cge_chain_tail *tail = nullptr);
 bool k_fit_flow_arm_region(cge_ctx *c, i64 N, i64 Tld, uint4 **ptr, i64 *n16, unsigned *word); // the fit's hand-off slots (for the tail above)
 void k_bvec_tiles(cge_ctx *c, const double *GD, const double *Ta, const double *Tb, const i32 *cm_off, i64 N, int directed); // the tile partials only
 void k_auc_prepare(cge_ctx *c, const i32 *v2l, const i32 *old2new, const double *vw_orig, const double *lweight, const i32 *pi,

@@ -655,32 +655,12 @@ __global__ __launch_bounds__(256) void bins_desc_kernel(const i32 *__restrict__ 
             }
     desc[k] = make_int4(slot[0], slot[1], slot[2], cnt > 4 ? -2 : slot[3]);
 }
-// the same for the strip fit's partials (kernels_fits.hip): bin (ca, cb) = the rectangle [row runs of ca] x [column segments of cb]
-// of partial[run * ncs + segment], runs ascending, then segments; c4 = per community the first / last run and segment, [4][C]
-__global__ __launch_bounds__(256) void bins_desc_strip_kernel(const i32 *__restrict__ cm_off, const i32 *__restrict__ c4, i64 C, int ncs,
-                                                              i32 zero_slot, int4 *__restrict__ desc) {
-    const i64 len = C * (C + 1) / 2;
-    const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (k >= len) return;
-    i64 ca, cb;
-    packed_pair(k, C, ca, cb);
-    i32 slot[4] = {zero_slot, zero_slot, zero_slot, zero_slot};
-    int cnt = 0;
-    if (cm_off[ca + 1] > cm_off[ca] && cm_off[cb + 1] > cm_off[cb])
-        for (i32 rr = c4[ca]; rr <= c4[C + ca]; rr++)
-            for (i32 cs = c4[2 * C + cb]; cs <= c4[3 * C + cb]; cs++) {
-                if (cnt < 4) slot[cnt] = rr * ncs + cs;
-                cnt++;
-            }
-    desc[k] = make_int4(slot[0], slot[1], slot[2], cnt > 4 ? -2 : slot[3]);
-}
 __global__ __launch_bounds__(256) void bins_js_kernel(const double *__restrict__ partial, const i32 *__restrict__ cm_off,
                                                       const i32 *__restrict__ fc, const i32 *__restrict__ ns,
                                                       const i32 *__restrict__ base, i64 C, int Nt, const double *__restrict__ vC,
                                                       double *__restrict__ vectB, int n_modes, double *__restrict__ part,
                                                       unsigned *counter, unsigned target, double *__restrict__ fpart,
-                                                      const int4 *__restrict__ desc, const cge_chain_tail tail,
-                                                      const i32 *__restrict__ st_c4, int st_ncs) {
+                                                      const int4 *__restrict__ desc, const cge_chain_tail tail) {
     __shared__ double sh[256];
     __shared__ int ok_sh;
     const i64 len = C * (C + 1) / 2;
@@ -711,12 +691,7 @@ __global__ __launch_bounds__(256) void bins_js_kernel(const double *__restrict__
             i64 ca = 0, cb = 1;
             if (dsc[u].w != -2)
                 acc = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(0.0, pv[u][0]), pv[u][1]), pv[u][2]), pv[u][3]);
-            else if (st_c4) { // more than four partials of the strip fit: runs ascending, then segments
-                packed_pair(k, C, ca, cb);
-                acc = 0.0;
-                for (i32 rr = st_c4[ca]; rr <= st_c4[C + ca]; rr++)
-                    for (i32 cs = st_c4[2 * C + cb]; cs <= st_c4[3 * C + cb]; cs++) acc = __dadd_rn(acc, partial[(i64)rr * st_ncs + cs]);
-            } else { // a rectangle over more than four tiles (communities of more than 64 landmarks): bvec_bins_kernel's walk
+            else { // a rectangle over more than four tiles (communities of more than 64 landmarks): bvec_bins_kernel's walk
                 packed_pair(k, C, ca, cb);
                 const i32 a0 = cm_off[ca], a1 = cm_off[ca + 1], b0 = cm_off[cb], b1 = cm_off[cb + 1];
                 acc = 0.0;
@@ -803,7 +778,7 @@ __global__ __launch_bounds__(256) void bins_js_kernel(const double *__restrict__
 }
 // fpart: n_modes x CGE_PARTIAL_BLOCKS block sums of the divergence terms (the caller adds them in block order, then / 2)
 void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, double *vectB, int n_modes, double *fpart,
-               const cge_chain_tail *tail, bool strip) {
+               const cge_chain_tail *tail) {
     const cge_chain_tail tl = tail ? *tail : cge_chain_tail{};
     ScopedKernelTimer t(c, "bvec_js");
     const int Nt = (int)((N + 63) / 64);
@@ -814,18 +789,9 @@ void k_bins_js(cge_ctx *c, const i32 *cm_off, i64 N, i64 C, const double *vC, do
         c->js_launches = 0;
     }
     c->js_launches++;
-    hipLaunchKernelGGL(bins_js_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, strip ? c->sw_st_part.p : c->sw_bt_part.p, cm_off,
-                       c->sw_bt_fc.p, c->sw_bt_ns.p, c->sw_bt_base.p, C, Nt, vC, vectB, n_modes, c->js_part.p, c->js_counter.p,
-                       (unsigned)(c->js_launches * JS_BLOCKS), fpart,
-                       reinterpret_cast<const int4 *>(strip ? c->sw_st_desc.p : c->sw_bt_desc.p), tl,
-                       strip ? (const i32 *)c->sw_st_c4.p : (const i32 *)nullptr, (int)c->sw_st_ncs);
-}
-void k_bins_prepare_strip(cge_ctx *c, const i32 *cm_off, i64 C, i64 n_runs, i64 n_segs) {
-    const i64 len = C * (C + 1) / 2;
-    c->sw_st_desc.ensure((size_t)4 * len);
-    HIP_CHECK(hipMemsetAsync(c->sw_st_part.p + n_runs * n_segs, 0, sizeof(double), c->stream));
-    hipLaunchKernelGGL(bins_desc_strip_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, cm_off, c->sw_st_c4.p, C,
-                       (int)n_segs, (i32)(n_runs * n_segs), reinterpret_cast<int4 *>(c->sw_st_desc.p));
+    hipLaunchKernelGGL(bins_js_kernel, dim3(JS_BLOCKS), dim3(256), 0, c->stream, c->sw_bt_part.p, cm_off, c->sw_bt_fc.p,
+                       c->sw_bt_ns.p, c->sw_bt_base.p, C, Nt, vC, vectB, n_modes, c->js_part.p, c->js_counter.p,
+                       (unsigned)(c->js_launches * JS_BLOCKS), fpart, reinterpret_cast<const int4 *>(c->sw_bt_desc.p), tl);
 }
 // once per sweep, after the tile tables are up: the bins' descriptors (positions of their partials) and the +0.0 slot behind
 // the partials that unused descriptor entries point to

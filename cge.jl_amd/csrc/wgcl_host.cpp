@@ -160,20 +160,15 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     // persistent form with one tile per wave.
     const bool tiles_req = orig != nullptr && !directed && c->opt_fit_fused && c->opt_exact_relabel && N >= 256 &&
                            C >= 2 && !c->opt_test_bvec_plain;
-    // Round 5 (late): the STRIP form of the undirected persistent fit (kernels_fits.hip) -- the whole matrix on the chip, one hand-off
-    // per iteration -- takes every score graph of <= 4096 vertices; the tile form stays for the directed fit (option fit_strip = 0:
-    // the tile form here too, A/B)
-    const bool strip_ok = !directed && c->opt_fit_strip && k_fit_strip_applies(c, N);
     const bool fuse_req = tiles_req && !c->fit_persistent_broken && c->opt_fit_persistent != 1 &&
-                          c->opt_pow_exp2 && (strip_ok || k_fit_flow_fused_applies(c, N));
+                          c->opt_pow_exp2 && k_fit_flow_fused_applies(c, N);
     const bool blocks = blocks_req || tiles_req;
     bool blocks_ok = blocks, pieces_ok = true;
     std::vector<i32> bt_fc, bt_ns, bt_base;
     i64 bt_total = 0; // tile partials in all
-    std::vector<i32> comm_new;
     if (blocks) { // per 64-vertex block of the relabelled graph: first community and number of communities; per tile: its partials
         const i64 Nt = (N + 63) / 64;
-        comm_new.resize(N);
+        std::vector<i32> comm_new(N);
         for (i64 q2 = 0; q2 < C; q2++)
             for (i32 t2 = cm_off[q2]; t2 < cm_off[q2 + 1]; t2++) comm_new[t2] = (i32)q2; // position t2 of the community-sorted order
         bt_fc.resize(Nt); bt_ns.resize(Nt); bt_base.assign(Nt * Nt + 1, 0);
@@ -206,52 +201,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             HIP_CHECK(hipStreamSynchronize(st)); // (the tables are locals)
         }
     }
-    bool fuse = fuse_req && blocks_ok && !strip_ok && pieces_ok; // (the strip form's fused epilogue is not written yet: it runs unfused)
-    // the strip fit's epilogue sums vect_B per (row run, column segment): a row run = a maximal run of one community inside a strip
-    // of 16 landmarks, a column segment = one inside 64 aligned columns (kernels_fits.hip)
-    bool strip_fused = fuse && strip_ok;
-    i64 st_runs = 0, st_segs = 0;
-    i32 st_csslot[9];
-    if (strip_fused) {
-        const i64 nstrips = (N + 15) / 16;
-        std::vector<i32> rmask(nstrips, 0), rr0(nstrips, 0), run_of(N), seg_of(N), cseg, c4(4 * C);
-        i32 run = -1, seg = -1;
-        for (i64 i = 0; i < N; i++) {
-            if ((i & 15) == 0 || comm_new[i] != comm_new[i - 1]) {
-                run++;
-                rmask[i >> 4] |= (i32)1 << (i & 15);
-                if ((i & 15) == 0) rr0[i >> 4] = run;
-            }
-            run_of[i] = run;
-            if ((i & 63) == 0 || comm_new[i] != comm_new[i - 1]) {
-                seg++;
-                cseg.push_back((i32)i);
-            }
-            seg_of[i] = seg;
-        }
-        cseg.push_back((i32)N);
-        st_runs = run + 1;
-        st_segs = seg + 1;
-        for (int s2 = 0; s2 < 9; s2++) st_csslot[s2] = (i64)512 * s2 < N ? seg_of[512 * s2] : (i32)st_segs;
-        for (i64 q2 = 0; q2 < C; q2++) {
-            const bool some = cm_off[q2 + 1] > cm_off[q2];
-            c4[q2] = some ? run_of[cm_off[q2]] : 0;
-            c4[C + q2] = some ? run_of[cm_off[q2 + 1] - 1] : -1;
-            c4[2 * C + q2] = some ? seg_of[cm_off[q2]] : 0;
-            c4[3 * C + q2] = some ? seg_of[cm_off[q2 + 1] - 1] : -1;
-        }
-        if (st_runs * st_segs > ((i64)1 << 28)) strip_fused = fuse = false; // (2 GB of partials: every landmark its own community)
-        else {
-            c->sw_st_rmask.ensure(nstrips); c->sw_st_rr0.ensure(nstrips); c->sw_st_cseg.ensure(st_segs + 1); c->sw_st_c4.ensure(4 * C);
-            c->sw_st_part.ensure(st_runs * st_segs + 1);
-            c->sw_st_ncs = st_segs;
-            HIP_CHECK(hipMemcpyAsync(c->sw_st_rmask.p, rmask.data(), sizeof(i32) * nstrips, hipMemcpyHostToDevice, st));
-            HIP_CHECK(hipMemcpyAsync(c->sw_st_rr0.p, rr0.data(), sizeof(i32) * nstrips, hipMemcpyHostToDevice, st));
-            HIP_CHECK(hipMemcpyAsync(c->sw_st_cseg.p, cseg.data(), sizeof(i32) * (st_segs + 1), hipMemcpyHostToDevice, st));
-            HIP_CHECK(hipMemcpyAsync(c->sw_st_c4.p, c4.data(), sizeof(i32) * 4 * C, hipMemcpyHostToDevice, st));
-            HIP_CHECK(hipStreamSynchronize(st)); // (the tables are locals)
-        }
-    }
+    bool fuse = fuse_req && blocks_ok && pieces_ok;
     if (!blocks_req && !tiles_req) blocks_ok = false;
     const bool relabel = (N > 8192 && c->opt_exact_relabel) || blocks_ok;
     c->bvec_blocks = blocks_ok;
@@ -294,7 +244,6 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     c->sw_cm_pos.ensure(N);
     HIP_CHECK(hipMemcpyAsync(c->sw_cm_pos.p, cm_pos.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
     if (c->bvec_blocks && !directed) k_bins_prepare(c, d_cm_off.p, N, C, bt_total); // where every bin's tile partials sit
-    if (strip_fused) k_bins_prepare_strip(c, d_cm_off.p, C, st_runs, st_segs);    // ... and the strip fit's
 
     // T (:118) / Tin,Tout (:399-402)
     std::vector<double> hT1(N, 1.0), hT2(N, 1.0);
@@ -425,12 +374,6 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             cge_fit_fused &e = h_epi[t];
             e = cge_fit_fused{};
             e.comm = G.comm; e.fc = c->sw_bt_fc.p; e.ns = c->sw_bt_ns.p; e.base = c->sw_bt_base.p; e.partial = c->sw_bt_part.p;
-            if (strip_fused) {
-                e.partial = c->sw_st_part.p;
-                e.st_rmask = c->sw_st_rmask.p; e.st_rr0 = c->sw_st_rr0.p; e.st_cseg = c->sw_st_cseg.p;
-                for (int s2 = 0; s2 < 9; s2++) e.st_csslot[s2] = st_csslot[s2];
-                e.st_ncs = (i32)st_segs;
-            }
             e.S = fz_s1 - fz_s0;
             e.dpos = ds.dpos.p + fz_s0; e.dneg = ds.dneg.p + fz_s0; e.wts = ds.wts.p + fz_s0;
             if (fuse_auc && e.S > 0) { // everything of the tally that depends neither on alpha nor on T, once
@@ -487,10 +430,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         sl.did_div = want_div;
         // the undirected persistent fit and vect_B read the upper triangle only; the exact-mode AUC, the directed vect_B
         // and the launch-per-iteration fits read whole rows
-        const bool gd_upper = landmarks && !directed && !strip_ok; // (the strip fit holds the whole matrix)
+        const bool gd_upper = landmarks && !directed;
         double *const GDc = GD.p; // this alpha's matrix
-        const bool fused_now = fuse && use_persistent && c->pow_logs_N == N && // (a fallback in mid-sweep ends it: the matrix is needed then)
-                               (!strip_fused || !c->pow_logs_upper);
+        const bool fused_now = fuse && use_persistent && c->pow_logs_N == N; // (a fallback in mid-sweep ends it: the matrix is needed then)
         bool auc_done = false, bvec_partials = false, copied_out = false;
         if (!fused_now) k_pow_matrix(c, D.p, N, alpha, GDc, gd_upper);
         if (directed || !use_persistent) HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
@@ -517,11 +459,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                     ffp = &ff;
                     ffd = reinterpret_cast<const cge_fit_fused *>(c->sw_fused_epi.p) + set;
                 }
-                const bool enq = strip_ok ? k_fit_strip_enqueue(c, fused_now ? nullptr : GDc, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld,
-                                                                Tld, G.vw, 0.25, delta, (int *)(scal.p + RES_FIT), ffp, ffd)
-                                          : k_fit_flow_enqueue(c, fused_now ? nullptr : GDc, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld,
-                                                               Tld, G.vw, 0.25, delta, (int *)(scal.p + RES_FIT), ffp, ffd);
-                if (enq) {
+                if (k_fit_flow_enqueue(c, fused_now ? nullptr : GDc, N, TT.p + (i64)tpar * Tld, TT.p + (i64)tnext * Tld,
+                                                           Tld, G.vw, 0.25, delta, (int *)(scal.p + RES_FIT), ffp, ffd)) {
                     if (fused_now) {
                         auc_done = ff.auc_part != nullptr;
                         bvec_partials = ff.partial != nullptr;
@@ -637,11 +576,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                 tail.res_js = (int)RES_JS;
                 tail.res_len = (int)RES_LEN;
                 bool arms = false;
-                if (use_persistent && ia < n_alpha_total)
-                    arms = strip_ok ? k_fit_strip_arm_region(c, N, Tld, &tail.arm, &tail.arm_n16, &tail.arm_word)
-                                    : k_fit_flow_arm_region(c, N, Tld, &tail.arm, &tail.arm_n16, &tail.arm_word);
+                if (use_persistent && ia < n_alpha_total) arms = k_fit_flow_arm_region(c, N, Tld, &tail.arm, &tail.arm_n16, &tail.arm_word);
                 if (!arms) { tail.arm = nullptr; tail.arm_n16 = 0; }
-                k_bins_js(c, d_cm_off.p, N, C, G.vectC, vectB.p, split ? 2 : 1, scal.p + RES_JS, &tail, bvec_partials && strip_fused);
+                k_bins_js(c, d_cm_off.p, N, C, G.vectC, vectB.p, split ? 2 : 1, scal.p + RES_JS, &tail);
                 if (arms) c->flow_armed_words = 4 * tail.arm_n16;
                 copied_out = true;
             } else {
@@ -664,7 +601,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
 
     // log2(1 - D) once for the whole sweep (the upper tiles only when every alpha reads only those); a fallback of the
     // persistent fit in mid-sweep makes k_pow_matrix use the library pow for the whole rows it then needs
-    k_pow_prepare(c, D.p, N, landmarks && !directed && !strip_ok);
+    k_pow_prepare(c, D.p, N, landmarks && !directed);
     i64 next_enqueue = 1;
     for (i64 ia = 1; ia <= n_alpha_total; ia++) {
         const double alpha = AlphaStep * (double)ia;

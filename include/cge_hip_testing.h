@@ -33,9 +33,7 @@ int cge_wave_tree_test(void *ctx, const double *x, int64_t n_rows, double *out_r
  *   "fit_persistent_test_delay"   n: the tile waves of the persistent fits nap n x ~3 us before their first load (start skew, as
  *                                 under contention);
  *   "fit_persistent_test_timeout" 1: the persistent fit abandons every launch at once (the fallback path runs);
- *   "test_bvec_plain"             1: vect_B by the kernels of score graphs beyond the LDS budget / 512 communities.
- *   "fit_strip"                   1: the undirected persistent fit in its strip form (kernels_fits.hip: the whole matrix on the
- *                                 chip, one hand-off per iteration; experimental, without the fused chain); default 0.             */
+ *   "test_bvec_plain"             1: vect_B by the kernels of score graphs beyond the LDS budget / 512 communities.              */
 int cge_set_test_option(void *ctx, const char *key, int64_t value);
 #ifdef __cplusplus
 }

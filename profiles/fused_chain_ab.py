@@ -1,5 +1,5 @@
 """A/B aid (round 5): the alpha chain riding on the persistent fit's launch (option fit_fused, the default) against the
-separate launches (fit_fused = 0), for the strip form of the fit (kernels_fits.hip, the default) and the tile form (fit_strip = 0).  argv[1] = workload
+separate launches (fit_fused = 0, with vect_B by tiles so that the additions are the same).  argv[1] = workload
 (small | cfg2 | headline), argv[2] = runs.  Prints ms per score, the sweep phase, the fit's launch time and whether the
 result vectors and traces are identical."""
 import os
@@ -21,10 +21,8 @@ ctx = api.Context()
 ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
 ctx.profile_enable(True)
 out = {}
-for label, opts in (("strip fused", {"fit_strip": 1, "fit_fused": 1}), ("tile fused", {"fit_strip": 0, "fit_fused": 1}),
-                    ("strip separate", {"fit_strip": 1, "fit_fused": 0, "bvec_blocks": 1}),
-                    ("tile separate", {"fit_strip": 0, "fit_fused": 0, "bvec_blocks": 1}),
-                    ("separate+rows", {"fit_strip": 1, "fit_fused": 0, "bvec_blocks": 0})):
+for label, opts in (("fused", {"fit_fused": 1}), ("separate+tiles", {"fit_fused": 0, "bvec_blocks": 1}),
+                    ("separate+rows", {"fit_fused": 0, "bvec_blocks": 0})):
     for k, v in opts.items():
         ctx.set_option(k, v)
     r = ctx.score(g["clusters"], land, 4, "rss", seed=42, auc_samples=10000)
@@ -43,9 +41,10 @@ for label, opts in (("strip fused", {"fit_strip": 1, "fit_fused": 1}), ("tile fu
           f"{fit.get('launches', 0) // max(1, runs)} launches; fused alphas {ctx.get_stat('fit_fused_alphas')}; "
           f"sweep {ph.get('sweep', float('nan')):.3f} ms; result {[float(x) for x in r]}", flush=True)
     print("   iters", list(tr["iters"]), flush=True)
-ref = out["separate+rows"]
-for label, (r, tr) in out.items():
-    print(f"{label:16s} vs separate+rows: max rel diff of the result {float(np.max(np.abs(r - ref[0]) / np.maximum(1e-300, np.abs(ref[0])))):.3e}; "
-          f"iters equal {list(tr['iters']) == list(ref[1]['iters'])}; "
-          f"max rel diff of the div trace {float(np.nanmax(np.abs(np.asarray(tr['div']) - np.asarray(ref[1]['div'])) / np.maximum(1e-300, np.abs(np.asarray(ref[1]['div']))))):.3e}; "
-          f"auc trace {float(np.nanmax(np.abs(np.asarray(tr['auc']) - np.asarray(ref[1]['auc'])))):.3e}")
+a, b, c2 = out["fused"], out["separate+tiles"], out["separate+rows"]
+print("fused == separate+tiles (bits):", np.array_equal(a[0], b[0]), "traces:",
+      np.array_equal(np.asarray(a[1]["div"]), np.asarray(b[1]["div"]), equal_nan=True),
+      np.array_equal(np.asarray(a[1]["auc"]), np.asarray(b[1]["auc"]), equal_nan=True),
+      list(a[1]["iters"]) == list(b[1]["iters"]))
+print("fused vs separate+rows: max rel diff of the result", float(np.max(np.abs(a[0] - c2[0]) / np.maximum(1e-300, np.abs(c2[0])))),
+      "iters equal:", list(a[1]["iters"]) == list(c2[1]["iters"]))
