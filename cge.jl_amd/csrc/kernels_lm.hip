@@ -582,7 +582,8 @@ __global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__
                                                                 const i32 *__restrict__ chunk_beg,
                                                                 const i32 *__restrict__ chunk_end, i64 d, i64 nT,
                                                                 const double *__restrict__ mean,
-                                                                double *__restrict__ part /* [chunk][d*d] */) {
+                                                                double *__restrict__ part /* [chunk][d*d] */,
+                                                                const i32 *__restrict__ task_chunk_off, double *__restrict__ cov) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ i32 s_row[CGE_CHUNK_ROWS];
     __shared__ double s_sq[CGE_CHUNK_ROWS];
@@ -629,6 +630,10 @@ __global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__
         return (d2){col < d ? (r.x[0] - m0) * r.sq : 0.0, col + 1 < d ? (r.x[1] - m1) * r.sq : 0.0};
     };
     double *out = part + ch * d * d;
+    if (SAME && nT == 1) { // a group of ONE chunk (most groups of a batch): its partial IS the covariance -- straight to `cov`, and
+        const i64 t = chunk_task[ch]; // group_cov_final_kernel skips the group (no round trip of d x d doubles through `part`)
+        if (task_chunk_off[t + 1] - task_chunk_off[t] == 1) out = cov + t * d * d;
+    }
     if (SAME) { // upper-triangular blocks only, mirrored on the way out
         d4 acc[9];
         auto la = [&](i64 kc, int q) { return load(kc, q, ca); };
@@ -672,9 +677,10 @@ __global__ __launch_bounds__(256, 2) void group_cov_mfma_kernel(const double *__
 // `tiled` (d > 128, MFMA path): the chunk partials hold the 128 x 128 tiles on and above the diagonal only; the tiles
 // below it are the mirror images, written from the reduced sums.
 __global__ void group_cov_final_kernel(const double *__restrict__ part, const i32 *__restrict__ task_chunk_off, i64 d,
-                                       int tiled, double *__restrict__ cov) {
+                                       int tiled, int direct_single, double *__restrict__ cov) {
     const i64 t = blockIdx.y, dd = d * d;
     const i32 c0 = task_chunk_off[t], c1 = task_chunk_off[t + 1];
+    if (direct_single && c1 - c0 == 1) return; // (written by the chunk's own kernel)
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < dd; e += (i64)gridDim.x * blockDim.x) {
         const i64 i = e / d, j = e - i * d;
         if (tiled && (i >> 7) > (j >> 7)) continue;
@@ -692,10 +698,10 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
         const i64 nT = (d + 127) / 128;
         const size_t stage = (size_t)2 * MP_BK * MP_LD * sizeof(double);
         hipLaunchKernelGGL((group_cov_mfma_kernel<true>), dim3((unsigned)n_chunks, (unsigned)nT), block, stage, c->stream,
-                           Xr, vw, rows, chunk_task, chunk_beg, chunk_end, d, nT, mean, part);
+                           Xr, vw, rows, chunk_task, chunk_beg, chunk_end, d, nT, mean, part, task_chunk_off, cov);
         if (nT > 1)
             hipLaunchKernelGGL((group_cov_mfma_kernel<false>), dim3((unsigned)n_chunks, (unsigned)(nT * (nT - 1) / 2)), block,
-                               2 * stage, c->stream, Xr, vw, rows, chunk_task, chunk_beg, chunk_end, d, nT, mean, part);
+                               2 * stage, c->stream, Xr, vw, rows, chunk_task, chunk_beg, chunk_end, d, nT, mean, part, task_chunk_off, cov);
     } else {
         const int dpv = (int)((d + 7) / 8 * 8);
         int RT = 64;
@@ -714,7 +720,7 @@ void k_group_cov(cge_ctx *c, const double *Xr, const double *vw, const i32 *rows
     const i64 dd = d * d;
     dim3 g2((unsigned)std::min<i64>((dd + 255) / 256, 64), (unsigned)n_tasks);
     hipLaunchKernelGGL(group_cov_final_kernel, g2, dim3(256), 0, c->stream, part, task_chunk_off, d, (int)(d > 128),
-                       cov);
+                       (int)(d >= 48 && d <= 128), cov);
 }
 
 // ------------------------------------------------------------------------------------------------
