@@ -157,6 +157,7 @@ void cge_destroy(cge_ctx *c) {
     c->event_pool.clear();
     if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->samp_ev) (void)hipEventDestroy(c->samp_ev);
     for (int i = 0; i < 2; i++) {
         if (c->sweep_ev[i]) (void)hipEventDestroy(c->sweep_ev[i]);
         if (c->tab_ev[i]) (void)hipEventDestroy(c->tab_ev[i]);
@@ -794,6 +795,11 @@ static void landmarks_run_impl(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off
     double t0 = now_ms();
     land = clamp_to_unique_rows(c, land, &c->lm_truncated);
     c->phases.ms["lm_unique"] = now_ms() - t0;
+    if (c->after_unique) { // (cge_score: the sample draws go in here -- the host now sets up runsplit for a few hundred microseconds)
+        std::function<void()> f;
+        f.swap(c->after_unique);
+        f();
+    }
     std::vector<i64> gid;
     host_runsplit(c, cl_flat, cl_off, ncl, land, forced, method, gid, true); // leaves v2l and the landmark index on the device
     HIP_CHECK(hipStreamSynchronize(st));
@@ -953,7 +959,15 @@ int cge_draw_samples(cge_ctx *c, int64_t seed, int64_t stream_id, int64_t S, int
     CGE_CATCH(c)
 }
 
-static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_directed, SampleSet &smp) {
+// whether make_samples can be started ahead of the rest of a score: one seeded set, drawn on the device from a local edge list
+static bool samples_can_start_early(cge_ctx *c, i64 seed, bool exact_directed);
+// phase 0: everything; 1: enqueue the draws and the first rejection round, no synchronisation (samples_can_start_early only);
+// 2: the rest of a draw begun with phase 1
+static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_directed, SampleSet &smp, int phase = 0) {
+    if (phase == 2) {
+        k_draw_samples_finish(c);
+        return;
+    }
     // seeded: one set reused at every alpha (Random.seed! before each draw, src/divergence.jl:184,193);
     // unseeded: a fresh set per alpha, keyed by an arbitrary fixed base seed and the alpha index
     const i64 n_alpha = 40;
@@ -963,6 +977,10 @@ static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_d
     if (sampler_uses_device(c)) { // large resident graph: drawn, rejected and kept on the device (the same stream of draws)
         smp.on_device = true;
         smp.d_pos.ensure(smp.n_sets * S); smp.d_ni.ensure(smp.n_sets * S); smp.d_nj.ensure(smp.n_sets * S);
+        if (phase == 1) { // (one set, no second draw: samples_can_start_early)
+            k_draw_samples_begin(c, base, 0, S, directed, smp.d_pos.p, smp.d_ni.p, smp.d_nj.p);
+            return;
+        }
         for (i64 t = 0; t < smp.n_sets; t++)
             k_draw_samples_dev(c, base, t, S, directed, smp.d_pos.p + t * S, smp.d_ni.p + t * S, smp.d_nj.p + t * S);
         if (exact_directed) { // the un-reseeded second positive draw of :510 (its non-edges are not used)
@@ -985,6 +1003,10 @@ static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_d
         for (i64 t = 0; t < smp.n_sets; t++)
             host_draw_samples(c, base + 0x7777, 1000 + t, S, directed, &smp.pos_idx2[t * S], di.data(), dj.data());
     }
+}
+
+static bool samples_can_start_early(cge_ctx *c, i64 seed, bool exact_directed) {
+    return seed != -1 && !exact_directed && sampler_uses_device(c) && !c->edges_sharded;
 }
 
 // exact distance of one vertex pair with dist()'s own arithmetic (src/auxilary.jl:14-20)
@@ -1229,8 +1251,6 @@ int cge_wgcl(cge_ctx *c, const cge_wgcl_args *a, double out[7], int *out_len, cg
 }
 
 
-static void make_samples(cge_ctx *c, i64 seed, i64 S, int directed, bool exact_directed, SampleSet &smp);
-
 int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, cge_trace *trace) {
     if (!c || !a || !out || !out_len) return CGE_E_ARG;
     CGE_TRY(c)
@@ -1242,7 +1262,23 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     const i64 d = c->d;
     ScoreGraph G;
     OrigView ov;
+    std::vector<i32> lcomm_host;
     const bool landmarks = a->land != -1;
+    if (c->samp_pending.on) { // (a score that failed between the two halves of its draw)
+        HIP_CHECK(hipStreamSynchronize(st));
+        c->samp_pending.on = false;
+    }
+    // The local score's samples depend on the resident graph and the seed only: their draw and the first round of the rejection are
+    // enqueued early -- behind the first synchronisation of the landmark phase, whose host-side set-up then leaves the device idle
+    // for a few hundred microseconds; the verdict is looked at where the samples used to be drawn (a star graph's early return or
+    // an error in between leaves the draw pending: see above)
+    const bool samples_early = landmarks && samples_can_start_early(c, a->seed, false);
+    c->after_unique = nullptr;
+    if (samples_early)
+        c->after_unique = [c, a, directed]() {
+            c->smp.reset();
+            make_samples(c, a->seed, a->auc_samples, directed, false, c->smp, 1);
+        };
     DevBuf<double> &zeros = c->sw_zeros;
     double t0;
     DevBuf<i32> &star = c->s_star;
@@ -1259,6 +1295,7 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     if (landmarks) {
         landmarks_run_impl(c, a->clusters_flat, a->clusters_off, a->n_clusters, a->land, a->forced, a->method, directed,
                            directed != 0 || c->opt_landmark_edges != 0);
+        c->after_unique = nullptr;
         const i64 N = c->N, C = c->n_comm_max;
         // wGCL's own `maximum(edges)` / size asserts (src/divergence.jl:41,50): the highest-numbered
         // landmark must carry an edge -- always true when every vertex has positive weight
@@ -1285,14 +1322,16 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
         ov.n = c->n; ov.m = c->m; ov.Xr = c->Xr.p; ov.vw = c->vw.p; ov.v2l = c->v2l.p; ov.lweight = c->lweight.p;
         ov.src = c->src.p; ov.dst = c->dst.p; ov.h_w = c->h_w.empty() ? nullptr : c->h_w.data();
         double hi = 0.0;
+        lcomm_host.resize(N); // community of a landmark = community of any member (landmarks never span two): :427
         {
-            std::vector<i32> lcomm0(N); // community of a landmark = community of any member (landmarks never span two): :427
+            std::vector<i32> &lcomm0 = lcomm_host;
             HIP_CHECK(hipMemcpyAsync(lcomm0.data(), c->lcomm.p, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             hi = resident_diameter_lm(c, c->lemb.p, c->lweight.p, lcomm0, C, N, c->has_coll ? c->coll.rank : 0,
                                       c->has_coll ? c->coll.world : 1);
             hi = allreduce_scalar_max(c, hi);
         }
+        ov.h_lcomm = lcomm_host.data(); // (the sweep groups the landmarks by community: no second read-back)
         ov.hi = hi;
         c->stat_last_hi = hi;
         c->phases.ms["diameter"] = now_ms() - t0; // what the main thread still waited for
@@ -1325,8 +1364,11 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     }
     t0 = now_ms();
     SampleSet &smp = c->smp;
-    smp.reset();
-    make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
+    if (samples_early && c->samp_pending.on) make_samples(c, a->seed, a->auc_samples, directed, false, smp, 2);
+    else {
+        smp.reset();
+        make_samples(c, a->seed, a->auc_samples, directed, directed && !landmarks, smp);
+    }
     c->phases.ms["samples"] = now_ms() - t0;
     t0 = now_ms();
     host_wgcl_sweep(c, G, landmarks ? &ov : nullptr, c->src.p, c->dst.p, c->h_w.empty() ? nullptr : c->h_w.data(), c->m, directed, a->split, smp,

@@ -474,6 +474,18 @@ struct cge_ctx {
     DevBuf<unsigned> samp_attempt;
     DevBuf<i32> samp_todo_a, samp_todo_b, samp_hit, samp_flag;
     DevBuf<unsigned long long> samp_table, samp_count;
+    // a draw of the device sampler whose first round has been enqueued but not looked at yet (k_draw_samples_begin / _finish)
+    struct DrawPending {
+        bool on = false;
+        i64 seed = 0, stream_id = 0, S = 0, cnt = 0;
+        int directed = 0, round = 0;
+        i32 *d_pos = nullptr, *d_ni = nullptr, *d_nj = nullptr;
+        const i32 *todo = nullptr;
+        i32 *next = nullptr;
+    } samp_pending;
+    PinBuf<unsigned long long> samp_pin_cnt;
+    hipEvent_t samp_ev = nullptr;
+    std::function<void()> after_unique; // cge_score: work to enqueue behind the first synchronisation of the landmark phase (once)
     SampleSet smp;                 // library-drawn samples of the running score
     std::vector<std::unique_ptr<DevSamples>> dsets; // their device form (wgcl_host.cpp)
 
@@ -692,6 +704,49 @@ void k_permute_i32(cge_ctx *c, const i32 *src, const i32 *order, i64 n, i32 *dst
 void k_remap_i32(cge_ctx *c, i32 *idx, const i32 *map, i64 n); // idx[k] = map[idx[k]]
 #define CGE_WORD_SEGS 8
 void k_copy_words(cge_ctx *c, int nseg, void *const *dst, const void *const *src, const i64 *words); // 4-byte words, nseg <= 8
+// Several small host arrays -> their device arrays with ONE copy: the words are packed into a pinned staging buffer
+// (two of them alternate, each guarded by an event), copied to a device staging area and scattered by one kernel.
+// Every copy of its own from pageable memory costs ~20 us of idle stream; a batch has seven of them.
+struct WordPacker { // (landmarks_host.cpp: the tables of a batch; wgcl_host.cpp: the tables of a sweep)
+    cge_ctx *c;
+    std::vector<void *> dst;
+    std::vector<const void *> src;
+    std::vector<i64> words;
+    explicit WordPacker(cge_ctx *c_) : c(c_) {}
+    template <class T>
+    void add(T *device, const T *host, i64 count) {
+        static_assert(sizeof(T) % 4 == 0, "4-byte words");
+        if (count <= 0) return;
+        dst.push_back(device);
+        src.push_back(host);
+        words.push_back(count * (i64)(sizeof(T) / 4));
+    }
+    void flush() {
+        if (dst.empty()) return;
+        i64 tot = 0;
+        for (i64 w : words) tot += w + (w & 1); // keep 8-byte items aligned
+        const int slot = c->tab_slot;
+        c->tab_slot ^= 1;
+        HIP_CHECK(hipEventSynchronize(c->tab_ev[slot])); // the copy that last read this staging buffer is done
+        c->pin_tab[slot].ensure((size_t)tot);
+        c->dev_tab.ensure((size_t)tot);
+        i32 *h = c->pin_tab[slot].p;
+        std::vector<const void *> dsrc(dst.size());
+        i64 pos = 0;
+        for (size_t q = 0; q < dst.size(); q++) {
+            std::memcpy(h + pos, src[q], (size_t)words[q] * 4);
+            dsrc[q] = c->dev_tab.p + pos;
+            pos += words[q] + (words[q] & 1);
+        }
+        HIP_CHECK(hipMemcpyAsync(c->dev_tab.p, h, sizeof(i32) * (size_t)tot, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipEventRecord(c->tab_ev[slot], c->stream));
+        for (size_t q0 = 0; q0 < dst.size(); q0 += CGE_WORD_SEGS) {
+            const int n = (int)std::min<size_t>(CGE_WORD_SEGS, dst.size() - q0);
+            k_copy_words(c, n, &dst[q0], &dsrc[q0], &words[q0]);
+        }
+        dst.clear(); src.clear(); words.clear();
+    }
+};
 void k_gather_means_slots(cge_ctx *c, const double *arena, const i64 *off, const i64 *slot, i64 T, i64 d, i64 stride, i64 lead,
                           double *dst);
 void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only);
@@ -788,6 +843,10 @@ __host__ __device__ inline uint64_t cge_bounded(uint64_t r, uint64_t range) {
 }
 // positive / non-edge draws of one sample set on the device (kernels_fit.hip); 0-based i32 outputs of S entries
 void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i32 *d_pos, i32 *d_ni, i32 *d_nj);
+// the same in two halves: _begin enqueues the draws and the first round of the rejection and returns (no synchronisation);
+// _finish looks at the round's verdict and runs whatever rounds are left (a local edge list only: no exchange in between)
+void k_draw_samples_begin(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i32 *d_pos, i32 *d_ni, i32 *d_nj);
+void k_draw_samples_finish(cge_ctx *c);
 void k_prep_samples(cge_ctx *c, const i32 *pos, const i32 *pos_pairs, const i32 *ni_in, const i32 *nj_in, const i32 *e_src,
                     const i32 *e_dst, const double *e_w, i64 S, int directed, i32 *pi, i32 *pj, i32 *ni, i32 *nj, double *wts);
 void host_draw_samples(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i64 *pos_idx, i64 *neg_i, i64 *neg_j);
@@ -802,6 +861,7 @@ struct OrigView { // original graph pieces needed in landmark mode (device, 0-ba
     const i32 *src = nullptr, *dst = nullptr;
     const double *h_w = nullptr; // host edge weights
     double hi = 0.0;             // diameter
+    const i32 *h_lcomm = nullptr; // host copy of the landmarks' communities (the score graph's G.comm), when the caller has one
 };
 void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G, const OrigView *orig, const i32 *ex_src, const i32 *ex_dst,
                      const double *ex_hw, i64 ex_m, int directed, int split, const SampleSet &smp, double out[7],

@@ -1065,55 +1065,83 @@ __global__ void check_neg_flag_kernel(const i32 *__restrict__ todo, i64 cnt, con
         next[atomicAdd(next_cnt, 1ULL)] = (i32)k;
     }
 }
-void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i32 *d_pos, i32 *d_ni, i32 *d_nj) {
+// One round of the rejection: candidates for the samples of `todo` (round 0: all), marked against the edges, the rejected ones
+// listed in `next` and counted.  The verdict (count) is read back by the caller.
+static void draw_round(cge_ctx *c, cge_ctx::DrawPending &P) {
     const i64 n = c->n, m = c->m; // m: the edges resident on this rank
+    hipStream_t st = c->stream;
+    DevBuf<unsigned> &attempt = c->samp_attempt; // grow-only scratch of the context
+    DevBuf<i32> &hit = c->samp_hit;
+    DevBuf<unsigned long long> &table = c->samp_table, &count = c->samp_count;
+    const i64 cnt = P.cnt, S = P.S;
+    i64 tsize = 1024;
+    while (tsize < 4 * cnt) tsize <<= 1;
+    table.ensure(tsize);
+    hit.ensure(tsize);
+    HIP_CHECK(hipMemsetAsync(table.p, 0xFF, sizeof(unsigned long long) * tsize, st));
+    HIP_CHECK(hipMemsetAsync(hit.p, 0, sizeof(i32) * tsize, st));
+    HIP_CHECK(hipMemsetAsync(count.p, 0, sizeof(unsigned long long), st));
+    const unsigned g = (unsigned)((cnt + 255) / 256);
+    hipLaunchKernelGGL(draw_neg_kernel, dim3(g), dim3(256), 0, st, (uint64_t)P.seed, (uint64_t)P.stream_id, n, P.directed, P.todo, cnt,
+                       attempt.p, P.d_ni, P.d_nj, table.p, tsize - 1);
+    k_mark_edge_hits(c, c->src.p, c->dst.p, m, P.directed, reinterpret_cast<const uint64_t *>(table.p), tsize, hit.p);
+    if (c->edges_sharded) {
+        // every rank has marked the candidates that are among ITS edges; the verdicts travel by sample index (0 / 1 in 32-bit
+        // words, two to an 8-byte word, at most `world` per word half: no carry) and are added over the ranks
+        DevBuf<i32> &flag = c->samp_flag;
+        const i64 words = (S + 1) / 2;
+        flag.ensure(2 * words);
+        HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(i32) * 2 * words, st));
+        hipLaunchKernelGGL(collect_hit_kernel, dim3(g), dim3(256), 0, st, P.todo, cnt, P.d_ni, P.d_nj, table.p, tsize - 1, hit.p, flag.p);
+        cge_allreduce_dev(c, reinterpret_cast<double *>(flag.p), words, 2);
+        hipLaunchKernelGGL(check_neg_flag_kernel, dim3(g), dim3(256), 0, st, P.todo, cnt, flag.p, attempt.p, P.next, count.p);
+    } else {
+        hipLaunchKernelGGL(check_neg_kernel, dim3(g), dim3(256), 0, st, P.todo, cnt, P.d_ni, P.d_nj, table.p, tsize - 1, hit.p,
+                           attempt.p, P.next, count.p);
+    }
+    c->samp_pin_cnt.ensure(1);
+    HIP_CHECK(hipMemcpyAsync(c->samp_pin_cnt.p, count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (!c->samp_ev) HIP_CHECK(hipEventCreateWithFlags(&c->samp_ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(c->samp_ev, st));
+}
+void k_draw_samples_begin(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i32 *d_pos, i32 *d_ni, i32 *d_nj) {
+    if (c->samp_pending.on) CGE_THROW(CGE_E_ASSERT, "draw_samples: a draw is already pending");
     hipStream_t st = c->stream;
     const unsigned nb = (unsigned)((S + 255) / 256);
     // positive draws are rows of the caller's WHOLE list (a sharded list: the owner of a row answers for it, k_prep_samples)
     hipLaunchKernelGGL(draw_pos_kernel, dim3(nb), dim3(256), 0, st, (uint64_t)seed, (uint64_t)stream_id, S,
-                       c->edges_sharded ? c->m_total : m, d_pos);
-    DevBuf<unsigned> &attempt = c->samp_attempt; // grow-only scratch of the context
-    DevBuf<i32> &todo_a = c->samp_todo_a, &todo_b = c->samp_todo_b, &hit = c->samp_hit;
-    DevBuf<unsigned long long> &table = c->samp_table, &count = c->samp_count;
-    attempt.ensure(S); todo_a.ensure(S); todo_b.ensure(S); count.ensure(1);
-    HIP_CHECK(hipMemsetAsync(attempt.p, 0, sizeof(unsigned) * S, st));
-    i64 cnt = S;
-    const i32 *todo = nullptr; // round 0: every sample
-    i32 *next = todo_a.p;
-    for (int round = 0; round < 64 && cnt > 0; round++) {
-        i64 tsize = 1024;
-        while (tsize < 4 * cnt) tsize <<= 1;
-        table.ensure(tsize);
-        hit.ensure(tsize);
-        HIP_CHECK(hipMemsetAsync(table.p, 0xFF, sizeof(unsigned long long) * tsize, st));
-        HIP_CHECK(hipMemsetAsync(hit.p, 0, sizeof(i32) * tsize, st));
-        HIP_CHECK(hipMemsetAsync(count.p, 0, sizeof(unsigned long long), st));
-        const unsigned g = (unsigned)((cnt + 255) / 256);
-        hipLaunchKernelGGL(draw_neg_kernel, dim3(g), dim3(256), 0, st, (uint64_t)seed, (uint64_t)stream_id, n, directed, todo, cnt,
-                           attempt.p, d_ni, d_nj, table.p, tsize - 1);
-        k_mark_edge_hits(c, c->src.p, c->dst.p, m, directed, reinterpret_cast<const uint64_t *>(table.p), tsize, hit.p);
-        if (c->edges_sharded) {
-            // every rank has marked the candidates that are among ITS edges; the verdicts travel by sample index (0 / 1 in 32-bit
-            // words, two to an 8-byte word, at most `world` per word half: no carry) and are added over the ranks
-            DevBuf<i32> &flag = c->samp_flag;
-            const i64 words = (S + 1) / 2;
-            flag.ensure(2 * words);
-            HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(i32) * 2 * words, st));
-            hipLaunchKernelGGL(collect_hit_kernel, dim3(g), dim3(256), 0, st, todo, cnt, d_ni, d_nj, table.p, tsize - 1, hit.p, flag.p);
-            cge_allreduce_dev(c, reinterpret_cast<double *>(flag.p), words, 2);
-            hipLaunchKernelGGL(check_neg_flag_kernel, dim3(g), dim3(256), 0, st, todo, cnt, flag.p, attempt.p, next, count.p);
-        } else {
-            hipLaunchKernelGGL(check_neg_kernel, dim3(g), dim3(256), 0, st, todo, cnt, d_ni, d_nj, table.p, tsize - 1, hit.p,
-                               attempt.p, next, count.p);
-        }
-        unsigned long long hc = 0;
-        HIP_CHECK(hipMemcpyAsync(&hc, count.p, sizeof(hc), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        cnt = (i64)hc;
-        todo = next;
-        next = (next == todo_a.p) ? todo_b.p : todo_a.p;
+                       c->edges_sharded ? c->m_total : c->m, d_pos);
+    c->samp_attempt.ensure(S); c->samp_todo_a.ensure(S); c->samp_todo_b.ensure(S); c->samp_count.ensure(1);
+    HIP_CHECK(hipMemsetAsync(c->samp_attempt.p, 0, sizeof(unsigned) * S, st));
+    cge_ctx::DrawPending &P = c->samp_pending;
+    P = cge_ctx::DrawPending();
+    P.on = true;
+    P.seed = seed; P.stream_id = stream_id; P.S = S; P.directed = directed;
+    P.d_pos = d_pos; P.d_ni = d_ni; P.d_nj = d_nj;
+    P.cnt = S;
+    P.todo = nullptr; // round 0: every sample
+    P.next = c->samp_todo_a.p;
+    P.round = 0;
+    draw_round(c, P);
+}
+void k_draw_samples_finish(cge_ctx *c) {
+    cge_ctx::DrawPending &P = c->samp_pending;
+    if (!P.on) CGE_THROW(CGE_E_ASSERT, "draw_samples: no draw is pending");
+    for (;;) {
+        HIP_CHECK(hipEventSynchronize(c->samp_ev));
+        P.cnt = (i64)c->samp_pin_cnt.p[0];
+        P.todo = P.next;
+        P.next = (P.next == c->samp_todo_a.p) ? c->samp_todo_b.p : c->samp_todo_a.p;
+        P.round++;
+        if (P.cnt <= 0 || P.round >= 64) break;
+        draw_round(c, P);
     }
-    if (cnt > 0) CGE_THROW(CGE_E_ARG, "draw_samples: could not find enough non-edges (graph too dense?)");
+    P.on = false;
+    if (P.cnt > 0) CGE_THROW(CGE_E_ARG, "draw_samples: could not find enough non-edges (graph too dense?)");
+}
+void k_draw_samples_dev(cge_ctx *c, i64 seed, i64 stream_id, i64 S, int directed, i32 *d_pos, i32 *d_ni, i32 *d_nj) {
+    k_draw_samples_begin(c, seed, stream_id, S, directed, d_pos, d_ni, d_nj);
+    k_draw_samples_finish(c);
 }
 // sampled pairs -> what the AUC kernels read: the edge of every positive draw (canonical order when undirected) with the
 // weight of the FIRST draw (the directed exact-mode quirk of :510 overwrites the pairs, not the weights), the non-edges

@@ -379,49 +379,6 @@ void batch_tables(Batch &B, const std::vector<i64> &lens) {
     B.task_chunk_off[T] = (i32)B.chunk_task.size();
     B.NC = (i64)B.chunk_task.size();
 }
-// Several small host arrays -> their device arrays with ONE copy: the words are packed into a pinned staging buffer
-// (two of them alternate, each guarded by an event), copied to a device staging area and scattered by one kernel.
-// Every copy of its own from pageable memory costs ~20 us of idle stream; a batch has seven of them.
-struct WordPacker {
-    cge_ctx *c;
-    std::vector<void *> dst;
-    std::vector<const void *> src;
-    std::vector<i64> words;
-    explicit WordPacker(cge_ctx *c_) : c(c_) {}
-    template <class T>
-    void add(T *device, const T *host, i64 count) {
-        static_assert(sizeof(T) % 4 == 0, "4-byte words");
-        if (count <= 0) return;
-        dst.push_back(device);
-        src.push_back(host);
-        words.push_back(count * (i64)(sizeof(T) / 4));
-    }
-    void flush() {
-        if (dst.empty()) return;
-        i64 tot = 0;
-        for (i64 w : words) tot += w + (w & 1); // keep 8-byte items aligned
-        const int slot = c->tab_slot;
-        c->tab_slot ^= 1;
-        HIP_CHECK(hipEventSynchronize(c->tab_ev[slot])); // the copy that last read this staging buffer is done
-        c->pin_tab[slot].ensure((size_t)tot);
-        c->dev_tab.ensure((size_t)tot);
-        i32 *h = c->pin_tab[slot].p;
-        std::vector<const void *> dsrc(dst.size());
-        i64 pos = 0;
-        for (size_t q = 0; q < dst.size(); q++) {
-            std::memcpy(h + pos, src[q], (size_t)words[q] * 4);
-            dsrc[q] = c->dev_tab.p + pos;
-            pos += words[q] + (words[q] & 1);
-        }
-        HIP_CHECK(hipMemcpyAsync(c->dev_tab.p, h, sizeof(i32) * (size_t)tot, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipEventRecord(c->tab_ev[slot], c->stream));
-        for (size_t q0 = 0; q0 < dst.size(); q0 += CGE_WORD_SEGS) {
-            const int n = (int)std::min<size_t>(CGE_WORD_SEGS, dst.size() - q0);
-            k_copy_words(c, n, &dst[q0], &dsrc[q0], &words[q0]);
-        }
-        dst.clear(); src.clear(); words.clear();
-    }
-};
 // The other direction: device arrays -> one device staging area (one kernel) -> pinned memory (one copy).  fetch()
 // waits for its copy (fetch_async() + wait() split the two halves); the pointers returned by get() are valid until the next
 // gatherer of the same context is used.

@@ -124,8 +124,11 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
 
     // community -> members CSR of the score graph
     std::vector<i32> hcomm(N);
-    HIP_CHECK(hipMemcpyAsync(hcomm.data(), G.comm, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    if (orig && orig->h_lcomm) std::memcpy(hcomm.data(), orig->h_lcomm, sizeof(i32) * N); // (the caller read them back for the diameter)
+    else {
+        HIP_CHECK(hipMemcpyAsync(hcomm.data(), G.comm, sizeof(i32) * N, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
     std::vector<i32> cm_off(C + 1, 0), cm_mem(N);
     for (i64 i = 0; i < N; i++) {
         if (hcomm[i] < 0 || hcomm[i] >= C) CGE_THROW(CGE_E_ARG, "community id out of range");
@@ -164,6 +167,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                           c->opt_pow_exp2 && k_fit_flow_fused_applies(c, N);
     const bool blocks = blocks_req || tiles_req;
     bool blocks_ok = blocks, pieces_ok = true;
+    // the sweep's small tables travel together: one pinned staging buffer, one copy and one scatter kernel per flush instead of a
+    // copy from pageable memory (~20 us of idle stream) per table and a synchronisation wherever a table is a local
+    WordPacker pk(c);
     std::vector<i32> bt_fc, bt_ns, bt_base;
     i64 bt_total = 0; // tile partials in all
     if (blocks) { // per 64-vertex block of the relabelled graph: first community and number of communities; per tile: its partials
@@ -195,10 +201,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         bt_total = tot;
         if (blocks_ok) {
             c->sw_bt_fc.ensure(Nt); c->sw_bt_ns.ensure(Nt); c->sw_bt_base.ensure(Nt * Nt + 1); c->sw_bt_part.ensure(std::max<i64>(tot, 1) + 1); // (+ the +0.0 slot of k_bins_prepare)
-            HIP_CHECK(hipMemcpyAsync(c->sw_bt_fc.p, bt_fc.data(), sizeof(i32) * Nt, hipMemcpyHostToDevice, st));
-            HIP_CHECK(hipMemcpyAsync(c->sw_bt_ns.p, bt_ns.data(), sizeof(i32) * Nt, hipMemcpyHostToDevice, st));
-            HIP_CHECK(hipMemcpyAsync(c->sw_bt_base.p, bt_base.data(), sizeof(i32) * Nt * Nt, hipMemcpyHostToDevice, st));
-            HIP_CHECK(hipStreamSynchronize(st)); // (the tables are locals)
+            pk.add(c->sw_bt_fc.p, bt_fc.data(), Nt);
+            pk.add(c->sw_bt_ns.p, bt_ns.data(), Nt);
+            pk.add(c->sw_bt_base.p, bt_base.data(), Nt * Nt);
         }
     }
     bool fuse = fuse_req && blocks_ok && pieces_ok;
@@ -212,8 +217,9 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         d_old2new.ensure(N);
         std::vector<i32> old2new(N);
         for (i64 q = 0; q < N; q++) old2new[cm_mem[q]] = (i32)q;
-        HIP_CHECK(hipMemcpyAsync(d_order.p, cm_mem.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d_old2new.p, old2new.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+        pk.add(d_order.p, cm_mem.data(), N);
+        pk.add(d_old2new.p, old2new.data(), N);
+        pk.flush(); // (with the tile tables above)
         c->sw_rl_emb.ensure((size_t)N * d);
         c->sw_rl_vec.ensure((size_t)4 * N);
         c->sw_rl_comm.ensure(N);
@@ -226,8 +232,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         if (G.deg_out) { k_permute_rows(c, G.deg_out, d_order.p, N, 1, v + 3 * N); G.deg_out = v + 3 * N; }
         k_permute_i32(c, G.comm, d_order.p, N, c->sw_rl_comm.p);
         G.comm = c->sw_rl_comm.p;
-        HIP_CHECK(hipStreamSynchronize(st)); // old2new goes out of scope
-        for (i64 q = 0; q < N; q++) cm_mem[q] = (i32)q; // the member lists in the new numbering
+        for (i64 q = 0; q < N; q++) cm_mem[q] = (i32)q; // the member lists in the new numbering (the old ones sit in the staging buffer)
     }
 
     // D and its normalisation (:79-93 / :359-375)
@@ -237,12 +242,19 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
     DevBuf<i32> &d_cm_off = c->sw_cm_off, &d_cm_mem = c->sw_cm_mem;
     d_cm_off.ensure(C + 1);
     d_cm_mem.ensure(N);
-    HIP_CHECK(hipMemcpyAsync(d_cm_off.p, cm_off.data(), sizeof(i32) * (C + 1), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(d_cm_mem.p, cm_mem.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+    pk.add(d_cm_off.p, cm_off.data(), C + 1);
+    pk.add(d_cm_mem.p, cm_mem.data(), N);
     std::vector<i32> cm_pos(N); // position of every vertex in the community-sorted list
     for (i64 q = 0; q < N; q++) cm_pos[cm_mem[q]] = (i32)q;
     c->sw_cm_pos.ensure(N);
-    HIP_CHECK(hipMemcpyAsync(c->sw_cm_pos.p, cm_pos.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+    pk.add(c->sw_cm_pos.p, cm_pos.data(), N);
+    if (!directed) { // (the directed sweep reads the degrees back first, below)
+        std::vector<double> ones(N, 1.0); // T (:118)
+        pk.add(T1.p, ones.data(), N);
+        pk.add(T2.p, ones.data(), N);
+        pk.flush();
+    } else
+        pk.flush();
     if (c->bvec_blocks && !directed) k_bins_prepare(c, d_cm_off.p, N, C, bt_total); // where every bin's tile partials sit
 
     // T (:118) / Tin,Tout (:399-402)
@@ -257,9 +269,11 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             if (dout[i] == 0) hT2[i] = 0.0; // Tout
         }
     }
-    HIP_CHECK(hipMemcpyAsync(T1.p, hT1.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(T2.p, hT2.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    if (directed) {
+        pk.add(T1.p, hT1.data(), N);
+        pk.add(T2.p, hT2.data(), N);
+        pk.flush();
+    }
     const double *Tin = T1.p, *Tout = T2.p; // directed
     // undirected: T rotates through the three parts of TT (Tld doubles each, zero beyond N); Tcur = the current iterate.
     // Three, so that T_0 of an alpha survives the fit of the next alpha, which may be enqueued before this one is checked.
@@ -387,8 +401,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
             e.auc_part = scal.p + RES_AUC_EARLY;
         }
         c->sw_fused_epi.ensure(h_epi.size() * sizeof(cge_fit_fused));
-        HIP_CHECK(hipMemcpyAsync(c->sw_fused_epi.p, h_epi.data(), h_epi.size() * sizeof(cge_fit_fused), hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        static_assert(sizeof(cge_fit_fused) % 8 == 0, "packed as 4-byte words");
+        pk.add(reinterpret_cast<i32 *>(c->sw_fused_epi.p), reinterpret_cast<const i32 *>(h_epi.data()),
+               (i64)(h_epi.size() * sizeof(cge_fit_fused) / 4));
+        pk.flush();
     }
     c->stat_fit_fused = 0;
 
