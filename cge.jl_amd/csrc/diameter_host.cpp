@@ -67,7 +67,9 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
     {
         std::vector<i32> soff32(soff.begin(), soff.end());
         c->dm_soff.ensure(N + 1);
-        HIP_CHECK(hipMemcpyAsync(c->dm_soff.p, soff32.data(), sizeof(i32) * (N + 1), hipMemcpyHostToDevice, st));
+        WordPacker pk(c); // (small tables: one pinned staging buffer, no copy from pageable memory, no synchronisation for the local)
+        pk.add(c->dm_soff.p, soff32.data(), N + 1);
+        pk.flush();
         if (!(c->lm_index_on_device && mem_off.data() == c->h_mem_off.data())) {
             // index not produced by the landmark phase of this context (exact-mode callers): upload it
             if ((i64)mem.size() != n) return false; // no member lists on the host: the caller takes the brute-force path
@@ -79,7 +81,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
             d_mem = c->dm_mem.p;
         }
         k_diameter_layout(c, d_off, d_mem, c->dm_soff.p, N, c->pos2node.p, c->sub_land.p, lds_rows / 16);
-        HIP_CHECK(hipStreamSynchronize(st)); // soff32 goes out of scope
+        if (d_off == c->dm_memoff.p) HIP_CHECK(hipStreamSynchronize(st)); // (the caller's index was copied from pageable memory)
     }
     lap("dm_layout");
     // ---- reference points ---------------------------------------------------------------------------------
@@ -101,15 +103,21 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
         c->mp_refoff.ensure(C + 1);
         c->mp_refmem.ensure(N);
         c->mp_refmu.ensure((size_t)C * d);
-        HIP_CHECK(hipMemcpyAsync(c->mp_refoff.p, roff.data(), sizeof(i32) * (C + 1), hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(c->mp_refmem.p, rmem.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+        c->mp_lref.ensure(N);
+        WordPacker pk(c);
+        pk.add(c->mp_refoff.p, roff.data(), C + 1);
+        pk.add(c->mp_refmem.p, rmem.data(), N);
+        pk.add(c->mp_lref.p, lref.data(), N);
+        pk.flush();
         k_ref_centroids(c, mu, lw, c->mp_refoff.p, c->mp_refmem.p, C, d, c->mp_refmu.p);
-        HIP_CHECK(hipStreamSynchronize(st)); // roff / rmem go out of scope
         mu_ref = c->mp_refmu.p;
-    } else
+    } else {
         for (i64 a = 0; a < N; a++) lref[a] = (i32)a;
-    c->mp_lref.ensure(N);
-    HIP_CHECK(hipMemcpyAsync(c->mp_lref.p, lref.data(), sizeof(i32) * N, hipMemcpyHostToDevice, st));
+        c->mp_lref.ensure(N);
+        WordPacker pk(c);
+        pk.add(c->mp_lref.p, lref.data(), N);
+        pk.flush();
+    }
     const i64 ldm = (nref + 127) / 128 * 128;
     c->rns.ensure(lds_rows);
     c->Ms.ensure((size_t)ldm * dpad);
@@ -324,7 +332,11 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
         const i64 ldE = (E + 127) / 128 * 128 + 128;
         c->dm_soffE.ensure(N + 1); c->xe_pos.ensure(E); c->xe_glob.ensure(E + 2); c->xe_sub.ensure(ldE / 16);
         c->xe.ensure((size_t)ldE * dpad); c->xe_rns.ensure(ldE);
-        HIP_CHECK(hipMemcpyAsync(c->dm_soffE.p, eoff.data(), sizeof(i32) * (N + 1), hipMemcpyHostToDevice, st));
+        {
+            WordPacker pk(c);
+            pk.add(c->dm_soffE.p, eoff.data(), N + 1);
+            pk.flush();
+        }
         k_diameter_layout(c, d_off, d_mem, c->dm_soffE.p, N, c->xe_pos.p, c->xe_sub.p, ldE / 16);
         k_gather_centre_fm(c, c->Xr.p, c->xe_pos.p, c->gmean.p, c->xe.p, c->xe_rns.p, E, d, ldE, dpad);
         k_position_ids(c, c->xe_pos.p, RS ? c->loc2glob.p : nullptr, E, c->xe_glob.p);
@@ -347,7 +359,11 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
         if (!tiles.empty()) {
             c->stat_cand_tiles += (i64)tiles.size();
             c->tile_list.ensure(2 * tiles.size());
-            HIP_CHECK(hipMemcpyAsync(c->tile_list.p, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, st));
+            {
+                WordPacker pk(c);
+                pk.add(reinterpret_cast<i32 *>(c->tile_list.p), reinterpret_cast<const i32 *>(tiles.data()), (i64)(2 * tiles.size()));
+                pk.flush();
+            }
             double v;
             i64 pi, pj;
             k_pair_list(c, c->xe.p, c->xe_rns.p, ldE, E, dpad, c->tile_list.p, (i64)tiles.size(), &v, &pi, &pj);
@@ -360,8 +376,7 @@ bool host_diameter_pruned(cge_ctx *c, const double *mu, const double *lw, const 
                 best_gi = (i64)g2[0] - 1;
                 best_gj = (i64)g2[1] - 1;
             }
-        } else
-            HIP_CHECK(hipStreamSynchronize(st)); // eoff / tiles staging of this round
+        }
         if (RS) best = cge_allreduce_scalar_max(c, best); // the rounds are taken in lock-step with one threshold
         tile_cap = 131072;
     }

@@ -111,32 +111,37 @@ i64 means_alloc(cge_ctx *x, i64 cnt) {
 
 // 1-based binary min-heap on value with the reference's exact sift rules (src/landmarks.jl:12-46)
 struct Heap {
-    std::vector<Group *> a{nullptr};
+    struct Ent { // the key sits beside the pointer: sifting compares neighbours of one array instead of chasing a pointer per level
+        double value;
+        Group *g;
+    };
+    std::vector<Ent> a{Ent{0.0, nullptr}};
     size_t len() const { return a.size() - 1; }
+    Group *at(size_t i) const { return a[i].g; } // 1-based position = landmark id
     void put(Group *g) {
-        a.push_back(g);
+        const Ent e{g->value, g};
+        a.push_back(e);
         size_t i = a.size() - 1, j;
-        const double value = g->value;
         while ((j = i / 2) >= 1) {
-            if (value < a[j]->value) {
+            if (e.value < a[j].value) {
                 a[i] = a[j];
                 i = j;
             } else
                 break;
         }
-        a[i] = g;
+        a[i] = e;
     }
     Group *pop() {
-        Group *x = a[1];
-        Group *y = a.back();
+        Group *x = a[1].g;
+        const Ent y = a.back();
         a.pop_back();
         const size_t n = a.size() - 1;
         if (n > 0) {
             size_t i = 1, l;
             while ((l = 2 * i) <= n) {
                 const size_t r = l + 1;
-                const size_t j = (r > n || a[l]->value < a[r]->value) ? l : r;
-                if (a[j]->value < y->value) {
+                const size_t j = (r > n || a[l].value < a[r].value) ? l : r;
+                if (a[j].value < y.value) {
                     a[i] = a[j];
                     i = j;
                 } else
@@ -146,7 +151,7 @@ struct Heap {
         }
         return x;
     }
-    Group *top() const { return a[1]; }
+    Group *top() const { return a[1].g; }
 };
 
 // all host-parallel loops go through the ctx's persistent pool
@@ -1254,6 +1259,8 @@ void replay_one(Heap &h) {
 // many small per-community heaps of the forced phase, which need s-1 rounds anyway).
 void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64> &targets, int method,
                    GroupPool &pool, bool speculate) {
+    std::vector<Group *> frontier, stack, keep; // (reused by every round: no allocation per round)
+    std::vector<double> vals;
     for (;;) {
         PhaseAcc *ph = new PhaseAcc(c, "lm_heap"); // replay + choice of the next batch (host)
         std::vector<Group *> batch;
@@ -1266,14 +1273,12 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
                 continue;
             }
             const i64 remaining = targets[q] - (i64)h.len();
-            std::vector<Group *> frontier;
+            frontier.clear(); stack.clear(); vals.clear();
             // Exactly `remaining` more pops will happen.  A node can only be among them if its value ranks within
             // `remaining` among ALL known unpopped nodes (cached splits and unsplit ones alike): nodes still to be
             // discovered only add competitors.  So every unsplit node above that threshold is a candidate and
             // every one below it is certainly never popped.
-            std::vector<Group *> stack;
-            std::vector<double> vals;
-            for (size_t i = 1; i <= h.len(); i++) stack.push_back(h.a[i]);
+            for (size_t i = 1; i <= h.len(); i++) stack.push_back(h.at(i));
             while (!stack.empty()) {
                 Group *g = stack.back();
                 stack.pop_back();
@@ -1292,7 +1297,7 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
                 thr = vals[remaining - 1];
             }
             {
-                std::vector<Group *> keep;
+                keep.clear();
                 for (Group *g : frontier)
                     if (g->value <= thr || g == h.top()) keep.push_back(g);
                 frontier.swap(keep);
@@ -1312,7 +1317,7 @@ void advance_heaps(cge_ctx *c, std::vector<Heap *> &heaps, const std::vector<i64
                 std::nth_element(frontier.begin(), frontier.begin() + (take - 1), frontier.end(),
                                  [](const Group *a, const Group *b) { return a->value < b->value; });
                 const double cut = frontier[take - 1]->value;
-                std::vector<Group *> keep;
+                keep.clear();
                 for (Group *g : frontier)
                     if (g->value <= cut || g == h.top()) keep.push_back(g);
                 frontier.swap(keep);
@@ -1505,7 +1510,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                         g->value = w[b * per + 2 + 2 * s_];
                         g->owner = owner[b];
                     }
-                    L.a.push_back(g); // kept in pop order: the merge below reads the array front to back
+                    L.a.push_back(Heap::Ent{g->value, g}); // kept in pop order: the merge below reads the array front to back
                 }
             }
             sharded_forced = true;
@@ -1618,7 +1623,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
                     g->value = rec[1];
                     g->mean_off = rec[2] != 0.0 ? mbase + (b * forced + s_) * d : -1;
                     at += g->len;
-                    L.a.push_back(g); // kept in pop order: the merge below reads the array front to back
+                    L.a.push_back(Heap::Ent{g->value, g}); // kept in pop order: the merge below reads the array front to back
                 }
                 if (at != cl_off[cidx + 1]) CGE_THROW(CGE_E_ASSERT, "forced phase: gathered groups do not cover their community");
             }
@@ -1643,7 +1648,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
         } else {
             Heap &L = locals[li++].h;
             if (sharded_forced) { // already in pop order
-                for (size_t q2 = 1; q2 < L.a.size(); q2++) H.put(L.a[q2]);
+                for (size_t q2 = 1; q2 < L.a.size(); q2++) H.put(L.a[q2].g);
             } else
                 while (L.len() > 0) H.put(L.pop()); // :309-312
         }
@@ -1665,7 +1670,7 @@ void host_runsplit(cge_ctx *c, const i64 *cl_flat, const i64 *cl_off, i64 ncl, i
     c->h_gl_off.assign(NG + 1, 0);
     c->lm_owner.assign(NG, 0);
     for (i64 g = 0; g < NG; g++) {
-        const Group *G = H.a[g + 1];
+        const Group *G = H.at(g + 1);
         const bool mine = !RS || G->owner == me;
         goff[g] = mine ? (i32)G->off : 0; // (option shard_rows: another rank's group is an empty range here)
         glen[g] = mine ? (i32)G->len : 0;
