@@ -701,6 +701,33 @@ def test_wgcl_asserts_mirror_reference(ctx, test115):
                      False, ctx=ctx)
 
 
+def test_score_that_fails_between_the_halves_of_its_sample_draw(ctx, synth20k):
+    """cge_score enqueues the local score's sample draws behind the first synchronisation of the landmark phase and looks at
+    them where the sweep starts.  A score that raises in between (a homogeneous community: src/landmarks.jl:165-167) leaves a
+    draw pending; the next score on the context drains it and gives what a fresh context gives."""
+    from cge.jl_amd import api
+
+    g = synth20k
+    n, d = g["n"], g["embedding"].shape[1]
+    ctx.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+    good = ctx.score(g["clusters"], 120, 4, "rss", seed=1, auc_samples=5000)
+    # integer coordinates, all rows equal: every community is homogeneous, whatever the summation order
+    ctx.set_vertex_data(g["comm"], np.full(n, 2.0))
+    ctx.set_embedding(np.tile(np.arange(1.0, d + 1.0), (n, 1)))
+    with pytest.raises(api.CGEError, match="homogenous"):
+        ctx.score(g["clusters"], 120, 4, "rss", seed=1, auc_samples=5000)
+    ctx.set_vertex_data(g["comm"], g["vweights"])
+    ctx.set_embedding(g["embedding"])
+    again = ctx.score(g["clusters"], 120, 4, "rss", seed=1, auc_samples=5000)
+    assert np.array_equal(good, again)
+    fresh = api.Context()
+    try:
+        fresh.set_inputs(g["edges"], g["eweights"], g["vweights"], g["comm"], g["embedding"])
+        assert np.array_equal(good, fresh.score(g["clusters"], 120, 4, "rss", seed=1, auc_samples=5000))
+    finally:
+        fresh.close()
+
+
 @pytest.mark.parametrize("directed", [False, True])
 def test_edge_scatter_kernel(ctx, synth20k, directed):
     g = synth20k
