@@ -575,7 +575,7 @@ def main():
     # HBM traffic per launch from the committed PMC passes of this same command (profiles/run_profiles.sh)
     pmc = {}
     pmc_file = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(f)), "")
-    kernel_of = {"fit_symv": ("fit_step_kernel",), "fit_persistent": ("fit_flow_kernel",), "pcent": ("pcent_f32_rowres_kernel", "pcent_f32_kernel", "pcent_groups_kernel"),
+    kernel_of = {"fit_symv": ("fit_symtile_kernel", "fit_symreduce_kernel"), "fit_persistent": ("fit_flow_kernel",), "pcent": ("pcent_f32_rowres_kernel", "pcent_f32_kernel", "pcent_groups_kernel"),
                  "pcent_bf16": ("pcent_bf16_kernel", "pcent_groups_kernel"),
                  "pair_list": ("pair_list_kernel",), "edge_scatter": ("edge_pass_kernel", "edge_row_reduce_kernel"),
                  "edge_scatter_wedges": ("wedge_pass_kernel", "wedge_tile_kernel"),
