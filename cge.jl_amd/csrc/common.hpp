@@ -610,8 +610,8 @@ void k_gather_rows(cge_ctx *c, const i32 *arena, const i32 *task_off, const i32 
 void k_rss_child_keys(cge_ctx *c, const i32 *perm, const i32 *row_task, const i32 *task_row_off, const i32 *meta,
                       const i32 *rounds, i64 R, i64 T, unsigned char *keys, i32 *nlow);
 void k_side_counts(cge_ctx *c, const unsigned char *side, const i32 *task_row_off, i64 T, i32 *nlow);
-void k_sort_children(cge_ctx *c, const unsigned char *keys, const i32 *rows, const i32 *task_row_off, i64 R, i64 T,
-                     int key_bits, i32 *out);
+void k_sort_children(cge_ctx *c, const unsigned char *keys, const i32 *rows, const i32 *task_row_off, const i32 *chunk_beg,
+                     const i32 *chunk_end, const i32 *task_chunk_off, i64 n_chunks, i64 R, i64 T, int key_bits, i32 *out);
 i64 k_groups_to_index(cge_ctx *c, const i32 *arena, const i32 *goff, const i32 *glen, i64 N, i64 n, i32 *v2l, i32 *mem);
 void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 *row_task, const i32 *task_row_off,
                         i64 R, i64 T, double *zs, i32 *perm, i32 *srows, i32 *status, i64 max_len = 0 /* longest group, 0: unknown */);

@@ -705,7 +705,7 @@ void rule_rss_sorted_enqueue(LaneRun &L) {
     L.i_status = L.wg->add(c->sp_status.p, T); L.i_meta = L.wg->add(c->sp_meta.p, 2 * T);
     L.i_vals = L.wg->add(c->sp_vals.p, 2 * T); L.i_nlow = L.wg->add(c->ls_nlow.p, T);
     L.wg->fetch_async();
-    k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, R, T, 7, c->lm_arena.p + L.base);
+    k_sort_children(c, c->ls_keys.p, c->ls_rows.p, c->sp_tro.p, c->ls_cb.p, c->ls_ce.p, c->ls_tco.p, B.NC, R, T, 7, c->lm_arena.p + L.base);
 }
 void rule_rss_sorted_collect(LaneRun &L) {
     const i64 T = L.B.T, d = L.x->d;
@@ -791,7 +791,7 @@ void rule_cut_enqueue(LaneRun &L, bool use_median) {
     HIP_CHECK(hipMemcpyAsync(c->pin_sums.p, c->sp_vals.p, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(c->copy_done, st));
     // the children's member lists last: the host already has what its heap needs and builds the next batch meanwhile
-    k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, R, T, 2, c->lm_arena.p + L.base);
+    k_sort_children(c, c->ls_side.p, c->ls_rows.p, c->sp_tro.p, c->ls_cb.p, c->ls_ce.p, c->ls_tco.p, L.B.NC, R, T, 2, c->lm_arena.p + L.base);
 }
 void rule_cut_collect(LaneRun &L) {
     cge_ctx *c = L.x;
