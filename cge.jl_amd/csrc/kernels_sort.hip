@@ -162,11 +162,11 @@ void k_segmented_sort_z(cge_ctx *c, const double *z, const i32 *rows, const i32 
     ScopedKernelTimer tm(c, "segmented_sort");
     c->sort_idx.ensure(R);
     const unsigned nb = (unsigned)((R + 255) / 256);
-    // CGE_SEGSORT: 0 = rocPRIM only, 1 (default) = the LDS network for batches of few long groups, 2 = for every batch whose
-    // groups fit it
-    const int segsort = 1;
+    // the LDS network for every batch whose longest group fits its pieces (round 5: also for batches of many short groups, where
+    // rocPRIM's segmented radix sort used to run: 0.57 -> 0.41 ms per step at config 2, same order); beyond that, two device-wide
+    // stable sorts (few long groups) or rocPRIM's segmented sort
     const bool long_groups = R / std::max<i64>(T, 1) >= 768;
-    if (max_len > 0 && max_len <= (i64)SEGSORT_CAP * SEGSORT_MAXPIECES && ((segsort == 1 && long_groups) || segsort == 2)) {
+    if (max_len > 0 && max_len <= (i64)SEGSORT_CAP * SEGSORT_MAXPIECES) {
         int cap = 64;
         while (cap < std::min<i64>(max_len, SEGSORT_CAP)) cap <<= 1;
         const unsigned npieces = (unsigned)((max_len + SEGSORT_CAP - 1) / SEGSORT_CAP);

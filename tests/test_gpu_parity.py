@@ -93,6 +93,31 @@ def test_landmarks_parity_synthetic(ctx, orc, synth20k, method):
     _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
 
 
+@pytest.mark.parametrize("shape", ["two_giants", "giant_and_dwarfs"])
+def test_landmarks_groups_beyond_the_lds_sort(ctx, orc, shape):
+    """The per-group sort along the principal axis runs in LDS pieces for groups of up to 32 768 rows; beyond that a batch takes two
+    device-wide stable sorts (few long groups) or the segmented radix sort (one giant among many short groups).  Both shapes
+    against the oracle."""
+    import cge.jl_amd as cg
+
+    rng = np.random.default_rng(17)
+    sizes = [36000, 35000] if shape == "two_giants" else [40000] + [100] * 100
+    n, d = int(sum(sizes)), 8
+    comm1 = np.repeat(np.arange(1, len(sizes) + 1), sizes)
+    centres = rng.normal(size=(len(sizes), d)) * 3.0
+    emb = centres[comm1 - 1] + rng.normal(size=(n, d))
+    m = 6 * n
+    edges = np.stack([rng.integers(1, n + 1, size=m), rng.integers(1, n + 1, size=m)], axis=1).astype(np.int64)
+    edges = edges[edges[:, 0] != edges[:, 1]]
+    ew = np.ones(len(edges))
+    vw = np.bincount(np.concatenate([edges[:, 0], edges[:, 1]]) - 1, minlength=n).astype(np.float64)
+    vw[vw == 0] = 1.0
+    comm = comm1.reshape(-1, 1).astype(np.int64)
+    clusters = [np.flatnonzero(comm1 == c) + 1 for c in range(1, len(sizes) + 1)]
+    args = (edges, ew, vw, clusters, comm, emb, False, 3 * len(sizes) + 40, 2, "rss", False)
+    _check_landmarks(cg.landmarks(*args, ctx=ctx), orc.landmarks(*args))
+
+
 def test_landmarks_weighted_directed_and_truncation(ctx, orc, test115):
     import cge.jl_amd as cg
 
