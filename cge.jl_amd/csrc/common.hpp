@@ -371,6 +371,7 @@ struct cge_ctx {
     int opt_pow_exp2 = 1; // (1 - D)^alpha as exp2(alpha * log2(1 - D)) with the logarithm computed once per score
     i64 pow_logs_N = 0;   // log2(1 - D) of the current sweep is in sw_Lh / sw_Ll (0: not prepared)
     bool pow_logs_upper = false;
+    i64 pow_logs_blocked_N = 0; // ... or, for the fused persistent fit only, tile-blocked (kernels_fit.hip: log_matrix_tiles_kernel)
     DevBuf<double> sw_Lh;
     DevBuf<float> sw_Ll;
     bool opt_exact_relabel = true; // exact mode, N > 8192: relabel the score graph by community (wgcl_host.cpp)
@@ -749,7 +750,7 @@ struct WordPacker { // (landmarks_host.cpp: the tables of a batch; wgcl_host.cpp
 };
 void k_gather_means_slots(cge_ctx *c, const double *arena, const i64 *off, const i64 *slot, i64 T, i64 d, i64 stride, i64 lead,
                           double *dst);
-void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only);
+void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only, bool blocked = false);
 void k_pow_matrix(cge_ctx *c, const double *D, i64 N, double alpha, double *GD, bool upper_only = false);
 void k_pow_test(cge_ctx *c, const double *x, i64 n, double alpha, int method, double *out);
 // What rides on the launch of the undirected persistent fit in a landmark-mode sweep relabelled by community (round 5): the

@@ -81,11 +81,42 @@ __global__ __launch_bounds__(256) void exp2_matrix_upper_kernel(const double *__
         GD[e] = exp2_parts(alpha, Lh[e], Ll[e]);
     }
 }
+// the same TILE-BLOCKED for the fused persistent fit (kernels_fitp.hip): upper tile t = (I, J), I <= J, in the order the fit deals
+// them to its waves; inside a tile the 8 x 8 block of lane 8 rq + cq (rows 8 rq.., columns 8 cq..) is contiguous, row by row:
+// element ((t * 64 + lane) * 64 + 8 a + b).  Outside the matrix: 0 (the fit masks those elements).
+__global__ __launch_bounds__(256) void log_matrix_tiles_kernel(const double *__restrict__ D, i64 N, int Nt, double *__restrict__ Lh,
+                                                               float *__restrict__ Ll) {
+    const i64 t = blockIdx.x;
+    int I = 0;
+    i64 rem = t;
+    while (rem >= Nt - I) { rem -= Nt - I; I++; }
+    const i64 J = I + rem;
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int lane = e >> 6, ab = e & 63, a = ab >> 3, b = ab & 7, rq = lane >> 3, cq = lane & 7;
+        const i64 row = 64 * (i64)I + 8 * rq + a, col = 64 * J + 8 * cq + b;
+        double lh = 0.0;
+        float ll = 0.f;
+        if (row < N && col < N) log_parts(D[row * N + col], lh, ll);
+        Lh[t * 4096 + e] = lh;
+        Ll[t * 4096 + e] = ll;
+    }
+}
 // log2(1 - D) for the sweep that follows (whole matrix, or the upper tiles only); false = not enough room, k_pow_matrix
-// then uses the library pow
-void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only) {
+// then uses the library pow.  `blocked`: the tile-blocked form for the fused fit ONLY (pow_logs_blocked_N; k_pow_matrix cannot
+// read it -- a sweep that leaves the fused path prepares the row-major form then)
+void k_pow_prepare(cge_ctx *c, const double *D, i64 N, bool upper_only, bool blocked) {
     c->pow_logs_N = 0;
+    c->pow_logs_blocked_N = 0;
     if (!c->opt_pow_exp2) return;
+    if (blocked) {
+        const i64 Nt = (N + 63) / 64, NT = Nt * (Nt + 1) / 2;
+        c->sw_Lh.ensure((size_t)NT * 4096);
+        c->sw_Ll.ensure((size_t)NT * 4096);
+        ScopedKernelTimer t(c, "pow_log2");
+        hipLaunchKernelGGL(log_matrix_tiles_kernel, dim3((unsigned)NT), dim3(256), 0, c->stream, D, N, (int)Nt, c->sw_Lh.p, c->sw_Ll.p);
+        c->pow_logs_blocked_N = N;
+        return;
+    }
     { // 12 bytes per entry of D: only when they fit comfortably (exact mode at n ~ 10^5 keeps two n x n matrices already)
         size_t free_b = 0, total_b = 0;
         const size_t need = (size_t)N * N * 12;

@@ -241,23 +241,31 @@ __global__ __launch_bounds__(64 * NW) void fit_flow_kernel(const double *__restr
             // load is unconditional (indices clamped into the matrix, the result selected afterwards): no divergent branches
             const int Ic = tI[s] < 0 ? 0 : tI[s], Jc = tJ[s] < 0 ? 0 : tJ[s];
             const unsigned Nu = (unsigned)N;
-            unsigned rowc[8], colc[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                rowc[q] = min(64u * Ic + 8u * rq + q, Nu - 1u);
-                colc[q] = min(64u * Jc + 8u * cq + q, Nu - 1u);
-            }
+            // The logarithm sits TILE-BLOCKED (k_pow_prepare, blocked form): the 64 doubles (and 64 floats) of a lane's 8 x 8 block are
+            // contiguous, a wave's tile is 32 KB (16 KB) of consecutive memory -- 16-byte loads, every line used whole.  (Rounds
+            // 4-5 read the row-major matrix: 64 eight-byte loads per lane at a stride of 64 B, 12-26 us of prologue.)
+            const size_t tb = ((size_t)(tI[s] < 0 ? 0 : (wg * NW + wave) + s * NW * G) * 64 + (size_t)lane) * 64;
+            const dbl2f *bh = reinterpret_cast<const dbl2f *>(fz.Lh + tb);
 #pragma unroll
             for (int a = 0; a < 8; a++)
 #pragma unroll
-                for (int b = 0; b < 8; b++) g[s][a][b] = fz.Lh[(i64)rowc[a] * N + colc[b]];
+                for (int b = 0; b < 4; b++) {
+                    const dbl2f v2 = bh[a * 4 + b];
+                    g[s][a][2 * b] = v2.x;
+                    g[s][a][2 * b + 1] = v2.y;
+                }
+            typedef float flt4f __attribute__((ext_vector_type(4)));
+            const flt4f *bl = reinterpret_cast<const flt4f *>(fz.Ll + tb);
 #pragma unroll
             for (int h = 0; h < 2; h++) { // the float parts by half tiles: 32 registers beside the 128 of the tile
                 float ll[4][8];
 #pragma unroll
                 for (int a = 0; a < 4; a++)
 #pragma unroll
-                    for (int b = 0; b < 8; b++) ll[a][b] = fz.Ll[(i64)rowc[4 * h + a] * N + colc[b]];
+                    for (int b = 0; b < 2; b++) {
+                        const flt4f v4 = bl[(4 * h + a) * 2 + b];
+                        ll[a][4 * b] = v4.x; ll[a][4 * b + 1] = v4.y; ll[a][4 * b + 2] = v4.z; ll[a][4 * b + 3] = v4.w;
+                    }
 #pragma unroll
                 for (int a = 0; a < 4; a++)
 #pragma unroll

@@ -448,7 +448,8 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
         // and the launch-per-iteration fits read whole rows
         const bool gd_upper = landmarks && !directed;
         double *const GDc = GD.p; // this alpha's matrix
-        const bool fused_now = fuse && use_persistent && c->pow_logs_N == N; // (a fallback in mid-sweep ends it: the matrix is needed then)
+        const bool fused_now = fuse && use_persistent && c->pow_logs_blocked_N == N; // (a fallback in mid-sweep ends it: the matrix is needed then)
+        if (fuse && !fused_now && c->pow_logs_N != N) k_pow_prepare(c, D.p, N, landmarks && !directed); // (left the fused path: the row-major logarithm)
         bool auc_done = false, bvec_partials = false, copied_out = false;
         if (!fused_now) k_pow_matrix(c, D.p, N, alpha, GDc, gd_upper);
         if (directed || !use_persistent) HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
@@ -487,7 +488,10 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
                     tpar = tnext;
                 } else { // the register-resident form does not apply to this size: one launch per iteration from here on
                     use_persistent = false;
-                    if (fused_now) k_pow_matrix(c, D.p, N, alpha, GDc, gd_upper); // (the fused launch was to supply the matrix)
+                    if (fused_now) { // (the fused launch was to supply the matrix)
+                        k_pow_prepare(c, D.p, N, landmarks && !directed);
+                        k_pow_matrix(c, D.p, N, alpha, GDc, gd_upper);
+                    }
                     HIP_CHECK(hipMemsetAsync(flags.p, 0, sizeof(int) * 4, st));
                 }
             }
@@ -617,7 +621,7 @@ void host_wgcl_sweep(cge_ctx *c, const ScoreGraph &G_in, const OrigView *orig, c
 
     // log2(1 - D) once for the whole sweep (the upper tiles only when every alpha reads only those); a fallback of the
     // persistent fit in mid-sweep makes k_pow_matrix use the library pow for the whole rows it then needs
-    k_pow_prepare(c, D.p, N, landmarks && !directed);
+    k_pow_prepare(c, D.p, N, landmarks && !directed, fuse);
     i64 next_enqueue = 1;
     for (i64 ia = 1; ia <= n_alpha_total; ia++) {
         const double alpha = AlphaStep * (double)ia;
