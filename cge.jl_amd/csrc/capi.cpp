@@ -1273,6 +1273,11 @@ int cge_score(cge_ctx *c, const cge_score_args *a, double out[7], int *out_len, 
     // for a few hundred microseconds; the verdict is looked at where the samples used to be drawn (a star graph's early return or
     // an error in between leaves the draw pending: see above)
     const bool samples_early = landmarks && samples_can_start_early(c, a->seed, false);
+    // (the hook captures this call's arguments: whatever happens, it does not outlive the call)
+    struct HookGuard {
+        cge_ctx *c;
+        ~HookGuard() { c->after_unique = nullptr; }
+    } hook_guard{c};
     c->after_unique = nullptr;
     if (samples_early)
         c->after_unique = [c, a, directed]() {
